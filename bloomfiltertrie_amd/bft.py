@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference interface for the batched path (include/bft.h, include/insertNode.h,
+include/presenceNode.h of GuillaumeHolley/BloomFilterTrie), over the C-ABI of include/bft_gpu.h.
+
+Names follow the reference: create_cdbg / insert_kmers_new_genome / insertKmers / is present / get_annotation +
+get_list_id_genomes.  Batches are numpy uint8 arrays [n, CEIL(2k/8)] in the reference's packed layout
+(bloomfiltertrie_amd.synth / src/fasta.c:3-53).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .synth import ascii_to_packed, kmer_bytes
+
+INFO_FIELDS = ["k", "kmers", "nodes", "ccs", "uc_rows", "child_nodes", "prefixes", "ccs_s4", "max_ccs_per_node",
+               "pairs", "colorsets", "genomes", "image_bytes", "root_ccs", "root_uc_rows", "pending_pairs"]
+
+
+class BFT:
+    """One Bloom Filter Trie resident in the HBM of one MI355X (replaces BFT_Root, include/Node.h:96-122)."""
+
+    def __init__(self, k, device=0, r1=0, r2=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.bft_gpu_create_seeded(k, device, r1, r2, C.byref(h)))  # create_cdbg, include/bft.h:62
+        self._h = h
+        self.k = k
+        self.nb = kmer_bytes(k)
+        self.device = device
+
+    # -- lifecycle ----------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bft_gpu_free(self._h)  # free_cdbg, include/bft.h:63
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        if kmers.ndim != 2 or kmers.shape[1] != self.nb:
+            raise ValueError(f"expected packed k-mers of shape [n, {self.nb}], got {kmers.shape}")
+        return kmers
+
+    # -- insertion ----------------------------------------------------------------------------------------------
+    def add_genome(self, name):
+        """add_genomes_BFT_Root (include/CC.h:307-338)."""
+        gid = C.c_uint32()
+        _lib.check(self._lib.bft_gpu_add_genome(self._h, name.encode(), C.byref(gid)))
+        return gid.value
+
+    def insert_kmers(self, kmers, id_genome):
+        """insertKmers(root, array_kmers, nb_kmers, id_genome, size_id_genome) (include/insertNode.h:26)."""
+        kmers = self._chk(kmers)
+        _lib.check(self._lib.bft_gpu_insert_kmers(self._h, kmers.ctypes.data, len(kmers), id_genome))
+
+    def insert_kmers_dev(self, d_ptr, n, id_genome):
+        _lib.check(self._lib.bft_gpu_insert_kmers_dev(self._h, d_ptr, n, id_genome))
+
+    def insert_kmers_new_genome(self, kmers_ascii, genome_name):
+        """insert_kmers_new_genome(nb_kmers, kmers, genome_name, bft) (include/bft.h:72)."""
+        gid = self.add_genome(genome_name)
+        packed, valid = ascii_to_packed(kmers_ascii, self.k)
+        if not valid.all():
+            raise ValueError("k-mer with a character outside ACGTU (reference get_kmer/insert path exits, src/bft.c:239)")
+        self.insert_kmers(packed, gid)
+        return gid
+
+    def build(self):
+        _lib.check(self._lib.bft_gpu_build(self._h))
+
+    # -- queries ------------------------------------------------------------------------------------------------
+    def query_presence(self, kmers):
+        """Loop of src/file_io.c:726-768 over isKmerPresent: presence bitmap (bit i%8 of byte i//8)."""
+        kmers = self._chk(kmers)
+        bits = np.zeros((len(kmers) + 7) // 8, dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_query_presence(self._h, kmers.ctypes.data, len(kmers), bits.ctypes.data))
+        return bits
+
+    def query_presence_dev(self, d_kmers_ptr, n, d_bits_ptr, stream=None):
+        """Device-resident variant: pointers into HBM (e.g. torch tensor .data_ptr()); asynchronous on `stream`."""
+        _lib.check(self._lib.bft_gpu_query_presence_dev(self._h, d_kmers_ptr, n, d_bits_ptr, stream))
+
+    def query_colors(self, kmers):
+        """get_annotation + get_list_id_genomes per k-mer: (bits, offsets[n+1], ids)."""
+        kmers = self._chk(kmers)
+        n = len(kmers)
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(1024, 4 * n)
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            need = C.c_uint64()
+            rc = self._lib.bft_gpu_query_colors(self._h, kmers.ctypes.data, n, bits.ctypes.data, offsets.ctypes.data,
+                                                ids.ctypes.data, cap, C.byref(need))
+            if rc == -6:  # BFT_GPU_E_NOSPACE
+                cap = int(need.value)
+                continue
+            _lib.check(rc)
+            return bits, offsets, ids[:int(need.value)]
+
+    def query_color_rows(self, kmers):
+        """Fixed-width colour rows (the CSV row of src/file_io.c:744-765 before formatting)."""
+        kmers = self._chk(kmers)
+        n = len(kmers)
+        g = self.info()["genomes"]
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        rows = np.zeros((n, (g + 7) // 8), dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_query_color_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
+        return bits, rows
+
+    # -- introspection ------------------------------------------------------------------------------------------
+    def info(self):
+        out = (C.c_uint64 * 16)()
+        _lib.check(self._lib.bft_gpu_info(self._h, out, 16))
+        return dict(zip(INFO_FIELDS, [int(x) for x in out]))
+
+    def kernel_time(self, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        _lib.check(self._lib.bft_gpu_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def build_time(self):
+        out = (C.c_double * 5)()
+        _lib.check(self._lib.bft_gpu_build_time(self._h, out, 5))
+        return dict(zip(["gpu_sort_dedupe_ms", "d2h_ms", "color_intern_ms", "assemble_ms", "upload_ms"], list(out)))
+
+    def extract(self):
+        n = C.c_uint64()
+        _lib.check(self._lib.bft_gpu_extract(self._h, None, None, 0, C.byref(n)))
+        kmers = np.zeros((n.value, self.nb), dtype=np.uint8)
+        cs = np.zeros(n.value, dtype=np.uint32)
+        _lib.check(self._lib.bft_gpu_extract(self._h, kmers.ctypes.data, cs.ctypes.data, n.value, C.byref(n)))
+        return kmers, cs
+
+    def colorset(self, cs):
+        n = C.c_uint32()
+        _lib.check(self._lib.bft_gpu_colorset(self._h, int(cs), None, 0, C.byref(n)))
+        ids = np.zeros(n.value, dtype=np.uint32)
+        _lib.check(self._lib.bft_gpu_colorset(self._h, int(cs), ids.ctypes.data, n.value, C.byref(n)))
+        return ids.tolist()
+
+
+def create_cdbg(k, device=0):
+    """create_cdbg(k, treshold_compression) (include/bft.h:62)."""
+    return BFT(k, device)

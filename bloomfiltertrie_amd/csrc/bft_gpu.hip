@@ -1,0 +1,903 @@
+// bft_gpu.hip -- HIP kernels (gfx950) and the C-ABI of include/bft_gpu.h.
+//
+// Kernels:
+//   k_pack_to_tform   packed 2-bit k-mers -> T-form words (the per-level rev[]/rotation work of
+//                     src/presenceNode.c:1327-1371 done once per k-mer)
+//   k_query           batched isKmerPresent (src/presenceNode.c:1823-1921): one lane per k-mer,
+//                     256 k-mers per workgroup staged through LDS with coalesced dword loads,
+//                     presence bits produced with a wavefront __ballot (64 k-mers -> one u64 store)
+//   k_color_*         batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
+//   k_flags/k_scatter de-duplication of sorted (k-mer, genome) pairs for the bulk build
+// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); the container
+// assembly (bft_index.cpp) and colour interning currently run on the host between the two GPU
+// stages -- see DESIGN.md "Insertion".
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bft_gpu.h"
+#include "bft_hash.h"
+#include "bft_image.h"
+#include "bft_index.h"
+#include "bft_walk.h"
+
+#define BFT_BLOCK 256
+#define BFT_ABSENT_ROW 0xFFFFFFFFu
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(BFT_GPU_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define CK(expr)                  \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 8;
+        HIPCK(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(bytes, o.bytes);
+    }
+};
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+
+// All threads of the block copy nbytes from g (global) to lds with dword loads where possible.
+__device__ __forceinline__ void stage_bytes(const uint8_t* __restrict__ g, uint32_t nbytes, uint8_t* lds) {
+    const uint32_t tid = threadIdx.x;
+    if ((((uintptr_t)g) & 3u) == 0) {
+        const uint32_t nd = nbytes >> 2;
+        const uint32_t* g4 = (const uint32_t*)g;
+        uint32_t* l4 = (uint32_t*)lds;
+        for (uint32_t i = tid; i < nd; i += BFT_BLOCK) l4[i] = g4[i];
+        for (uint32_t i = (nd << 2) + tid; i < nbytes; i += BFT_BLOCK) lds[i] = g[i];
+    } else {
+        for (uint32_t i = tid; i < nbytes; i += BFT_BLOCK) lds[i] = g[i];
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void x_from_lds(const uint8_t* lds, int B, uint64_t* x) {
+#pragma unroll
+    for (int w = 0; w < W; w++) x[w] = 0;
+    const uint8_t* p = lds + (size_t)threadIdx.x * B;
+    for (int b = 0; b < B; b++) x[b >> 3] |= (uint64_t)p[b] << (8 * (b & 7));
+}
+
+template <int W>
+__global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int L,
+                                                             uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
+                                                             uint32_t* __restrict__ gout, uint32_t gid) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t first = blk * BFT_BLOCK;
+        const uint32_t cnt = (uint32_t)min((uint64_t)BFT_BLOCK, n - first);
+        stage_bytes(packed + first * B, cnt * B, lds);
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            uint64_t x[W], t[W];
+            x_from_lds<W>(lds, B, x);
+            bft_tform_from_x<W>(x, L, t);
+#pragma unroll
+            for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + first + threadIdx.x] = t[w];
+            gout[off + first + threadIdx.x] = gid;
+        }
+        __syncthreads();
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(BFT_BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                     uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t first = blk * BFT_BLOCK;
+        const uint32_t cnt = (uint32_t)min((uint64_t)BFT_BLOCK, n - first);
+        stage_bytes(packed + first * B, cnt * B, lds);
+        __syncthreads();
+        int present = 0;
+        uint32_t row = BFT_ABSENT_ROW;
+        if (threadIdx.x < cnt) {
+            uint64_t x[W], t[W];
+            x_from_lds<W>(lds, B, x);
+            bft_tform_from_x<W>(x, im.L, t);
+            BftHit h = bft_walk<W>(im, t);
+            present = h.present;
+            if (present) row = (uint32_t)h.row;
+        }
+        const uint64_t mask = __ballot(present);
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint64_t q0 = first + (uint64_t)wave * 64;
+        if (lane == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        if (rows && threadIdx.x < cnt) rows[first + threadIdx.x] = row;
+        __syncthreads();
+    }
+}
+
+__global__ void k_iota(uint32_t* p, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
+template <class T>
+__global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ perm, T* __restrict__ out, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
+}
+
+// sorted (T, g) pairs -> head-of-k-mer flag and keep-pair flag
+__global__ void k_flags(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
+                        uint32_t* __restrict__ head, uint32_t* __restrict__ keep) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool same = i > 0;
+        if (same)
+            for (int w = 0; w < W; w++) same = same && (keys[(uint64_t)w * stride + i] == keys[(uint64_t)w * stride + i - 1]);
+        head[i] = same ? 0u : 1u;
+        keep[i] = (!same || g[i] != g[i - 1]) ? 1u : 0u;
+    }
+}
+
+__global__ void k_scatter(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
+                          const uint32_t* __restrict__ head, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ posK,
+                          const uint32_t* __restrict__ posP, uint64_t* __restrict__ pk, uint64_t pstride, uint32_t* __restrict__ pg,
+                          uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (keep[i]) {
+            const uint32_t p = posP[i];
+            for (int w = 0; w < W; w++) pk[(uint64_t)w * pstride + p] = keys[(uint64_t)w * stride + i];
+            pg[p] = g[i];
+        }
+        if (head[i]) {
+            const uint32_t q = posK[i];
+            for (int w = 0; w < W; w++) tk[(uint64_t)q * W + w] = keys[(uint64_t)w * stride + i];
+            seg_off[q] = posP[i];
+        }
+    }
+}
+
+__global__ void k_color_counts(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
+                               uint64_t n, uint64_t* __restrict__ counts) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rows[i];
+        uint64_t c = 0;
+        if (r != BFT_ABSENT_ROW) {
+            const uint32_t cs = tcol[r];
+            c = cs_off[cs + 1] - cs_off[cs];
+        }
+        counts[i] = c;
+    }
+}
+
+__global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
+                             const uint32_t* __restrict__ cs_ids, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* __restrict__ ids) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rows[i];
+        if (r == BFT_ABSENT_ROW) continue;
+        const uint32_t cs = tcol[r];
+        const uint32_t a = cs_off[cs], b = cs_off[cs + 1];
+        uint64_t o = offsets[i];
+        for (uint32_t q = a; q < b; q++) ids[o++] = cs_ids[q];
+    }
+}
+
+__global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
+                             const uint32_t* __restrict__ cs_ids, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t* o = out + i * rowbytes;
+        for (uint32_t b = 0; b < rowbytes; b++) o[b] = 0;
+        const uint32_t r = rows[i];
+        if (r == BFT_ABSENT_ROW) continue;
+        const uint32_t cs = tcol[r];
+        for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) {
+            const uint32_t gid = cs_ids[q];
+            o[gid >> 3] |= (uint8_t)(1u << (gid & 7));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct bft_gpu {
+    int k = 0, L = 0, W = 0, B = 0, device = 0, r1 = 0, r2 = 0;
+    hipStream_t stream = nullptr;
+    std::vector<std::string> genomes;
+    uint32_t max_gid_seen = 0;
+    bool any_insert = false;
+
+    // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
+    DevBuf log_k, log_g;
+    uint64_t log_n = 0, log_cap = 0;
+
+    // canonical store: sorted unique (T, genome) pairs, SoA
+    DevBuf pair_k, pair_g;
+    uint64_t n_pairs = 0;
+
+    // image
+    bool built = false;
+    uint64_t n_kmers = 0;
+    DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_f3, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids;
+    BftImage im;
+    std::vector<uint32_t> hashmod;
+    std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary
+    uint64_t info[16] = {0};
+    double build_ms[5] = {0, 0, 0, 0, 0};
+
+    // kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_ev;
+    double kernel_ms = 0;
+    uint64_t kernel_launches = 0;
+    bool timing = true;
+};
+
+static int grid_for(uint64_t nblk) {
+    const uint64_t cap = 256ull * 8ull;  // 256 CUs x 8 resident workgroups of 256 threads
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(nblk, cap));
+}
+
+static int set_device(bft_gpu* h) {
+    HIPCK(hipSetDevice(h->device));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI: lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* bft_gpu_last_error(void) { return g_err.c_str(); }
+extern "C" const char* bft_gpu_version(void) { return "bft-mi355x 0.1 (gfx950)"; }
+
+extern "C" int bft_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out) {
+    if (!out) return fail(BFT_GPU_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (!bft_valid_k(k)) return fail(BFT_GPU_E_ARG, "Length k (for k-mers) must be a multiple of 9 in [9,126] (reference src/main.c:61-63)");
+    int ndev = 0;
+    HIPCK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(BFT_GPU_E_HIP, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(BFT_GPU_E_ARG, "bad device index");
+    bft_gpu* h = new bft_gpu();
+    h->k = k;
+    h->L = k / 9;
+    h->W = bft_words_for_k(k);
+    h->B = bft_bytes_for_k(k);
+    h->device = device;
+    h->r1 = r1 > 0 ? r1 : BFT_DEFAULT_R1;
+    h->r2 = r2 > 0 ? r2 : BFT_DEFAULT_R2;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+        delete h;
+        return fail(BFT_GPU_E_HIP, "hipSetDevice/hipStreamCreate failed");
+    }
+    h->hashmod.resize(16384);
+    bft_make_hashmod(h->r1, h->r2, h->hashmod.data());
+    if (h->d_hashmod.alloc(16384 * 4) != 0 ||
+        hipMemcpy(h->d_hashmod.p, h->hashmod.data(), 16384 * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return fail(BFT_GPU_E_HIP, "hash table upload failed");
+    }
+    memset(&h->im, 0, sizeof(h->im));
+    *out = h;
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_create(int k, int device, bft_gpu** out) { return bft_gpu_create_seeded(k, device, 0, 0, out); }
+
+static void drain_events(bft_gpu* h) {
+    for (auto& pr : h->pending_ev) {
+        float ms = 0;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            h->kernel_ms += ms;
+            h->kernel_launches++;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    h->pending_ev.clear();
+}
+
+extern "C" void bft_gpu_free(bft_gpu* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    drain_events(h);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int bft_gpu_add_genome(bft_gpu* h, const char* name, uint32_t* id_genome) {
+    if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
+    h->genomes.push_back(name);
+    if (id_genome) *id_genome = (uint32_t)h->genomes.size() - 1;
+    return BFT_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// insertion log
+// ------------------------------------------------------------------------------------------------
+static int log_reserve(bft_gpu* h, uint64_t need) {
+    if (need <= h->log_cap) return 0;
+    uint64_t ncap = std::max<uint64_t>(need, h->log_cap * 2);
+    ncap = std::max<uint64_t>(ncap, 1 << 16);
+    DevBuf nk, ng;
+    CK(nk.alloc(ncap * h->W * 8));
+    CK(ng.alloc(ncap * 4));
+    if (h->log_n) {
+        for (int w = 0; w < h->W; w++)
+            HIPCK(hipMemcpyAsync(nk.as<uint64_t>() + (uint64_t)w * ncap, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
+                                 h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(ng.p, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    h->log_k.swap(nk);
+    h->log_g.swap(ng);
+    h->log_cap = ncap;
+    return 0;
+}
+
+template <int W>
+static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid) {
+    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
+    hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), BFT_BLOCK * h->B, h->stream, d_packed, n, h->B,
+                       h->L, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome) {
+    if (!h || (!d_kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (n == 0) return BFT_GPU_OK;
+    CK(set_device(h));
+    if (h->log_n + n + h->n_pairs >= 0x7FFFFFFFull) return fail(BFT_GPU_E_LIMIT, "more than 2^31-1 (k-mer, genome) pairs");
+    CK(log_reserve(h, h->log_n + n));
+    const uint8_t* p = (const uint8_t*)d_kmers;
+    switch (h->W) {
+    case 1: CK(launch_pack<1>(h, p, n, id_genome)); break;
+    case 2: CK(launch_pack<2>(h, p, n, id_genome)); break;
+    case 3: CK(launch_pack<3>(h, p, n, id_genome)); break;
+    default: CK(launch_pack<4>(h, p, n, id_genome)); break;
+    }
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->log_n += n;
+    h->max_gid_seen = std::max(h->max_gid_seen, id_genome);
+    h->any_insert = true;
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint32_t id_genome) {
+    if (!h || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (n == 0) return BFT_GPU_OK;
+    CK(set_device(h));
+    const uint64_t chunk = 1ull << 26;
+    DevBuf tmp;
+    CK(tmp.alloc(std::min(n, chunk) * h->B));
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        HIPCK(hipMemcpy(tmp.p, kmers + a * h->B, m * h->B, hipMemcpyHostToDevice));
+        CK(bft_gpu_insert_kmers_dev(h, tmp.p, m, id_genome));
+    }
+    return BFT_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bulk build
+// ------------------------------------------------------------------------------------------------
+static int bits_for(uint64_t v) {
+    int b = 1;
+    while (b < 64 && (v >> b)) b++;
+    return b;
+}
+
+// Stable LSD sort of `total` entries by (keys word 0..W-1 as one big integer, then g).
+// keys: SoA with stride `stride`.  Result in okeys (stride ostride) / og.
+static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const uint32_t* g, uint64_t total, uint64_t* okeys,
+                      uint64_t ostride, uint32_t* og) {
+    const int W = h->W;
+    const int n = (int)total;
+    DevBuf perm, perm2, ku, ku2, kg, kg2, tmp;
+    CK(perm.alloc(total * 4));
+    CK(perm2.alloc(total * 4));
+    CK(ku.alloc(total * 8));
+    CK(ku2.alloc(total * 8));
+    CK(kg.alloc(total * 4));
+    CK(kg2.alloc(total * 4));
+    const int grid = grid_for((total + 255) / 256);
+    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, h->stream, perm.as<uint32_t>(), total);
+    size_t tb32 = 0, tb64 = 0;
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb32, kg.as<uint32_t>(), kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 32, h->stream));
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb64, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 64, h->stream));
+    CK(tmp.alloc(std::max(tb32, tb64)));
+    // pass 0: genome id (least significant)
+    {
+        size_t tb = tmp.bytes;
+        const int gb = bits_for(h->max_gid_seen);
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, g, kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, gb, h->stream));
+        perm.swap(perm2);
+    }
+    // passes over the key words, least significant word (W-1) first
+    for (int w = W - 1; w >= 0; w--) {
+        const int nbits = (w == 0) ? (2 * h->k - 64 * (W - 1)) : 64;
+        hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, keys + (uint64_t)w * stride, perm.as<uint32_t>(), ku.as<uint64_t>(), total);
+        size_t tb = tmp.bytes;
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
+        perm.swap(perm2);
+    }
+    for (int w = 0; w < W; w++)
+        hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, keys + (uint64_t)w * stride, perm.as<uint32_t>(), okeys + (uint64_t)w * ostride, total);
+    hipLaunchKernelGGL(k_gather<uint32_t>, dim3(grid), dim3(256), 0, h->stream, g, perm.as<uint32_t>(), og, total);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// exact colour-set interning (host): list of sorted ids -> dense id
+struct Interner {
+    std::vector<uint32_t>& off;
+    std::vector<uint32_t>& ids;
+    std::vector<int64_t> slots;
+    uint64_t nsets = 0;
+    Interner(std::vector<uint32_t>& o, std::vector<uint32_t>& i) : off(o), ids(i) {
+        off.assign(1, 0);
+        ids.clear();
+        slots.assign(1024, -1);
+    }
+    static uint64_t hash(const uint32_t* p, uint32_t n) {
+        uint64_t hsh = 0x9E3779B97F4A7C15ULL ^ n;
+        for (uint32_t i = 0; i < n; i++) {
+            hsh ^= p[i];
+            hsh *= 0x100000001B3ULL;
+            hsh ^= hsh >> 29;
+        }
+        hsh *= 0xBF58476D1CE4E5B9ULL;
+        return hsh ^ (hsh >> 31);
+    }
+    void grow() {
+        std::vector<int64_t> ns(slots.size() * 2, -1);
+        for (int64_t s : slots) {
+            if (s < 0) continue;
+            uint64_t hh = hash(&ids[off[s]], off[s + 1] - off[s]);
+            size_t p = hh & (ns.size() - 1);
+            while (ns[p] >= 0) p = (p + 1) & (ns.size() - 1);
+            ns[p] = s;
+        }
+        slots.swap(ns);
+    }
+    uint32_t intern(const uint32_t* p, uint32_t n) {
+        if ((nsets + 1) * 2 > slots.size()) grow();
+        uint64_t hh = hash(p, n);
+        size_t q = hh & (slots.size() - 1);
+        while (slots[q] >= 0) {
+            int64_t s = slots[q];
+            if (off[s + 1] - off[s] == n && memcmp(&ids[off[s]], p, (size_t)n * 4) == 0) return (uint32_t)s;
+            q = (q + 1) & (slots.size() - 1);
+        }
+        slots[q] = (int64_t)nsets;
+        ids.insert(ids.end(), p, p + n);
+        off.push_back((uint32_t)ids.size());
+        return (uint32_t)nsets++;
+    }
+};
+
+template <class T>
+static int upload(DevBuf& d, const std::vector<T>& v) {
+    CK(d.alloc(v.size() * sizeof(T)));
+    if (!v.empty()) HIPCK(hipMemcpy(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int bft_gpu_build(bft_gpu* h) {
+    if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    CK(set_device(h));
+    if (h->built && h->log_n == 0) return BFT_GPU_OK;
+    const int W = h->W;
+    const uint64_t total = h->n_pairs + h->log_n;
+    double t0 = now_ms();
+
+    DevBuf tk, seg_off, npk, npg;
+    uint64_t nk = 0, np = 0;
+    if (total > 0) {
+        // 1. concatenate the sorted store and the log
+        DevBuf ck, cg, sk, sg;
+        CK(ck.alloc(total * W * 8));
+        CK(cg.alloc(total * 4));
+        for (int w = 0; w < W; w++) {
+            if (h->n_pairs)
+                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total, h->pair_k.as<uint64_t>() + (uint64_t)w * h->n_pairs,
+                                     h->n_pairs * 8, hipMemcpyDeviceToDevice, h->stream));
+            if (h->log_n)
+                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total + h->n_pairs, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
+                                     h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
+        }
+        if (h->n_pairs) HIPCK(hipMemcpyAsync(cg.p, h->pair_g.p, h->n_pairs * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (h->log_n) HIPCK(hipMemcpyAsync(cg.as<uint32_t>() + h->n_pairs, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        h->log_k.release();
+        h->log_g.release();
+        h->log_cap = 0;
+        // 2. sort by (T, genome)
+        CK(sk.alloc(total * W * 8));
+        CK(sg.alloc(total * 4));
+        CK(sort_pairs(h, ck.as<uint64_t>(), total, cg.as<uint32_t>(), total, sk.as<uint64_t>(), total, sg.as<uint32_t>()));
+        ck.release();
+        cg.release();
+        // 3. flags, scans, compaction
+        DevBuf head, keep, posK, posP, tmp;
+        CK(head.alloc(total * 4));
+        CK(keep.alloc(total * 4));
+        CK(posK.alloc(total * 4));
+        CK(posP.alloc(total * 4));
+        const int grid = grid_for((total + 255) / 256);
+        hipLaunchKernelGGL(k_flags, dim3(grid), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, W, sg.as<uint32_t>(), total, head.as<uint32_t>(), keep.as<uint32_t>());
+        size_t tb = 0;
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, head.as<uint32_t>(), posK.as<uint32_t>(), (int)total, h->stream));
+        CK(tmp.alloc(tb));
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, head.as<uint32_t>(), posK.as<uint32_t>(), (int)total, h->stream));
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, keep.as<uint32_t>(), posP.as<uint32_t>(), (int)total, h->stream));
+        uint32_t lastK[2], lastP[2];
+        HIPCK(hipMemcpyAsync(&lastK[0], posK.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(&lastK[1], head.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(&lastP[0], posP.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(&lastP[1], keep.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        nk = (uint64_t)lastK[0] + lastK[1];
+        np = (uint64_t)lastP[0] + lastP[1];
+        CK(tk.alloc(nk * W * 8));
+        CK(seg_off.alloc((nk + 1) * 4));
+        CK(npk.alloc(np * W * 8));
+        CK(npg.alloc(np * 4));
+        hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, W, sg.as<uint32_t>(), total,
+                           head.as<uint32_t>(), keep.as<uint32_t>(), posK.as<uint32_t>(), posP.as<uint32_t>(), npk.as<uint64_t>(), np,
+                           npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+        const uint32_t np32 = (uint32_t)np;
+        HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    double t1 = now_ms();
+
+    // 4. device -> host: the sorted table, segment offsets and genome ids
+    std::vector<uint64_t> h_tk(nk * W);
+    std::vector<uint32_t> h_seg(nk + 1, 0), h_pg(np);
+    if (nk) {
+        HIPCK(hipMemcpy(h_tk.data(), tk.p, nk * W * 8, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(h_seg.data(), seg_off.p, (nk + 1) * 4, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(h_pg.data(), npg.p, np * 4, hipMemcpyDeviceToHost));
+    }
+    double t2 = now_ms();
+
+    // 5. colour sets (exact interning)
+    std::vector<uint32_t> h_tcol(nk);
+    {
+        Interner in(h->cs_off, h->cs_ids);
+        for (uint64_t i = 0; i < nk; i++) h_tcol[i] = in.intern(h_pg.data() + h_seg[i], h_seg[i + 1] - h_seg[i]);
+    }
+    double t3 = now_ms();
+
+    // 6. containers
+    BftHostIndex idx;
+    if (!bft_build_index(h_tk.data(), nk, h->k, h->hashmod.data(), idx)) return fail(BFT_GPU_E_LIMIT, idx.error);
+    double t4 = now_ms();
+
+    // 7. upload
+    CK(upload(h->d_nodes, idx.nodes));
+    CK(upload(h->d_bfT, idx.bfT));
+    CK(upload(h->d_ccs, idx.ccs));
+    CK(upload(h->d_f2w, idx.f2w));
+    CK(upload(h->d_clus, idx.clus));
+    CK(upload(h->d_f3, idx.f3));
+    CK(upload(h->d_child, idx.child));
+    CK(upload(h->d_uck, idx.uck));
+    CK(upload(h->d_ucrow, idx.ucrow));
+    CK(upload(h->d_tcol, h_tcol));
+    CK(upload(h->d_cs_off, h->cs_off));
+    CK(upload(h->d_cs_ids, h->cs_ids));
+    h->d_tk.swap(tk);
+    if (!h->d_tk.p) CK(h->d_tk.alloc(8));
+    h->pair_k.swap(npk);
+    h->pair_g.swap(npg);
+    h->n_pairs = np;
+    h->log_n = 0;
+    h->n_kmers = nk;
+    double t5 = now_ms();
+
+    BftImage& im = h->im;
+    im.k = h->k;
+    im.L = h->L;
+    im.W = W;
+    im.nb_genomes = std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0);
+    im.n_kmers = nk;
+    im.hashmod = h->d_hashmod.as<uint32_t>();
+    im.nodes = h->d_nodes.as<BftNode>();
+    im.bfT = h->d_bfT.as<uint8_t>();
+    im.ccs = h->d_ccs.as<BftCC>();
+    im.f2w = h->d_f2w.as<uint64_t>();
+    im.clus = h->d_clus.as<uint16_t>();
+    im.f3 = h->d_f3.as<uint8_t>();
+    im.child = h->d_child.as<uint64_t>();
+    im.tk = h->d_tk.as<uint64_t>();
+    im.tcol = h->d_tcol.as<uint32_t>();
+    im.uck = h->d_uck.as<uint64_t>();
+    im.ucrow = h->d_ucrow.as<uint32_t>();
+    im.cs_off = h->d_cs_off.as<uint32_t>();
+    im.cs_ids = h->d_cs_ids.as<uint32_t>();
+
+    uint64_t* I = h->info;
+    I[0] = h->k;
+    I[1] = nk;
+    I[2] = idx.nodes.size();
+    I[3] = idx.ccs.size();
+    I[4] = idx.ucrow.size();
+    I[5] = idx.n_child_nodes;
+    I[6] = idx.n_prefixes;
+    I[7] = idx.n_ccs_s4;
+    I[8] = idx.max_ccs_per_node;
+    I[9] = np;
+    I[10] = h->cs_off.size() - 1;
+    I[11] = im.nb_genomes;
+    I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_f3.bytes + h->d_child.bytes +
+            h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes;
+    I[13] = idx.nodes.empty() ? 0 : idx.nodes[0].ncc;
+    I[14] = idx.nodes.empty() ? 0 : idx.nodes[0].uc_n;
+    h->build_ms[0] = t1 - t0;
+    h->build_ms[1] = t2 - t1;
+    h->build_ms[2] = t3 - t2;
+    h->build_ms[3] = t4 - t3;
+    h->build_ms[4] = t5 - t4;
+    h->built = true;
+    return BFT_GPU_OK;
+}
+
+static int ensure_built(bft_gpu* h) {
+    if (!h->built || h->log_n) return bft_gpu_build(h);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// queries
+// ------------------------------------------------------------------------------------------------
+static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+    if (n == 0) return 0;
+    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
+    const dim3 grid(grid_for(nblk)), block(BFT_BLOCK);
+    const size_t lds = (size_t)BFT_BLOCK * h->B;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        HIPCK(hipEventCreate(&e0));
+        HIPCK(hipEventCreate(&e1));
+        HIPCK(hipEventRecord(e0, s));
+    }
+    switch (h->W) {
+    case 1: hipLaunchKernelGGL(k_query<1>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
+    case 2: hipLaunchKernelGGL(k_query<2>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
+    case 3: hipLaunchKernelGGL(k_query<3>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
+    default: hipLaunchKernelGGL(k_query<4>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
+    }
+    HIPCK(hipGetLastError());
+    if (h->timing) {
+        HIPCK(hipEventRecord(e1, s));
+        h->pending_ev.push_back({e0, e1});
+        if (h->pending_ev.size() > 8192) drain_events(h);
+    }
+    return 0;
+}
+
+extern "C" int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* hip_stream) {
+    if (!h || ((!d_kmers || !d_present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    return launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, nullptr, s);
+}
+
+extern "C" int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits) {
+    if (!h || ((!kmers || !present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint64_t chunk = 1ull << 26;  // multiple of 64: chunks are byte aligned in the bitmap
+    DevBuf dk, db;
+    CK(dk.alloc(std::min(n, chunk) * h->B));
+    CK(db.alloc(((std::min(n, chunk) + 63) / 64) * 8));
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        HIPCK(hipMemcpyAsync(dk.p, kmers + a * h->B, m * h->B, hipMemcpyHostToDevice, h->stream));
+        CK(launch_query(h, dk.as<uint8_t>(), m, db.as<uint64_t>(), nullptr, h->stream));
+        HIPCK(hipMemcpyAsync(present_bits + a / 8, db.p, (m + 7) / 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return BFT_GPU_OK;
+}
+
+// shared front half of the colour queries: rows + presence bits for one chunk
+static int query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t m, DevBuf& dk, DevBuf& db, DevBuf& dr, uint8_t* present_bits) {
+    HIPCK(hipMemcpyAsync(dk.p, kmers, m * h->B, hipMemcpyHostToDevice, h->stream));
+    CK(launch_query(h, dk.as<uint8_t>(), m, db.as<uint64_t>(), dr.as<uint32_t>(), h->stream));
+    if (present_bits) HIPCK(hipMemcpyAsync(present_bits, db.p, (m + 7) / 8, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint64_t* offsets,
+                                    uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed) {
+    if (!h || !offsets || ((!kmers) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint64_t chunk = 1ull << 24;
+    const uint64_t mc = std::min(n, chunk);
+    DevBuf dk, db, dr, dcnt, doff, dids, tmp;
+    CK(dk.alloc(mc * h->B));
+    CK(db.alloc(((mc + 63) / 64) * 8));
+    CK(dr.alloc(mc * 4));
+    CK(dcnt.alloc((mc + 1) * 8));
+    CK(doff.alloc((mc + 1) * 8));
+    size_t tb = 0;
+    HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dcnt.as<uint64_t>(), doff.as<uint64_t>(), (int)(mc + 1), h->stream));
+    CK(tmp.alloc(tb));
+    uint64_t total = 0;
+    bool overflow = false;
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        CK(query_rows(h, kmers + a * h->B, m, dk, db, dr, present_bits ? present_bits + a / 8 : nullptr));
+        const int grid = grid_for((m + 255) / 256);
+        hipLaunchKernelGGL(k_color_counts, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, m, dcnt.as<uint64_t>());
+        HIPCK(hipMemsetAsync(dcnt.as<uint64_t>() + m, 0, 8, h->stream));
+        size_t tb2 = tmp.bytes;
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, dcnt.as<uint64_t>(), doff.as<uint64_t>(), (int)(m + 1), h->stream));
+        HIPCK(hipMemcpyAsync(offsets + a, doff.p, (m + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        const uint64_t cnt = offsets[a + m];
+        for (uint64_t i = 0; i <= m; i++) offsets[a + i] += total;  // chunk-local -> global
+        if (!overflow && ids && total + cnt <= ids_cap) {
+            if (cnt) {
+                CK(dids.alloc(cnt * 4));
+                hipLaunchKernelGGL(k_color_fill, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids,
+                                   doff.as<uint64_t>(), m, dids.as<uint32_t>());
+                HIPCK(hipMemcpyAsync(ids + total, dids.p, cnt * 4, hipMemcpyDeviceToHost, h->stream));
+                HIPCK(hipStreamSynchronize(h->stream));
+            }
+        } else
+            overflow = true;
+        total += cnt;
+    }
+    if (n == 0) offsets[0] = 0;
+    if (ids_needed) *ids_needed = total;
+    if (overflow) return fail(BFT_GPU_E_NOSPACE, "ids buffer too small");
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint8_t* rows) {
+    if (!h || !rows || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
+    if (rowbytes == 0) return BFT_GPU_OK;
+    const uint64_t chunk = 1ull << 22;
+    const uint64_t mc = std::min(n, chunk);
+    DevBuf dk, db, dr, dout;
+    CK(dk.alloc(mc * h->B));
+    CK(db.alloc(((mc + 63) / 64) * 8));
+    CK(dr.alloc(mc * 4));
+    CK(dout.alloc(mc * rowbytes));
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        CK(query_rows(h, kmers + a * h->B, m, dk, db, dr, present_bits ? present_bits + a / 8 : nullptr));
+        const int grid = grid_for((m + 255) / 256);
+        hipLaunchKernelGGL(k_color_rows, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, m, rowbytes, dout.as<uint8_t>());
+        HIPCK(hipMemcpyAsync(rows + a * rowbytes, dout.p, m * rowbytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return BFT_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// info / timing / extraction
+// ------------------------------------------------------------------------------------------------
+extern "C" int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out) {
+    if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
+    h->info[0] = h->k;
+    h->info[15] = h->log_n;
+    for (int i = 0; i < n_out && i < 16; i++) out[i] = h->info[i];
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset) {
+    if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    CK(set_device(h));
+    drain_events(h);
+    if (ms) *ms = h->kernel_ms;
+    if (launches) *launches = h->kernel_launches;
+    if (reset) {
+        h->kernel_ms = 0;
+        h->kernel_launches = 0;
+    }
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
+    if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
+    for (int i = 0; i < n_out && i < 5; i++) ms[i] = h->build_ms[i];
+    return BFT_GPU_OK;
+}
+
+template <int W>
+static void unpack_rows(const std::vector<uint64_t>& tk, uint64_t n, int L, int B, uint8_t* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t x[W];
+        bft_x_from_tform<W>(&tk[i * W], L, x);
+        for (int b = 0; b < B; b++) out[i * B + b] = (uint8_t)(x[b >> 3] >> (8 * (b & 7)));
+    }
+}
+
+extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorset_out, uint64_t cap, uint64_t* n_out) {
+    if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    if (n_out) *n_out = h->n_kmers;
+    if (!kmers_out && !colorset_out) return BFT_GPU_OK;
+    if (cap < h->n_kmers) return fail(BFT_GPU_E_NOSPACE, "extract buffer too small");
+    const uint64_t n = h->n_kmers;
+    if (kmers_out && n) {
+        std::vector<uint64_t> tk(n * h->W);
+        HIPCK(hipMemcpy(tk.data(), h->d_tk.p, n * h->W * 8, hipMemcpyDeviceToHost));
+        switch (h->W) {
+        case 1: unpack_rows<1>(tk, n, h->L, h->B, kmers_out); break;
+        case 2: unpack_rows<2>(tk, n, h->L, h->B, kmers_out); break;
+        case 3: unpack_rows<3>(tk, n, h->L, h->B, kmers_out); break;
+        default: unpack_rows<4>(tk, n, h->L, h->B, kmers_out); break;
+        }
+    }
+    if (colorset_out && n) HIPCK(hipMemcpy(colorset_out, h->d_tcol.p, n * 4, hipMemcpyDeviceToHost));
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t cap, uint32_t* n_out) {
+    if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
+    const uint32_t a = h->cs_off[cs], b = h->cs_off[cs + 1];
+    if (n_out) *n_out = b - a;
+    if (ids) {
+        if (cap < b - a) return fail(BFT_GPU_E_NOSPACE, "ids buffer too small");
+        memcpy(ids, &h->cs_ids[a], (size_t)(b - a) * 4);
+    }
+    return BFT_GPU_OK;
+}

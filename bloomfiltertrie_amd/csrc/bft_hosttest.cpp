@@ -1,0 +1,132 @@
+// bft_hosttest.cpp -- TEST-ONLY helper library (libbft_hosttest.so), never loaded by the package.
+//
+// The development container has no GPU, so the host-side logic that feeds the kernels is unit
+// tested on the CPU through this file: T-form conversion, container assembly (bft_index.cpp) and
+// the shared per-query walk of bft_walk.h (the same source the HIP kernel compiles for the device).
+// Nothing here is reachable from the bft_gpu_* C-ABI, which has no CPU path.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "bft_hash.h"
+#include "bft_index.h"
+#include "bft_walk.h"
+
+struct HostTrie {
+    int k, L, W, B;
+    std::vector<uint32_t> hashmod;
+    std::vector<uint64_t> tk;
+    std::vector<uint32_t> tcol, cs_off, cs_ids;
+    BftHostIndex idx;
+    BftImage im;
+};
+
+template <int W>
+static void to_tform(const uint8_t* packed, uint64_t n, int B, int L, std::vector<uint64_t>& out) {
+    out.resize(n * W);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t x[W] = {0}, t[W];
+        for (int b = 0; b < B; b++) x[b >> 3] |= (uint64_t)packed[i * B + b] << (8 * (b & 7));
+        bft_tform_from_x<W>(x, L, t);
+        for (int w = 0; w < W; w++) out[i * W + w] = t[w];
+    }
+}
+
+static void tform_any(const uint8_t* packed, uint64_t n, int k, std::vector<uint64_t>& out) {
+    int W = bft_words_for_k(k), B = bft_bytes_for_k(k), L = k / 9;
+    switch (W) {
+    case 1: to_tform<1>(packed, n, B, L, out); break;
+    case 2: to_tform<2>(packed, n, B, L, out); break;
+    case 3: to_tform<3>(packed, n, B, L, out); break;
+    default: to_tform<4>(packed, n, B, L, out); break;
+    }
+}
+
+extern "C" void* bft_hosttest_build(const uint8_t* kmers, uint64_t n, int k, int r1, int r2) {
+    if (!bft_valid_k(k)) return nullptr;
+    HostTrie* t = new HostTrie();
+    t->k = k; t->L = k / 9; t->W = bft_words_for_k(k); t->B = bft_bytes_for_k(k);
+    t->hashmod.resize(16384);
+    bft_make_hashmod(r1 > 0 ? r1 : BFT_DEFAULT_R1, r2 > 0 ? r2 : BFT_DEFAULT_R2, t->hashmod.data());
+    std::vector<uint64_t> all;
+    tform_any(kmers, n, k, all);
+    const int W = t->W;
+    std::vector<uint64_t> order(n);
+    for (uint64_t i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        for (int w = 0; w < W; w++) if (all[a * W + w] != all[b * W + w]) return all[a * W + w] < all[b * W + w];
+        return false;
+    });
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t* cur = &all[order[i] * W];
+        if (!t->tk.empty() && memcmp(&t->tk[t->tk.size() - W], cur, W * 8) == 0) continue;
+        t->tk.insert(t->tk.end(), cur, cur + W);
+    }
+    uint64_t nk = t->tk.size() / W;
+    t->tcol.assign(nk, 0);
+    t->cs_off = {0, 1};
+    t->cs_ids = {0};
+    if (!bft_build_index(t->tk.data(), nk, k, t->hashmod.data(), t->idx)) { delete t; return nullptr; }
+    BftImage& im = t->im;
+    memset(&im, 0, sizeof(im));
+    im.k = k; im.L = t->L; im.W = W; im.nb_genomes = 1; im.n_kmers = nk;
+    im.hashmod = t->hashmod.data();
+    im.nodes = t->idx.nodes.data(); im.bfT = t->idx.bfT.data(); im.ccs = t->idx.ccs.data();
+    im.f2w = t->idx.f2w.data(); im.clus = t->idx.clus.data(); im.f3 = t->idx.f3.data(); im.child = t->idx.child.data();
+    im.tk = t->tk.data(); im.tcol = t->tcol.data(); im.uck = t->idx.uck.data(); im.ucrow = t->idx.ucrow.data();
+    im.cs_off = t->cs_off.data(); im.cs_ids = t->cs_ids.data();
+    return t;
+}
+
+template <int W>
+static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
+    std::vector<uint64_t> tq;
+    to_tform<W>(q, nq, t->B, t->L, tq);
+    uint64_t cnt = 0;
+    memset(bits, 0, (nq + 7) / 8);
+    for (uint64_t i = 0; i < nq; i++) {
+        BftHit h = bft_walk<W>(t->im, &tq[i * W]);
+        if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
+        if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
+    }
+    return cnt;
+}
+
+extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
+    HostTrie* t = (HostTrie*)hv;
+    switch (t->W) {
+    case 1: return query<1>(t, q, nq, bits, rows);
+    case 2: return query<2>(t, q, nq, bits, rows);
+    case 3: return query<3>(t, q, nq, bits, rows);
+    default: return query<4>(t, q, nq, bits, rows);
+    }
+}
+
+// out[0]=k-mers [1]=nodes [2]=CCs [3]=UC rows [4]=child nodes [5]=prefixes [6]=CCs s=4 [7]=max CCs/node [8]=root CCs [9]=root UC rows
+extern "C" void bft_hosttest_stats(void* hv, uint64_t* out) {
+    HostTrie* t = (HostTrie*)hv;
+    out[0] = t->tk.size() / t->W; out[1] = t->idx.nodes.size(); out[2] = t->idx.ccs.size(); out[3] = t->idx.ucrow.size();
+    out[4] = t->idx.n_child_nodes; out[5] = t->idx.n_prefixes; out[6] = t->idx.n_ccs_s4; out[7] = t->idx.max_ccs_per_node;
+    out[8] = t->idx.nodes[0].ncc; out[9] = t->idx.nodes[0].uc_n;
+}
+
+// T-form round trip: packed -> T -> packed
+extern "C" void bft_hosttest_roundtrip(const uint8_t* kmers, uint64_t n, int k, uint8_t* out, uint64_t* tform_out) {
+    std::vector<uint64_t> all;
+    tform_any(kmers, n, k, all);
+    int W = bft_words_for_k(k), B = bft_bytes_for_k(k), L = k / 9;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t x[BFT_MAX_W] = {0};
+        switch (W) {
+        case 1: bft_x_from_tform<1>(&all[i * W], L, x); break;
+        case 2: bft_x_from_tform<2>(&all[i * W], L, x); break;
+        case 3: bft_x_from_tform<3>(&all[i * W], L, x); break;
+        default: bft_x_from_tform<4>(&all[i * W], L, x); break;
+        }
+        for (int b = 0; b < B; b++) out[i * B + b] = (uint8_t)(x[b >> 3] >> (8 * (b & 7)));
+        if (tform_out) for (int w = 0; w < W; w++) tform_out[i * W + w] = all[i * W + w];
+    }
+}
+
+extern "C" void bft_hosttest_hashmod(int r1, int r2, uint32_t* out) { bft_make_hashmod(r1, r2, out); }
+extern "C" void bft_hosttest_free(void* hv) { delete (HostTrie*)hv; }

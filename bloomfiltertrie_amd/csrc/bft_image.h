@@ -1,0 +1,73 @@
+// bft_image.h -- flattened, pointer-free HBM image of a Bloom Filter Trie.
+//
+// The reference links Node -> CC[] -> {BF_filter2, filter3, extra_filter3, children_type,
+// children UC[], children_Node_container} through heap pointers (include/Node.h:55-58,
+// include/CC.h:34-67) and finds children by counting from the left (include/CC.h:471-550).
+// The serialized .bft holds neither the Bloom filters nor the skip tables, so the
+// device layout is ours; only query results must match.  Layout, MI355X-first:
+//
+//  * k-mers are kept in "T-form": the L = k/9 rotated 18-bit prefixes r_d = n2..n9,n1 of
+//    src/presenceNode.c:1367-1371, most significant first, in W = ceil(2k/64) u64 words
+//    (word 0 most significant).  Sorting T-form integers is a DFS of the trie with every CC's
+//    prefixes in filter3 order, so ONE sorted table `tk` holds every suffix group and every child
+//    Node as a contiguous run; containers are offsets into it.  Stripping 9 nt per level
+//    (src/presenceNode.c:1853-1861) becomes a digit index.
+//  * per node, the CC Bloom filters are bit-sliced: for each of the 1504 bit positions a mask over
+//    the node's CCs, so "first BF-positive CC" (src/presenceNode.c:1353-1362) is
+//    two loads, an AND and a count-trailing-zeros instead of 2 byte loads per CC.
+//  * filter2 is stored 48 bits + 16-bit running rank per u64: bit test and rank
+//    (src/presenceNode.c:1619-1636, SkipFilter2) are one load + one popcount.
+//  * extra_filter3 select (src/presenceNode.c:1648-1688, SkipFilter3) is a u16 cluster-start table.
+//  * children_type counting (include/CC.h:471-550) is a per-prefix u64 {count:8 | row-or-node:40}.
+#pragma once
+#include <stdint.h>
+
+#define BFT_MAX_W 4            // k <= 126 -> 252 bits
+#define BFT_MODULO_HASH 1504   // include/default_param.h:41
+#define BFT_NB_KMERS_PER_UC 255 // include/default_param.h:17-31
+#define BFT_TRESH_SUF_PREF 3584 // include/default_param.h:42
+#define BFT_F2_BITS_PER_WORD 48
+
+struct BftNode {          // 16 B
+    uint32_t cc_first;    // index of the node's first CC in ccs[]
+    uint32_t bf_off;      // offset of the bit-sliced Bloom block in bfT, in 8-byte units
+    uint32_t uc_first;    // first row of the node's UC in uck[] / ucrow[]
+    uint16_t ncc;         // number of CCs
+    uint8_t uc_n;         // UC rows (< 255, include/default_param.h:31)
+    uint8_t bf_wb;        // bytes per Bloom bit position: 1, 2, 4 or 8*ceil(ncc/64)
+};
+
+struct BftCC {            // 32 B
+    uint32_t f2_off;      // into f2w[] (u64 units)
+    uint32_t clus_off;    // into clus[] (u16 units); nclus+1 entries
+    uint32_t f3_off;      // into f3[] (bytes)
+    uint32_t child_off;   // into child[] (u64 units)
+    uint16_t nb_elem;     // prefixes in this CC (include/CC.h:36)
+    uint8_t s;            // length of p_v in bits: 8, or 4 once nb_elem >= 3584 (src/insertNode.c:134-135)
+    uint8_t pad0;
+    uint32_t nclus;
+    uint32_t pad1, pad2;
+};
+
+#define BFT_CHILD_IDX_MASK 0xFFFFFFFFFFULL
+#define BFT_CHILD_CNT_SHIFT 40
+
+struct BftImage {
+    int k, L, W;
+    uint32_t nb_genomes;
+    uint64_t n_kmers;
+    const uint32_t* hashmod;  // [16384] (hash_v[2i] % 1504) | (hash_v[2i+1] % 1504) << 16
+    const BftNode* nodes;
+    const uint8_t* bfT;
+    const BftCC* ccs;
+    const uint64_t* f2w;
+    const uint16_t* clus;
+    const uint8_t* f3;
+    const uint64_t* child;
+    const uint64_t* tk;       // [n_kmers * W] sorted T-form table
+    const uint32_t* tcol;     // [n_kmers] colour-set id per row
+    const uint64_t* uck;      // [n_uc_rows * W] node-UC rows (T-form)
+    const uint32_t* ucrow;    // [n_uc_rows] row of that k-mer in tk
+    const uint32_t* cs_off;   // [n_cs + 1] colour-set dictionary (sorted genome ids)
+    const uint32_t* cs_ids;
+};

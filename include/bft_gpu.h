@@ -1,0 +1,111 @@
+/*
+ * bft_gpu.h -- C-ABI of the MI355X-native batched k-mer presence / colour / insertion path of the
+ * Bloom Filter Trie.  This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  Every entry point names the reference interface (GuillaumeHolley/BloomFilterTrie,
+ * file:line) it replaces or batches.  Library: bloomfiltertrie_amd/csrc/libbft_gpu.so
+ * (hipcc --offload-arch=gfx950).  INTEGRATION.md shows the binding a maintainer adds to the
+ * reference's src/file_io.c / src/bft.c.
+ *
+ * k-mer batches use the reference's packed layout everywhere (parseKmerCount, src/fasta.c:3-53;
+ * README.md:171-172): CEIL(2k/8) bytes per k-mer, nucleotide j in byte j/4 bits 2(j%4)..+1,
+ * A=0 C=1 G=2 T=3, k-mers contiguous -- the `array_kmers` argument of insertKmers
+ * (include/insertNode.h:26) and the 4096-byte chunks of src/file_io.c:726-730.
+ *
+ * Presence bitmaps: CEIL(n/8) bytes, k-mer i -> bit i%8 of byte i/8.
+ *
+ * All functions return BFT_GPU_OK (0) or a negative error code; bft_gpu_last_error() gives the
+ * message for the calling thread.  (The reference has no error codes: ERROR() prints and exits,
+ * include/useful_macros.h:33-43; the C wrapper of INTEGRATION.md keeps that behaviour.)
+ * There is NO CPU fallback: without a usable HIP device every call fails with BFT_GPU_E_HIP.
+ */
+#ifndef BFT_GPU_H
+#define BFT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFT_GPU_OK 0
+#define BFT_GPU_E_ARG (-1)      /* bad argument (k not a multiple of 9, NULL pointer, ...) */
+#define BFT_GPU_E_HIP (-2)      /* HIP runtime / device error */
+#define BFT_GPU_E_LIMIT (-3)    /* a container limit of the format was exceeded */
+#define BFT_GPU_E_STATE (-4)    /* call order (query before anything was built, ...) */
+#define BFT_GPU_E_IO (-5)       /* file error / malformed .bft */
+#define BFT_GPU_E_NOSPACE (-6)  /* caller-provided output buffer too small */
+
+typedef struct bft_gpu bft_gpu; /* opaque: one BFT resident on one GPU (replaces BFT_Root, include/Node.h:96-122) */
+
+const char* bft_gpu_last_error(void);
+int bft_gpu_device_count(void);
+const char* bft_gpu_version(void);
+
+/* createBFT_Root(k, treshold_compression, compressed=0) (include/CC.h:214-258) / create_cdbg
+ * (include/bft.h:62).  k must be a multiple of 9 in [9,126] (src/main.c:61-63).  The Bloom seeds are
+ * the reference's un-seeded rand() values (include/CC.h:246-248) unless r1/r2 > 0 are given. */
+int bft_gpu_create(int k, int device, bft_gpu** out);
+int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out);
+/* freeBFT_Root (include/CC.h:260-268) / free_cdbg (include/bft.h:63) */
+void bft_gpu_free(bft_gpu* h);
+
+/* add_genomes_BFT_Root (include/CC.h:307-338): register a genome name; returns its id in *id_genome
+ * (ids are 0-based and increase, as the reference's nb_genomes-1). */
+int bft_gpu_add_genome(bft_gpu* h, const char* name, uint32_t* id_genome);
+
+/* insertKmers(root, array_kmers, nb_kmers, id_genome, size_id_genome) (include/insertNode.h:26,
+ * src/insertNode.c:18-36).  The batch is converted on the GPU and appended to a device-side log;
+ * the trie image is (re)built in bulk by bft_gpu_build (or lazily by the first query).
+ * `kmers` is a HOST pointer; the _dev variant takes a DEVICE pointer to the same layout. */
+int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint32_t id_genome);
+int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, uint32_t id_genome);
+
+/* Bulk construction of the device image from everything inserted so far: GPU radix sort +
+ * de-duplication of (k-mer, genome) pairs, colour-set interning, container assembly.
+ * Replaces the per-k-mer work of insertKmer_Node / insertSP_CC / transform2CC
+ * (src/insertNode.c:38-423, src/CC.c:40-1474) with the invariants of SURVEY.md A.7. */
+int bft_gpu_build(bft_gpu* h);
+
+/* The loop of src/file_io.c:726-768 over isKmerPresent (include/presenceNode.h:57,
+ * src/presenceNode.c:1823): one bit per k-mer.  Host buffers in, host bitmap out. */
+int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits);
+/* Same with inputs and outputs resident in HBM; runs on `hip_stream` (a hipStream_t, NULL = the
+ * handle's own stream) and does not synchronise. d_present_bits: CEIL(n/64)*8 bytes. */
+int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_present_bits,
+                               void* hip_stream);
+
+/* get_annotation + get_list_id_genomes (include/bft.h:97,115; src/bft.c:363-387, 622-641;
+ * src/annotation.c:2086-2250) for a batch: offsets[n+1] into ids (sorted genome ids per k-mer, none
+ * for absent k-mers).  If ids_cap is too small nothing is written to ids, *ids_needed is set and
+ * BFT_GPU_E_NOSPACE is returned. */
+int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
+                         uint64_t* offsets, uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed);
+/* Fixed-width variant = the CSV row of src/file_io.c:744-765 before formatting: row i is
+ * CEIL(nb_genomes/8) bytes, genome g -> bit g%8 of byte g/8 (all zero for absent k-mers). */
+int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
+                             uint8_t* rows);
+
+/* Shape / size counters (the walk of src/printMemory.c:255).  out[0]=k, [1]=distinct k-mers,
+ * [2]=nodes, [3]=CCs, [4]=node-UC rows, [5]=child nodes, [6]=prefixes, [7]=CCs in s=4 mode,
+ * [8]=max CCs per node, [9]=(k-mer,genome) pairs, [10]=distinct colour sets, [11]=genomes,
+ * [12]=image bytes in HBM, [13]=root CCs, [14]=root UC rows, [15]=pending (unbuilt) pairs. */
+int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
+
+/* HIP-event timing of the query kernels launched through this handle since the last reset:
+ * *ms = summed kernel time, *launches = number of launches. */
+int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
+/* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
+ * ms[1]=device->host copies, ms[2]=colour interning (host), ms[3]=container assembly (host),
+ * ms[4]=host->device upload. */
+int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
+
+/* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,
+ * ascending T-form order) and its colour-set id; either pointer may be NULL. */
+int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorset_out, uint64_t cap, uint64_t* n_out);
+int bft_gpu_colorset(bft_gpu* h, uint32_t colorset, uint32_t* ids, uint32_t cap, uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs, bit-exact (integer/bit work: no tolerance), plus ground truth set semantics."""
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _bft(k, **kw):
+    from bloomfiltertrie_amd import BFT
+    return BFT(k, device=0, **kw)
+
+
+def _queries(km, k, seed=0, n_rand=None):
+    rng = np.random.default_rng(seed)
+    n_rand = n_rand or max(1000, len(km) // 2)
+    parts = [km, S.pack_codes(rng.integers(0, 4, (n_rand, k), dtype=np.uint8))]
+    if len(km):
+        parts.append(S.snp_mutants(km, k, seed + 1))
+    q = np.concatenate(parts)
+    return np.ascontiguousarray(q[rng.permutation(len(q))])
+
+
+def _check(t, o, km, k, seed=0):
+    q = _queries(km, k, seed)
+    got = t.query_presence(q)
+    exp = o.query_presence(q)
+    assert (got == exp).all()
+    assert (S.from_bits(got, len(q)) == S.member(q, km)).all()
+    return q
+
+
+@pytest.mark.parametrize("k", [9, 18, 27, 36, 45, 63, 72, 99, 126])
+def test_presence_random_genome(oracle_mod, k):
+    km = S.distinct(S.kmers_of(S.random_genome(150000, 10 + k), k))
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    _check(t, o, km, k)
+    info = t.info()
+    assert info["kmers"] == len(km) == o.stats()["kmers"]
+    ek, _ = t.extract()
+    assert sorted(S.row_keys(ek).tolist()) == sorted(S.row_keys(km).tolist())
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 254, 255, 256, 257, 300, 1000])
+def test_tiny_and_ragged(oracle_mod, n):
+    k = 27
+    km = S.distinct(S.pack_codes(np.random.default_rng(n).integers(0, 4, (n, k), dtype=np.uint8))) if n else np.zeros((0, 7), np.uint8)
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    t.build()
+    for nq in (0, 1, 7, 8, 63, 64, 65, 255, 256, 257, 1023):
+        q = _queries(km, k, seed=nq, n_rand=nq)[:nq] if nq else np.zeros((0, 7), np.uint8)
+        got = t.query_presence(q)
+        assert (got == o.query_presence(q)).all()
+
+
+@pytest.mark.parametrize("k,levels", [(18, 1), (27, 1), (27, 2), (36, 2), (36, 3), (63, 3), (45, 4), (126, 5)])
+def test_deep_tries(oracle_mod, k, levels):
+    km = S.low_entropy_kmers(120000, k, 24, seed=k * 7 + levels, levels=levels)
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    _check(t, o, km, k)
+    assert t.info()["child_nodes"] > 0 and o.stats()["child_nodes"] > 0
+
+
+def test_large_root_both_filter_geometries(oracle_mod):
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(1200000, 77), k))
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    _check(t, o, km, k)
+    info = t.info()
+    assert 0 < info["ccs_s4"] < info["ccs"]
+
+
+@pytest.mark.parametrize("k,ngen", [(27, 6), (18, 10), (36, 70), (27, 200)])
+def test_colours(oracle_mod, k, ngen):
+    anc = S.random_genome(3000 if ngen > 20 else 30000, 5)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 100 + g) if g else anc, k)) for g in range(ngen)]
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+        t.insert_kmers(km[:10], g)  # duplicate (k-mer, genome) pairs are no-ops, as in the reference
+        o.insert_kmers(km, g)
+    allk = S.distinct(np.concatenate(gk))
+    q = _queries(allk, k, seed=3)
+    bits, off, ids = t.query_colors(q)
+    obits, ooff, oids = o.query_colors(q)
+    assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+    bits2, rows = t.query_color_rows(q)
+    assert (bits2 == obits).all()
+    pres = S.from_bits(obits, len(q))
+    unp = np.unpackbits(rows, axis=1, bitorder="little")[:, :ngen]
+    for i in np.flatnonzero(pres)[:3000]:
+        assert np.flatnonzero(unp[i]).tolist() == oids[int(ooff[i]):int(ooff[i + 1])].tolist()
+    assert not unp[~pres].any()
+    # every stored k-mer and its colour set equals the oracle's extraction
+    ek, ecs = t.extract()
+    ok, ocs = o.extract()
+    omap = {key: o.colorset(c) for key, c in zip(S.row_keys(ok).tolist(), ocs.tolist())}
+    assert len(ek) == len(ok)
+    cache = {}
+    for key, c in zip(S.row_keys(ek).tolist(), ecs.tolist()):
+        if c not in cache:
+            cache[c] = t.colorset(c)
+        assert cache[c] == omap[key]
+
+
+def test_incremental_insert_and_rebuild(oracle_mod):
+    k = 27
+    anc = S.random_genome(50000, 9)
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    allk = np.zeros((0, 7), np.uint8)
+    for g in range(4):
+        km = S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k))
+        t.insert_kmers(km, g)
+        o.insert_kmers(km, g)
+        allk = S.distinct(np.concatenate([allk, km]))
+        q = _queries(allk, k, seed=g)
+        bits, off, ids = t.query_colors(q)  # lazily rebuilds the image
+        obits, ooff, oids = o.query_colors(q)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+    assert t.info()["kmers"] == len(allk)
+
+
+def test_device_resident_api_matches_host_api(oracle_mod):
+    import torch
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(100000, 21), k))
+    t = _bft(k)
+    t.insert_kmers(km, 0)
+    t.build()
+    q = _queries(km, k, seed=5)
+    dq = torch.from_numpy(q).cuda()
+    dbits = torch.zeros(((len(q) + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    t.query_presence_dev(dq.data_ptr(), len(q), dbits.data_ptr(), stream)
+    torch.cuda.synchronize()
+    got = dbits.cpu().numpy()[: (len(q) + 7) // 8]
+    assert (got == t.query_presence(q)).all()
+    ms, launches = t.kernel_time()
+    assert launches >= 2 and ms > 0
+
+
+def test_rejects_bad_k():
+    from bloomfiltertrie_amd import BFT
+    from bloomfiltertrie_amd._lib import BFTError
+    for k in (31, 8, 135):
+        with pytest.raises(BFTError):
+            BFT(k)
