@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 (ROCm 7.x, rocpd sqlite) --kernel-trace --stats result into a short text summary.
+
+usage: summarize_rocpd.py results.db [--pmc]  > profiles/<round>_<what>.txt
+"""
+import sqlite3
+import sys
+
+
+def short(name, n=110):
+    name = name.replace("void ", "")
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    print(f"# source: {sys.argv[1]} (rocprofv3 --kernel-trace --stats)")
+    print(f"{'kernel':112s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}")
+    for name, calls, tot, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print(f"{short(name):112s} {calls:6d} {tot:12.1f} {avg:12.2f} {pct:7.2f}")
+    print("\n# product kernels: launch geometry and registers (first dispatch of each)")
+    seen = set()
+    q = ("select name,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count,min(duration),max(duration),"
+         "avg(duration),count(*) from kernels where name like '%k_%' group by name")
+    for row in cur.execute(q):
+        name = row[0]
+        if "at::native" in name or "rocprim" in name or name in seen:
+            continue
+        seen.add(name)
+        print(f"{short(name, 90):92s} grid={row[1]} wg={row[2]} lds={row[3]} scratch={row[4]} vgpr={row[5]} agpr={row[6]} sgpr={row[7]} "
+              f"min/avg/max_us={row[8] / 1e3:.1f}/{row[10] / 1e3:.1f}/{row[9] / 1e3:.1f} n={row[11]}")
+    if "--pmc" in sys.argv:
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        print("\n# tables:", [t for t in tabs if "pmc" in t.lower() or "counter" in t.lower()])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/bft_gpu.h declares, fails loudly
+without a device, and the host logic that feeds the kernels (T-form conversion, container assembly, the shared
+per-query walk of csrc/bft_walk.h) matches the oracle and ground truth."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import _lib, synth as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def built():
+    subprocess.check_call(["make", "-C", _lib.CSRC, "all"], stdout=subprocess.DEVNULL)
+    return True
+
+
+def test_header_symbols_are_exported(built):
+    hdr = open(_lib.HEADER).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(bft_gpu_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (bft_gpu_[a-z_0-9]+)", out))
+    assert declared <= exported
+
+
+def test_fails_loudly_without_a_device(built):
+    lib = _lib.load()
+    if lib.bft_gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from bloomfiltertrie_amd import BFT
+    with pytest.raises(_lib.BFTError):
+        BFT(27)
+
+
+def test_rejects_k_not_multiple_of_9(built):
+    lib = _lib.load()
+    h = C.c_void_p()
+    for k in (31, 8, 135, 0):
+        assert lib.bft_gpu_create(k, 0, C.byref(h)) == -1  # BFT_GPU_E_ARG, before any device is touched
+        assert b"multiple of 9" in lib.bft_gpu_last_error()
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "bloomfiltertrie_amd")):
+        for f in fs:
+            if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle|liborc|bft_oracle", txt, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad
+
+
+# ---- host logic through the test-only helper library ---------------------------------------------------------------
+@pytest.fixture(scope="session")
+def hostlib(built):
+    lib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
+    lib.bft_hosttest_build.restype = C.c_void_p
+    lib.bft_hosttest_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    lib.bft_hosttest_query.restype = C.c_uint64
+    lib.bft_hosttest_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_hashmod.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    lib.bft_hosttest_free.argtypes = [C.c_void_p]
+    return lib
+
+
+def test_hash_table_matches_oracle_and_reference(hostlib, oracle_mod):
+    hm = np.zeros(16384, np.uint32)
+    hostlib.bft_hosttest_hashmod(oracle_mod._load().orc_create and 1804289383, 846930886, hm.ctypes.data)
+    t = oracle_mod.OracleBFT(27)
+    hv = t.hash_v(2 * 16384)
+    exp = np.array([(hv[2 * i] % 1504) | ((hv[2 * i + 1] % 1504) << 16) for i in range(16384)], dtype=np.uint32)
+    assert (hm == exp).all()
+    ref = oracle_mod.ref_prims()
+    if ref is not None:  # the reference's own xxhash.c
+        for i in (0, 1, 2, 77, 16383):
+            key = bytes([(i >> 10) & 0xFF, (i >> 2) & 0xFF, (i << 6) & 0xFF])
+            assert (hm[i] & 0xFFFF) == ref.BFT_HASH_XXH64(key, 3, 1804289383) % 1504
+            assert (hm[i] >> 16) == ref.BFT_HASH_XXH64(key, 3, 846930886) % 1504
+
+
+@pytest.mark.parametrize("k", [9, 18, 27, 36, 45, 54, 63, 72, 81, 90, 99, 108, 117, 126])
+def test_tform_roundtrip(hostlib, k):
+    km = np.ascontiguousarray(S.pack_codes(np.random.default_rng(k).integers(0, 4, (2000, k), dtype=np.uint8)))
+    out = np.zeros_like(km)
+    W = (2 * k + 63) // 64
+    tf = np.zeros((len(km), W), dtype=np.uint64)
+    hostlib.bft_hosttest_roundtrip(km.ctypes.data, len(km), k, out.ctypes.data, tf.ctypes.data)
+    assert (out == km).all()
+    # T-form order == order of the per-level rotated prefixes n2..n9,n1 (src/presenceNode.c:1367-1371)
+    codes = S.unpack_codes(km, k)
+    for i in range(0, 50):
+        val = 0
+        for d in range(k // 9):
+            n = codes[i, 9 * d:9 * d + 9].tolist()
+            r = 0
+            for x in n[1:] + n[:1]:
+                r = (r << 2) | x
+            val = (val << 18) | r
+        got = 0
+        for w in range(W):
+            got = (got << 64) | int(tf[i, w])
+        assert got == val
+
+
+def _host_check(hostlib, oracle_mod, km, k, seed=0):
+    km = np.ascontiguousarray(km)
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    assert h
+    rng = np.random.default_rng(seed)
+    parts = [km, S.pack_codes(rng.integers(0, 4, (max(500, len(km) // 2), k), dtype=np.uint8))]
+    if len(km):
+        parts.append(S.snp_mutants(km, k, seed + 1))
+    q = np.concatenate(parts)
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    bits = np.zeros((len(q) + 7) // 8, np.uint8)
+    rows = np.zeros(len(q), np.uint32)
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, rows.ctypes.data)
+    o = oracle_mod.OracleBFT(k)
+    o.insert_kmers(km, 0)
+    assert (bits == o.query_presence(q)).all()
+    assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
+    st = np.zeros(10, np.uint64)
+    hostlib.bft_hosttest_stats(h, st.ctypes.data)
+    hostlib.bft_hosttest_free(h)
+    return st.tolist()
+
+
+@pytest.mark.parametrize("k", [9, 18, 27, 36, 63, 126])
+def test_host_index_random(hostlib, oracle_mod, k):
+    st = _host_check(hostlib, oracle_mod, S.distinct(S.kmers_of(S.random_genome(80000, 7 + k), k)), k)
+    assert st[2] > 1  # several CCs in the root
+
+
+@pytest.mark.parametrize("k,levels", [(18, 1), (27, 2), (36, 3), (63, 3), (45, 4)])
+def test_host_index_deep(hostlib, oracle_mod, k, levels):
+    st = _host_check(hostlib, oracle_mod, S.low_entropy_kmers(60000, k, 24, seed=k + levels, levels=levels), k)
+    assert st[4] > 0  # child nodes
+
+
+@pytest.mark.parametrize("n", [0, 1, 254, 255, 256, 300])
+def test_host_index_tiny(hostlib, oracle_mod, n):
+    km = S.distinct(S.pack_codes(np.random.default_rng(n).integers(0, 4, (n, 27), dtype=np.uint8))) if n else np.zeros((0, 7), np.uint8)
+    st = _host_check(hostlib, oracle_mod, km, 27)
+    if len(km) < 255:
+        assert st[2] == 0 and st[9] == len(km)  # UC only, as src/insertNode.c:183-223
+    else:
+        assert st[2] >= 1
+
+
+def test_host_index_invariants_a7(hostlib, oracle_mod):
+    """UC non-empty => last CC holds >= 255 prefixes; UC < 255 rows; both filter2 geometries."""
+    km = S.distinct(S.kmers_of(S.random_genome(600000, 3), 27))
+    st = _host_check(hostlib, oracle_mod, km, 27)
+    assert st[6] > 0 and st[6] < st[2]
+    assert st[9] < 255
