@@ -119,6 +119,9 @@ class BFT:
         _lib.check(self._lib.bft_gpu_query_color_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
         return bits, rows
 
+    def set_option(self, name, value):
+        _lib.check(self._lib.bft_gpu_set_option(self._h, name.encode(), int(value)))
+
     # -- introspection ------------------------------------------------------------------------------------------
     def info(self):
         out = (C.c_uint64 * 16)()

@@ -4,8 +4,9 @@
 //   k_pack_to_tform   packed 2-bit k-mers -> T-form words (the per-level rev[]/rotation work of
 //                     src/presenceNode.c:1327-1371 done once per k-mer)
 //   k_query           batched isKmerPresent (src/presenceNode.c:1823-1921): one lane per k-mer,
-//                     256 k-mers per workgroup staged through LDS with coalesced dword loads,
-//                     presence bits produced with a wavefront __ballot (64 k-mers -> one u64 store)
+//                     coalesced dword loads of the packed batch, hash table + root Bloom block +
+//                     root CC headers staged in LDS, presence bits produced with a wavefront
+//                     __ballot (64 k-mers -> one u64 store)
 //   k_color_*         batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
 //   k_flags/k_scatter de-duplication of sorted (k-mer, genome) pairs for the bulk build
 // The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); the container
@@ -83,77 +84,123 @@ static double now_ms() {
 // device helpers
 // ------------------------------------------------------------------------------------------------
 
-// All threads of the block copy nbytes from g (global) to lds with dword loads where possible.
-__device__ __forceinline__ void stage_bytes(const uint8_t* __restrict__ g, uint32_t nbytes, uint8_t* lds) {
-    const uint32_t tid = threadIdx.x;
-    if ((((uintptr_t)g) & 3u) == 0) {
-        const uint32_t nd = nbytes >> 2;
-        const uint32_t* g4 = (const uint32_t*)g;
-        uint32_t* l4 = (uint32_t*)lds;
-        for (uint32_t i = tid; i < nd; i += BFT_BLOCK) l4[i] = g4[i];
-        for (uint32_t i = (nd << 2) + tid; i < nbytes; i += BFT_BLOCK) lds[i] = g[i];
-    } else {
-        for (uint32_t i = tid; i < nbytes; i += BFT_BLOCK) lds[i] = g[i];
-    }
-}
-
+// Packed k-mer i -> X words, straight from global memory: the 64 lanes of a wavefront read one
+// contiguous 64*B-byte span with aligned dword loads (each lane the <= 2W+1 dwords that cover its
+// B bytes), then funnel-shift.  The last k-mers of a buffer whose window would cross the end of the
+// buffer take a byte path.
 template <int W>
-__device__ __forceinline__ void x_from_lds(const uint8_t* lds, int B, uint64_t* x) {
+__device__ __forceinline__ void load_x(const uint8_t* __restrict__ packed, uint64_t i, int B, uint64_t end_aligned, uint64_t* x) {
+    constexpr int NDW = 2 * W + 1;
+    const uint64_t addr = (uint64_t)packed + i * (uint64_t)B;
+    const uint64_t a = addr & ~3ull;
+    const uint32_t mis = (uint32_t)(addr & 3ull), sh = mis * 8;
+    const uint32_t need = (mis + (uint32_t)B + 3u) >> 2;
+    uint32_t dw[NDW];
+    if (a + 4ull * need <= end_aligned) {
+        const uint32_t* p = (const uint32_t*)a;
 #pragma unroll
-    for (int w = 0; w < W; w++) x[w] = 0;
-    const uint8_t* p = lds + (size_t)threadIdx.x * B;
-    for (int b = 0; b < B; b++) x[b >> 3] |= (uint64_t)p[b] << (8 * (b & 7));
+        for (int j = 0; j < NDW; j++) dw[j] = ((uint32_t)j < need) ? p[j] : 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NDW; j++) dw[j] = 0;
+        const uint8_t* q = (const uint8_t*)addr;
+        for (int b = 0; b < B; b++) {
+            const uint32_t pos = mis + (uint32_t)b, v = (uint32_t)q[b] << (8 * (pos & 3));
+#pragma unroll
+            for (int j = 0; j < NDW; j++)
+                if ((pos >> 2) == (uint32_t)j) dw[j] |= v;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t lo = (uint64_t)dw[2 * w] | ((uint64_t)dw[2 * w + 1] << 32);
+        const uint64_t hi = dw[2 * w + 2];
+        x[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    }
+    const int rem = B - 8 * (W - 1);
+    if (rem < 8) x[W - 1] &= (1ull << (8 * rem)) - 1ull;
 }
 
 template <int W>
 __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int L,
                                                              uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
                                                              uint32_t* __restrict__ gout, uint32_t gid) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t first = blk * BFT_BLOCK;
-        const uint32_t cnt = (uint32_t)min((uint64_t)BFT_BLOCK, n - first);
-        stage_bytes(packed + first * B, cnt * B, lds);
-        __syncthreads();
-        if (threadIdx.x < cnt) {
-            uint64_t x[W], t[W];
-            x_from_lds<W>(lds, B, x);
-            bft_tform_from_x<W>(x, L, t);
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)BFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BFT_BLOCK) {
+        uint64_t x[W], t[W];
+        load_x<W>(packed, i, B, end_aligned, x);
+        bft_tform_from_x<W>(x, L, t);
 #pragma unroll
-            for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + first + threadIdx.x] = t[w];
-            gout[off + first + threadIdx.x] = gid;
-        }
-        __syncthreads();
+        for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + i] = t[w];
+        gout[off + i] = gid;
     }
 }
 
-template <int W>
-__global__ __launch_bounds__(BFT_BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                     uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+// The hash table (64 KiB) and the root node's bit-sliced Bloom block and CC headers live in LDS:
+// every query of a batch reads them, and a divergent LDS read costs a few cycles where a divergent
+// vector-memory read occupies the CU's texture path for ~64.
+template <bool STAGED>
+struct BftRootLds {
+    const BftImage& im;
+    const uint32_t* hm;
+    const uint8_t* bf;
+    const BftCC* cc;
+    __device__ __forceinline__ uint32_t hashmod(uint32_t key) const { return hm[key]; }
+    __device__ __forceinline__ int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
+        if (STAGED) return bft_first_cc_blk(bf, nd.bf_wb, h1, h2);
+        return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
+    }
+    __device__ __forceinline__ BftCC root_cc(const BftNode& nd, int c) const {
+        if (STAGED) return cc[c];
+        return im.ccs[nd.cc_first + c];
+    }
+};
+
+#define BFT_LDS_HM_BYTES 65536u
+#define BFT_LDS_ROOT_MAX_CC 64u
+
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                 uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
+    uint32_t* l_hm = (uint32_t*)lds;
+    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    const BftNode root = im.nodes[0];
+    const bool stage_root = STAGED;  // host side: root.ncc in [1, 64]
+    const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
+    BftCC* l_cc = (BftCC*)(l_bf + bf_bytes);
+    {
+        const uint4* g = (const uint4*)im.hashmod;
+        uint4* l = (uint4*)l_hm;
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (stage_root) {
+            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
+            uint64_t* lb = (uint64_t*)l_bf;
+            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;  // 1504*wb is a multiple of 8
+            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccs[root.cc_first + i];
+        }
+    }
+    __syncthreads();
+    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t first = blk * BFT_BLOCK;
-        const uint32_t cnt = (uint32_t)min((uint64_t)BFT_BLOCK, n - first);
-        stage_bytes(packed + first * B, cnt * B, lds);
-        __syncthreads();
+        const uint64_t i = blk * BLOCK + threadIdx.x;
         int present = 0;
         uint32_t row = BFT_ABSENT_ROW;
-        if (threadIdx.x < cnt) {
+        if (i < n) {
             uint64_t x[W], t[W];
-            x_from_lds<W>(lds, B, x);
+            load_x<W>(packed, i, B, end_aligned, x);
             bft_tform_from_x<W>(x, im.L, t);
-            BftHit h = bft_walk<W>(im, t);
+            const BftHit h = bft_walk<W>(im, acc, root, t);
             present = h.present;
             if (present) row = (uint32_t)h.row;
         }
         const uint64_t mask = __ballot(present);
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const uint64_t q0 = first + (uint64_t)wave * 64;
-        if (lane == 0 && q0 < n) bits64[q0 >> 6] = mask;
-        if (rows && threadIdx.x < cnt) rows[first + threadIdx.x] = row;
-        __syncthreads();
+        const uint64_t q0 = i & ~63ull;  // first query of this wavefront
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        if (rows && i < n) rows[i] = row;
     }
 }
 
@@ -256,7 +303,7 @@ struct bft_gpu {
     // image
     bool built = false;
     uint64_t n_kmers = 0;
-    DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_f3, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids;
+    DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids;
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary
@@ -268,6 +315,9 @@ struct bft_gpu {
     double kernel_ms = 0;
     uint64_t kernel_launches = 0;
     bool timing = true;
+    uint32_t root_ncc = 0;
+    int opt_block = 1024;     // k_query workgroup size (256 / 512 / 1024)
+    int opt_grid_mult = 1;    // grid = resident workgroups x this
 };
 
 static int grid_for(uint64_t nblk) {
@@ -380,7 +430,7 @@ static int log_reserve(bft_gpu* h, uint64_t need) {
 template <int W>
 static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid) {
     const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
-    hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), BFT_BLOCK * h->B, h->stream, d_packed, n, h->B,
+    hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), 0, h->stream, d_packed, n, h->B,
                        h->L, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
     HIPCK(hipGetLastError());
     return 0;
@@ -626,7 +676,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     CK(upload(h->d_ccs, idx.ccs));
     CK(upload(h->d_f2w, idx.f2w));
     CK(upload(h->d_clus, idx.clus));
-    CK(upload(h->d_f3, idx.f3));
     CK(upload(h->d_child, idx.child));
     CK(upload(h->d_uck, idx.uck));
     CK(upload(h->d_ucrow, idx.ucrow));
@@ -653,8 +702,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     im.bfT = h->d_bfT.as<uint8_t>();
     im.ccs = h->d_ccs.as<BftCC>();
     im.f2w = h->d_f2w.as<uint64_t>();
-    im.clus = h->d_clus.as<uint16_t>();
-    im.f3 = h->d_f3.as<uint8_t>();
+    im.clus = h->d_clus.as<uint64_t>();
     im.child = h->d_child.as<uint64_t>();
     im.tk = h->d_tk.as<uint64_t>();
     im.tcol = h->d_tcol.as<uint32_t>();
@@ -676,9 +724,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     I[9] = np;
     I[10] = h->cs_off.size() - 1;
     I[11] = im.nb_genomes;
-    I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_f3.bytes + h->d_child.bytes +
+    I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes +
             h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes;
     I[13] = idx.nodes.empty() ? 0 : idx.nodes[0].ncc;
+    h->root_ncc = (uint32_t)I[13];
     I[14] = idx.nodes.empty() ? 0 : idx.nodes[0].uc_n;
     h->build_ms[0] = t1 - t0;
     h->build_ms[1] = t2 - t1;
@@ -697,11 +746,38 @@ static int ensure_built(bft_gpu* h) {
 // ------------------------------------------------------------------------------------------------
 // queries
 // ------------------------------------------------------------------------------------------------
+template <int W, int BLOCK, bool STAGED>
+static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+    // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers; two 1024-thread workgroups per CU
+    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCC) : 0);
+    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    const uint64_t resident = 256ull * (2048 / BLOCK);  // 256 CUs x workgroups per CU at full occupancy
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_query<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+template <int W>
+static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+    const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
+    if (staged) {
+        if (h->opt_block == 1024) return launch_query_k<W, 1024, true>(h, d_kmers, n, d_bits64, d_rows, s);
+        if (h->opt_block == 512) return launch_query_k<W, 512, true>(h, d_kmers, n, d_bits64, d_rows, s);
+        return launch_query_k<W, 256, true>(h, d_kmers, n, d_bits64, d_rows, s);
+    }
+    if (h->opt_block == 1024) return launch_query_k<W, 1024, false>(h, d_kmers, n, d_bits64, d_rows, s);
+    if (h->opt_block == 512) return launch_query_k<W, 512, false>(h, d_kmers, n, d_bits64, d_rows, s);
+    return launch_query_k<W, 256, false>(h, d_kmers, n, d_bits64, d_rows, s);
+}
+
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
     if (n == 0) return 0;
-    const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
-    const dim3 grid(grid_for(nblk)), block(BFT_BLOCK);
-    const size_t lds = (size_t)BFT_BLOCK * h->B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         HIPCK(hipEventCreate(&e0));
@@ -709,12 +785,11 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         HIPCK(hipEventRecord(e0, s));
     }
     switch (h->W) {
-    case 1: hipLaunchKernelGGL(k_query<1>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
-    case 2: hipLaunchKernelGGL(k_query<2>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
-    case 3: hipLaunchKernelGGL(k_query<3>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
-    default: hipLaunchKernelGGL(k_query<4>, grid, block, lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows); break;
+    case 1: CK(launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s)); break;
+    case 2: CK(launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s)); break;
+    case 3: CK(launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s)); break;
+    default: CK(launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s)); break;
     }
-    HIPCK(hipGetLastError());
     if (h->timing) {
         HIPCK(hipEventRecord(e1, s));
         h->pending_ev.push_back({e0, e1});
@@ -832,6 +907,24 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // ------------------------------------------------------------------------------------------------
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
+extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
+    if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
+    const std::string nm(name);
+    if (nm == "query_block") {
+        if (value != 256 && value != 512 && value != 1024) return fail(BFT_GPU_E_ARG, "query_block must be 256, 512 or 1024");
+        h->opt_block = (int)value;
+    } else if (nm == "query_grid_mult") {
+        if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
+        h->opt_grid_mult = (int)value;
+    } else if (nm == "debug_stop") {
+        h->im.debug_stop = (uint32_t)value;  // perf probing only: truncates the walk, results are wrong
+    } else if (nm == "timing") {
+        h->timing = value != 0;
+    } else
+        return fail(BFT_GPU_E_ARG, "unknown option");
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out) {
     if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     h->info[0] = h->k;

@@ -72,7 +72,7 @@ extern "C" void* bft_hosttest_build(const uint8_t* kmers, uint64_t n, int k, int
     im.k = k; im.L = t->L; im.W = W; im.nb_genomes = 1; im.n_kmers = nk;
     im.hashmod = t->hashmod.data();
     im.nodes = t->idx.nodes.data(); im.bfT = t->idx.bfT.data(); im.ccs = t->idx.ccs.data();
-    im.f2w = t->idx.f2w.data(); im.clus = t->idx.clus.data(); im.f3 = t->idx.f3.data(); im.child = t->idx.child.data();
+    im.f2w = t->idx.f2w.data(); im.clus = t->idx.clus.data(); im.child = t->idx.child.data();
     im.tk = t->tk.data(); im.tcol = t->tcol.data(); im.uck = t->idx.uck.data(); im.ucrow = t->idx.ucrow.data();
     im.cs_off = t->cs_off.data(); im.cs_ids = t->cs_ids.data();
     return t;
@@ -85,7 +85,7 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
     uint64_t cnt = 0;
     memset(bits, 0, (nq + 7) / 8);
     for (uint64_t i = 0; i < nq; i++) {
-        BftHit h = bft_walk<W>(t->im, &tq[i * W]);
+        BftHit h = bft_walk<W>(t->im, BftRootGlobal(t->im), t->im.nodes[0], &tq[i * W]);
         if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
         if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
     }

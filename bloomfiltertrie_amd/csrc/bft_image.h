@@ -17,8 +17,12 @@
 //    two loads, an AND and a count-trailing-zeros instead of 2 byte loads per CC.
 //  * filter2 is stored 48 bits + 16-bit running rank per u64: bit test and rank
 //    (src/presenceNode.c:1619-1636, SkipFilter2) are one load + one popcount.
-//  * extra_filter3 select (src/presenceNode.c:1648-1688, SkipFilter3) is a u16 cluster-start table.
-//  * children_type counting (include/CC.h:471-550) is a per-prefix u64 {count:8 | row-or-node:40}.
+//  * filter3 (the p_v of each prefix, src/presenceNode.c:1399-1410,1472-1489) and children_type counting
+//    (include/CC.h:471-550) are fused into ONE u64 "prefix entry" {p_v:8 | count:8 | row-or-node:40}.
+//  * extra_filter3 select + cluster length (src/presenceNode.c:1648-1688, SkipFilter3) is a u64 table
+//    indexed by the filter2 rank: a cluster of one prefix (the common case) holds that prefix entry
+//    inline; a longer cluster holds {bit63 | length:16 | start:32} into the CC's run of `child[]`,
+//    where its entries are binary-searched on p_v.
 #pragma once
 #include <stdint.h>
 
@@ -37,32 +41,32 @@ struct BftNode {          // 16 B
     uint8_t bf_wb;        // bytes per Bloom bit position: 1, 2, 4 or 8*ceil(ncc/64)
 };
 
-struct BftCC {            // 32 B
+struct BftCC {            // 16 B: one dwordx4 load
     uint32_t f2_off;      // into f2w[] (u64 units)
-    uint32_t clus_off;    // into clus[] (u16 units); nclus+1 entries
-    uint32_t f3_off;      // into f3[] (bytes)
-    uint32_t child_off;   // into child[] (u64 units)
+    uint32_t clus_off;    // into clus[] (u64 units); one entry per cluster (= per set filter2 bit)
+    uint32_t child_off;   // into child[] (u64 units); prefix entries of the multi-prefix clusters
     uint16_t nb_elem;     // prefixes in this CC (include/CC.h:36)
     uint8_t s;            // length of p_v in bits: 8, or 4 once nb_elem >= 3584 (src/insertNode.c:134-135)
     uint8_t pad0;
-    uint32_t nclus;
-    uint32_t pad1, pad2;
 };
 
 #define BFT_CHILD_IDX_MASK 0xFFFFFFFFFFULL
 #define BFT_CHILD_CNT_SHIFT 40
+#define BFT_CHILD_PV_SHIFT 48
+#define BFT_CLUS_MULTI (1ull << 63)
+#define BFT_CLUS_LEN_SHIFT 32
 
 struct BftImage {
     int k, L, W;
     uint32_t nb_genomes;
+    uint32_t debug_stop;      // perf probing only (tools/perf_probe.py): 0 = full walk; results are wrong when != 0
     uint64_t n_kmers;
     const uint32_t* hashmod;  // [16384] (hash_v[2i] % 1504) | (hash_v[2i+1] % 1504) << 16
     const BftNode* nodes;
     const uint8_t* bfT;
     const BftCC* ccs;
     const uint64_t* f2w;
-    const uint16_t* clus;
-    const uint8_t* f3;
+    const uint64_t* clus;
     const uint64_t* child;
     const uint64_t* tk;       // [n_kmers * W] sorted T-form table
     const uint32_t* tcol;     // [n_kmers] colour-set id per row

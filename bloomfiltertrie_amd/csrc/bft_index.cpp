@@ -137,7 +137,7 @@ struct Builder {
         nd.cc_first = (uint32_t)o.ccs.size();
         o.ccs.resize(o.ccs.size() + ncc);
 
-        struct Pending { size_t child_slot; uint64_t s, e; };
+        struct Pending { bool in_clus; size_t slot; uint64_t s, e; };
         std::vector<Pending> pending;
 
         for (int c = 0; c < ncc; c++) {
@@ -154,38 +154,44 @@ struct Builder {
             const size_t nwords = ((size_t(1) << p) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
             cc.f2_off = (uint32_t)o.f2w.size();
             cc.clus_off = (uint32_t)o.clus.size();
-            cc.f3_off = (uint32_t)o.f3.size();
             cc.child_off = (uint32_t)o.child.size();
-            if (o.f2w.size() + nwords > 0xFFFFFFFFull || o.clus.size() + ne + 1 > 0xFFFFFFFFull ||
-                o.f3.size() + ne > 0xFFFFFFFFull || o.child.size() + ne > 0xFFFFFFFFull) {
+            if (o.f2w.size() + nwords > 0xFFFFFFFFull || o.clus.size() + ne > 0xFFFFFFFFull ||
+                o.child.size() + ne > 0xFFFFFFFFull) {
                 o.error = "index array offset overflow (u32)";
                 return id;
             }
             o.f2w.resize(o.f2w.size() + nwords, 0);
-            o.f3.resize(o.f3.size() + (cc.s == 8 ? ne : (ne + 1) / 2), 0);
-            o.child.resize(o.child.size() + ne, 0);
             uint64_t* f2 = &o.f2w[cc.f2_off];
-            uint8_t* f3 = &o.f3[cc.f3_off];
-            uint32_t prev_pu = 0xFFFFFFFFu, nclus = 0;
-            for (size_t j = 0; j < ne; j++) {
-                const Pref& pf = prefs[pl[j]];
-                const uint32_t pu = pf.r >> cc.s, pv = pf.r & ((1u << cc.s) - 1u);
-                if (pu != prev_pu) {
-                    f2[pu / BFT_F2_BITS_PER_WORD] |= 1ull << (pu % BFT_F2_BITS_PER_WORD);
-                    o.clus.push_back((uint16_t)j);
-                    nclus++;
-                    prev_pu = pu;
+            // clusters = runs of equal p_u; a run of one prefix is stored inline in clus[]
+            for (size_t j = 0; j < ne;) {
+                const uint32_t pu = prefs[pl[j]].r >> cc.s;
+                size_t j2 = j;
+                while (j2 + 1 < ne && (prefs[pl[j2 + 1]].r >> cc.s) == pu) j2++;
+                const size_t len = j2 - j + 1;
+                f2[pu / BFT_F2_BITS_PER_WORD] |= 1ull << (pu % BFT_F2_BITS_PER_WORD);
+                const size_t clus_slot = o.clus.size();
+                if (len == 1) o.clus.push_back(0);
+                else o.clus.push_back(BFT_CLUS_MULTI | ((uint64_t)len << BFT_CLUS_LEN_SHIFT) | (uint64_t)(o.child.size() - cc.child_off));
+                for (size_t q = j; q <= j2; q++) {
+                    const Pref& pf = prefs[pl[q]];
+                    const uint32_t pv = pf.r & ((1u << cc.s) - 1u);
+                    const uint64_t cnt = pf.e - pf.s;
+                    const uint64_t pvf = (uint64_t)pv << BFT_CHILD_PV_SHIFT;
+                    uint64_t ent;
+                    bool pend = false;
+                    if (d == L - 1) ent = pvf | (1ull << BFT_CHILD_CNT_SHIFT) | pf.s;  // leaf: one annotation per prefix
+                    else if (cnt <= BFT_NB_KMERS_PER_UC) ent = pvf | (cnt << BFT_CHILD_CNT_SHIFT) | pf.s;
+                    else { ent = pvf; pend = true; }  // > 255 suffixes: child Node, id patched in below
+                    if (len == 1) {
+                        o.clus[clus_slot] = ent;
+                        if (pend) pending.push_back(Pending{true, clus_slot, pf.s, pf.e});
+                    } else {
+                        if (pend) pending.push_back(Pending{false, o.child.size(), pf.s, pf.e});
+                        o.child.push_back(ent);
+                    }
                 }
-                if (cc.s == 8) f3[j] = (uint8_t)pv;
-                else f3[j >> 1] |= (uint8_t)(pv << ((j & 1) * 4));
-                const uint64_t cnt = pf.e - pf.s;
-                const size_t slot = cc.child_off + j;
-                if (d == L - 1) o.child[slot] = (1ull << BFT_CHILD_CNT_SHIFT) | pf.s;  // leaf: one annotation per prefix
-                else if (cnt <= BFT_NB_KMERS_PER_UC) o.child[slot] = (cnt << BFT_CHILD_CNT_SHIFT) | pf.s;
-                else pending.push_back(Pending{slot, pf.s, pf.e});  // > 255 suffixes: child Node
+                j = j2 + 1;
             }
-            o.clus.push_back((uint16_t)ne);  // sentinel (ne <= 65535)
-            cc.nclus = nclus;
             uint32_t rank = 0;
             for (size_t w = 0; w < nwords; w++) {
                 uint32_t pc = (uint32_t)__builtin_popcountll(f2[w]);
@@ -199,7 +205,7 @@ struct Builder {
         for (const Pending& pe : pending) {
             uint32_t child = build_node(pe.s, pe.e, d + 1);
             if (!o.error.empty()) return id;
-            o.child[pe.child_slot] = (uint64_t)child;  // count field 0 => child Node
+            (pe.in_clus ? o.clus[pe.slot] : o.child[pe.slot]) |= (uint64_t)child;  // count field 0 => child Node
             o.n_child_nodes++;
         }
         return id;

@@ -21,8 +21,7 @@ struct BftHostIndex {
     std::vector<uint8_t> bfT;
     std::vector<BftCC> ccs;
     std::vector<uint64_t> f2w;
-    std::vector<uint16_t> clus;
-    std::vector<uint8_t> f3;
+    std::vector<uint64_t> clus;
     std::vector<uint64_t> child;
     std::vector<uint64_t> uck;
     std::vector<uint32_t> ucrow;

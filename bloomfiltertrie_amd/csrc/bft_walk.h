@@ -39,6 +39,34 @@ BFT_HD uint32_t bft_unrot_prefix(uint32_t r) {
     return raw;
 }
 
+// 18 bits at bit offset `off` of a little-endian multiword integer (register arrays are indexed
+// through unrolled selects: a dynamic index would push them to scratch memory on the GPU).
+template <int W>
+BFT_HD uint32_t bft_get18_le(const uint64_t* le, int off) {
+    const int wi = off >> 6, sh = off & 63;
+    if (W == 1) return (uint32_t)(le[0] >> sh) & 0x3FFFFu;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        if (w == wi) lo = le[w];
+        if (w == wi + 1) hi = le[w];
+    }
+    uint64_t v = lo >> sh;
+    if (sh > 46) v |= hi << (64 - sh);
+    return (uint32_t)v & 0x3FFFFu;
+}
+template <int W>
+BFT_HD void bft_or18_le(uint64_t* le, int off, uint64_t r) {
+    const int wi = off >> 6, sh = off & 63;
+    if (W == 1) { le[0] |= r << sh; return; }
+    const uint64_t lo = r << sh, hi = sh > 46 ? r >> (64 - sh) : 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        if (w == wi) le[w] |= lo;
+        if (w == wi + 1) le[w] |= hi;
+    }
+}
+
 // X (W little-endian u64 words of the packed k-mer) -> T-form (W words, word 0 most significant).
 template <int W>
 BFT_HD void bft_tform_from_x(const uint64_t* x, int L, uint64_t* t) {
@@ -46,13 +74,8 @@ BFT_HD void bft_tform_from_x(const uint64_t* x, int L, uint64_t* t) {
 #pragma unroll
     for (int w = 0; w < W; w++) tl[w] = 0;
     for (int d = 0; d < L; d++) {
-        int o = 18 * d, wi = o >> 6, sh = o & 63;
-        uint64_t v = x[wi] >> sh;
-        if (sh > 46 && wi + 1 < W) v |= x[wi + 1] << (64 - sh);
-        uint64_t r = bft_rot_prefix((uint32_t)v & 0x3FFFFu);
-        int oo = 18 * (L - 1 - d), wo = oo >> 6, so = oo & 63;
-        tl[wo] |= r << so;
-        if (so > 46 && wo + 1 < W) tl[wo + 1] |= r >> (64 - so);
+        const uint64_t r = bft_rot_prefix(bft_get18_le<W>(x, 18 * d));
+        bft_or18_le<W>(tl, 18 * (L - 1 - d), r);
     }
 #pragma unroll
     for (int w = 0; w < W; w++) t[w] = tl[W - 1 - w];
@@ -65,23 +88,18 @@ BFT_HD void bft_x_from_tform(const uint64_t* t, int L, uint64_t* x) {
 #pragma unroll
     for (int w = 0; w < W; w++) { tl[w] = t[W - 1 - w]; x[w] = 0; }
     for (int d = 0; d < L; d++) {
-        int oo = 18 * (L - 1 - d), wo = oo >> 6, so = oo & 63;
-        uint64_t v = tl[wo] >> so;
-        if (so > 46 && wo + 1 < W) v |= tl[wo + 1] << (64 - so);
-        uint64_t raw = bft_unrot_prefix((uint32_t)v & 0x3FFFFu);
-        int o = 18 * d, wi = o >> 6, sh = o & 63;
-        x[wi] |= raw << sh;
-        if (sh > 46 && wi + 1 < W) x[wi + 1] |= raw >> (64 - sh);
+        const uint64_t raw = bft_unrot_prefix(bft_get18_le<W>(tl, 18 * (L - 1 - d)));
+        bft_or18_le<W>(x, 18 * d, raw);
     }
 }
 
 // rotated prefix of level d (0 = root) out of a T-form k-mer
 template <int W>
 BFT_HD uint32_t bft_digit(const uint64_t* t, int L, int d) {
-    int oo = 18 * (L - 1 - d), wo = oo >> 6, so = oo & 63;
-    uint64_t v = t[W - 1 - wo] >> so;
-    if (so > 46 && wo + 1 < W) v |= t[W - 2 - wo] << (64 - so);
-    return (uint32_t)v & 0x3FFFFu;
+    uint64_t tl[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) tl[w] = t[W - 1 - w];
+    return bft_get18_le<W>(tl, 18 * (L - 1 - d));
 }
 
 template <int W>
@@ -109,23 +127,74 @@ BFT_HD uint32_t bft_rows_lower_bound(const uint64_t* rows, uint32_t n, const uin
     return lo;
 }
 
-// "first CC of the node whose Bloom filter holds both bits" on the bit-sliced block.
-BFT_HD int bft_first_cc(const BftImage& im, const BftNode& nd, uint32_t h1, uint32_t h2) {
-    const uint8_t* blk = im.bfT + (size_t)nd.bf_off * 8;
-    if (nd.bf_wb == 1) {
+// Exact search of t among the n sorted rows of a suffix group, starting from an interpolated guess g
+// (suffix values are close to uniform inside a group, so the guess is a few rows off): probe, gallop
+// towards the target, finish with a binary search in the bracket.  Same result as the reference's
+// binary_search_UC + memcmp (src/UC.c:81-124, src/presenceNode.c:1886-1913), ~1-2 cache lines instead
+// of ~log2(n).  Returns the row index or -1.
+template <int W>
+BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, uint32_t g) {
+    uint64_t r[W];
+    if (g >= n) g = n - 1;
+    uint32_t lo = 0, hi = n;
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = rows[(size_t)g * W + w];
+    int c = bft_cmp<W>(r, t);
+    if (c == 0) return (int)g;
+    uint32_t step = 1;
+    if (c < 0) {
+        lo = g + 1;
+        while (lo < hi) {
+            uint32_t p = lo + step - 1;
+            if (p >= hi) p = hi - 1;
+#pragma unroll
+            for (int w = 0; w < W; w++) r[w] = rows[(size_t)p * W + w];
+            c = bft_cmp<W>(r, t);
+            if (c == 0) return (int)p;
+            if (c < 0) { lo = p + 1; step <<= 1; }
+            else { hi = p; break; }
+        }
+    } else {
+        hi = g;
+        while (lo < hi) {
+            uint32_t p = hi - lo > step ? hi - step : lo;
+#pragma unroll
+            for (int w = 0; w < W; w++) r[w] = rows[(size_t)p * W + w];
+            c = bft_cmp<W>(r, t);
+            if (c == 0) return (int)p;
+            if (c > 0) { hi = p; step <<= 1; }
+            else { lo = p + 1; break; }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+#pragma unroll
+        for (int w = 0; w < W; w++) r[w] = rows[(size_t)mid * W + w];
+        c = bft_cmp<W>(r, t);
+        if (c == 0) return (int)mid;
+        if (c < 0) lo = mid + 1;
+        else hi = mid;
+    }
+    return -1;
+}
+
+// "first CC of the node whose Bloom filter holds both bits" on a bit-sliced block (blk = the node's
+// block, wb = bytes per bit position).
+BFT_HD int bft_first_cc_blk(const uint8_t* blk, uint32_t wb, uint32_t h1, uint32_t h2) {
+    if (wb == 1) {
         uint32_t m = blk[h1] & blk[h2];
         return m ? __builtin_ctz(m) : -1;
-    } else if (nd.bf_wb == 2) {
+    } else if (wb == 2) {
         const uint16_t* b = (const uint16_t*)blk;
         uint32_t m = b[h1] & b[h2];
         return m ? __builtin_ctz(m) : -1;
-    } else if (nd.bf_wb == 4) {
+    } else if (wb == 4) {
         const uint32_t* b = (const uint32_t*)blk;
         uint32_t m = b[h1] & b[h2];
         return m ? __builtin_ctz(m) : -1;
     }
     const uint64_t* b = (const uint64_t*)blk;
-    int nw = nd.bf_wb >> 3;
+    const int nw = (int)(wb >> 3);
     for (int w = 0; w < nw; w++) {
         uint64_t m = b[(size_t)h1 * nw + w] & b[(size_t)h2 * nw + w];
         if (m) return w * 64 + __builtin_ctzll(m);
@@ -133,26 +202,43 @@ BFT_HD int bft_first_cc(const BftImage& im, const BftNode& nd, uint32_t h1, uint
     return -1;
 }
 
+// Where the walk reads the hash table, and the root node's Bloom block and CC headers, from.
+// Host tests and non-staged kernels read the image in global memory; k_query stages them in LDS
+// (BftRootLds in bft_gpu.hip) because every query of a batch goes through them.
+struct BftRootGlobal {
+    const BftImage& im;
+    BFT_HD explicit BftRootGlobal(const BftImage& i) : im(i) {}
+    BFT_HD uint32_t hashmod(uint32_t key) const { return im.hashmod[key]; }
+    BFT_HD int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
+        return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
+    }
+    BFT_HD BftCC root_cc(const BftNode& nd, int c) const { return im.ccs[nd.cc_first + c]; }
+};
+
 struct BftHit {
     int present;
     uint64_t row;  // row of the k-mer in tk (valid when present)
 };
 
-template <int W>
-BFT_HD BftHit bft_walk(const BftImage& im, const uint64_t* t) {
+template <int W, class Root>
+BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t) {
     BftHit hit;
     hit.present = 0;
     hit.row = 0;
     uint32_t node = 0;
     const int L = im.L;
     for (int d = 0; d < L; d++) {
-        const BftNode nd = im.nodes[node];
+        BftNode nd;
+        if (d == 0) nd = root_node;
+        else nd = im.nodes[node];
         const uint32_t r = bft_digit<W>(t, L, d);
         int c = -1;
         if (nd.ncc) {
-            const uint32_t hm = im.hashmod[r >> 4];  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
-            c = bft_first_cc(im, nd, hm & 0xFFFFu, hm >> 16);
+            const uint32_t hm = root.hashmod(r >> 4);  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
+            if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
+            else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
         }
+        if (im.debug_stop == 1) { hit.present = c >= 0; return hit; }
         if (c < 0) {
             // no Bloom-positive CC: the node's UC (src/presenceNode.c:1554-1573)
             if (nd.uc_n) {
@@ -167,40 +253,42 @@ BFT_HD BftHit bft_walk(const BftImage& im, const uint64_t* t) {
             }
             return hit;
         }
-        const BftCC cc = im.ccs[nd.cc_first + c];
+        BftCC cc;
+        if (d == 0) cc = root.root_cc(nd, c);
+        else cc = im.ccs[nd.cc_first + c];
         const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
         const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
         const uint64_t fw = im.f2w[cc.f2_off + wi];
+        if (im.debug_stop == 2) { hit.present = (int)(fw & 1); return hit; }
         if (!((fw >> bi) & 1ull)) return hit;  // filter2 miss => absent (src/presenceNode.c:1546-1548)
         const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
-        uint32_t lo = im.clus[cc.clus_off + clu], hi = im.clus[cc.clus_off + clu + 1];
-        const uint32_t end = hi;
-        const uint8_t* f3 = im.f3 + cc.f3_off;
-        if (cc.s == 8) {  // src/presenceNode.c:1399-1410
-            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (f3[mid] < pv) lo = mid + 1; else hi = mid; }
-            if (lo >= end || f3[lo] != pv) return hit;
-        } else {          // nibble-packed, src/presenceNode.c:1472-1489
+        uint64_t e = im.clus[cc.clus_off + clu];
+        if (im.debug_stop == 3) { hit.present = (int)(e & 1); return hit; }
+        if (e & BFT_CLUS_MULTI) {
+            // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
+            const uint64_t* ch = im.child + cc.child_off;
+            uint32_t lo = (uint32_t)e, hi = lo + (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
+            const uint32_t end = hi;
+            e = 0;
             while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                uint32_t v = (f3[mid >> 1] >> ((mid & 1) * 4)) & 0xFu;
-                if (v < pv) lo = mid + 1; else hi = mid;
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t m = ch[mid];
+                if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
+                else { hi = mid; e = m; }
             }
-            if (lo >= end || (((uint32_t)f3[lo >> 1] >> ((lo & 1) * 4)) & 0xFu) != pv) return hit;
+            if (lo >= end) return hit;
         }
-        const uint64_t ch = im.child[cc.child_off + lo];
-        const uint32_t cnt = (uint32_t)(ch >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
-        const uint64_t idx = ch & BFT_CHILD_IDX_MASK;
+        if (((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return hit;
+        const uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
+        const uint64_t idx = e & BFT_CHILD_IDX_MASK;
+        if (im.debug_stop == 4) { hit.present = (int)(cnt & 1); return hit; }
         if (d == L - 1) { hit.present = 1; hit.row = idx; return hit; }  // leaf: annotation row
         if (cnt == 0) { node = (uint32_t)idx; continue; }                 // child Node (src/presenceNode.c:1867)
-        // suffix group of cnt rows (src/presenceNode.c:1874-1915)
+        // suffix group of cnt rows (src/presenceNode.c:1874-1915): interpolate on the next two prefixes
         const uint64_t* rows = im.tk + idx * W;
-        uint32_t z = bft_rows_lower_bound<W>(rows, cnt, t);
-        if (z < cnt) {
-            uint64_t q[W];
-#pragma unroll
-            for (int w = 0; w < W; w++) q[w] = rows[(size_t)z * W + w];
-            if (bft_cmp<W>(q, t) == 0) { hit.present = 1; hit.row = idx + z; }
-        }
+        const uint64_t next36 = ((uint64_t)bft_digit<W>(t, L, d + 1) << 18) | (d + 2 < L ? bft_digit<W>(t, L, d + 2) : 0u);
+        const int z = bft_rows_find<W>(rows, cnt, t, (uint32_t)((next36 * cnt) >> 36));
+        if (z >= 0) { hit.present = 1; hit.row = idx + (uint32_t)z; }
         return hit;
     }
     return hit;

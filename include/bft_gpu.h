@@ -92,6 +92,10 @@ int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers
  * [12]=image bytes in HBM, [13]=root CCs, [14]=root UC rows, [15]=pending (unbuilt) pairs. */
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 
+/* Tuning knobs: "query_block" (k_query workgroup size: 256, 512 or 1024), "query_grid_mult"
+ * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels). */
+int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
+
 /* HIP-event timing of the query kernels launched through this handle since the last reset:
  * *ms = summed kernel time, *launches = number of launches. */
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Development probe (GPU box): time k_query under the tuning knobs on several workloads, checking results each time.
+
+usage: python tools/perf_probe.py [--queries N] [--workloads cfg2,deep,k63]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def workload(name):
+    from bloomfiltertrie_amd import synth as S
+    if name == "cfg2":
+        k = 27
+        anc = S.random_genome(2_000_000, 1234)
+        gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]
+    elif name == "deep":  # low-entropy: three trie levels are exercised
+        k = 27
+        gk = [S.low_entropy_kmers(6_000_000, k, 600, seed=7, levels=1)]
+    elif name == "deep2":
+        k = 27
+        gk = [S.low_entropy_kmers(6_000_000, k, 40, seed=8, levels=2)]
+    elif name == "k63":
+        k = 63
+        anc = S.random_genome(1_000_000, 4321)
+        gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 2000 + g), k)) for g in range(4)]
+    else:
+        raise SystemExit(name)
+    return k, gk
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=50_000_000)
+    ap.add_argument("--workloads", default="cfg2,deep,deep2,k63")
+    ap.add_argument("--blocks", default="256,512,1024")
+    ap.add_argument("--mults", default="1,2,4")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stops", action="store_true", help="time the walk truncated after each stage (results wrong)")
+    args = ap.parse_args()
+    import torch
+    from bloomfiltertrie_amd import BFT, synth as S
+    sys.path.insert(0, ROOT)
+    from bench import make_queries_on_device
+    dev = torch.device("cuda", 0)
+    for wl in args.workloads.split(","):
+        k, gk = workload(wl)
+        t = BFT(k)
+        t0 = time.time()
+        for g, km in enumerate(gk):
+            t.insert_kmers(km, g)
+        t.build()
+        info = t.info()
+        union = S.distinct(np.concatenate(gk)) if len(gk) > 1 else gk[0]
+        nq = args.queries
+        dq = make_queries_on_device(union, k, nq, 5, dev)
+        dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        nv = 500_000
+        truth = S.member(dq[:nv].cpu().numpy(), union)
+        print(json.dumps({"workload": wl, "k": k, "build_s": round(time.time() - t0, 2), **{x: info[x] for x in ("kmers", "nodes", "ccs", "child_nodes", "uc_rows", "root_ccs", "image_bytes")}}), flush=True)
+        for blk in [int(x) for x in args.blocks.split(",")]:
+            for mult in [int(x) for x in args.mults.split(",")]:
+                t.set_option("query_block", blk)
+                t.set_option("query_grid_mult", mult)
+                dbits.zero_()
+                t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+                torch.cuda.synchronize()
+                ok = bool((S.from_bits(dbits[: (nv + 7) // 8].cpu().numpy(), nv) == truth).all())
+                t.kernel_time(reset=True)
+                for _ in range(args.reps):
+                    t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+                torch.cuda.synchronize()
+                ms, n = t.kernel_time(reset=True)
+                print(json.dumps({"workload": wl, "block": blk, "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
+        if args.stops:
+            t.set_option("query_block", 1024)
+            t.set_option("query_grid_mult", 1)
+            for stop in (1, 2, 3, 4, 0):
+                t.set_option("debug_stop", stop)
+                t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t.kernel_time(reset=True)
+                for _ in range(args.reps):
+                    t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+                torch.cuda.synchronize()
+                ms, n = t.kernel_time(reset=True)
+                print(json.dumps({"workload": wl, "debug_stop": stop, "ms": round(ms / n, 3)}), flush=True)
+        t.close()
+        del dq, dbits
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
