@@ -136,7 +136,14 @@ class BFT:
     def build_time(self):
         out = (C.c_double * 5)()
         _lib.check(self._lib.bft_gpu_build_time(self._h, out, 5))
-        return dict(zip(["gpu_sort_dedupe_ms", "d2h_ms", "color_intern_ms", "assemble_ms", "upload_ms"], list(out)))
+        return dict(zip(["gpu_sort_dedupe_ms", "color_intern_ms", "assemble_ms", "bookkeeping_ms", "unused_ms"], list(out)))
+
+    def debug_array(self, name, dtype=np.uint8):
+        n = C.c_uint64()
+        _lib.check(self._lib.bft_gpu_debug_get_array(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_debug_get_array(self._h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
+        return out.view(dtype)
 
     def extract(self):
         n = C.c_uint64()

@@ -1,0 +1,802 @@
+// bft_assemble.hip -- GPU construction of the BFT containers and of the colour-set dictionary.
+//
+// Bulk counterpart of the reference's per-k-mer insertion work (insertKmer_Node / insertKmer_Node_special
+// src/insertNode.c:38-423; transform2CC / insertSP_CC / transform_Filter2n3 src/CC.c:40-1664; annotation
+// updates src/retrieveAnnotation.c:232-314), level-synchronous over the sorted T-form table:
+//   per depth, for all nodes of that depth at once:
+//     k_prefix_flags/scatter   runs of equal 18-bit digit = the node's prefixes; runs of equal r>>4 = Bloom keys
+//     k_assign_cc              one workgroup per node: CCs are opened while >= 255 k-mers are unassigned; the
+//                              first <= 255 unassigned keys seed the Bloom filter (LDS bitset, atomicOr), every
+//                              unassigned key the filter holds is claimed (first-BF-positive rule)
+//     hipCUB radix sort        prefixes grouped by (node, CC), prefix order kept
+//     k_runs / k_clusters      CC boundaries, filter2 clusters (runs of equal p_u)
+//     k_entries                prefix entries {p_v | count | row-or-child-node}, filter2 bits (atomicOr), child nodes
+//     k_ranks                  running rank into each filter2 word
+//     k_uc_rows, k_bloom_slice node UC rows; bit-sliced Bloom block of each node
+// The arrays are bit-identical to the host restatement bft_index.cpp (tests/test_gpu_build.py).
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "bft_dev.h"
+#include "bft_image.h"
+#include "bft_index.h"
+#include "bft_walk.h"
+
+#define ABLK 256
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+struct Scan {
+    DevBuf tmp;
+    hipStream_t s;
+    explicit Scan(hipStream_t st) : s(st) {}
+    // out = exclusive sum of in (u32), returns total in *total
+    int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {
+        if (n == 0) { if (total) *total = 0; return 0; }
+        size_t tb = 0;
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
+        if (tb > tmp.bytes) CK(tmp.alloc(tb));
+        tb = tmp.bytes;
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
+        if (total) {
+            uint32_t a = 0, b = 0;
+            HIPCK(hipMemcpyAsync(&a, in + n - 1, 4, hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(&b, out + n - 1, 4, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            *total = (uint64_t)a + b;
+        }
+        return 0;
+    }
+};
+
+__device__ __forceinline__ uint32_t find_node(const uint32_t* __restrict__ node_off, uint32_t M, uint32_t j) {
+    uint32_t lo = 0, hi = M;  // last m with node_off[m] <= j
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (node_off[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_sizes(const uint32_t* lo, const uint32_t* hi, uint32_t* sz, uint32_t M) {
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) sz[m] = hi[m] - lo[m];
+}
+
+// head[j] = row j starts a new prefix of its node; khead[j] = ... a new Bloom key
+template <int W>
+__global__ void k_prefix_flags(const uint64_t* __restrict__ tk, int L, int d, const uint32_t* __restrict__ nd_lo,
+                               const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, uint32_t* __restrict__ head,
+                               uint32_t* __restrict__ khead) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < A; j += gridDim.x * blockDim.x) {
+        const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
+        const uint32_t row = nd_lo[m] + (j - node_off[m]);
+        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, L, d);
+        uint32_t h = 1, kh = 1;
+        if (row != nd_lo[m]) {
+            const uint32_t rp = bft_digit<W>(tk + (size_t)(row - 1) * W, L, d);
+            h = r != rp;
+            kh = (r >> 4) != (rp >> 4);
+        }
+        head[j] = h;
+        khead[j] = kh;
+    }
+}
+
+template <int W>
+__global__ void k_prefix_scatter(const uint64_t* __restrict__ tk, int L, int d, const uint32_t* __restrict__ nd_lo,
+                                 const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, const uint32_t* __restrict__ head,
+                                 const uint32_t* __restrict__ khead, const uint32_t* __restrict__ ppos, const uint32_t* __restrict__ kpos,
+                                 uint32_t* __restrict__ pref_r, uint32_t* __restrict__ pref_row, uint32_t* __restrict__ pref_node,
+                                 uint32_t* __restrict__ pref_key, uint32_t* __restrict__ key_val, uint32_t* __restrict__ key_row,
+                                 uint32_t* __restrict__ key_node, uint32_t* __restrict__ node_kb) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < A; j += gridDim.x * blockDim.x) {
+        if (!head[j]) continue;
+        const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
+        const uint32_t row = nd_lo[m] + (j - node_off[m]);
+        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, L, d);
+        const uint32_t p = ppos[j];
+        const uint32_t kk = kpos[j] + khead[j] - 1;
+        pref_r[p] = r;
+        pref_row[p] = row;
+        pref_node[p] = m;
+        pref_key[p] = kk;
+        if (khead[j]) {
+            key_val[kk] = r >> 4;
+            key_row[kk] = row;
+            key_node[kk] = m;
+            if (row == nd_lo[m]) node_kb[m] = kk;
+        }
+    }
+}
+
+// count of rows under each prefix / key: next start in the same node, else the node's end
+__global__ void k_counts(const uint32_t* __restrict__ start, const uint32_t* __restrict__ node, const uint32_t* __restrict__ nd_hi, uint32_t n,
+                         uint32_t* __restrict__ cnt) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t m = node[i];
+        const uint32_t end = (i + 1 < n && node[i + 1] == m) ? start[i + 1] : nd_hi[m];
+        cnt[i] = end - start[i];
+    }
+}
+
+// One workgroup per node.  cc_bits == nullptr: counting pass (node_ncc only).
+__global__ __launch_bounds__(ABLK) void k_assign_cc(const uint32_t* __restrict__ key_val, const uint32_t* __restrict__ key_cnt,
+                                                    const uint32_t* __restrict__ node_kb, const uint32_t* __restrict__ nd_lo,
+                                                    const uint32_t* __restrict__ nd_hi, const uint32_t* __restrict__ hashmod,
+                                                    int32_t* __restrict__ key_cc, uint32_t* __restrict__ node_ncc,
+                                                    const uint32_t* __restrict__ node_ccb, uint32_t* __restrict__ cc_bits, uint32_t M) {
+    __shared__ uint32_t bits[48];
+    __shared__ uint32_t wsum[ABLK / 64];
+    __shared__ uint32_t s_total;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t m = blockIdx.x; m < M; m += gridDim.x) {
+        const uint32_t kb = node_kb[m], ke = node_kb[m + 1];
+        uint32_t U = nd_hi[m] - nd_lo[m];
+        uint32_t ncc = 0;
+        while (U >= BFT_NB_KMERS_PER_UC) {
+            if (tid < 48) bits[tid] = 0;
+            __syncthreads();
+            // seeds: the first <= 255 unassigned keys, in prefix order
+            uint32_t running = 0;
+            for (uint32_t base = kb; base < ke && running < BFT_NB_KMERS_PER_UC; base += ABLK) {
+                const uint32_t idx = base + tid;
+                const bool un = idx < ke && key_cc[idx] < 0;
+                const uint64_t bal = __ballot(un);
+                const uint32_t inwave = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wsum[wave] = (uint32_t)__builtin_popcountll(bal);
+                __syncthreads();
+                uint32_t before = 0, total = 0;
+                for (uint32_t w = 0; w < ABLK / 64; w++) {
+                    if (w < wave) before += wsum[w];
+                    total += wsum[w];
+                }
+                const uint32_t rank = running + before + inwave;
+                if (un && rank < BFT_NB_KMERS_PER_UC) {
+                    const uint32_t hm = hashmod[key_val[idx]];
+                    const uint32_t h1 = hm & 0xFFFFu, h2 = hm >> 16;
+                    atomicOr(&bits[h1 >> 5], 1u << (h1 & 31));
+                    atomicOr(&bits[h2 >> 5], 1u << (h2 & 31));
+                }
+                running += total;
+                __syncthreads();
+            }
+            __syncthreads();
+            // claim every unassigned key the Bloom filter holds
+            uint32_t local = 0;
+            for (uint32_t idx = kb + tid; idx < ke; idx += ABLK) {
+                if (key_cc[idx] >= 0) continue;
+                const uint32_t hm = hashmod[key_val[idx]];
+                const uint32_t h1 = hm & 0xFFFFu, h2 = hm >> 16;
+                if (((bits[h1 >> 5] >> (h1 & 31)) & 1u) && ((bits[h2 >> 5] >> (h2 & 31)) & 1u)) {
+                    key_cc[idx] = (int32_t)ncc;
+                    local += key_cnt[idx];
+                }
+            }
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+            if (local) atomicAdd(&s_total, local);
+            __syncthreads();
+            U -= s_total;
+            if (cc_bits && tid < 48) cc_bits[(size_t)(node_ccb[m] + ncc) * 48 + tid] = bits[tid];
+            ncc++;
+            __syncthreads();
+        }
+        if (tid == 0) node_ncc[m] = ncc;
+        __syncthreads();
+    }
+}
+
+__global__ void k_sort_keys(const uint32_t* __restrict__ pref_node, const uint32_t* __restrict__ pref_key, const int32_t* __restrict__ key_cc,
+                            uint32_t P, uint64_t* __restrict__ skey, uint32_t* __restrict__ iota) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        skey[p] = ((uint64_t)pref_node[p] << 17) | (uint32_t)(key_cc[pref_key[p]] + 1);
+        iota[p] = p;
+    }
+}
+
+// run boundaries of the sorted (node, cc+1) keys: real CCs -> cc_qb/cc_qe, UC pseudo-CC -> uc_qb/uc_qe
+__global__ void k_runs(const uint64_t* __restrict__ skey, uint32_t P, const uint32_t* __restrict__ node_ccb, uint32_t* __restrict__ cc_qb,
+                       uint32_t* __restrict__ cc_qe, uint32_t* __restrict__ uc_qb, uint32_t* __restrict__ uc_qe) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
+        const uint64_t k = skey[q];
+        const uint32_t m = (uint32_t)(k >> 17), c1 = (uint32_t)(k & 0x1FFFFu);
+        const bool first = q == 0 || skey[q - 1] != k, last = q + 1 == P || skey[q + 1] != k;
+        if (c1 == 0) {
+            if (first) uc_qb[m] = q;
+            if (last) uc_qe[m] = q + 1;
+        } else {
+            const uint32_t ci = node_ccb[m] + c1 - 1;
+            if (first) cc_qb[ci] = q;
+            if (last) cc_qe[ci] = q + 1;
+        }
+    }
+}
+
+__global__ void k_cc_meta(const uint32_t* __restrict__ cc_qb, const uint32_t* __restrict__ cc_qe, uint32_t C, uint32_t* __restrict__ cc_nb,
+                          uint32_t* __restrict__ cc_s, uint32_t* __restrict__ cc_nwords) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const uint32_t nb = cc_qe[c] - cc_qb[c];
+        const uint32_t s = nb >= BFT_TRESH_SUF_PREF ? 4u : 8u;
+        cc_nb[c] = nb;
+        cc_s[c] = s;
+        cc_nwords[c] = ((1u << (18 - s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+    }
+}
+
+// per sorted prefix q: cluster-head flag, child-node flag, UC row count
+__global__ void k_cluster_flags(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ pref_r,
+                                const uint32_t* __restrict__ pref_cnt, uint32_t P, const uint32_t* __restrict__ node_ccb,
+                                const uint32_t* __restrict__ cc_qb, const uint32_t* __restrict__ cc_s, int last_level,
+                                uint32_t* __restrict__ chead, uint32_t* __restrict__ pend, uint32_t* __restrict__ ucn) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
+        const uint64_t k = skey[q];
+        const uint32_t m = (uint32_t)(k >> 17), c1 = (uint32_t)(k & 0x1FFFFu);
+        const uint32_t p = sp[q];
+        if (c1 == 0) {
+            chead[q] = 0;
+            pend[q] = 0;
+            ucn[q] = pref_cnt[p];
+            continue;
+        }
+        const uint32_t ci = node_ccb[m] + c1 - 1, s = cc_s[ci];
+        uint32_t h = 1;
+        if (q != cc_qb[ci]) h = (pref_r[p] >> s) != (pref_r[sp[q - 1]] >> s);
+        chead[q] = h;
+        pend[q] = (!last_level && pref_cnt[p] > BFT_NB_KMERS_PER_UC) ? 1u : 0u;
+        ucn[q] = 0;
+    }
+}
+
+__global__ void k_cluster_scatter(const uint32_t* __restrict__ chead, const uint32_t* __restrict__ cidx, uint32_t P, uint32_t* __restrict__ clus_q) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x)
+        if (chead[q]) clus_q[cidx[q]] = q;
+}
+
+// cluster length and its number of entries in child[] (0 for a single-prefix cluster)
+__global__ void k_cluster_len(const uint32_t* __restrict__ clus_q, uint32_t Q, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ node_ccb,
+                              const uint32_t* __restrict__ cc_qe, uint32_t* __restrict__ clus_len, uint32_t* __restrict__ multi) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < Q; c += gridDim.x * blockDim.x) {
+        const uint32_t q = clus_q[c];
+        const uint64_t k = skey[q];
+        const uint32_t ci = node_ccb[(uint32_t)(k >> 17)] + (uint32_t)(k & 0x1FFFFu) - 1;
+        uint32_t end = cc_qe[ci];
+        if (c + 1 < Q && clus_q[c + 1] < end) end = clus_q[c + 1];
+        const uint32_t len = end - q;
+        clus_len[c] = len;
+        multi[c] = len > 1 ? len : 0;
+    }
+}
+
+__global__ void k_cc_headers(const uint32_t* __restrict__ cc_qb, const uint32_t* __restrict__ cc_nb, const uint32_t* __restrict__ cc_s,
+                             const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ cpos, uint32_t C,
+                             uint32_t f2_base, uint32_t clus_base, uint32_t child_base, BftCC* __restrict__ out) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        BftCC cc;
+        const uint32_t firstc = cidx[cc_qb[c]];
+        cc.f2_off = f2_base + cc_f2[c];
+        cc.clus_off = clus_base + firstc;
+        cc.child_off = child_base + cpos[firstc];
+        cc.nb_elem = (uint16_t)cc_nb[c];
+        cc.s = (uint8_t)cc_s[c];
+        cc.pad0 = 0;
+        out[c] = cc;
+    }
+}
+
+// prefix entries, filter2 bits, child nodes of the next depth
+__global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ pref_r,
+                          const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, uint32_t P,
+                          const uint32_t* __restrict__ node_ccb, const uint32_t* __restrict__ cc_qb, const uint32_t* __restrict__ cc_s,
+                          const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ chead, const uint32_t* __restrict__ cidx,
+                          const uint32_t* __restrict__ clus_q, const uint32_t* __restrict__ clus_len, const uint32_t* __restrict__ cpos,
+                          const uint32_t* __restrict__ pend, const uint32_t* __restrict__ nrank, int last_level, uint32_t next_node_base,
+                          uint64_t* __restrict__ f2w, uint64_t* __restrict__ clus, uint64_t* __restrict__ child, uint32_t* __restrict__ next_lo,
+                          uint32_t* __restrict__ next_hi) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
+        const uint64_t k = skey[q];
+        const uint32_t c1 = (uint32_t)(k & 0x1FFFFu);
+        if (c1 == 0) continue;
+        const uint32_t ci = node_ccb[(uint32_t)(k >> 17)] + c1 - 1, s = cc_s[ci];
+        const uint32_t p = sp[q], r = pref_r[p], cnt = pref_cnt[p], row = pref_row[p];
+        const uint32_t pu = r >> s, pv = r & ((1u << s) - 1u);
+        uint64_t ent = (uint64_t)pv << BFT_CHILD_PV_SHIFT;
+        if (last_level) ent |= (1ull << BFT_CHILD_CNT_SHIFT) | row;
+        else if (!pend[q]) ent |= ((uint64_t)cnt << BFT_CHILD_CNT_SHIFT) | row;
+        else {
+            const uint32_t nn = nrank[q];
+            ent |= (uint64_t)(next_node_base + nn);
+            next_lo[nn] = row;
+            next_hi[nn] = row + cnt;
+        }
+        const uint32_t c = cidx[q] + chead[q] - 1;  // cluster of q
+        const uint32_t len = clus_len[c];
+        const uint32_t firstc = cidx[cc_qb[ci]];
+        if (len == 1) clus[c] = ent;
+        else {
+            child[cpos[c] + (q - clus_q[c])] = ent;
+            if (chead[q]) clus[c] = BFT_CLUS_MULTI | ((uint64_t)len << BFT_CLUS_LEN_SHIFT) | (uint64_t)(cpos[c] - cpos[firstc]);
+        }
+        if (chead[q]) atomicOr((unsigned long long*)&f2w[cc_f2[ci] + pu / BFT_F2_BITS_PER_WORD], 1ull << (pu % BFT_F2_BITS_PER_WORD));
+    }
+}
+
+__global__ void k_ranks(const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ cc_nwords, uint32_t C, uint64_t* __restrict__ f2w) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        uint64_t* f2 = f2w + cc_f2[c];
+        uint32_t rank = 0;
+        for (uint32_t w = 0; w < cc_nwords[c]; w++) {
+            const uint32_t pc = (uint32_t)__builtin_popcountll(f2[w]);
+            f2[w] |= (uint64_t)rank << 48;
+            rank += pc;
+        }
+    }
+}
+
+__global__ void k_uc_rows(const uint64_t* __restrict__ tk, int W, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp,
+                          const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, const uint32_t* __restrict__ ucpos, uint32_t P,
+                          uint32_t uc_base_unused, uint64_t* __restrict__ uck, uint32_t* __restrict__ ucrow) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
+        if ((uint32_t)(skey[q] & 0x1FFFFu) != 0) continue;
+        const uint32_t p = sp[q], row0 = pref_row[p], cnt = pref_cnt[p], o = ucpos[q];
+        for (uint32_t i = 0; i < cnt; i++) {
+            for (int w = 0; w < W; w++) uck[(size_t)(o + i) * W + w] = tk[(size_t)(row0 + i) * W + w];
+            ucrow[o + i] = row0 + i;
+        }
+    }
+}
+
+__global__ void k_node_meta(const uint32_t* __restrict__ node_ncc, const uint32_t* __restrict__ uc_qb, const uint32_t* __restrict__ uc_qe,
+                            const uint32_t* __restrict__ ucpos, const uint32_t* __restrict__ ucn, uint32_t M, uint32_t* __restrict__ node_ucn,
+                            uint32_t* __restrict__ node_bf8) {
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        uint32_t n = 0;
+        if (uc_qe[m] > uc_qb[m]) n = ucpos[uc_qe[m] - 1] + ucn[uc_qe[m] - 1] - ucpos[uc_qb[m]];
+        node_ucn[m] = n;
+        const uint32_t ncc = node_ncc[m];
+        const uint32_t wb = ncc == 0 ? 0 : ncc <= 8 ? 1 : ncc <= 16 ? 2 : ncc <= 32 ? 4 : 8 * ((ncc + 63) / 64);
+        node_bf8[m] = (BFT_MODULO_HASH * wb) / 8;
+    }
+}
+
+__global__ void k_node_records(const uint32_t* __restrict__ node_ncc, const uint32_t* __restrict__ node_ccb, const uint32_t* __restrict__ node_ucn,
+                               const uint32_t* __restrict__ node_ucoff, const uint32_t* __restrict__ node_bfoff, uint32_t M, uint32_t cc_base,
+                               uint32_t uc_base, uint32_t bf_base8, BftNode* __restrict__ out) {
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        BftNode nd;
+        const uint32_t ncc = node_ncc[m];
+        const uint32_t wb = ncc == 0 ? 0 : ncc <= 8 ? 1 : ncc <= 16 ? 2 : ncc <= 32 ? 4 : 8 * ((ncc + 63) / 64);
+        nd.cc_first = cc_base + node_ccb[m];
+        nd.bf_off = ncc ? bf_base8 + node_bfoff[m] : 0;
+        nd.uc_first = uc_base + node_ucoff[m];
+        nd.ncc = (uint16_t)ncc;
+        nd.uc_n = (uint8_t)node_ucn[m];
+        nd.bf_wb = (uint8_t)wb;
+        out[m] = nd;
+    }
+}
+
+// one workgroup per node: transpose the CC bitsets into the bit-sliced block
+__global__ __launch_bounds__(ABLK) void k_bloom_slice(const uint32_t* __restrict__ node_ncc, const uint32_t* __restrict__ node_ccb,
+                                                      const uint32_t* __restrict__ node_bfoff, const uint32_t* __restrict__ cc_bits, uint32_t M,
+                                                      uint8_t* __restrict__ bfT) {
+    for (uint32_t m = blockIdx.x; m < M; m += gridDim.x) {
+        const uint32_t ncc = node_ncc[m];
+        if (ncc == 0) continue;
+        const uint32_t wb = ncc <= 8 ? 1 : ncc <= 16 ? 2 : ncc <= 32 ? 4 : 8 * ((ncc + 63) / 64);
+        uint8_t* blk = bfT + (size_t)node_bfoff[m] * 8;
+        const uint32_t* bits = cc_bits + (size_t)node_ccb[m] * 48;
+        for (uint32_t h = threadIdx.x; h < BFT_MODULO_HASH; h += ABLK) {
+            for (uint32_t b = 0; b < wb; b++) {
+                uint32_t v = 0;
+                for (uint32_t c = b * 8; c < ncc && c < b * 8 + 8; c++) v |= ((bits[(size_t)c * 48 + (h >> 5)] >> (h & 31)) & 1u) << (c & 7);
+                blk[(size_t)h * wb + b] = (uint8_t)v;
+            }
+        }
+    }
+}
+
+struct Seg {  // per-depth output segments, concatenated at the end
+    DevBuf nodes, bfT, ccs, f2w, clus, child, uck, ucrow;
+    uint64_t n_nodes = 0, n_bf8 = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_uc = 0;
+};
+
+template <int W>
+int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out) {
+    const int L = k / 9;
+    Scan scan(s);
+    std::vector<Seg> segs;
+    DevBuf nd_lo, nd_hi;
+    CK(nd_lo.alloc(4));
+    CK(nd_hi.alloc(4));
+    {
+        const uint32_t z = 0, nn = (uint32_t)n;
+        HIPCK(hipMemcpyAsync(nd_lo.p, &z, 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(nd_hi.p, &nn, 4, hipMemcpyHostToDevice, s));
+    }
+    uint64_t M = 1;
+    uint64_t T_nodes = 0, T_ccs = 0, T_f2w = 0, T_clus = 0, T_child = 0, T_bf8 = 0, T_uc = 0;
+#define G(nelem) dim3(bft_grid_for(((uint64_t)(nelem) + ABLK - 1) / ABLK)), dim3(ABLK), 0, s
+    for (int d = 0; d < L && M > 0; d++) {
+        const int last_level = d == L - 1;
+        Seg sg;
+        // ---- active rows ----
+        DevBuf nsz, node_off;
+        CK(nsz.alloc(M * 4));
+        CK(node_off.alloc((M + 1) * 4));
+        hipLaunchKernelGGL(k_sizes, G(M), nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), nsz.as<uint32_t>(), (uint32_t)M);
+        uint64_t A = 0;
+        CK(scan.run(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, &A));
+        {
+            const uint32_t a32 = (uint32_t)A;
+            HIPCK(hipMemcpyAsync(node_off.as<uint32_t>() + M, &a32, 4, hipMemcpyHostToDevice, s));
+        }
+        // ---- prefixes and keys ----
+        DevBuf head, khead, ppos, kpos;
+        CK(head.alloc(A * 4));
+        CK(khead.alloc(A * 4));
+        CK(ppos.alloc(A * 4));
+        CK(kpos.alloc(A * 4));
+        uint64_t P = 0, K = 0;
+        if (A) {
+            hipLaunchKernelGGL(k_prefix_flags<W>, G(A), tk, L, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
+                               head.as<uint32_t>(), khead.as<uint32_t>());
+            CK(scan.run(head.as<uint32_t>(), ppos.as<uint32_t>(), A, &P));
+            CK(scan.run(khead.as<uint32_t>(), kpos.as<uint32_t>(), A, &K));
+        }
+        DevBuf pref_r, pref_row, pref_node, pref_key, pref_cnt, key_val, key_row, key_node, key_cnt, node_kb;
+        CK(pref_r.alloc(P * 4));
+        CK(pref_row.alloc(P * 4));
+        CK(pref_node.alloc(P * 4));
+        CK(pref_key.alloc(P * 4));
+        CK(pref_cnt.alloc(P * 4));
+        CK(key_val.alloc(K * 4));
+        CK(key_row.alloc(K * 4));
+        CK(key_node.alloc(K * 4));
+        CK(key_cnt.alloc(K * 4));
+        CK(node_kb.alloc((M + 1) * 4));
+        {
+            // nodes of an empty trie (n == 0) have no keys: node_kb = 0
+            HIPCK(hipMemsetAsync(node_kb.p, 0, (M + 1) * 4, s));
+            const uint32_t k32 = (uint32_t)K;
+            HIPCK(hipMemcpyAsync(node_kb.as<uint32_t>() + M, &k32, 4, hipMemcpyHostToDevice, s));
+        }
+        if (A) {
+            hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, L, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
+                               head.as<uint32_t>(), khead.as<uint32_t>(), ppos.as<uint32_t>(), kpos.as<uint32_t>(), pref_r.as<uint32_t>(),
+                               pref_row.as<uint32_t>(), pref_node.as<uint32_t>(), pref_key.as<uint32_t>(), key_val.as<uint32_t>(),
+                               key_row.as<uint32_t>(), key_node.as<uint32_t>(), node_kb.as<uint32_t>());
+            hipLaunchKernelGGL(k_counts, G(P), pref_row.as<uint32_t>(), pref_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)P, pref_cnt.as<uint32_t>());
+            hipLaunchKernelGGL(k_counts, G(K), key_row.as<uint32_t>(), key_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)K, key_cnt.as<uint32_t>());
+        }
+        head.release(); khead.release(); ppos.release(); kpos.release();
+
+        // ---- CC assignment: counting pass, scan, writing pass ----
+        DevBuf key_cc, node_ncc, node_ccb, cc_bits;
+        CK(key_cc.alloc(K * 4));
+        CK(node_ncc.alloc(M * 4));
+        CK(node_ccb.alloc((M + 1) * 4));
+        HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
+        const dim3 ngrid((unsigned)std::min<uint64_t>(M, 65535ull * 16));
+        hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
+                           nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)M);
+        uint64_t C = 0;
+        CK(scan.run(node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), M, &C));
+        {
+            const uint32_t c32 = (uint32_t)C;
+            HIPCK(hipMemcpyAsync(node_ccb.as<uint32_t>() + M, &c32, 4, hipMemcpyHostToDevice, s));
+        }
+        CK(cc_bits.alloc(C * 48 * 4));
+        HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
+        hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
+                           nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
+                           node_ccb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
+        // limits (format): CCs per node, Bloom slice width
+        std::vector<uint32_t> h_ncc(M);
+        HIPCK(hipMemcpyAsync(h_ncc.data(), node_ncc.p, M * 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        for (uint64_t m = 0; m < M; m++) {
+            if (h_ncc[m] > 2040) return bft_fail(BFT_GPU_E_LIMIT, "node with too many CCs for bf_wb");
+            out.max_ccs_per_node = std::max<uint64_t>(out.max_ccs_per_node, h_ncc[m]);
+        }
+        if (d == 0) out.root_ncc = h_ncc[0];
+
+        // ---- prefixes grouped by (node, cc) ----
+        DevBuf skey, skey_s, iota, sp;
+        CK(skey.alloc(P * 8));
+        CK(skey_s.alloc(P * 8));
+        CK(iota.alloc(P * 4));
+        CK(sp.alloc(P * 4));
+        if (P) {
+            hipLaunchKernelGGL(k_sort_keys, G(P), pref_node.as<uint32_t>(), pref_key.as<uint32_t>(), key_cc.as<int32_t>(), (uint32_t)P,
+                               skey.as<uint64_t>(), iota.as<uint32_t>());
+            int mbits = 1;
+            while (mbits < 32 && (M >> mbits)) mbits++;
+            size_t tb = 0;
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
+            DevBuf tmp;
+            CK(tmp.alloc(tb));
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
+            HIPCK(hipStreamSynchronize(s));
+        }
+        skey.release(); iota.release();
+
+        // ---- CC runs, clusters ----
+        DevBuf cc_qb, cc_qe, uc_qb, uc_qe, cc_nb, cc_s, cc_nwords, cc_f2;
+        CK(cc_qb.alloc_zero(C * 4, s));
+        CK(cc_qe.alloc_zero(C * 4, s));
+        CK(uc_qb.alloc_zero(M * 4, s));
+        CK(uc_qe.alloc_zero(M * 4, s));
+        CK(cc_nb.alloc(C * 4));
+        CK(cc_s.alloc(C * 4));
+        CK(cc_nwords.alloc(C * 4));
+        CK(cc_f2.alloc(C * 4));
+        if (P) hipLaunchKernelGGL(k_runs, G(P), skey_s.as<uint64_t>(), (uint32_t)P, node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_qe.as<uint32_t>(),
+                                  uc_qb.as<uint32_t>(), uc_qe.as<uint32_t>());
+        uint64_t F2 = 0;
+        if (C) {
+            hipLaunchKernelGGL(k_cc_meta, G(C), cc_qb.as<uint32_t>(), cc_qe.as<uint32_t>(), (uint32_t)C, cc_nb.as<uint32_t>(), cc_s.as<uint32_t>(),
+                               cc_nwords.as<uint32_t>());
+            CK(scan.run(cc_nwords.as<uint32_t>(), cc_f2.as<uint32_t>(), C, &F2));
+            std::vector<uint32_t> h_nb(C);
+            HIPCK(hipMemcpyAsync(h_nb.data(), cc_nb.p, C * 4, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            for (uint64_t c = 0; c < C; c++) {
+                if (h_nb[c] > 65535) return bft_fail(BFT_GPU_E_LIMIT, "CC with more than 65535 prefixes (nb_elem is uint16, include/CC.h:36)");
+                out.n_prefixes += h_nb[c];
+                if (h_nb[c] >= BFT_TRESH_SUF_PREF) out.n_ccs_s4++;
+            }
+        }
+        DevBuf chead, pend, ucn, cidx, nrank, ucpos;
+        CK(chead.alloc(P * 4));
+        CK(pend.alloc(P * 4));
+        CK(ucn.alloc(P * 4));
+        CK(cidx.alloc(P * 4));
+        CK(nrank.alloc(P * 4));
+        CK(ucpos.alloc(P * 4));
+        uint64_t Q = 0, Mnext = 0, UCR = 0;
+        if (P) {
+            hipLaunchKernelGGL(k_cluster_flags, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_r.as<uint32_t>(), pref_cnt.as<uint32_t>(), (uint32_t)P,
+                               node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_s.as<uint32_t>(), last_level, chead.as<uint32_t>(), pend.as<uint32_t>(),
+                               ucn.as<uint32_t>());
+            CK(scan.run(chead.as<uint32_t>(), cidx.as<uint32_t>(), P, &Q));
+            CK(scan.run(pend.as<uint32_t>(), nrank.as<uint32_t>(), P, &Mnext));
+            CK(scan.run(ucn.as<uint32_t>(), ucpos.as<uint32_t>(), P, &UCR));
+        }
+        DevBuf clus_q, clus_len, multi, cpos;
+        CK(clus_q.alloc(Q * 4));
+        CK(clus_len.alloc(Q * 4));
+        CK(multi.alloc(Q * 4));
+        CK(cpos.alloc(Q * 4));
+        uint64_t E = 0;
+        if (Q) {
+            hipLaunchKernelGGL(k_cluster_scatter, G(P), chead.as<uint32_t>(), cidx.as<uint32_t>(), (uint32_t)P, clus_q.as<uint32_t>());
+            hipLaunchKernelGGL(k_cluster_len, G(Q), clus_q.as<uint32_t>(), (uint32_t)Q, skey_s.as<uint64_t>(), node_ccb.as<uint32_t>(), cc_qe.as<uint32_t>(),
+                               clus_len.as<uint32_t>(), multi.as<uint32_t>());
+            CK(scan.run(multi.as<uint32_t>(), cpos.as<uint32_t>(), Q, &E));
+        }
+        if (T_f2w + F2 > 0xFFFFFFFFull || T_clus + Q > 0xFFFFFFFFull || T_child + E > 0xFFFFFFFFull || T_uc + UCR > 0xFFFFFFFFull)
+            return bft_fail(BFT_GPU_E_LIMIT, "index array offset overflow (u32)");
+
+        // ---- outputs of this depth ----
+        CK(sg.ccs.alloc(C * sizeof(BftCC)));
+        CK(sg.f2w.alloc_zero(F2 * 8, s));
+        CK(sg.clus.alloc(Q * 8));
+        CK(sg.child.alloc(E * 8));
+        CK(sg.uck.alloc(UCR * W * 8));
+        CK(sg.ucrow.alloc(UCR * 4));
+        CK(sg.nodes.alloc(M * sizeof(BftNode)));
+        DevBuf next_lo, next_hi;
+        CK(next_lo.alloc(Mnext * 4));
+        CK(next_hi.alloc(Mnext * 4));
+        if (C) {
+            // cc_f2 is relative to this depth's f2w segment while filling; headers carry global offsets
+            hipLaunchKernelGGL(k_cc_headers, G(C), cc_qb.as<uint32_t>(), cc_nb.as<uint32_t>(), cc_s.as<uint32_t>(), cc_f2.as<uint32_t>(), cidx.as<uint32_t>(),
+                               cpos.as<uint32_t>(), (uint32_t)C, (uint32_t)T_f2w, (uint32_t)T_clus, (uint32_t)T_child, sg.ccs.as<BftCC>());
+            hipLaunchKernelGGL(k_entries, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_r.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
+                               (uint32_t)P, node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_s.as<uint32_t>(), cc_f2.as<uint32_t>(), chead.as<uint32_t>(),
+                               cidx.as<uint32_t>(), clus_q.as<uint32_t>(), clus_len.as<uint32_t>(), cpos.as<uint32_t>(), pend.as<uint32_t>(),
+                               nrank.as<uint32_t>(), last_level, (uint32_t)(T_nodes + M), sg.f2w.as<uint64_t>(), sg.clus.as<uint64_t>(),
+                               sg.child.as<uint64_t>(), next_lo.as<uint32_t>(), next_hi.as<uint32_t>());
+            hipLaunchKernelGGL(k_ranks, G(C), cc_f2.as<uint32_t>(), cc_nwords.as<uint32_t>(), (uint32_t)C, sg.f2w.as<uint64_t>());
+        }
+        if (UCR) hipLaunchKernelGGL(k_uc_rows, G(P), tk, W, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
+                                    ucpos.as<uint32_t>(), (uint32_t)P, 0u, sg.uck.as<uint64_t>(), sg.ucrow.as<uint32_t>());
+        // nodes
+        DevBuf node_ucn, node_bf8, node_ucoff, node_bfoff;
+        CK(node_ucn.alloc(M * 4));
+        CK(node_bf8.alloc(M * 4));
+        CK(node_ucoff.alloc(M * 4));
+        CK(node_bfoff.alloc(M * 4));
+        hipLaunchKernelGGL(k_node_meta, G(M), node_ncc.as<uint32_t>(), uc_qb.as<uint32_t>(), uc_qe.as<uint32_t>(), ucpos.as<uint32_t>(), ucn.as<uint32_t>(),
+                           (uint32_t)M, node_ucn.as<uint32_t>(), node_bf8.as<uint32_t>());
+        uint64_t BF8 = 0, ucchk = 0;
+        CK(scan.run(node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(), M, &ucchk));
+        CK(scan.run(node_bf8.as<uint32_t>(), node_bfoff.as<uint32_t>(), M, &BF8));
+        if (T_bf8 + BF8 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "Bloom block offset overflow");
+        CK(sg.bfT.alloc(BF8 * 8));
+        hipLaunchKernelGGL(k_node_records, G(M), node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(),
+                           node_bfoff.as<uint32_t>(), (uint32_t)M, (uint32_t)T_ccs, (uint32_t)T_uc, (uint32_t)T_bf8, sg.nodes.as<BftNode>());
+        if (BF8) hipLaunchKernelGGL(k_bloom_slice, ngrid, dim3(ABLK), 0, s, node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_bfoff.as<uint32_t>(),
+                                    cc_bits.as<uint32_t>(), (uint32_t)M, sg.bfT.as<uint8_t>());
+        HIPCK(hipGetLastError());
+        if (d == 0) {
+            uint32_t ru = 0;
+            HIPCK(hipMemcpyAsync(&ru, node_ucn.p, 4, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            out.root_uc = ru;
+        }
+        HIPCK(hipStreamSynchronize(s));
+        sg.n_nodes = M; sg.n_bf8 = BF8; sg.n_ccs = C; sg.n_f2w = F2; sg.n_clus = Q; sg.n_child = E; sg.n_uc = UCR;
+        T_nodes += M; T_ccs += C; T_f2w += F2; T_clus += Q; T_child += E; T_bf8 += BF8; T_uc += UCR;
+        out.n_child_nodes += Mnext;
+        segs.push_back(std::move(sg));
+        nd_lo.swap(next_lo);
+        nd_hi.swap(next_hi);
+        M = Mnext;
+    }
+#undef G
+    // ---- concatenate the per-depth segments ----
+    CK(out.nodes.alloc(T_nodes * sizeof(BftNode)));
+    CK(out.bfT.alloc(T_bf8 * 8));
+    CK(out.ccs.alloc(T_ccs * sizeof(BftCC)));
+    CK(out.f2w.alloc(T_f2w * 8));
+    CK(out.clus.alloc(T_clus * 8));
+    CK(out.child.alloc(T_child * 8));
+    CK(out.uck.alloc(T_uc * W * 8));
+    CK(out.ucrow.alloc(T_uc * 4));
+    uint64_t o_n = 0, o_b = 0, o_c = 0, o_f = 0, o_q = 0, o_e = 0, o_u = 0;
+    for (Seg& g : segs) {
+#define CP(dst, src, off, nbytes) if (nbytes) HIPCK(hipMemcpyAsync((uint8_t*)(dst).p + (off), (src).p, (nbytes), hipMemcpyDeviceToDevice, s))
+        CP(out.nodes, g.nodes, o_n * sizeof(BftNode), g.n_nodes * sizeof(BftNode));
+        CP(out.bfT, g.bfT, o_b * 8, g.n_bf8 * 8);
+        CP(out.ccs, g.ccs, o_c * sizeof(BftCC), g.n_ccs * sizeof(BftCC));
+        CP(out.f2w, g.f2w, o_f * 8, g.n_f2w * 8);
+        CP(out.clus, g.clus, o_q * 8, g.n_clus * 8);
+        CP(out.child, g.child, o_e * 8, g.n_child * 8);
+        CP(out.uck, g.uck, o_u * W * 8, g.n_uc * W * 8);
+        CP(out.ucrow, g.ucrow, o_u * 4, g.n_uc * 4);
+#undef CP
+        o_n += g.n_nodes; o_b += g.n_bf8; o_c += g.n_ccs; o_f += g.n_f2w; o_q += g.n_clus; o_e += g.n_child; o_u += g.n_uc;
+    }
+    HIPCK(hipStreamSynchronize(s));
+    out.n_nodes = T_nodes; out.n_ccs = T_ccs; out.n_f2w = T_f2w; out.n_clus = T_clus; out.n_child = T_child; out.n_bf8 = T_bf8; out.n_uc = T_uc;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// colour sets
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+// signature of the sorted genome-id list of each k-mer
+__global__ void k_cs_sig(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint64_t* __restrict__ sig, uint32_t* __restrict__ iota) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+        uint64_t h = 0x9E3779B97F4A7C15ULL ^ (seg_off[i + 1] - seg_off[i]);
+        for (uint32_t q = seg_off[i]; q < seg_off[i + 1]; q++) h = mix64(h ^ (pg[q] + 0x632BE59BD9B4E019ULL)) * 0x100000001B3ULL + pg[q];
+        sig[i] = h;
+        iota[i] = i;
+    }
+}
+
+__device__ __forceinline__ bool same_list(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t a, uint32_t b) {
+    const uint32_t la = seg_off[a + 1] - seg_off[a], lb = seg_off[b + 1] - seg_off[b];
+    if (la != lb) return false;
+    for (uint32_t i = 0; i < la; i++)
+        if (pg[seg_off[a] + i] != pg[seg_off[b] + i]) return false;
+    return true;
+}
+
+// a new colour set starts where the (signature-sorted) list differs from its predecessor: exact comparison
+__global__ void k_cs_heads(const uint64_t* __restrict__ sig_s, const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_off,
+                           const uint32_t* __restrict__ pg, uint32_t nk, uint32_t* __restrict__ head, uint32_t* __restrict__ len) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+        const uint32_t a = order[i];
+        uint32_t h = 1;
+        if (i > 0 && sig_s[i] == sig_s[i - 1] && same_list(seg_off, pg, a, order[i - 1])) h = 0;
+        head[i] = h;
+        len[i] = h ? seg_off[a + 1] - seg_off[a] : 0;
+    }
+}
+
+__global__ void k_cs_assign(const uint32_t* __restrict__ order, const uint32_t* __restrict__ head, const uint32_t* __restrict__ csid_ex,
+                            const uint32_t* __restrict__ off_ex, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk,
+                            uint32_t* __restrict__ tcol, uint32_t* __restrict__ cs_off, uint32_t* __restrict__ cs_ids) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+        const uint32_t a = order[i];
+        const uint32_t cs = csid_ex[i] + head[i] - 1;
+        tcol[a] = cs;
+        if (head[i]) {
+            cs_off[cs] = off_ex[i];
+            for (uint32_t q = seg_off[a]; q < seg_off[a + 1]; q++) cs_ids[off_ex[i] + (q - seg_off[a])] = pg[q];
+        }
+    }
+}
+
+// exactness check: every k-mer's list equals the dictionary entry it was assigned
+__global__ void k_cs_verify(const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids,
+                            const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint32_t* __restrict__ bad) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+        const uint32_t cs = tcol[i];
+        const uint32_t l = seg_off[i + 1] - seg_off[i];
+        bool ok = (cs_off[cs + 1] - cs_off[cs]) == l;
+        for (uint32_t q = 0; ok && q < l; q++) ok = cs_ids[cs_off[cs] + q] == pg[seg_off[i] + q];
+        if (!ok) atomicAdd(bad, 1u);
+    }
+}
+
+}  // namespace
+
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
+    if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be a multiple of 9 in [9, 126]");
+    if (n >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 k-mers");
+    switch (bft_words_for_k(k)) {
+    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out);
+    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out);
+    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out);
+    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out);
+    }
+}
+
+// Interning of the colour sets (sorted genome-id list of each distinct k-mer, CSR seg_off/pg) into a dictionary:
+// signature -> radix sort -> run heads by EXACT list comparison with the predecessor -> ids; then a verification
+// pass over every k-mer.  Two different sets can never share an id (the comparison is exact); two equal sets get
+// the same id whenever they are adjacent after the sort, which only a 64-bit signature collision can prevent
+// (that would cost a duplicate dictionary entry, never a wrong answer).
+int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids) {
+    n_sets = 0;
+    n_ids = 0;
+    CK(d_tcol.alloc(nk * 4));
+    if (nk == 0) {
+        CK(d_cs_off.alloc_zero(4, s));
+        CK(d_cs_ids.alloc(4));
+        HIPCK(hipStreamSynchronize(s));
+        return 0;
+    }
+    Scan scan(s);
+    DevBuf sig, sig_s, iota, order, head, len, csid, off, tmp, bad;
+    CK(sig.alloc(nk * 8));
+    CK(sig_s.alloc(nk * 8));
+    CK(iota.alloc(nk * 4));
+    CK(order.alloc(nk * 4));
+    CK(head.alloc(nk * 4));
+    CK(len.alloc(nk * 4));
+    CK(csid.alloc(nk * 4));
+    CK(off.alloc(nk * 4));
+    const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
+    hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, sig.as<uint64_t>(), iota.as<uint32_t>());
+    size_t tb = 0;
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 64, s));
+    CK(tmp.alloc(tb));
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 64, s));
+    hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, head.as<uint32_t>(), len.as<uint32_t>());
+    CK(scan.run(head.as<uint32_t>(), csid.as<uint32_t>(), nk, &n_sets));
+    CK(scan.run(len.as<uint32_t>(), off.as<uint32_t>(), nk, &n_ids));
+    CK(d_cs_off.alloc((n_sets + 1) * 4));
+    CK(d_cs_ids.alloc(n_ids * 4));
+    {
+        const uint32_t t32 = (uint32_t)n_ids;
+        HIPCK(hipMemcpyAsync(d_cs_off.as<uint32_t>() + n_sets, &t32, 4, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_cs_assign, grid, block, 0, s, order.as<uint32_t>(), head.as<uint32_t>(), csid.as<uint32_t>(), off.as<uint32_t>(), d_seg_off, d_pg,
+                       (uint32_t)nk, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>());
+    CK(bad.alloc_zero(4, s));
+    hipLaunchKernelGGL(k_cs_verify, grid, block, 0, s, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
+                       bad.as<uint32_t>());
+    uint32_t nbad = 0;
+    HIPCK(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    if (nbad) return bft_fail(BFT_GPU_E_LIMIT, "colour-set interning self-check failed");
+    (void)np;
+    return 0;
+}

@@ -1,0 +1,69 @@
+// bft_dev.h -- small HIP host-side helpers shared by the translation units of libbft_gpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/bft_gpu.h"
+
+int bft_fail(int code, const std::string& msg);  // records the thread's last error, returns code
+
+#define HIPCK(expr)                                                                                           \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return bft_fail(BFT_GPU_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define CK(expr)                  \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 8;
+        HIPCK(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    int alloc_zero(size_t n, hipStream_t s) {
+        CK(alloc(n));
+        HIPCK(hipMemsetAsync(p, 0, bytes, s));
+        return 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(bytes, o.bytes);
+    }
+};
+
+static inline int bft_grid_for(uint64_t nblk) {
+    const uint64_t cap = 256ull * 8ull;  // 256 CUs x 8 resident workgroups of 256 threads
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(nblk, cap));
+}
+
+// GPU container assembly and colour interning (bft_assemble.hip)
+struct BftDeviceIndex {
+    DevBuf nodes, bfT, ccs, f2w, clus, child, uck, ucrow;
+    uint64_t n_nodes = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_bf8 = 0, n_uc = 0;
+    uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0, root_ncc = 0, root_uc = 0;
+};
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out);
+int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids);

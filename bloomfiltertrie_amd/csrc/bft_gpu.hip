@@ -9,9 +9,8 @@
 //                     __ballot (64 k-mers -> one u64 store)
 //   k_color_*         batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
 //   k_flags/k_scatter de-duplication of sorted (k-mer, genome) pairs for the bulk build
-// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); the container
-// assembly (bft_index.cpp) and colour interning currently run on the host between the two GPU
-// stages -- see DESIGN.md "Insertion".
+// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); colour-set interning
+// and container assembly are the kernels of bft_assemble.hip -- see DESIGN.md "Insertion".
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -22,6 +21,7 @@
 #include <vector>
 
 #include "../../include/bft_gpu.h"
+#include "bft_dev.h"
 #include "bft_hash.h"
 #include "bft_image.h"
 #include "bft_index.h"
@@ -30,51 +30,12 @@
 #define BFT_BLOCK 256
 #define BFT_ABSENT_ROW 0xFFFFFFFFu
 
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+int bft_fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-#define HIPCK(expr)                                                                                   \
-    do {                                                                                              \
-        hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess) return fail(BFT_GPU_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-#define CK(expr)                  \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_ != 0) return rc_; \
-    } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    DevBuf() {}
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-    int alloc(size_t n) {
-        release();
-        if (n == 0) n = 8;
-        HIPCK(hipMalloc(&p, n));
-        bytes = n;
-        return 0;
-    }
-    template <class T>
-    T* as() const { return (T*)p; }
-    void swap(DevBuf& o) {
-        std::swap(p, o.p);
-        std::swap(bytes, o.bytes);
-    }
-};
+static int fail(int code, const std::string& msg) { return bft_fail(code, msg); }
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -316,14 +277,12 @@ struct bft_gpu {
     uint64_t kernel_launches = 0;
     bool timing = true;
     uint32_t root_ncc = 0;
+    uint64_t idx_sizes[9] = {0};
     int opt_block = 1024;     // k_query workgroup size (256 / 512 / 1024)
     int opt_grid_mult = 1;    // grid = resident workgroups x this
 };
 
-static int grid_for(uint64_t nblk) {
-    const uint64_t cap = 256ull * 8ull;  // 256 CUs x 8 resident workgroups of 256 threads
-    return (int)std::max<uint64_t>(1, std::min<uint64_t>(nblk, cap));
-}
+static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
 
 static int set_device(bft_gpu* h) {
     HIPCK(hipSetDevice(h->device));
@@ -522,54 +481,6 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
     return 0;
 }
 
-// exact colour-set interning (host): list of sorted ids -> dense id
-struct Interner {
-    std::vector<uint32_t>& off;
-    std::vector<uint32_t>& ids;
-    std::vector<int64_t> slots;
-    uint64_t nsets = 0;
-    Interner(std::vector<uint32_t>& o, std::vector<uint32_t>& i) : off(o), ids(i) {
-        off.assign(1, 0);
-        ids.clear();
-        slots.assign(1024, -1);
-    }
-    static uint64_t hash(const uint32_t* p, uint32_t n) {
-        uint64_t hsh = 0x9E3779B97F4A7C15ULL ^ n;
-        for (uint32_t i = 0; i < n; i++) {
-            hsh ^= p[i];
-            hsh *= 0x100000001B3ULL;
-            hsh ^= hsh >> 29;
-        }
-        hsh *= 0xBF58476D1CE4E5B9ULL;
-        return hsh ^ (hsh >> 31);
-    }
-    void grow() {
-        std::vector<int64_t> ns(slots.size() * 2, -1);
-        for (int64_t s : slots) {
-            if (s < 0) continue;
-            uint64_t hh = hash(&ids[off[s]], off[s + 1] - off[s]);
-            size_t p = hh & (ns.size() - 1);
-            while (ns[p] >= 0) p = (p + 1) & (ns.size() - 1);
-            ns[p] = s;
-        }
-        slots.swap(ns);
-    }
-    uint32_t intern(const uint32_t* p, uint32_t n) {
-        if ((nsets + 1) * 2 > slots.size()) grow();
-        uint64_t hh = hash(p, n);
-        size_t q = hh & (slots.size() - 1);
-        while (slots[q] >= 0) {
-            int64_t s = slots[q];
-            if (off[s + 1] - off[s] == n && memcmp(&ids[off[s]], p, (size_t)n * 4) == 0) return (uint32_t)s;
-            q = (q + 1) & (slots.size() - 1);
-        }
-        slots[q] = (int64_t)nsets;
-        ids.insert(ids.end(), p, p + n);
-        off.push_back((uint32_t)ids.size());
-        return (uint32_t)nsets++;
-    }
-};
-
 template <class T>
 static int upload(DevBuf& d, const std::vector<T>& v) {
     CK(d.alloc(v.size() * sizeof(T)));
@@ -647,49 +558,40 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     double t1 = now_ms();
 
-    // 4. device -> host: the sorted table, segment offsets and genome ids
-    std::vector<uint64_t> h_tk(nk * W);
-    std::vector<uint32_t> h_seg(nk + 1, 0), h_pg(np);
-    if (nk) {
-        HIPCK(hipMemcpy(h_tk.data(), tk.p, nk * W * 8, hipMemcpyDeviceToHost));
-        HIPCK(hipMemcpy(h_seg.data(), seg_off.p, (nk + 1) * 4, hipMemcpyDeviceToHost));
-        HIPCK(hipMemcpy(h_pg.data(), npg.p, np * 4, hipMemcpyDeviceToHost));
+    // 4. colour sets: signature sort + exact run detection + verification, all on the GPU
+    uint64_t n_sets = 0, n_ids = 0;
+    if (nk == 0) {
+        CK(seg_off.alloc_zero(4, h->stream));
+        CK(npg.alloc(4));
     }
+    CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, h->d_tcol, h->d_cs_off, h->d_cs_ids, n_sets, n_ids));
+    h->cs_off.assign(n_sets + 1, 0);
+    h->cs_ids.assign(n_ids, 0);
+    HIPCK(hipMemcpy(h->cs_off.data(), h->d_cs_off.p, (n_sets + 1) * 4, hipMemcpyDeviceToHost));
+    if (n_ids) HIPCK(hipMemcpy(h->cs_ids.data(), h->d_cs_ids.p, n_ids * 4, hipMemcpyDeviceToHost));
     double t2 = now_ms();
 
-    // 5. colour sets (exact interning)
-    std::vector<uint32_t> h_tcol(nk);
-    {
-        Interner in(h->cs_off, h->cs_ids);
-        for (uint64_t i = 0; i < nk; i++) h_tcol[i] = in.intern(h_pg.data() + h_seg[i], h_seg[i + 1] - h_seg[i]);
-    }
+    // 5. containers, level by level, on the GPU
+    if (!tk.p) CK(tk.alloc(8));
+    BftDeviceIndex idx;
+    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx));
     double t3 = now_ms();
 
-    // 6. containers
-    BftHostIndex idx;
-    if (!bft_build_index(h_tk.data(), nk, h->k, h->hashmod.data(), idx)) return fail(BFT_GPU_E_LIMIT, idx.error);
-    double t4 = now_ms();
-
-    // 7. upload
-    CK(upload(h->d_nodes, idx.nodes));
-    CK(upload(h->d_bfT, idx.bfT));
-    CK(upload(h->d_ccs, idx.ccs));
-    CK(upload(h->d_f2w, idx.f2w));
-    CK(upload(h->d_clus, idx.clus));
-    CK(upload(h->d_child, idx.child));
-    CK(upload(h->d_uck, idx.uck));
-    CK(upload(h->d_ucrow, idx.ucrow));
-    CK(upload(h->d_tcol, h_tcol));
-    CK(upload(h->d_cs_off, h->cs_off));
-    CK(upload(h->d_cs_ids, h->cs_ids));
+    h->d_nodes.swap(idx.nodes);
+    h->d_bfT.swap(idx.bfT);
+    h->d_ccs.swap(idx.ccs);
+    h->d_f2w.swap(idx.f2w);
+    h->d_clus.swap(idx.clus);
+    h->d_child.swap(idx.child);
+    h->d_uck.swap(idx.uck);
+    h->d_ucrow.swap(idx.ucrow);
     h->d_tk.swap(tk);
-    if (!h->d_tk.p) CK(h->d_tk.alloc(8));
     h->pair_k.swap(npk);
     h->pair_g.swap(npg);
     h->n_pairs = np;
     h->log_n = 0;
     h->n_kmers = nk;
-    double t5 = now_ms();
+    double t4 = now_ms(), t5 = t4;
 
     BftImage& im = h->im;
     im.k = h->k;
@@ -714,21 +616,24 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     uint64_t* I = h->info;
     I[0] = h->k;
     I[1] = nk;
-    I[2] = idx.nodes.size();
-    I[3] = idx.ccs.size();
-    I[4] = idx.ucrow.size();
+    I[2] = idx.n_nodes;
+    I[3] = idx.n_ccs;
+    I[4] = idx.n_uc;
     I[5] = idx.n_child_nodes;
     I[6] = idx.n_prefixes;
     I[7] = idx.n_ccs_s4;
     I[8] = idx.max_ccs_per_node;
     I[9] = np;
-    I[10] = h->cs_off.size() - 1;
+    I[10] = n_sets;
     I[11] = im.nb_genomes;
     I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes +
             h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes;
-    I[13] = idx.nodes.empty() ? 0 : idx.nodes[0].ncc;
-    h->root_ncc = (uint32_t)I[13];
-    I[14] = idx.nodes.empty() ? 0 : idx.nodes[0].uc_n;
+    I[13] = idx.root_ncc;
+    I[14] = idx.root_uc;
+    h->root_ncc = (uint32_t)idx.root_ncc;
+    h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
+    h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
+    h->idx_sizes[6] = idx.n_uc * (uint64_t)W * 8; h->idx_sizes[7] = idx.n_uc * 4; h->idx_sizes[8] = nk * (uint64_t)W * 8;
     h->build_ms[0] = t1 - t0;
     h->build_ms[1] = t2 - t1;
     h->build_ms[2] = t3 - t2;
@@ -907,6 +812,24 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // ------------------------------------------------------------------------------------------------
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
+// Test hook (tests/test_gpu_build.py): raw copy of one index array of the image.
+extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes) {
+    if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    static const char* names[9] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk"};
+    const DevBuf* bufs[9] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk};
+    for (int i = 0; i < 9; i++)
+        if (std::string(name) == names[i]) {
+            if (nbytes) *nbytes = h->idx_sizes[i];
+            if (!out) return BFT_GPU_OK;
+            if (cap_bytes < h->idx_sizes[i]) return fail(BFT_GPU_E_NOSPACE, "buffer too small");
+            if (h->idx_sizes[i]) HIPCK(hipMemcpy(out, bufs[i]->p, h->idx_sizes[i], hipMemcpyDeviceToHost));
+            return BFT_GPU_OK;
+        }
+    return fail(BFT_GPU_E_ARG, "unknown array");
+}
+
 extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     const std::string nm(name);

@@ -6,6 +6,7 @@
 // Nothing here is reachable from the bft_gpu_* C-ABI, which has no CPU path.
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "bft_hash.h"
@@ -130,3 +131,24 @@ extern "C" void bft_hosttest_roundtrip(const uint8_t* kmers, uint64_t n, int k, 
 
 extern "C" void bft_hosttest_hashmod(int r1, int r2, uint32_t* out) { bft_make_hashmod(r1, r2, out); }
 extern "C" void bft_hosttest_free(void* hv) { delete (HostTrie*)hv; }
+
+// raw copy of one host-built index array (same names as bft_gpu_debug_get_array)
+extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uint64_t cap, uint64_t* nbytes) {
+    HostTrie* t = (HostTrie*)hv;
+    const std::string nm(name);
+    const void* p = nullptr;
+    uint64_t n = 0;
+    if (nm == "nodes") { p = t->idx.nodes.data(); n = t->idx.nodes.size() * sizeof(BftNode); }
+    else if (nm == "bfT") { p = t->idx.bfT.data(); n = t->idx.bfT.size(); }
+    else if (nm == "ccs") { p = t->idx.ccs.data(); n = t->idx.ccs.size() * sizeof(BftCC); }
+    else if (nm == "f2w") { p = t->idx.f2w.data(); n = t->idx.f2w.size() * 8; }
+    else if (nm == "clus") { p = t->idx.clus.data(); n = t->idx.clus.size() * 8; }
+    else if (nm == "child") { p = t->idx.child.data(); n = t->idx.child.size() * 8; }
+    else if (nm == "uck") { p = t->idx.uck.data(); n = t->idx.uck.size() * 8; }
+    else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }
+    else if (nm == "tk") { p = t->tk.data(); n = t->tk.size() * 8; }
+    else return -1;
+    if (nbytes) *nbytes = n;
+    if (out) { if (cap < n) return -6; memcpy(out, p, n); }
+    return 0;
+}

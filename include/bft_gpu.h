@@ -96,12 +96,15 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
  * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
+/* Test hook: raw device->host copy of one array of the image ("nodes", "bfT", "ccs", "f2w", "clus",
+ * "child", "uck", "ucrow", "tk"); out may be NULL to query the size. */
+int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes);
+
 /* HIP-event timing of the query kernels launched through this handle since the last reset:
  * *ms = summed kernel time, *launches = number of launches. */
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
- * ms[1]=device->host copies, ms[2]=colour interning (host), ms[3]=container assembly (host),
- * ms[4]=host->device upload. */
+ * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=0. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,
