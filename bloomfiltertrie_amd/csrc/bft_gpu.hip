@@ -252,6 +252,9 @@ struct bft_gpu {
     std::vector<std::string> genomes;
     uint32_t max_gid_seen = 0;
     bool any_insert = false;
+    bool log_g_sorted = true;   // the log's genome ids are non-decreasing and >= every id of the pair store
+    uint32_t log_last_gid = 0, store_max_gid = 0;
+    bool store_any = false;
 
     // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
     DevBuf log_k, log_g;
@@ -409,6 +412,8 @@ extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_
     default: CK(launch_pack<4>(h, p, n, id_genome)); break;
     }
     HIPCK(hipStreamSynchronize(h->stream));
+    if ((h->log_n > 0 && id_genome < h->log_last_gid) || (h->store_any && id_genome < h->store_max_gid)) h->log_g_sorted = false;
+    h->log_last_gid = id_genome;
     h->log_n += n;
     h->max_gid_seen = std::max(h->max_gid_seen, id_genome);
     h->any_insert = true;
@@ -442,7 +447,7 @@ static int bits_for(uint64_t v) {
 // Stable LSD sort of `total` entries by (keys word 0..W-1 as one big integer, then g).
 // keys: SoA with stride `stride`.  Result in okeys (stride ostride) / og.
 static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const uint32_t* g, uint64_t total, uint64_t* okeys,
-                      uint64_t ostride, uint32_t* og) {
+                      uint64_t ostride, uint32_t* og, bool g_already_ordered) {
     const int W = h->W;
     const int n = (int)total;
     DevBuf perm, perm2, ku, ku2, kg, kg2, tmp;
@@ -458,8 +463,9 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
     HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb32, kg.as<uint32_t>(), kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 32, h->stream));
     HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb64, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 64, h->stream));
     CK(tmp.alloc(std::max(tb32, tb64)));
-    // pass 0: genome id (least significant)
-    {
+    // pass 0: genome id (least significant); skipped when the input is already in genome-id order
+    // (ids inserted in non-decreasing order, as the reference requires: the stable key passes keep it)
+    if (!g_already_ordered) {
         size_t tb = tmp.bytes;
         const int gb = bits_for(h->max_gid_seen);
         HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, g, kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, gb, h->stream));
@@ -520,7 +526,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
         CK(sg.alloc(total * 4));
-        CK(sort_pairs(h, ck.as<uint64_t>(), total, cg.as<uint32_t>(), total, sk.as<uint64_t>(), total, sg.as<uint32_t>()));
+        CK(sort_pairs(h, ck.as<uint64_t>(), total, cg.as<uint32_t>(), total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted));
         ck.release();
         cg.release();
         // 3. flags, scans, compaction
@@ -590,6 +596,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->pair_g.swap(npg);
     h->n_pairs = np;
     h->log_n = 0;
+    h->log_g_sorted = true;
+    h->store_any = np > 0;
+    h->store_max_gid = h->max_gid_seen;
     h->n_kmers = nk;
     double t4 = now_ms(), t5 = t4;
 

@@ -155,3 +155,25 @@ def test_rejects_bad_k():
     for k in (31, 8, 135):
         with pytest.raises(BFTError):
             BFT(k)
+
+
+def test_out_of_order_genome_ids_ground_truth():
+    """Genome ids arriving in decreasing order take the full (k-mer, genome) sort; colour sets stay sorted id lists."""
+    k = 27
+    anc = S.random_genome(20000, 8)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 50 + g), k)) for g in range(5)]
+    t = _bft(k)
+    for g in (4, 2, 3, 0, 1):
+        t.insert_kmers(gk[g], g)
+    truth = {}
+    for g, km in enumerate(gk):
+        for key in S.row_keys(km).tolist():
+            truth.setdefault(key, []).append(g)
+    allk = S.distinct(np.concatenate(gk))
+    q = _queries(allk, k, seed=9)
+    bits, off, ids = t.query_colors(q)
+    pres = S.from_bits(bits, len(q))
+    for i, key in enumerate(S.row_keys(q).tolist()):
+        exp = truth.get(key, [])
+        assert pres[i] == bool(exp)
+        assert ids[int(off[i]):int(off[i + 1])].tolist() == exp

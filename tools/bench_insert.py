@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Config 3 (BASELINE.json): insertKmers build path, 100 synthetic genomes (~2x10^8 (k-mer, genome) pairs) on one
+MI355X.  Genomes are generated and packed on the GPU with torch (input plumbing), inserted genome by genome through
+bft_gpu_insert_kmers_dev (ids ascending, as the reference requires) and built in bulk by bft_gpu_build.
+Parity at this size is checked through size-independent properties: the number of distinct k-mers, the number of
+distinct (k-mer, genome) pairs, and presence + colour sets of a random sample against per-genome sorted tables."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pack_windows(codes, k):
+    """codes: uint8 tensor [G] on device -> packed k-mers [G-k+1, ceil(2k/8)] (reference layout)."""
+    import torch
+    n = codes.numel() - k + 1
+    nb = (2 * k + 7) // 8
+    win = codes.unfold(0, k, 1)  # [n, k] view
+    pad = torch.zeros((n, nb * 4), dtype=torch.uint8, device=codes.device)
+    pad[:, :k] = win
+    q = pad.view(n, nb, 4)
+    return (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).contiguous()
+
+
+def keys_of(packed):
+    import torch
+    n, nb = packed.shape
+    assert nb <= 8
+    pad = torch.zeros((n, 8), dtype=torch.uint8, device=packed.device)
+    pad[:, :nb] = packed
+    return pad.view(torch.int64).reshape(n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=27)
+    ap.add_argument("--genomes", type=int, default=100)
+    ap.add_argument("--genome-len", type=int, default=2_000_000)
+    ap.add_argument("--snp-rate", type=float, default=0.01)
+    ap.add_argument("--sample", type=int, default=2_000_000)
+    args = ap.parse_args()
+    import torch
+    from bloomfiltertrie_amd import BFT
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    anc = torch.randint(0, 4, (args.genome_len,), generator=g, device=dev, dtype=torch.uint8)
+    t = BFT(args.k)
+    t_ins = 0.0
+    npairs_in = 0
+    per_genome_keys = []
+    for gid in range(args.genomes):
+        m = torch.rand(args.genome_len, generator=g, device=dev) < args.snp_rate
+        delta = torch.randint(1, 4, (args.genome_len,), generator=g, device=dev, dtype=torch.uint8)
+        genome = torch.where(m, (anc + delta) & 3, anc)
+        packed = pack_windows(genome, args.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t.insert_kmers_dev(packed.data_ptr(), packed.shape[0], gid)
+        t_ins += time.perf_counter() - t0
+        npairs_in += packed.shape[0]
+        per_genome_keys.append(torch.unique(keys_of(packed)))  # sorted
+        del packed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t.build()
+    t_build = time.perf_counter() - t0
+    info = t.info()
+    # ---- properties ----
+    allk = torch.unique(torch.cat(per_genome_keys))
+    pairs = int(sum(int(x.numel()) for x in per_genome_keys))
+    ok_counts = info["kmers"] == int(allk.numel()) and info["pairs"] == pairs
+    # sample: half present, half random
+    ns = args.sample
+    idx = torch.randint(0, allk.numel(), (ns // 2,), generator=g, device=dev)
+    qk = torch.cat([allk[idx], torch.randint(0, 1 << (2 * args.k), (ns - ns // 2,), generator=g, device=dev, dtype=torch.int64)])
+    nb = (2 * args.k + 7) // 8
+    q = qk.view(torch.uint8).reshape(-1, 8)[:, :nb].contiguous().cpu().numpy()
+    bits, rows = t.query_color_rows(q)
+    got = np.unpackbits(rows, axis=1, bitorder="little")[:, :args.genomes].astype(bool)
+    exp = np.zeros_like(got)
+    for gid, gkeys in enumerate(per_genome_keys):
+        pos = torch.searchsorted(gkeys, qk).clamp(max=gkeys.numel() - 1)
+        exp[:, gid] = (gkeys[pos] == qk).cpu().numpy()
+    ok_colors = bool((got == exp).all())
+    ok_presence = bool((np.unpackbits(bits, bitorder="little")[:ns].astype(bool) == exp.any(axis=1)).all())
+    out = {
+        "metric": "M (k-mer, genome) pairs/sec inserted (insertKmers bulk build)",
+        "workload": f"k={args.k}, {args.genomes} genomes x {args.genome_len} nt, {args.snp_rate:.0%} SNPs, ids ascending",
+        "pairs_in": npairs_in, "pairs_distinct": info["pairs"], "distinct_kmers": info["kmers"], "colorsets": info["colorsets"],
+        "insert_s": round(t_ins, 3), "build_s": round(t_build, 3),
+        "value": round(npairs_in / (t_ins + t_build) / 1e6, 2), "unit": "M pairs/s",
+        "build_breakdown_ms": {k_: round(v, 1) for k_, v in t.build_time().items()},
+        "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
+        "parity": {"counts": bool(ok_counts), "presence_sample": ok_presence, "colors_sample": ok_colors, "sample": ns},
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
