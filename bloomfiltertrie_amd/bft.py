@@ -19,14 +19,31 @@ INFO_FIELDS = ["k", "kmers", "nodes", "ccs", "uc_rows", "child_nodes", "prefixes
 class BFT:
     """One Bloom Filter Trie resident in the HBM of one MI355X (replaces BFT_Root, include/Node.h:96-122)."""
 
-    def __init__(self, k, device=0, r1=0, r2=0):
+    def __init__(self, k, device=0, r1=0, r2=0, _handle=None):
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.bft_gpu_create_seeded(k, device, r1, r2, C.byref(h)))  # create_cdbg, include/bft.h:62
+        if _handle is not None:
+            h = _handle
+        else:
+            _lib.check(self._lib.bft_gpu_create_seeded(k, device, r1, r2, C.byref(h)))  # create_cdbg, include/bft.h:62
         self._h = h
         self.k = k
         self.nb = kmer_bytes(k)
         self.device = device
+
+    @classmethod
+    def load_bft(cls, path, device=0):
+        """load_BFT (include/bft.h:176)."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.bft_gpu_load_bft(path.encode(), device, C.byref(h)))
+        out = (C.c_uint64 * 16)()
+        _lib.check(lib.bft_gpu_info(h, out, 16))
+        return cls(int(out[0]), device=device, _handle=h)
+
+    def write_bft(self, path):
+        """write_BFT (include/bft.h:175)."""
+        _lib.check(self._lib.bft_gpu_write_bft(self._h, path.encode()))
 
     # -- lifecycle ----------------------------------------------------------------------------------------------
     def close(self):

@@ -1,0 +1,551 @@
+// bft_file.cpp -- the reference's serialised .bft format, host side.
+//
+//   bft_file_read : read_BFT_Root / read_Node / read_UC / read_CC (src/write_to_disk.c:260-776) reduced to what
+//                   the GPU build needs: every stored k-mer with its sorted genome-id list, decoded from the
+//                   reference's annotation encodings (modes 0/1/2, src/annotation.c:2086-2250; the one extra
+//                   byte of the extended-annotation table, src/UC.c:501-521).  Bloom filters and skip tables
+//                   are not in the file; the image rebuilds its own.
+//   bft_file_write: write_BFT_Root / write_Node / write_UC / write_CC (src/write_to_disk.c:21-258) from a host copy
+//                   of the image arrays, in the reference's container layout (filter2 | filter3 |
+//                   extra_filter3 or in-row cluster flags | children_type | 128-prefix UC buckets | child Nodes).
+// File (de)serialisation is host work in the reference too; nothing here is on the query path.
+#include "bft_file.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "bft_index.h"
+#include "bft_walk.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// annotation codec (src/annotation.c)
+// ------------------------------------------------------------------------------------------------
+int nb_bytes_id(uint32_t id) {  // get_nb_bytes_power2_annot, include/log2.h:45-50
+    int bits = id ? 32 - __builtin_clz(id) : 1;
+    return (bits + 5) / 6;
+}
+
+int put_id(uint8_t* out, uint32_t id, uint8_t start_flag, uint8_t cont_flag) {
+    const int nb = nb_bytes_id(id);
+    for (int j = 0; j < nb; j++) out[j] = (uint8_t)((((id >> (6 * (nb - 1 - j))) & 0x3f) << 2) | (j == 0 ? start_flag : cont_flag));
+    return nb;
+}
+
+// smallest of the three live encodings (tie rules of compute_best_mode, src/annotation.c:634-650)
+void annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) {
+    out.clear();
+    if (n == 0) { out.push_back(0); return; }
+    size_t s1 = 0, s2 = 0;
+    for (uint32_t a = 0; a < n;) {
+        uint32_t b = a;
+        while (b + 1 < n && ids[b + 1] == ids[b] + 1) b++;
+        s1 += nb_bytes_id(ids[a]) + nb_bytes_id(ids[b]);
+        a = b + 1;
+    }
+    for (uint32_t a = 0; a < n; a++) s2 += nb_bytes_id(ids[a]);
+    const size_t s0 = (3 + (size_t)ids[n - 1] + 7) / 8;
+    int mode;
+    size_t sz;
+    if (s2 <= s1) { mode = 2; sz = s2; } else { mode = 1; sz = s1; }
+    if (sz >= s0) { mode = 0; sz = s0; }
+    out.assign(sz, 0);
+    if (mode == 0) {
+        for (uint32_t a = 0; a < n; a++) out[(ids[a] + 2) / 8] |= (uint8_t)(1u << ((ids[a] + 2) % 8));
+    } else if (mode == 1) {
+        size_t o = 0;
+        for (uint32_t a = 0; a < n;) {
+            uint32_t b = a;
+            while (b + 1 < n && ids[b + 1] == ids[b] + 1) b++;
+            o += put_id(&out[o], ids[a], 0x1, 0x2);
+            o += put_id(&out[o], ids[b], 0x1, 0x2);
+            a = b + 1;
+        }
+    } else {
+        size_t o = 0;
+        for (uint32_t a = 0; a < n; a++) o += put_id(&out[o], ids[a], 0x2, 0x1);
+    }
+}
+
+// get_id_genomes_from_annot, modes 0/1/2 (src/annotation.c:2086-2250)
+bool annot_decode(const uint8_t* a, size_t size, std::vector<uint32_t>& ids) {
+    ids.clear();
+    if (size == 0) return true;
+    const int mode = a[0] & 3;
+    size_t i = 0;
+    if (mode == 0) {
+        for (size_t b = 2; b < size * 8; b++)
+            if (a[b / 8] & (1u << (b % 8))) ids.push_back((uint32_t)(b - 2));
+    } else if (mode == 1) {
+        bool second = false;
+        uint32_t prev = 0;
+        while (i < size && (a[i] & 0x1)) {
+            uint32_t v = a[i++] >> 2;
+            while (i < size && (a[i] & 0x2)) v = (v << 6) | (a[i++] >> 2);
+            if (second) { for (uint32_t j = prev + 1; j <= v && prev != v; j++) ids.push_back(j); }
+            else { ids.push_back(v); prev = v; }
+            second = !second;
+        }
+    } else if (mode == 2) {
+        while (i < size && (a[i] & 0x2)) {
+            uint32_t v = a[i++] >> 2;
+            while (i < size && (a[i] & 0x1)) v = (v << 6) | (a[i++] >> 2);
+            ids.push_back(v);
+        }
+    } else
+        return false;  // mode 3: index into comp_set_colors (Judy-compressed files)
+    return true;
+}
+
+inline int nb_bytes(int i) { return (2 * i + 7) / 8; }
+inline bool level_min_of(int k, int i) { return i == k || i % 36 == 9; }  // src/CC.c:1906-1989
+
+// ------------------------------------------------------------------------------------------------
+// reader: parse the stream into a tree of raw containers, then walk it with the path known
+// ------------------------------------------------------------------------------------------------
+struct Rows {
+    std::vector<uint8_t> data;
+    int size_annot = 0, nbs = 0, count = 0;
+    std::vector<int> ext_pos;
+    std::vector<uint8_t> ext_byte;
+};
+struct PNode;
+struct PCC {
+    int s = 8, n = 0;
+    std::vector<uint8_t> f2, f3, ex;
+    std::vector<uint16_t> cnts;
+    std::vector<Rows> buckets;
+    std::vector<PNode> children;  // child Nodes in prefix order
+};
+struct PNode {
+    int flag = 0;
+    Rows uc;
+    std::vector<PCC> ccs;
+};
+
+struct Reader {
+    FILE* f = nullptr;
+    bool err = false;
+    std::string msg;
+    int k = 0;
+    BftFileContent* out = nullptr;
+    std::vector<uint8_t> cur;  // nucleotide codes of the k-mer being rebuilt
+    std::vector<uint32_t> ids;
+    std::vector<uint8_t> packed;
+
+    void fail(const char* m) { if (!err) { err = true; msg = m; } }
+    void rd(void* p, size_t n) { if (!err && n && fread(p, 1, n, f) != n) fail("truncated file"); }
+    uint16_t u16() { uint16_t v = 0; rd(&v, 2); return v; }
+    uint32_t u32() { uint32_t v = 0; rd(&v, 4); return v; }
+    int32_t i32() { int32_t v = 0; rd(&v, 4); return v; }
+
+    // read_UC, uncompressed branch (src/write_to_disk.c:383-531)
+    void read_rows(Rows& r, int nbs, int count) {
+        r.nbs = nbs; r.count = count;
+        if (!count) return;
+        const uint16_t next = u16();
+        const int32_t sa = i32();
+        if (err) return;
+        if (next == 0xffff || sa < 0 || sa > (1 << 24)) { fail("compressed UC or bad size_annot"); return; }
+        r.size_annot = sa;
+        r.data.resize((size_t)count * (nbs + sa));
+        rd(r.data.data(), r.data.size());
+        int pos = 0;
+        for (int e = 0; e < next && !err; e++) {  // extended annotations: 2-byte big-endian position delta + 1 byte (src/UC.c:501-521)
+            uint8_t t[3];
+            rd(t, 3);
+            pos += (t[0] << 8) | t[1];
+            r.ext_pos.push_back(pos);
+            r.ext_byte.push_back(t[2]);
+        }
+    }
+    void parse_node(PNode& nd, int i) {  // read_Node (src/write_to_disk.c:353-381)
+        const uint16_t field = u16();
+        if (err) return;
+        nd.flag = field & 1;
+        read_rows(nd.uc, nb_bytes(i), field >> 1);
+        const uint32_t ncc = u32();
+        if (err || ncc > (1u << 24)) { fail("bad CC count"); return; }
+        nd.ccs.resize(ncc);
+        for (uint32_t c = 0; c < ncc && !err; c++) parse_cc(nd.ccs[c], i);
+    }
+    void parse_cc(PCC& cc, int i) {  // read_CC (src/write_to_disk.c:533-646)
+        const uint16_t type = u16(), n = u16(), nnodes = u16();
+        if (err) return;
+        cc.s = (type >> 1) & 0x1f;
+        cc.n = n;
+        const int p = 18 - cc.s, tbyte = (type >> 6) & 1;
+        if (cc.s != 4 && cc.s != 8) { fail("bad CC type"); return; }
+        cc.f2.resize((size_t(1) << p) / 8);
+        cc.f3.resize(cc.s == 8 ? n : (n + 1) / 2);
+        cc.ex.assign((n + 7) / 8 + 1, 0);
+        rd(cc.f2.data(), cc.f2.size());
+        rd(cc.f3.data(), cc.f3.size());
+        if (level_min_of(k, i)) rd(cc.ex.data(), (n + 7) / 8);
+        const int nbk = (n + 127) / 128;
+        cc.cnts.assign(n, 1);
+        cc.buckets.resize(nbk);
+        if (i != 9) {
+            std::vector<uint8_t> ct(tbyte ? n : (n + 1) / 2);
+            rd(ct.data(), ct.size());
+            uint32_t zeros = 0;
+            for (int j = 0; j < n; j++) {
+                cc.cnts[j] = tbyte ? ct[j] : ((j & 1) ? ct[j / 2] >> 4 : ct[j / 2] & 0xf);
+                zeros += cc.cnts[j] == 0;
+            }
+            if (zeros != nnodes) { fail("children_type / nb_Node_children mismatch"); return; }
+            for (int b = 0; b < nbk && !err; b++) read_rows(cc.buckets[b], nb_bytes(i - 9), u16());
+            cc.children.resize(nnodes);
+            for (uint32_t c = 0; c < nnodes && !err; c++) parse_node(cc.children[c], i - 9);
+        } else {
+            for (int b = 0; b < nbk && !err; b++) read_rows(cc.buckets[b], 0, b != nbk - 1 ? 128 : n - b * 128);
+        }
+    }
+
+    // ---- second pass: k-mers ----
+    void row_ids(const Rows& r, int q) {  // inline annotation bytes + the extended byte if the row has one
+        const uint8_t* a = r.data.data() + (size_t)q * (r.nbs + r.size_annot) + r.nbs;
+        auto it = std::lower_bound(r.ext_pos.begin(), r.ext_pos.end(), q);
+        bool ok;
+        if (it != r.ext_pos.end() && *it == q) {
+            std::vector<uint8_t> tmp(a, a + r.size_annot);
+            tmp.push_back(r.ext_byte[it - r.ext_pos.begin()]);
+            ok = annot_decode(tmp.data(), tmp.size(), ids);
+        } else
+            ok = annot_decode(a, (size_t)r.size_annot, ids);
+        if (!ok) fail("mode-3 (Judy-compressed) annotations are not supported");
+    }
+    void put_suffix(int at, const uint8_t* bytes, int len_nt, bool mask_flag) {
+        const int last = nb_bytes(len_nt) - 1;
+        for (int j = 0; j < len_nt; j++) {
+            uint8_t b = bytes[j / 4];
+            if (mask_flag && j / 4 == last) b &= 0x7f;
+            cur[at + j] = (b >> (2 * (j % 4))) & 3;
+        }
+    }
+    void put_prefix(int at, uint32_t r) {  // r = n2..n9,n1
+        cur[at] = r & 3;
+        for (int j = 1; j < 9; j++) cur[at + j] = (r >> (2 * (9 - j))) & 3;
+    }
+    void emit() {
+        const int B = nb_bytes(k);
+        packed.assign(B, 0);
+        for (int j = 0; j < k; j++) packed[j / 4] |= (uint8_t)(cur[j] << (2 * (j % 4)));
+        for (uint32_t g : ids) {
+            if (g >= out->per_genome.size()) out->per_genome.resize((size_t)g + 1);
+            out->per_genome[g].insert(out->per_genome[g].end(), packed.begin(), packed.end());
+        }
+        out->n_kmers++;
+    }
+    void emit_node(const PNode& nd, int i) {
+        const int at = k - i;
+        for (int q = 0; q < nd.uc.count && !err; q++) {
+            put_suffix(at, nd.uc.data.data() + (size_t)q * (nd.uc.nbs + nd.uc.size_annot), i, false);
+            row_ids(nd.uc, q);
+            emit();
+        }
+        for (const PCC& cc : nd.ccs) emit_cc(cc, i);
+    }
+    void emit_cc(const PCC& cc, int i) {
+        if (err) return;
+        const int n = cc.n, s = cc.s, p = 18 - s, at = k - i, nbk = (n + 127) / 128;
+        const bool lm = level_min_of(k, i);
+        // cluster starts: extra_filter3, or on level_min == 0 levels bit 7 of the group's first row / bit 0 of the child
+        // Node's UC.nb_children (src/presenceNode.c:1690-1812)
+        std::vector<uint8_t> starts(n, 0);
+        if (lm || i == 9) {
+            for (int j = 0; j < n; j++) starts[j] = (cc.ex[j >> 3] >> (j & 7)) & 1;
+        } else {
+            std::vector<int> row_at(nbk, 0);
+            size_t cn = 0;
+            for (int j = 0; j < n; j++) {
+                const int b = j / 128;
+                if (cc.cnts[j] == 0) { starts[j] = (uint8_t)cc.children[cn++].flag; continue; }
+                const Rows& r = cc.buckets[b];
+                if (row_at[b] + cc.cnts[j] > r.count) { fail("children_type / bucket mismatch"); return; }
+                starts[j] = r.data[(size_t)row_at[b] * (r.nbs + r.size_annot) + r.nbs - 1] >> 7;
+                row_at[b] += cc.cnts[j];
+            }
+        }
+        std::vector<uint32_t> rs(n, 0);
+        {
+            int j = 0;
+            for (int pu = 0; pu < (1 << p); pu++) {
+                if (!(cc.f2[pu >> 3] & (1u << (pu & 7)))) continue;
+                bool first = true;
+                while (j < n && (first || !starts[j])) {
+                    const uint32_t pv = s == 8 ? cc.f3[j] : ((j & 1) ? cc.f3[j / 2] >> 4 : cc.f3[j / 2] & 0xf);
+                    rs[j++] = ((uint32_t)pu << s) | pv;
+                    first = false;
+                }
+            }
+            if (j != n) { fail("filter2 / cluster starts mismatch"); return; }
+        }
+        std::vector<int> row_at(nbk, 0);
+        size_t cn = 0;
+        for (int j = 0; j < n && !err; j++) {
+            const int b = j / 128;
+            put_prefix(at, rs[j]);
+            if (i == 9) {
+                row_ids(cc.buckets[b], j % 128);
+                emit();
+            } else if (cc.cnts[j] == 0) {
+                emit_node(cc.children[cn++], i - 9);
+            } else {
+                const Rows& r = cc.buckets[b];
+                if (row_at[b] + cc.cnts[j] > r.count) { fail("children_type / bucket mismatch"); return; }
+                for (int q = 0; q < cc.cnts[j]; q++) {
+                    const int row = row_at[b] + q;
+                    put_suffix(at + 9, r.data.data() + (size_t)row * (r.nbs + r.size_annot), i - 9, !lm);
+                    row_ids(r, row);
+                    emit();
+                }
+                row_at[b] += cc.cnts[j];
+            }
+        }
+    }
+};
+
+}  // namespace
+
+bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
+    out = BftFileContent();
+    Reader R;
+    R.f = fopen(path, "rb");
+    if (!R.f) { err = std::string("cannot open ") + path; return false; }
+    const int lcs = R.i32();
+    if (lcs != 0) { fclose(R.f); err = "file holds Judy-compressed colour sets (mode-3 annotations): not supported"; return false; }
+    out.r1 = R.i32();
+    out.r2 = R.i32();
+    (void)R.i32();
+    const int nbg = R.i32();
+    out.k = R.i32();
+    uint8_t comp = 0;
+    R.rd(&comp, 1);
+    if (R.err || comp != 0 || nbg < 0 || nbg > 100000000 || !bft_valid_k(out.k)) { fclose(R.f); err = "bad .bft header"; return false; }
+    for (int g = 0; g < nbg && !R.err; g++) {
+        const uint16_t len = R.u16();
+        std::string name(len, '\0');
+        R.rd(&name[0], len);
+        if (!name.empty() && name.back() == '\0') name.pop_back();
+        out.genomes.push_back(name);
+    }
+    for (int i = 9; i <= out.k && !R.err; i += 9)
+        for (int q = 0; q < 7; q++) (void)R.i32();
+    R.k = out.k;
+    R.out = &out;
+    R.cur.assign(out.k, 0);
+    PNode root;
+    if (!R.err) R.parse_node(root, out.k);
+    fclose(R.f);
+    if (!R.err) R.emit_node(root, out.k);
+    if (R.err) { err = R.msg; return false; }
+    if (out.per_genome.size() < (size_t)nbg) out.per_genome.resize(nbg);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// writer
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Writer {
+    FILE* f;
+    const BftHostImage& im;
+    int k, L, W;
+    bool err = false;
+    std::vector<uint8_t> enc;
+
+    void wr(const void* p, size_t n) { if (!err && n && fwrite(p, 1, n, f) != n) err = true; }
+    void u16(uint16_t v) { wr(&v, 2); }
+    void u32(uint32_t v) { wr(&v, 4); }
+    void i32(int32_t v) { wr(&v, 4); }
+
+    // nucleotides [from, k) of the k-mer at T-form row -> packed suffix bytes
+    template <int WW>
+    void suffix_bytes_w(const uint64_t* t, int from, uint8_t* out, int nbytes) const {
+        uint64_t x[WW];
+        bft_x_from_tform<WW>(t, L, x);
+        memset(out, 0, (size_t)nbytes);
+        for (int j = from; j < k; j++) {
+            const uint32_t code = (uint32_t)(x[(2 * j) >> 6] >> ((2 * j) & 63)) & 3u;
+            const int q = j - from;
+            out[q / 4] |= (uint8_t)(code << (2 * (q % 4)));
+        }
+    }
+    void suffix_bytes(const uint64_t* t, int from, uint8_t* out, int nbytes) const {
+        switch (W) {
+        case 1: suffix_bytes_w<1>(t, from, out, nbytes); break;
+        case 2: suffix_bytes_w<2>(t, from, out, nbytes); break;
+        case 3: suffix_bytes_w<3>(t, from, out, nbytes); break;
+        default: suffix_bytes_w<4>(t, from, out, nbytes); break;
+        }
+    }
+    void annot_of_row(uint64_t row, std::vector<uint8_t>& a) {
+        const uint32_t cs = im.tcol[row];
+        annot_encode(&im.cs_ids[im.cs_off[cs]], im.cs_off[cs + 1] - im.cs_off[cs], a);
+    }
+
+    // rows (given by tk row indices) -> sorted by memcmp of the suffix bytes, with annotations; write_UC layout
+    struct Block { std::vector<uint8_t> data; int size_annot = 0; int count = 0; };
+    void make_rows(const std::vector<uint64_t>& rows, int from_nt, int nbs, std::vector<std::vector<uint8_t>>& suf, std::vector<std::vector<uint8_t>>& ann) {
+        suf.assign(rows.size(), std::vector<uint8_t>(nbs));
+        ann.assign(rows.size(), std::vector<uint8_t>());
+        std::vector<size_t> order(rows.size());
+        for (size_t q = 0; q < rows.size(); q++) {
+            suffix_bytes(&im.tk[rows[q] * W], from_nt, suf[q].data(), nbs);
+            annot_of_row(rows[q], ann[q]);
+            order[q] = q;
+        }
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return memcmp(suf[a].data(), suf[b].data(), (size_t)nbs) < 0; });
+        std::vector<std::vector<uint8_t>> s2(rows.size()), a2(rows.size());
+        for (size_t q = 0; q < rows.size(); q++) { s2[q].swap(suf[order[q]]); a2[q].swap(ann[order[q]]); }
+        suf.swap(s2);
+        ann.swap(a2);
+    }
+    void write_block(const std::vector<std::vector<uint8_t>>& suf, const std::vector<std::vector<uint8_t>>& ann, int nbs, int header_field, bool with_header) {
+        if (with_header) u16((uint16_t)header_field);
+        if (suf.empty()) return;
+        size_t sa = 1;
+        for (auto& a : ann) sa = std::max(sa, a.size());
+        u16(0);  // nb_extended_annot
+        i32((int32_t)sa);
+        std::vector<uint8_t> line(nbs + sa);
+        for (size_t q = 0; q < suf.size(); q++) {
+            std::fill(line.begin(), line.end(), 0);
+            if (nbs) memcpy(line.data(), suf[q].data(), (size_t)nbs);
+            memcpy(line.data() + nbs, ann[q].data(), ann[q].size());
+            wr(line.data(), line.size());
+        }
+    }
+
+    void write_node(uint32_t node, int d, int flag) {
+        const BftNode& nd = im.nodes[node];
+        const int i = k - 9 * d;
+        {   // node UC (write_Node -> write_UC, src/write_to_disk.c:84-105)
+            std::vector<uint64_t> rows;
+            for (uint32_t q = 0; q < nd.uc_n; q++) rows.push_back(im.ucrow[nd.uc_first + q]);
+            std::vector<std::vector<uint8_t>> suf, ann;
+            make_rows(rows, 9 * d, nb_bytes(i), suf, ann);
+            write_block(suf, ann, nb_bytes(i), (nd.uc_n << 1) | flag, true);
+        }
+        u32(nd.ncc);
+        for (uint32_t c = 0; c < nd.ncc && !err; c++) write_cc(im.ccs[nd.cc_first + c], d, c + 1 == nd.ncc);
+    }
+
+    void write_cc(const BftCC& cc, int d, bool last) {
+        const int i = k - 9 * d, s = cc.s, p = 18 - s, n = cc.nb_elem;
+        const bool lm = level_min_of(k, i), leaf = i == 9;
+        // prefixes in filter3 order, from the filter2 words and the cluster table
+        struct P { uint32_t r; uint32_t cnt; uint64_t idx; bool start; };
+        std::vector<P> prefs;
+        prefs.reserve(n);
+        std::vector<uint8_t> f2((size_t(1) << p) / 8, 0);
+        const size_t nwords = ((size_t(1) << p) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+        uint32_t clu = 0;
+        for (size_t w = 0; w < nwords; w++) {
+            const uint64_t fw = im.f2w[cc.f2_off + w];
+            for (int b = 0; b < BFT_F2_BITS_PER_WORD; b++) {
+                if (!((fw >> b) & 1ull)) continue;
+                const uint32_t pu = (uint32_t)(w * BFT_F2_BITS_PER_WORD + b);
+                f2[pu >> 3] |= (uint8_t)(1u << (pu & 7));
+                uint64_t e = im.clus[cc.clus_off + clu++];
+                if (e & BFT_CLUS_MULTI) {
+                    const uint32_t st = (uint32_t)e, len = (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
+                    for (uint32_t q = 0; q < len; q++) {
+                        const uint64_t m = im.child[cc.child_off + st + q];
+                        prefs.push_back(P{(pu << s) | ((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu), (uint32_t)(m >> BFT_CHILD_CNT_SHIFT) & 0xFFu, m & BFT_CHILD_IDX_MASK, q == 0});
+                    }
+                } else
+                    prefs.push_back(P{(pu << s) | ((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu), (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu, e & BFT_CHILD_IDX_MASK, true});
+            }
+        }
+        if ((int)prefs.size() != n) { err = true; return; }
+        bool tbyte = false;
+        uint16_t nnodes = 0;
+        if (!leaf)
+            for (auto& pf : prefs) { if (pf.cnt >= 16) tbyte = true; if (pf.cnt == 0) nnodes++; }
+        u16((uint16_t)((188u << 7) | ((tbyte ? 1u : 0u) << 6) | ((uint32_t)s << 1) | (last ? 1u : 0u)));
+        u16((uint16_t)n);
+        u16(nnodes);
+        wr(f2.data(), f2.size());
+        std::vector<uint8_t> f3(s == 8 ? n : (n + 1) / 2, 0), ex((n + 7) / 8, 0);
+        for (int j = 0; j < n; j++) {
+            const uint32_t pv = prefs[j].r & ((1u << s) - 1u);
+            if (s == 8) f3[j] = (uint8_t)pv;
+            else f3[j / 2] |= (uint8_t)((j & 1) ? (pv << 4) : pv);
+            if (prefs[j].start) ex[j >> 3] |= (uint8_t)(1u << (j & 7));
+        }
+        wr(f3.data(), f3.size());
+        if (lm) wr(ex.data(), ex.size());
+        const int nbk = (n + 127) / 128;
+        if (!leaf) {
+            std::vector<uint8_t> ct(tbyte ? n : (n + 1) / 2, 0);
+            for (int j = 0; j < n; j++) {
+                if (tbyte) ct[j] = (uint8_t)prefs[j].cnt;
+                else ct[j / 2] |= (uint8_t)((j & 1) ? (prefs[j].cnt << 4) : prefs[j].cnt);
+            }
+            wr(ct.data(), ct.size());
+            const int nbs = nb_bytes(i - 9);
+            for (int b = 0; b < nbk && !err; b++) {
+                std::vector<std::vector<uint8_t>> bsuf, bann;
+                for (int j = b * 128; j < std::min(n, b * 128 + 128); j++) {
+                    if (!prefs[j].cnt) continue;
+                    std::vector<uint64_t> rows;
+                    for (uint32_t q = 0; q < prefs[j].cnt; q++) rows.push_back(prefs[j].idx + q);
+                    std::vector<std::vector<uint8_t>> suf, ann;
+                    make_rows(rows, 9 * (d + 1), nbs, suf, ann);
+                    if (!lm && prefs[j].start) suf[0][nbs - 1] |= 0x80;  // cluster-start flag, src/CC.c:349-352
+                    for (size_t q = 0; q < suf.size(); q++) { bsuf.push_back(std::move(suf[q])); bann.push_back(std::move(ann[q])); }
+                }
+                write_block(bsuf, bann, nbs, (int)bsuf.size(), true);
+            }
+        } else {
+            for (int b = 0; b < nbk && !err; b++) {
+                std::vector<std::vector<uint8_t>> bsuf, bann;
+                for (int j = b * 128; j < std::min(n, b * 128 + 128); j++) {
+                    bsuf.push_back(std::vector<uint8_t>());
+                    bann.push_back(std::vector<uint8_t>());
+                    annot_of_row(prefs[j].idx, bann.back());
+                }
+                write_block(bsuf, bann, 0, 0, false);
+            }
+        }
+        if (!leaf)
+            for (int j = 0; j < n && !err; j++)
+                if (prefs[j].cnt == 0) write_node((uint32_t)prefs[j].idx, d + 1, (!lm && prefs[j].start) ? 1 : 0);  // src/insertNode.c:308-311
+    }
+};
+
+}  // namespace
+
+bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) {
+    FILE* f = fopen(path, "wb");
+    if (!f) { err = std::string("cannot create ") + path; return false; }
+    Writer w{f, im, im.k, im.k / 9, bft_words_for_k(im.k)};
+    w.i32(0);  // length_comp_set_colors
+    w.i32(im.r1);
+    w.i32(im.r2);
+    w.i32(0);  // treshold_compression
+    w.i32((int32_t)im.genomes.size());
+    w.i32(im.k);
+    const uint8_t comp = 0;
+    w.wr(&comp, 1);
+    for (const std::string& g : im.genomes) {
+        w.u16((uint16_t)(g.size() + 1));
+        w.wr(g.c_str(), g.size() + 1);
+    }
+    for (int i = 9; i <= im.k; i += 9) {  // src/write_to_disk.c:76-84
+        w.i32(128); w.i32(128); w.i32(128); w.i32(255);
+        w.i32(level_min_of(im.k, i) ? 1 : 0);
+        w.i32(BFT_MODULO_HASH);
+        w.i32(BFT_TRESH_SUF_PREF);
+    }
+    w.write_node(0, 0, 0);
+    fclose(f);
+    if (w.err) { err = "write error or inconsistent image"; return false; }
+    return true;
+}

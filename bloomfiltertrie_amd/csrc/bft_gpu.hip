@@ -22,6 +22,7 @@
 
 #include "../../include/bft_gpu.h"
 #include "bft_dev.h"
+#include "bft_file.h"
 #include "bft_hash.h"
 #include "bft_image.h"
 #include "bft_index.h"
@@ -821,6 +822,64 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // ------------------------------------------------------------------------------------------------
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// .bft files
+// ------------------------------------------------------------------------------------------------
+extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
+    if (!path || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
+    *out = nullptr;
+    BftFileContent fc;
+    std::string err;
+    if (!bft_file_read(path, fc, err)) return fail(BFT_GPU_E_IO, err);
+    bft_gpu* h = nullptr;
+    CK(bft_gpu_create_seeded(fc.k, device, fc.r1, fc.r2, &h));
+    int rc = 0;
+    for (const std::string& g : fc.genomes) h->genomes.push_back(g);
+    const size_t B = (size_t)h->B;
+    for (size_t g = 0; g < fc.per_genome.size() && rc == 0; g++)
+        if (!fc.per_genome[g].empty()) rc = bft_gpu_insert_kmers(h, fc.per_genome[g].data(), fc.per_genome[g].size() / B, (uint32_t)g);
+    if (rc == 0) rc = bft_gpu_build(h);
+    if (rc != 0) {
+        const std::string keep = g_err;
+        bft_gpu_free(h);
+        return fail(rc, keep);
+    }
+    *out = h;
+    return BFT_GPU_OK;
+}
+
+template <class T>
+static int download(const DevBuf& d, uint64_t bytes, std::vector<T>& v) {
+    v.assign(bytes / sizeof(T), T());
+    if (bytes) HIPCK(hipMemcpy(v.data(), d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
+    if (!h || !path) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    BftHostImage hi;
+    hi.k = h->k;
+    hi.r1 = h->r1;
+    hi.r2 = h->r2;
+    hi.genomes = h->genomes;
+    while (hi.genomes.size() < h->im.nb_genomes) hi.genomes.push_back("genome_" + std::to_string(hi.genomes.size()));
+    CK(download(h->d_nodes, h->idx_sizes[0], hi.nodes));
+    CK(download(h->d_ccs, h->idx_sizes[2], hi.ccs));
+    CK(download(h->d_f2w, h->idx_sizes[3], hi.f2w));
+    CK(download(h->d_clus, h->idx_sizes[4], hi.clus));
+    CK(download(h->d_child, h->idx_sizes[5], hi.child));
+    CK(download(h->d_ucrow, h->idx_sizes[7], hi.ucrow));
+    CK(download(h->d_tk, h->idx_sizes[8], hi.tk));
+    CK(download(h->d_tcol, h->n_kmers * 4, hi.tcol));
+    hi.cs_off = h->cs_off;
+    hi.cs_ids = h->cs_ids;
+    std::string err;
+    if (!bft_file_write(path, hi, err)) return fail(BFT_GPU_E_IO, err);
+    return BFT_GPU_OK;
+}
+
 // Test hook (tests/test_gpu_build.py): raw copy of one index array of the image.
 extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");

@@ -152,3 +152,34 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     if (out) { if (cap < n) return -6; memcpy(out, p, n); }
     return 0;
 }
+
+// ---- .bft reader / writer (bft_file.cpp) on the CPU ----
+#include "bft_file.h"
+
+// product writer fed by the host-built index (single genome "genome_0")
+extern "C" int bft_hosttest_write_bft(void* hv, const char* path) {
+    HostTrie* t = (HostTrie*)hv;
+    BftHostImage hi;
+    hi.k = t->k; hi.r1 = BFT_DEFAULT_R1; hi.r2 = BFT_DEFAULT_R2;
+    hi.genomes = {"genome_0"};
+    hi.nodes = t->idx.nodes; hi.ccs = t->idx.ccs; hi.f2w = t->idx.f2w; hi.clus = t->idx.clus; hi.child = t->idx.child;
+    hi.ucrow = t->idx.ucrow; hi.tk = t->tk; hi.tcol = t->tcol; hi.cs_off = t->cs_off; hi.cs_ids = t->cs_ids;
+    std::string err;
+    return bft_file_write(path, hi, err) ? 0 : -1;
+}
+
+// product reader: returns a handle whose per-genome k-mer lists can be copied out
+extern "C" void* bft_hosttest_read_bft(const char* path, int* k, int* nb_genomes, uint64_t* n_kmers) {
+    BftFileContent* fc = new BftFileContent();
+    std::string err;
+    if (!bft_file_read(path, *fc, err)) { delete fc; return nullptr; }
+    *k = fc->k; *nb_genomes = (int)fc->per_genome.size(); *n_kmers = fc->n_kmers;
+    return fc;
+}
+extern "C" uint64_t bft_hosttest_read_genome(void* fv, int g, uint8_t* out) {
+    BftFileContent* fc = (BftFileContent*)fv;
+    const std::vector<uint8_t>& v = fc->per_genome[g];
+    if (out && !v.empty()) memcpy(out, v.data(), v.size());
+    return v.size();
+}
+extern "C" void bft_hosttest_read_free(void* fv) { delete (BftFileContent*)fv; }

@@ -86,6 +86,14 @@ int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, ui
 int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
                              uint8_t* rows);
 
+/* load_BFT / read_BFT_Root (include/bft.h:176, src/write_to_disk.c:260-776): parse a reference .bft file
+ * (compressed == 0; annotation modes 0/1/2 and extended-annotation bytes) and build the GPU image from its
+ * k-mers and colour sets, with the file's Bloom seeds and genome names. */
+int bft_gpu_load_bft(const char* path, int device, bft_gpu** out);
+/* write_BFT / write_BFT_Root (include/bft.h:175, src/write_to_disk.c:21-258): serialise the image in the
+ * reference's container layout so that the reference's `bft load` reads it back (invariants of SURVEY.md A.7). */
+int bft_gpu_write_bft(bft_gpu* h, const char* path);
+
 /* Shape / size counters (the walk of src/printMemory.c:255).  out[0]=k, [1]=distinct k-mers,
  * [2]=nodes, [3]=CCs, [4]=node-UC rows, [5]=child nodes, [6]=prefixes, [7]=CCs in s=4 mode,
  * [8]=max CCs per node, [9]=(k-mer,genome) pairs, [10]=distinct colour sets, [11]=genomes,

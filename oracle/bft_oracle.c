@@ -320,6 +320,7 @@ struct orc_bft {
     uint16_t *hmod;     /* hash_v % 1504 for the 2^14 keys used when compressed==0 */
     orc_node root;
     int dirty;
+    int nb_genomes_loaded;
     long nkmers;
     /* colour sets, interned; set 0 is empty */
     uint32_t *cs_ids; long cs_ids_n, cs_ids_cap;
@@ -1270,3 +1271,272 @@ long orc_extract(orc_bft *t, uint8_t *kmers_out, uint32_t *cs_out) {
     memset(cur, 0, sizeof(cur));
     return extract_node(t, &t->root, t->k, cur, kmers_out, cs_out, 0);
 }
+
+/* ------------------------------------------------------------------ */
+/* .bft writer / reader (src/write_to_disk.c)                         */
+/* ------------------------------------------------------------------ */
+
+static inline int level_min_of(const orc_bft *t, int i) { return i == t->k || i % 36 == 9; } /* src/CC.c:1906-1989 */
+
+static void wr(FILE *f, const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) { fprintf(stderr, "oracle: write error\n"); exit(1); } }
+static void wr_u16(FILE *f, uint16_t v) { wr(f, &v, 2); }
+static void wr_u32(FILE *f, uint32_t v) { wr(f, &v, 4); }
+static void wr_i32(FILE *f, int32_t v) { wr(f, &v, 4); }
+
+/* write_UC, uncompressed branch (src/write_to_disk.c:107-213) */
+static void write_uc(FILE *f, const uint8_t *data, int size_annot, int nbs, int count, int header_field, int with_header) {
+    if (with_header) wr_u16(f, (uint16_t)header_field);
+    if (count) {
+        wr_u16(f, 0);             /* nb_extended_annot */
+        wr_i32(f, size_annot);    /* UC_SIZE_ANNOT_T */
+        wr(f, data, (size_t)count * (nbs + size_annot));
+    }
+}
+
+static void write_node(FILE *f, orc_bft *t, orc_node *nd, int i, int flag);
+
+/* write_CC (src/write_to_disk.c:215-258) */
+static void write_cc(FILE *f, orc_bft *t, orc_cc *cc, int i) {
+    int s = (cc->type >> 1) & 0x1f, p = 18 - s, n = cc->nb_elem, lm = level_min_of(t, i);
+    wr_u16(f, cc->type);
+    wr_u16(f, cc->nb_elem);
+    wr_u16(f, cc->nb_Node_children);
+    wr(f, cc->BF_filter2 + SIZE_BF_BYTES, (size_t)(1 << p) / 8);
+    wr(f, cc->filter3, (size_t)(s == 8 ? n : CEIL(n, 2)));
+    if (lm) wr(f, cc->extra_filter3, (size_t)CEIL(n, 8));
+    int nbk = CEIL(n, NB_UC_PER_SKP);
+    if (i != 9) {
+        int type = (cc->type >> 6) & 1, nbs = nbm1_bytes(i);
+        wr(f, cc->children_type, (size_t)(type ? n : CEIL(n, 2)));
+        for (int b = 0; b < nbk; b++) {
+            orc_uc *uc = &cc->children[b];
+            int stride = nbs + uc->size_annot;
+            uint8_t *tmp = xmalloc((size_t)uc->nb_children * stride + 1);
+            if (uc->nb_children) memcpy(tmp, uc->suffixes, (size_t)uc->nb_children * stride);
+            if (!lm) { /* cluster-start flags live in bit 7 of the first row's last suffix byte (src/CC.c:349-352) */
+                int row = 0, j1 = b * 128 + 128 < n ? b * 128 + 128 : n;
+                for (int j = b * 128; j < j1; j++) {
+                    int cnt = getNbElts(cc, j, type);
+                    if (cnt && (cc->extra_filter3[j >> 3] & (1u << (j & 7)))) tmp[(size_t)row * stride + nbs - 1] |= 0x80;
+                    row += cnt;
+                }
+            }
+            write_uc(f, tmp, uc->size_annot, nbs, uc->nb_children, uc->nb_children, 1);
+            free(tmp);
+        }
+    } else {
+        for (int b = 0; b < nbk; b++) {
+            int cnt = b != nbk - 1 ? NB_UC_PER_SKP : n - b * NB_UC_PER_SKP;
+            write_uc(f, cc->children[b].suffixes, cc->children[b].size_annot, 0, cnt, 0, 0);
+        }
+    }
+    if (i != 9) {
+        int type = (cc->type >> 6) & 1, kn = 0;
+        for (int j = 0; j < n; j++)
+            if (getNbElts(cc, j, type) == 0) {
+                int flag = !lm && (cc->extra_filter3[j >> 3] & (1u << (j & 7))) ? 1 : 0; /* src/insertNode.c:308-311 */
+                write_node(f, t, cc->children_nodes[kn++], i - 9, flag);
+            }
+    }
+}
+
+/* write_Node (src/write_to_disk.c:84-105) */
+static void write_node(FILE *f, orc_bft *t, orc_node *nd, int i, int flag) {
+    write_uc(f, nd->fuc.suffixes, nd->fuc.size_annot, nb_bytes(i), nd->uc_n, (nd->uc_n << 1) | flag, 1);
+    wr_u32(f, (uint32_t)nd->ncc);
+    for (int c = 0; c < nd->ncc; c++) write_cc(f, t, &nd->ccs[c], i);
+}
+
+int orc_write_bft(orc_bft *t, const char *path, int nb_genomes) {
+    orc_freeze(t);
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    wr_i32(f, 0); /* length_comp_set_colors */
+    wr_i32(f, t->r1); wr_i32(f, t->r2); wr_i32(f, 0 /* treshold_compression */); wr_i32(f, nb_genomes); wr_i32(f, t->k);
+    uint8_t comp = 0;
+    wr(f, &comp, 1);
+    for (int g = 0; g < nb_genomes; g++) {
+        char name[64];
+        snprintf(name, sizeof(name), "genome_%d", g);
+        wr_u16(f, (uint16_t)(strlen(name) + 1));
+        wr(f, name, strlen(name) + 1);
+    }
+    for (int i = 9; i <= t->k; i += 9) { /* src/write_to_disk.c:76-84 */
+        wr_i32(f, NB_UC_PER_SKP); wr_i32(f, NB_UC_PER_SKP); wr_i32(f, NB_UC_PER_SKP); wr_i32(f, NB_KMERS_PER_UC);
+        wr_i32(f, level_min_of(t, i)); wr_i32(f, MODULO_HASH); wr_i32(f, TRESH_SUF_PREF);
+    }
+    write_node(f, t, &t->root, t->k, 0);
+    fclose(f);
+    return 0;
+}
+
+typedef struct { FILE *f; int err; int nb_genomes; } rd_ctx;
+static void rd(rd_ctx *c, void *p, size_t n) { if (n && fread(p, 1, n, c->f) != n) c->err = 1; }
+static uint16_t rd_u16(rd_ctx *c) { uint16_t v = 0; rd(c, &v, 2); return v; }
+static uint32_t rd_u32(rd_ctx *c) { uint32_t v = 0; rd(c, &v, 4); return v; }
+static int32_t rd_i32(rd_ctx *c) { int32_t v = 0; rd(c, &v, 4); return v; }
+
+static uint32_t cs_from_annot(orc_bft *t, const uint8_t *annot, int size) {
+    uint32_t ids[4096];
+    int n = orc_annot_decode(annot, size, ids, 4096);
+    uint32_t cs = 0;
+    for (int a = 0; a < n && a < 4096; a++) cs = cs_add(t, cs, ids[a]);
+    return cs;
+}
+
+/* read_UC uncompressed branch (src/write_to_disk.c:383-531): returns rows (nbs + size_annot each) */
+static uint8_t *read_uc(rd_ctx *c, int nbs, int count, int *size_annot) {
+    *size_annot = 0;
+    if (!count) return NULL;
+    uint16_t next = rd_u16(c);
+    int32_t sa = rd_i32(c);
+    if (c->err || sa < 0 || sa > (1 << 20) || next == 0xffff) { c->err = 1; return NULL; }
+    size_t n = (size_t)count * (nbs + sa) + (size_t)next * 3;
+    uint8_t *buf = xmalloc(n);
+    rd(c, buf, n);
+    if (next) c->err = 1; /* extended annotations are never produced by the writers in this repository */
+    *size_annot = sa;
+    return buf;
+}
+
+static void load_node(rd_ctx *c, orc_bft *t, orc_node *nd, int i, int *flag_out);
+
+static void load_cc(rd_ctx *c, orc_bft *t, orc_cc *cc, int i) {
+    memset(cc, 0, sizeof(*cc));
+    uint16_t type = rd_u16(c), n = rd_u16(c), nnodes = rd_u16(c);
+    int s = (type >> 1) & 0x1f, p = 18 - s, tbyte = (type >> 6) & 1, lm = level_min_of(t, i);
+    if (c->err || (s != 4 && s != 8)) { c->err = 1; return; }
+    uint8_t *f2 = xmalloc((size_t)(1 << p) / 8), *f3 = xmalloc((size_t)(s == 8 ? n : CEIL(n, 2)) + 1), *ex = xcalloc(1, (size_t)CEIL(n, 8) + 1);
+    rd(c, f2, (size_t)(1 << p) / 8);
+    rd(c, f3, (size_t)(s == 8 ? n : CEIL(n, 2)));
+    if (lm) rd(c, ex, (size_t)CEIL(n, 8));
+    int nbk = CEIL(n, NB_UC_PER_SKP);
+    uint16_t *cnts = xcalloc((size_t)n + 1, 2);
+    cc->prefs = xcalloc((size_t)n + 1, sizeof(orc_pref));
+    cc->n = cc->cap = n;
+    if (i != 9) {
+        int nbs = nbm1_bytes(i);
+        uint8_t *ct = xmalloc((size_t)(tbyte ? n : CEIL(n, 2)) + 1);
+        rd(c, ct, (size_t)(tbyte ? n : CEIL(n, 2)));
+        for (int j = 0; j < n; j++) cnts[j] = tbyte ? ct[j] : ((j & 1) ? ct[j / 2] >> 4 : ct[j / 2] & 0xf);
+        free(ct);
+        for (int b = 0; b < nbk && !c->err; b++) {
+            int cnt = rd_u16(c), sa;
+            uint8_t *rows = read_uc(c, nbs, cnt, &sa);
+            int row = 0, j1 = b * 128 + 128 < n ? b * 128 + 128 : n;
+            for (int j = b * 128; j < j1 && !c->err; j++) {
+                orc_pref *pf = &cc->prefs[j];
+                pf->cnt = cnts[j];
+                if (!cnts[j]) continue;
+                if (row + cnts[j] > cnt) { c->err = 1; break; }
+                pf->c.rows = xmalloc((size_t)cnts[j] * (nbs + 4));
+                for (int q = 0; q < cnts[j]; q++) {
+                    uint8_t *src = rows + (size_t)(row + q) * (nbs + sa), *dst = pf->c.rows + (size_t)q * (nbs + 4);
+                    memcpy(dst, src, (size_t)nbs);
+                    if (!lm && q == 0) { if (dst[nbs - 1] & 0x80) ex[j >> 3] |= (uint8_t)(1u << (j & 7)); }
+                    if (!lm) dst[nbs - 1] &= 0x7f;
+                    row_set_cs(dst, nbs, cs_from_annot(t, src + nbs, sa));
+                }
+                row += cnts[j];
+            }
+            free(rows);
+        }
+        for (int j = 0; j < n && !c->err; j++)
+            if (!cnts[j]) {
+                int flag = 0;
+                cc->prefs[j].c.node = xcalloc(1, sizeof(orc_node));
+                load_node(c, t, cc->prefs[j].c.node, i - 9, &flag);
+                if (!lm && flag) ex[j >> 3] |= (uint8_t)(1u << (j & 7));
+            }
+    } else {
+        for (int b = 0; b < nbk && !c->err; b++) {
+            int cnt = b != nbk - 1 ? NB_UC_PER_SKP : n - b * NB_UC_PER_SKP, sa;
+            uint8_t *rows = read_uc(c, 0, cnt, &sa);
+            for (int q = 0; q < cnt && !c->err; q++) { cc->prefs[b * 128 + q].cnt = 1; cc->prefs[b * 128 + q].c.cs = cs_from_annot(t, rows + (size_t)q * sa, sa); }
+            free(rows);
+        }
+    }
+    (void)nnodes;
+    /* prefixes: walk filter2 bits and the cluster starts, as read_CC does to rebuild the Bloom filter (:649-681) */
+    int j = 0;
+    for (int pu = 0; pu < (1 << p) && !c->err; pu++) {
+        if (!(f2[pu >> 3] & (1u << (pu & 7)))) continue;
+        int first = 1;
+        while (j < n && (first || !(ex[j >> 3] & (1u << (j & 7))))) {
+            uint32_t pv = s == 8 ? f3[j] : ((j & 1) ? f3[j / 2] >> 4 : f3[j / 2] & 0xf);
+            uint32_t r = ((uint32_t)pu << s) | pv, key = r >> 4;
+            cc->prefs[j].r = r;
+            bf_set(cc->bf, t->hmod[key * 2]);
+            bf_set(cc->bf, t->hmod[key * 2 + 1]);
+            j++;
+            first = 0;
+        }
+    }
+    if (j != n) c->err = 1;
+    free(f2); free(f3); free(ex); free(cnts);
+}
+
+static void load_node(rd_ctx *c, orc_bft *t, orc_node *nd, int i, int *flag_out) {
+    memset(nd, 0, sizeof(*nd));
+    uint16_t field = rd_u16(c);
+    int cnt = field >> 1, sa, nbi = nb_bytes(i);
+    if (flag_out) *flag_out = field & 1;
+    uint8_t *rows = read_uc(c, nbi, cnt, &sa);
+    if (cnt && !c->err) {
+        nd->uc = xmalloc((size_t)cnt * (nbi + 4));
+        nd->uc_n = cnt;
+        for (int q = 0; q < cnt; q++) {
+            memcpy(nd->uc + (size_t)q * (nbi + 4), rows + (size_t)q * (nbi + sa), (size_t)nbi);
+            row_set_cs(nd->uc + (size_t)q * (nbi + 4), nbi, cs_from_annot(t, rows + (size_t)q * (nbi + sa) + nbi, sa));
+        }
+    }
+    free(rows);
+    uint32_t ncc = rd_u32(c);
+    if (c->err || ncc > 1000000) { c->err = 1; return; }
+    nd->ccs = xcalloc(ncc ? ncc : 1, sizeof(orc_cc));
+    nd->ncc = (int)ncc;
+    for (uint32_t q = 0; q < ncc && !c->err; q++) load_cc(c, t, &nd->ccs[q], i);
+}
+
+static long count_kmers(const orc_node *nd, int i) {
+    long n = nd->uc_n;
+    for (int c = 0; c < nd->ncc; c++)
+        for (int j = 0; j < nd->ccs[c].n; j++) {
+            const orc_pref *p = &nd->ccs[c].prefs[j];
+            if (i == 9) n++;
+            else if (p->cnt == 0) n += p->c.node ? count_kmers(p->c.node, i - 9) : 0;
+            else n += p->cnt;
+        }
+    return n;
+}
+
+orc_bft *orc_load_bft(const char *path) {
+    rd_ctx c = {fopen(path, "rb"), 0, 0};
+    if (!c.f) return NULL;
+    int lcs = rd_i32(&c);
+    if (lcs != 0) { fclose(c.f); return NULL; } /* mode-3 annotations need Judy-built comp_set_colors: not supported */
+    int r1 = rd_i32(&c), r2 = rd_i32(&c);
+    (void)rd_i32(&c);
+    int nbg = rd_i32(&c), k = rd_i32(&c);
+    uint8_t comp = 0;
+    rd(&c, &comp, 1);
+    if (c.err || comp != 0 || nbg < 0) { fclose(c.f); return NULL; }
+    orc_bft *t = orc_create(k, r1, r2);
+    if (!t) { fclose(c.f); return NULL; }
+    for (int g = 0; g < nbg && !c.err; g++) {
+        uint16_t len = rd_u16(&c);
+        char buf[70000];
+        rd(&c, buf, len);
+    }
+    for (int i = 9; i <= k && !c.err; i += 9)
+        for (int q = 0; q < 7; q++) (void)rd_i32(&c);
+    if (!c.err) load_node(&c, t, &t->root, k, NULL);
+    fclose(c.f);
+    if (c.err) { orc_free(t); return NULL; }
+    t->nkmers = count_kmers(&t->root, k);
+    t->dirty = 1;
+    t->nb_genomes_loaded = nbg;
+    return t;
+}
+
+int orc_nb_genomes_loaded(const orc_bft *t) { return t->nb_genomes_loaded; }

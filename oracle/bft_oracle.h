@@ -120,6 +120,13 @@ long orc_extract(orc_bft *t, uint8_t *kmers_out, uint32_t *cs_out);
 /* colour set by id: returns the number of genome ids. */
 int orc_colorset(orc_bft *t, uint32_t cs, uint32_t *ids, int cap);
 
+/* write_BFT_Root / read_BFT_Root (src/write_to_disk.c:21-258, :260-776): the .bft file format of
+ * SURVEY.md A.6 (compressed == 0, no comp_set_colors, no extended annotations).  genome names are
+ * "genome_<id>".  orc_load_bft returns NULL on a malformed file. */
+int orc_write_bft(orc_bft *t, const char *path, int nb_genomes);
+orc_bft *orc_load_bft(const char *path);
+int orc_nb_genomes_loaded(const orc_bft *t);
+
 #ifdef __cplusplus
 }
 #endif

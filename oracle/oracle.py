@@ -59,6 +59,11 @@ def _load(count=False):
     lib.orc_extract.restype = C.c_long
     lib.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_colorset.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    lib.orc_write_bft.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.orc_load_bft.restype = C.c_void_p
+    lib.orc_load_bft.argtypes = [C.c_char_p]
+    lib.orc_nb_genomes_loaded.argtypes = [C.c_void_p]
+    lib.orc_k.argtypes = [C.c_void_p]
     _LIBS[name] = lib
     return lib
 
@@ -116,13 +121,30 @@ class OracleBFT:
     """Mirror of the reference calls on the path: createBFT_Root / insertKmers / isKmerPresent /
     get_annotation + get_list_id_genomes."""
 
-    def __init__(self, k, r1=0, r2=0, count=False):
+    def __init__(self, k, r1=0, r2=0, count=False, _handle=None):
         self.lib = _load(count)
-        self.h = self.lib.orc_create(k, r1, r2)
+        self.h = _handle if _handle else self.lib.orc_create(k, r1, r2)
         if not self.h:
             raise ValueError("k must be a multiple of 9 in [9, 126] (reference src/main.c:61-63)")
         self.k = k
         self.nb = self.lib.orc_kmer_bytes(self.h)
+
+    @classmethod
+    def load_bft(cls, path, count=False):
+        """read_BFT_Root (src/write_to_disk.c:260-776)."""
+        lib = _load(count)
+        h = lib.orc_load_bft(path.encode())
+        if not h:
+            raise ValueError(f"cannot load {path}")
+        return cls(lib.orc_k(h), count=count, _handle=h)
+
+    def write_bft(self, path, nb_genomes):
+        """write_BFT_Root (src/write_to_disk.c:21-258)."""
+        if self.lib.orc_write_bft(self.h, path.encode(), nb_genomes) != 0:
+            raise IOError(path)
+
+    def nb_genomes_loaded(self):
+        return self.lib.orc_nb_genomes_loaded(self.h)
 
     def close(self):
         if self.h:

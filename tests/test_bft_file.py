@@ -1,0 +1,114 @@
+"""The reference's .bft file format, CPU side:
+ - oracle writer/reader round trip (byte-identical rewrite), incl. level_min==0 levels and child Nodes;
+ - the product's reader (csrc/bft_file.cpp) on oracle-written files: k-mers and colour sets recovered exactly;
+ - the product's writer on a host-built image, loaded back by the oracle and queried with the restated reference
+   algorithm (proves the bulk-built containers satisfy the invariants of SURVEY.md A.7);
+ - the size of the config-1 file against the reference run recorded in BASELINE.md (6.36 MB)."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import _lib, synth as S
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    subprocess.check_call(["make", "-C", _lib.CSRC, "libbft_hosttest.so"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
+    lib.bft_hosttest_build.restype = C.c_void_p
+    lib.bft_hosttest_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    lib.bft_hosttest_free.argtypes = [C.c_void_p]
+    lib.bft_hosttest_write_bft.argtypes = [C.c_void_p, C.c_char_p]
+    lib.bft_hosttest_read_bft.restype = C.c_void_p
+    lib.bft_hosttest_read_bft.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    lib.bft_hosttest_read_genome.restype = C.c_uint64
+    lib.bft_hosttest_read_genome.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.bft_hosttest_read_free.argtypes = [C.c_void_p]
+    return lib
+
+
+def _product_read(hostlib, path):
+    k, g, n = C.c_int(), C.c_int(), C.c_uint64()
+    h = hostlib.bft_hosttest_read_bft(path.encode(), C.byref(k), C.byref(g), C.byref(n))
+    assert h, "product reader rejected the file"
+    nb = (2 * k.value + 7) // 8
+    out = []
+    for gi in range(g.value):
+        sz = hostlib.bft_hosttest_read_genome(h, gi, None)
+        buf = np.zeros(sz, np.uint8)
+        hostlib.bft_hosttest_read_genome(h, gi, buf.ctypes.data)
+        out.append(buf.reshape(-1, nb))
+    hostlib.bft_hosttest_read_free(h)
+    return k.value, n.value, out
+
+
+CASES = [(9, 1, 1), (18, 1, 3), (27, 2, 1), (27, 1, 6), (36, 3, 3), (45, 2, 2), (63, 3, 70), (126, 2, 2)]
+
+
+@pytest.mark.parametrize("k,levels,ngen", CASES)
+def test_oracle_roundtrip_and_product_reader(oracle_mod, hostlib, tmp_path, k, levels, ngen):
+    base = S.low_entropy_kmers(30000, k, 16, seed=k + levels, levels=levels)
+    gk = [base[:: (g % 5) + 1] for g in range(ngen)]
+    a = oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        a.insert_kmers(km, g)
+    p1, p2 = str(tmp_path / "a.bft"), str(tmp_path / "b.bft")
+    a.write_bft(p1, ngen)
+    b = oracle_mod.OracleBFT.load_bft(p1)
+    assert b.nb_genomes_loaded() == ngen and a.stats() == b.stats()
+    b.write_bft(p2, ngen)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    q = np.concatenate([base, S.snp_mutants(base, k, 1)])
+    ra, rb = a.query_colors(q), b.query_colors(q)
+    assert all((x == y).all() for x, y in zip(ra, rb))
+    # product reader: per-genome k-mer sets
+    kk, n, per = _product_read(hostlib, p1)
+    assert kk == k and n == len(base) and len(per) == ngen
+    for g in range(ngen):
+        assert sorted(S.row_keys(per[g]).tolist()) == sorted(S.row_keys(gk[g]).tolist())
+
+
+@pytest.mark.parametrize("k,levels,n", [(9, 1, 20000), (18, 1, 30000), (27, 1, 200000), (27, 2, 40000), (36, 3, 40000), (63, 3, 40000), (45, 4, 40000), (27, 1, 100), (27, 1, 255)])
+def test_product_writer_loaded_by_oracle(oracle_mod, hostlib, tmp_path, k, levels, n):
+    km = S.low_entropy_kmers(n, k, 24, seed=n + k, levels=levels) if n > 1000 else S.distinct(S.pack_codes(np.random.default_rng(n).integers(0, 4, (n, k), dtype=np.uint8)))
+    if k == 27 and n == 200000:
+        km = S.distinct(S.kmers_of(S.random_genome(n, 3), k))  # a large root with both filter2 geometries
+    km = np.ascontiguousarray(km)
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    path = str(tmp_path / "p.bft")
+    assert hostlib.bft_hosttest_write_bft(h, path.encode()) == 0
+    hostlib.bft_hosttest_free(h)
+    o = oracle_mod.OracleBFT.load_bft(path)  # the restated reference reader + query algorithm on OUR containers
+    assert o.stats()["kmers"] == len(km)
+    rng = np.random.default_rng(0)
+    q = np.concatenate([km, S.snp_mutants(km, k, 2), S.pack_codes(rng.integers(0, 4, (2000, k), dtype=np.uint8))])
+    bits, off, ids = o.query_colors(q)
+    truth = S.member(q, km)
+    assert (S.from_bits(bits, len(q)) == truth).all()
+    assert (ids == 0).all() and len(ids) == truth.sum()
+    # and the product reader reads its own file
+    kk, nk, per = _product_read(hostlib, path)
+    assert nk == len(km) and sorted(S.row_keys(per[0]).tolist()) == sorted(S.row_keys(km).tolist())
+
+
+def test_config1_file_size_matches_reference_run(oracle_mod, tmp_path):
+    """`bft build 27` on the config-1 genome wrote a 6.36 MB .bft."""
+    random.seed(1)
+    g = "".join(random.choice("ACGT") for _ in range(1000000))
+    km = S.distinct(S.kmers_of(S._CODE[np.frombuffer(g.encode(), dtype=np.uint8)], 27))
+    t = oracle_mod.OracleBFT(27)
+    t.insert_kmers(km, 0)
+    p = str(tmp_path / "c1.bft")
+    t.write_bft(p, 1)
+    assert 6.355e6 <= os.path.getsize(p) < 6.365e6
+
+
+def test_reader_rejects_garbage(hostlib, tmp_path):
+    p = str(tmp_path / "bad.bft")
+    open(p, "wb").write(b"\x00" * 10)
+    k, g, n = C.c_int(), C.c_int(), C.c_uint64()
+    assert not hostlib.bft_hosttest_read_bft(p.encode(), C.byref(k), C.byref(g), C.byref(n))

@@ -177,3 +177,32 @@ def test_out_of_order_genome_ids_ground_truth():
         exp = truth.get(key, [])
         assert pres[i] == bool(exp)
         assert ids[int(off[i]):int(off[i + 1])].tolist() == exp
+
+
+@pytest.mark.parametrize("k,levels,ngen", [(27, 1, 6), (36, 3, 3), (63, 2, 70), (18, 1, 10)])
+def test_bft_files_both_directions(oracle_mod, tmp_path, k, levels, ngen):
+    """write_BFT / load_BFT: GPU image -> .bft -> restated reference reader+query; oracle .bft -> GPU image."""
+    from bloomfiltertrie_amd import BFT
+    base = S.low_entropy_kmers(60000, k, 24, seed=k + levels, levels=levels)
+    gk = [base[:: (g % 4) + 1] for g in range(ngen)]
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        t.add_genome(f"g{g}.fa")
+        t.insert_kmers(km, g)
+        o.insert_kmers(km, g)
+    q = _queries(base, k, seed=4)
+    exp = o.query_colors(q)
+    p1, p2 = str(tmp_path / "gpu.bft"), str(tmp_path / "orc.bft")
+    t.write_bft(p1)
+    o2 = oracle_mod.OracleBFT.load_bft(p1)
+    assert o2.nb_genomes_loaded() == ngen
+    got = o2.query_colors(q)
+    assert all((a == b).all() for a, b in zip(got, exp))
+    o.write_bft(p2, ngen)
+    t2 = BFT.load_bft(p2)
+    got2 = t2.query_colors(q)
+    assert all((a == b).all() for a, b in zip(got2, exp))
+    assert t2.info()["kmers"] == len(base) and t2.info()["genomes"] == ngen
+    # a GPU-written file read back by the GPU path
+    t3 = BFT.load_bft(p1)
+    assert all((a == b).all() for a, b in zip(t3.query_colors(q), exp))
