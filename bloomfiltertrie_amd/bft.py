@@ -136,6 +136,16 @@ class BFT:
         _lib.check(self._lib.bft_gpu_query_color_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
         return bits, rows
 
+    def query_branching(self, kmers, with_counts=False):
+        """-query_branching (src/file_io.c:897-1020): bit per k-mer, optionally (successors << 4) | predecessors."""
+        kmers = self._chk(kmers)
+        n = len(kmers)
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        counts = np.zeros(n, dtype=np.uint8) if with_counts else None
+        _lib.check(self._lib.bft_gpu_query_branching(self._h, kmers.ctypes.data, n, bits.ctypes.data,
+                                                     counts.ctypes.data if with_counts else None))
+        return (bits, counts) if with_counts else bits
+
     def set_option(self, name, value):
         _lib.check(self._lib.bft_gpu_set_option(self._h, name.encode(), int(value)))
 

@@ -166,6 +166,80 @@ __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __r
     }
 }
 
+// Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
+// successors of a k-mer = present k-mers kmer[1..k-1]+N, predecessors = present k-mers N+kmer[0..k-2], N in ACGT.
+// In T-form the four successors differ only in bits 2..3 of the last digit (n9 of the last prefix) and the four
+// predecessors only in bits 0..1 of the first digit (n1 of the first prefix): one conversion per side, then four walks
+// that share every container down to the last cluster / suffix group (src/presenceNode.c:15-1211 exploits the same).
+// counts[i] = (successors << 4) | predecessors when requested; the bit = successors > 1 || predecessors > 1.
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                     uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t* l_hm = (uint32_t*)lds;
+    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    const BftNode root = im.nodes[0];
+    const uint32_t bf_bytes = STAGED ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
+    BftCC* l_cc = (BftCC*)(l_bf + bf_bytes);
+    {
+        const uint4* g = (const uint4*)im.hashmod;
+        uint4* l = (uint4*)l_hm;
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (STAGED) {
+            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
+            uint64_t* lb = (uint64_t*)l_bf;
+            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
+            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccs[root.cc_first + i];
+        }
+    }
+    __syncthreads();
+    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    const int k = im.k, L = im.L;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * BLOCK + threadIdx.x;
+        int branching = 0;
+        if (i < n) {
+            uint64_t x[W], y[W], t[W];
+            load_x<W>(packed, i, B, end_aligned, x);
+            // successors: drop the first nucleotide, the last one is the wildcard
+#pragma unroll
+            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
+            bft_tform_from_x<W>(y, L, t);
+            int cr = 0, cl = 0;
+            for (uint64_t nt = 0; nt < 4 && (counts || cr < 2); nt++) {
+                uint64_t tt[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) tt[w] = t[w];
+                tt[W - 1] |= nt << 2;
+                cr += bft_walk<W>(im, acc, root, tt).present;
+            }
+            if (counts || cr < 2) {
+                // predecessors: shift in a wildcard first nucleotide, drop the last one
+#pragma unroll
+                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
+                const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
+                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
+                bft_tform_from_x<W>(y, L, t);
+                const int o = 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
+                for (uint64_t nt = 0; nt < 4 && (counts || cl < 2); nt++) {
+                    uint64_t tt[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) tt[w] = t[w] | (w == ow ? nt << osh : 0ull);
+                    cl += bft_walk<W>(im, acc, root, tt).present;
+                }
+            }
+            branching = cr > 1 || cl > 1;
+            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
+        }
+        const uint64_t mask = __ballot(branching);
+        const uint64_t q0 = i & ~63ull;
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+    }
+}
+
 __global__ void k_iota(uint32_t* p, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
 }
@@ -711,6 +785,74 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         if (h->pending_ev.size() > 8192) drain_events(h);
     }
     return 0;
+}
+
+template <int W, bool STAGED>
+static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
+    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCC) : 0);
+    const uint64_t nblk = (n + 1023) / 1024;
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 512)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_branching<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
+    if (n == 0) return 0;
+    const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        HIPCK(hipEventCreate(&e0));
+        HIPCK(hipEventCreate(&e1));
+        HIPCK(hipEventRecord(e0, s));
+    }
+#define BR(WW) (staged ? launch_branching_k<WW, true>(h, d_kmers, n, d_bits64, d_counts, s) : launch_branching_k<WW, false>(h, d_kmers, n, d_bits64, d_counts, s))
+    switch (h->W) {
+    case 1: CK(BR(1)); break;
+    case 2: CK(BR(2)); break;
+    case 3: CK(BR(3)); break;
+    default: CK(BR(4)); break;
+    }
+#undef BR
+    if (h->timing) {
+        HIPCK(hipEventRecord(e1, s));
+        h->pending_ev.push_back({e0, e1});
+    }
+    return 0;
+}
+
+extern "C" int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_branching_bits, void* d_counts, void* hip_stream) {
+    if (!h || ((!d_kmers || !d_branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    return launch_branching(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_branching_bits, (uint8_t*)d_counts, s);
+}
+
+extern "C" int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* branching_bits, uint8_t* counts) {
+    if (!h || ((!kmers || !branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint64_t chunk = 1ull << 26;
+    const uint64_t mc = std::min(n, chunk);
+    DevBuf dk, db, dc;
+    CK(dk.alloc(mc * h->B));
+    CK(db.alloc(((mc + 63) / 64) * 8));
+    if (counts) CK(dc.alloc(mc));
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        HIPCK(hipMemcpyAsync(dk.p, kmers + a * h->B, m * h->B, hipMemcpyHostToDevice, h->stream));
+        CK(launch_branching(h, dk.as<uint8_t>(), m, db.as<uint64_t>(), counts ? dc.as<uint8_t>() : nullptr, h->stream));
+        HIPCK(hipMemcpyAsync(branching_bits + a / 8, db.p, (m + 7) / 8, hipMemcpyDeviceToHost, h->stream));
+        if (counts) HIPCK(hipMemcpyAsync(counts + a, dc.p, m, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return BFT_GPU_OK;
 }
 
 extern "C" int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* hip_stream) {

@@ -86,6 +86,14 @@ int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, ui
 int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
                              uint8_t* rows);
 
+/* The loop of src/file_io.c:943-998 (-query_branching): isBranchingRight / isBranchingLeft
+ * (src/branchingNode.c:16-112, :240-340) for a batch.  Bit i = k-mer i has more than one successor
+ * (present k-mers kmer[1..k-1]+N) or more than one predecessor (present N+kmer[0..k-2]); the sum of the bits is
+ * the CLI's "Nb branching k-mers".  counts (optional, n bytes): (successors << 4) | predecessors. */
+int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* branching_bits, uint8_t* counts);
+int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_branching_bits, void* d_counts,
+                                void* hip_stream);
+
 /* load_BFT / read_BFT_Root (include/bft.h:176, src/write_to_disk.c:260-776): parse a reference .bft file
  * (compressed == 0; annotation modes 0/1/2 and extended-annotation bytes) and build the GPU image from its
  * k-mers and colour sets, with the file's Bloom seeds and genome names. */

@@ -1540,3 +1540,37 @@ orc_bft *orc_load_bft(const char *path) {
 }
 
 int orc_nb_genomes_loaded(const orc_bft *t) { return t->nb_genomes_loaded; }
+
+/* ------------------------------------------------------------------ */
+/* branching (src/branchingNode.c)                                    */
+/* ------------------------------------------------------------------ */
+long orc_query_branching(orc_bft *t, const uint8_t *kmers, long n, uint8_t *bits, uint8_t *counts) {
+    orc_freeze(t);
+    const int nb = nb_bytes(t->k), k = t->k;
+    long nbr = 0;
+    memset(bits, 0, (size_t)CEIL(n, 8));
+    orc_res res;
+    for (long a = 0; a < n; a++) {
+        const uint8_t *km = kmers + (size_t)a * nb;
+        uint8_t sh[40];
+        int cr = 0, cl = 0;
+        /* right_shifting, src/branchingNode.c:43-48: drop the first nucleotide */
+        for (int i = 0; i < nb; i++) { sh[i] = (uint8_t)(km[i] >> 2); if (i + 1 < nb) sh[i] |= (uint8_t)(km[i + 1] << 6); }
+        for (int x = 0; x < 4; x++) {
+            sh[(k - 1) / 4] = (uint8_t)((sh[(k - 1) / 4] & ~(3u << (2 * ((k - 1) % 4)))) | ((unsigned)x << (2 * ((k - 1) % 4))));
+            is_kmer_present(t, sh, &res);
+            cr += res.found;
+        }
+        /* left: shift in a first nucleotide, drop the last (src/branchingNode.c:266-276) */
+        for (int i = nb - 1; i >= 0; i--) { sh[i] = (uint8_t)(km[i] << 2); if (i > 0) sh[i] |= (uint8_t)(km[i - 1] >> 6); }
+        if ((2 * k) % 8) sh[nb - 1] &= (uint8_t)((1u << ((2 * k) % 8)) - 1u);
+        for (int x = 0; x < 4; x++) {
+            sh[0] = (uint8_t)((sh[0] & ~3u) | (unsigned)x);
+            is_kmer_present(t, sh, &res);
+            cl += res.found;
+        }
+        if (counts) counts[a] = (uint8_t)((cr << 4) | cl);
+        if (cr > 1 || cl > 1) { bits[a >> 3] |= (uint8_t)(1u << (a & 7)); nbr++; }
+    }
+    return nbr;
+}

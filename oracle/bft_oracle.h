@@ -120,6 +120,13 @@ long orc_extract(orc_bft *t, uint8_t *kmers_out, uint32_t *cs_out);
 /* colour set by id: returns the number of genome ids. */
 int orc_colorset(orc_bft *t, uint32_t cs, uint32_t *ids, int cap);
 
+/* Loop of src/file_io.c:943-998 over isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340):
+ * successors = present k-mers kmer[1..k-1]+N, predecessors = present N+kmer[0..k-2] (N in ACGT).  Restated at the
+ * level of its definition -- four isKmerPresent calls per side -- not as the 4-way wildcard variants
+ * presenceNeighborsRight/Left (src/presenceNode.c:15-1211), which compute the same counts in one walk.
+ * counts (optional): (successors << 4) | predecessors.  Returns the number of branching k-mers. */
+long orc_query_branching(orc_bft *t, const uint8_t *kmers, long n, uint8_t *branching_bits, uint8_t *counts);
+
 /* write_BFT_Root / read_BFT_Root (src/write_to_disk.c:21-258, :260-776): the .bft file format of
  * SURVEY.md A.6 (compressed == 0, no comp_set_colors, no extended annotations).  genome names are
  * "genome_<id>".  orc_load_bft returns NULL on a malformed file. */

@@ -59,6 +59,8 @@ def _load(count=False):
     lib.orc_extract.restype = C.c_long
     lib.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_colorset.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    lib.orc_query_branching.restype = C.c_long
+    lib.orc_query_branching.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     lib.orc_write_bft.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.orc_load_bft.restype = C.c_void_p
     lib.orc_load_bft.argtypes = [C.c_char_p]
@@ -199,6 +201,13 @@ class OracleBFT:
             if tot <= cap:
                 return bits, offsets, ids[:tot]
             cap = tot
+
+    def query_branching(self, kmers):
+        kmers = self._chk(kmers)
+        bits = np.zeros((len(kmers) + 7) // 8, dtype=np.uint8)
+        counts = np.zeros(len(kmers), dtype=np.uint8)
+        n = self.lib.orc_query_branching(self.h, kmers.ctypes.data, len(kmers), bits.ctypes.data, counts.ctypes.data)
+        return bits, counts, int(n)
 
     def stats(self):
         out = (C.c_long * 10)()

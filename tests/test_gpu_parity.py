@@ -206,3 +206,22 @@ def test_bft_files_both_directions(oracle_mod, tmp_path, k, levels, ngen):
     # a GPU-written file read back by the GPU path
     t3 = BFT.load_bft(p1)
     assert all((a == b).all() for a, b in zip(t3.query_colors(q), exp))
+
+
+@pytest.mark.parametrize("k,deep", [(9, 0), (18, 0), (27, 0), (27, 2), (36, 0), (36, 3), (63, 0), (126, 0)])
+def test_branching(oracle_mod, k, deep):
+    if deep:
+        km = S.low_entropy_kmers(40000, k, 16, seed=k, levels=deep)
+    else:
+        anc = S.random_genome(30000, 3)
+        km = S.distinct(np.concatenate([S.kmers_of(g, k) for g in (anc, S.mutate(anc, 0.03, 1), S.mutate(anc, 0.03, 2))]))
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    q = _queries(km, k, seed=2)
+    obits, ocounts, onbr = o.query_branching(q)
+    bits, counts = t.query_branching(q, with_counts=True)
+    assert (counts == ocounts).all()
+    assert (bits == obits).all()
+    assert (t.query_branching(q) == obits).all()  # early-exit variant
+    assert int(np.unpackbits(bits, bitorder="little")[: len(q)].sum()) == onbr

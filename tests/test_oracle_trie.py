@@ -159,3 +159,24 @@ def test_rejects_k_not_multiple_of_9(oracle_mod):
     for k in (31, 8, 135, 0):
         with pytest.raises(ValueError):
             oracle_mod.OracleBFT(k)
+
+
+@pytest.mark.parametrize("k", [9, 18, 27, 36, 63])
+def test_branching_against_ground_truth(oracle_mod, k):
+    """-query_branching semantics (src/file_io.c:943-998): >1 successor or >1 predecessor among stored k-mers."""
+    anc = S.random_genome(4000, 3)
+    genomes = [anc, S.mutate(anc, 0.05, 1), S.mutate(anc, 0.05, 2)]
+    km = S.distinct(np.concatenate([S.kmers_of(g, k) for g in genomes]))
+    t = oracle_mod.OracleBFT(k)
+    t.insert_kmers(km, 0)
+    q = np.concatenate([km, S.snp_mutants(km[::3], k, 5)])
+    bits, counts, nbr = t.query_branching(q)
+    present = set(map(bytes, km))
+    codes = S.unpack_codes(q, k)
+    for i in range(0, len(q), 7):
+        c = codes[i]
+        succ = sum(bytes(S.pack_codes(np.concatenate([c[1:], [x]])[None, :])[0]) in present for x in range(4))
+        pred = sum(bytes(S.pack_codes(np.concatenate([[x], c[:-1]])[None, :])[0]) in present for x in range(4))
+        assert counts[i] == (succ << 4 | pred), (i, counts[i], succ, pred)
+        assert bool(bits[i >> 3] >> (i & 7) & 1) == (succ > 1 or pred > 1)
+    assert nbr == int(np.unpackbits(bits, bitorder="little")[: len(q)].sum())
