@@ -15,6 +15,14 @@
 #define BFT_HD inline
 #endif
 
+// Random 8-byte gathers from the big tables (each touched cache line is used once by the wavefront): on the
+// device they can be issued as non-temporal loads; selected at compile time with -DBFT_NT_LOADS=1.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BFT_NT_LOADS) && BFT_NT_LOADS
+#define BFT_GATHER(p) __builtin_nontemporal_load(p)
+#else
+#define BFT_GATHER(p) (*(p))
+#endif
+
 // 18-bit raw prefix (nucleotide j at bits 2j, the packed layout of src/fasta.c:11-23)
 //   -> P = n1..n9 with n1 in the top bits (what rev[] yields, src/presenceNode.c:1327-1329)
 //   -> rotated r = n2..n9,n1 (src/presenceNode.c:1367-1371).
@@ -120,7 +128,7 @@ BFT_HD uint32_t bft_rows_lower_bound(const uint64_t* rows, uint32_t n, const uin
         uint32_t mid = (lo + hi) >> 1;
         uint64_t r[W];
 #pragma unroll
-        for (int w = 0; w < W; w++) r[w] = rows[(size_t)mid * W + w];
+        for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)mid * W + w]);
         if (bft_cmp<W>(r, t) < 0) lo = mid + 1;
         else hi = mid;
     }
@@ -138,7 +146,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
     if (g >= n) g = n - 1;
     uint32_t lo = 0, hi = n;
 #pragma unroll
-    for (int w = 0; w < W; w++) r[w] = rows[(size_t)g * W + w];
+    for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)g * W + w]);
     int c = bft_cmp<W>(r, t);
     if (c == 0) return (int)g;
     uint32_t step = 1;
@@ -148,7 +156,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
             uint32_t p = lo + step - 1;
             if (p >= hi) p = hi - 1;
 #pragma unroll
-            for (int w = 0; w < W; w++) r[w] = rows[(size_t)p * W + w];
+            for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)p * W + w]);
             c = bft_cmp<W>(r, t);
             if (c == 0) return (int)p;
             if (c < 0) { lo = p + 1; step <<= 1; }
@@ -159,7 +167,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
         while (lo < hi) {
             uint32_t p = hi - lo > step ? hi - step : lo;
 #pragma unroll
-            for (int w = 0; w < W; w++) r[w] = rows[(size_t)p * W + w];
+            for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)p * W + w]);
             c = bft_cmp<W>(r, t);
             if (c == 0) return (int)p;
             if (c > 0) { hi = p; step <<= 1; }
@@ -169,7 +177,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
 #pragma unroll
-        for (int w = 0; w < W; w++) r[w] = rows[(size_t)mid * W + w];
+        for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)mid * W + w]);
         c = bft_cmp<W>(r, t);
         if (c == 0) return (int)mid;
         if (c < 0) lo = mid + 1;
@@ -262,7 +270,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
         if (im.debug_stop == 2) { hit.present = (int)(fw & 1); return hit; }
         if (!((fw >> bi) & 1ull)) return hit;  // filter2 miss => absent (src/presenceNode.c:1546-1548)
         const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
-        uint64_t e = im.clus[cc.clus_off + clu];
+        uint64_t e = BFT_GATHER(&im.clus[cc.clus_off + clu]);
         if (im.debug_stop == 3) { hit.present = (int)(e & 1); return hit; }
         if (e & BFT_CLUS_MULTI) {
             // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
@@ -272,7 +280,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
             e = 0;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                const uint64_t m = ch[mid];
+                const uint64_t m = BFT_GATHER(&ch[mid]);
                 if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
                 else { hi = mid; e = m; }
             }
