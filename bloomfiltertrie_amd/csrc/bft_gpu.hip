@@ -434,6 +434,14 @@ extern "C" void bft_gpu_free(bft_gpu* h) {
     delete h;
 }
 
+extern "C" int bft_gpu_genome_name(bft_gpu* h, uint32_t id_genome, char* out, uint32_t cap) {
+    if (!h || !out || cap == 0) return fail(BFT_GPU_E_ARG, "NULL argument");
+    const std::string name = id_genome < h->genomes.size() ? h->genomes[id_genome] : "genome_" + std::to_string(id_genome);
+    if (name.size() + 1 > cap) return fail(BFT_GPU_E_NOSPACE, "name buffer too small");
+    memcpy(out, name.c_str(), name.size() + 1);
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_add_genome(bft_gpu* h, const char* name, uint32_t* id_genome) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     h->genomes.push_back(name);

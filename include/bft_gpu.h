@@ -54,6 +54,9 @@ void bft_gpu_free(bft_gpu* h);
  * (ids are 0-based and increase, as the reference's nb_genomes-1). */
 int bft_gpu_add_genome(bft_gpu* h, const char* name, uint32_t* id_genome);
 
+/* BFT_Root::filenames[id] (include/Node.h:97): NUL-terminated genome name ("genome_<id>" if none was registered). */
+int bft_gpu_genome_name(bft_gpu* h, uint32_t id_genome, char* out, uint32_t cap);
+
 /* insertKmers(root, array_kmers, nb_kmers, id_genome, size_id_genome) (include/insertNode.h:26,
  * src/insertNode.c:18-36).  The batch is converted on the GPU and appended to a device-side log;
  * the trie image is (re)built in bulk by bft_gpu_build (or lazily by the first query).

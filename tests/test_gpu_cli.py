@@ -1,0 +1,78 @@
+"""The C harness bft_gpu (csrc/bft_gpu_cli.c) end to end on the GPU box: `build` -> .bft -> `load -query_kmers` /
+`-query_branching`, outputs compared byte for byte with the reference's format filled from the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import _lib, synth as S
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(_lib.CSRC, "bft_gpu")
+
+
+def _write_ascii(path, kmers, k, extra_lines=()):
+    lines = S.packed_to_ascii(kmers, k) + list(extra_lines)
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return lines
+
+
+def test_build_load_query_csv(oracle_mod, tmp_path):
+    k = 27
+    anc = S.random_genome(20000, 4)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 10 + g), k)) for g in range(3)]
+    os.chdir(tmp_path)
+    names = []
+    for g, km in enumerate(gk):
+        _write_ascii(tmp_path / f"genome{g}.kmers", km, k)
+        names.append(f"genome{g}.kmers")
+    (tmp_path / "list.txt").write_text("".join(str(tmp_path / n) + "\n" for n in names))
+    out = subprocess.run([CLI, "build", str(k), "kmers", "list.txt", "out.bft"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    # the oracle (restated reference reader) loads the GPU-written file
+    o = oracle_mod.OracleBFT.load_bft(str(tmp_path / "out.bft"))
+    allk = S.distinct(np.concatenate(gk))
+    assert o.stats()["kmers"] == len(allk)
+    # queries: present, absent, and two invalid lines (all-0 rows, src/file_io.c:844-850)
+    rng = np.random.default_rng(0)
+    q = np.concatenate([allk[::5], S.snp_mutants(allk[::7], k, 3)])
+    q = q[rng.permutation(len(q))]
+    lines = _write_ascii(tmp_path / "queries.txt", q, k, extra_lines=["ACGTNNNNACGTACGTACGTACGTACG", "ACGT"])
+    (tmp_path / "qlist.txt").write_text(str(tmp_path / "queries.txt") + "\n")
+    out = subprocess.run([CLI, "load", "out.bft", "-query_kmers", "kmers", "qlist.txt", "-query_branching", "kmers", "qlist.txt"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    bits, off, ids = o.query_colors(q)
+    pres = S.from_bits(bits, len(q))
+    exp = ",".join(names) + "\n"
+    for i in range(len(q)):
+        have = set(ids[int(off[i]):int(off[i + 1])].tolist())
+        exp += ",".join("1" if g in have else "0" for g in range(3)) + "\n"
+    exp += "0,0,0\n0,0,0\n"
+    exp = exp[:-1] + "\0"  # the final newline is overwritten by NUL (src/file_io.c:873-876)
+    got = (tmp_path / "queries.csv").read_bytes().decode()
+    assert got == exp
+    assert f"Nb k-mers present = {int(pres.sum())}" in out.stdout
+    _, _, nbr = o.query_branching(q)
+    assert f"Nb branching k-mers = {nbr}" in out.stdout
+
+
+def test_kmers_comp_input_and_bad_k(tmp_path):
+    k = 18
+    km = S.distinct(S.kmers_of(S.random_genome(5000, 1), k))
+    os.chdir(tmp_path)
+    with open("g.kmers_comp", "wb") as f:
+        f.write(f"{k}\n{len(km)}\n".encode())
+        f.write(km.tobytes())
+    (tmp_path / "list.txt").write_text(str(tmp_path / "g.kmers_comp") + "\n")
+    assert subprocess.run([CLI, "build", str(k), "kmers_comp", "list.txt", "o.bft"], capture_output=True).returncode == 0
+    with open("q.kmers_comp", "wb") as f:
+        f.write(f"{k}\n{len(km)}\n".encode())
+        f.write(km[:1000].tobytes())
+    (tmp_path / "ql.txt").write_text(str(tmp_path / "q.kmers_comp") + "\n")
+    out = subprocess.run([CLI, "load", "o.bft", "-query_kmers", "kmers_comp", "ql.txt"], capture_output=True, text=True)
+    assert out.returncode == 0 and "Nb k-mers present = 1000" in out.stdout
+    bad = subprocess.run([CLI, "build", "31", "kmers", "list.txt", "x.bft"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "multiple of 9" in bad.stderr
