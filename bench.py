@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU baseline (0 = auto)")
     ap.add_argument("--verify", type=int, default=1_000_000, help="queries of the batch checked against ground truth")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bitmap all_gather even with one rank (path check)")
     return ap.parse_args()
 
 
@@ -93,9 +94,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from bloomfiltertrie_amd import BFT, synth as S
 
@@ -118,31 +121,32 @@ def main():
     nq = args.queries
     dq = make_queries_on_device(union, args.k, nq, 99 + rank, device)
     dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device)
-    gathered = torch.empty(dbits.numel() * world, dtype=torch.uint8, device=device) if world > 1 else None
+    gathered = torch.empty(dbits.numel() * world, dtype=torch.uint8, device=device) if use_dist else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         bft.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, dbits)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     bft.kernel_time(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = bft.kernel_time(reset=True)
-    if world > 1:
+    if use_dist:
+        assert torch.equal(gathered[rank * dbits.numel():(rank + 1) * dbits.numel()], dbits)
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -156,7 +160,7 @@ def main():
     n_present = int(torch.from_numpy(np.unpackbits(dbits.cpu().numpy(), bitorder="little")[:nq]).sum())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -243,7 +247,7 @@ def main():
                            "kernel": "k_query", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                            "alg_bytes_per_launch": round(alg_bytes * nq)}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -63,7 +63,6 @@ def test_config2_full_batch_properties():
     assert torch.equal(first, dbits)
     # (4) host API == device API on a slice that is not 64-aligned in length
     ns = 1_000_003
-    assert (t.query_presence(dq[:ns].cpu().numpy()) == first[: (ns + 7) // 8].cpu().numpy()[: (ns + 7) // 8]).all() or True
     hb = t.query_presence(dq[:ns].cpu().numpy())
     assert (np.unpackbits(hb, bitorder="little")[:ns] == got[:ns]).all()
 
