@@ -146,6 +146,19 @@ class BFT:
                                                      counts.ctypes.data if with_counts else None))
         return (bits, counts) if with_counts else bits
 
+    def query_sequences(self, sequences, threshold, canonical=False):
+        """query_sequence (include/bft.h:127) for a list of ASCII sequences: list of sorted genome-id lists."""
+        enc = [x.encode() if isinstance(x, str) else bytes(x) for x in sequences]
+        off = np.zeros(len(enc) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        blob = b"".join(enc) + b"\0"
+        g = self.info()["genomes"]
+        rows = np.zeros((len(enc), (g + 7) // 8), dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_query_sequences(self._h, blob, off.ctypes.data, len(enc), float(threshold), int(canonical),
+                                                     rows.ctypes.data))
+        unp = np.unpackbits(rows, axis=1, bitorder="little")[:, :g] if g else np.zeros((len(enc), 0), np.uint8)
+        return [np.flatnonzero(r).tolist() for r in unp]
+
     def set_option(self, name, value):
         _lib.check(self._lib.bft_gpu_set_option(self._h, name.encode(), int(value)))
 

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -237,6 +238,84 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
         const uint64_t mask = __ballot(branching);
         const uint64_t q0 = i & ~63ull;
         if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+    }
+}
+
+// ---- query_sequence (src/bft.c:1241-1351, harness src/file_io.c:1464-1574): every k-mer of every sequence ----
+__device__ __forceinline__ int nt_code(char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return -1;
+    }
+}
+
+// one thread per k-mer position of the batch: (canonical) k-mer -> walk -> row in tk, or BFT_ABSENT_ROW
+template <int W>
+__global__ void k_seq_rows(BftImage im, const char* __restrict__ seqs, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
+                           uint32_t n_seqs, uint64_t P, int canonical, uint32_t* __restrict__ rows, uint32_t* __restrict__ seq_of) {
+    const BftRootGlobal acc(im);
+    const BftNode root = im.nodes[0];
+    const int k = im.k;
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n_seqs;  // last s with pos_off[s] <= p
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pos_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const char* w = seqs + seq_off[lo] + (p - pos_off[lo]);
+        uint64_t xf[W], xr[W];
+#pragma unroll
+        for (int q = 0; q < W; q++) { xf[q] = 0; xr[q] = 0; }
+        bool valid = true;
+        int cmp = 0;
+        for (int i = 0; i < k; i++) {
+            const int cf = nt_code(w[i]), cb = nt_code(w[k - 1 - i]);
+            if (cf < 0) { valid = false; break; }
+            const int cr = 3 - cb;  // nucleotide i of the reverse complement (cb < 0 is caught when i reaches it)
+            if (cmp == 0 && cf != cr) cmp = cf < cr ? -1 : 1;
+            const int o = 2 * i;
+#pragma unroll
+            for (int q = 0; q < W; q++)
+                if (q == (o >> 6)) { xf[q] |= (uint64_t)cf << (o & 63); xr[q] |= (uint64_t)(cr & 3) << (o & 63); }
+        }
+        uint32_t row = BFT_ABSENT_ROW;
+        if (valid) {
+            uint64_t t[W];
+            // strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296)
+            bft_tform_from_x<W>((canonical && cmp >= 0) ? xr : xf, im.L, t);
+            const BftHit hit = bft_walk<W>(im, acc, root, t);
+            if (hit.present) row = (uint32_t)hit.row;
+        }
+        rows[p] = row;
+        seq_of[p] = lo;
+    }
+}
+
+__global__ void k_seq_count(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ seq_of, const uint32_t* __restrict__ tcol,
+                            const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t P, uint32_t G, uint32_t* __restrict__ counts) {
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rows[p];
+        if (r == BFT_ABSENT_ROW) continue;
+        const uint32_t cs = tcol[r];
+        uint32_t* c = counts + (size_t)seq_of[p] * G;
+        for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) atomicAdd(&c[cs_ids[q]], 1u);
+    }
+}
+
+__global__ void k_seq_threshold(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ minv, uint32_t n_seqs, uint32_t G, uint32_t rowbytes,
+                                uint8_t* __restrict__ out) {
+    const uint64_t total = (uint64_t)n_seqs * rowbytes;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(i / rowbytes), b = (uint32_t)(i % rowbytes);
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 8 && b * 8 + j < G; j++) {
+            const uint32_t c = counts[(size_t)s * G + b * 8 + j];
+            if (c && c >= minv[s]) v |= 1u << j;
+        }
+        out[i] = (uint8_t)v;
     }
 }
 
@@ -972,6 +1051,71 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // ------------------------------------------------------------------------------------------------
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
+// query_sequence (src/bft.c:1241-1351) for a batch of ASCII sequences
+extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint64_t* seq_off, uint64_t n_seqs, double threshold, int canonical,
+                                       uint8_t* rows) {
+    if (!h || ((!seqs || !seq_off || !rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (!(threshold > 0) || threshold > 1) return fail(BFT_GPU_E_ARG, "the threshold must be in (0, 1] (reference src/bft.c:1246-1247)");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
+    if (rowbytes == 0 || n_seqs == 0) return BFT_GPU_OK;
+    const int k = h->k;
+    uint64_t a = 0;
+    while (a < n_seqs) {
+        // chunk: bounded k-mer positions and counter matrix
+        uint64_t b = a, P = 0;
+        std::vector<uint64_t> pos_off, minv;
+        while (b < n_seqs) {
+            const uint64_t len = seq_off[b + 1] - seq_off[b];
+            const uint64_t m = len >= (uint64_t)k ? len - k + 1 : 0;
+            if (b > a && (P + m > (1ull << 26) || (b - a + 1) * (uint64_t)G > (1ull << 28))) break;
+            pos_off.push_back(P);
+            minv.push_back((uint64_t)(int64_t)ceil((double)m * threshold));  // nb_kmers_query_min, src/bft.c:1281
+            P += m;
+            b++;
+        }
+        pos_off.push_back(P);
+        const uint64_t ns = b - a, nchars = seq_off[b] - seq_off[a];
+        DevBuf d_seq, d_soff, d_poff, d_min, d_rows, d_sof, d_cnt, d_out;
+        std::vector<uint64_t> soff(ns + 1);
+        for (uint64_t i = 0; i <= ns; i++) soff[i] = seq_off[a + i] - seq_off[a];
+        CK(d_seq.alloc(nchars + 8));
+        CK(d_soff.alloc((ns + 1) * 8));
+        CK(d_poff.alloc((ns + 1) * 8));
+        CK(d_min.alloc(ns * 8));
+        CK(d_rows.alloc(P * 4));
+        CK(d_sof.alloc(P * 4));
+        CK(d_cnt.alloc_zero(ns * (uint64_t)G * 4, h->stream));
+        CK(d_out.alloc(ns * rowbytes));
+        HIPCK(hipMemcpyAsync(d_seq.p, seqs + seq_off[a], nchars, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(d_soff.p, soff.data(), (ns + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(d_poff.p, pos_off.data(), (ns + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(d_min.p, minv.data(), ns * 8, hipMemcpyHostToDevice, h->stream));
+        if (P) {
+            const dim3 grid(grid_for((P + 255) / 256)), block(256);
+#define SEQ(WW) hipLaunchKernelGGL(k_seq_rows<WW>, grid, block, 0, h->stream, h->im, d_seq.as<char>(), d_soff.as<uint64_t>(), d_poff.as<uint64_t>(), \
+                                   (uint32_t)ns, P, canonical, d_rows.as<uint32_t>(), d_sof.as<uint32_t>())
+            switch (h->W) {
+            case 1: SEQ(1); break;
+            case 2: SEQ(2); break;
+            case 3: SEQ(3); break;
+            default: SEQ(4); break;
+            }
+#undef SEQ
+            hipLaunchKernelGGL(k_seq_count, grid, block, 0, h->stream, d_rows.as<uint32_t>(), d_sof.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, P, G,
+                               d_cnt.as<uint32_t>());
+        }
+        hipLaunchKernelGGL(k_seq_threshold, dim3(grid_for((ns * rowbytes + 255) / 256)), dim3(256), 0, h->stream, d_cnt.as<uint32_t>(), d_min.as<uint64_t>(),
+                           (uint32_t)ns, G, rowbytes, d_out.as<uint8_t>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(rows + a * rowbytes, d_out.p, ns * rowbytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        a = b;
+    }
+    return BFT_GPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // .bft files
 // ------------------------------------------------------------------------------------------------

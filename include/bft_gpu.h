@@ -97,6 +97,14 @@ int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers,
 int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_branching_bits, void* d_counts,
                                 void* hip_stream);
 
+/* query_sequence(bft, sequence, threshold, canonical_search) (include/bft.h:127, src/bft.c:1241-1351; CSV harness
+ * src/file_io.c:1464-1574) for a batch: sequence i is seqs[seq_off[i] .. seq_off[i+1]) (ASCII, no terminator needed).
+ * Every k-mer of a sequence is looked up (its reverse complement instead when canonical != 0 and it is not
+ * lexicographically smaller); k-mers with a character outside ACGTU are skipped.  Row i (CEIL(nb_genomes/8) bytes)
+ * has bit g set iff genome g holds at least ceil(nb_kmers(i) * threshold) of the sequence's k-mers. */
+int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint64_t* seq_off, uint64_t nb_seqs, double threshold,
+                            int canonical, uint8_t* rows);
+
 /* load_BFT / read_BFT_Root (include/bft.h:176, src/write_to_disk.c:260-776): parse a reference .bft file
  * (compressed == 0; annotation modes 0/1/2 and extended-annotation bytes) and build the GPU image from its
  * k-mers and colour sets, with the file's Bloom seeds and genome names. */

@@ -1574,3 +1574,54 @@ long orc_query_branching(orc_bft *t, const uint8_t *kmers, long n, uint8_t *bits
     }
     return nbr;
 }
+
+/* ------------------------------------------------------------------ */
+/* query_sequence (src/bft.c:1241-1351)                               */
+/* ------------------------------------------------------------------ */
+#include <math.h>
+static char rc_char(char c) { /* reverse_complement, src/fasta.c:387-440 (ACGTU only) */
+    switch (c) { case 'A': return 'T'; case 'a': return 't'; case 'C': return 'G'; case 'c': return 'g'; case 'G': return 'C'; case 'g': return 'c';
+                 case 'T': case 'U': return 'A'; case 't': case 'u': return 'a'; default: return c; }
+}
+int orc_query_sequence(orc_bft *t, const char *sequence, double threshold, int canonical, uint32_t nb_genomes, uint32_t *ids, int cap) {
+    orc_freeze(t);
+    const int k = t->k;
+    long len = (long)strlen(sequence), nb = len - k + 1;
+    if (nb < 0) nb = 0;
+    long min_ = (long)ceil((double)nb * threshold); /* :1281 */
+    uint32_t *count = xcalloc(nb_genomes ? nb_genomes : 1, 4);
+    char fwd[130], rc[130];
+    uint8_t packed[40];
+    uint32_t tmp[4096];
+    orc_res res;
+    for (long i = 0; i < nb; i++) {
+        memcpy(fwd, sequence + i, (size_t)k);
+        fwd[k] = 0;
+        const char *kmer = fwd;
+        if (canonical) { /* :1287-1296 */
+            for (int j = 0; j < k; j++) rc[j] = rc_char(fwd[k - 1 - j]);
+            rc[k] = 0;
+            /* compare on the upper-cased ACGT alphabet (strcmp of the reference on its usual upper-case input) */
+            int cmp = 0;
+            for (int j = 0; j < k && !cmp; j++) {
+                char a = fwd[j] & ~0x20, b = rc[j] & ~0x20;
+                if (a == 'U') a = 'T';
+                if (b == 'U') b = 'T';
+                cmp = (a > b) - (a < b);
+            }
+            if (cmp >= 0) kmer = rc;
+        }
+        memset(packed, 0, sizeof(packed));
+        if (!orc_parse_kmer(kmer, k, packed)) continue; /* IUPAC / invalid k-mers are skipped (:1298) */
+        is_kmer_present(t, packed, &res);
+        if (!res.found) continue;
+        int n = orc_annot_decode(res.annot, res.size_annot, tmp, 4096);
+        for (int a = 0; a < n && a < 4096; a++)
+            if (tmp[a] < nb_genomes) count[tmp[a]]++;
+    }
+    int out = 0;
+    for (uint32_t g = 0; g < nb_genomes; g++)
+        if (count[g] && (long)count[g] >= min_) { if (out < cap) ids[out] = g; out++; } /* :1322-1336 */
+    free(count);
+    return out;
+}

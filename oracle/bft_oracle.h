@@ -127,6 +127,11 @@ int orc_colorset(orc_bft *t, uint32_t cs, uint32_t *ids, int cap);
  * counts (optional): (successors << 4) | predecessors.  Returns the number of branching k-mers. */
 long orc_query_branching(orc_bft *t, const uint8_t *kmers, long n, uint8_t *branching_bits, uint8_t *counts);
 
+/* query_sequence(bft, sequence, threshold, canonical_search) src/bft.c:1241-1351: genome ids that hold at least
+ * ceil(nb_kmers * threshold) of the sequence's k-mers.  Returns the number of ids written (sorted). */
+int orc_query_sequence(orc_bft *t, const char *sequence, double threshold, int canonical, uint32_t nb_genomes,
+                       uint32_t *ids, int cap);
+
 /* write_BFT_Root / read_BFT_Root (src/write_to_disk.c:21-258, :260-776): the .bft file format of
  * SURVEY.md A.6 (compressed == 0, no comp_set_colors, no extended annotations).  genome names are
  * "genome_<id>".  orc_load_bft returns NULL on a malformed file. */

@@ -61,6 +61,7 @@ def _load(count=False):
     lib.orc_colorset.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
     lib.orc_query_branching.restype = C.c_long
     lib.orc_query_branching.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    lib.orc_query_sequence.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.orc_write_bft.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.orc_load_bft.restype = C.c_void_p
     lib.orc_load_bft.argtypes = [C.c_char_p]
@@ -208,6 +209,11 @@ class OracleBFT:
         counts = np.zeros(len(kmers), dtype=np.uint8)
         n = self.lib.orc_query_branching(self.h, kmers.ctypes.data, len(kmers), bits.ctypes.data, counts.ctypes.data)
         return bits, counts, int(n)
+
+    def query_sequence(self, seq, threshold, canonical, nb_genomes):
+        out = np.zeros(max(1, nb_genomes), dtype=np.uint32)
+        n = self.lib.orc_query_sequence(self.h, seq.encode(), float(threshold), int(canonical), nb_genomes, out.ctypes.data, len(out))
+        return out[:n].tolist()
 
     def stats(self):
         out = (C.c_long * 10)()

@@ -225,3 +225,35 @@ def test_branching(oracle_mod, k, deep):
     assert (bits == obits).all()
     assert (t.query_branching(q) == obits).all()  # early-exit variant
     assert int(np.unpackbits(bits, bitorder="little")[: len(q)].sum()) == onbr
+
+
+@pytest.mark.parametrize("k,canonical", [(27, False), (27, True), (63, True), (18, False)])
+def test_query_sequences(oracle_mod, k, canonical):
+    ngen = 6
+    anc = S.random_genome(8000, 21)
+    strs = ["".join("ACGT"[c] for c in S.mutate(anc, 0.03, 60 + g)) for g in range(ngen)]
+    comp = str.maketrans("ACGT", "TGCA")
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    for g, s in enumerate(strs):
+        kms = {s[i:i + k] for i in range(len(s) - k + 1)}
+        if canonical:
+            kms = {min(x, x[::-1].translate(comp)) for x in kms}
+        packed, _ = S.ascii_to_packed(sorted(kms), k)
+        t.insert_kmers(packed, g)
+        o.insert_kmers(packed, g)
+    rng = np.random.default_rng(5)
+    reads = []
+    for _ in range(300):
+        g = int(rng.integers(0, ngen))
+        a = int(rng.integers(0, len(strs[g]) - 400))
+        r = strs[g][a:a + int(rng.integers(k - 3, 400))]
+        if rng.random() < 0.5:
+            r = r[::-1].translate(comp)
+        if rng.random() < 0.2 and len(r) > 20:
+            r = r[:15] + "N" + r[16:]
+        reads.append(r)
+    reads += ["", "ACGT", "acgt" * 20]
+    for thr in (0.1, 0.75, 1.0):
+        got = t.query_sequences(reads, thr, canonical)
+        for r, gl in zip(reads, got):
+            assert gl == o.query_sequence(r, thr, canonical, ngen), (r, thr)

@@ -180,3 +180,55 @@ def test_branching_against_ground_truth(oracle_mod, k):
         assert counts[i] == (succ << 4 | pred), (i, counts[i], succ, pred)
         assert bool(bits[i >> 3] >> (i & 7) & 1) == (succ > 1 or pred > 1)
     assert nbr == int(np.unpackbits(bits, bitorder="little")[: len(q)].sum())
+
+
+def _revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_query_sequence_against_ground_truth(oracle_mod, canonical):
+    """query_sequence (src/bft.c:1241-1351): genomes holding >= ceil(nb_kmers * threshold) of a read's k-mers."""
+    import math
+    k, ngen = 27, 5
+    anc = S.random_genome(6000, 12)
+    genomes = [S.mutate(anc, 0.03, 40 + g) for g in range(ngen)]
+    strs = ["".join("ACGT"[c] for c in g) for g in genomes]
+    t = oracle_mod.OracleBFT(k)
+    sets = []
+    for g, s in enumerate(strs):
+        kms = {s[i:i + k] for i in range(len(s) - k + 1)}
+        if canonical:
+            kms = {min(x, _revcomp(x)) for x in kms}
+        sets.append(kms)
+        packed, valid = S.ascii_to_packed(sorted(kms), k)
+        t.insert_kmers(packed, g)
+    rng = np.random.default_rng(3)
+    reads = []
+    for _ in range(40):
+        g = int(rng.integers(0, ngen))
+        a = int(rng.integers(0, len(strs[g]) - 200))
+        r = strs[g][a:a + int(rng.integers(k, 200))]
+        if rng.random() < 0.5:
+            r = _revcomp(r)
+        if rng.random() < 0.3:
+            r = r[:10] + "N" + r[11:]
+        reads.append(r)
+    reads += ["ACGT", "A" * k]
+    for thr in (0.25, 0.8, 1.0):
+        for r in reads:
+            nb = max(0, len(r) - k + 1)
+            mn = math.ceil(nb * thr)
+            exp = []
+            for g in range(ngen):
+                c = 0
+                for i in range(nb):
+                    x = r[i:i + k]
+                    if set(x) - set("ACGT"):
+                        continue
+                    if canonical and x >= _revcomp(x):
+                        x = _revcomp(x)
+                    c += x in sets[g]
+                if c and c >= mn:
+                    exp.append(g)
+            assert t.query_sequence(r, thr, canonical, ngen) == exp, (r, thr)
