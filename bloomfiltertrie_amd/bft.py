@@ -5,12 +5,27 @@ Names follow the reference: create_cdbg / insert_kmers_new_genome / insertKmers 
 get_list_id_genomes.  Batches are numpy uint8 arrays [n, CEIL(2k/8)] in the reference's packed layout
 (bloomfiltertrie_amd.synth / src/fasta.c:3-53).
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _lib
 from .synth import ascii_to_packed, kmer_bytes
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    """Free every live handle before the interpreter (and the HIP runtime under it) is torn down."""
+    for t in list(_LIVE):
+        try:
+            t.close()
+        except Exception:
+            pass
+
 
 INFO_FIELDS = ["k", "kmers", "nodes", "ccs", "uc_rows", "child_nodes", "prefixes", "ccs_s4", "max_ccs_per_node",
                "pairs", "colorsets", "genomes", "image_bytes", "root_ccs", "root_uc_rows", "pending_pairs"]
@@ -30,6 +45,7 @@ class BFT:
         self.k = k
         self.nb = kmer_bytes(k)
         self.device = device
+        _LIVE.add(self)
 
     @classmethod
     def load_bft(cls, path, device=0):
@@ -130,6 +146,7 @@ class BFT:
         """Fixed-width colour rows (the CSV row of src/file_io.c:744-765 before formatting)."""
         kmers = self._chk(kmers)
         n = len(kmers)
+        self.build()  # the genome count is known once the image exists
         g = self.info()["genomes"]
         bits = np.zeros((n + 7) // 8, dtype=np.uint8)
         rows = np.zeros((n, (g + 7) // 8), dtype=np.uint8)
@@ -152,6 +169,7 @@ class BFT:
         off = np.zeros(len(enc) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(e) for e in enc])
         blob = b"".join(enc) + b"\0"
+        self.build()
         g = self.info()["genomes"]
         rows = np.zeros((len(enc), (g + 7) // 8), dtype=np.uint8)
         _lib.check(self._lib.bft_gpu_query_sequences(self._h, blob, off.ctypes.data, len(enc), float(threshold), int(canonical),
