@@ -5,6 +5,7 @@
  *   bft_gpu build k {kmers|kmers_comp} list_genome_files output_file
  *   bft_gpu load file_bft [-query_kmers {kmers|kmers_comp} list_kmer_files]
  *                         [-query_branching {kmers|kmers_comp} list_kmer_files]
+ *                         [-query_sequences threshold {canonical|non_canonical} list_sequence_files]
  *
  * It is the per-k-mer loops of src/file_io.c:89-213 (build), :651-895 (presence CSV) and :897-1020 (branching)
  * rewired to one batched GPU call per file; file reading, ASCII parsing (parseKmerCount, src/fasta.c:3-53) and CSV
@@ -133,13 +134,63 @@ static void query_branching(bft_gpu* h, const char* path, int k, int binary) {
     free(bits); free(b.kmers); free(b.valid);
 }
 
+/* query_sequences_outputCSV (src/file_io.c:1464-1574): one sequence per line, one CSV row per line */
+static void query_sequences(bft_gpu* h, const char* path, double threshold, int canonical, uint32_t nb_genomes, char** names) {
+    FILE* f = fopen(path, "r");
+    if (!f) DIE("Cannot open %s\n", path);
+    char* blob = NULL;
+    size_t blen = 0, bcap = 0, ns = 0, ocap = 1024;
+    uint64_t* off = malloc(ocap * sizeof(uint64_t));
+    off[0] = 0;
+    char* line = NULL;
+    size_t lcap = 0;
+    while (getline(&line, &lcap, f) != -1) {
+        line[strcspn(line, "\r\n")] = 0;
+        const size_t l = strlen(line);
+        if (blen + l + 1 > bcap) { bcap = (blen + l + 1) * 2; blob = realloc(blob, bcap); }
+        memcpy(blob + blen, line, l);
+        blen += l;
+        if (ns + 2 > ocap) { ocap *= 2; off = realloc(off, ocap * sizeof(uint64_t)); }
+        off[++ns] = blen;
+    }
+    free(line);
+    fclose(f);
+    if (!blob) blob = calloc(1, 1);
+    const uint32_t rowbytes = (nb_genomes + 7) / 8;
+    uint8_t* rows = calloc(ns ? ns : 1, rowbytes ? rowbytes : 1);
+    ck(bft_gpu_query_sequences(h, blob, off, ns, threshold, canonical, rows));
+    char* tmp = strdup(path);
+    char* base = basename(tmp);
+    char* outname = malloc(strlen(base) + 5);
+    strcpy(outname, base);
+    char* dot = strrchr(outname, '.');
+    if (dot) strcpy(dot, ".csv"); else strcat(outname, ".csv");
+    FILE* out = fopen(outname, "w");
+    if (!out) DIE("Cannot create %s\n", outname);
+    for (uint32_t g = 0; g < nb_genomes; g++) fprintf(out, "%s%c", names[g], g + 1 < nb_genomes ? ',' : '\n');
+    char* row = malloc((size_t)nb_genomes * 2 + 1);
+    for (size_t i = 0; i < ns; i++) {
+        for (uint32_t g = 0; g < nb_genomes; g++) {
+            row[2 * g] = ((rows[i * rowbytes + (g >> 3)] >> (g & 7)) & 1) ? '1' : '0';
+            row[2 * g + 1] = g + 1 < nb_genomes ? ',' : '\n';
+        }
+        fwrite(row, 1, (size_t)nb_genomes * 2, out);
+    }
+    fseek(out, -1L, SEEK_CUR);
+    fputc('\0', out);
+    fclose(out);
+    printf("\nFile %s has been processed.\n", path);
+    free(row); free(outname); free(tmp); free(rows); free(off); free(blob);
+}
+
 int main(int argc, char** argv) {
     if (argc < 3)
         DIE("\nUsage:\n"
             "bft_gpu build k {kmers|kmers_comp} list_genome_files output_file\n"
             "bft_gpu load file_bft [Options]\n\nOptions:\n"
             "[-query_kmers {kmers|kmers_comp} list_kmer_files]\n"
-            "[-query_branching {kmers|kmers_comp} list_kmer_files]\n\n");
+            "[-query_branching {kmers|kmers_comp} list_kmer_files]\n"
+            "[-query_sequences threshold {canonical|non_canonical} list_sequence_files]\n\n");
     bft_gpu* h = NULL;
     int k = 0, i = 0;
     char buffer[2048];
@@ -189,6 +240,22 @@ int main(int argc, char** argv) {
         ck(bft_gpu_genome_name(h, g, names[g], 4096));
     }
     for (; i + 2 < argc; i += 3) {
+        if (strcmp(argv[i], "-query_sequences") == 0) { /* src/main.c:270-296: four arguments */
+            if (i + 3 >= argc) DIE("-query_sequences threshold {canonical|non_canonical} list_sequence_files\n");
+            const double threshold = atof(argv[i + 1]);
+            if (threshold == 0) DIE("Could not parse threshold for command -query_sequences.\n");
+            if (strcmp(argv[i + 2], "canonical") != 0 && strcmp(argv[i + 2], "non_canonical") != 0)
+                DIE("Unrecognized type of k-mers to search for %s.\n", argv[i]);
+            FILE* lst = fopen(argv[i + 3], "r");
+            if (!lst) DIE("Invalid sequence query file list.\n");
+            while (fgets(buffer, sizeof buffer, lst)) {
+                buffer[strcspn(buffer, "\r\n")] = 0;
+                if (buffer[0]) query_sequences(h, buffer, threshold, strcmp(argv[i + 2], "canonical") == 0, nb_genomes, names);
+            }
+            fclose(lst);
+            i++;
+            continue;
+        }
         const int binary = strcmp(argv[i + 1], "kmers_comp") == 0;
         if (!binary && strcmp(argv[i + 1], "kmers") != 0) DIE("Unrecognized type of input files for %s.\n", argv[i]);
         FILE* lst = fopen(argv[i + 2], "r");
