@@ -76,3 +76,32 @@ def test_kmers_comp_input_and_bad_k(tmp_path):
     assert out.returncode == 0 and "Nb k-mers present = 1000" in out.stdout
     bad = subprocess.run([CLI, "build", "31", "kmers", "list.txt", "x.bft"], capture_output=True, text=True)
     assert bad.returncode != 0 and "multiple of 9" in bad.stderr
+
+
+def test_query_sequences_csv(oracle_mod, tmp_path):
+    k, ngen = 27, 4
+    anc = S.random_genome(6000, 14)
+    strs = ["".join("ACGT"[c] for c in S.mutate(anc, 0.03, 80 + g)) for g in range(ngen)]
+    os.chdir(tmp_path)
+    names = []
+    o = oracle_mod.OracleBFT(k)
+    for g, s in enumerate(strs):
+        km = S.distinct(S.kmers_of(S._CODE[np.frombuffer(s.encode(), dtype=np.uint8)], k))
+        _write_ascii(tmp_path / f"g{g}.kmers", km, k)
+        names.append(f"g{g}.kmers")
+        o.insert_kmers(km, g)
+    (tmp_path / "list.txt").write_text("".join(str(tmp_path / n) + "\n" for n in names))
+    assert subprocess.run([CLI, "build", str(k), "kmers", "list.txt", "o.bft"], capture_output=True).returncode == 0
+    rng = np.random.default_rng(2)
+    reads = [strs[int(rng.integers(0, ngen))][a:a + int(rng.integers(30, 250))] for a in rng.integers(0, 5000, 60)]
+    reads += ["ACGTACGT", "N" * 40]
+    (tmp_path / "reads.txt").write_text("\n".join(reads) + "\n")
+    (tmp_path / "rl.txt").write_text(str(tmp_path / "reads.txt") + "\n")
+    out = subprocess.run([CLI, "load", "o.bft", "-query_sequences", "0.6", "non_canonical", "rl.txt"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    exp = ",".join(names) + "\n"
+    for r in reads:
+        have = set(o.query_sequence(r, 0.6, False, ngen))
+        exp += ",".join("1" if g in have else "0" for g in range(ngen)) + "\n"
+    exp = exp[:-1] + "\0"
+    assert (tmp_path / "reads.csv").read_bytes().decode() == exp
