@@ -1,0 +1,47 @@
+"""Randomised cross-check on the GPU box: many seeded configurations (k, sizes, entropy, genomes, insertion batches),
+HIP path vs oracle for presence, colours, branching and extraction."""
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz(oracle_mod, seed):
+    from bloomfiltertrie_amd import BFT
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([9, 18, 27, 36, 45, 54, 63, 72, 81, 90, 99, 108, 117, 126]))
+    ngen = int(rng.integers(1, 9))
+    levels = int(rng.integers(0, min(4, k // 9) + 1))
+    n = int(rng.choice([0, 1, 200, 254, 255, 256, 257, 3000, 40000]))
+    if levels and n:
+        base = S.low_entropy_kmers(n, k, int(rng.integers(2, 40)), seed=seed, levels=levels)
+    elif n:
+        base = S.distinct(S.pack_codes(rng.integers(0, 4, (n, k), dtype=np.uint8)))
+    else:
+        base = np.zeros((0, S.kmer_bytes(k)), np.uint8)
+    t, o = BFT(k), oracle_mod.OracleBFT(k)
+    for g in range(ngen):
+        km = base[rng.random(len(base)) < rng.uniform(0.2, 1.0)] if len(base) else base
+        for part in np.array_split(km, int(rng.integers(1, 4))):
+            t.insert_kmers(np.ascontiguousarray(part), g)
+        o.insert_kmers(np.ascontiguousarray(km), g)
+        if rng.random() < 0.4:
+            t.build()  # incremental rebuilds at random points
+    parts = [S.pack_codes(rng.integers(0, 4, (int(rng.integers(1, 500)), k), dtype=np.uint8))]
+    if len(base):
+        parts += [base[:: max(1, len(base) // 3000)], S.snp_mutants(base[:: max(1, len(base) // 2000)], k, seed)]
+    q = np.concatenate(parts)
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    bits, off, ids = t.query_colors(q)
+    obits, ooff, oids = o.query_colors(q)
+    assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+    assert (t.query_presence(q) == obits).all()
+    bb, bc = t.query_branching(q, with_counts=True)
+    ob, oc, _ = o.query_branching(q)
+    assert (bc == oc).all() and (bb == ob).all()
+    ek, _ = t.extract()
+    ok, _ = o.extract()
+    assert sorted(map(bytes, ek)) == sorted(map(bytes, ok))
