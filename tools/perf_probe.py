@@ -21,6 +21,12 @@ def workload(name):
         k = 27
         anc = S.random_genome(2_000_000, 1234)
         gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]
+    elif name == "small":  # the whole table fits the 4 MiB L2 of one XCD
+        k = 27
+        gk = [S.distinct(S.kmers_of(S.random_genome(300_000, 5), k))]
+    elif name == "mid":  # fits the 256 MiB Infinity Cache, not L2
+        k = 27
+        gk = [S.distinct(S.kmers_of(S.random_genome(3_000_000, 6), k))]
     elif name == "deep":  # low-entropy: three trie levels are exercised
         k = 27
         gk = [S.low_entropy_kmers(6_000_000, k, 600, seed=7, levels=1)]
