@@ -3,7 +3,8 @@
  * `bft` binary for the hot path (src/main.c:40-47, :180-316):
  *
  *   bft_gpu build k {kmers|kmers_comp} list_genome_files output_file
- *   bft_gpu load file_bft [-query_kmers {kmers|kmers_comp} list_kmer_files]
+ *   bft_gpu load file_bft [-add_genomes {kmers|kmers_comp} list_genome_files output_file]
+ *                         [-query_kmers {kmers|kmers_comp} list_kmer_files]
  *                         [-query_branching {kmers|kmers_comp} list_kmer_files]
  *                         [-query_sequences threshold {canonical|non_canonical} list_sequence_files]
  *
@@ -183,11 +184,36 @@ static void query_sequences(bft_gpu* h, const char* path, double threshold, int 
     free(row); free(outname); free(tmp); free(rows); free(off); free(blob);
 }
 
+/* insert_Genomes_from_KmerFiles (src/file_io.c:89-213): one genome per listed file, ids in file order */
+static void insert_genomes(bft_gpu* h, const char* list_path, int k, int binary) {
+    char buffer[2048];
+    FILE* lst = fopen(list_path, "r");
+    if (!lst) DIE("Invalid list_genome_files.\n");
+    while (fgets(buffer, sizeof buffer, lst)) {
+        buffer[strcspn(buffer, "\r\n")] = 0;
+        if (!buffer[0]) continue;
+        uint32_t gid;
+        char* tmp = strdup(buffer);
+        ck(bft_gpu_add_genome(h, basename(tmp), &gid));
+        free(tmp);
+        printf("\nFile %u: %s\n\n", gid, buffer);
+        batch b = read_kmer_file(buffer, k, binary);
+        const int nb = (2 * k + 7) / 8;
+        uint64_t m = 0; /* invalid lines are skipped on insertion (src/file_io.c:159) */
+        for (uint64_t q = 0; q < b.n_lines; q++)
+            if (b.valid[q]) { if (m != q) memmove(b.kmers + m * nb, b.kmers + q * nb, (size_t)nb); m++; }
+        ck(bft_gpu_insert_kmers(h, b.kmers, m, gid));
+        free(b.kmers); free(b.valid);
+    }
+    fclose(lst);
+    ck(bft_gpu_build(h));
+}
+
 int main(int argc, char** argv) {
     if (argc < 3)
         DIE("\nUsage:\n"
             "bft_gpu build k {kmers|kmers_comp} list_genome_files output_file\n"
-            "bft_gpu load file_bft [Options]\n\nOptions:\n"
+            "bft_gpu load file_bft [-add_genomes {kmers|kmers_comp} list_genome_files output_file] [Options]\n\nOptions:\n"
             "[-query_kmers {kmers|kmers_comp} list_kmer_files]\n"
             "[-query_branching {kmers|kmers_comp} list_kmer_files]\n"
             "[-query_sequences threshold {canonical|non_canonical} list_sequence_files]\n\n");
@@ -200,33 +226,20 @@ int main(int argc, char** argv) {
         if (k <= 0) DIE("Provided length k (for k-mers) is either <= 0 or not a number.\n");
         if (k % 9 != 0) DIE("Length k (for k-mers) must be a multiple of 9.\n"); /* src/main.c:63 */
         const int binary = strcmp(argv[3], "kmers_comp") == 0;
-        FILE* lst = fopen(argv[4], "r");
-        if (!lst) DIE("Invalid list_genome_files.\n");
         ck(bft_gpu_create(k, 0, &h));
-        int fno = 0;
-        while (fgets(buffer, sizeof buffer, lst)) {
-            buffer[strcspn(buffer, "\r\n")] = 0;
-            if (!buffer[0]) continue;
-            uint32_t gid;
-            char* tmp = strdup(buffer);
-            ck(bft_gpu_add_genome(h, basename(tmp), &gid));
-            free(tmp);
-            printf("\nFile %d: %s\n\n", fno++, buffer);
-            batch b = read_kmer_file(buffer, k, binary);
-            const int nb = (2 * k + 7) / 8;
-            uint64_t m = 0; /* invalid lines are skipped on insertion (src/file_io.c:159) */
-            for (uint64_t q = 0; q < b.n_lines; q++)
-                if (b.valid[q]) { if (m != q) memmove(b.kmers + m * nb, b.kmers + q * nb, (size_t)nb); m++; }
-            ck(bft_gpu_insert_kmers(h, b.kmers, m, gid));
-            free(b.kmers); free(b.valid);
-        }
-        fclose(lst);
-        ck(bft_gpu_build(h));
+        insert_genomes(h, argv[4], k, binary);
         ck(bft_gpu_write_bft(h, argv[5]));
         i = 6;
     } else if (strcmp(argv[1], "load") == 0) {
         ck(bft_gpu_load_bft(argv[2], 0, &h));
         i = 3;
+        if (i + 3 < argc && strcmp(argv[i], "-add_genomes") == 0) { /* src/main.c:217-246 */
+            uint64_t inf[16];
+            ck(bft_gpu_info(h, inf, 16));
+            insert_genomes(h, argv[i + 2], (int)inf[0], strcmp(argv[i + 1], "kmers_comp") == 0);
+            ck(bft_gpu_write_bft(h, argv[i + 3]));
+            i += 4;
+        }
     } else
         DIE("Unrecognized command %s.\n", argv[1]);
 

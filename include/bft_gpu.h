@@ -17,6 +17,8 @@
  * message for the calling thread.  (The reference has no error codes: ERROR() prints and exits,
  * include/useful_macros.h:33-43; the C wrapper of INTEGRATION.md keeps that behaviour.)
  * There is NO CPU fallback: without a usable HIP device every call fails with BFT_GPU_E_HIP.
+ * A handle is not thread-safe (like BFT_Root, whose scratch fields make insertion and colour decoding non re-entrant,
+ * include/Node.h:107-109): use one handle per thread, or serialise calls; distinct handles are independent.
  */
 #ifndef BFT_GPU_H
 #define BFT_GPU_H
