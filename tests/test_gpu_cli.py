@@ -105,3 +105,26 @@ def test_query_sequences_csv(oracle_mod, tmp_path):
         exp += ",".join("1" if g in have else "0" for g in range(ngen)) + "\n"
     exp = exp[:-1] + "\0"
     assert (tmp_path / "reads.csv").read_bytes().decode() == exp
+
+
+def test_add_genomes(oracle_mod, tmp_path):
+    """bft load X -add_genomes kmers list out (src/main.c:217-246): the extended index equals a one-shot build."""
+    k = 18
+    anc = S.random_genome(8000, 31)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.03, 5 + g), k)) for g in range(4)]
+    os.chdir(tmp_path)
+    for g, km in enumerate(gk):
+        _write_ascii(tmp_path / f"g{g}.kmers", km, k)
+    (tmp_path / "l01.txt").write_text("".join(str(tmp_path / f"g{g}.kmers") + "\n" for g in (0, 1)))
+    (tmp_path / "l23.txt").write_text("".join(str(tmp_path / f"g{g}.kmers") + "\n" for g in (2, 3)))
+    assert subprocess.run([CLI, "build", str(k), "kmers", "l01.txt", "a.bft"], capture_output=True).returncode == 0
+    out = subprocess.run([CLI, "load", "a.bft", "-add_genomes", "kmers", "l23.txt", "b.bft"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    o = oracle_mod.OracleBFT.load_bft(str(tmp_path / "b.bft"))
+    ref = oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        ref.insert_kmers(km, g)
+    allk = S.distinct(np.concatenate(gk))
+    q = np.concatenate([allk, S.snp_mutants(allk[::3], k, 1)])
+    assert all((a == b).all() for a, b in zip(o.query_colors(q), ref.query_colors(q)))
+    assert o.nb_genomes_loaded() == 4
