@@ -2,8 +2,9 @@
 //
 //   bft_file_read : read_BFT_Root / read_Node / read_UC / read_CC (src/write_to_disk.c:260-776) reduced to what
 //                   the GPU build needs: every stored k-mer with its sorted genome-id list, decoded from the
-//                   reference's annotation encodings (modes 0/1/2, src/annotation.c:2086-2250; the one extra
-//                   byte of the extended-annotation table, src/UC.c:501-521).  Bloom filters and skip tables
+//                   reference's annotation encodings (modes 0/1/2, src/annotation.c:2086-2250; mode 3 = index
+//                   into the file's comp_set_colors with delta-coded entries, :1840-1922; the one extra byte of
+//                   the extended-annotation table, src/UC.c:501-521).  Bloom filters and skip tables
 //                   are not in the file; the image rebuilds its own.
 //   bft_file_write: write_BFT_Root / write_Node / write_UC / write_CC (src/write_to_disk.c:21-258) from a host copy
 //                   of the image arrays, in the reference's container layout (filter2 | filter3 |
@@ -96,7 +97,38 @@ bool annot_decode(const uint8_t* a, size_t size, std::vector<uint32_t>& ids) {
             ids.push_back(v);
         }
     } else
-        return false;  // mode 3: index into comp_set_colors (Judy-compressed files)
+        return false;  // mode 3: index into comp_set_colors, resolved by the reader (needs the file's dictionary)
+    return true;
+}
+
+// comp_set_colors (src/write_to_disk.c:283-310): elements of equal-size entries; an entry in mode 1/2 is delta-coded
+// by comp_annotation (src/annotation.c:1777-1838) and decoded as decomp_annotation + get_id_genomes_from_annot with
+// comp_annot > 0 do (:1840-1922, :2179-2226)
+struct CompElem {
+    int64_t last_index = 0;
+    int size_annot = 0;
+    std::vector<uint8_t> bytes;
+};
+
+bool decode_comp_entry(const uint8_t* a, size_t size, std::vector<uint32_t>& ids) {
+    if (size == 0) { ids.clear(); return true; }
+    const int mode = a[0] & 3;
+    if (mode == 0) return annot_decode(a, size, ids);
+    if (mode == 3) return false;
+    ids.clear();
+    const uint8_t flag1 = mode == 2 ? 2 : 1, flag2 = mode == 2 ? 1 : 2;
+    std::vector<uint32_t> st;
+    size_t i = 0;
+    while (i < size && (a[i] & flag1)) {
+        uint32_t v = a[i++] >> 2;
+        while (i < size && (a[i] & flag2)) v = (v << 6) | (a[i++] >> 2);
+        st.push_back(v);
+    }
+    for (size_t q = 1; q < st.size(); q++) st[q] += st[q - 1];
+    if (mode == 2) ids = st;
+    else
+        for (size_t q = 0; q + 1 < st.size(); q += 2)
+            for (uint32_t v = st[q]; v <= st[q + 1]; v++) ids.push_back(v);
     return true;
 }
 
@@ -135,6 +167,21 @@ struct Reader {
     std::vector<uint8_t> cur;  // nucleotide codes of the k-mer being rebuilt
     std::vector<uint32_t> ids;
     std::vector<uint8_t> packed;
+    std::vector<CompElem> comp;  // the file's comp_set_colors
+
+    // any annotation of the file -> ids; mode 3 = index into comp_set_colors (src/annotation.c:2097-2119)
+    bool decode_annot(const uint8_t* a, size_t size) {
+        if (size && (a[0] & 3) == 3) {
+            uint32_t pos = a[0] >> 2;
+            for (size_t i = 1; i < size && (a[i] & 1); i++) pos |= ((uint32_t)(a[i] >> 1)) << (6 + (i - 1) * 7);
+            size_t e = 0;
+            while (e < comp.size() && (int64_t)pos > comp[e].last_index) e++;
+            if (e >= comp.size()) return false;
+            const int64_t rel = e == 0 ? (int64_t)pos : (int64_t)pos - comp[e - 1].last_index - 1;
+            return decode_comp_entry(comp[e].bytes.data() + rel * comp[e].size_annot, (size_t)comp[e].size_annot, ids);
+        }
+        return annot_decode(a, size, ids);
+    }
 
     void fail(const char* m) { if (!err) { err = true; msg = m; } }
     void rd(void* p, size_t n) { if (!err && n && fread(p, 1, n, f) != n) fail("truncated file"); }
@@ -213,10 +260,10 @@ struct Reader {
         if (it != r.ext_pos.end() && *it == q) {
             std::vector<uint8_t> tmp(a, a + r.size_annot);
             tmp.push_back(r.ext_byte[it - r.ext_pos.begin()]);
-            ok = annot_decode(tmp.data(), tmp.size(), ids);
+            ok = decode_annot(tmp.data(), tmp.size());
         } else
-            ok = annot_decode(a, (size_t)r.size_annot, ids);
-        if (!ok) fail("mode-3 (Judy-compressed) annotations are not supported");
+            ok = decode_annot(a, (size_t)r.size_annot);
+        if (!ok) fail("undecodable annotation (bad comp_set_colors index or nested mode 3)");
     }
     void put_suffix(int at, const uint8_t* bytes, int len_nt, bool mask_flag) {
         const int last = nb_bytes(len_nt) - 1;
@@ -317,7 +364,16 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
     R.f = fopen(path, "rb");
     if (!R.f) { err = std::string("cannot open ") + path; return false; }
     const int lcs = R.i32();
-    if (lcs != 0) { fclose(R.f); err = "file holds Judy-compressed colour sets (mode-3 annotations): not supported"; return false; }
+    if (R.err || lcs < 0 || lcs > (1 << 24)) { fclose(R.f); err = "bad .bft header"; return false; }
+    R.comp.resize(lcs);
+    for (int e = 0; e < lcs && !R.err; e++) {  // src/write_to_disk.c:283-310
+        R.rd(&R.comp[e].last_index, 8);
+        R.comp[e].size_annot = R.i32();
+        const int64_t cnt = e ? R.comp[e].last_index - R.comp[e - 1].last_index : R.comp[e].last_index + 1;
+        if (R.err || cnt < 0 || R.comp[e].size_annot < 0 || cnt * R.comp[e].size_annot > (int64_t(1) << 32)) { R.fail("bad comp_set_colors"); break; }
+        R.comp[e].bytes.resize((size_t)(cnt * R.comp[e].size_annot));
+        R.rd(R.comp[e].bytes.data(), R.comp[e].bytes.size());
+    }
     out.r1 = R.i32();
     out.r2 = R.i32();
     (void)R.i32();

@@ -314,8 +314,15 @@ struct orc_node {
     orc_uc fuc; /* frozen node UC */
 };
 
+/* comp_set_colors (src/write_to_disk.c:283-310): elements of equal-size entries */
+typedef struct { int64_t last_index; int size_annot; uint8_t *bytes; } comp_elem;
+
 struct orc_bft {
     int k, r1, r2;
+    /* optional test mode: annotations written as mode-3 indices into comp_set_colors, and/or with the last
+     * annotation byte of the widest rows moved to the extended-annotation table (what reference-built files hold) */
+    int comp_on, ext_on;
+    uint32_t *cs_pos; comp_elem *celems; int ncelems;
     uint64_t *hash_v;   /* include/Node.h:158-185 */
     uint16_t *hmod;     /* hash_v % 1504 for the 2^14 keys used when compressed==0 */
     orc_node root;
@@ -328,6 +335,43 @@ struct orc_bft {
     /* memo (cs, gid) -> cs' open addressing */
     uint64_t *memo_key; uint32_t *memo_val; long memo_cap, memo_n;
 };
+
+static comp_elem *g_comp = NULL; /* only used while a file is being loaded (single-threaded test infrastructure) */
+static int g_ncomp = 0;
+
+/* decomp_annotation + get_id_genomes_from_annot with comp_annot > 0 (src/annotation.c:1840-1922, :2179-2226):
+ * the stored ids are deltas to the previous stored id; mode 1 then expands (start, stop) pairs */
+static int decode_comp_entry(const uint8_t *a, int size, uint32_t *ids, int cap) {
+    int mode = a[0] & 3;
+    if (mode == 0 || mode == 3) return orc_annot_decode(a, size, ids, cap);
+    uint8_t flag1 = mode == 2 ? 2 : 1, flag2 = mode == 2 ? 1 : 2;
+    uint32_t st[8192];
+    int ns = 0, i = 0;
+    while (i < size && (a[i] & flag1) && ns < 8192) {
+        uint32_t v = a[i++] >> 2;
+        while (i < size && (a[i] & flag2)) v = (v << 6) | (a[i++] >> 2);
+        st[ns++] = v;
+    }
+    for (int q = 1; q < ns; q++) st[q] += st[q - 1];
+    int n = 0;
+    if (mode == 2) { for (int q = 0; q < ns; q++) { if (n < cap) ids[n] = st[q]; n++; } }
+    else for (int q = 0; q + 1 < ns; q += 2) for (uint32_t v = st[q]; v <= st[q + 1]; v++) { if (n < cap) ids[n] = v; n++; }
+    return n;
+}
+
+static int decode_any(const uint8_t *annot, int size, uint32_t *ids, int cap) {
+    if (size > 0 && (annot[0] & 3) == 3) { /* index into comp_set_colors (src/annotation.c:2097-2119) */
+        uint32_t pos = annot[0] >> 2;
+        for (int i = 1; i < size && (annot[i] & 1); i++) pos |= ((uint32_t)(annot[i] >> 1)) << (6 + (i - 1) * 7);
+        int e = 0;
+        while (e < g_ncomp && (int64_t)pos > g_comp[e].last_index) e++;
+        if (e >= g_ncomp) return -1;
+        int64_t rel = e == 0 ? pos : (int64_t)pos - g_comp[e - 1].last_index - 1;
+        return decode_comp_entry(g_comp[e].bytes + rel * g_comp[e].size_annot, g_comp[e].size_annot, ids, cap);
+    }
+    return orc_annot_decode(annot, size, ids, cap);
+}
+
 
 static inline int nb_bytes(int i) { return CEIL(i * 2, 8); }
 static inline int nbm1_bytes(int i) { return i > 9 ? CEIL((i - 9) * 2, 8) : 0; }
@@ -506,6 +550,8 @@ static void free_node(orc_node *nd, int i) {
 void orc_free(orc_bft *t) {
     if (!t) return;
     free_node(&t->root, t->k);
+    for (int e = 0; e < t->ncelems; e++) free(t->celems[e].bytes);
+    free(t->celems); free(t->cs_pos);
     free(t->hash_v); free(t->hmod); free(t->cs_ids); free(t->cs_off); free(t->memo_key); free(t->memo_val);
     free(t);
 }
@@ -735,13 +781,22 @@ int orc_insert_kmers(orc_bft *t, const uint8_t *kmers, long n, uint32_t id_genom
 /* freeze: packed arrays of include/CC.h:34-67                        */
 /* ------------------------------------------------------------------ */
 
+/* index of a comp_set_colors entry as annotation bytes (src/replaceAnnotation.c:380-386) */
+static int put_comp_index(uint32_t id, uint8_t *out) {
+    int n = 1;
+    out[0] = (uint8_t)(((id & 0x3f) << 2) | 0x3);
+    for (uint32_t rest = id >> 6; rest; rest >>= 7) out[n++] = (uint8_t)(((rest & 0x7f) << 1) | 0x1);
+    return n;
+}
 static int cs_encode(orc_bft *t, uint32_t cs, uint8_t *out, int cap) {
     long a = t->cs_off[cs], b = t->cs_off[cs + 1];
+    if (t->comp_on && b > a) { uint8_t tmp[8]; int n = put_comp_index(t->cs_pos[cs], tmp); if (n > cap) return -1; memcpy(out, tmp, (size_t)n); return n; }
     return orc_annot_encode(t->cs_ids + a, (int)(b - a), out, cap);
 }
 static int cs_size(orc_bft *t, uint32_t cs) {
     long a = t->cs_off[cs], b = t->cs_off[cs + 1];
     int mode;
+    if (t->comp_on && b > a) { uint8_t tmp[8]; return put_comp_index(t->cs_pos[cs], tmp); }
     return b > a ? annot_best(t->cs_ids + a, (int)(b - a), &mode) : 1;
 }
 
@@ -1164,6 +1219,8 @@ long orc_query_presence_count(orc_bft *t, const uint8_t *kmers, long n, uint8_t 
 
 long orc_query_colors(orc_bft *t, const uint8_t *kmers, long n, uint8_t *present_bits, uint64_t *offsets, uint32_t *ids, long ids_cap) {
     orc_freeze(t);
+    g_comp = t->celems;
+    g_ncomp = t->ncelems;
     int nb = nb_bytes(t->k);
     long total = 0;
     memset(present_bits, 0, (size_t)CEIL(n, 8));
@@ -1174,7 +1231,7 @@ long orc_query_colors(orc_bft *t, const uint8_t *kmers, long n, uint8_t *present
         if (!res.found) continue;
         present_bits[a >> 3] |= (uint8_t)(1u << (a & 7));
         long room = ids_cap - total;
-        int cnt = orc_annot_decode(res.annot, res.size_annot, room > 0 ? ids + total : NULL, room > 0 ? (int)(room > INT_MAX ? INT_MAX : room) : 0);
+        int cnt = decode_any(res.annot, res.size_annot, room > 0 ? ids + total : NULL, room > 0 ? (int)(room > INT_MAX ? INT_MAX : room) : 0);
         total += cnt;
     }
     offsets[n] = (uint64_t)total;
@@ -1283,13 +1340,32 @@ static void wr_u16(FILE *f, uint16_t v) { wr(f, &v, 2); }
 static void wr_u32(FILE *f, uint32_t v) { wr(f, &v, 4); }
 static void wr_i32(FILE *f, int32_t v) { wr(f, &v, 4); }
 
-/* write_UC, uncompressed branch (src/write_to_disk.c:107-213) */
+static int g_write_ext = 0;
+/* write_UC, uncompressed branch (src/write_to_disk.c:107-213).  With g_write_ext the last annotation byte of the rows
+ * that use all size_annot bytes goes to the extended-annotation table (src/UC.c:321-521) and size_annot shrinks by
+ * one: the shape reference-built files have after annotations grew by one byte. */
 static void write_uc(FILE *f, const uint8_t *data, int size_annot, int nbs, int count, int header_field, int with_header) {
     if (with_header) wr_u16(f, (uint16_t)header_field);
-    if (count) {
-        wr_u16(f, 0);             /* nb_extended_annot */
-        wr_i32(f, size_annot);    /* UC_SIZE_ANNOT_T */
-        wr(f, data, (size_t)count * (nbs + size_annot));
+    if (!count) return;
+    int stride = nbs + size_annot, next = 0;
+    if (g_write_ext && size_annot >= 2)
+        for (int q = 0; q < count; q++) next += data[(size_t)q * stride + stride - 1] != 0;
+    if (!next) {
+        wr_u16(f, 0);          /* nb_extended_annot */
+        wr_i32(f, size_annot); /* UC_SIZE_ANNOT_T */
+        wr(f, data, (size_t)count * stride);
+        return;
+    }
+    wr_u16(f, (uint16_t)next);
+    wr_i32(f, size_annot - 1);
+    for (int q = 0; q < count; q++) wr(f, data + (size_t)q * stride, (size_t)stride - 1);
+    int prev = 0;
+    for (int q = 0; q < count; q++) {
+        uint8_t last = data[(size_t)q * stride + stride - 1];
+        if (!last) continue;
+        uint8_t e[3] = {(uint8_t)((q - prev) >> 8), (uint8_t)((q - prev) & 0xff), last};
+        wr(f, e, 3);
+        prev = q;
     }
 }
 
@@ -1351,7 +1427,15 @@ int orc_write_bft(orc_bft *t, const char *path, int nb_genomes) {
     orc_freeze(t);
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
-    wr_i32(f, 0); /* length_comp_set_colors */
+    g_write_ext = t->ext_on;
+    wr_i32(f, t->comp_on ? t->ncelems : 0); /* length_comp_set_colors */
+    if (t->comp_on)
+        for (int e = 0; e < t->ncelems; e++) { /* src/write_to_disk.c:36-61 */
+            int64_t cnt = e ? t->celems[e].last_index - t->celems[e - 1].last_index : t->celems[e].last_index + 1;
+            wr(f, &t->celems[e].last_index, 8);
+            wr_i32(f, t->celems[e].size_annot);
+            wr(f, t->celems[e].bytes, (size_t)(cnt * t->celems[e].size_annot));
+        }
     wr_i32(f, t->r1); wr_i32(f, t->r2); wr_i32(f, 0 /* treshold_compression */); wr_i32(f, nb_genomes); wr_i32(f, t->k);
     uint8_t comp = 0;
     wr(f, &comp, 1);
@@ -1367,7 +1451,67 @@ int orc_write_bft(orc_bft *t, const char *path, int nb_genomes) {
     }
     write_node(f, t, &t->root, t->k, 0);
     fclose(f);
+    g_write_ext = 0;
     return 0;
+}
+
+/* comp_annotation (src/annotation.c:1777-1838): delta-code the stored ids of a mode-1 / mode-2 annotation */
+static int comp_entry(const uint32_t *ids, int n, uint8_t *out, int cap) {
+    uint8_t plain[8192];
+    int sz = orc_annot_encode(ids, n, plain, (int)sizeof(plain));
+    if (sz < 0) return -1;
+    int mode = plain[0] & 3;
+    if (mode == 0) { if (sz > cap) return -1; memcpy(out, plain, (size_t)sz); return sz; }
+    uint32_t st[8192];
+    int ns = 0;
+    if (mode == 2) for (int a = 0; a < n && ns < 8192; a++) st[ns++] = ids[a];
+    else for (int a = 0; a < n && ns + 1 < 8192;) { int b = a; while (b + 1 < n && ids[b + 1] == ids[b] + 1) b++; st[ns++] = ids[a]; st[ns++] = ids[b]; a = b + 1; }
+    for (int q = ns - 1; q > 0; q--) st[q] -= st[q - 1];
+    int o = 0;
+    for (int q = 0; q < ns; q++) { if (o + 6 > cap) return -1; o += put_id(out + o, st[q], mode == 2 ? 0x2 : 0x1, mode == 2 ? 0x1 : 0x2); }
+    return o;
+}
+
+typedef struct { int size; uint32_t cs; } comp_ord;
+static int cmp_comp_ord(const void *a, const void *b) {
+    const comp_ord *x = a, *y = b;
+    if (x->size != y->size) return x->size - y->size;
+    return x->cs < y->cs ? -1 : x->cs > y->cs;
+}
+
+void orc_set_annotation_modes(orc_bft *t, int comp_on, int ext_on) {
+    for (int e = 0; e < t->ncelems; e++) free(t->celems[e].bytes);
+    free(t->celems); free(t->cs_pos);
+    t->celems = NULL; t->cs_pos = NULL; t->ncelems = 0;
+    t->comp_on = comp_on; t->ext_on = ext_on; t->dirty = 1;
+    if (!comp_on || t->cs_n <= 1) { t->comp_on = 0; return; }
+    long ncs = t->cs_n - 1; /* set 0 is the empty set */
+    uint8_t **enc = xcalloc((size_t)ncs, sizeof(uint8_t *));
+    comp_ord *ord = xmalloc((size_t)ncs * sizeof(comp_ord));
+    for (long c = 0; c < ncs; c++) {
+        long a = t->cs_off[c + 1], b = t->cs_off[c + 2];
+        uint8_t tmp[16384];
+        int sz = comp_entry(t->cs_ids + a, (int)(b - a), tmp, (int)sizeof(tmp));
+        if (sz < 0) { fprintf(stderr, "oracle: colour set too large for the test compressor\n"); exit(1); }
+        enc[c] = xmalloc((size_t)sz);
+        memcpy(enc[c], tmp, (size_t)sz);
+        ord[c].size = sz; ord[c].cs = (uint32_t)(c + 1);
+    }
+    qsort(ord, (size_t)ncs, sizeof(comp_ord), cmp_comp_ord);
+    t->cs_pos = xcalloc((size_t)t->cs_n, 4);
+    t->celems = xcalloc((size_t)ncs, sizeof(comp_elem));
+    for (long q = 0; q < ncs;) {
+        long q2 = q;
+        while (q2 + 1 < ncs && ord[q2 + 1].size == ord[q].size) q2++;
+        comp_elem *el = &t->celems[t->ncelems++];
+        el->size_annot = ord[q].size;
+        el->last_index = q2;
+        el->bytes = xmalloc((size_t)(q2 - q + 1) * ord[q].size);
+        for (long z = q; z <= q2; z++) { memcpy(el->bytes + (size_t)(z - q) * ord[q].size, enc[ord[z].cs - 1], (size_t)ord[q].size); t->cs_pos[ord[z].cs] = (uint32_t)z; }
+        q = q2 + 1;
+    }
+    for (long c = 0; c < ncs; c++) free(enc[c]);
+    free(enc); free(ord);
 }
 
 typedef struct { FILE *f; int err; int nb_genomes; } rd_ctx;
@@ -1378,24 +1522,37 @@ static int32_t rd_i32(rd_ctx *c) { int32_t v = 0; rd(c, &v, 4); return v; }
 
 static uint32_t cs_from_annot(orc_bft *t, const uint8_t *annot, int size) {
     uint32_t ids[4096];
-    int n = orc_annot_decode(annot, size, ids, 4096);
+    int n = decode_any(annot, size, ids, 4096);
     uint32_t cs = 0;
     for (int a = 0; a < n && a < 4096; a++) cs = cs_add(t, cs, ids[a]);
     return cs;
 }
 
-/* read_UC uncompressed branch (src/write_to_disk.c:383-531): returns rows (nbs + size_annot each) */
+/* read_UC uncompressed branch (src/write_to_disk.c:383-531): returns rows (nbs + size_annot each).  Rows that own an
+ * entry of the extended-annotation table (3-byte entries: big-endian position delta + 1 byte, src/UC.c:501-521) get
+ * that byte appended: the rows are returned one byte wider (*size_annot is the widened size). */
 static uint8_t *read_uc(rd_ctx *c, int nbs, int count, int *size_annot) {
     *size_annot = 0;
     if (!count) return NULL;
     uint16_t next = rd_u16(c);
     int32_t sa = rd_i32(c);
     if (c->err || sa < 0 || sa > (1 << 20) || next == 0xffff) { c->err = 1; return NULL; }
-    size_t n = (size_t)count * (nbs + sa) + (size_t)next * 3;
-    uint8_t *buf = xmalloc(n);
-    rd(c, buf, n);
-    if (next) c->err = 1; /* extended annotations are never produced by the writers in this repository */
-    *size_annot = sa;
+    size_t n = (size_t)count * (nbs + sa);
+    uint8_t *raw = xmalloc(n + 1);
+    rd(c, raw, n);
+    if (!next) { *size_annot = sa; return raw; }
+    uint8_t *buf = xcalloc((size_t)count, (size_t)(nbs + sa + 1));
+    for (int q = 0; q < count; q++) memcpy(buf + (size_t)q * (nbs + sa + 1), raw + (size_t)q * (nbs + sa), (size_t)(nbs + sa));
+    int pos = 0;
+    for (int e = 0; e < next && !c->err; e++) {
+        uint8_t t3[3];
+        rd(c, t3, 3);
+        pos += (t3[0] << 8) | t3[1];
+        if (pos >= count) { c->err = 1; break; }
+        buf[(size_t)pos * (nbs + sa + 1) + nbs + sa] = t3[2];
+    }
+    free(raw);
+    *size_annot = sa + 1;
     return buf;
 }
 
@@ -1514,15 +1671,26 @@ orc_bft *orc_load_bft(const char *path) {
     rd_ctx c = {fopen(path, "rb"), 0, 0};
     if (!c.f) return NULL;
     int lcs = rd_i32(&c);
-    if (lcs != 0) { fclose(c.f); return NULL; } /* mode-3 annotations need Judy-built comp_set_colors: not supported */
+    if (lcs < 0 || lcs > (1 << 24)) { fclose(c.f); return NULL; }
+    comp_elem *celems = xcalloc((size_t)lcs + 1, sizeof(comp_elem));
+    for (int e = 0; e < lcs && !c.err; e++) { /* src/write_to_disk.c:283-310 */
+        rd(&c, &celems[e].last_index, 8);
+        celems[e].size_annot = rd_i32(&c);
+        int64_t cnt = e ? celems[e].last_index - celems[e - 1].last_index : celems[e].last_index + 1;
+        if (c.err || cnt < 0 || celems[e].size_annot < 0 || cnt * celems[e].size_annot > (1LL << 32)) { c.err = 1; break; }
+        celems[e].bytes = xmalloc((size_t)(cnt * celems[e].size_annot) + 1);
+        rd(&c, celems[e].bytes, (size_t)(cnt * celems[e].size_annot));
+    }
+    g_comp = celems;
+    g_ncomp = lcs;
     int r1 = rd_i32(&c), r2 = rd_i32(&c);
     (void)rd_i32(&c);
     int nbg = rd_i32(&c), k = rd_i32(&c);
     uint8_t comp = 0;
     rd(&c, &comp, 1);
-    if (c.err || comp != 0 || nbg < 0) { fclose(c.f); return NULL; }
+    if (c.err || comp != 0 || nbg < 0) { fclose(c.f); g_comp = NULL; g_ncomp = 0; return NULL; }
     orc_bft *t = orc_create(k, r1, r2);
-    if (!t) { fclose(c.f); return NULL; }
+    if (!t) { fclose(c.f); g_comp = NULL; g_ncomp = 0; return NULL; }
     for (int g = 0; g < nbg && !c.err; g++) {
         uint16_t len = rd_u16(&c);
         char buf[70000];
@@ -1532,6 +1700,10 @@ orc_bft *orc_load_bft(const char *path) {
         for (int q = 0; q < 7; q++) (void)rd_i32(&c);
     if (!c.err) load_node(&c, t, &t->root, k, NULL);
     fclose(c.f);
+    for (int e = 0; e < lcs; e++) free(celems[e].bytes);
+    free(celems);
+    g_comp = NULL;
+    g_ncomp = 0;
     if (c.err) { orc_free(t); return NULL; }
     t->nkmers = count_kmers(&t->root, k);
     t->dirty = 1;
@@ -1615,7 +1787,9 @@ int orc_query_sequence(orc_bft *t, const char *sequence, double threshold, int c
         if (!orc_parse_kmer(kmer, k, packed)) continue; /* IUPAC / invalid k-mers are skipped (:1298) */
         is_kmer_present(t, packed, &res);
         if (!res.found) continue;
-        int n = orc_annot_decode(res.annot, res.size_annot, tmp, 4096);
+        g_comp = t->celems;
+        g_ncomp = t->ncelems;
+        int n = decode_any(res.annot, res.size_annot, tmp, 4096);
         for (int a = 0; a < n && a < 4096; a++)
             if (tmp[a] < nb_genomes) count[tmp[a]]++;
     }

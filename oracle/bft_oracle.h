@@ -136,6 +136,11 @@ int orc_query_sequence(orc_bft *t, const char *sequence, double threshold, int c
  * SURVEY.md A.6 (compressed == 0, no comp_set_colors, no extended annotations).  genome names are
  * "genome_<id>".  orc_load_bft returns NULL on a malformed file. */
 int orc_write_bft(orc_bft *t, const char *path, int nb_genomes);
+/* Test modes of the writer, to produce the shapes reference-built files have: comp_on = annotations stored as mode-3
+ * indices into comp_set_colors (what compress_annotations_disk leaves, src/file_io.c:3-76; entries delta-coded by
+ * comp_annotation, src/annotation.c:1777-1838); ext_on = the widest rows of each UC keep their last annotation byte
+ * in the extended-annotation table (src/UC.c:321-521).  Call after the insertions, before orc_write_bft. */
+void orc_set_annotation_modes(orc_bft *t, int comp_on, int ext_on);
 orc_bft *orc_load_bft(const char *path);
 int orc_nb_genomes_loaded(const orc_bft *t);
 

@@ -62,6 +62,7 @@ def _load(count=False):
     lib.orc_query_branching.restype = C.c_long
     lib.orc_query_branching.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     lib.orc_query_sequence.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+    lib.orc_set_annotation_modes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.orc_write_bft.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.orc_load_bft.restype = C.c_void_p
     lib.orc_load_bft.argtypes = [C.c_char_p]
@@ -145,6 +146,10 @@ class OracleBFT:
         """write_BFT_Root (src/write_to_disk.c:21-258)."""
         if self.lib.orc_write_bft(self.h, path.encode(), nb_genomes) != 0:
             raise IOError(path)
+
+    def set_annotation_modes(self, comp=False, ext=False):
+        """Writer test modes: mode-3 indices into comp_set_colors and/or extended-annotation bytes."""
+        self.lib.orc_set_annotation_modes(self.h, int(comp), int(ext))
 
     def nb_genomes_loaded(self):
         return self.lib.orc_nb_genomes_loaded(self.h)

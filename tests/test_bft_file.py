@@ -112,3 +112,35 @@ def test_reader_rejects_garbage(hostlib, tmp_path):
     open(p, "wb").write(b"\x00" * 10)
     k, g, n = C.c_int(), C.c_int(), C.c_uint64()
     assert not hostlib.bft_hosttest_read_bft(p.encode(), C.byref(k), C.byref(g), C.byref(n))
+
+
+@pytest.mark.parametrize("comp,ext", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("k,levels,ngen", [(27, 1, 9), (36, 3, 70), (18, 1, 200)])
+def test_reference_shaped_annotations(oracle_mod, hostlib, tmp_path, k, levels, ngen, comp, ext):
+    """Files as the reference's CLI leaves them: mode-3 annotations indexing comp_set_colors (>= 7 genomes,
+    src/file_io.c:192-193) and extended-annotation bytes (src/UC.c:321-521).  Read back by the oracle's reader and by
+    the product's reader."""
+    base = S.low_entropy_kmers(20000, k, 16, seed=k + levels, levels=levels)
+    rng = np.random.default_rng(ngen)
+    gk = [base[rng.random(len(base)) < rng.uniform(0.05, 0.9)] for _ in range(ngen)]
+    a = oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        a.insert_kmers(np.ascontiguousarray(km), g)
+    q = np.concatenate([base, S.snp_mutants(base[::3], k, 1)])
+    exp = a.query_colors(q)
+    a.set_annotation_modes(comp=comp, ext=ext)
+    got = a.query_colors(q)  # the oracle itself now decodes through comp_set_colors
+    assert all((x == y).all() for x, y in zip(got, exp))
+    p = str(tmp_path / "r.bft")
+    a.write_bft(p, ngen)
+    plain = str(tmp_path / "plain.bft")
+    a.set_annotation_modes(False, False)
+    a.write_bft(plain, ngen)
+    if comp:
+        assert os.path.getsize(p) != os.path.getsize(plain)
+    b = oracle_mod.OracleBFT.load_bft(p)
+    assert all((x == y).all() for x, y in zip(b.query_colors(q), exp))
+    kk, n, per = _product_read(hostlib, p)
+    assert kk == k and n == len(S.distinct(np.concatenate(gk)))
+    for g in range(ngen):
+        assert sorted(S.row_keys(per[g]).tolist()) == sorted(S.row_keys(gk[g]).tolist())

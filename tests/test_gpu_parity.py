@@ -257,3 +257,22 @@ def test_query_sequences(oracle_mod, k, canonical):
         got = t.query_sequences(reads, thr, canonical)
         for r, gl in zip(reads, got):
             assert gl == o.query_sequence(r, thr, canonical, ngen), (r, thr)
+
+
+def test_load_reference_shaped_file(oracle_mod, tmp_path):
+    """load_BFT of a file with mode-3 annotations (comp_set_colors) and extended-annotation bytes."""
+    from bloomfiltertrie_amd import BFT
+    k, ngen = 27, 40
+    base = S.low_entropy_kmers(50000, k, 24, seed=5, levels=2)
+    rng = np.random.default_rng(7)
+    o = oracle_mod.OracleBFT(k)
+    for g in range(ngen):
+        o.insert_kmers(np.ascontiguousarray(base[rng.random(len(base)) < rng.uniform(0.05, 0.9)]), g)
+    q = _queries(base, k, seed=6)
+    exp = o.query_colors(q)
+    o.set_annotation_modes(comp=True, ext=True)
+    p = str(tmp_path / "ref_shaped.bft")
+    o.write_bft(p, ngen)
+    t = BFT.load_bft(p)
+    assert all((a == b).all() for a, b in zip(t.query_colors(q), exp))
+    assert t.info()["genomes"] == ngen
