@@ -69,16 +69,16 @@ __global__ void k_sizes(const uint32_t* lo, const uint32_t* hi, uint32_t* sz, ui
 
 // head[j] = row j starts a new prefix of its node; khead[j] = ... a new Bloom key
 template <int W>
-__global__ void k_prefix_flags(const uint64_t* __restrict__ tk, int L, int d, const uint32_t* __restrict__ nd_lo,
+__global__ void k_prefix_flags(const uint64_t* __restrict__ tk, int k, int d, const uint32_t* __restrict__ nd_lo,
                                const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, uint32_t* __restrict__ head,
                                uint32_t* __restrict__ khead) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < A; j += gridDim.x * blockDim.x) {
         const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
         const uint32_t row = nd_lo[m] + (j - node_off[m]);
-        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, L, d);
+        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, k, d);
         uint32_t h = 1, kh = 1;
         if (row != nd_lo[m]) {
-            const uint32_t rp = bft_digit<W>(tk + (size_t)(row - 1) * W, L, d);
+            const uint32_t rp = bft_digit<W>(tk + (size_t)(row - 1) * W, k, d);
             h = r != rp;
             kh = (r >> 4) != (rp >> 4);
         }
@@ -88,7 +88,7 @@ __global__ void k_prefix_flags(const uint64_t* __restrict__ tk, int L, int d, co
 }
 
 template <int W>
-__global__ void k_prefix_scatter(const uint64_t* __restrict__ tk, int L, int d, const uint32_t* __restrict__ nd_lo,
+__global__ void k_prefix_scatter(const uint64_t* __restrict__ tk, int k, int d, const uint32_t* __restrict__ nd_lo,
                                  const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, const uint32_t* __restrict__ head,
                                  const uint32_t* __restrict__ khead, const uint32_t* __restrict__ ppos, const uint32_t* __restrict__ kpos,
                                  uint32_t* __restrict__ pref_r, uint32_t* __restrict__ pref_row, uint32_t* __restrict__ pref_node,
@@ -98,7 +98,7 @@ __global__ void k_prefix_scatter(const uint64_t* __restrict__ tk, int L, int d, 
         if (!head[j]) continue;
         const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
         const uint32_t row = nd_lo[m] + (j - node_off[m]);
-        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, L, d);
+        const uint32_t r = bft_digit<W>(tk + (size_t)row * W, k, d);
         const uint32_t p = ppos[j];
         const uint32_t kk = kpos[j] + khead[j] - 1;
         pref_r[p] = r;
@@ -294,7 +294,7 @@ __global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __r
                           const uint32_t* __restrict__ node_ccb, const uint32_t* __restrict__ cc_qb, const uint32_t* __restrict__ cc_s,
                           const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ chead, const uint32_t* __restrict__ cidx,
                           const uint32_t* __restrict__ clus_q, const uint32_t* __restrict__ clus_len, const uint32_t* __restrict__ cpos,
-                          const uint32_t* __restrict__ pend, const uint32_t* __restrict__ nrank, int last_level, uint32_t next_node_base,
+                          const uint32_t* __restrict__ pend, const uint32_t* __restrict__ nrank, int last_level, int rb, uint32_t next_node_base,
                           uint64_t* __restrict__ f2w, uint64_t* __restrict__ clus, uint64_t* __restrict__ child, uint32_t* __restrict__ next_lo,
                           uint32_t* __restrict__ next_hi) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
@@ -305,7 +305,8 @@ __global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __r
         const uint32_t p = sp[q], r = pref_r[p], cnt = pref_cnt[p], row = pref_row[p];
         const uint32_t pu = r >> s, pv = r & ((1u << s) - 1u);
         uint64_t ent = (uint64_t)pv << BFT_CHILD_PV_SHIFT;
-        if (last_level) ent |= (1ull << BFT_CHILD_CNT_SHIFT) | row;
+        if (last_level && rb == 0) ent |= (1ull << BFT_CHILD_CNT_SHIFT) | row;
+        else if (last_level) ent = BFT_REM_ENTRY(pv, cnt, row);
         else if (!pend[q]) ent |= ((uint64_t)cnt << BFT_CHILD_CNT_SHIFT) | row;
         else {
             const uint32_t nn = nrank[q];
@@ -407,7 +408,7 @@ struct Seg {  // per-depth output segments, concatenated at the end
 
 template <int W>
 int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out) {
-    const int L = k / 9;
+    const int L = k / 9, rb = 2 * (k - 9 * L);
     Scan scan(s);
     std::vector<Seg> segs;
     DevBuf nd_lo, nd_hi;
@@ -443,7 +444,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(kpos.alloc(A * 4));
         uint64_t P = 0, K = 0;
         if (A) {
-            hipLaunchKernelGGL(k_prefix_flags<W>, G(A), tk, L, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
+            hipLaunchKernelGGL(k_prefix_flags<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
                                head.as<uint32_t>(), khead.as<uint32_t>());
             CK(scan.run(head.as<uint32_t>(), ppos.as<uint32_t>(), A, &P));
             CK(scan.run(khead.as<uint32_t>(), kpos.as<uint32_t>(), A, &K));
@@ -466,7 +467,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             HIPCK(hipMemcpyAsync(node_kb.as<uint32_t>() + M, &k32, 4, hipMemcpyHostToDevice, s));
         }
         if (A) {
-            hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, L, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
+            hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
                                head.as<uint32_t>(), khead.as<uint32_t>(), ppos.as<uint32_t>(), kpos.as<uint32_t>(), pref_r.as<uint32_t>(),
                                pref_row.as<uint32_t>(), pref_node.as<uint32_t>(), pref_key.as<uint32_t>(), key_val.as<uint32_t>(),
                                key_row.as<uint32_t>(), key_node.as<uint32_t>(), node_kb.as<uint32_t>());
@@ -601,7 +602,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             hipLaunchKernelGGL(k_entries, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_r.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
                                (uint32_t)P, node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_s.as<uint32_t>(), cc_f2.as<uint32_t>(), chead.as<uint32_t>(),
                                cidx.as<uint32_t>(), clus_q.as<uint32_t>(), clus_len.as<uint32_t>(), cpos.as<uint32_t>(), pend.as<uint32_t>(),
-                               nrank.as<uint32_t>(), last_level, (uint32_t)(T_nodes + M), sg.f2w.as<uint64_t>(), sg.clus.as<uint64_t>(),
+                               nrank.as<uint32_t>(), last_level, rb, (uint32_t)(T_nodes + M), sg.f2w.as<uint64_t>(), sg.clus.as<uint64_t>(),
                                sg.child.as<uint64_t>(), next_lo.as<uint32_t>(), next_hi.as<uint32_t>());
             hipLaunchKernelGGL(k_ranks, G(C), cc_f2.as<uint32_t>(), cc_nwords.as<uint32_t>(), (uint32_t)C, sg.f2w.as<uint64_t>());
         }
@@ -736,7 +737,7 @@ __global__ void k_cs_verify(const uint32_t* __restrict__ tcol, const uint32_t* _
 }  // namespace
 
 int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
-    if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be a multiple of 9 in [9, 126]");
+    if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be in [9, 126]");
     if (n >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 k-mers");
     switch (bft_words_for_k(k)) {
     case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out);

@@ -381,7 +381,7 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
     out.k = R.i32();
     uint8_t comp = 0;
     R.rd(&comp, 1);
-    if (R.err || comp != 0 || nbg < 0 || nbg > 100000000 || !bft_valid_k(out.k)) { fclose(R.f); err = "bad .bft header"; return false; }
+    if (R.err || comp != 0 || nbg < 0 || nbg > 100000000 || !bft_reference_k(out.k)) { fclose(R.f); err = "bad .bft header"; return false; }
     for (int g = 0; g < nbg && !R.err; g++) {
         const uint16_t len = R.u16();
         std::string name(len, '\0');
@@ -424,7 +424,7 @@ struct Writer {
     template <int WW>
     void suffix_bytes_w(const uint64_t* t, int from, uint8_t* out, int nbytes) const {
         uint64_t x[WW];
-        bft_x_from_tform<WW>(t, L, x);
+        bft_x_from_tform<WW>(t, k, x);
         memset(out, 0, (size_t)nbytes);
         for (int j = from; j < k; j++) {
             const uint32_t code = (uint32_t)(x[(2 * j) >> 6] >> ((2 * j) & 63)) & 3u;

@@ -85,14 +85,14 @@ __device__ __forceinline__ void load_x(const uint8_t* __restrict__ packed, uint6
 }
 
 template <int W>
-__global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int L,
+__global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
                                                              uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
                                                              uint32_t* __restrict__ gout, uint32_t gid) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     for (uint64_t i = blockIdx.x * (uint64_t)BFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BFT_BLOCK) {
         uint64_t x[W], t[W];
         load_x<W>(packed, i, B, end_aligned, x);
-        bft_tform_from_x<W>(x, L, t);
+        bft_tform_from_x<W>(x, k, t);
 #pragma unroll
         for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + i] = t[w];
         gout[off + i] = gid;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __r
         if (i < n) {
             uint64_t x[W], t[W];
             load_x<W>(packed, i, B, end_aligned, x);
-            bft_tform_from_x<W>(x, im.L, t);
+            bft_tform_from_x<W>(x, im.k, t);
             const BftHit h = bft_walk<W>(im, acc, root, t);
             present = h.present;
             if (present) row = (uint32_t)h.row;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
     const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
-    const int k = im.k, L = im.L;
+    const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const uint64_t i = blk * BLOCK + threadIdx.x;
         int branching = 0;
@@ -208,13 +208,13 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
             // successors: drop the first nucleotide, the last one is the wildcard
 #pragma unroll
             for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
-            bft_tform_from_x<W>(y, L, t);
+            bft_tform_from_x<W>(y, k, t);
             int cr = 0, cl = 0;
             for (uint64_t nt = 0; nt < 4 && (counts || cr < 2); nt++) {
                 uint64_t tt[W];
 #pragma unroll
                 for (int w = 0; w < W; w++) tt[w] = t[w];
-                tt[W - 1] |= nt << 2;
+                tt[W - 1] |= nt << (rb ? 0 : 2);  // last nucleotide: n9 of the last prefix, or the end of the k % 9 remainder
                 cr += bft_walk<W>(im, acc, root, tt).present;
             }
             if (counts || cr < 2) {
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
                 for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
                 const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
                 if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
-                bft_tform_from_x<W>(y, L, t);
-                const int o = 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
+                bft_tform_from_x<W>(y, k, t);
+                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
                 for (uint64_t nt = 0; nt < 4 && (counts || cl < 2); nt++) {
                     uint64_t tt[W];
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ void k_seq_rows(BftImage im, const char* __restrict__ seqs, const uin
         if (valid) {
             uint64_t t[W];
             // strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296)
-            bft_tform_from_x<W>((canonical && cmp >= 0) ? xr : xf, im.L, t);
+            bft_tform_from_x<W>((canonical && cmp >= 0) ? xr : xf, im.k, t);
             const BftHit hit = bft_walk<W>(im, acc, root, t);
             if (hit.present) row = (uint32_t)hit.row;
         }
@@ -461,7 +461,7 @@ extern "C" int bft_gpu_device_count(void) {
 extern "C" int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out) {
     if (!out) return fail(BFT_GPU_E_ARG, "out is NULL");
     *out = nullptr;
-    if (!bft_valid_k(k)) return fail(BFT_GPU_E_ARG, "Length k (for k-mers) must be a multiple of 9 in [9,126] (reference src/main.c:61-63)");
+    if (!bft_valid_k(k)) return fail(BFT_GPU_E_ARG, "Length k (for k-mers) must be in [9,126] (a multiple of 9 for reference-compatible indexes, src/main.c:61-63)");
     int ndev = 0;
     HIPCK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(BFT_GPU_E_HIP, "no HIP device: this library has no CPU fallback");
@@ -555,7 +555,7 @@ template <int W>
 static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid) {
     const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
     hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), 0, h->stream, d_packed, n, h->B,
-                       h->L, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
+                       h->k, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1151,6 +1151,7 @@ static int download(const DevBuf& d, uint64_t bytes, std::vector<T>& v) {
 
 extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     if (!h || !path) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (!bft_reference_k(h->k)) return fail(BFT_GPU_E_ARG, "the .bft format requires k % 9 == 0 (reference src/main.c:61-63)");
     CK(set_device(h));
     CK(ensure_built(h));
     BftHostImage hi;
@@ -1238,10 +1239,10 @@ extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
 }
 
 template <int W>
-static void unpack_rows(const std::vector<uint64_t>& tk, uint64_t n, int L, int B, uint8_t* out) {
+static void unpack_rows(const std::vector<uint64_t>& tk, uint64_t n, int k, int B, uint8_t* out) {
     for (uint64_t i = 0; i < n; i++) {
         uint64_t x[W];
-        bft_x_from_tform<W>(&tk[i * W], L, x);
+        bft_x_from_tform<W>(&tk[i * W], k, x);
         for (int b = 0; b < B; b++) out[i * B + b] = (uint8_t)(x[b >> 3] >> (8 * (b & 7)));
     }
 }
@@ -1258,10 +1259,10 @@ extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorse
         std::vector<uint64_t> tk(n * h->W);
         HIPCK(hipMemcpy(tk.data(), h->d_tk.p, n * h->W * 8, hipMemcpyDeviceToHost));
         switch (h->W) {
-        case 1: unpack_rows<1>(tk, n, h->L, h->B, kmers_out); break;
-        case 2: unpack_rows<2>(tk, n, h->L, h->B, kmers_out); break;
-        case 3: unpack_rows<3>(tk, n, h->L, h->B, kmers_out); break;
-        default: unpack_rows<4>(tk, n, h->L, h->B, kmers_out); break;
+        case 1: unpack_rows<1>(tk, n, h->k, h->B, kmers_out); break;
+        case 2: unpack_rows<2>(tk, n, h->k, h->B, kmers_out); break;
+        case 3: unpack_rows<3>(tk, n, h->k, h->B, kmers_out); break;
+        default: unpack_rows<4>(tk, n, h->k, h->B, kmers_out); break;
         }
     }
     if (colorset_out && n) HIPCK(hipMemcpy(colorset_out, h->d_tcol.p, n * 4, hipMemcpyDeviceToHost));

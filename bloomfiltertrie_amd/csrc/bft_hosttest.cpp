@@ -28,18 +28,18 @@ static void to_tform(const uint8_t* packed, uint64_t n, int B, int L, std::vecto
     for (uint64_t i = 0; i < n; i++) {
         uint64_t x[W] = {0}, t[W];
         for (int b = 0; b < B; b++) x[b >> 3] |= (uint64_t)packed[i * B + b] << (8 * (b & 7));
-        bft_tform_from_x<W>(x, L, t);
+        bft_tform_from_x<W>(x, L, t);  // L holds k here
         for (int w = 0; w < W; w++) out[i * W + w] = t[w];
     }
 }
 
 static void tform_any(const uint8_t* packed, uint64_t n, int k, std::vector<uint64_t>& out) {
-    int W = bft_words_for_k(k), B = bft_bytes_for_k(k), L = k / 9;
+    int W = bft_words_for_k(k), B = bft_bytes_for_k(k);
     switch (W) {
-    case 1: to_tform<1>(packed, n, B, L, out); break;
-    case 2: to_tform<2>(packed, n, B, L, out); break;
-    case 3: to_tform<3>(packed, n, B, L, out); break;
-    default: to_tform<4>(packed, n, B, L, out); break;
+    case 1: to_tform<1>(packed, n, B, k, out); break;
+    case 2: to_tform<2>(packed, n, B, k, out); break;
+    case 3: to_tform<3>(packed, n, B, k, out); break;
+    default: to_tform<4>(packed, n, B, k, out); break;
     }
 }
 
@@ -82,7 +82,7 @@ extern "C" void* bft_hosttest_build(const uint8_t* kmers, uint64_t n, int k, int
 template <int W>
 static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
     std::vector<uint64_t> tq;
-    to_tform<W>(q, nq, t->B, t->L, tq);
+    to_tform<W>(q, nq, t->B, t->k, tq);
     uint64_t cnt = 0;
     memset(bits, 0, (nq + 7) / 8);
     for (uint64_t i = 0; i < nq; i++) {
@@ -115,7 +115,7 @@ extern "C" void bft_hosttest_stats(void* hv, uint64_t* out) {
 extern "C" void bft_hosttest_roundtrip(const uint8_t* kmers, uint64_t n, int k, uint8_t* out, uint64_t* tform_out) {
     std::vector<uint64_t> all;
     tform_any(kmers, n, k, all);
-    int W = bft_words_for_k(k), B = bft_bytes_for_k(k), L = k / 9;
+    int W = bft_words_for_k(k), B = bft_bytes_for_k(k), L = k;  // the helpers take k
     for (uint64_t i = 0; i < n; i++) {
         uint64_t x[BFT_MAX_W] = {0};
         switch (W) {
@@ -159,6 +159,7 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
 // product writer fed by the host-built index (single genome "genome_0")
 extern "C" int bft_hosttest_write_bft(void* hv, const char* path) {
     HostTrie* t = (HostTrie*)hv;
+    if (!bft_reference_k(t->k)) return -1;
     BftHostImage hi;
     hi.k = t->k; hi.r1 = BFT_DEFAULT_R1; hi.r2 = BFT_DEFAULT_R2;
     hi.genomes = {"genome_0"};

@@ -53,6 +53,14 @@ struct BftCC {            // 16 B: one dwordx4 load
 #define BFT_CHILD_IDX_MASK 0xFFFFFFFFFFULL
 #define BFT_CHILD_CNT_SHIFT 40
 #define BFT_CHILD_PV_SHIFT 48
+// Last level of a k % 9 != 0 index only ("remainder groups", up to 4^8 rows): count-1 on 16 bits = bits 40..47 (low 8),
+// bits 56..62 (next 7; bit 63 stays free for BFT_CLUS_MULTI) and bit 39 (the top one; rows are < 2^31, so bit 39 of
+// the row field is otherwise always 0).
+#define BFT_REM_ENTRY(pv, cnt, row)                                                                                                  \
+    (((uint64_t)(pv) << BFT_CHILD_PV_SHIFT) | ((((uint64_t)(cnt)-1) & 0xFFull) << BFT_CHILD_CNT_SHIFT) |                           \
+     (((((uint64_t)(cnt)-1) >> 8) & 0x7Full) << 56) | (((((uint64_t)(cnt)-1) >> 15) & 1ull) << 39) | (uint64_t)(row))
+#define BFT_REM_COUNT(e) ((uint32_t)((((e) >> BFT_CHILD_CNT_SHIFT) & 0xFFull) | ((((e) >> 56) & 0x7Full) << 8) | ((((e) >> 39) & 1ull) << 15)) + 1u)
+#define BFT_REM_ROW(e) ((e) & 0x7FFFFFFFFFull)
 #define BFT_CLUS_MULTI (1ull << 63)
 #define BFT_CLUS_LEN_SHIFT 32
 

@@ -28,7 +28,7 @@ struct BloomBits {
 
 template <int W>
 bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex& o) {
-    const int L = k / 9;
+    const int L = k / 9, rb = 2 * (k - 9 * L);
     std::vector<NodeRange> cur{{0, n}};
     uint32_t node_base = 0;  // global id of cur[0]
     for (int d = 0; d < L && !cur.empty(); d++) {
@@ -45,7 +45,7 @@ bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex
             node_pb[m] = (uint32_t)pref_r.size();
             uint32_t cur_r = 0xFFFFFFFFu;
             for (uint64_t row = cur[m].lo; row < cur[m].hi; row++) {
-                const uint32_t r = bft_digit<W>(tk + row * W, L, d);
+                const uint32_t r = bft_digit<W>(tk + row * W, k, d);
                 if (row == cur[m].lo || r != cur_r) {
                     if (row == cur[m].lo || (r >> 4) != (cur_r >> 4)) {
                         key_val.push_back(r >> 4);
@@ -186,7 +186,9 @@ bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex
                         const uint32_t pv = pref_r[p] & ((1u << cc.s) - 1u);
                         const uint64_t cnt = pref_cnt[p];
                         uint64_t ent = (uint64_t)pv << BFT_CHILD_PV_SHIFT;
-                        if (d == L - 1) ent |= (1ull << BFT_CHILD_CNT_SHIFT) | pref_row[p];  // leaf: one annotation per prefix
+                        if (d == L - 1 && rb == 0) ent |= (1ull << BFT_CHILD_CNT_SHIFT) | pref_row[p];  // leaf: one annotation per prefix
+                        else if (d == L - 1)  // k % 9 != 0: the rows of the prefix differ in the remaining nucleotides; count-1 on 16 bits
+                            ent = BFT_REM_ENTRY(pv, cnt, pref_row[p]);
                         else if (cnt <= BFT_NB_KMERS_PER_UC) ent |= (cnt << BFT_CHILD_CNT_SHIFT) | pref_row[p];
                         else {  // > 255 suffixes: child Node (count field 0), ids in breadth-first order
                             ent |= (uint64_t)(node_base + M + next.size());
@@ -218,7 +220,7 @@ bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex
 
 bool bft_build_index(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, BftHostIndex& out) {
     out = BftHostIndex();
-    if (!bft_valid_k(k)) { out.error = "k must be a multiple of 9 in [9, 126]"; return false; }
+    if (!bft_valid_k(k)) { out.error = "k must be in [9, 126]"; return false; }
     if (n >= 0xFFFFFFFFull) { out.error = "more than 2^32-1 k-mers: row index overflow"; return false; }
     switch (bft_words_for_k(k)) {
     case 1: return run<1>(tk, n, k, hashmod, out);

@@ -35,4 +35,5 @@ bool bft_build_index(const uint64_t* tk, uint64_t n, int k, const uint32_t* hash
 
 static inline int bft_words_for_k(int k) { return (2 * k + 63) / 64; }
 static inline int bft_bytes_for_k(int k) { return (2 * k + 7) / 8; }
-static inline bool bft_valid_k(int k) { return k >= 9 && k <= 126 && k % 9 == 0; }  // src/main.c:61-63
+static inline bool bft_valid_k(int k) { return k >= 9 && k <= 126; }  // the reference additionally requires k % 9 == 0 (src/main.c:61-63)
+static inline bool bft_reference_k(int k) { return bft_valid_k(k) && k % 9 == 0; }

@@ -83,15 +83,25 @@ BFT_HD void bft_or18_le(uint64_t* le, int off, uint64_t r) {
     }
 }
 
-// X (W little-endian u64 words of the packed k-mer) -> T-form (W words, word 0 most significant).
+// T-form of a k-mer (any k >= 9): the L = k/9 rotated prefixes, most significant first, then -- when k is not a
+// multiple of 9, an extension the reference does not have (it requires k % 9 == 0, src/main.c:61-63) -- the R = k % 9
+// remaining nucleotides, first one most significant.  2k bits in W words, word 0 most significant.
+// X (W little-endian u64 words of the packed k-mer) -> T-form.
 template <int W>
-BFT_HD void bft_tform_from_x(const uint64_t* x, int L, uint64_t* t) {
+BFT_HD void bft_tform_from_x(const uint64_t* x, int k, uint64_t* t) {
+    const int L = k / 9, R = k - 9 * L, rb = 2 * R;
     uint64_t tl[W];
 #pragma unroll
     for (int w = 0; w < W; w++) tl[w] = 0;
     for (int d = 0; d < L; d++) {
         const uint64_t r = bft_rot_prefix(bft_get18_le<W>(x, 18 * d));
-        bft_or18_le<W>(tl, 18 * (L - 1 - d), r);
+        bft_or18_le<W>(tl, rb + 18 * (L - 1 - d), r);
+    }
+    if (R) {
+        const uint32_t raw = bft_get18_le<W>(x, 18 * L);  // the R remaining nucleotides, first one in the low bits
+        uint64_t rem = 0;
+        for (int j = 0; j < R; j++) rem |= (uint64_t)((raw >> (2 * j)) & 3u) << (2 * (R - 1 - j));
+        tl[0] |= rem;  // rb <= 16 bits at offset 0
     }
 #pragma unroll
     for (int w = 0; w < W; w++) t[w] = tl[W - 1 - w];
@@ -99,23 +109,48 @@ BFT_HD void bft_tform_from_x(const uint64_t* x, int L, uint64_t* t) {
 
 // T-form -> X (inverse), host side helpers only need it for extraction
 template <int W>
-BFT_HD void bft_x_from_tform(const uint64_t* t, int L, uint64_t* x) {
+BFT_HD void bft_x_from_tform(const uint64_t* t, int k, uint64_t* x) {
+    const int L = k / 9, R = k - 9 * L, rb = 2 * R;
     uint64_t tl[W];
 #pragma unroll
     for (int w = 0; w < W; w++) { tl[w] = t[W - 1 - w]; x[w] = 0; }
     for (int d = 0; d < L; d++) {
-        const uint64_t raw = bft_unrot_prefix(bft_get18_le<W>(tl, 18 * (L - 1 - d)));
+        const uint64_t raw = bft_unrot_prefix(bft_get18_le<W>(tl, rb + 18 * (L - 1 - d)));
         bft_or18_le<W>(x, 18 * d, raw);
+    }
+    if (R) {
+        const uint64_t rem = tl[0] & ((1ull << rb) - 1ull);
+        uint64_t raw = 0;
+        for (int j = 0; j < R; j++) raw |= ((rem >> (2 * (R - 1 - j))) & 3ull) << (2 * j);
+        bft_or18_le<W>(x, 18 * L, raw);
     }
 }
 
 // rotated prefix of level d (0 = root) out of a T-form k-mer
 template <int W>
-BFT_HD uint32_t bft_digit(const uint64_t* t, int L, int d) {
+BFT_HD uint32_t bft_digit(const uint64_t* t, int k, int d) {
+    const int L = k / 9, rb = 2 * (k - 9 * L);
     uint64_t tl[W];
 #pragma unroll
     for (int w = 0; w < W; w++) tl[w] = t[W - 1 - w];
-    return bft_get18_le<W>(tl, 18 * (L - 1 - d));
+    return bft_get18_le<W>(tl, rb + 18 * (L - 1 - d));
+}
+
+// the (up to) 36 bits that follow level d in a T-form k-mer, left-aligned in 36 bits: interpolation key of a suffix group
+template <int W>
+BFT_HD uint64_t bft_next36(const uint64_t* t, int k, int d) {
+    const int L = k / 9, rb = 2 * (k - 9 * L);
+    const int remaining = rb + 18 * (L - 1 - d);  // bits below level d
+    uint64_t tl[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) tl[w] = t[W - 1 - w];
+    if (remaining >= 36) return ((uint64_t)bft_get18_le<W>(tl, remaining - 18) << 18) | bft_get18_le<W>(tl, remaining - 36);
+    if (remaining > 18) {
+        const uint64_t hi = bft_get18_le<W>(tl, remaining - 18), lo = tl[0] & ((1ull << (remaining - 18)) - 1ull);
+        return (hi << 18) | (lo << (36 - remaining));
+    }
+    if (remaining > 0) return (tl[0] & ((1ull << remaining) - 1ull)) << (36 - remaining);
+    return 0;
 }
 
 template <int W>
@@ -242,12 +277,12 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
     hit.present = 0;
     hit.row = 0;
     uint32_t node = 0;
-    const int L = im.L;
+    const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
     for (int d = 0; d < L; d++) {
         BftNode nd;
         if (d == 0) nd = root_node;
         else nd = im.nodes[node];
-        const uint32_t r = bft_digit<W>(t, L, d);
+        const uint32_t r = bft_digit<W>(t, im.k, d);
         int c = -1;
         if (nd.ncc) {
             const uint32_t hm = root.hashmod(r >> 4);  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
@@ -295,13 +330,16 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
             if (lo >= end) return hit;
         }
         if (((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return hit;
-        const uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
-        const uint64_t idx = e & BFT_CHILD_IDX_MASK;
+        uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
+        uint64_t idx = e & BFT_CHILD_IDX_MASK;
         if (im.debug_stop == 4) { hit.present = (int)(cnt & 1); return hit; }
-        if (d == L - 1) { hit.present = 1; hit.row = idx; return hit; }  // leaf: annotation row
-        if (cnt == 0) { node = (uint32_t)idx; continue; }                 // child Node (src/presenceNode.c:1867)
+        if (d == L - 1) {
+            if (rb == 0) { hit.present = 1; hit.row = idx; return hit; }  // leaf: annotation row
+            cnt = BFT_REM_COUNT(e);  // remainder group: count-1 on 16 bits
+            idx = BFT_REM_ROW(e);
+        } else if (cnt == 0) { node = (uint32_t)idx; continue; }          // child Node (src/presenceNode.c:1867)
         // suffix group of cnt rows (src/presenceNode.c:1874-1915): interpolate on the next two prefixes
-        const uint64_t next36 = ((uint64_t)bft_digit<W>(t, L, d + 1) << 18) | (d + 2 < L ? bft_digit<W>(t, L, d + 2) : 0u);
+        const uint64_t next36 = bft_next36<W>(t, im.k, d);
         const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
         if (W == 1 && cnt >= BFT_WINDOW_PROBE) {

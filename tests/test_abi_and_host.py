@@ -43,12 +43,12 @@ def test_fails_loudly_without_a_device(built):
         BFT(27)
 
 
-def test_rejects_k_not_multiple_of_9(built):
+def test_rejects_k_out_of_range(built):
     lib = _lib.load()
     h = C.c_void_p()
-    for k in (31, 8, 135, 0):
+    for k in (8, 127, 135, 0, -9):
         assert lib.bft_gpu_create(k, 0, C.byref(h)) == -1  # BFT_GPU_E_ARG, before any device is touched
-        assert b"multiple of 9" in lib.bft_gpu_last_error()
+        assert b"[9,126]" in lib.bft_gpu_last_error()
 
 
 def test_product_does_not_reference_the_oracle():
@@ -167,3 +167,47 @@ def test_host_index_invariants_a7(hostlib, oracle_mod):
     st = _host_check(hostlib, oracle_mod, km, 27)
     assert st[6] > 0 and st[6] < st[2]
     assert st[9] < 255
+
+
+# ---- extension beyond the reference: k that is not a multiple of 9 (the reference rejects it, src/main.c:61-63) ----
+@pytest.mark.parametrize("k", [10, 13, 17, 22, 31, 35, 40, 64, 125])
+def test_host_index_any_k_ground_truth(hostlib, k):
+    km = np.ascontiguousarray(S.distinct(S.kmers_of(S.random_genome(60000, 7 + k), k)))
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    assert h
+    rng = np.random.default_rng(1)
+    q = np.concatenate([km, S.pack_codes(rng.integers(0, 4, (5000, k), dtype=np.uint8)), S.snp_mutants(km, k, 3)])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    bits = np.zeros((len(q) + 7) // 8, np.uint8)
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, None)
+    assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
+    hostlib.bft_hosttest_free(h)
+
+
+@pytest.mark.parametrize("k,levels", [(31, 1), (31, 3), (22, 2), (40, 3), (17, 1)])
+def test_host_index_any_k_deep(hostlib, k, levels):
+    km = np.ascontiguousarray(S.low_entropy_kmers(50000, k, 24, seed=k + levels, levels=levels))
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    q = np.ascontiguousarray(np.concatenate([km, S.snp_mutants(km, k, 3)]))
+    bits = np.zeros((len(q) + 7) // 8, np.uint8)
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, None)
+    assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
+    hostlib.bft_hosttest_free(h)
+
+
+def test_host_index_dense_remainder_groups(hostlib):
+    """all 4^4 remainders under a few 27-mers (k=31) and tens of thousands of 8-nt remainders under one 9-mer (k=17)."""
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 4, (20, 27), dtype=np.uint8)
+    rem = np.array([[(i >> 6) & 3, (i >> 4) & 3, (i >> 2) & 3, i & 3] for i in range(256)], dtype=np.uint8)
+    c31 = np.concatenate([np.concatenate([np.repeat(base[j:j + 1], 256, 0), rem], axis=1) for j in range(20)])
+    b9 = rng.integers(0, 4, (2, 9), dtype=np.uint8)
+    c17 = np.concatenate([np.concatenate([np.repeat(b9[j:j + 1], 60000, 0), rng.integers(0, 4, (60000, 8), dtype=np.uint8)], axis=1) for j in range(2)])
+    for k, codes in ((31, c31), (17, c17)):
+        km = np.ascontiguousarray(S.distinct(S.pack_codes(codes)))
+        h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+        q = np.ascontiguousarray(np.concatenate([km, S.snp_mutants(km, k, 3)]))
+        bits = np.zeros((len(q) + 7) // 8, np.uint8)
+        hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, None)
+        assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
+        hostlib.bft_hosttest_free(h)

@@ -54,13 +54,13 @@ def _compare(hostlib, km, k, pieces=1):
     return t.info()
 
 
-@pytest.mark.parametrize("k", [9, 18, 27, 36, 63, 126])
+@pytest.mark.parametrize("k", [9, 18, 27, 36, 63, 126, 31, 13, 40, 17, 100])
 def test_random_genome(hostlib, k):
     info = _compare(hostlib, S.distinct(S.kmers_of(S.random_genome(300000, 3 + k), k)), k, pieces=3)
     assert info["ccs"] > 1
 
 
-@pytest.mark.parametrize("k,levels", [(18, 1), (27, 1), (27, 2), (36, 3), (63, 3), (45, 4)])
+@pytest.mark.parametrize("k,levels", [(18, 1), (27, 1), (27, 2), (36, 3), (63, 3), (45, 4), (31, 2), (31, 3), (22, 1), (40, 4)])
 def test_deep(hostlib, k, levels):
     info = _compare(hostlib, S.low_entropy_kmers(200000, k, 24, seed=k + levels, levels=levels), k, pieces=2)
     assert info["child_nodes"] > 0

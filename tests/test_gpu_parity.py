@@ -152,7 +152,7 @@ def test_device_resident_api_matches_host_api(oracle_mod):
 def test_rejects_bad_k():
     from bloomfiltertrie_amd import BFT
     from bloomfiltertrie_amd._lib import BFTError
-    for k in (31, 8, 135):
+    for k in (8, 127, 135):
         with pytest.raises(BFTError):
             BFT(k)
 
@@ -276,3 +276,53 @@ def test_load_reference_shaped_file(oracle_mod, tmp_path):
     t = BFT.load_bft(p)
     assert all((a == b).all() for a, b in zip(t.query_colors(q), exp))
     assert t.info()["genomes"] == ngen
+
+
+# ---- extension beyond the reference: k % 9 != 0 (the headline metric names k = 31; the reference rejects it) ----
+@pytest.mark.parametrize("k,deep", [(31, 0), (31, 2), (13, 0), (22, 1), (40, 3), (17, 0), (64, 0), (100, 2)])
+def test_any_k_against_ground_truth(k, deep, tmp_path):
+    from bloomfiltertrie_amd._lib import BFTError
+    ngen = 4
+    if deep:
+        base = S.low_entropy_kmers(60000, k, 24, seed=k + deep, levels=deep)
+    else:
+        base = S.distinct(S.kmers_of(S.random_genome(80000, 3 + k), k))
+    rng = np.random.default_rng(k)
+    gk = [np.ascontiguousarray(base[rng.random(len(base)) < 0.6]) for _ in range(ngen)]
+    t = _bft(k)
+    truth = {}
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+        for key in map(bytes, km):
+            truth.setdefault(key, []).append(g)
+    q = _queries(base, k, seed=3)
+    bits, off, ids = t.query_colors(q)
+    pres = S.from_bits(bits, len(q))
+    for i, key in enumerate(map(bytes, q)):
+        exp = truth.get(key, [])
+        assert pres[i] == bool(exp) and ids[int(off[i]):int(off[i + 1])].tolist() == exp
+    assert (t.query_presence(q) == bits).all()
+    # branching counts on a sample
+    bb, bc = t.query_branching(q[:1500], with_counts=True)
+    codes = S.unpack_codes(q[:1500], k)
+    for i in range(0, 1500, 3):
+        c = codes[i]
+        succ = sum(bytes(S.pack_codes(np.concatenate([c[1:], [x]])[None, :])[0]) in truth for x in range(4))
+        pred = sum(bytes(S.pack_codes(np.concatenate([[x], c[:-1]])[None, :])[0]) in truth for x in range(4))
+        assert bc[i] == (succ << 4 | pred)
+    ek, _ = t.extract()
+    assert sorted(map(bytes, ek)) == sorted(truth)
+    with pytest.raises(BFTError):  # the .bft format cannot express k % 9 != 0
+        t.write_bft(str(tmp_path / "x.bft"))
+
+
+def test_k31_dense_remainder_groups():
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 4, (30, 27), dtype=np.uint8)
+    rem = np.array([[(i >> 6) & 3, (i >> 4) & 3, (i >> 2) & 3, i & 3] for i in range(256)], dtype=np.uint8)
+    codes = np.concatenate([np.concatenate([np.repeat(base[j:j + 1], 256, 0), rem], axis=1) for j in range(30)])
+    km = S.distinct(S.pack_codes(codes))
+    t = _bft(31)
+    t.insert_kmers(km, 0)
+    q = np.concatenate([km, S.snp_mutants(km, 31, 1)])
+    assert (S.from_bits(t.query_presence(q), len(q)) == S.member(q, km)).all()
