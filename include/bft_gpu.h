@@ -45,7 +45,8 @@ int bft_gpu_device_count(void);
 const char* bft_gpu_version(void);
 
 /* createBFT_Root(k, treshold_compression, compressed=0) (include/CC.h:214-258) / create_cdbg
- * (include/bft.h:62).  k must be a multiple of 9 in [9,126] (src/main.c:61-63).  The Bloom seeds are
+ * (include/bft.h:62).  k in [9,126]; the reference requires a multiple of 9 (src/main.c:61-63) and only such
+ * indexes can be written as .bft; other k (e.g. 31) are an extension verified against ground truth.  The Bloom seeds are
  * the reference's un-seeded rand() values (include/CC.h:246-248) unless r1/r2 > 0 are given. */
 int bft_gpu_create(int k, int device, bft_gpu** out);
 int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out);
