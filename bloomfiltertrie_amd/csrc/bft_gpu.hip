@@ -382,6 +382,45 @@ __global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* 
     }
 }
 
+// colour-set dictionary as bitmaps (one CEIL(G/8)-byte row per set), built once per image
+__global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t n_sets, uint32_t rowbytes,
+                             uint8_t* __restrict__ bm) {
+    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_sets; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t* o = bm + c * rowbytes;
+        for (uint32_t q = cs_off[c]; q < cs_off[c + 1]; q++) o[cs_ids[q] >> 3] |= (uint8_t)(1u << (cs_ids[q] & 7));
+    }
+}
+
+// one thread per aligned output dword (the rows of consecutive k-mers are contiguous, a dword may straddle two
+// rows): coalesced 4-byte stores, bytes gathered from the bitmap dictionary row of each present k-mer
+__global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm, uint64_t n,
+                                uint32_t rowbytes, uint8_t* __restrict__ out) {
+    const uint64_t total = n * rowbytes, ndw = (total + 3) / 4;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < ndw; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t byte = i * 4;
+        uint64_t q = byte / rowbytes;
+        uint32_t b = (uint32_t)(byte - q * rowbytes);
+        uint32_t r = rows[q];
+        const uint8_t* src = r == BFT_ABSENT_ROW ? nullptr : bm + (uint64_t)tcol[r] * rowbytes;
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (byte + j < total) {
+                if (src) v |= (uint32_t)src[b] << (8 * j);
+                if (++b == rowbytes && byte + j + 1 < total) {
+                    b = 0;
+                    q++;
+                    r = rows[q];
+                    src = r == BFT_ABSENT_ROW ? nullptr : bm + (uint64_t)tcol[r] * rowbytes;
+                }
+            }
+        }
+        if (byte + 4 <= total) *(uint32_t*)(out + byte) = v;
+        else
+            for (int j = 0; byte + j < total; j++) out[byte + j] = (uint8_t)(v >> (8 * j));
+    }
+}
+
 __global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
                              const uint32_t* __restrict__ cs_ids, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -421,7 +460,8 @@ struct bft_gpu {
     // image
     bool built = false;
     uint64_t n_kmers = 0;
-    DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids;
+    DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
+    bool has_cs_bm = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary
@@ -783,6 +823,19 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     im.ucrow = h->d_ucrow.as<uint32_t>();
     im.cs_off = h->d_cs_off.as<uint32_t>();
     im.cs_ids = h->d_cs_ids.as<uint32_t>();
+    {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
+        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->cs_off.size() - 1;
+        h->has_cs_bm = false;
+        h->d_cs_bm.release();
+        if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
+            CK(h->d_cs_bm.alloc_zero(nsets * rowbytes, h->stream));
+            hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, im.cs_off, im.cs_ids, nsets, (uint32_t)rowbytes,
+                               h->d_cs_bm.as<uint8_t>());
+            HIPCK(hipGetLastError());
+            HIPCK(hipStreamSynchronize(h->stream));
+            h->has_cs_bm = true;
+        }
+    }
 
     uint64_t* I = h->info;
     I[0] = h->k;
@@ -798,7 +851,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     I[10] = n_sets;
     I[11] = im.nb_genomes;
     I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes +
-            h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes;
+            h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes;
     I[13] = idx.root_ncc;
     I[14] = idx.root_uc;
     h->root_ncc = (uint32_t)idx.root_ncc;
@@ -1024,6 +1077,29 @@ extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n
     return BFT_GPU_OK;
 }
 
+static int launch_color_rows(bft_gpu* h, const uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s) {
+    if (h->has_cs_bm)
+        hipLaunchKernelGGL(k_color_rows_bm, dim3(grid_for((n * rowbytes / 4 + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, h->d_cs_bm.as<uint8_t>(), n, rowbytes, d_out);
+    else
+        hipLaunchKernelGGL(k_color_rows, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, h->im.cs_off, h->im.cs_ids, n, rowbytes, d_out);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// device-resident colour rows: presence bits + CEIL(nb_genomes/8)-byte bitmap row per k-mer, no synchronisation
+extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* d_rows, void* d_scratch_rows_u32,
+                                            void* hip_stream) {
+    if (!h || ((!d_kmers || !d_present_bits || !d_rows || !d_scratch_rows_u32) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
+    if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
+    CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s));
+    CK(launch_color_rows(h, (const uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s));
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint8_t* rows) {
     if (!h || !rows || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     CK(set_device(h));
@@ -1040,8 +1116,7 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
     for (uint64_t a = 0; a < n; a += chunk) {
         const uint64_t m = std::min(chunk, n - a);
         CK(query_rows(h, kmers + a * h->B, m, dk, db, dr, present_bits ? present_bits + a / 8 : nullptr));
-        const int grid = grid_for((m + 255) / 256);
-        hipLaunchKernelGGL(k_color_rows, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, m, rowbytes, dout.as<uint8_t>());
+        CK(launch_color_rows(h, dr.as<uint32_t>(), m, rowbytes, dout.as<uint8_t>(), h->stream));
         HIPCK(hipMemcpyAsync(rows + a * rowbytes, dout.p, m * rowbytes, hipMemcpyDeviceToHost, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
     }

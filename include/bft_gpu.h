@@ -116,6 +116,11 @@ int bft_gpu_load_bft(const char* path, int device, bft_gpu** out);
  * reference's container layout so that the reference's `bft load` reads it back (invariants of SURVEY.md A.7). */
 int bft_gpu_write_bft(bft_gpu* h, const char* path);
 
+/* Device-resident variant: d_rows = n * CEIL(nb_genomes/8) bytes, d_scratch_rows_u32 = n * 4 bytes of scratch (the row
+ * index of every k-mer), d_present_bits as in bft_gpu_query_presence_dev; runs on hip_stream, does not synchronise. */
+int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_present_bits, void* d_rows,
+                                 void* d_scratch_rows_u32, void* hip_stream);
+
 /* Shape / size counters (the walk of src/printMemory.c:255).  out[0]=k, [1]=distinct k-mers,
  * [2]=nodes, [3]=CCs, [4]=node-UC rows, [5]=child nodes, [6]=prefixes, [7]=CCs in s=4 mode,
  * [8]=max CCs per node, [9]=(k-mer,genome) pairs, [10]=distinct colour sets, [11]=genomes,

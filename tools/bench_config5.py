@@ -69,6 +69,20 @@ def main():
         t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
     torch.cuda.synchronize()
     ms_p, n_p = t.kernel_time(reset=True)
+    # colour rows, device resident: presence + ceil(G/8)-byte bitmap row per k-mer
+    rowbytes = (args.genomes + 7) // 8
+    nqc = min(nq, 4_000_000)
+    drows = torch.zeros((nqc, rowbytes), dtype=torch.uint8, device=dev)
+    dscr = torch.zeros(nqc, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        L.check(lib.bft_gpu_query_color_rows_dev(t._h, dq.data_ptr(), nqc, dbits.data_ptr(), drows.data_ptr(), dscr.data_ptr(), stream))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        L.check(lib.bft_gpu_query_color_rows_dev(t._h, dq.data_ptr(), nqc, dbits.data_ptr(), drows.data_ptr(), dscr.data_ptr(), stream))
+    torch.cuda.synchronize()
+    t_rows_dev = (time.perf_counter() - t0) / 5
+    t.kernel_time(reset=True)
     # colour sets through the host API on a slice (output-bound: ~1000 ids per present k-mer)
     ns = min(nq, 200_000)
     t0 = time.perf_counter()
@@ -105,6 +119,8 @@ def main():
         "branching_M_kmers_per_s": round(nq / (ms_b / n_b) / 1e3, 1), "branching_ms": round(ms_b / n_b, 3),
         "branching_fraction": round(float(np.unpackbits(dbits.cpu().numpy(), bitorder='little')[:nq].mean()), 4),
         "presence_M_kmers_per_s": round(nq / (ms_p / n_p) / 1e3, 1),
+        "color_rows_dev": {"queries": nqc, "row_bytes": rowbytes, "ms": round(t_rows_dev * 1e3, 3), "M_kmers_per_s": round(nqc / t_rows_dev / 1e6, 1),
+                           "GB_per_s_written": round(nqc * rowbytes / t_rows_dev / 1e9, 1)},
         "colors_host_api": {"queries": ns, "ids_returned": int(len(ids)), "s": round(t_col, 3), "M_kmers_per_s": round(ns / t_col / 1e6, 3),
                             "rows_s": round(t_rows, 3), "rows_M_kmers_per_s": round(ns / t_rows / 1e6, 3)},
         "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
