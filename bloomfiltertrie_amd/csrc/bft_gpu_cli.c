@@ -7,6 +7,7 @@
  *                         [-query_kmers {kmers|kmers_comp} list_kmer_files]
  *                         [-query_branching {kmers|kmers_comp} list_kmer_files]
  *                         [-query_sequences threshold {canonical|non_canonical} list_sequence_files]
+ *                         [-extract_kmers {kmers|kmers_comp} output_file]
  *
  * It is the per-k-mer loops of src/file_io.c:89-213 (build), :651-895 (presence CSV) and :897-1020 (branching)
  * rewired to one batched GPU call per file; file reading, ASCII parsing (parseKmerCount, src/fasta.c:3-53) and CSV
@@ -209,6 +210,32 @@ static void insert_genomes(bft_gpu* h, const char* list_path, int k, int binary)
     ck(bft_gpu_build(h));
 }
 
+/* extract_kmers_to_disk (src/bft.c:255-290): every stored k-mer, ASCII one per line or "k\ncount\n" + packed k-mers.
+ * The reference writes them in its trie iteration order; the set is the same, the order here is the image's. */
+static void extract_kmers(bft_gpu* h, const char* path, int k, int compressed) {
+    uint64_t n = 0;
+    ck(bft_gpu_extract(h, NULL, NULL, 0, &n));
+    const int nb = (2 * k + 7) / 8;
+    uint8_t* km = malloc(n ? n * nb : 1);
+    ck(bft_gpu_extract(h, km, NULL, n, &n));
+    FILE* f = fopen(path, "w");
+    if (!f) DIE("extract_kmers_to_disk(): failed to create/open output file.\n");
+    if (compressed) {
+        fprintf(f, "%d\n%llu\n", k, (unsigned long long)n);
+        fwrite(km, (size_t)nb, n, f);
+    } else {
+        char* line = malloc((size_t)k + 2);
+        for (uint64_t i = 0; i < n; i++) {
+            for (int j = 0; j < k; j++) line[j] = "ACGT"[(km[i * nb + j / 4] >> (2 * (j % 4))) & 3];
+            line[k] = '\n';
+            fwrite(line, 1, (size_t)k + 1, f);
+        }
+        free(line);
+    }
+    fclose(f);
+    free(km);
+}
+
 int main(int argc, char** argv) {
     if (argc < 3)
         DIE("\nUsage:\n"
@@ -216,7 +243,8 @@ int main(int argc, char** argv) {
             "bft_gpu load file_bft [-add_genomes {kmers|kmers_comp} list_genome_files output_file] [Options]\n\nOptions:\n"
             "[-query_kmers {kmers|kmers_comp} list_kmer_files]\n"
             "[-query_branching {kmers|kmers_comp} list_kmer_files]\n"
-            "[-query_sequences threshold {canonical|non_canonical} list_sequence_files]\n\n");
+            "[-query_sequences threshold {canonical|non_canonical} list_sequence_files]\n"
+            "[-extract_kmers {kmers|kmers_comp} output_file]\n\n");
     bft_gpu* h = NULL;
     int k = 0, i = 0;
     char buffer[2048];
@@ -271,6 +299,7 @@ int main(int argc, char** argv) {
         }
         const int binary = strcmp(argv[i + 1], "kmers_comp") == 0;
         if (!binary && strcmp(argv[i + 1], "kmers") != 0) DIE("Unrecognized type of input files for %s.\n", argv[i]);
+        if (strcmp(argv[i], "-extract_kmers") == 0) { extract_kmers(h, argv[i + 2], k, binary); continue; }
         FILE* lst = fopen(argv[i + 2], "r");
         if (!lst) DIE("Invalid k-mer queries files list.\n");
         while (fgets(buffer, sizeof buffer, lst)) {
