@@ -128,3 +128,21 @@ def test_add_genomes(oracle_mod, tmp_path):
     q = np.concatenate([allk, S.snp_mutants(allk[::3], k, 1)])
     assert all((a == b).all() for a, b in zip(o.query_colors(q), ref.query_colors(q)))
     assert o.nb_genomes_loaded() == 4
+
+
+def test_extract_kmers(tmp_path):
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(4000, 2), k))
+    os.chdir(tmp_path)
+    _write_ascii(tmp_path / "g.kmers", km, k)
+    (tmp_path / "l.txt").write_text(str(tmp_path / "g.kmers") + "\n")
+    assert subprocess.run([CLI, "build", str(k), "kmers", "l.txt", "o.bft"], capture_output=True).returncode == 0
+    out = subprocess.run([CLI, "load", "o.bft", "-extract_kmers", "kmers", "x.txt", "-extract_kmers", "kmers_comp", "x.bin"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = [l for l in (tmp_path / "x.txt").read_text().split("\n") if l]
+    assert sorted(got) == sorted(S.packed_to_ascii(km, k))
+    raw = (tmp_path / "x.bin").read_bytes()
+    head = f"{k}\n{len(km)}\n".encode()
+    assert raw.startswith(head)
+    packed = np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(-1, 7)
+    assert sorted(map(bytes, packed)) == sorted(map(bytes, km))
