@@ -5,10 +5,13 @@ import pytest
 
 from bloomfiltertrie_amd import synth as S
 
+import os
+
 pytestmark = pytest.mark.gpu
+N_SEEDS = int(os.environ.get("BFT_FUZZ_SEEDS", "24"))  # BFT_FUZZ_SEEDS=400 for a soak run
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(N_SEEDS)))
 def test_fuzz(oracle_mod, seed):
     from bloomfiltertrie_amd import BFT
     rng = np.random.default_rng(1000 + seed)
