@@ -464,7 +464,9 @@ struct bft_gpu {
     bool has_cs_bm = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
-    std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary
+    std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
+    uint64_t n_sets = 0, n_ids = 0;
+    bool cs_on_host = false;
     uint64_t info[16] = {0};
     double build_ms[5] = {0, 0, 0, 0, 0};
 
@@ -652,6 +654,34 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
                       uint64_t ostride, uint32_t* og, bool g_already_ordered) {
     const int W = h->W;
     const int n = (int)total;
+    if (W == 1) {
+        // one-word keys: sort the (key, genome) pairs themselves; the radix sort is stable, so a genome-id pass
+        // first (skipped when the ids already ascend) followed by the key pass gives (T, genome) order
+        DevBuf k2, g2, tmp1;
+        const uint64_t* kin = keys;
+        const uint32_t* gin = g;
+        if (!g_already_ordered) {
+            CK(k2.alloc(total * 8));
+            CK(g2.alloc(total * 4));
+            size_t tb = 0;
+            const int gb = bits_for(h->max_gid_seen);
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
+            CK(tmp1.alloc(tb));
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
+            kin = k2.as<uint64_t>();
+            gin = g2.as<uint32_t>();
+        }
+        size_t tb = 0;
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
+        if (tb > tmp1.bytes) {
+            HIPCK(hipStreamSynchronize(h->stream));
+            CK(tmp1.alloc(tb));
+        }
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
     DevBuf perm, perm2, ku, ku2, kg, kg2, tmp;
     CK(perm.alloc(total * 4));
     CK(perm2.alloc(total * 4));
@@ -696,6 +726,17 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
     return 0;
 }
 
+// The colour-set dictionary lives in HBM; only bft_gpu_colorset and bft_gpu_write_bft need it on the host.
+static int host_colorsets(bft_gpu* h) {
+    if (h->cs_on_host) return 0;
+    h->cs_off.assign(h->n_sets + 1, 0);
+    h->cs_ids.assign(h->n_ids, 0);
+    HIPCK(hipMemcpy(h->cs_off.data(), h->d_cs_off.p, (h->n_sets + 1) * 4, hipMemcpyDeviceToHost));
+    if (h->n_ids) HIPCK(hipMemcpy(h->cs_ids.data(), h->d_cs_ids.p, h->n_ids * 4, hipMemcpyDeviceToHost));
+    h->cs_on_host = true;
+    return 0;
+}
+
 extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     CK(set_device(h));
@@ -707,30 +748,36 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     DevBuf tk, seg_off, npk, npg;
     uint64_t nk = 0, np = 0;
     if (total > 0) {
-        // 1. concatenate the sorted store and the log
+        // 1. the pairs to sort: the log alone on a first build, else the sorted store followed by the log
         DevBuf ck, cg, sk, sg;
-        CK(ck.alloc(total * W * 8));
-        CK(cg.alloc(total * 4));
-        for (int w = 0; w < W; w++) {
-            if (h->n_pairs)
-                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total, h->pair_k.as<uint64_t>() + (uint64_t)w * h->n_pairs,
-                                     h->n_pairs * 8, hipMemcpyDeviceToDevice, h->stream));
-            if (h->log_n)
-                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total + h->n_pairs, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
-                                     h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
+        const uint64_t* src_k = h->log_k.as<uint64_t>();
+        const uint32_t* src_g = h->log_g.as<uint32_t>();
+        uint64_t src_stride = h->log_cap;
+        if (h->n_pairs) {
+            CK(ck.alloc(total * W * 8));
+            CK(cg.alloc(total * 4));
+            for (int w = 0; w < W; w++) {
+                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total, h->pair_k.as<uint64_t>() + (uint64_t)w * h->n_pairs, h->n_pairs * 8,
+                                     hipMemcpyDeviceToDevice, h->stream));
+                if (h->log_n)
+                    HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total + h->n_pairs, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
+                                         h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
+            }
+            HIPCK(hipMemcpyAsync(cg.p, h->pair_g.p, h->n_pairs * 4, hipMemcpyDeviceToDevice, h->stream));
+            if (h->log_n) HIPCK(hipMemcpyAsync(cg.as<uint32_t>() + h->n_pairs, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
+            src_k = ck.as<uint64_t>();
+            src_g = cg.as<uint32_t>();
+            src_stride = total;
         }
-        if (h->n_pairs) HIPCK(hipMemcpyAsync(cg.p, h->pair_g.p, h->n_pairs * 4, hipMemcpyDeviceToDevice, h->stream));
-        if (h->log_n) HIPCK(hipMemcpyAsync(cg.as<uint32_t>() + h->n_pairs, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream));
-        h->log_k.release();
-        h->log_g.release();
-        h->log_cap = 0;
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
         CK(sg.alloc(total * 4));
-        CK(sort_pairs(h, ck.as<uint64_t>(), total, cg.as<uint32_t>(), total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted));
+        CK(sort_pairs(h, src_k, src_stride, src_g, total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted));
         ck.release();
         cg.release();
+        h->log_k.release();
+        h->log_g.release();
+        h->log_cap = 0;
         // 3. flags, scans, compaction
         DevBuf head, keep, posK, posP, tmp;
         CK(head.alloc(total * 4));
@@ -773,10 +820,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(npg.alloc(4));
     }
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, h->d_tcol, h->d_cs_off, h->d_cs_ids, n_sets, n_ids));
-    h->cs_off.assign(n_sets + 1, 0);
-    h->cs_ids.assign(n_ids, 0);
-    HIPCK(hipMemcpy(h->cs_off.data(), h->d_cs_off.p, (n_sets + 1) * 4, hipMemcpyDeviceToHost));
-    if (n_ids) HIPCK(hipMemcpy(h->cs_ids.data(), h->d_cs_ids.p, n_ids * 4, hipMemcpyDeviceToHost));
+    h->n_sets = n_sets;
+    h->n_ids = n_ids;
+    h->cs_on_host = false;
+    h->cs_off.clear();
+    h->cs_ids.clear();
     double t2 = now_ms();
 
     // 5. containers, level by level, on the GPU
@@ -824,7 +872,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     im.cs_off = h->d_cs_off.as<uint32_t>();
     im.cs_ids = h->d_cs_ids.as<uint32_t>();
     {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
-        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->cs_off.size() - 1;
+        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->n_sets;
         h->has_cs_bm = false;
         h->d_cs_bm.release();
         if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
@@ -1243,6 +1291,7 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     CK(download(h->d_ucrow, h->idx_sizes[7], hi.ucrow));
     CK(download(h->d_tk, h->idx_sizes[8], hi.tk));
     CK(download(h->d_tcol, h->n_kmers * 4, hi.tcol));
+    CK(host_colorsets(h));
     hi.cs_off = h->cs_off;
     hi.cs_ids = h->cs_ids;
     std::string err;
@@ -1346,6 +1395,9 @@ extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorse
 
 extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t cap, uint32_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    CK(host_colorsets(h));
     if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
     const uint32_t a = h->cs_off[cs], b = h->cs_off[cs + 1];
     if (n_out) *n_out = b - a;
