@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--verify", type=int, default=1_000_000, help="queries of the batch checked against ground truth")
     ap.add_argument("--no-k31", action="store_true", help="skip the secondary k=31 measurement (extension beyond the reference)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bitmap all_gather even with one rank (path check)")
+    ap.add_argument("--replicate", choices=["rebuild", "broadcast"], default="rebuild",
+                    help="how every rank gets the trie: each rank builds it (default, no collective outside the bitmap gather) "
+                         "or rank 0 builds it and one RCCL broadcast replicates the image")
     return ap.parse_args()
 
 
@@ -107,13 +110,18 @@ def main():
     t_build0 = time.time()
     gk = build_genome_kmers(args)
     t_gen = time.time() - t_build0
-    bft = BFT(args.k, device=local_rank)
     t0 = time.time()
-    for gid, km in enumerate(gk):
-        bft.add_genome(f"genome_{gid}")
-        bft.insert_kmers(km, gid)
-    bft.build()
+    bft = None
+    if rank == 0 or not (use_dist and args.replicate == "broadcast"):
+        bft = BFT(args.k, device=local_rank)
+        for gid, km in enumerate(gk):
+            bft.add_genome(f"genome_{gid}")
+            bft.insert_kmers(km, gid)
+        bft.build()
     t_insert = time.time() - t0
+    if use_dist and args.replicate == "broadcast":
+        from bloomfiltertrie_amd.dist import replicate_image
+        bft = replicate_image(bft, local_rank, src=0, always_copy=args.force_dist and world == 1)
     info = bft.info()
     union = S.distinct(np.concatenate(gk))
     assert info["kmers"] == len(union), (info["kmers"], len(union))
@@ -185,13 +193,26 @@ def main():
             "k": args.k, "genomes": args.genomes, "genome_len": args.genome_len, "snp_rate": args.snp_rate,
             "queries_per_gpu": nq, "distinct_kmers": info["kmers"], "pairs": info["pairs"],
             "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
-            "parallelism": f"query-shard x{world}, trie replicated",
+            "parallelism": f"query-shard x{world}, trie replicated ({args.replicate if use_dist else 'single copy'})",
         },
         "parity_ok": parity_ok,
         "present_fraction": round(n_present / nq, 4),
         "build": {"kmer_gen_s": round(t_gen, 2), "insert_build_s": round(t_insert, 2),
                   "M_pairs_per_s": round(info["pairs"] / t_insert / 1e6, 3), **{k_: round(v, 1) for k_, v in bft.build_time().items()}},
     }
+
+    # ---- secondary: the host-buffer entry point (H2D + kernel + D2H through bft_gpu_query_presence); never `value` ----
+    if world == 1:
+        nh = min(nq, 20_000_000)
+        hq = np.ascontiguousarray(dq[:nh].cpu().numpy())
+        bft.query_presence(hq[:1000])
+        t0 = time.perf_counter()
+        hb = bft.query_presence(hq)
+        th = time.perf_counter() - t0
+        out["pcie_inclusive"] = {"value": round(nh / th / 1e6, 3), "unit": "M k-mers/s", "queries": nh,
+                                 "same_bits": bool((hb == dbits[: (nh + 7) // 8].cpu().numpy()).all()),
+                                 "note": "pageable host buffers in and out, one call; for reference only"}
+        del hq
 
     # ---- secondary: the same workload at the k the metric names (k=31), an extension the reference cannot run ----
     if not args.no_k31 and world == 1:

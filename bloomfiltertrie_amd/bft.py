@@ -57,6 +57,27 @@ class BFT:
         _lib.check(lib.bft_gpu_info(h, out, 16))
         return cls(int(out[0]), device=device, _handle=h)
 
+    @classmethod
+    def from_image(cls, d_blob_ptr, nbytes, device=0):
+        """New index on `device` from an image blob resident in that GPU's memory (see image_pack)."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.bft_gpu_image_unpack(d_blob_ptr, nbytes, device, C.byref(h)))
+        out = (C.c_uint64 * 16)()
+        _lib.check(lib.bft_gpu_info(h, out, 16))
+        return cls(int(out[0]), device=device, _handle=h)
+
+    def image_size(self):
+        """Bytes of the device blob that image_pack writes."""
+        n = C.c_uint64()
+        _lib.check(self._lib.bft_gpu_image_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def image_pack(self, d_blob_ptr, cap, stream=None):
+        """Copy the built index (containers, k-mer table, colour sets, pair store, genome names) into one
+        contiguous device buffer -- the payload of the broadcast that replicates the trie on the other GPUs."""
+        _lib.check(self._lib.bft_gpu_image_pack(self._h, d_blob_ptr, cap, stream))
+
     def write_bft(self, path):
         """write_BFT (include/bft.h:175)."""
         _lib.check(self._lib.bft_gpu_write_bft(self._h, path.encode()))

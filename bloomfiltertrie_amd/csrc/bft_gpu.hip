@@ -15,6 +15,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -726,6 +727,44 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
     return 0;
 }
 
+// Points h->im at the device arrays of the handle and derives the bitmap form of the colour-set dictionary.
+static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
+    BftImage& im = h->im;
+    im.k = h->k;
+    im.L = h->L;
+    im.W = h->W;
+    im.nb_genomes = nb_genomes;
+    im.n_kmers = h->n_kmers;
+    im.hashmod = h->d_hashmod.as<uint32_t>();
+    im.nodes = h->d_nodes.as<BftNode>();
+    im.bfT = h->d_bfT.as<uint8_t>();
+    im.ccs = h->d_ccs.as<BftCC>();
+    im.f2w = h->d_f2w.as<uint64_t>();
+    im.clus = h->d_clus.as<uint64_t>();
+    im.child = h->d_child.as<uint64_t>();
+    im.tk = h->d_tk.as<uint64_t>();
+    im.tcol = h->d_tcol.as<uint32_t>();
+    im.uck = h->d_uck.as<uint64_t>();
+    im.ucrow = h->d_ucrow.as<uint32_t>();
+    im.cs_off = h->d_cs_off.as<uint32_t>();
+    im.cs_ids = h->d_cs_ids.as<uint32_t>();
+    {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
+        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->n_sets;
+        h->has_cs_bm = false;
+        h->d_cs_bm.release();
+        if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
+            CK(h->d_cs_bm.alloc_zero(nsets * rowbytes, h->stream));
+            hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, im.cs_off, im.cs_ids, nsets, (uint32_t)rowbytes,
+                               h->d_cs_bm.as<uint8_t>());
+            HIPCK(hipGetLastError());
+            HIPCK(hipStreamSynchronize(h->stream));
+            h->has_cs_bm = true;
+        }
+    }
+
+    return 0;
+}
+
 // The colour-set dictionary lives in HBM; only bft_gpu_colorset and bft_gpu_write_bft need it on the host.
 static int host_colorsets(bft_gpu* h) {
     if (h->cs_on_host) return 0;
@@ -852,38 +891,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->n_kmers = nk;
     double t4 = now_ms(), t5 = t4;
 
+    CK(bind_image(h, std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0)));
     BftImage& im = h->im;
-    im.k = h->k;
-    im.L = h->L;
-    im.W = W;
-    im.nb_genomes = std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0);
-    im.n_kmers = nk;
-    im.hashmod = h->d_hashmod.as<uint32_t>();
-    im.nodes = h->d_nodes.as<BftNode>();
-    im.bfT = h->d_bfT.as<uint8_t>();
-    im.ccs = h->d_ccs.as<BftCC>();
-    im.f2w = h->d_f2w.as<uint64_t>();
-    im.clus = h->d_clus.as<uint64_t>();
-    im.child = h->d_child.as<uint64_t>();
-    im.tk = h->d_tk.as<uint64_t>();
-    im.tcol = h->d_tcol.as<uint32_t>();
-    im.uck = h->d_uck.as<uint64_t>();
-    im.ucrow = h->d_ucrow.as<uint32_t>();
-    im.cs_off = h->d_cs_off.as<uint32_t>();
-    im.cs_ids = h->d_cs_ids.as<uint32_t>();
-    {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
-        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->n_sets;
-        h->has_cs_bm = false;
-        h->d_cs_bm.release();
-        if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
-            CK(h->d_cs_bm.alloc_zero(nsets * rowbytes, h->stream));
-            hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, im.cs_off, im.cs_ids, nsets, (uint32_t)rowbytes,
-                               h->d_cs_bm.as<uint8_t>());
-            HIPCK(hipGetLastError());
-            HIPCK(hipStreamSynchronize(h->stream));
-            h->has_cs_bm = true;
-        }
-    }
 
     uint64_t* I = h->info;
     I[0] = h->k;
@@ -930,10 +939,11 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
     const uint64_t resident = 256ull * (2048 / BLOCK);  // 256 CUs x workgroups per CU at full occupancy
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
+    const uint64_t dev_bit = 1ull << (h->device & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
         HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_query<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
     HIPCK(hipGetLastError());
@@ -980,10 +990,11 @@ static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, ui
     const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCC) : 0);
     const uint64_t nblk = (n + 1023) / 1024;
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 512)));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devs{0};
+    const uint64_t dev_bit = 1ull << (h->device & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
         HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_branching<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
     HIPCK(hipGetLastError());
@@ -1296,6 +1307,140 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     hi.cs_ids = h->cs_ids;
     std::string err;
     if (!bft_file_write(path, hi, err)) return fail(BFT_GPU_E_IO, err);
+    return BFT_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image replication (one contiguous device blob: header, then 256-byte aligned sections)
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t BLOB_MAGIC = 0x3130555047544642ull;  // "BFTGPU01"
+constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 15;
+enum { H_MAGIC, H_TOTAL, H_K, H_R1, H_R2, H_NKMERS, H_NPAIRS, H_NSETS, H_NIDS, H_ROOTNCC, H_MAXGID, H_ANYINS, H_NBGEN, H_NNAMES,
+       H_STOREMAX, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
+
+struct BlobPlan {
+    uint64_t hdr[BLOB_HDR_WORDS];
+    uint64_t off[BLOB_SECTIONS];
+    const void* src[BLOB_SECTIONS];
+    std::string names;
+};
+
+inline uint64_t align256(uint64_t v) { return (v + 255ull) & ~255ull; }
+
+void plan_blob(bft_gpu* h, BlobPlan& p) {
+    memset(p.hdr, 0, sizeof(p.hdr));
+    p.names.clear();
+    for (const std::string& g : h->genomes) { p.names += g; p.names.push_back('\0'); }
+    const uint64_t sz[BLOB_SECTIONS] = {h->idx_sizes[0], h->idx_sizes[1], h->idx_sizes[2], h->idx_sizes[3], h->idx_sizes[4], h->idx_sizes[5], h->idx_sizes[6],
+                                        h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * 4,
+                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size()};
+    const void* src[BLOB_SECTIONS] = {h->d_nodes.p, h->d_bfT.p, h->d_ccs.p, h->d_f2w.p, h->d_clus.p, h->d_child.p, h->d_uck.p, h->d_ucrow.p,
+                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr};
+    uint64_t o = BLOB_HDR_WORDS * 8;
+    for (int i = 0; i < BLOB_SECTIONS; i++) {
+        p.off[i] = o;
+        p.src[i] = src[i];
+        p.hdr[H_SEC + i] = sz[i];
+        o = align256(o + sz[i]);
+    }
+    uint64_t* H = p.hdr;
+    H[H_MAGIC] = BLOB_MAGIC; H[H_TOTAL] = o; H[H_K] = h->k; H[H_R1] = h->r1; H[H_R2] = h->r2; H[H_NKMERS] = h->n_kmers; H[H_NPAIRS] = h->n_pairs;
+    H[H_NSETS] = h->n_sets; H[H_NIDS] = h->n_ids; H[H_ROOTNCC] = h->root_ncc; H[H_MAXGID] = h->max_gid_seen; H[H_ANYINS] = h->any_insert;
+    H[H_NBGEN] = h->im.nb_genomes; H[H_NNAMES] = h->genomes.size(); H[H_STOREMAX] = h->store_max_gid; H[H_STOREANY] = h->store_any;
+    for (int i = 0; i < 16; i++) H[H_INFO + i] = h->info[i];
+    for (int i = 0; i < 9; i++) H[H_IDX + i] = h->idx_sizes[i];
+}
+}  // namespace
+
+extern "C" int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes) {
+    if (!h || !nbytes) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    BlobPlan p;
+    plan_blob(h, p);
+    *nbytes = p.hdr[H_TOTAL];
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* hip_stream) {
+    if (!h || !d_blob) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    BlobPlan p;
+    plan_blob(h, p);
+    if (cap < p.hdr[H_TOTAL]) return fail(BFT_GPU_E_NOSPACE, "blob buffer too small");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    uint8_t* d = (uint8_t*)d_blob;
+    HIPCK(hipMemcpyAsync(d, p.hdr, sizeof(p.hdr), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < BLOB_SECTIONS; i++) {
+        const uint64_t n = p.hdr[H_SEC + i];
+        if (!n) continue;
+        if (p.src[i]) HIPCK(hipMemcpyAsync(d + p.off[i], p.src[i], n, hipMemcpyDeviceToDevice, s));
+        else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));
+    }
+    HIPCK(hipStreamSynchronize(s));  // the header and the names are host temporaries
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int device, bft_gpu** out) {
+    if (!d_blob || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
+    *out = nullptr;
+    if (nbytes < BLOB_HDR_WORDS * 8) return fail(BFT_GPU_E_ARG, "blob shorter than its header");
+    int ndev = 0;
+    HIPCK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BFT_GPU_E_ARG, "bad device index");
+    HIPCK(hipSetDevice(device));
+    uint64_t H[BLOB_HDR_WORDS];
+    HIPCK(hipMemcpy(H, d_blob, sizeof(H), hipMemcpyDeviceToHost));
+    if (H[H_MAGIC] != BLOB_MAGIC) return fail(BFT_GPU_E_IO, "not a bft_gpu image blob");
+    if (H[H_TOTAL] > nbytes) return fail(BFT_GPU_E_IO, "truncated image blob");
+    uint64_t off[BLOB_SECTIONS], o = BLOB_HDR_WORDS * 8;
+    for (int i = 0; i < BLOB_SECTIONS; i++) {
+        off[i] = o;
+        if (H[H_SEC + i] > H[H_TOTAL] - o) return fail(BFT_GPU_E_IO, "image blob section out of range");
+        o = align256(o + H[H_SEC + i]);
+    }
+    bft_gpu* h = nullptr;
+    CK(bft_gpu_create_seeded((int)H[H_K], device, (int)H[H_R1], (int)H[H_R2], &h));
+    const uint8_t* d = (const uint8_t*)d_blob;
+    DevBuf* dst[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow,
+                       &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g};
+    int rc = 0;
+    for (int i = 0; i < 14 && rc == 0; i++) {
+        rc = dst[i]->alloc(H[H_SEC + i]);
+        if (rc == 0 && H[H_SEC + i] &&
+            hipMemcpyAsync(dst[i]->p, d + off[i], H[H_SEC + i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+            rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
+    }
+    std::string names(H[H_SEC + 14], '\0');
+    if (rc == 0 && !names.empty() && hipMemcpyAsync(&names[0], d + off[14], names.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
+    if (rc == 0 && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
+    if (rc == 0) {
+        size_t a = 0;
+        for (uint64_t i = 0; i < H[H_NNAMES] && a < names.size(); i++) {
+            const size_t e = names.find('\0', a);
+            h->genomes.push_back(names.substr(a, e == std::string::npos ? std::string::npos : e - a));
+            a = e == std::string::npos ? names.size() : e + 1;
+        }
+        h->n_kmers = H[H_NKMERS]; h->n_pairs = H[H_NPAIRS]; h->n_sets = H[H_NSETS]; h->n_ids = H[H_NIDS];
+        h->root_ncc = (uint32_t)H[H_ROOTNCC]; h->max_gid_seen = (uint32_t)H[H_MAXGID]; h->any_insert = H[H_ANYINS] != 0;
+        h->store_max_gid = (uint32_t)H[H_STOREMAX]; h->store_any = H[H_STOREANY] != 0;
+        for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
+        for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
+        h->cs_on_host = false;
+        rc = bind_image(h, (uint32_t)H[H_NBGEN]);
+    }
+    if (rc != 0) {
+        const std::string keep = g_err;
+        bft_gpu_free(h);
+        return fail(rc, keep);
+    }
+    h->info[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes +
+                  h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes;
+    h->built = true;
+    *out = h;
     return BFT_GPU_OK;
 }
 

@@ -41,3 +41,28 @@ def query_presence_sharded(bft, kmers, group=None):
     dev = torch.device("cuda", bft.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     t = torch.from_numpy(np.ascontiguousarray(bits)).to(dev)
     return gather_bitmaps(t, n, ws, rk, per, group).cpu().numpy()
+
+
+def replicate_image(bft, device, src=0, group=None, always_copy=False):
+    """Replicate the index built on rank `src` into the HBM of every rank's GPU with ONE broadcast (RCCL over
+    xGMI): `bft` is the built index on rank src and ignored (may be None) elsewhere; returns a BFT on `device`
+    on every rank (rank src gets its own object back unless always_copy).  SURVEY.md 8e: "trie image replicated
+    per GPU"."""
+    import torch
+    import torch.distributed as dist
+    from .bft import BFT
+    rk = dist.get_rank(group)
+    dev = torch.device("cuda", device)
+    size = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rk == src:
+        size[0] = bft.image_size()
+    dist.broadcast(size, src, group=group)
+    nbytes = int(size.item())
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if rk == src:
+        bft.image_pack(blob.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+    dist.broadcast(blob, src, group=group)
+    if rk == src and not always_copy:
+        return bft
+    torch.cuda.synchronize(dev)
+    return BFT.from_image(blob.data_ptr(), nbytes, device=device)

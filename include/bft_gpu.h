@@ -35,7 +35,7 @@ extern "C" {
 #define BFT_GPU_E_HIP (-2)      /* HIP runtime / device error */
 #define BFT_GPU_E_LIMIT (-3)    /* a container limit of the format was exceeded */
 #define BFT_GPU_E_STATE (-4)    /* call order (query before anything was built, ...) */
-#define BFT_GPU_E_IO (-5)       /* file error / malformed .bft */
+#define BFT_GPU_E_IO (-5)       /* file error / malformed .bft or image blob */
 #define BFT_GPU_E_NOSPACE (-6)  /* caller-provided output buffer too small */
 
 typedef struct bft_gpu bft_gpu; /* opaque: one BFT resident on one GPU (replaces BFT_Root, include/Node.h:96-122) */
@@ -146,6 +146,16 @@ int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
  * ascending T-form order) and its colour-set id; either pointer may be NULL. */
 int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorset_out, uint64_t cap, uint64_t* n_out);
 int bft_gpu_colorset(bft_gpu* h, uint32_t colorset, uint32_t* ids, uint32_t cap, uint32_t* n_out);
+
+/* Replication of a built index on another GPU (the query path shards over GPUs with the trie image
+ * replicated in each GPU's HBM; the reference has one BFT_Root per process, include/Node.h:96-122).
+ * bft_gpu_image_size: bytes of the self-describing device blob; bft_gpu_image_pack: writes it at d_blob (device
+ * memory of the handle's GPU, cap >= size) on hip_stream (0 = the handle's stream) and synchronises that stream;
+ * bft_gpu_image_unpack: new handle on `device` from a blob resident in that GPU's memory (e.g. the receive buffer
+ * of one RCCL broadcast) -- same answers, same bft_gpu_write_bft bytes, and insertion can continue on it. */
+int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes);
+int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* hip_stream);
+int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int device, bft_gpu** out);
 
 #ifdef __cplusplus
 }

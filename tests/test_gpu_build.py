@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from bloomfiltertrie_amd import _lib, synth as S
+from bloomfiltertrie_amd import BFT, _lib, synth as S
 
 pytestmark = pytest.mark.gpu
 
@@ -82,3 +82,79 @@ def test_many_small_nodes(hostlib):
     km = S.low_entropy_kmers(1500000, 27, 3000, seed=11, levels=1)
     info = _compare(hostlib, km, 27)
     assert info["child_nodes"] > 1000
+
+
+def _rk(n, k, seed):
+    return S.distinct(S.kmers_of(S.random_genome(n + k - 1, seed), k))
+
+
+def test_image_pack_unpack_roundtrip(tmp_path):
+    """bft_gpu_image_pack -> bft_gpu_image_unpack gives an index with the same answers, the same .bft bytes, and
+    insertion continues on the copy exactly as on the original."""
+    import torch
+    k = 27
+    g0 = _rk(30000, k, 5)
+    g1 = np.concatenate([g0[:10000], _rk(15000, k, 6)])
+    a = BFT(k)
+    a.add_genome("first.fa")
+    a.insert_kmers(g0, 0)
+    a.add_genome("second.fa")
+    a.insert_kmers(g1, 1)
+    a.build()
+    n = a.image_size()
+    blob = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    a.image_pack(blob.data_ptr(), n)
+    b = BFT.from_image(blob.data_ptr(), n, device=0)
+    del blob
+    ia, ib = a.info(), b.info()
+    assert ia == ib
+    q = np.concatenate([g0[::3], g1[::3], _rk(20000, k, 7)])
+    assert (a.query_presence(q) == b.query_presence(q)).all()
+    ba, ra = a.query_color_rows(q)
+    bb, rb = b.query_color_rows(q)
+    assert (ba == bb).all() and (ra == rb).all()
+    assert (a.query_branching(q[:5000]) == b.query_branching(q[:5000])).all()
+    a.write_bft(str(tmp_path / "a.bft"))
+    b.write_bft(str(tmp_path / "b.bft"))
+    assert open(tmp_path / "a.bft", "rb").read() == open(tmp_path / "b.bft", "rb").read()
+    g2 = _rk(5000, k, 8)
+    for t in (a, b):
+        t.add_genome("third.fa")
+        t.insert_kmers(np.concatenate([g2, g0[:100]]), 2)
+        t.build()
+    assert a.info() == b.info()
+    q2 = np.concatenate([g2, g0[:200]])
+    assert (a.query_color_rows(q2)[1] == b.query_color_rows(q2)[1]).all()
+    ka, ca = a.extract()
+    kb, cb = b.extract()
+    assert (ka == kb).all() and (ca == cb).all()
+
+
+def test_image_unpack_rejects_garbage():
+    import torch
+    blob = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(Exception):
+        BFT.from_image(blob.data_ptr(), 4096, device=0)
+    with pytest.raises(Exception):
+        BFT.from_image(blob.data_ptr(), 16, device=0)
+
+
+def test_replicate_image_single_rank_rccl():
+    """dist.replicate_image over the nccl (= RCCL) backend with world_size 1: the broadcast path end to end."""
+    import torch
+    import torch.distributed as dist
+    from bloomfiltertrie_amd.dist import replicate_image
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        a = BFT(18)
+        km = _rk(5000, 18, 3)
+        a.insert_kmers(km, 0)
+        a.build()
+        assert replicate_image(a, 0, src=0) is a
+        b = replicate_image(a, 0, src=0, always_copy=True)
+        q = np.concatenate([km[::2], _rk(3000, 18, 4)])
+        assert b is not a and (a.query_presence(q) == b.query_presence(q)).all() and a.info() == b.info()
+    finally:
+        dist.destroy_process_group()
