@@ -671,6 +671,105 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
 }
 
 // ---------------------------------------------------------------------------------------------
+// flat form of the big CCs (bft_image.h): derived from ccs / f2w / clus / child
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flat_flags(const BftCC* __restrict__ ccs, uint32_t C, uint32_t flat_min, uint32_t* __restrict__ flag, uint32_t* __restrict__ cnt) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const uint32_t f = ccs[c].nb_elem >= flat_min ? 1u : 0u;
+        flag[c] = f;
+        cnt[c] = f ? ccs[c].nb_elem : 0u;
+    }
+}
+
+__global__ void k_ccx(const BftCC* __restrict__ ccs, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ fidx, const uint32_t* __restrict__ foff,
+                      uint32_t C, BftCCX* __restrict__ out) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const BftCC cc = ccs[c];
+        BftCCX x;
+        x.f2_off = cc.f2_off; x.clus_off = cc.clus_off; x.child_off = cc.child_off; x.nb_elem = cc.nb_elem; x.s = cc.s;
+        x.flat = (uint8_t)flag[c];
+        x.f18_off = flag[c] ? fidx[c] * BFT_F18_WORDS : 0u;
+        x.fent_off = flag[c] ? foff[c] : 0u;
+        x.pad[0] = 0; x.pad[1] = 0;
+        out[c] = x;
+    }
+}
+
+#define FLAT_MAX_F2W 352  // filter2 words of one CC: ceil(2^14 / 48) = 342 (s = 4), 22 (s = 8)
+
+// one workgroup per flat CC: walk the clusters in p_u order, emit every prefix entry in r order and set bit r
+__global__ __launch_bounds__(ABLK) void k_flat_fill(const BftCCX* __restrict__ ccx, uint32_t C, const uint64_t* __restrict__ f2w, const uint64_t* __restrict__ clus,
+                                                    const uint64_t* __restrict__ child, uint64_t* __restrict__ f18, uint64_t* __restrict__ fent) {
+    __shared__ uint32_t wpos[FLAT_MAX_F2W];
+    for (uint32_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const BftCCX cc = ccx[c];
+        if (!cc.flat) continue;  // uniform over the workgroup
+        const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+        for (uint32_t w = threadIdx.x; w < nw; w += ABLK) {
+            const uint64_t fw = f2w[cc.f2_off + w];
+            uint64_t bits = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+            uint32_t clu = (uint32_t)(fw >> 48), n = 0;
+            for (; bits; bits &= bits - 1, clu++) {
+                const uint64_t e = clus[cc.clus_off + clu];
+                n += (e & BFT_CLUS_MULTI) ? (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+            }
+            wpos[w] = n;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (uint32_t w = 0; w < nw; w++) { const uint32_t n = wpos[w]; wpos[w] = acc; acc += n; }
+        }
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < nw; w += ABLK) {
+            const uint64_t fw = f2w[cc.f2_off + w];
+            uint64_t bits = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+            uint32_t clu = (uint32_t)(fw >> 48), pos = wpos[w];
+            for (; bits; bits &= bits - 1, clu++) {
+                const uint32_t pu = w * BFT_F2_BITS_PER_WORD + (uint32_t)__builtin_ctzll(bits);
+                const uint64_t e = clus[cc.clus_off + clu];
+                const uint32_t len = (e & BFT_CLUS_MULTI) ? (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+                for (uint32_t j = 0; j < len; j++) {
+                    const uint64_t ent = (e & BFT_CLUS_MULTI) ? child[cc.child_off + (uint32_t)e + j] : e;
+                    const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
+                    fent[cc.fent_off + pos++] = ent;
+                    atomicOr((unsigned long long*)&f18[cc.f18_off + r / BFT_F2_BITS_PER_WORD], 1ull << (r % BFT_F2_BITS_PER_WORD));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// running rank into each word of the flat bitmaps (separate launch: the bits were set with atomics)
+__global__ __launch_bounds__(ABLK) void k_flat_ranks(const BftCCX* __restrict__ ccx, uint32_t C, uint64_t* __restrict__ f18) {
+    __shared__ uint32_t part[ABLK];
+    const uint32_t per = (BFT_F18_WORDS + ABLK - 1) / ABLK;
+    for (uint32_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const BftCCX cc = ccx[c];
+        if (!cc.flat) continue;
+        uint64_t* f = f18 + cc.f18_off;
+        const uint32_t w0 = threadIdx.x * per, w1 = w0 + per < BFT_F18_WORDS ? w0 + per : BFT_F18_WORDS;
+        uint32_t n = 0;
+        for (uint32_t w = w0; w < w1; w++) n += (uint32_t)__builtin_popcountll(f[w]);
+        part[threadIdx.x] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < ABLK; i++) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
+        }
+        __syncthreads();
+        uint32_t rank = part[threadIdx.x];
+        for (uint32_t w = w0; w < w1; w++) {
+            const uint64_t v = f[w];
+            f[w] = v | ((uint64_t)rank << 48);
+            rank += (uint32_t)__builtin_popcountll(v);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // colour sets
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -745,6 +844,43 @@ int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_
     case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out);
     default: return assemble<4>(d_tk, n, k, d_hashmod, s, out);
     }
+}
+
+int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, const uint64_t* d_clus, const uint64_t* d_child, uint32_t flat_min,
+                    hipStream_t s, DevBuf& ccx, DevBuf& f18, DevBuf& fent, uint64_t& n_f18, uint64_t& n_fent) {
+    n_f18 = 0;
+    n_fent = 0;
+    CK(ccx.alloc(n_ccs * sizeof(BftCCX)));
+    if (n_ccs == 0) {
+        CK(f18.alloc(8));
+        CK(fent.alloc(8));
+        return 0;
+    }
+    const uint32_t C = (uint32_t)n_ccs;
+    Scan scan(s);
+    DevBuf flag, cnt, fidx, foff;
+    CK(flag.alloc(n_ccs * 4));
+    CK(cnt.alloc(n_ccs * 4));
+    CK(fidx.alloc(n_ccs * 4));
+    CK(foff.alloc(n_ccs * 4));
+    const dim3 grid(bft_grid_for((n_ccs + ABLK - 1) / ABLK)), block(ABLK);
+    hipLaunchKernelGGL(k_flat_flags, grid, block, 0, s, d_ccs, C, flat_min, flag.as<uint32_t>(), cnt.as<uint32_t>());
+    uint64_t nflat = 0;
+    CK(scan.run(flag.as<uint32_t>(), fidx.as<uint32_t>(), n_ccs, &nflat));
+    CK(scan.run(cnt.as<uint32_t>(), foff.as<uint32_t>(), n_ccs, &n_fent));
+    n_f18 = nflat * BFT_F18_WORDS;
+    if (n_f18 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "flat prefix bitmaps exceed 2^32 words");
+    CK(f18.alloc_zero(n_f18 * 8, s));
+    CK(fent.alloc(n_fent * 8));
+    hipLaunchKernelGGL(k_ccx, grid, block, 0, s, d_ccs, flag.as<uint32_t>(), fidx.as<uint32_t>(), foff.as<uint32_t>(), C, ccx.as<BftCCX>());
+    if (nflat) {
+        const dim3 g2((unsigned)std::min<uint64_t>(n_ccs, 65535));
+        hipLaunchKernelGGL(k_flat_fill, g2, block, 0, s, ccx.as<BftCCX>(), C, d_f2w, d_clus, d_child, f18.as<uint64_t>(), fent.as<uint64_t>());
+        hipLaunchKernelGGL(k_flat_ranks, g2, block, 0, s, ccx.as<BftCCX>(), C, f18.as<uint64_t>());
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s));
+    return 0;
 }
 
 // Interning of the colour sets (sorted genome-id list of each distinct k-mer, CSR seg_off/pg) into a dictionary:

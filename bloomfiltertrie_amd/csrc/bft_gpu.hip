@@ -108,15 +108,15 @@ struct BftRootLds {
     const BftImage& im;
     const uint32_t* hm;
     const uint8_t* bf;
-    const BftCC* cc;
+    const BftCCX* cc;
     __device__ __forceinline__ uint32_t hashmod(uint32_t key) const { return hm[key]; }
     __device__ __forceinline__ int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
         if (STAGED) return bft_first_cc_blk(bf, nd.bf_wb, h1, h2);
         return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
     }
-    __device__ __forceinline__ BftCC root_cc(const BftNode& nd, int c) const {
+    __device__ __forceinline__ BftCCX root_cc(const BftNode& nd, int c) const {
         if (STAGED) return cc[c];
-        return im.ccs[nd.cc_first + c];
+        return im.ccx[nd.cc_first + c];
     }
 };
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __r
     const BftNode root = im.nodes[0];
     const bool stage_root = STAGED;  // host side: root.ncc in [1, 64]
     const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
-    BftCC* l_cc = (BftCC*)(l_bf + bf_bytes);
+    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
     {
         const uint4* g = (const uint4*)im.hashmod;
         uint4* l = (uint4*)l_hm;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __r
             uint64_t* lb = (uint64_t*)l_bf;
             const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;  // 1504*wb is a multiple of 8
             for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
-            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccs[root.cc_first + i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
         }
     }
     __syncthreads();
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
     const BftNode root = im.nodes[0];
     const uint32_t bf_bytes = STAGED ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
-    BftCC* l_cc = (BftCC*)(l_bf + bf_bytes);
+    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
     {
         const uint4* g = (const uint4*)im.hashmod;
         uint4* l = (uint4*)l_hm;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
             uint64_t* lb = (uint64_t*)l_bf;
             const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
             for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
-            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccs[root.cc_first + i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
         }
     }
     __syncthreads();
@@ -462,6 +462,9 @@ struct bft_gpu {
     bool built = false;
     uint64_t n_kmers = 0;
     DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
+    DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
+    uint64_t n_f18 = 0, n_fent = 0;
+    uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
@@ -727,6 +730,12 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
     return 0;
 }
 
+static uint64_t image_bytes(const bft_gpu* h) {
+    return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
+           h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
+           h->d_f18.bytes + h->d_fent.bytes;
+}
+
 // Points h->im at the device arrays of the handle and derives the bitmap form of the colour-set dictionary.
 static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     BftImage& im = h->im;
@@ -748,6 +757,11 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     im.ucrow = h->d_ucrow.as<uint32_t>();
     im.cs_off = h->d_cs_off.as<uint32_t>();
     im.cs_ids = h->d_cs_ids.as<uint32_t>();
+    CK(bft_flatten_gpu(im.ccs, h->idx_sizes[2] / sizeof(BftCC), im.f2w, im.clus, im.child, h->opt_flat_min, h->stream, h->d_ccx, h->d_f18, h->d_fent,
+                       h->n_f18, h->n_fent));
+    im.ccx = h->d_ccx.as<BftCCX>();
+    im.f18 = h->d_f18.as<uint64_t>();
+    im.fent = h->d_fent.as<uint64_t>();
     {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
         const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->n_sets;
         h->has_cs_bm = false;
@@ -889,10 +903,14 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->store_any = np > 0;
     h->store_max_gid = h->max_gid_seen;
     h->n_kmers = nk;
-    double t4 = now_ms(), t5 = t4;
+    h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
+    h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
+    h->idx_sizes[6] = idx.n_uc * (uint64_t)W * 8; h->idx_sizes[7] = idx.n_uc * 4; h->idx_sizes[8] = nk * (uint64_t)W * 8;
+    double t4 = now_ms();
 
     CK(bind_image(h, std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0)));
     BftImage& im = h->im;
+    double t5 = now_ms();
 
     uint64_t* I = h->info;
     I[0] = h->k;
@@ -907,14 +925,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     I[9] = np;
     I[10] = n_sets;
     I[11] = im.nb_genomes;
-    I[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes +
-            h->d_tk.bytes + h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes;
+    I[12] = image_bytes(h);
     I[13] = idx.root_ncc;
     I[14] = idx.root_uc;
     h->root_ncc = (uint32_t)idx.root_ncc;
-    h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
-    h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
-    h->idx_sizes[6] = idx.n_uc * (uint64_t)W * 8; h->idx_sizes[7] = idx.n_uc * 4; h->idx_sizes[8] = nk * (uint64_t)W * 8;
     h->build_ms[0] = t1 - t0;
     h->build_ms[1] = t2 - t1;
     h->build_ms[2] = t3 - t2;
@@ -935,7 +949,7 @@ static int ensure_built(bft_gpu* h) {
 template <int W, int BLOCK, bool STAGED>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers; two 1024-thread workgroups per CU
-    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCC) : 0);
+    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
     const uint64_t resident = 256ull * (2048 / BLOCK);  // 256 CUs x workgroups per CU at full occupancy
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
@@ -987,7 +1001,7 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
 
 template <int W, bool STAGED>
 static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
-    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCC) : 0);
+    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
     const uint64_t nblk = (n + 1023) / 1024;
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 512)));
     static std::atomic<uint64_t> attr_devs{0};
@@ -1437,8 +1451,7 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         bft_gpu_free(h);
         return fail(rc, keep);
     }
-    h->info[12] = h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes +
-                  h->d_tcol.bytes + h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes;
+    h->info[12] = image_bytes(h);
     h->built = true;
     *out = h;
     return BFT_GPU_OK;
@@ -1449,14 +1462,17 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     CK(set_device(h));
     CK(ensure_built(h));
-    static const char* names[9] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk"};
-    const DevBuf* bufs[9] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk};
-    for (int i = 0; i < 9; i++)
+    static const char* names[12] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent"};
+    const DevBuf* bufs[12] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
+                              &h->d_ccx, &h->d_f18, &h->d_fent};
+    const uint64_t derived[3] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8};
+    for (int i = 0; i < 12; i++)
         if (std::string(name) == names[i]) {
-            if (nbytes) *nbytes = h->idx_sizes[i];
+            const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
+            if (nbytes) *nbytes = sz;
             if (!out) return BFT_GPU_OK;
-            if (cap_bytes < h->idx_sizes[i]) return fail(BFT_GPU_E_NOSPACE, "buffer too small");
-            if (h->idx_sizes[i]) HIPCK(hipMemcpy(out, bufs[i]->p, h->idx_sizes[i], hipMemcpyDeviceToHost));
+            if (cap_bytes < sz) return fail(BFT_GPU_E_NOSPACE, "buffer too small");
+            if (sz) HIPCK(hipMemcpy(out, bufs[i]->p, sz, hipMemcpyDeviceToHost));
             return BFT_GPU_OK;
         }
     return fail(BFT_GPU_E_ARG, "unknown array");
@@ -1475,6 +1491,14 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         h->im.debug_stop = (uint32_t)value;  // perf probing only: truncates the walk, results are wrong
     } else if (nm == "timing") {
         h->timing = value != 0;
+    } else if (nm == "flat_min") {
+        if (value < 1 || value > 65536) return fail(BFT_GPU_E_ARG, "flat_min must be in [1,65536]");
+        h->opt_flat_min = (uint32_t)value;
+        if (h->built) {  // re-derive the flat arrays of the current image
+            CK(set_device(h));
+            CK(bind_image(h, h->im.nb_genomes));
+            h->info[12] = image_bytes(h);
+        }
     } else
         return fail(BFT_GPU_E_ARG, "unknown option");
     return BFT_GPU_OK;

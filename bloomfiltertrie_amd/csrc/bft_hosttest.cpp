@@ -68,12 +68,14 @@ extern "C" void* bft_hosttest_build(const uint8_t* kmers, uint64_t n, int k, int
     t->cs_off = {0, 1};
     t->cs_ids = {0};
     if (!bft_build_index(t->tk.data(), nk, k, t->hashmod.data(), t->idx)) { delete t; return nullptr; }
+    bft_flatten_index(t->idx, BFT_TRESH_SUF_PREF);
     BftImage& im = t->im;
     memset(&im, 0, sizeof(im));
     im.k = k; im.L = t->L; im.W = W; im.nb_genomes = 1; im.n_kmers = nk;
     im.hashmod = t->hashmod.data();
     im.nodes = t->idx.nodes.data(); im.bfT = t->idx.bfT.data(); im.ccs = t->idx.ccs.data();
     im.f2w = t->idx.f2w.data(); im.clus = t->idx.clus.data(); im.child = t->idx.child.data();
+    im.ccx = t->idx.ccx.data(); im.f18 = t->idx.f18.data(); im.fent = t->idx.fent.data();
     im.tk = t->tk.data(); im.tcol = t->tcol.data(); im.uck = t->idx.uck.data(); im.ucrow = t->idx.ucrow.data();
     im.cs_off = t->cs_off.data(); im.cs_ids = t->cs_ids.data();
     return t;
@@ -129,6 +131,13 @@ extern "C" void bft_hosttest_roundtrip(const uint8_t* kmers, uint64_t n, int k, 
     }
 }
 
+// re-derive the flat form with another threshold (mirrors bft_gpu_set_option "flat_min")
+extern "C" void bft_hosttest_flatten(void* hv, uint32_t flat_min) {
+    HostTrie* t = (HostTrie*)hv;
+    bft_flatten_index(t->idx, flat_min);
+    t->im.ccx = t->idx.ccx.data(); t->im.f18 = t->idx.f18.data(); t->im.fent = t->idx.fent.data();
+}
+
 extern "C" void bft_hosttest_hashmod(int r1, int r2, uint32_t* out) { bft_make_hashmod(r1, r2, out); }
 extern "C" void bft_hosttest_free(void* hv) { delete (HostTrie*)hv; }
 
@@ -143,6 +152,9 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     else if (nm == "ccs") { p = t->idx.ccs.data(); n = t->idx.ccs.size() * sizeof(BftCC); }
     else if (nm == "f2w") { p = t->idx.f2w.data(); n = t->idx.f2w.size() * 8; }
     else if (nm == "clus") { p = t->idx.clus.data(); n = t->idx.clus.size() * 8; }
+    else if (nm == "ccx") { p = t->idx.ccx.data(); n = t->idx.ccx.size() * sizeof(BftCCX); }
+    else if (nm == "f18") { p = t->idx.f18.data(); n = t->idx.f18.size() * 8; }
+    else if (nm == "fent") { p = t->idx.fent.data(); n = t->idx.fent.size() * 8; }
     else if (nm == "child") { p = t->idx.child.data(); n = t->idx.child.size() * 8; }
     else if (nm == "uck") { p = t->idx.uck.data(); n = t->idx.uck.size() * 8; }
     else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }

@@ -23,6 +23,11 @@
 //    indexed by the filter2 rank: a cluster of one prefix (the common case) holds that prefix entry
 //    inline; a longer cluster holds {bit63 | length:16 | start:32} into the CC's run of `child[]`,
 //    where its entries are binary-searched on p_v.
+//  * CCs in s = 4 mode (>= 3584 prefixes: the big CCs every query of a level funnels through) also get a FLAT form,
+//    derived from the arrays above when the image is bound (bft_flatten_gpu): one bit per 18-bit rotated prefix r,
+//    48 bits + 16-bit running rank per u64 (`f18`), and all prefix entries of the CC in r order (`fent`).  filter2 bit
+//    test + rank + cluster select + filter3 search then cost two dependent loads instead of three to five.  The walk reads
+//    CC headers in their 32-byte extended form `ccx` (the 16-byte header + the two flat offsets).
 #pragma once
 #include <stdint.h>
 
@@ -50,6 +55,24 @@ struct BftCC {            // 16 B: one dwordx4 load
     uint8_t pad0;
 };
 
+#define BFT_F18_WORDS 5462u  // ceil(2^18 / 48) u64 words of a flat CC's prefix bitmap
+
+struct BftCCX {           // 32 B: what the walk reads per CC
+    uint32_t f2_off, clus_off, child_off;
+    uint16_t nb_elem;
+    uint8_t s;
+    uint8_t flat;         // 1: f18_off / fent_off are valid and the walk uses them
+    uint32_t f18_off;     // into f18[] (u64 units), BFT_F18_WORDS words
+    uint32_t fent_off;    // into fent[] (u64 units), nb_elem entries in r order
+    uint32_t pad[2];
+};
+
+#if defined(__cplusplus)
+static_assert(sizeof(BftCC) == 16 && sizeof(BftCCX) == 32, "CC headers are 16 / 32 bytes");
+static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0) && __builtin_offsetof(BftCCX, s) == __builtin_offsetof(BftCC, s),
+              "the first half of BftCCX is laid out like BftCC");
+#endif
+
 #define BFT_CHILD_IDX_MASK 0xFFFFFFFFFFULL
 #define BFT_CHILD_CNT_SHIFT 40
 #define BFT_CHILD_PV_SHIFT 48
@@ -73,6 +96,9 @@ struct BftImage {
     const BftNode* nodes;
     const uint8_t* bfT;
     const BftCC* ccs;
+    const BftCCX* ccx;        // [n_ccs] extended headers (derived, see above)
+    const uint64_t* f18;      // flat prefix bitmaps + ranks of the s = 4 CCs
+    const uint64_t* fent;     // flat prefix entries of the s = 4 CCs
     const uint64_t* f2w;
     const uint64_t* clus;
     const uint64_t* child;

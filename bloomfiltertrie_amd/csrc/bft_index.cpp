@@ -229,3 +229,46 @@ bool bft_build_index(const uint64_t* tk, uint64_t n, int k, const uint32_t* hash
     default: return run<4>(tk, n, k, hashmod, out);
     }
 }
+
+void bft_flatten_index(BftHostIndex& io, uint32_t flat_min) {
+    io.ccx.assign(io.ccs.size(), BftCCX());
+    io.f18.clear();
+    io.fent.clear();
+    for (size_t c = 0; c < io.ccs.size(); c++) {
+        const BftCC& cc = io.ccs[c];
+        BftCCX x;
+        memset(&x, 0, sizeof(x));
+        x.f2_off = cc.f2_off; x.clus_off = cc.clus_off; x.child_off = cc.child_off; x.nb_elem = cc.nb_elem; x.s = cc.s;
+        if (cc.nb_elem >= flat_min) {
+            x.flat = 1;
+            x.f18_off = (uint32_t)io.f18.size();
+            x.fent_off = (uint32_t)io.fent.size();
+            io.f18.resize(io.f18.size() + BFT_F18_WORDS, 0);
+            uint64_t* f = &io.f18[x.f18_off];
+            const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+            for (uint32_t w = 0; w < nw; w++) {
+                const uint64_t fw = io.f2w[cc.f2_off + w];
+                uint32_t clu = (uint32_t)(fw >> 48);
+                for (uint32_t b = 0; b < BFT_F2_BITS_PER_WORD; b++) {
+                    if (!((fw >> b) & 1ull)) continue;
+                    const uint32_t pu = w * BFT_F2_BITS_PER_WORD + b;
+                    const uint64_t e = io.clus[cc.clus_off + clu++];
+                    const uint32_t len = (e & BFT_CLUS_MULTI) ? (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+                    for (uint32_t j = 0; j < len; j++) {
+                        const uint64_t ent = (e & BFT_CLUS_MULTI) ? io.child[cc.child_off + (uint32_t)e + j] : e;
+                        const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
+                        io.fent.push_back(ent);
+                        f[r / BFT_F2_BITS_PER_WORD] |= 1ull << (r % BFT_F2_BITS_PER_WORD);
+                    }
+                }
+            }
+            uint32_t rank = 0;
+            for (uint32_t w = 0; w < BFT_F18_WORDS; w++) {
+                const uint32_t pc = (uint32_t)__builtin_popcountll(f[w]);
+                f[w] |= (uint64_t)rank << 48;
+                rank += pc;
+            }
+        }
+        io.ccx[c] = x;
+    }
+}

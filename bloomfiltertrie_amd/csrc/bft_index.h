@@ -25,6 +25,9 @@ struct BftHostIndex {
     std::vector<uint64_t> child;
     std::vector<uint64_t> uck;
     std::vector<uint32_t> ucrow;
+    // derived by bft_flatten_index: extended CC headers and the flat form of the CCs with >= flat_min prefixes
+    std::vector<BftCCX> ccx;
+    std::vector<uint64_t> f18, fent;
     std::string error;
     // shape counters (printMemory.c-style)
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0;
@@ -32,6 +35,9 @@ struct BftHostIndex {
 
 // tk: n sorted distinct T-form k-mers (W = ceil(2k/64) words each, word 0 most significant).
 bool bft_build_index(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, BftHostIndex& out);
+
+// Flat form (bft_image.h) of the CCs holding at least flat_min prefixes, from ccs / f2w / clus / child.
+void bft_flatten_index(BftHostIndex& io, uint32_t flat_min);
 
 static inline int bft_words_for_k(int k) { return (2 * k + 63) / 64; }
 static inline int bft_bytes_for_k(int k) { return (2 * k + 7) / 8; }

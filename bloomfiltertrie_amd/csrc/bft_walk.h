@@ -263,7 +263,7 @@ struct BftRootGlobal {
     BFT_HD int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
         return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
     }
-    BFT_HD BftCC root_cc(const BftNode& nd, int c) const { return im.ccs[nd.cc_first + c]; }
+    BFT_HD BftCCX root_cc(const BftNode& nd, int c) const { return im.ccx[nd.cc_first + c]; }
 };
 
 struct BftHit {
@@ -304,32 +304,49 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
             }
             return hit;
         }
-        BftCC cc;
+        BftCCX cc;
         if (d == 0) cc = root.root_cc(nd, c);
-        else cc = im.ccs[nd.cc_first + c];
-        const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
-        const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
-        const uint64_t fw = im.f2w[cc.f2_off + wi];
-        if (im.debug_stop == 2) { hit.present = (int)(fw & 1); return hit; }
-        if (!((fw >> bi) & 1ull)) return hit;  // filter2 miss => absent (src/presenceNode.c:1546-1548)
-        const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
-        uint64_t e = BFT_GATHER(&im.clus[cc.clus_off + clu]);
-        if (im.debug_stop == 3) { hit.present = (int)(e & 1); return hit; }
-        if (e & BFT_CLUS_MULTI) {
-            // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
-            const uint64_t* ch = im.child + cc.child_off;
-            uint32_t lo = (uint32_t)e, hi = lo + (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
-            const uint32_t end = hi;
-            e = 0;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const uint64_t m = BFT_GATHER(&ch[mid]);
-                if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
-                else { hi = mid; e = m; }
-            }
-            if (lo >= end) return hit;
+        else {
+            // one 16-byte load (the first half is laid out like BftCC, `flat` in place of pad0); the flat offsets only when needed
+            const BftCCX* px = &im.ccx[nd.cc_first + c];
+            const BftCC hd = *(const BftCC*)px;
+            cc.f2_off = hd.f2_off; cc.clus_off = hd.clus_off; cc.child_off = hd.child_off; cc.nb_elem = hd.nb_elem; cc.s = hd.s; cc.flat = hd.pad0;
+            cc.f18_off = 0; cc.fent_off = 0;
+            if (cc.flat) { cc.f18_off = px->f18_off; cc.fent_off = px->fent_off; }
         }
-        if (((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return hit;
+        uint64_t e;
+        if (cc.flat) {
+            // flat CC: bit r of the prefix bitmap (= filter2 bit of p_u and p_v in that cluster's filter3 run), rank = entry
+            const uint32_t wi = r / BFT_F2_BITS_PER_WORD, bi = r % BFT_F2_BITS_PER_WORD;
+            const uint64_t fw = BFT_GATHER(&im.f18[cc.f18_off + wi]);
+            if (im.debug_stop == 2 || im.debug_stop == 3) { hit.present = (int)(fw & 1); return hit; }
+            if (!((fw >> bi) & 1ull)) return hit;
+            e = BFT_GATHER(&im.fent[cc.fent_off + (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull))]);
+        } else {
+            const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
+            const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
+            const uint64_t fw = im.f2w[cc.f2_off + wi];
+            if (im.debug_stop == 2) { hit.present = (int)(fw & 1); return hit; }
+            if (!((fw >> bi) & 1ull)) return hit;  // filter2 miss => absent (src/presenceNode.c:1546-1548)
+            const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
+            e = BFT_GATHER(&im.clus[cc.clus_off + clu]);
+            if (im.debug_stop == 3) { hit.present = (int)(e & 1); return hit; }
+            if (e & BFT_CLUS_MULTI) {
+                // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
+                const uint64_t* ch = im.child + cc.child_off;
+                uint32_t lo = (uint32_t)e, hi = lo + (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
+                const uint32_t end = hi;
+                e = 0;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t m = BFT_GATHER(&ch[mid]);
+                    if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
+                    else { hi = mid; e = m; }
+                }
+                if (lo >= end) return hit;
+            }
+            if (((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return hit;
+        }
         uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
         uint64_t idx = e & BFT_CHILD_IDX_MASK;
         if (im.debug_stop == 4) { hit.present = (int)(cnt & 1); return hit; }

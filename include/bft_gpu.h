@@ -128,11 +128,12 @@ int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_km
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512 or 1024), "query_grid_mult"
- * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels). */
+ * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels), "flat_min" (CCs with at
+ * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
 /* Test hook: raw device->host copy of one array of the image ("nodes", "bfT", "ccs", "f2w", "clus",
- * "child", "uck", "ucrow", "tk"); out may be NULL to query the size. */
+ * "child", "uck", "ucrow", "tk", and the derived "ccx", "f18", "fent"); out may be NULL to query the size. */
 int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes);
 
 /* HIP-event timing of the query kernels launched through this handle since the last reset:

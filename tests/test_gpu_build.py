@@ -11,7 +11,7 @@ from bloomfiltertrie_amd import BFT, _lib, synth as S
 
 pytestmark = pytest.mark.gpu
 
-ARRAYS = ["tk", "nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow"]
+ARRAYS = ["tk", "nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "ccx", "f18", "fent"]
 
 
 @pytest.fixture(scope="module")
@@ -158,3 +158,38 @@ def test_replicate_image_single_rank_rccl():
         assert b is not a and (a.query_presence(q) == b.query_presence(q)).all() and a.info() == b.info()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flat_min", [1, 255, 3584, 65536])
+def test_flat_form_matches_host_restatement(hostlib, flat_min):
+    """The derived arrays (extended CC headers, flat prefix bitmaps + ranks, flat entries) for any threshold are
+    bit-identical to bft_flatten_index on the host, and the answers do not depend on the threshold."""
+    k = 27
+    km = np.concatenate([S.low_entropy_kmers(60000, k, 6, seed=3, levels=2), _rk(200000, k, 9)])
+    km = S.distinct(km)
+    t = BFT(k)
+    t.insert_kmers(km, 0)
+    t.build()
+    q = np.concatenate([km[::7], S.snp_mutants(km[::11], k, 5), _rk(5000, k, 10)])
+    ref_bits = t.query_presence(q)
+    t.set_option("flat_min", flat_min)
+    assert (t.query_presence(q) == ref_bits).all()
+    hostlib.bft_hosttest_flatten.argtypes = [C.c_void_p, C.c_uint32]
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    assert h
+    try:
+        hostlib.bft_hosttest_flatten(h, flat_min)
+        for name in ("ccx", "f18", "fent"):
+            n = C.c_uint64()
+            assert hostlib.bft_hosttest_get_array(h, name.encode(), None, 0, C.byref(n)) == 0
+            host = np.zeros(n.value, np.uint8)
+            assert hostlib.bft_hosttest_get_array(h, name.encode(), host.ctypes.data, n.value, C.byref(n)) == 0
+            dev = t.debug_array(name)
+            assert dev.shape == host.shape, (name, dev.shape, host.shape)
+            assert (dev == host).all(), name
+            if flat_min == 1 and name != "ccx":
+                assert n.value > 0
+            if flat_min == 65536 and name != "ccx":
+                assert n.value == 0
+    finally:
+        hostlib.bft_hosttest_free(h)

@@ -26,6 +26,7 @@ def test_fuzz(oracle_mod, seed):
     else:
         base = np.zeros((0, S.kmer_bytes(k)), np.uint8)
     t, o = BFT(k), oracle_mod.OracleBFT(k)
+    t.set_option("flat_min", int(rng.choice([3584, 3584, 65536, 300, 1])))  # flat form of the CCs: default rule, off, small CCs too
     for g in range(ngen):
         km = base[rng.random(len(base)) < rng.uniform(0.2, 1.0)] if len(base) else base
         for part in np.array_split(km, int(rng.integers(1, 4))):
@@ -45,6 +46,8 @@ def test_fuzz(oracle_mod, seed):
     bb, bc = t.query_branching(q, with_counts=True)
     ob, oc, _ = o.query_branching(q)
     assert (bc == oc).all() and (bb == ob).all()
+    t.set_option("flat_min", int(rng.choice([1, 100, 3584, 65536])))  # re-derive the flat arrays of the built image
+    assert (t.query_presence(q) == obits).all()
     ek, _ = t.extract()
     ok, _ = o.extract()
     assert sorted(map(bytes, ek)) == sorted(map(bytes, ok))
