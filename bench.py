@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU baseline (0 = auto)")
     ap.add_argument("--verify", type=int, default=1_000_000, help="queries of the batch checked against ground truth")
     ap.add_argument("--no-k31", action="store_true", help="skip the secondary k=31 measurement (extension beyond the reference)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bitmap all_gather even with one rank (path check)")
     ap.add_argument("--replicate", choices=["rebuild", "broadcast"], default="rebuild",
                     help="how every rank gets the trie: each rank builds it (default, no collective outside the bitmap gather) "
@@ -202,7 +203,7 @@ def main():
     }
 
     # ---- secondary: the host-buffer entry point (H2D + kernel + D2H through bft_gpu_query_presence); never `value` ----
-    if world == 1:
+    if world == 1 and not args.no_pcie:
         nh = min(nq, 20_000_000)
         hq = np.ascontiguousarray(dq[:nh].cpu().numpy())
         bft.query_presence(hq[:1000])

@@ -69,11 +69,12 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("BFT_GPU_LIB", LIB_PATH)  # tuning experiments only: another build of the same sources
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
+            f"{path} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
             "bloomfiltertrie_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 --pmc passes for k_query on the config-2 workload (one counter set per pass, kernel trace only),
+# then tools/pmc_parse.py -> gpurun_out/pmc/pmc_traffic.json.  Run on the GPU box from the repo root:
+#   bash tools/pmc_collect.sh [workload] [queries] [reps]
+set -u
+WL=${1:-cfg2}; NQ=${2:-100000000}; REPS=${3:-3}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/pmc
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+# FETCH_SIZE and WRITE_SIZE do not fit one pass ("exceeds the capabilities of the hardware", and rocprofv3 then hangs):
+# one derived counter per pass, every pass under its own timeout.
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/tools/pmc_workload.py" "$WL" "$NQ" "$REPS" > "$OUT/pass$i.log" 2>&1
+done
+cd "$ROOT" && python3 tools/pmc_parse.py "$OUT" "$WL" "$NQ" "$REPS" > "$OUT/pmc_traffic.json"
+cat "$OUT/pmc_traffic.json"
