@@ -111,6 +111,10 @@ def main():
     t_build0 = time.time()
     gk = build_genome_kmers(args)
     t_gen = time.time() - t_build0
+    with BFT(args.k, device=local_rank) as warm:  # loads the code objects and the hipCUB kernels once (not part of any figure)
+        warm.insert_kmers(gk[0][:100000], 0)
+        warm.build()
+        warm.query_presence(gk[0][:1000])
     t0 = time.time()
     bft = None
     if rank == 0 or not (use_dist and args.replicate == "broadcast"):

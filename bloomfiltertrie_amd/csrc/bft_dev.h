@@ -20,23 +20,34 @@ int bft_fail(int code, const std::string& msg);  // records the thread's last er
         if (rc_ != 0) return rc_; \
     } while (0)
 
+// Device-memory cache behind DevBuf (bft_gpu.hip).  hipFree synchronises the device and costs ~0.1 ms per call on
+// large blocks; a bulk build releases dozens of temporaries.  Released blocks are kept (per device, tagged with the
+// stream of the ABI call that released them) and handed out again to requests of a similar size.  A block released
+// under another stream is only reused after that stream has drained; bft_gpu_free drops the blocks of its handle.
+int bft_pool_alloc(void** p, size_t n, size_t* cap);
+void bft_pool_release(void* p, size_t cap);
+void bft_pool_set_stream(int device, hipStream_t s);  // the stream of the current ABI call (thread-local)
+void bft_pool_drop_stream(hipStream_t s);             // the stream is about to be destroyed: free what it tagged
+
 struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;  // requested size
+    size_t cap = 0;    // size of the block behind it
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) bft_pool_release(p, cap);
         p = nullptr;
         bytes = 0;
+        cap = 0;
     }
     int alloc(size_t n) {
         release();
         if (n == 0) n = 8;
-        HIPCK(hipMalloc(&p, n));
+        CK(bft_pool_alloc(&p, n, &cap));
         bytes = n;
         return 0;
     }
@@ -50,6 +61,7 @@ struct DevBuf {
     void swap(DevBuf& o) {
         std::swap(p, o.p);
         std::swap(bytes, o.bytes);
+        std::swap(cap, o.cap);
     }
 };
 

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -438,6 +439,118 @@ __global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// device-memory cache (see bft_dev.h)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct PoolBlock {
+    void* p;
+    size_t cap;
+    int device;
+    hipStream_t stream;
+};
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MAX_BYTES = 24ull << 30;  // cached, unused memory kept at most (per process)
+constexpr size_t POOL_MAX_BLOCKS = 256;
+thread_local int t_pool_device = -1;
+thread_local hipStream_t t_pool_stream = nullptr;
+
+void pool_free_block(const PoolBlock& b) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != b.device) (void)hipSetDevice(b.device);
+    (void)hipFree(b.p);
+    if (cur != b.device && cur >= 0) (void)hipSetDevice(cur);
+}
+}  // namespace
+
+void bft_pool_set_stream(int device, hipStream_t s) {
+    t_pool_device = device;
+    t_pool_stream = s;
+}
+
+int bft_pool_alloc(void** p, size_t n, size_t* cap) {
+    *p = nullptr;
+    PoolBlock take{nullptr, 0, 0, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            const PoolBlock& b = g_pool[i];
+            if (b.device != t_pool_device || b.cap < n || b.cap > n + n / 2 + 4096) continue;  // similar size only
+            if (best == (size_t)-1 || b.cap < g_pool[best].cap) best = i;
+        }
+        if (best != (size_t)-1) {
+            take = g_pool[best];
+            g_pool[best] = g_pool.back();
+            g_pool.pop_back();
+            g_pool_bytes -= take.cap;
+        }
+    }
+    if (take.p) {
+        // released under another stream: its work must have drained before the block is written again
+        if (take.stream != t_pool_stream && hipStreamSynchronize(take.stream) != hipSuccess) {
+            pool_free_block(take);
+            take.p = nullptr;
+        }
+    }
+    if (take.p) {
+        *p = take.p;
+        *cap = take.cap;
+        return 0;
+    }
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess) {
+        // out of memory with blocks parked in the cache: give them back and retry once
+        std::vector<PoolBlock> all;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            all.swap(g_pool);
+            g_pool_bytes = 0;
+        }
+        for (const PoolBlock& b : all) pool_free_block(b);
+        (void)hipGetLastError();
+        e = hipMalloc(p, n);
+    }
+    if (e != hipSuccess) return bft_fail(BFT_GPU_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *cap = n;
+    return 0;
+}
+
+void bft_pool_release(void* p, size_t cap) {
+    if (!p) return;
+    PoolBlock b{p, cap, t_pool_device, t_pool_stream};
+    bool keep = t_pool_device >= 0 && cap >= (64u << 10);  // small blocks are cheap to free
+    if (keep) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < POOL_MAX_BLOCKS && g_pool_bytes + cap <= POOL_MAX_BYTES) {
+            g_pool.push_back(b);
+            g_pool_bytes += cap;
+        } else
+            keep = false;
+    }
+    if (!keep) (void)hipFree(p);
+}
+
+void bft_pool_drop_stream(hipStream_t s) {
+    std::vector<PoolBlock> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();) {
+            if (g_pool[i].stream == s) {
+                mine.push_back(g_pool[i]);
+                g_pool_bytes -= g_pool[i].cap;
+                g_pool[i] = g_pool.back();
+                g_pool.pop_back();
+            } else
+                i++;
+        }
+    }
+    for (const PoolBlock& b : mine) pool_free_block(b);
+}
+
+// ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
 struct bft_gpu {
@@ -489,6 +602,7 @@ static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
 
 static int set_device(bft_gpu* h) {
     HIPCK(hipSetDevice(h->device));
+    bft_pool_set_stream(h->device, h->stream);
     return 0;
 }
 
@@ -524,11 +638,12 @@ extern "C" int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu*
         delete h;
         return fail(BFT_GPU_E_HIP, "hipSetDevice/hipStreamCreate failed");
     }
+    bft_pool_set_stream(device, h->stream);
     h->hashmod.resize(16384);
     bft_make_hashmod(h->r1, h->r2, h->hashmod.data());
     if (h->d_hashmod.alloc(16384 * 4) != 0 ||
         hipMemcpy(h->d_hashmod.p, h->hashmod.data(), 16384 * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        delete h;
+        bft_gpu_free(h);
         return fail(BFT_GPU_E_HIP, "hash table upload failed");
     }
     memset(&h->im, 0, sizeof(h->im));
@@ -554,9 +669,14 @@ static void drain_events(bft_gpu* h) {
 extern "C" void bft_gpu_free(bft_gpu* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    bft_pool_set_stream(h->device, h->stream);
     drain_events(h);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
+    const hipStream_t s = h->stream;
+    if (s) (void)hipStreamSynchronize(s);
+    delete h;                      // its buffers go to the cache under this stream's tag ...
+    bft_pool_drop_stream(s);       // ... and are given back to the runtime here
+    bft_pool_set_stream(-1, nullptr);
+    if (s) (void)hipStreamDestroy(s);
 }
 
 extern "C" int bft_gpu_genome_name(bft_gpu* h, uint32_t id_genome, char* out, uint32_t cap) {
