@@ -521,7 +521,7 @@ int bft_pool_alloc(void** p, size_t n, size_t* cap) {
 void bft_pool_release(void* p, size_t cap) {
     if (!p) return;
     PoolBlock b{p, cap, t_pool_device, t_pool_stream};
-    bool keep = t_pool_device >= 0 && cap >= (64u << 10);  // small blocks are cheap to free
+    bool keep = t_pool_device >= 0;
     if (keep) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (g_pool.size() < POOL_MAX_BLOCKS && g_pool_bytes + cap <= POOL_MAX_BYTES) {
