@@ -125,8 +125,8 @@ struct BftRootLds {
 #define BFT_LDS_ROOT_MAX_CC 64u
 
 template <int W, int BLOCK, bool STAGED>
-__global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                 uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+__device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t* l_hm = (uint32_t*)lds;
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
@@ -167,6 +167,21 @@ __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __r
         if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
         if (rows && i < n) rows[i] = row;
     }
+}
+
+// Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in
+// SGPRs), which caps a SIMD at 7 waves, i.e. ONE 1024-thread workgroup per CU -- the fastest arrangement for a one-level
+// index (4 waves per SIMD keep the beyond-L2 gather path full, more only thrash it).  k_query8: held to 8 waves per SIMD
+// (78 SGPRs) so that two workgroups share a CU -- +10..40 % on deep tries and on L2-resident ones.
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                 uint32_t* __restrict__ rows) {
+    query_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, rows);
+}
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                                                             uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+    query_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, rows);
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
@@ -594,7 +609,10 @@ struct bft_gpu {
     bool timing = true;
     uint32_t root_ncc = 0;
     uint64_t idx_sizes[9] = {0};
-    int opt_block = 1024;     // k_query workgroup size (256 / 512 / 1024)
+    int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
+    int opt_wgs_per_cu = 0;   // resident k_query workgroups per CU: 1, 2, or 0 = measured when the image is bound (tune_residency)
+    int tuned_wgs = 0;        // result of that measurement (0 = none yet)
+    double tune_ms[2] = {0, 0};
     int opt_grid_mult = 1;    // grid = resident workgroups x this
 };
 
@@ -856,6 +874,8 @@ static uint64_t image_bytes(const bft_gpu* h) {
            h->d_f18.bytes + h->d_fent.bytes;
 }
 
+static int tune_residency(bft_gpu* h);
+
 // Points h->im at the device arrays of the handle and derives the bitmap form of the colour-set dictionary.
 static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     BftImage& im = h->im;
@@ -895,7 +915,8 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
             h->has_cs_bm = true;
         }
     }
-
+    h->tuned_wgs = 0;
+    if (h->opt_wgs_per_cu == 0) CK(tune_residency(h));
     return 0;
 }
 
@@ -1026,6 +1047,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
     h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
     h->idx_sizes[6] = idx.n_uc * (uint64_t)W * 8; h->idx_sizes[7] = idx.n_uc * 4; h->idx_sizes[8] = nk * (uint64_t)W * 8;
+    h->root_ncc = (uint32_t)idx.root_ncc;
     double t4 = now_ms();
 
     CK(bind_image(h, std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0)));
@@ -1066,20 +1088,33 @@ static int ensure_built(bft_gpu* h) {
 // ------------------------------------------------------------------------------------------------
 // queries
 // ------------------------------------------------------------------------------------------------
+// Resident k_query workgroups per CU.  Measured on MI355X (tools/perf_probe.py): a one-level index whose suffix-group
+// table exceeds the L2 runs at the beyond-L2 gather rate with 4 waves per SIMD and loses 10 % with 8; deep walks and
+// L2-resident indexes gain 10-40 % from 8; which side an index falls on is measured, not guessed (tune_residency).
+static int query_residency(const bft_gpu* h) {
+    if (h->opt_wgs_per_cu) return h->opt_wgs_per_cu;
+    return h->tuned_wgs ? h->tuned_wgs : 2;
+}
+
 template <int W, int BLOCK, bool STAGED>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
-    // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers; two 1024-thread workgroups per CU
-    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
+    // one workgroup per CU the request is padded past half the LDS so that the dispatcher cannot pair two on a CU.
+    const int wgs = query_residency(h);
+    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
-    const uint64_t resident = 256ull * (2048 / BLOCK);  // 256 CUs x workgroups per CU at full occupancy
+    const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
     static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_query<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1089,10 +1124,12 @@ static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     if (staged) {
         if (h->opt_block == 1024) return launch_query_k<W, 1024, true>(h, d_kmers, n, d_bits64, d_rows, s);
+        if (h->opt_block == 768) return launch_query_k<W, 768, true>(h, d_kmers, n, d_bits64, d_rows, s);
         if (h->opt_block == 512) return launch_query_k<W, 512, true>(h, d_kmers, n, d_bits64, d_rows, s);
         return launch_query_k<W, 256, true>(h, d_kmers, n, d_bits64, d_rows, s);
     }
     if (h->opt_block == 1024) return launch_query_k<W, 1024, false>(h, d_kmers, n, d_bits64, d_rows, s);
+    if (h->opt_block == 768) return launch_query_k<W, 768, false>(h, d_kmers, n, d_bits64, d_rows, s);
     if (h->opt_block == 512) return launch_query_k<W, 512, false>(h, d_kmers, n, d_bits64, d_rows, s);
     return launch_query_k<W, 256, false>(h, d_kmers, n, d_bits64, d_rows, s);
 }
@@ -1116,6 +1153,82 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         h->pending_ev.push_back({e0, e1});
         if (h->pending_ev.size() > 8192) drain_events(h);
     }
+    return 0;
+}
+
+// Synthetic batch for tune_residency: k-mers of the index itself (pseudo-random rows of tk), every other one with a
+// single-nucleotide change -- the mix of present k-mers and near misses that exercises the whole walk.
+template <int W>
+__global__ void k_tune_queries(const uint64_t* __restrict__ tk, uint64_t n_kmers, int k, int B, uint64_t m, uint8_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 31; z *= 0x94D049BB133111EBull; z ^= z >> 29;
+        const uint64_t row = z % n_kmers;
+        uint64_t t[W], x[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) t[w] = tk[row * W + w];
+        bft_x_from_tform<W>(t, k, x);
+        if (i & 1) {
+            const int pos = (int)((z >> 33) % (uint64_t)k);
+            const uint64_t flip = 1 + ((z >> 20) % 3);
+#pragma unroll
+            for (int w = 0; w < W; w++)
+                if (w == (2 * pos) >> 6) x[w] ^= flip << ((2 * pos) & 63);
+        }
+        for (int b = 0; b < B; b++) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++)
+                if (w == (b >> 3)) v = x[w];
+            out[i * B + b] = (uint8_t)(v >> (8 * (b & 7)));
+        }
+    }
+}
+
+// One or two resident workgroups per CU for k_query on THIS image: time both on a batch drawn from the index.
+static int tune_residency(bft_gpu* h) {
+    if (h->n_kmers < (1u << 16)) { h->tuned_wgs = 2; return 0; }  // small (L2-resident) indexes: always two
+    const uint64_t m = 1ull << 22;
+    DevBuf q, bits;
+    CK(q.alloc(m * h->B));
+    CK(bits.alloc(((m + 63) / 64) * 8));
+    const dim3 grid(grid_for((m + 255) / 256)), block(256);
+    switch (h->W) {
+    case 1: hipLaunchKernelGGL(k_tune_queries<1>, grid, block, 0, h->stream, h->im.tk, h->n_kmers, h->k, h->B, m, q.as<uint8_t>()); break;
+    case 2: hipLaunchKernelGGL(k_tune_queries<2>, grid, block, 0, h->stream, h->im.tk, h->n_kmers, h->k, h->B, m, q.as<uint8_t>()); break;
+    case 3: hipLaunchKernelGGL(k_tune_queries<3>, grid, block, 0, h->stream, h->im.tk, h->n_kmers, h->k, h->B, m, q.as<uint8_t>()); break;
+    default: hipLaunchKernelGGL(k_tune_queries<4>, grid, block, 0, h->stream, h->im.tk, h->n_kmers, h->k, h->B, m, q.as<uint8_t>()); break;
+    }
+    HIPCK(hipGetLastError());
+    const bool timing = h->timing;
+    const uint32_t dbg = h->im.debug_stop;
+    h->timing = false;
+    h->im.debug_stop = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
+    float best[2] = {0, 0};
+    for (int cfg = 1; cfg <= 2 && rc == 0; cfg++) {
+        h->tuned_wgs = cfg;
+        best[cfg - 1] = 1e30f;
+        for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches
+            if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
+            if (rc == 0) rc = launch_query(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
+            if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
+            float ms = 0;
+            if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
+            if (rep > 0 && ms < best[cfg - 1]) best[cfg - 1] = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    h->timing = timing;
+    h->im.debug_stop = dbg;
+    h->tuned_wgs = 0;
+    CK(rc);
+    h->tune_ms[0] = best[0];
+    h->tune_ms[1] = best[1];
+    h->tuned_wgs = best[0] < best[1] ? 1 : 2;
     return 0;
 }
 
@@ -1602,8 +1715,11 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     const std::string nm(name);
     if (nm == "query_block") {
-        if (value != 256 && value != 512 && value != 1024) return fail(BFT_GPU_E_ARG, "query_block must be 256, 512 or 1024");
+        if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(BFT_GPU_E_ARG, "query_block must be 256, 512, 768 or 1024");
         h->opt_block = (int)value;
+    } else if (nm == "query_wgs_per_cu") {
+        if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1 or 2");
+        h->opt_wgs_per_cu = (int)value;
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;
@@ -1647,7 +1763,8 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    for (int i = 0; i < n_out && i < 5; i++) ms[i] = h->build_ms[i];
+    const double v[8] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1]};
+    for (int i = 0; i < n_out && i < 8; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

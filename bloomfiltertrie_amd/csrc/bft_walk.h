@@ -163,6 +163,25 @@ BFT_HD int bft_cmp(const uint64_t* a, const uint64_t* b) {
     return 0;
 }
 
+// One table row (W words).  Rows of 2 or 4 words start on 16-byte boundaries (the tables are 256-byte aligned), so the
+// device reads them with 16-byte loads: a divergent load costs per lane and per instruction, not per byte.
+template <int W>
+BFT_HD void bft_load_row(const uint64_t* p, uint64_t* r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (W == 2 || W == 4) {
+#pragma unroll
+        for (int w = 0; w < W; w += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + w);
+            r[w] = v.x;
+            r[w + 1] = v.y;
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&p[w]);
+}
+
 // lower bound of t among n sorted rows; returns index in [0, n]
 template <int W>
 BFT_HD uint32_t bft_rows_lower_bound(const uint64_t* rows, uint32_t n, const uint64_t* t) {
@@ -170,8 +189,7 @@ BFT_HD uint32_t bft_rows_lower_bound(const uint64_t* rows, uint32_t n, const uin
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
         uint64_t r[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)mid * W + w]);
+        bft_load_row<W>(rows + (size_t)mid * W, r);
         if (bft_cmp<W>(r, t) < 0) lo = mid + 1;
         else hi = mid;
     }
@@ -188,8 +206,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
     uint64_t r[W];
     if (g >= n) g = n - 1;
     uint32_t lo = 0, hi = n;
-#pragma unroll
-    for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)g * W + w]);
+    bft_load_row<W>(rows + (size_t)g * W, r);
     int c = bft_cmp<W>(r, t);
     if (c == 0) return (int)g;
     uint32_t step = 1;
@@ -198,8 +215,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
         while (lo < hi) {
             uint32_t p = lo + step - 1;
             if (p >= hi) p = hi - 1;
-#pragma unroll
-            for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)p * W + w]);
+            bft_load_row<W>(rows + (size_t)p * W, r);
             c = bft_cmp<W>(r, t);
             if (c == 0) return (int)p;
             if (c < 0) { lo = p + 1; step <<= 1; }
@@ -209,8 +225,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
         hi = g;
         while (lo < hi) {
             uint32_t p = hi - lo > step ? hi - step : lo;
-#pragma unroll
-            for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)p * W + w]);
+            bft_load_row<W>(rows + (size_t)p * W, r);
             c = bft_cmp<W>(r, t);
             if (c == 0) return (int)p;
             if (c > 0) { hi = p; step <<= 1; }
@@ -219,8 +234,7 @@ BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, ui
     }
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-#pragma unroll
-        for (int w = 0; w < W; w++) r[w] = BFT_GATHER(&rows[(size_t)mid * W + w]);
+        bft_load_row<W>(rows + (size_t)mid * W, r);
         c = bft_cmp<W>(r, t);
         if (c == 0) return (int)mid;
         if (c < 0) lo = mid + 1;
@@ -271,6 +285,60 @@ struct BftHit {
     uint64_t row;  // row of the k-mer in tk (valid when present)
 };
 
+// The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
+template <int W>
+BFT_HD void bft_uc_search(const BftImage& im, const BftNode& nd, const uint64_t* t, BftHit& hit) {
+    if (!nd.uc_n) return;
+    const uint64_t* rows = im.uck + (size_t)nd.uc_first * W;
+    const uint32_t z = bft_rows_lower_bound<W>(rows, nd.uc_n, t);
+    if (z < nd.uc_n) {
+        uint64_t q[W];
+        bft_load_row<W>(rows + (size_t)z * W, q);
+        if (bft_cmp<W>(q, t) == 0) { hit.present = 1; hit.row = im.ucrow[nd.uc_first + z]; }
+    }
+}
+
+// Prefix r inside one CC: filter2 bit -> rank -> cluster -> filter3 search (src/presenceNode.c:1381-1489, findCluster
+// :1578-1821), or the two loads of the flat form.  Returns false when the CC does not hold r; else *e = its prefix entry.
+// `stop` (perf probing only) != 0 ends the walk early with a dummy result in *e.
+BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint64_t* e, bool* stop) {
+    *stop = false;
+    if (cc.flat) {
+        // bit r of the prefix bitmap (= filter2 bit of p_u and p_v in that cluster's filter3 run); its rank = the entry
+        const uint32_t wi = r / BFT_F2_BITS_PER_WORD, bi = r % BFT_F2_BITS_PER_WORD;
+        const uint64_t fw = BFT_GATHER(&im.f18[cc.f18_off + wi]);
+        if (im.debug_stop == 2 || im.debug_stop == 3) { *e = fw; *stop = true; return true; }
+        if (!((fw >> bi) & 1ull)) return false;
+        *e = BFT_GATHER(&im.fent[cc.fent_off + (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull))]);
+        return true;
+    }
+    const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
+    const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
+    const uint64_t fw = im.f2w[cc.f2_off + wi];
+    if (im.debug_stop == 2) { *e = fw; *stop = true; return true; }
+    if (!((fw >> bi) & 1ull)) return false;  // filter2 miss (src/presenceNode.c:1546-1548)
+    const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
+    uint64_t v = BFT_GATHER(&im.clus[cc.clus_off + clu]);
+    if (im.debug_stop == 3) { *e = v; *stop = true; return true; }
+    if (v & BFT_CLUS_MULTI) {
+        // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
+        const uint64_t* ch = im.child + cc.child_off;
+        uint32_t lo = (uint32_t)v, hi = lo + (uint32_t)((v >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
+        const uint32_t end = hi;
+        v = 0;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t m = BFT_GATHER(&ch[mid]);
+            if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
+            else { hi = mid; v = m; }
+        }
+        if (lo >= end) return false;
+    }
+    if (((uint32_t)(v >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return false;
+    *e = v;
+    return true;
+}
+
 template <int W, class Root>
 BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t) {
     BftHit hit;
@@ -283,70 +351,38 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
         if (d == 0) nd = root_node;
         else nd = im.nodes[node];
         const uint32_t r = bft_digit<W>(t, im.k, d);
-        int c = -1;
-        if (nd.ncc) {
+        // Which CC: the first one whose Bloom filter holds the key (src/presenceNode.c:1353-1362).  A node with ONE CC needs
+        // no filter below the root: every prefix of a CC is Bloom-positive in it and every UC row is Bloom-negative
+        // (SURVEY A.7/A.8), so "CC first, then the UC" gives what "Bloom, then CC or UC" gives, two gathers earlier.
+        const bool single = d > 0 && nd.ncc == 1;
+        int c = single ? 0 : -1;
+        if (nd.ncc && !single) {
             const uint32_t hm = root.hashmod(r >> 4);  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
             if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
             else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
         }
         if (im.debug_stop == 1) { hit.present = c >= 0; return hit; }
-        if (c < 0) {
-            // no Bloom-positive CC: the node's UC (src/presenceNode.c:1554-1573)
-            if (nd.uc_n) {
-                const uint64_t* rows = im.uck + (size_t)nd.uc_first * W;
-                uint32_t z = bft_rows_lower_bound<W>(rows, nd.uc_n, t);
-                if (z < nd.uc_n) {
-                    uint64_t q[W];
-#pragma unroll
-                    for (int w = 0; w < W; w++) q[w] = rows[(size_t)z * W + w];
-                    if (bft_cmp<W>(q, t) == 0) { hit.present = 1; hit.row = im.ucrow[nd.uc_first + z]; }
-                }
+        uint64_t e = 0;
+        bool stop = false, found = false;
+        if (c >= 0) {
+            BftCCX cc;
+            if (d == 0) cc = root.root_cc(nd, c);
+            else {
+                // one 16-byte load (the first half is laid out like BftCC, `flat` in place of pad0); the flat offsets only when needed
+                const BftCCX* px = &im.ccx[nd.cc_first + c];
+                const BftCC hd = *(const BftCC*)px;
+                cc.f2_off = hd.f2_off; cc.clus_off = hd.clus_off; cc.child_off = hd.child_off; cc.nb_elem = hd.nb_elem; cc.s = hd.s; cc.flat = hd.pad0;
+                cc.f18_off = 0; cc.fent_off = 0;
+                if (cc.flat) { cc.f18_off = px->f18_off; cc.fent_off = px->fent_off; }
             }
+            found = bft_cc_lookup(im, cc, r, &e, &stop);
+            if (!found && !single) return hit;  // Bloom-positive CC without the prefix: absent (src/presenceNode.c:1546-1548)
+        }
+        if (!found) {
+            bft_uc_search<W>(im, nd, t, hit);   // no Bloom-positive CC (or a single CC without the prefix): the node's UC
             return hit;
         }
-        BftCCX cc;
-        if (d == 0) cc = root.root_cc(nd, c);
-        else {
-            // one 16-byte load (the first half is laid out like BftCC, `flat` in place of pad0); the flat offsets only when needed
-            const BftCCX* px = &im.ccx[nd.cc_first + c];
-            const BftCC hd = *(const BftCC*)px;
-            cc.f2_off = hd.f2_off; cc.clus_off = hd.clus_off; cc.child_off = hd.child_off; cc.nb_elem = hd.nb_elem; cc.s = hd.s; cc.flat = hd.pad0;
-            cc.f18_off = 0; cc.fent_off = 0;
-            if (cc.flat) { cc.f18_off = px->f18_off; cc.fent_off = px->fent_off; }
-        }
-        uint64_t e;
-        if (cc.flat) {
-            // flat CC: bit r of the prefix bitmap (= filter2 bit of p_u and p_v in that cluster's filter3 run), rank = entry
-            const uint32_t wi = r / BFT_F2_BITS_PER_WORD, bi = r % BFT_F2_BITS_PER_WORD;
-            const uint64_t fw = BFT_GATHER(&im.f18[cc.f18_off + wi]);
-            if (im.debug_stop == 2 || im.debug_stop == 3) { hit.present = (int)(fw & 1); return hit; }
-            if (!((fw >> bi) & 1ull)) return hit;
-            e = BFT_GATHER(&im.fent[cc.fent_off + (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull))]);
-        } else {
-            const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
-            const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
-            const uint64_t fw = im.f2w[cc.f2_off + wi];
-            if (im.debug_stop == 2) { hit.present = (int)(fw & 1); return hit; }
-            if (!((fw >> bi) & 1ull)) return hit;  // filter2 miss => absent (src/presenceNode.c:1546-1548)
-            const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
-            e = BFT_GATHER(&im.clus[cc.clus_off + clu]);
-            if (im.debug_stop == 3) { hit.present = (int)(e & 1); return hit; }
-            if (e & BFT_CLUS_MULTI) {
-                // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
-                const uint64_t* ch = im.child + cc.child_off;
-                uint32_t lo = (uint32_t)e, hi = lo + (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu);
-                const uint32_t end = hi;
-                e = 0;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const uint64_t m = BFT_GATHER(&ch[mid]);
-                    if (((uint32_t)(m >> BFT_CHILD_PV_SHIFT) & 0xFFu) < pv) lo = mid + 1;
-                    else { hi = mid; e = m; }
-                }
-                if (lo >= end) return hit;
-            }
-            if (((uint32_t)(e >> BFT_CHILD_PV_SHIFT) & 0xFFu) != pv) return hit;
-        }
+        if (stop) { hit.present = (int)(e & 1); return hit; }
         uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
         uint64_t idx = e & BFT_CHILD_IDX_MASK;
         if (im.debug_stop == 4) { hit.present = (int)(cnt & 1); return hit; }
