@@ -184,6 +184,10 @@ class BFT:
                                                      counts.ctypes.data if with_counts else None))
         return (bits, counts) if with_counts else bits
 
+    def query_branching_dev(self, d_kmers_ptr, n, d_bits_ptr, d_counts_ptr=None, stream=None):
+        """Device-resident variant of query_branching: asynchronous on `stream`."""
+        _lib.check(self._lib.bft_gpu_query_branching_dev(self._h, d_kmers_ptr, n, d_bits_ptr, d_counts_ptr, stream))
+
     def query_sequences(self, sequences, threshold, canonical=False):
         """query_sequence (include/bft.h:127) for a list of ASCII sequences: list of sorted genome-id lists."""
         enc = [x.encode() if isinstance(x, str) else bytes(x) for x in sequences]

@@ -191,8 +191,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // that share every container down to the last cluster / suffix group (src/presenceNode.c:15-1211 exploits the same).
 // counts[i] = (successors << 4) | predecessors when requested; the bit = successors > 1 || predecessors > 1.
 template <int W, int BLOCK, bool STAGED>
-__global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                     uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
+__device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                               uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t* l_hm = (uint32_t*)lds;
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
@@ -256,6 +256,19 @@ __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t*
         const uint64_t q0 = i & ~63ull;
         if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
     }
+}
+
+// the two register budgets of k_query / k_query8 (see there)
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                     uint8_t* __restrict__ counts) {
+    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
+}
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_branching8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n,
+                                                                                                 int B, uint64_t* __restrict__ bits64,
+                                                                                                 uint8_t* __restrict__ counts) {
+    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
 }
 
 // ---- query_sequence (src/bft.c:1241-1351, harness src/file_io.c:1464-1574): every k-mer of every sequence ----
@@ -1234,16 +1247,20 @@ static int tune_residency(bft_gpu* h) {
 
 template <int W, bool STAGED>
 static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
-    const size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    const int wgs = query_residency(h);  // eight walks per k-mer: the residency measured for k_query applies
+    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
     const uint64_t nblk = (n + 1023) / 1024;
-    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 512)));
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * (uint64_t)wgs)));
     static std::atomic<uint64_t> attr_devs{0};
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_branching8<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_branching<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    if (wgs == 1) hipLaunchKernelGGL((k_branching<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    else hipLaunchKernelGGL((k_branching8<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
     HIPCK(hipGetLastError());
     return 0;
 }
