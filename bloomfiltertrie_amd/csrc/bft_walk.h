@@ -354,7 +354,11 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
         // Which CC: the first one whose Bloom filter holds the key (src/presenceNode.c:1353-1362).  A node with ONE CC needs
         // no filter below the root: every prefix of a CC is Bloom-positive in it and every UC row is Bloom-negative
         // (SURVEY A.7/A.8), so "CC first, then the UC" gives what "Bloom, then CC or UC" gives, two gathers earlier.
+#ifdef BFT_NO_SINGLE
+        const bool single = false;
+#else
         const bool single = d > 0 && nd.ncc == 1;
+#endif
         int c = single ? 0 : -1;
         if (nd.ncc && !single) {
             const uint32_t hm = root.hashmod(r >> 4);  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
