@@ -30,6 +30,13 @@ def main():
         seen.add(name)
         print(f"{short(name, 90):92s} grid={row[1]} wg={row[2]} lds={row[3]} scratch={row[4]} vgpr={row[5]} agpr={row[6]} sgpr={row[7]} "
               f"min/avg/max_us={row[8] / 1e3:.1f}/{row[10] / 1e3:.1f}/{row[9] / 1e3:.1f} n={row[11]}")
+    # the timed launches of the bench are the long ones: the warm-up index and the residency tuning of bft_gpu_build launch
+    # the same kernels on small batches, so list the query kernels again by duration class
+    print("\n# query kernels by duration class (bench.py times the launches of the full batch)")
+    q = ("select name, case when duration >= 1000000 then '>=1ms' else '<1ms' end as cls, count(*), avg(duration), min(duration), max(duration) "
+         "from kernels where name like '%k_query%' or name like '%k_branching%' group by name, cls order by name, cls")
+    for name, cls, n, avg, mn, mx in cur.execute(q):
+        print(f"{short(name, 90):92s} {cls:6s} n={n:4d} avg_us={avg / 1e3:10.2f} min/max_us={mn / 1e3:.1f}/{mx / 1e3:.1f}")
     if "--pmc" in sys.argv:
         tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
         print("\n# tables:", [t for t in tabs if "pmc" in t.lower() or "counter" in t.lower()])

@@ -6,7 +6,7 @@ set -u
 WL=${1:-cfg2}; NQ=${2:-100000000}; REPS=${3:-3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # the parser reads every CSV below it
 cd /tmp && export TMPDIR=/tmp
 i=0
 # FETCH_SIZE and WRITE_SIZE do not fit one pass ("exceeds the capabilities of the hardware", and rocprofv3 then hangs):

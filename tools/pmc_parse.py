@@ -10,15 +10,19 @@ from collections import defaultdict
 out_dir, wl, nq, reps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 per_counter = defaultdict(lambda: defaultdict(float))  # counter -> dispatch -> summed value
 durations = []
+# bft_gpu_build launches k_query on a small batch to choose its residency: only the LAST `reps` dispatches of a pass are
+# the launches of the full batch
 for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "k_query" not in row.get("Kernel_Name", ""):
-            continue
-        per_counter[row["Counter_Name"]][(f, row.get("Dispatch_Id"))] += float(row["Counter_Value"])
+    rows = [r for r in csv.DictReader(open(f)) if "k_query" in r.get("Kernel_Name", "")]
+    keep = set(sorted({int(r["Dispatch_Id"]) for r in rows})[-reps:])
+    for row in rows:
+        if int(row["Dispatch_Id"]) in keep:
+            per_counter[row["Counter_Name"]][(f, row["Dispatch_Id"])] += float(row["Counter_Value"])
 for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*kernel_trace.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "k_query" in row.get("Kernel_Name", ""):
-            durations.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    rows = [r for r in csv.DictReader(open(f)) if "k_query" in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    for row in rows[-reps:]:
+        durations.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 avg = {c: sum(d.values()) / len(d) for c, d in per_counter.items()}
 res = {
     "_comment": f"rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only; tools/pmc_collect.sh) of tools/pmc_workload.py {wl} {nq} {reps}: "
