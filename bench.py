@@ -134,17 +134,33 @@ def main():
     # ---- the query batch, resident in HBM ----
     nq = args.queries
     dq = make_queries_on_device(union, args.k, nq, 99 + rank, device)
-    dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device)
-    gathered = torch.empty(dbits.numel() * world, dtype=torch.uint8, device=device) if use_dist else None
+    # two result buffers: the bitmap gather of step i (RCCL, its own stream) overlaps the query kernel of step i+1
+    nbuf = 2 if use_dist else 1
+    bits_buf = [torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+    gath_buf = [torch.empty(bits_buf[0].numel() * world, dtype=torch.uint8, device=device) for _ in range(nbuf)] if use_dist else None
+    pending = [None] * nbuf
     stream = torch.cuda.current_stream().cuda_stream
+    step_no = [0]
 
     def step():
-        bft.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()  # the gather that last read this buffer
+            pending[b] = None
+        bft.query_presence_dev(dq.data_ptr(), nq, bits_buf[b].data_ptr(), stream)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, dbits)
+            pending[b] = dist.all_gather_into_tensor(gath_buf[b], bits_buf[b], async_op=True)
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     bft.kernel_time(reset=True)
     if use_dist:
@@ -153,14 +169,19 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = bft.kernel_time(reset=True)
+    dbits = bits_buf[(step_no[0] - 1) % nbuf]  # the last step's answers
     if use_dist:
+        gathered = gath_buf[(step_no[0] - 1) % nbuf]
         assert torch.equal(gathered[rank * dbits.numel():(rank + 1) * dbits.numel()], dbits)
+        if nbuf > 1 and step_no[0] > 1:
+            assert torch.equal(bits_buf[0], bits_buf[1])  # every step answers the same batch
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -303,9 +324,15 @@ def main():
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel": "k_query", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                            "alg_bytes_per_launch": round(alg_bytes * nq)}
-    print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    # RCCL writes its banner through C stdio: flush that first so that the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
