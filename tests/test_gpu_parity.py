@@ -326,3 +326,32 @@ def test_k31_dense_remainder_groups():
     t.insert_kmers(km, 0)
     q = np.concatenate([km, S.snp_mutants(km, 31, 1)])
     assert (S.from_bits(t.query_presence(q), len(q)) == S.member(q, km)).all()
+
+
+@pytest.mark.parametrize("k,deep", [(27, False), (27, True), (63, True)])
+def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
+    """Workgroup size, residency (k_query / k_query8 register budgets) and grid multiplier are tuning knobs only:
+    presence, rows-based colours and branching are identical under every setting, and equal to the oracle's."""
+    from bloomfiltertrie_amd import BFT
+    km = S.low_entropy_kmers(120000, k, 12, seed=4, levels=2) if deep else S.distinct(S.kmers_of(S.random_genome(150000, 8), k))
+    t, o = BFT(k), oracle_mod.OracleBFT(k)
+    for g, part in enumerate(np.array_split(km, 3)):
+        t.insert_kmers(np.ascontiguousarray(part), g)
+        o.insert_kmers(np.ascontiguousarray(part), g)
+    q = np.concatenate([km[::5], S.snp_mutants(km[::9], k, 2)])
+    obits, ooff, oids = o.query_colors(q)
+    ob, oc, _ = o.query_branching(q[:20000])
+    tuned = t.build_time()["query_wgs_per_cu"]
+    assert tuned in (1.0, 2.0)
+    for blk, wgs, mult in [(1024, 0, 1), (1024, 1, 1), (1024, 2, 1), (768, 2, 1), (512, 1, 3), (512, 2, 1), (256, 2, 2)]:
+        t.set_option("query_block", blk)
+        t.set_option("query_wgs_per_cu", wgs)
+        t.set_option("query_grid_mult", mult)
+        bits, off, ids = t.query_colors(q)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult)
+        bb, bc = t.query_branching(q[:20000], with_counts=True)
+        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult)
+    with pytest.raises(Exception):
+        t.set_option("query_block", 100)
+    with pytest.raises(Exception):
+        t.set_option("query_wgs_per_cu", 3)
