@@ -44,6 +44,8 @@ SIGNATURES = {
     "bft_gpu_build_time": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
     "bft_gpu_extract": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bft_gpu_colorset": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bft_gpu_query_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P]),
+    "bft_gpu_colorset_annot": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bft_gpu_image_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "bft_gpu_image_pack": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "bft_gpu_image_unpack": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(_P)]),

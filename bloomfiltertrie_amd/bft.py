@@ -163,6 +163,17 @@ class BFT:
             _lib.check(rc)
             return bits, offsets, ids[:int(need.value)]
 
+    def query_rows(self, kmers):
+        """What resultPresence holds for each k-mer (include/Node.h:60-92) as indexes: (bits, row in the stored k-mer
+        table, colour-set id); 0xFFFFFFFF where absent."""
+        kmers = self._chk(kmers)
+        n = len(kmers)
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        rows = np.zeros(n, dtype=np.uint32)
+        sets = np.zeros(n, dtype=np.uint32)
+        _lib.check(self._lib.bft_gpu_query_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data, sets.ctypes.data))
+        return bits, rows, sets
+
     def query_color_rows(self, kmers):
         """Fixed-width colour rows (the CSV row of src/file_io.c:744-765 before formatting)."""
         kmers = self._chk(kmers)
@@ -243,6 +254,14 @@ class BFT:
         ids = np.zeros(n.value, dtype=np.uint32)
         _lib.check(self._lib.bft_gpu_colorset(self._h, int(cs), ids.ctypes.data, n.value, C.byref(n)))
         return ids.tolist()
+
+    def colorset_annot(self, cs):
+        """The colour set as the reference's annotation bytes (BFT_annotation::annot, src/bft.c:363-387)."""
+        n = C.c_uint32()
+        _lib.check(self._lib.bft_gpu_colorset_annot(self._h, int(cs), None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_colorset_annot(self._h, int(cs), out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value].tobytes()
 
 
 def create_cdbg(k, device=0):

@@ -578,6 +578,8 @@ struct Writer {
 
 }  // namespace
 
+void bft_annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) { annot_encode(ids, n, out); }
+
 bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) {
     FILE* f = fopen(path, "wb");
     if (!f) { err = std::string("cannot create ") + path; return false; }

@@ -24,3 +24,6 @@ struct BftHostImage {  // host copy of the device image, for serialisation
     std::vector<uint32_t> ucrow, tcol, cs_off, cs_ids;
 };
 bool bft_file_write(const char* path, const BftHostImage& im, std::string& err);
+
+// annotation bytes of a sorted genome-id list: the smallest of the reference's modes 0/1/2 (src/annotation.c:634-650)
+void bft_annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out);

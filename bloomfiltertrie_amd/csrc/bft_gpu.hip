@@ -451,6 +451,14 @@ __global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_
     }
 }
 
+// colour-set id of every located k-mer (BFT_ABSENT_ROW stays BFT_ABSENT_ROW)
+__global__ void k_row_colorsets(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, uint64_t n, uint32_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rows[i];
+        out[i] = r == BFT_ABSENT_ROW ? BFT_ABSENT_ROW : tcol[r];
+    }
+}
+
 __global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
                              const uint32_t* __restrict__ cs_ids, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1827,6 +1835,52 @@ extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t
     if (ids) {
         if (cap < b - a) return fail(BFT_GPU_E_NOSPACE, "ids buffer too small");
         memcpy(ids, &h->cs_ids[a], (size_t)(b - a) * 4);
+    }
+    return BFT_GPU_OK;
+}
+
+// What the reference keeps in resultPresence (include/Node.h:60-92) for a found k-mer, as indexes instead of host pointers:
+// the row of the k-mer in the sorted table (the order of bft_gpu_extract) and the id of its colour set.
+extern "C" int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint32_t* rows, uint32_t* colorsets) {
+    if (!h || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    const uint64_t chunk = 1ull << 24;
+    const uint64_t mc = std::min(n, chunk);
+    DevBuf dk, db, dr, dc;
+    CK(dk.alloc(mc * h->B));
+    CK(db.alloc(((mc + 63) / 64) * 8));
+    CK(dr.alloc(mc * 4));
+    if (colorsets) CK(dc.alloc(mc * 4));
+    for (uint64_t a = 0; a < n; a += chunk) {
+        const uint64_t m = std::min(chunk, n - a);
+        CK(query_rows(h, kmers + a * h->B, m, dk, db, dr, present_bits ? present_bits + a / 8 : nullptr));
+        if (rows) HIPCK(hipMemcpyAsync(rows + a, dr.p, m * 4, hipMemcpyDeviceToHost, h->stream));
+        if (colorsets) {
+            hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((m + 255) / 256)), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, m, dc.as<uint32_t>());
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(colorsets + a, dc.p, m * 4, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return BFT_GPU_OK;
+}
+
+// The colour set `cs` in the reference's annotation bytes (smallest of modes 0/1/2, compute_best_mode,
+// src/annotation.c:634-650) -- what get_annotation hands out as BFT_annotation::annot (src/bft.c:363-387).
+extern "C" int bft_gpu_colorset_annot(bft_gpu* h, uint32_t cs, uint8_t* annot, uint32_t cap, uint32_t* n_out) {
+    if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
+    CK(set_device(h));
+    CK(ensure_built(h));
+    CK(host_colorsets(h));
+    if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
+    const uint32_t a = h->cs_off[cs], b = h->cs_off[cs + 1];
+    std::vector<uint8_t> enc;
+    bft_annot_encode(b > a ? &h->cs_ids[a] : nullptr, b - a, enc);
+    if (n_out) *n_out = (uint32_t)enc.size();
+    if (annot) {
+        if (cap < enc.size()) return fail(BFT_GPU_E_NOSPACE, "annotation buffer too small");
+        memcpy(annot, enc.data(), enc.size());
     }
     return BFT_GPU_OK;
 }

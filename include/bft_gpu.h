@@ -150,6 +150,18 @@ int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorset_out, uint64_t cap, uint64_t* n_out);
 int bft_gpu_colorset(bft_gpu* h, uint32_t colorset, uint32_t* ids, uint32_t cap, uint32_t* n_out);
 
+/* What the reference keeps in resultPresence for a found k-mer (include/Node.h:60-92, filled by isKmerPresent,
+ * src/presenceNode.c:1823-1921), as indexes instead of host pointers: rows[i] = position of k-mer i in the stored k-mer
+ * table (the order of bft_gpu_extract), colorsets[i] = id of its colour set (argument of bft_gpu_colorset);
+ * 0xFFFFFFFF for an absent k-mer.  Any of present_bits / rows / colorsets may be NULL.  Host buffers. */
+int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits, uint32_t* rows,
+                       uint32_t* colorsets);
+
+/* A colour set as the reference's annotation bytes -- BFT_annotation::annot as get_annotation returns it
+ * (include/bft.h:97, src/bft.c:363-387): the smallest of modes 0 (bitmap, genome g <-> bit g+2), 1 (ranges) and
+ * 2 (id list) with the tie rules of compute_best_mode (src/annotation.c:634-650).  annot may be NULL to query the size. */
+int bft_gpu_colorset_annot(bft_gpu* h, uint32_t colorset, uint8_t* annot, uint32_t cap, uint32_t* n_out);
+
 /* Replication of a built index on another GPU (the query path shards over GPUs with the trie image
  * replicated in each GPU's HBM; the reference has one BFT_Root per process, include/Node.h:96-122).
  * bft_gpu_image_size: bytes of the self-describing device blob; bft_gpu_image_pack: writes it at d_blob (device

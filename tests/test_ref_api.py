@@ -1,0 +1,218 @@
+"""The reference's public C API (<bft/bft.h>, -lbft) served by the GPU library.
+
+CPU part: include/bft/bft.h declares only functions libbft.so exports, every one of them cites the reference, and a
+program written against the reference's API compiles and links unchanged.
+GPU part: that program (tests/c/ref_api_program.c: create_cdbg, insert_genomes_from_files, insert_kmers_new_genome /
+_last_genome, get_kmer, is_kmer_in_cdbg, get_annotation, get_list_id_genomes, get_count_id_genomes, presence_genome,
+get_predecessors / get_successors / get_neighbors, query_sequence, iterate_over_kmers, extract_kmers_to_disk, write_BFT,
+load_BFT) runs on the GPU box and every line it prints is compared with the oracle and with ground truth."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from bloomfiltertrie_amd import _lib, synth as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT_HEADER = os.path.join(ROOT, "include", "bft", "bft.h")
+LIBBFT = os.path.join(_lib.CSRC, "libbft.so")
+PROGRAM_SRC = os.path.join(ROOT, "tests", "c", "ref_api_program.c")
+
+
+@pytest.fixture(scope="session")
+def built():
+    subprocess.check_call(["make", "-C", _lib.CSRC, "all"], stdout=subprocess.DEVNULL)
+    return True
+
+
+def _declared():
+    hdr = re.sub(r"/\*.*?\*/", "", open(COMPAT_HEADER).read(), flags=re.S)
+    hdr = re.sub(r"typedef[^;{]*\{.*?\}[^;]*;", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef[^;]*;", "", hdr)
+    return set(re.findall(r"\b([a-zA-Z_][a-zA-Z_0-9]*)\s*\([^;{]*\)\s*;", hdr))
+
+
+def _compile(tmp_path):
+    exe = str(tmp_path / "ref_api_program")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, PROGRAM_SRC,
+                           "-L", _lib.CSRC, "-lbft", f"-Wl,-rpath,{_lib.CSRC}", f"-Wl,-rpath-link,{_lib.CSRC}",
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_compat_header_symbols_are_exported(built):
+    declared = _declared()
+    assert {"create_cdbg", "free_cdbg", "insert_genomes_from_files", "insert_kmers_new_genome", "insert_kmers_last_genome",
+            "get_kmer", "is_kmer_in_cdbg", "get_annotation", "get_list_id_genomes", "presence_genome", "query_sequence",
+            "get_successors", "get_predecessors", "get_neighbors", "iterate_over_kmers", "v_iterate_over_kmers", "write_BFT",
+            "load_BFT", "extract_kmers_to_disk", "free_BFT_kmer", "free_BFT_annotation"} <= declared
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIBBFT]).decode()
+    exported = set(re.findall(r" T ([A-Za-z_0-9]+)", out))
+    assert declared <= exported, declared - exported
+    lib = C.CDLL(LIBBFT)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_compat_layer_is_plain_c_over_the_abi(built):
+    """libbft.so holds no device code and no algorithm: it needs libbft_gpu.so, and the only bft_gpu_* calls it makes are
+    declared in include/bft_gpu.h."""
+    needed = subprocess.check_output(["readelf", "-d", LIBBFT]).decode()
+    assert "libbft_gpu.so" in needed
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", LIBBFT]).decode()
+    used = set(re.findall(r" U (bft_gpu_[a-z_0-9]+)", und))
+    assert used and used <= set(_lib.SIGNATURES), used - set(_lib.SIGNATURES)
+    assert not re.search(r" U (hip|__hip)", und)
+
+
+def test_reference_style_program_compiles_and_links(built, tmp_path):
+    exe = _compile(tmp_path)
+    src = open(PROGRAM_SRC).read()
+    assert "#include <bft/bft.h>" in src and "bft_gpu_" not in src  # the reference's API only
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+def _neighbour_bits(kmer, side, present):
+    out = ""
+    for c in "ACGT":
+        s = (c + kmer[:-1]) if side == 0 else (kmer[1:] + c)
+        out += "1" if s in present else "0"
+    return out
+
+
+@pytest.mark.gpu
+def test_reference_style_program_against_oracle(built, oracle_mod, tmp_path):
+    k = 27
+    exe = _compile(tmp_path)
+    anc = S.random_genome(12000, 21)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 30 + g), k)) for g in range(4)]
+    gk[1] = np.concatenate([gk[1], S.low_entropy_kmers(30000, k, 6, seed=5, levels=2)])  # child Nodes below the root
+    files = []
+    for g, km in enumerate(gk):
+        p = tmp_path / f"genome{g}.txt"
+        lines = S.packed_to_ascii(km, k)
+        if g == 0:
+            lines = lines[:50] + ["NOT_A_KMER", "ACGTNACGTNACGTNACGTNACGTNAC"] + lines[50:]  # skipped (src/file_io.c:159)
+        p.write_text("\n".join(lines) + "\n")
+        files.append(str(p))
+    o = oracle_mod.OracleBFT(k)
+    for g, km in enumerate(gk):
+        o.insert_kmers(np.ascontiguousarray(km), g)
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(3)
+    q = np.concatenate([allk[::11], S.snp_mutants(allk[::17], k, 9), S.pack_codes(rng.integers(0, 4, (300, k), dtype=np.uint8))])
+    q = q[rng.permutation(len(q))]
+    qa = S.packed_to_ascii(q, k)
+    (tmp_path / "queries.txt").write_text("\n".join(qa) + "\n")
+    g0 = "".join("ACGT"[c] for c in S.mutate(anc, 0.02, 30))
+    seqs = [g0[100:400], g0[5000:5100], "".join("ACGT"[c] for c in S.random_genome(200, 77)), g0[20:20 + k], "ACGT"]
+    (tmp_path / "seqs.txt").write_text("\n".join(seqs) + "\n")
+    r = subprocess.run([exe, str(k), str(tmp_path / "out.bft"), str(tmp_path / "queries.txt"), str(tmp_path / "seqs.txt"),
+                        str(tmp_path / "extracted.txt")] + files, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    lines = r.stdout.split("\n")
+    assert not any(x.startswith("BAD") for x in lines)
+
+    names = [f"genome{g}.txt" for g in range(3)] + ["the_last_genome"]
+    assert lines[0] == "GENOMES 4 " + " ".join(names)
+    # presence + colour sets, before and after the .bft round trip, against the oracle
+    bits, off, ids = o.query_colors(q)
+    pres = S.from_bits(bits, len(q))
+    for tag in ("Q", "R"):
+        got = [x for x in lines if x.startswith(tag + " ") and not x.startswith(tag + " present")]
+        assert len(got) == len(q)
+        for i, x in enumerate(got):
+            exp = f"{tag} {qa[i]} 0"
+            if pres[i]:
+                exp = f"{tag} {qa[i]} 1 " + ",".join(str(v) for v in ids[int(off[i]):int(off[i + 1])].tolist())
+            assert x == exp
+        assert f"{tag} present {int(pres.sum())}" in lines
+    assert "RELOADED 27 4 " + " ".join(names) in lines
+    # neighbours against ground truth and the oracle's branching counts
+    present = set(S.packed_to_ascii(allk, k))
+    nlines = [x for x in lines if x.startswith("N ")]
+    assert len(nlines) == min(300, int(pres.sum()))
+    nq = S.ascii_to_packed([x.split()[1] for x in nlines], k)[0]
+    _, counts, _ = o.query_branching(nq)
+    for x, c in zip(nlines, counts.tolist()):
+        _, km, pb, sb = x.split()
+        assert pb == _neighbour_bits(km, 0, present) and sb == _neighbour_bits(km, 1, present)
+        assert c == (sb.count("1") << 4 | pb.count("1"))
+    # sequence queries against the oracle's restatement of query_sequence
+    for i, s in enumerate(seqs):
+        a = o.query_sequence(s, 0.7, False, 4)
+        b = o.query_sequence(s, 1.0, True, 4)
+        c = sorted(set(a) & set(b))
+        fmt = lambda v: ",".join(str(t) for t in v)  # noqa: E731
+        assert f"S {i} {fmt(a)} | {fmt(b)} | {fmt(c)}" in lines
+    # iteration and extraction: the stored set, each k-mer once
+    npairs = sum(len(S.distinct(km)) for km in gk)
+    assert f"ITER {len(allk)} {npairs}" in lines
+    assert "ITER_STOP 10" in lines
+    ext = (tmp_path / "extracted.txt").read_text().split("\n")
+    assert ext[-1] == "" and len(ext) - 1 == len(allk) and set(ext[:-1]) == present
+    assert f"LOOSE {qa[0]} 0" in lines
+    # the file the program wrote is a reference-format .bft: the oracle's reader loads it and agrees
+    o2 = oracle_mod.OracleBFT.load_bft(str(tmp_path / "out.bft"))
+    b2, off2, ids2 = o2.query_colors(q)
+    assert (b2 == bits).all() and (off2 == off).all() and (ids2 == ids).all()
+
+
+@pytest.mark.gpu
+def test_reference_api_error_behaviour(built, tmp_path):
+    """ERROR() semantics (include/useful_macros.h:33-43): message on stderr, exit(EXIT_FAILURE)."""
+    src = tmp_path / "bad.c"
+    src.write_text(r'''
+#include <bft/bft.h>
+#include <string.h>
+int main(int argc, char** argv) {
+    BFT* bft = create_cdbg(27, 0);
+    char* km[1] = {"ACGTACGTACGTACGTACGTACGTACG"};
+    insert_kmers_new_genome(1, km, "g", bft);
+    if (!strcmp(argv[1], "annot")) { BFT_kmer* a = get_kmer("TTTTTTTTTTTTTTTTTTTTTTTTTTT", bft); get_annotation(a); }
+    if (!strcmp(argv[1], "char")) get_kmer("ACGTACGTACGTNCGTACGTACGTACG", bft);
+    if (!strcmp(argv[1], "thr")) query_sequence(bft, km[0], 1.5, false);
+    if (!strcmp(argv[1], "ins")) { char* bad[1] = {"ACGTACGTACGTACGTACGTACGTAXG"}; insert_kmers_last_genome(1, bad, bft); }
+    if (!strcmp(argv[1], "ok")) { BFT_kmer* a = get_kmer(km[0], bft); return is_kmer_in_cdbg(a) ? 0 : 5; }
+    return 0;
+}
+''')
+    exe = str(tmp_path / "bad")
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src), "-L", _lib.CSRC, "-lbft",
+                           f"-Wl,-rpath,{_lib.CSRC}", f"-Wl,-rpath-link,{_lib.CSRC}", "-Wl,-rpath-link,/opt/rocm/lib"])
+    assert subprocess.run([exe, "ok"]).returncode == 0
+    for what, msg in [("annot", "k-mer is not present in the graph"), ("char", "Unexpected character"),
+                      ("thr", "inferior or equal to 1"), ("ins", "unvalid characters")]:
+        r = subprocess.run([exe, what], capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr, (what, r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_query_rows_and_annotation_bytes(oracle_mod):
+    """bft_gpu_query_rows: row = position in extraction order, colour set = that row's; bft_gpu_colorset_annot: the
+    reference's annotation bytes (oracle's restated encoder / decoder agree)."""
+    from bloomfiltertrie_amd import BFT
+    k = 36
+    anc = S.random_genome(8000, 2)
+    t = BFT(k)
+    for g in range(70):  # > 64 genomes: two-byte ids in modes 1/2
+        t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.01 * (1 + g % 3), 100 + g), k))[:: 1 + g % 4], g)
+    stored, cs = t.extract()
+    q = np.concatenate([stored[::3], S.snp_mutants(stored[::5], k, 1)])
+    bits, rows, sets = t.query_rows(q)
+    pres = S.from_bits(bits, len(q)).astype(bool)
+    assert (pres == S.member(q, stored)).all()
+    assert (rows[~pres] == 0xFFFFFFFF).all() and (sets[~pres] == 0xFFFFFFFF).all()
+    assert (stored[rows[pres]] == q[pres]).all() and (cs[rows[pres]] == sets[pres]).all()
+    seen_modes = set()
+    for c in np.unique(cs)[:400].tolist():
+        ids = t.colorset(c)
+        a = t.colorset_annot(c)
+        assert a == oracle_mod.annot_encode(ids)
+        assert oracle_mod.annot_decode(a) == ids
+        seen_modes.add(a[0] & 3)
+    assert seen_modes >= {0, 2} or seen_modes >= {1, 2}
