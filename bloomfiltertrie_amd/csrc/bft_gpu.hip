@@ -508,6 +508,7 @@ void bft_pool_set_stream(int device, hipStream_t s) {
 
 int bft_pool_alloc(void** p, size_t n, size_t* cap) {
     *p = nullptr;
+    n += 256;  // slack behind every device array: aligned multi-row probes may read past the last row (bft_load_pair)
     PoolBlock take{nullptr, 0, 0, nullptr};
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -633,6 +634,8 @@ struct bft_gpu {
     int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
     int opt_wgs_per_cu = 0;   // resident k_query workgroups per CU: 1, 2, or 0 = measured when the image is bound (tune_residency)
     int tuned_wgs = 0;        // result of that measurement (0 = none yet)
+    int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big), 0 = measured with the residency
+    int tuned_probe = 0;
     double tune_ms[2] = {0, 0};
     int opt_grid_mult = 1;    // grid = resident workgroups x this
 };
@@ -937,7 +940,9 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
         }
     }
     h->tuned_wgs = 0;
-    if (h->opt_wgs_per_cu == 0) CK(tune_residency(h));
+    h->tuned_probe = 0;
+    h->im.probe_big = h->opt_probe == 8;
+    if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     return 0;
 }
 
@@ -1208,7 +1213,12 @@ __global__ void k_tune_queries(const uint64_t* __restrict__ tk, uint64_t n_kmers
 
 // One or two resident workgroups per CU for k_query on THIS image: time both on a batch drawn from the index.
 static int tune_residency(bft_gpu* h) {
-    if (h->n_kmers < (1u << 16)) { h->tuned_wgs = 2; return 0; }  // small (L2-resident) indexes: always two
+    if (h->n_kmers < (1u << 16)) {  // small (L2-resident) indexes: always two workgroups, 4-row probes
+        h->tuned_wgs = 2;
+        h->tuned_probe = 4;
+        h->im.probe_big = h->opt_probe == 8;
+        return 0;
+    }
     const uint64_t m = 1ull << 22;
     DevBuf q, bits;
     CK(q.alloc(m * h->B));
@@ -1228,17 +1238,20 @@ static int tune_residency(bft_gpu* h) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
-    float best[2] = {0, 0};
-    for (int cfg = 1; cfg <= 2 && rc == 0; cfg++) {
-        h->tuned_wgs = cfg;
-        best[cfg - 1] = 1e30f;
+    // (workgroups per CU) x (probe block): 1/4, 2/4, 1/8, 2/8; options fixed by the caller are not varied
+    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    for (int cfg = 0; cfg < 4 && rc == 0; cfg++) {
+        const int wgs = 1 + (cfg & 1), probe = (cfg & 2) ? 8 : 4;
+        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W != 1 && probe == 8)) continue;
+        h->tuned_wgs = wgs;
+        h->im.probe_big = probe == 8;
         for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
             if (rc == 0) rc = launch_query(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
             float ms = 0;
             if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
-            if (rep > 0 && ms < best[cfg - 1]) best[cfg - 1] = ms;
+            if (rep > 0 && ms < best[cfg]) best[cfg] = ms;
         }
     }
     if (e0) (void)hipEventDestroy(e0);
@@ -1246,10 +1259,16 @@ static int tune_residency(bft_gpu* h) {
     h->timing = timing;
     h->im.debug_stop = dbg;
     h->tuned_wgs = 0;
+    h->im.probe_big = h->opt_probe == 8;
     CK(rc);
-    h->tune_ms[0] = best[0];
-    h->tune_ms[1] = best[1];
-    h->tuned_wgs = best[0] < best[1] ? 1 : 2;
+    int win = 0;
+    for (int cfg = 1; cfg < 4; cfg++)
+        if (best[cfg] < best[win]) win = cfg;
+    h->tune_ms[0] = std::min(best[0], best[2]) < 1e29f ? std::min(best[0], best[2]) : 0;
+    h->tune_ms[1] = std::min(best[1], best[3]) < 1e29f ? std::min(best[1], best[3]) : 0;
+    h->tuned_wgs = 1 + (win & 1);
+    h->tuned_probe = (win & 2) ? 8 : 4;
+    h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
     return 0;
 }
 
@@ -1745,6 +1764,10 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "query_wgs_per_cu") {
         if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1 or 2");
         h->opt_wgs_per_cu = (int)value;
+    } else if (nm == "query_probe") {
+        if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
+        h->opt_probe = (int)value;
+        h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;
@@ -1788,8 +1811,9 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[8] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1]};
-    for (int i = 0; i < n_out && i < 8; i++) ms[i] = v[i];
+    const double v[9] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+                         h->im.probe_big ? 8.0 : 4.0};
+    for (int i = 0; i < n_out && i < 9; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

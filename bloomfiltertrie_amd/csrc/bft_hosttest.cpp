@@ -95,6 +95,9 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
     return cnt;
 }
 
+// suffix-group probe mode of the walk (BftImage::probe_big): same answers either way
+extern "C" void bft_hosttest_set_probe(void* hv, int big) { ((HostTrie*)hv)->im.probe_big = big ? 1u : 0u; }
+
 extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
     HostTrie* t = (HostTrie*)hv;
     switch (t->W) {

@@ -91,6 +91,8 @@ struct BftImage {
     int k, L, W;
     uint32_t nb_genomes;
     uint32_t debug_stop;      // perf probing only (tools/perf_probe.py): 0 = full walk; results are wrong when != 0
+    uint32_t probe_big;       // suffix-group search (bft_group_probe): 0 = 4-row blocks, step to the adjacent block;
+                              // 1 = 8-row blocks, next guess re-interpolated (big groups); same answers either way
     uint64_t n_kmers;
     const uint32_t* hashmod;  // [16384] (hash_v[2i] % 1504) | (hash_v[2i+1] % 1504) << 16
     const BftNode* nodes;

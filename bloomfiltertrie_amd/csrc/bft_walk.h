@@ -339,6 +339,84 @@ BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint
     return true;
 }
 
+// Two adjacent one-word rows of the table, first one at an even index: one 16-byte load.  Device buffers carry 256 bytes
+// of slack (bft_pool_alloc), so a pair that straddles the end of the table is still readable; the host copy is clamped.
+BFT_HD void bft_load_pair(const BftImage& im, uint64_t gi, uint64_t* a, uint64_t* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(im.tk + gi);
+    *a = v.x;
+    *b = v.y;
+#else
+    *a = gi < im.n_kmers ? im.tk[gi] : ~0ull;
+    *b = gi + 1 < im.n_kmers ? im.tk[gi + 1] : ~0ull;
+#endif
+}
+
+// Search of a one-word suffix group [idx, idx+cnt) of the table for tv, from the interpolated guess g (src/UC.c:81-124 and
+// src/presenceNode.c:1886-1913 give the same answer by binary search + memcmp).  A probe = NR/2 independent 16-byte loads
+// of the NR-row ALIGNED block of the table that holds the guess (32 or 64 bytes: never straddles a cache line); rows of the
+// block outside the bracket are ignored.  tv inside the block's range ends the search; otherwise the bracket shrinks to the
+// side that can still hold tv and the next probe goes to the adjacent block (im.probe_big == 0, 4-row blocks: best when
+// groups hold ~10-20 rows) or to a guess re-interpolated from the nearest row just read (im.probe_big == 1, 8-row blocks:
+// best for groups of dozens to 255 rows).  The mode is one flag per image, so the branch is uniform across a wavefront.
+// After BFT_PROBE_STEPS probes, binary search in what is left of the bracket.
+#ifndef BFT_PROBE_STEPS
+#define BFT_PROBE_STEPS 3
+#endif
+
+// One probe.  Returns true when the search is over (hit filled when found).  Else: dir < 0, bracket cut to rows below the
+// block, *edge = first bracket row of the block; dir > 0, bracket cut to rows above it, *edge = the last one.
+template <int NR>
+BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, uint64_t tv, uint64_t* lo2, uint64_t* hi2, uint64_t* edge, int* dir, BftHit& hit) {
+    const uint64_t ga = guess & ~(uint64_t)(NR - 1);
+    uint64_t w[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j += 2) bft_load_pair(im, ga + j, &w[j], &w[j + 1]);
+    uint32_t nin = 0, nlt = 0;  // block rows inside the bracket; those below tv
+    uint64_t found = ~0ull, first = 0, last = 0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const uint64_t gi = ga + j;
+        const bool in = gi >= *lo2 && gi < *hi2;
+        if (in && !nin) first = w[j];
+        if (in) last = w[j];
+        nin += in;
+        nlt += in && w[j] < tv;
+        if (in && w[j] == tv) found = gi;
+    }
+    if (found != ~0ull) { hit.present = 1; hit.row = found; return true; }
+    if (nlt != 0 && nlt != nin) return true;  // strictly between two rows of the block: absent
+    if (nlt == 0) { *hi2 = ga > *lo2 ? ga : *lo2; *edge = first; *dir = -1; }
+    else { *lo2 = ga + NR < *hi2 ? ga + NR : *hi2; *edge = last; *dir = 1; }
+    return *lo2 >= *hi2;
+}
+
+// rem = number of key bits below the level that owns the group (the group's rows differ only there)
+BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, uint64_t tv, int rem, BftHit& hit) {
+    uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge = 0;
+    int dir = 0;
+    const bool big = im.probe_big != 0;
+#pragma unroll
+    for (int step = 0; step < BFT_PROBE_STEPS; step++) {
+        if (big ? bft_probe_block<8>(im, guess, tv, &lo2, &hi2, &edge, &dir, hit) : bft_probe_block<4>(im, guess, tv, &lo2, &hi2, &edge, &dir, hit)) return;
+        uint64_t d = 0;
+        if (big) {  // rows between the edge row and tv, by the group's mean density
+            const uint64_t m36 = (1ull << 36) - 1ull;
+            const uint64_t a = rem >= 36 ? (tv >> (rem - 36)) & m36 : (tv << (36 - rem)) & m36;
+            const uint64_t b = rem >= 36 ? (edge >> (rem - 36)) & m36 : (edge << (36 - rem)) & m36;
+            d = ((a > b ? a - b : b - a) * cnt) >> 36;
+        }
+        if (dir < 0) guess = hi2 - lo2 > d + 1 ? hi2 - 1 - d : lo2;
+        else guess = hi2 - lo2 > d ? lo2 + d : hi2 - 1;
+    }
+    while (lo2 < hi2) {
+        const uint64_t mid = (lo2 + hi2) >> 1;
+        const uint64_t r = im.tk[mid];
+        if (r == tv) { hit.present = 1; hit.row = mid; return; }
+        if (r < tv) lo2 = mid + 1; else hi2 = mid;
+    }
+}
+
 template <int W, class Root>
 BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t) {
     BftHit hit;
@@ -400,42 +478,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
         const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
         if (W == 1 && cnt >= BFT_WINDOW_PROBE) {
-            // one round of two independent 16-byte loads: the 4 table rows around the guess (aligned pairs of the
-            // global table; rows outside the group are ignored), then only the side that can still hold t
-            const uint64_t lo_row = idx, hi_row = idx + cnt;  // group = [lo_row, hi_row)
-            uint64_t ga = (idx + (g ? g - 1 : 0)) & ~1ull;
-            if (ga + 4 > im.n_kmers) ga = im.n_kmers >= 4 ? (im.n_kmers - 4) & ~1ull : 0;
-            uint64_t w4[4];
-            const uint64_t* base = im.tk + ga;
-            w4[0] = base[0]; w4[1] = base[1];
-            w4[2] = ga + 2 < im.n_kmers ? base[2] : ~0ull; w4[3] = ga + 3 < im.n_kmers ? base[3] : ~0ull;
-            const uint64_t tv = t[0];
-            int found = -1;
-            uint64_t first_in = ~0ull, last_in = 0;  // window rows inside the group
-            bool any = false, below = false, above = false;  // t below the first / above the last in-group window row
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint64_t gi = ga + j;
-                if (gi >= lo_row && gi < hi_row) {
-                    if (!any) { first_in = gi; below = tv < w4[j]; any = true; }
-                    last_in = gi;
-                    above = tv > w4[j];
-                    if (w4[j] == tv) found = (int)(gi - lo_row);
-                }
-            }
-            if (found >= 0) { hit.present = 1; hit.row = idx + (uint32_t)found; return hit; }
-            if (any && !below && !above) return hit;  // strictly between two window rows: absent
-            // not in the window: binary search on the side that can still hold t
-            uint32_t lo2 = 0, hi2 = cnt;
-            if (any && below) hi2 = (uint32_t)(first_in - lo_row);
-            else if (any && above) lo2 = (uint32_t)(last_in - lo_row) + 1;
-            const uint64_t* rows = im.tk + idx;
-            while (lo2 < hi2) {
-                const uint32_t mid = (lo2 + hi2) >> 1;
-                const uint64_t r = rows[mid];
-                if (r == tv) { hit.present = 1; hit.row = idx + mid; return hit; }
-                if (r < tv) lo2 = mid + 1; else hi2 = mid;
-            }
+            bft_group_probe(im, idx, cnt, g, t[0], rb + 18 * (L - 1 - d), hit);
             return hit;
         }
 #endif

@@ -128,7 +128,8 @@ int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_km
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
- * per CU: 1, 2, 0 = chosen from the shape of the index), "query_grid_mult"
+ * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
+ * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
  * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels), "flat_min" (CCs with at
  * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
@@ -142,7 +143,7 @@ int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t ca
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
  * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, colour-set bitmaps) + k_query residency tuning, ms[5]=resident
- * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned). */
+ * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8). */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

@@ -70,6 +70,7 @@ def hostlib(built):
     lib.bft_hosttest_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
     lib.bft_hosttest_query.restype = C.c_uint64
     lib.bft_hosttest_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_set_probe.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_hashmod.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -129,6 +130,11 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     bits = np.zeros((len(q) + 7) // 8, np.uint8)
     rows = np.zeros(len(q), np.uint32)
     hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, rows.ctypes.data)
+    bits8, rows8 = np.zeros_like(bits), np.zeros_like(rows)
+    hostlib.bft_hosttest_set_probe(h, 1)  # 8-row blocks + re-interpolated guesses: a tuning mode, same answers
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+    hostlib.bft_hosttest_set_probe(h, 0)
+    assert (bits8 == bits).all() and (rows8 == rows).all()
     o = oracle_mod.OracleBFT(k)
     o.insert_kmers(km, 0)
     assert (bits == o.query_presence(q)).all()

@@ -330,7 +330,7 @@ def test_k31_dense_remainder_groups():
 
 @pytest.mark.parametrize("k,deep", [(27, False), (27, True), (63, True)])
 def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
-    """Workgroup size, residency (k_query / k_query8 register budgets) and grid multiplier are tuning knobs only:
+    """Workgroup size, residency (k_query / k_query8 register budgets), grid multiplier and the suffix-group probe mode are tuning knobs only:
     presence, rows-based colours and branching are identical under every setting, and equal to the oracle's."""
     from bloomfiltertrie_amd import BFT
     km = S.low_entropy_kmers(120000, k, 12, seed=4, levels=2) if deep else S.distinct(S.kmers_of(S.random_genome(150000, 8), k))
@@ -343,10 +343,12 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     ob, oc, _ = o.query_branching(q[:20000])
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0)
-    for blk, wgs, mult in [(1024, 0, 1), (1024, 1, 1), (1024, 2, 1), (768, 2, 1), (512, 1, 3), (512, 2, 1), (256, 2, 2)]:
+    assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
+    for blk, wgs, mult, probe in [(1024, 0, 1, 0), (1024, 1, 1, 4), (1024, 2, 1, 8), (768, 2, 1, 4), (512, 1, 3, 8), (512, 2, 1, 0), (256, 2, 2, 8)]:
         t.set_option("query_block", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)
+        t.set_option("query_probe", probe)
         bits, off, ids = t.query_colors(q)
         assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult)
         bb, bc = t.query_branching(q[:20000], with_counts=True)
@@ -355,3 +357,5 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
         t.set_option("query_block", 100)
     with pytest.raises(Exception):
         t.set_option("query_wgs_per_cu", 3)
+    with pytest.raises(Exception):
+        t.set_option("query_probe", 16)
