@@ -124,7 +124,7 @@ struct BftRootLds {
 #define BFT_LDS_HM_BYTES 65536u
 #define BFT_LDS_ROOT_MAX_CC 64u
 
-template <int W, int BLOCK, bool STAGED>
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                            uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
             uint64_t x[W], t[W];
             load_x<W>(packed, i, B, end_aligned, x);
             bft_tform_from_x<W>(x, im.k, t);
-            const BftHit h = bft_walk<W>(im, acc, root, t);
+            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
             present = h.present;
             if (present) row = (uint32_t)h.row;
         }
@@ -173,15 +173,17 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
 // SGPRs), which caps a SIMD at 7 waves, i.e. ONE 1024-thread workgroup per CU -- the fastest arrangement for a one-level
 // index (4 waves per SIMD keep the beyond-L2 gather path full, more only thrash it).  k_query8: held to 8 waves per SIMD
 // (78 SGPRs) so that two workgroups share a CU -- +10..40 % on deep tries and on L2-resident ones.
-template <int W, int BLOCK, bool STAGED>
+// PROBE: suffix-group probe mode fixed at compile time (0 = 4-row blocks, 1 = 8-row blocks; the 1024-thread kernels) or read
+// from the image (-1; the other workgroup sizes): the 4-row code alone fits the 64 VGPRs of k_query8 without spilling.
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                  uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, rows);
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
 }
-template <int W, int BLOCK, bool STAGED>
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                                                                              uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, rows);
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
@@ -232,7 +234,7 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
 #pragma unroll
                 for (int w = 0; w < W; w++) tt[w] = t[w];
                 tt[W - 1] |= nt << (rb ? 0 : 2);  // last nucleotide: n9 of the last prefix, or the end of the k % 9 remainder
-                cr += bft_walk<W>(im, acc, root, tt).present;
+                cr += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
             }
             if (counts || cr < 2) {
                 // predecessors: shift in a wildcard first nucleotide, drop the last one
@@ -246,7 +248,7 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
                     uint64_t tt[W];
 #pragma unroll
                     for (int w = 0; w < W; w++) tt[w] = t[w] | (w == ow ? nt << osh : 0ull);
-                    cl += bft_walk<W>(im, acc, root, tt).present;
+                    cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
                 }
             }
             branching = cr > 1 || cl > 1;
@@ -316,7 +318,7 @@ __global__ void k_seq_rows(BftImage im, const char* __restrict__ seqs, const uin
             uint64_t t[W];
             // strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296)
             bft_tform_from_x<W>((canonical && cmp >= 0) ? xr : xf, im.k, t);
-            const BftHit hit = bft_walk<W>(im, acc, root, t);
+            const BftHit hit = bft_walk<W, BftRootGlobal, 0>(im, acc, root, t);
             if (hit.present) row = (uint32_t)hit.row;
         }
         rows[p] = row;
@@ -1122,7 +1124,7 @@ static int query_residency(const bft_gpu* h) {
     return h->tuned_wgs ? h->tuned_wgs : 2;
 }
 
-template <int W, int BLOCK, bool STAGED>
+template <int W, int BLOCK, bool STAGED, int PROBE>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
     // one workgroup per CU the request is padded past half the LDS so that the dispatcher cannot pair two on a CU.
@@ -1135,29 +1137,31 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
-    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
     HIPCK(hipGetLastError());
     return 0;
+}
+
+template <int W, bool STAGED>
+static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+    if (h->opt_block == 1024) {
+        if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, 1024, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s);
+        return launch_query_k<W, 1024, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s);
+    }
+    if (h->opt_block == 768) return launch_query_k<W, 768, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
+    if (h->opt_block == 512) return launch_query_k<W, 512, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
+    return launch_query_k<W, 256, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
 }
 
 template <int W>
 static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    if (staged) {
-        if (h->opt_block == 1024) return launch_query_k<W, 1024, true>(h, d_kmers, n, d_bits64, d_rows, s);
-        if (h->opt_block == 768) return launch_query_k<W, 768, true>(h, d_kmers, n, d_bits64, d_rows, s);
-        if (h->opt_block == 512) return launch_query_k<W, 512, true>(h, d_kmers, n, d_bits64, d_rows, s);
-        return launch_query_k<W, 256, true>(h, d_kmers, n, d_bits64, d_rows, s);
-    }
-    if (h->opt_block == 1024) return launch_query_k<W, 1024, false>(h, d_kmers, n, d_bits64, d_rows, s);
-    if (h->opt_block == 768) return launch_query_k<W, 768, false>(h, d_kmers, n, d_bits64, d_rows, s);
-    if (h->opt_block == 512) return launch_query_k<W, 512, false>(h, d_kmers, n, d_bits64, d_rows, s);
-    return launch_query_k<W, 256, false>(h, d_kmers, n, d_bits64, d_rows, s);
+    return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s);
 }
 
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
@@ -1242,7 +1246,7 @@ static int tune_residency(bft_gpu* h) {
     float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
     for (int cfg = 0; cfg < 4 && rc == 0; cfg++) {
         const int wgs = 1 + (cfg & 1), probe = (cfg & 2) ? 8 : 4;
-        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W != 1 && probe == 8)) continue;
+        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W > BFT_PROBE_MAX_W && probe == 8)) continue;
         h->tuned_wgs = wgs;
         h->im.probe_big = probe == 8;
         for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches

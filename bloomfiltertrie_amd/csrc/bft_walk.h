@@ -363,61 +363,89 @@ BFT_HD void bft_load_pair(const BftImage& im, uint64_t gi, uint64_t* a, uint64_t
 #ifndef BFT_PROBE_STEPS
 #define BFT_PROBE_STEPS 3
 #endif
+#ifndef BFT_PROBE_MAX_W
+#define BFT_PROBE_MAX_W 2   // rows of one or two words (k <= 64); longer rows keep the galloping search
+#endif
 
-// One probe.  Returns true when the search is over (hit filled when found).  Else: dir < 0, bracket cut to rows below the
-// block, *edge = first bracket row of the block; dir > 0, bracket cut to rows above it, *edge = the last one.
-template <int NR>
-BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, uint64_t tv, uint64_t* lo2, uint64_t* hi2, uint64_t* edge, int* dir, BftHit& hit) {
+// One probe of NR rows of W words (W = 1: NR/2 loads of a pair of rows; W = 2: one load per row).  Returns true when the
+// search is over (hit filled when found).  Else: dir < 0, bracket cut to rows below the block, edge = first bracket row
+// of the block; dir > 0, bracket cut to rows above it, edge = the last one.
+template <int W, int NR>
+BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, const uint64_t* t, uint64_t* lo2, uint64_t* hi2, uint64_t* edge, int* dir, BftHit& hit) {
     const uint64_t ga = guess & ~(uint64_t)(NR - 1);
-    uint64_t w[NR];
+    uint64_t w[NR][W];
+    if (W == 1) {
 #pragma unroll
-    for (int j = 0; j < NR; j += 2) bft_load_pair(im, ga + j, &w[j], &w[j + 1]);
-    uint32_t nin = 0, nlt = 0;  // block rows inside the bracket; those below tv
-    uint64_t found = ~0ull, first = 0, last = 0;
+        for (int j = 0; j < NR; j += 2) bft_load_pair(im, ga + j, &w[j][0], &w[j + 1][0]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            bft_load_row<W>(im.tk + (ga + j) * W, w[j]);  // slack behind the table: see bft_load_pair
+#else
+            for (int x = 0; x < W; x++) w[j][x] = ga + j < im.n_kmers ? im.tk[(ga + j) * W + x] : ~0ull;
+#endif
+        }
+    }
+    uint32_t nin = 0, nlt = 0;  // block rows inside the bracket; those below t
+    uint64_t found = ~0ull;
+    int jf = 0, jl = 0;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const uint64_t gi = ga + j;
         const bool in = gi >= *lo2 && gi < *hi2;
-        if (in && !nin) first = w[j];
-        if (in) last = w[j];
+        const int c = bft_cmp<W>(w[j], t);
+        if (in && !nin) jf = j;
+        if (in) jl = j;
         nin += in;
-        nlt += in && w[j] < tv;
-        if (in && w[j] == tv) found = gi;
+        nlt += in && c < 0;
+        if (in && c == 0) found = gi;
     }
     if (found != ~0ull) { hit.present = 1; hit.row = found; return true; }
     if (nlt != 0 && nlt != nin) return true;  // strictly between two rows of the block: absent
-    if (nlt == 0) { *hi2 = ga > *lo2 ? ga : *lo2; *edge = first; *dir = -1; }
-    else { *lo2 = ga + NR < *hi2 ? ga + NR : *hi2; *edge = last; *dir = 1; }
+    const int je = nlt == 0 ? jf : jl;
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+        if (j == je) {
+#pragma unroll
+            for (int x = 0; x < W; x++) edge[x] = w[j][x];
+        }
+    if (nlt == 0) { *hi2 = ga > *lo2 ? ga : *lo2; *dir = -1; }
+    else { *lo2 = ga + NR < *hi2 ? ga + NR : *hi2; *dir = 1; }
     return *lo2 >= *hi2;
 }
 
-// rem = number of key bits below the level that owns the group (the group's rows differ only there)
-BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, uint64_t tv, int rem, BftHit& hit) {
-    uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge = 0;
+// d = the level that owns the group (its rows differ only in the key bits below that level)
+// PROBE: 0 / 1 fixes the mode at compile time (k_query: the 4-row code needs fewer registers than the 8-row one), -1 reads
+// im.probe_big.
+template <int W, int PROBE>
+BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
+    uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
     int dir = 0;
-    const bool big = im.probe_big != 0;
+    const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
+    constexpr int NS = W == 1 ? 4 : 2, NB = W == 1 ? 8 : 4;  // 32-byte / 64-byte blocks
 #pragma unroll
     for (int step = 0; step < BFT_PROBE_STEPS; step++) {
-        if (big ? bft_probe_block<8>(im, guess, tv, &lo2, &hi2, &edge, &dir, hit) : bft_probe_block<4>(im, guess, tv, &lo2, &hi2, &edge, &dir, hit)) return;
-        uint64_t d = 0;
-        if (big) {  // rows between the edge row and tv, by the group's mean density
-            const uint64_t m36 = (1ull << 36) - 1ull;
-            const uint64_t a = rem >= 36 ? (tv >> (rem - 36)) & m36 : (tv << (36 - rem)) & m36;
-            const uint64_t b = rem >= 36 ? (edge >> (rem - 36)) & m36 : (edge << (36 - rem)) & m36;
-            d = ((a > b ? a - b : b - a) * cnt) >> 36;
+        if (big ? bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit) : bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit)) return;
+        uint64_t dist = 0;
+        if (big) {  // rows between the edge row and t, by the group's mean density
+            const uint64_t a = bft_next36<W>(t, im.k, d), b = bft_next36<W>(edge, im.k, d);
+            dist = ((a > b ? a - b : b - a) * cnt) >> 36;
         }
-        if (dir < 0) guess = hi2 - lo2 > d + 1 ? hi2 - 1 - d : lo2;
-        else guess = hi2 - lo2 > d ? lo2 + d : hi2 - 1;
+        if (dir < 0) guess = hi2 - lo2 > dist + 1 ? hi2 - 1 - dist : lo2;
+        else guess = hi2 - lo2 > dist ? lo2 + dist : hi2 - 1;
     }
     while (lo2 < hi2) {
         const uint64_t mid = (lo2 + hi2) >> 1;
-        const uint64_t r = im.tk[mid];
-        if (r == tv) { hit.present = 1; hit.row = mid; return; }
-        if (r < tv) lo2 = mid + 1; else hi2 = mid;
+        uint64_t r[W];
+        bft_load_row<W>(im.tk + mid * W, r);
+        const int c = bft_cmp<W>(r, t);
+        if (c == 0) { hit.present = 1; hit.row = mid; return; }
+        if (c < 0) lo2 = mid + 1; else hi2 = mid;
     }
 }
 
-template <int W, class Root>
+template <int W, class Root, int PROBE = -1>
 BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t) {
     BftHit hit;
     hit.present = 0;
@@ -477,8 +505,8 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
         const uint64_t next36 = bft_next36<W>(t, im.k, d);
         const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
-        if (W == 1 && cnt >= BFT_WINDOW_PROBE) {
-            bft_group_probe(im, idx, cnt, g, t[0], rb + 18 * (L - 1 - d), hit);
+        if (W <= BFT_PROBE_MAX_W && cnt >= BFT_WINDOW_PROBE) {
+            bft_group_probe<W, PROBE>(im, idx, cnt, g, t, d, hit);
             return hit;
         }
 #endif

@@ -93,7 +93,7 @@ def main():
                     t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
                 torch.cuda.synchronize()
                 ms, n = t.kernel_time(reset=True)
-                print(json.dumps({"workload": wl, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "tuned": t.build_time(), "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
+                print(json.dumps({"workload": wl, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
         if args.stops:
             t.set_option("query_block", 1024)
             t.set_option("query_grid_mult", 1)
