@@ -15,10 +15,11 @@
 #define BFT_HD inline
 #endif
 
-// Suffix groups of at least this many rows are searched with one round of two 16-byte loads around the
-// interpolated guess before anything else (0 disables).  Measured on MI355X: 8 is best (config 2: +8 %).
+// Suffix groups of at least this many rows are searched with aligned block probes (bft_group_probe), smaller ones by
+// galloping from the interpolated guess (0 disables the probes).  Measured on MI355X: 4 (k=63: +6 % over 8; non-temporal
+// loads of the table rows: 1.7x slower).
 #ifndef BFT_WINDOW_PROBE
-#define BFT_WINDOW_PROBE 8
+#define BFT_WINDOW_PROBE 4
 #endif
 
 // Random 8-byte gathers from the big tables (each touched cache line is used once by the wavefront): on the
