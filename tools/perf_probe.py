@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--wgs", default="0", help="comma list of query_wgs_per_cu settings (0 = automatic)")
     ap.add_argument("--probes", default="0", help="comma list of query_probe settings (0 = automatic, 4, 8)")
     ap.add_argument("--flat-mins", default="3584", help="comma list of flat_min settings to time (65536 = flat form off)")
+    ap.add_argument("--bucket-bits", type=int, default=0, help="experiment: stable-sort the query batch by the top bits of its rotated root prefix (n2..) before timing")
     ap.add_argument("--stops", action="store_true", help="time the walk truncated after each stage (results wrong)")
     args = ap.parse_args()
     import torch
@@ -70,6 +71,14 @@ def main():
         union = S.distinct(np.concatenate(gk)) if len(gk) > 1 else gk[0]
         nq = args.queries
         dq = make_queries_on_device(union, k, nq, 5, dev)
+        if args.bucket_bits:
+            nn = (args.bucket_bits + 1) // 2
+            key = torch.zeros(nq, dtype=torch.int32, device=dev)
+            for j in range(1, 1 + nn):  # n2, n3, ...: nucleotide j (0-based) sits in byte j//4, bits 2*(j%4)
+                key = (key << 2) | ((dq[:, j // 4].to(torch.int32) >> (2 * (j % 4))) & 3)
+            order = torch.sort(key, stable=True).indices
+            dq = dq[order].contiguous()
+            del key, order
         dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
         nv = 500_000
