@@ -113,6 +113,39 @@ def test_colours(oracle_mod, k, ngen):
         assert cache[c] == omap[key]
 
 
+@pytest.mark.parametrize("ngen", [16, 17, 131, 260, 1999])
+def test_colour_rows_wide_against_ground_truth(ngen):
+    """Fixed-width colour rows for row widths around the 16-byte chunks of k_color_rows_bm (2, 3, 17, 33, 250 bytes):
+    every byte of every row against the sets that were inserted; absent k-mers give all-zero rows."""
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(6000, 91), k))
+    rng = np.random.default_rng(ngen)
+    member = rng.random((ngen, len(km))) < (0.6 if ngen < 100 else 0.08)
+    member[0, :] = True  # every k-mer is stored at least once
+    t = BFT(k)
+    for g in range(ngen):
+        t.insert_kmers(np.ascontiguousarray(km[member[g]]), g)
+    q = np.concatenate([km, S.snp_mutants(km[::3], k, 4)])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    bits, rows = t.query_color_rows(q)
+    assert rows.shape == (len(q), (ngen + 7) // 8)
+    pres = S.member(q, km)
+    assert (S.from_bits(bits, len(q)).astype(bool) == pres).all()
+    pos = {key: i for i, key in enumerate(S.row_keys(km).tolist())}
+    exp = np.zeros((len(q), ngen), dtype=np.uint8)
+    for i, key in enumerate(S.row_keys(q).tolist()):
+        if key in pos:
+            exp[i] = member[:, pos[key]]
+    got = np.unpackbits(rows, axis=1, bitorder="little")
+    assert (got[:, :ngen] == exp).all()
+    assert not got[:, ngen:].any()  # padding bits of the last byte stay zero
+    # odd batch sizes: the tail of the row stream is not a multiple of 16 bytes
+    for m in (1, 5, 63, 1000):
+        b2, r2 = t.query_color_rows(np.ascontiguousarray(q[:m]))
+        assert (r2 == rows[:m]).all()
+
+
 def test_incremental_insert_and_rebuild(oracle_mod):
     k = 27
     anc = S.random_genome(50000, 9)
