@@ -1843,6 +1843,12 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "query_wgs_per_cu") {
         if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1 or 2");
         h->opt_wgs_per_cu = (int)value;
+    } else if (nm == "reserve_pairs") {
+        // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
+        // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)
+        if (value < 0 || value >= 0x7FFFFFFFll) return fail(BFT_GPU_E_ARG, "reserve_pairs must be in [0, 2^31-1)");
+        CK(set_device(h));
+        CK(log_reserve(h, (uint64_t)value));
     } else if (nm == "query_probe") {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;

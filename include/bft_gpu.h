@@ -130,7 +130,8 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
  * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
- * (grid = resident workgroups x value), "timing" (0/1: record HIP events around query kernels), "flat_min" (CCs with at
+ * (grid = resident workgroups x value), "reserve_pairs" (room in the insertion log for this many
+ * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels), "flat_min" (CCs with at
  * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=2_000_000)
     ap.add_argument("--snp-rate", type=float, default=0.01)
     ap.add_argument("--sample", type=int, default=2_000_000)
+    ap.add_argument("--reserve", action="store_true", help="reserve the insertion log for the total up front instead of letting it grow by doubling")
     args = ap.parse_args()
     import torch
     from bloomfiltertrie_amd import BFT
@@ -51,8 +52,18 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(4242)
     anc = torch.randint(0, 4, (args.genome_len,), generator=g, device=dev, dtype=torch.uint8)
+    with BFT(args.k) as warm:  # loads the code objects and the hipCUB kernels once (≈25 ms on the first call of a process;
+        w = pack_windows(anc[:50000], args.k)  # bench.py does the same): not part of any figure
+        warm.insert_kmers_dev(w.data_ptr(), w.shape[0], 0)
+        warm.build()
+        warm.query_presence(w[:1000].cpu().numpy())
+        del w
     t = BFT(args.k)
     t_ins = 0.0
+    if args.reserve:  # the total is known up front (genomes x windows), as with the count line of a kmers_comp file
+        t0 = time.perf_counter()
+        t.set_option("reserve_pairs", args.genomes * (args.genome_len - args.k + 1))
+        t_ins += time.perf_counter() - t0
     npairs_in = 0
     per_genome_keys = []
     for gid in range(args.genomes):
@@ -93,7 +104,7 @@ def main():
     out = {
         "metric": "M (k-mer, genome) pairs/sec inserted (insertKmers bulk build)",
         "workload": f"k={args.k}, {args.genomes} genomes x {args.genome_len} nt, {args.snp_rate:.0%} SNPs, ids ascending",
-        "pairs_in": npairs_in, "pairs_distinct": info["pairs"], "distinct_kmers": info["kmers"], "colorsets": info["colorsets"],
+        "reserved": args.reserve, "warmed_up": True, "pairs_in": npairs_in, "pairs_distinct": info["pairs"], "distinct_kmers": info["kmers"], "colorsets": info["colorsets"],
         "insert_s": round(t_ins, 3), "build_s": round(t_build, 3),
         "value": round(npairs_in / (t_ins + t_build) / 1e6, 2), "unit": "M pairs/s",
         "build_breakdown_ms": {k_: round(v, 1) for k_, v in t.build_time().items()},
