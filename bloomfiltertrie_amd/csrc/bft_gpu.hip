@@ -284,56 +284,140 @@ __device__ __forceinline__ int nt_code(char c) {
     }
 }
 
-// one thread per k-mer position of the batch: (canonical) k-mer -> walk -> row in tk, or BFT_ABSENT_ROW
+// Sequence queries, step 0.  The ASCII blob -> 2 bits per character (32 characters per u64, character c at bits 2(c%32) of
+// word c/32: the packed layout of src/fasta.c:11-23 continued over the whole blob) + one "not ACGTU" bit per character.
+// One thread per 32 characters; the blob is padded to a multiple of 32 bytes.
+__global__ void k_seq_encode(const char* __restrict__ seqs, uint64_t n_words, uint64_t* __restrict__ codes, uint32_t* __restrict__ bad) {
+    for (uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4* src = (const uint4*)(seqs + wi * 32);
+        const uint4 a = src[0], b = src[1];
+        const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint64_t cw = 0;
+        uint32_t bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int code = nt_code((char)((d[j] >> (8 * c)) & 0xFFu));
+                const int i = 4 * j + c;
+                cw |= (uint64_t)(code & 3) << (2 * i);
+                bw |= (code < 0 ? 1u : 0u) << i;
+            }
+        }
+        codes[wi] = cw;
+        bad[wi] = bw;
+    }
+}
+
+// reverse the 32 two-bit fields of a word
+__device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
+    x = __brevll(x);
+    return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+}
+
+// Step 1.  One thread per k-mer position of the batch: its window is 2k bits of the code stream at a bit offset (W+1 word
+// loads + funnel shifts, O(1) instead of a scan over k characters), valid unless one of its k "bad" bits is set (windows
+// with a character outside ACGTU are skipped by the reference, src/bft.c:1298).  canonical: the reverse complement =
+// complement, reverse the 2-bit fields of the 2k-bit string; strcmp(kmer, revcomp) >= 0 -> the reverse complement is
+// searched (src/bft.c:1290-1296) = comparison of the lowest differing field.  Output: W zero-padded words per position (the
+// record layout k_query reads with a record size of 8W bytes), valid[p], seq_of[p] = the sequence of position p.
 template <int W>
-__global__ void k_seq_rows(BftImage im, const char* __restrict__ seqs, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
-                           uint32_t n_seqs, uint64_t P, int canonical, uint32_t* __restrict__ rows, uint32_t* __restrict__ seq_of) {
-    const BftRootGlobal acc(im);
-    const BftNode root = im.nodes[0];
-    const int k = im.k;
+__global__ void k_seq_pack(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
+                           const uint64_t* __restrict__ pos_off, uint32_t n_seqs, uint64_t P, int k, int canonical, uint64_t* __restrict__ words,
+                           uint8_t* __restrict__ valid, uint32_t* __restrict__ seq_of) {
     for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t lo = 0, hi = n_seqs;  // last s with pos_off[s] <= p
+        // the sequence of position p: last s with pos_off[s] <= p.  The 64 positions of a wavefront are consecutive, so the
+        // binary search runs once per wavefront on its first position (uniform values: scalar loads) and every lane
+        // walks forward from there (sequences shorter than k own no position and are stepped over).
+        const uint64_t p0 = p - (threadIdx.x & 63u);
+        const uint64_t p0u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p0 >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p0);
+        uint32_t lo = 0, hi = n_seqs;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (pos_off[mid] <= p) lo = mid; else hi = mid;
+            if (pos_off[mid] <= p0u) lo = mid; else hi = mid;
         }
-        const char* w = seqs + seq_off[lo] + (p - pos_off[lo]);
-        uint64_t xf[W], xr[W];
+        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
+        const uint64_t c0 = seq_off[lo] + (p - pos_off[lo]);  // first character of the window, as an index into the blob
+        // 2k bits of the code stream from bit 2*c0
+        const uint64_t w0 = c0 >> 5;
+        const uint32_t sh = (uint32_t)(c0 & 31u) * 2u;
+        uint64_t cw[W + 1], xf[W], xr[W];
 #pragma unroll
-        for (int q = 0; q < W; q++) { xf[q] = 0; xr[q] = 0; }
-        bool valid = true;
-        int cmp = 0;
-        for (int i = 0; i < k; i++) {
-            const int cf = nt_code(w[i]), cb = nt_code(w[k - 1 - i]);
-            if (cf < 0) { valid = false; break; }
-            const int cr = 3 - cb;  // nucleotide i of the reverse complement (cb < 0 is caught when i reaches it)
-            if (cmp == 0 && cf != cr) cmp = cf < cr ? -1 : 1;
-            const int o = 2 * i;
+        for (int q = 0; q <= W; q++) cw[q] = codes[w0 + q];  // the code array has W+1 words of slack
 #pragma unroll
-            for (int q = 0; q < W; q++)
-                if (q == (o >> 6)) { xf[q] |= (uint64_t)cf << (o & 63); xr[q] |= (uint64_t)(cr & 3) << (o & 63); }
+        for (int q = 0; q < W; q++) xf[q] = sh ? (cw[q] >> sh) | (cw[q + 1] << (64u - sh)) : cw[q];
+        const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
+        if (top < 64) xf[W - 1] &= (1ull << top) - 1ull;
+        // any bad character in [c0, c0 + k)?
+        bool ok = true;
+        {
+            const uint64_t b0 = c0 >> 5;
+            const uint32_t bs = (uint32_t)(c0 & 31u);
+            int left = k;
+            uint32_t first = bad[b0] >> bs;
+            if (left < 32 - (int)bs) first &= (1u << left) - 1u;
+            ok = first == 0;
+            left -= 32 - (int)bs;
+            for (uint64_t j = b0 + 1; left > 0; j++, left -= 32) {
+                uint32_t m = bad[j];
+                if (left < 32) m &= (1u << left) - 1u;
+                ok = ok && m == 0;
+            }
         }
-        uint32_t row = BFT_ABSENT_ROW;
-        if (valid) {
-            uint64_t t[W];
-            // strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296)
-            bft_tform_from_x<W>((canonical && cmp >= 0) ? xr : xf, im.k, t);
-            const BftHit hit = bft_walk<W, BftRootGlobal, 0>(im, acc, root, t);
-            if (hit.present) row = (uint32_t)hit.row;
+        bool use_rc = false;
+        if (canonical) {
+            // complement, then reverse the fields of the 64W-bit string and shift the 2k bits of interest back down
+            uint64_t rv[W + 1];
+#pragma unroll
+            for (int q = 0; q < W; q++) rv[q] = rev2_64(~xf[W - 1 - q]);
+            rv[W] = 0;
+            const uint32_t dn = (uint32_t)(64 * W - 2 * k);  // < 64
+#pragma unroll
+            for (int q = 0; q < W; q++) xr[q] = dn ? (rv[q] >> dn) | (rv[q + 1] << (64u - dn)) : rv[q];
+            if (top < 64) xr[W - 1] &= (1ull << top) - 1ull;
+            use_rc = true;  // equal strings: the (identical) reverse complement
+#pragma unroll
+            for (int q = W - 1; q >= 0; q--) {  // the lowest differing field decides: word 0 last
+                const uint64_t df = xf[q] ^ xr[q];
+                if (df) {
+                    const int fs = __builtin_ctzll(df) & ~1;
+                    use_rc = ((xf[q] >> fs) & 3ull) > ((xr[q] >> fs) & 3ull);
+                }
+            }
         }
-        rows[p] = row;
+#pragma unroll
+        for (int q = 0; q < W; q++) words[p * W + q] = ok ? (use_rc ? xr[q] : xf[q]) : 0ull;
+        valid[p] = ok ? 1 : 0;
         seq_of[p] = lo;
     }
 }
 
-__global__ void k_seq_count(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ seq_of, const uint32_t* __restrict__ tcol,
-                            const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t P, uint32_t G, uint32_t* __restrict__ counts) {
-    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = rows[p];
-        if (r == BFT_ABSENT_ROW) continue;
-        const uint32_t cs = tcol[r];
-        uint32_t* c = counts + (size_t)seq_of[p] * G;
-        for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) atomicAdd(&c[cs_ids[q]], 1u);
+// Step 3 (step 2 is k_query on the word records): per-(sequence, genome) counters.  Consecutive k-mers of a read mostly
+// carry the same colour set, so counting works on runs: the 64 lanes of a wavefront hold 64 consecutive positions, run
+// boundaries come from a shuffle + __ballot, and the first lane of every run of equal (sequence, colour set) adds the run
+// length (up to the end of the wavefront) once per genome of the set -- instead of one atomic per k-mer and genome.
+__global__ void k_seq_count(const uint32_t* __restrict__ rows, const uint8_t* __restrict__ valid, const uint32_t* __restrict__ seq_of,
+                            const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t P, uint32_t G,
+                            uint32_t* __restrict__ counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nblk = (P + blockDim.x - 1) / blockDim.x;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
+        const uint64_t p = blk * blockDim.x + threadIdx.x;
+        uint32_t cs = 0xFFFFFFFFu, sq = 0xFFFFFFFFu;
+        if (p < P) {
+            sq = seq_of[p];
+            const uint32_t r = rows[p];
+            if (r != BFT_ABSENT_ROW && valid[p]) cs = tcol[r];
+        }
+        const uint32_t pcs = __shfl_up(cs, 1), psq = __shfl_up(sq, 1);
+        const bool boundary = lane == 0 || pcs != cs || psq != sq;
+        const uint64_t bmask = __ballot(boundary);
+        if (boundary && cs != 0xFFFFFFFFu) {
+            const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
+            const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+            uint32_t* c = counts + (size_t)sq * G;
+            for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) atomicAdd(&c[cs_ids[q]], len);
+        }
     }
 }
 
@@ -700,6 +784,7 @@ struct bft_gpu {
     int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
     int opt_wgs_per_cu = 0;   // resident k_query workgroups per CU: 1, 2, or 0 = measured when the image is bound (tune_residency)
     int tuned_wgs = 0;        // result of that measurement (0 = none yet)
+    int rec_bytes = 0;        // bytes per input record of the next k_query launch (0 = B; 8W for the word records of the sequence path)
     int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big), 0 = measured with the residency
     int tuned_probe = 0;
     double tune_ms[2] = {0, 0};
@@ -1206,8 +1291,9 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
         HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
-    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_rows);
+    const int rec = h->rec_bytes ? h->rec_bytes : h->B;  // load_x reads `rec` bytes per k-mer; padding bytes of a word record are zero
+    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
+    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1581,15 +1667,21 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
         }
         pos_off.push_back(P);
         const uint64_t ns = b - a, nchars = seq_off[b] - seq_off[a];
-        DevBuf d_seq, d_soff, d_poff, d_min, d_rows, d_sof, d_cnt, d_out;
+        DevBuf d_seq, d_soff, d_poff, d_min, d_rows, d_sof, d_cnt, d_out, d_words, d_valid, d_bits, d_codes, d_bad;
         std::vector<uint64_t> soff(ns + 1);
         for (uint64_t i = 0; i <= ns; i++) soff[i] = seq_off[a + i] - seq_off[a];
-        CK(d_seq.alloc(nchars + 8));
+        const uint64_t n_cw = (nchars + 31) / 32;  // code words of the blob (32 characters each)
+        CK(d_seq.alloc_zero(n_cw * 32 + 32, h->stream));  // zero padding: k_seq_encode reads whole 32-byte groups
+        CK(d_codes.alloc_zero((n_cw + BFT_MAX_W + 2) * 8, h->stream));
+        CK(d_bad.alloc_zero((n_cw + BFT_MAX_W + 2) * 4, h->stream));
         CK(d_soff.alloc((ns + 1) * 8));
         CK(d_poff.alloc((ns + 1) * 8));
         CK(d_min.alloc(ns * 8));
         CK(d_rows.alloc(P * 4));
         CK(d_sof.alloc(P * 4));
+        CK(d_words.alloc(P * (uint64_t)h->W * 8));
+        CK(d_valid.alloc(P));
+        CK(d_bits.alloc(((P + 63) / 64) * 8));
         CK(d_cnt.alloc_zero(ns * (uint64_t)G * 4, h->stream));
         CK(d_out.alloc(ns * rowbytes));
         HIPCK(hipMemcpyAsync(d_seq.p, seqs + seq_off[a], nchars, hipMemcpyHostToDevice, h->stream));
@@ -1598,8 +1690,10 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
         HIPCK(hipMemcpyAsync(d_min.p, minv.data(), ns * 8, hipMemcpyHostToDevice, h->stream));
         if (P) {
             const dim3 grid(grid_for((P + 255) / 256)), block(256);
-#define SEQ(WW) hipLaunchKernelGGL(k_seq_rows<WW>, grid, block, 0, h->stream, h->im, d_seq.as<char>(), d_soff.as<uint64_t>(), d_poff.as<uint64_t>(), \
-                                   (uint32_t)ns, P, canonical, d_rows.as<uint32_t>(), d_sof.as<uint32_t>())
+            hipLaunchKernelGGL(k_seq_encode, dim3(grid_for((n_cw + 255) / 256)), dim3(256), 0, h->stream, d_seq.as<char>(), n_cw, d_codes.as<uint64_t>(),
+                               d_bad.as<uint32_t>());
+#define SEQ(WW) hipLaunchKernelGGL(k_seq_pack<WW>, grid, block, 0, h->stream, d_codes.as<uint64_t>(), d_bad.as<uint32_t>(), d_soff.as<uint64_t>(), \
+                                   d_poff.as<uint64_t>(), (uint32_t)ns, P, k, canonical, d_words.as<uint64_t>(), d_valid.as<uint8_t>(), d_sof.as<uint32_t>())
             switch (h->W) {
             case 1: SEQ(1); break;
             case 2: SEQ(2); break;
@@ -1607,8 +1701,14 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
             default: SEQ(4); break;
             }
 #undef SEQ
-            hipLaunchKernelGGL(k_seq_count, grid, block, 0, h->stream, d_rows.as<uint32_t>(), d_sof.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, P, G,
-                               d_cnt.as<uint32_t>());
+            HIPCK(hipGetLastError());
+            // the presence kernel of the k-mer queries, on records of W words (8W bytes, zero padded) instead of B bytes
+            h->rec_bytes = 8 * h->W;
+            const int rcq = launch_query(h, d_words.as<uint8_t>(), P, d_bits.as<uint64_t>(), d_rows.as<uint32_t>(), h->stream);
+            h->rec_bytes = 0;
+            CK(rcq);
+            hipLaunchKernelGGL(k_seq_count, grid, block, 0, h->stream, d_rows.as<uint32_t>(), d_valid.as<uint8_t>(), d_sof.as<uint32_t>(), h->im.tcol, h->im.cs_off,
+                               h->im.cs_ids, P, G, d_cnt.as<uint32_t>());
         }
         hipLaunchKernelGGL(k_seq_threshold, dim3(grid_for((ns * rowbytes + 255) / 256)), dim3(256), 0, h->stream, d_cnt.as<uint32_t>(), d_min.as<uint64_t>(),
                            (uint32_t)ns, G, rowbytes, d_out.as<uint8_t>());
