@@ -39,10 +39,22 @@ def test_fuzz(oracle_mod, seed):
         parts += [base[:: max(1, len(base) // 3000)], S.snp_mutants(base[:: max(1, len(base) // 2000)], k, seed)]
     q = np.concatenate(parts)
     q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    t.set_option("query_probe", int(rng.choice([0, 4, 8])))  # suffix-group probe mode: a tuning knob, same answers
     bits, off, ids = t.query_colors(q)
     obits, ooff, oids = o.query_colors(q)
     assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
     assert (t.query_presence(q) == obits).all()
+    if ngen:  # fixed-width rows and (row, colour set) locations agree with the id lists
+        _, rows = t.query_color_rows(q)
+        unp = np.unpackbits(rows, axis=1, bitorder="little")[:, :ngen]
+        exp = np.zeros_like(unp)
+        for i in range(len(q)):
+            exp[i, oids[int(ooff[i]):int(ooff[i + 1])]] = 1
+        assert (unp == exp).all()
+        b3, rws, sets = t.query_rows(q)
+        assert (b3 == obits).all()
+        pres = S.from_bits(obits, len(q)).astype(bool)
+        assert (rws[~pres] == 0xFFFFFFFF).all() and (sets[pres] != 0xFFFFFFFF).all()
     bb, bc = t.query_branching(q, with_counts=True)
     ob, oc, _ = o.query_branching(q)
     assert (bc == oc).all() and (bb == ob).all()
