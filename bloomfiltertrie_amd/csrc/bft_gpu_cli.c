@@ -237,6 +237,10 @@ static void extract_kmers(bft_gpu* h, const char* path, int k, int compressed) {
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "-v") == 0)) { /* src/main.c:51-55 */
+        fprintf(stderr, "0.8 (%s)\n", bft_gpu_version());
+        return 0;
+    }
     if (argc < 3)
         DIE("\nUsage:\n"
             "bft_gpu build k {kmers|kmers_comp} list_genome_files output_file\n"
