@@ -90,3 +90,57 @@ def test_union_is_or_of_genomes():
         assert (pg == unp[:, g]).all()  # colour g of the whole index == presence in genome g's own index
         acc |= pg
     assert (w == acc).all()
+
+
+def test_host_entry_points_across_their_chunk_boundaries():
+    """The host-buffer entry points work in chunks (2^26 k-mers for presence / branching, 2^24 for colour lists and row
+    locations, 2^22 for colour rows): batches one chunk plus a ragged tail long, checked against ground truth and against
+    each other, so that bitmap bytes, offsets and rows line up across the boundary."""
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    anc = S.random_genome(200000, 3)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 40 + g), k)) for g in range(3)]
+    t = BFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+    allk = S.distinct(np.concatenate(gk))
+    base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])
+    rng = np.random.default_rng(1)
+
+    def batch(n):
+        return np.ascontiguousarray(base[rng.integers(0, len(base), n)])
+
+    # presence: 2^26 + 777
+    n = (1 << 26) + 777
+    q = batch(n)
+    bits = t.query_presence(q)
+    truth = S.member(q, allk)
+    assert (S.from_bits(bits, n).astype(bool) == truth).all()
+    # colour lists and row locations: 2^24 + 13 (a prefix of the same batch)
+    m = (1 << 24) + 13
+    b2, off, ids = t.query_colors(q[:m])
+    assert (S.from_bits(b2, m).astype(bool) == truth[:m]).all()
+    assert off[0] == 0 and (np.diff(off.astype(np.int64)) >= 0).all() and off[-1] == len(ids)
+    assert ((np.diff(off.astype(np.int64)) > 0) == truth[:m]).all()
+    b3, rows, sets = t.query_rows(q[:m])
+    assert (b3 == b2).all() and ((rows != 0xFFFFFFFF) == truth[:m]).all()
+    stored, cs = t.extract()
+    pr = truth[:m]
+    assert (stored[rows[pr]] == q[:m][pr]).all() and (cs[rows[pr]] == sets[pr]).all()
+    # sizes of the id lists around the 2^24 boundary == sizes of the colour sets found by query_rows
+    set_size = {c: len(t.colorset(c)) for c in np.unique(sets[pr]).tolist()}
+    for i in list(range((1 << 24) - 50, m)):
+        assert int(off[i + 1] - off[i]) == (set_size[int(sets[i])] if pr[i] else 0)
+    # colour rows: 2^22 + 5
+    r = (1 << 22) + 5
+    b4, crow = t.query_color_rows(q[:r])
+    assert (S.from_bits(b4, r).astype(bool) == truth[:r]).all()
+    unp = np.unpackbits(crow, axis=1, bitorder="little")[:, :3]
+    assert (unp.any(axis=1) == truth[:r]).all()
+    for i in list(range((1 << 22) - 20, r)) + list(range(0, 20)):
+        have = ids[int(off[i]):int(off[i + 1])].tolist()
+        assert np.flatnonzero(unp[i]).tolist() == have
+    # branching: same boundary as presence; idempotent and equal to the device-side popcount on a slice
+    bb = t.query_branching(q)
+    bb2 = t.query_branching(q[: (1 << 26)])
+    assert (bb[: (1 << 23)] == bb2).all()
