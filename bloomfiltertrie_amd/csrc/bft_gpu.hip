@@ -542,7 +542,9 @@ __device__ __forceinline__ uint32_t color_dword(const uint32_t* __restrict__ tro
 // Every thread works on CR_UNROLL dwords (one per grid stride) at a time, stage by stage (row index -> colour set -> bitmap
 // dwords).  Dwords that straddle rows go through color_dword.  Measured (config 5, 250-byte rows, 10^9 bytes out): 0.83 ms
 // = 1.2 TB/s written; byte gathers from unpadded dictionary rows took 1.2 ms; 16-byte chunks per thread were slower (a
-// wavefront then touches four dictionary rows per load instruction), more chains in flight per thread changed nothing.  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
+// wavefront then touches four dictionary rows per load instruction), more chains in flight per thread changed nothing,
+// non-temporal stores neither; without the dictionary reads or without the stores the kernel is only 17 % faster either
+// way: at 4 bytes per thread it is bound by its own index arithmetic (~30 instructions per dword).  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
 // a tile are 32-bit and byte / rowbytes is a multiply-high by the host's magic number (div_m, div_l; exact on u32).
 #define CR_UNROLL 4
 __global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm, uint32_t stride,
