@@ -544,7 +544,7 @@ __device__ __forceinline__ uint32_t color_dword(const uint32_t* __restrict__ tro
 // = 1.2 TB/s written; byte gathers from unpadded dictionary rows took 1.2 ms; 16-byte chunks per thread were slower (a
 // wavefront then touches four dictionary rows per load instruction), more chains in flight per thread changed nothing,
 // non-temporal stores neither; without the dictionary reads or without the stores the kernel is only 17 % faster either
-// way: at 4 bytes per thread it is bound by its own index arithmetic (~30 instructions per dword).  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
+// way; 8 bytes per thread (three source dwords, one 8-byte store) was 30 % slower again, like the 16-byte variant.  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
 // a tile are 32-bit and byte / rowbytes is a multiply-high by the host's magic number (div_m, div_l; exact on u32).
 #define CR_UNROLL 4
 __global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm, uint32_t stride,
