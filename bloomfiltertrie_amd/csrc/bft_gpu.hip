@@ -228,14 +228,9 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
 #pragma unroll
             for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
             bft_tform_from_x<W>(y, k, t);
-            int cr = 0, cl = 0;
-            for (uint64_t nt = 0; nt < 4 && (counts || cr < 2); nt++) {
-                uint64_t tt[W];
-#pragma unroll
-                for (int w = 0; w < W; w++) tt[w] = t[w];
-                tt[W - 1] |= nt << (rb ? 0 : 2);  // last nucleotide: n9 of the last prefix, or the end of the k % 9 remainder
-                cr += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
-            }
+            int cl = 0;
+            // the four successors differ in the last nucleotide only: one shared descent, four finishes
+            const int cr = bft_walk_last4<W, BftRootLds<STAGED>>(im, acc, root, t, counts != nullptr);
             if (counts || cr < 2) {
                 // predecessors: shift in a wildcard first nucleotide, drop the last one
 #pragma unroll

@@ -446,16 +446,35 @@ BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint
     }
 }
 
+// Search of the suffix group [idx, idx+cnt) of level d for t (src/presenceNode.c:1874-1915): interpolate on the next two
+// prefixes, then block probes (groups of >= BFT_WINDOW_PROBE rows of one or two words) or a galloping search.
+template <int W, int PROBE>
+BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit) {
+    const uint64_t next36 = bft_next36<W>(t, im.k, d);
+    const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
+#if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
+    if (W <= BFT_PROBE_MAX_W && cnt >= BFT_WINDOW_PROBE) {
+        bft_group_probe<W, PROBE>(im, idx, cnt, g, t, d, hit);
+        return;
+    }
+#endif
+    const uint64_t* rows = im.tk + idx * W;
+    const int z = bft_rows_find<W>(rows, cnt, t, g);
+    if (z >= 0) { hit.present = 1; hit.row = idx + (uint32_t)z; }
+}
+
+// start_node / d0: the walk normally starts at the root (level 0); bft_walk_last4 resumes it at the last level of a node
+// it has already reached.
 template <int W, class Root, int PROBE = -1>
-BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t) {
+BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& start_node, const uint64_t* t, const int d0 = 0) {
     BftHit hit;
     hit.present = 0;
     hit.row = 0;
     uint32_t node = 0;
     const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
-    for (int d = 0; d < L; d++) {
+    for (int d = d0; d < L; d++) {
         BftNode nd;
-        if (d == 0) nd = root_node;
+        if (d == d0) nd = start_node;
         else nd = im.nodes[node];
         const uint32_t r = bft_digit<W>(t, im.k, d);
         // Which CC: the first one whose Bloom filter holds the key (src/presenceNode.c:1353-1362).  A node with ONE CC needs
@@ -502,19 +521,166 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& root
             cnt = BFT_REM_COUNT(e);  // remainder group: count-1 on 16 bits
             idx = BFT_REM_ROW(e);
         } else if (cnt == 0) { node = (uint32_t)idx; continue; }          // child Node (src/presenceNode.c:1867)
-        // suffix group of cnt rows (src/presenceNode.c:1874-1915): interpolate on the next two prefixes
-        const uint64_t next36 = bft_next36<W>(t, im.k, d);
-        const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
-#if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
-        if (W <= BFT_PROBE_MAX_W && cnt >= BFT_WINDOW_PROBE) {
-            bft_group_probe<W, PROBE>(im, idx, cnt, g, t, d, hit);
-            return hit;
-        }
-#endif
-        const uint64_t* rows = im.tk + idx * W;
-        const int z = bft_rows_find<W>(rows, cnt, t, g);
-        if (z >= 0) { hit.present = 1; hit.row = idx + (uint32_t)z; }
+        bft_group_search<W, PROBE>(im, idx, cnt, t, d, hit);  // suffix group of cnt rows
         return hit;
     }
     return hit;
+}
+
+// How many of the four rows t | v << vo (v = 0..3; t has those two bits clear) the suffix group [idx, idx+cnt) holds.  The
+// four values lie within 13 consecutive integers, so their rows are neighbours in the sorted group: ONE search for the
+// first row >= t (64-byte block probes from the interpolated guess, as in bft_group_probe, then a binary search), then a
+// scan of the few rows up to t | 3 << vo.  Four separate searches cost four times the gathers even though they end in the
+// same cache lines (a lane's line rarely survives in the L1 between two of its own probes).
+template <int W>
+BFT_HD int bft_group_count4(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, int vo, bool need_all) {
+    constexpr int NR = W == 1 ? 8 : 4;
+    const uint64_t end = idx + cnt;
+    uint64_t th[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) th[w] = t[w];
+    th[W - 1] |= 3ull << vo;
+    uint64_t lo2 = idx, hi2 = end;  // rows before lo2 are < t; rows from hi2 on are >= t
+    uint64_t guess = idx + (uint32_t)((bft_next36<W>(t, im.k, d) * cnt) >> 36);
+    uint64_t p = ~0ull;             // position of the first row >= t, once known
+#pragma unroll
+    for (int step = 0; step < BFT_PROBE_STEPS && p == ~0ull; step++) {
+        const uint64_t ga = guess & ~(uint64_t)(NR - 1);
+        uint64_t w[NR][W];
+        if (W == 1) {
+#pragma unroll
+            for (int j = 0; j < NR; j += 2) bft_load_pair(im, ga + j, &w[j][0], &w[j + 1][0]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                bft_load_row<W>(im.tk + (ga + j) * W, w[j]);
+#else
+                for (int x = 0; x < W; x++) w[j][x] = ga + j < im.n_kmers ? im.tk[(ga + j) * W + x] : ~0ull;
+#endif
+            }
+        }
+        uint32_t nin = 0, nlt = 0;
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const uint64_t gi = ga + j;
+            const bool in = gi >= lo2 && gi < hi2;
+            nin += in;
+            nlt += in && bft_cmp<W>(w[j], t) < 0;
+        }
+        const uint64_t first_in = ga > lo2 ? ga : lo2, end_in = ga + NR < hi2 ? ga + NR : hi2;
+        if (nlt == nin) {              // every bracket row of the block is below t
+            lo2 = end_in;
+            if (lo2 >= hi2) p = lo2; else guess = lo2;
+        } else if (nlt == 0 && first_in > lo2) {  // every one is >= t and rows remain on the left
+            hi2 = first_in;
+            guess = hi2 - 1;
+        } else
+            p = first_in + nlt;
+    }
+    if (p == ~0ull) {
+        while (lo2 < hi2) {
+            const uint64_t mid = (lo2 + hi2) >> 1;
+            uint64_t r[W];
+            bft_load_row<W>(im.tk + mid * W, r);
+            if (bft_cmp<W>(r, t) < 0) lo2 = mid + 1; else hi2 = mid;
+        }
+        p = lo2;
+    }
+    int count = 0;
+    for (uint64_t j = p; j < end; j++) {
+        uint64_t r[W];
+        bft_load_row<W>(im.tk + j * W, r);
+        if (bft_cmp<W>(r, th) > 0) break;
+        bool same = ((r[W - 1] ^ t[W - 1]) & ~(3ull << vo)) == 0;
+#pragma unroll
+        for (int w = 0; w + 1 < W; w++) same = same && r[w] == t[w];
+        count += same;
+        if (!need_all && count >= 2) break;
+    }
+    return count;
+}
+
+// The four k-mers t | v << vo (v = 0..3) that differ only in their LAST nucleotide (vo = 2: n9 of the last prefix; vo = 0:
+// the end of the k % 9 remainder) -- the successors of a k-mer (src/branchingNode.c:16-112; src/presenceNode.c:15-1211
+// shares the descent the same way).  They take the same path through every level that does not hold the varying bits: one
+// descent with the routing of bft_walk (kept as its own copy so that the presence kernel's code is untouched), then four
+// finishes in the container the path ends in -- the same suffix group, the same node UC, or the same last-level node.
+// Returns how many of the four are present (stops at two unless need_all).
+template <int W, class Root>
+BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& root_node, const uint64_t* t, bool need_all) {
+    const int L = im.L, rb = 2 * (im.k - 9 * im.L);
+    const int vo = rb ? 0 : 2;
+    int count = 0;
+    uint32_t node = 0;
+    uint64_t tt[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) tt[w] = t[w];
+    for (int d = 0; d < L; d++) {
+        BftNode nd;
+        if (d == 0) nd = root_node;
+        else nd = im.nodes[node];
+        if (rb == 0 && d == L - 1) {  // the last prefix itself varies: four prefixes of this node
+            for (uint64_t v = 0; v < 4 && (need_all || count < 2); v++) {
+                tt[W - 1] = t[W - 1] | (v << vo);
+                count += bft_walk<W, Root, 0>(im, root, nd, tt, d).present;
+            }
+            return count;
+        }
+        const uint32_t r = bft_digit<W>(t, im.k, d);
+#ifdef BFT_NO_SINGLE
+        const bool single = false;
+#else
+        const bool single = d > 0 && nd.ncc == 1;
+#endif
+        int c = single ? 0 : -1;
+        if (nd.ncc && !single) {
+            const uint32_t hm = root.hashmod(r >> 4);
+            if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
+            else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
+        }
+        uint64_t e = 0;
+        bool stop = false, found = false;
+        if (c >= 0) {
+            BftCCX cc;
+            if (d == 0) cc = root.root_cc(nd, c);
+            else {
+                const BftCCX* px = &im.ccx[nd.cc_first + c];
+                const BftCC hd = *(const BftCC*)px;
+                cc.f2_off = hd.f2_off; cc.clus_off = hd.clus_off; cc.child_off = hd.child_off; cc.nb_elem = hd.nb_elem; cc.s = hd.s; cc.flat = hd.pad0;
+                cc.f18_off = 0; cc.fent_off = 0;
+                if (cc.flat) { cc.f18_off = px->f18_off; cc.fent_off = px->fent_off; }
+            }
+            found = bft_cc_lookup(im, cc, r, &e, &stop);
+            if (!found && !single) return 0;  // Bloom-positive CC without the prefix: all four absent
+        }
+        if (!found) {  // the node's UC holds whole k-mers: four searches
+            for (uint64_t v = 0; v < 4 && (need_all || count < 2); v++) {
+                BftHit hit;
+                hit.present = 0;
+                hit.row = 0;
+                tt[W - 1] = t[W - 1] | (v << vo);
+                bft_uc_search<W>(im, nd, tt, hit);
+                count += hit.present;
+            }
+            return count;
+        }
+        uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
+        uint64_t idx = e & BFT_CHILD_IDX_MASK;
+        if (d == L - 1) {  // rb != 0 here: the remainder group of this prefix holds all four
+            cnt = BFT_REM_COUNT(e);
+            idx = BFT_REM_ROW(e);
+        } else if (cnt == 0) { node = (uint32_t)idx; continue; }
+        if (W <= BFT_PROBE_MAX_W) return bft_group_count4<W>(im, idx, cnt, t, d, vo, need_all);
+        for (uint64_t v = 0; v < 4 && (need_all || count < 2); v++) {
+            BftHit hit;
+            hit.present = 0;
+            hit.row = 0;
+            tt[W - 1] = t[W - 1] | (v << vo);
+            bft_group_search<W, 0>(im, idx, cnt, tt, d, hit);
+            count += hit.present;
+        }
+        return count;
+    }
+    return count;
 }
