@@ -781,7 +781,6 @@ struct bft_gpu {
     int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
     int opt_wgs_per_cu = 0;   // resident k_query workgroups per CU: 1, 2, or 0 = measured when the image is bound (tune_residency)
     int tuned_wgs = 0;        // result of that measurement (0 = none yet)
-    int rec_bytes = 0;        // bytes per input record of the next k_query launch (0 = B; 8W for the word records of the sequence path)
     int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big), 0 = measured with the residency
     int tuned_probe = 0;
     double tune_ms[2] = {0, 0};
@@ -1272,7 +1271,7 @@ static int query_residency(const bft_gpu* h) {
 }
 
 template <int W, int BLOCK, bool STAGED, int PROBE>
-static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
     // one workgroup per CU the request is padded past half the LDS so that the dispatcher cannot pair two on a CU.
     const int wgs = query_residency(h);
@@ -1288,7 +1287,7 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
         HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    const int rec = h->rec_bytes ? h->rec_bytes : h->B;  // load_x reads `rec` bytes per k-mer; padding bytes of a word record are zero
+    // rec: bytes per input record (B, or 8W for the zero-padded word records of the sequence path); load_x reads that many
     if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
     else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
     HIPCK(hipGetLastError());
@@ -1296,24 +1295,25 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
 }
 
 template <int W, bool STAGED>
-static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     if (h->opt_block == 1024) {
-        if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, 1024, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s);
-        return launch_query_k<W, 1024, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s);
+        if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, 1024, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+        return launch_query_k<W, 1024, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
     }
-    if (h->opt_block == 768) return launch_query_k<W, 768, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
-    if (h->opt_block == 512) return launch_query_k<W, 512, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
-    return launch_query_k<W, 256, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s);
+    if (h->opt_block == 768) return launch_query_k<W, 768, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (h->opt_block == 512) return launch_query_k<W, 512, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    return launch_query_k<W, 256, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
 template <int W>
-static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s);
+    return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s, rec) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
-static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s) {
+static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
+    const int rec = rec_bytes ? rec_bytes : h->B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         HIPCK(hipEventCreate(&e0));
@@ -1321,10 +1321,10 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         HIPCK(hipEventRecord(e0, s));
     }
     switch (h->W) {
-    case 1: CK(launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s)); break;
-    case 2: CK(launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s)); break;
-    case 3: CK(launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s)); break;
-    default: CK(launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s)); break;
+    case 1: CK(launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
+    case 2: CK(launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
+    case 3: CK(launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
+    default: CK(launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
     }
     if (h->timing) {
         HIPCK(hipEventRecord(e1, s));
@@ -1700,10 +1700,7 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
 #undef SEQ
             HIPCK(hipGetLastError());
             // the presence kernel of the k-mer queries, on records of W words (8W bytes, zero padded) instead of B bytes
-            h->rec_bytes = 8 * h->W;
-            const int rcq = launch_query(h, d_words.as<uint8_t>(), P, d_bits.as<uint64_t>(), d_rows.as<uint32_t>(), h->stream);
-            h->rec_bytes = 0;
-            CK(rcq);
+            CK(launch_query(h, d_words.as<uint8_t>(), P, d_bits.as<uint64_t>(), d_rows.as<uint32_t>(), h->stream, 8 * h->W));
             hipLaunchKernelGGL(k_seq_count, grid, block, 0, h->stream, d_rows.as<uint32_t>(), d_valid.as<uint8_t>(), d_sof.as<uint32_t>(), h->im.tcol, h->im.cs_off,
                                h->im.cs_ids, P, G, d_cnt.as<uint32_t>());
         }
