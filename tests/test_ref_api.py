@@ -76,6 +76,31 @@ def test_reference_style_program_compiles_and_links(built, tmp_path):
     assert r.returncode == 2 and "usage" in r.stderr
 
 
+def test_header_is_usable_from_cpp(built, tmp_path):
+    """README.md:100-111 of the reference: C++ programs wrap the include in extern "C" and link -lbft."""
+    src = tmp_path / "user.cpp"
+    src.write_text('''
+extern "C" {
+    #include <bft/bft.h>
+}
+#include <cstdio>
+int main(int argc, char**) {
+    if (argc > 5) {  // never run here: only has to compile and link
+        BFT* g = create_cdbg(27, 0);
+        BFT_kmer* km = get_kmer("ACGTACGTACGTACGTACGTACGTACG", g);
+        std::printf("%d\\n", (int)is_kmer_in_cdbg(km));
+        free_BFT_kmer(km, 1);
+        free_cdbg(g);
+    }
+    return 0;
+}
+''')
+    exe = str(tmp_path / "user")
+    subprocess.check_call(["g++", "-fpermissive", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src), "-L", _lib.CSRC, "-lbft",
+                           f"-Wl,-rpath,{_lib.CSRC}", f"-Wl,-rpath-link,{_lib.CSRC}", "-Wl,-rpath-link,/opt/rocm/lib"])
+    assert subprocess.run([exe]).returncode == 0
+
+
 def _neighbour_bits(kmer, side, present):
     out = ""
     for c in "ACGT":
