@@ -63,3 +63,47 @@ def test_fuzz(oracle_mod, seed):
     ek, _ = t.extract()
     ok, _ = o.extract()
     assert sorted(map(bytes, ek)) == sorted(map(bytes, ok))
+
+
+def _keys64(packed):
+    pad = np.zeros((len(packed), 8), dtype=np.uint8)
+    pad[:, :packed.shape[1]] = packed
+    return pad.view(np.uint64).reshape(-1)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_fuzz_large_groups_against_ground_truth(seed):
+    """Bigger indexes than the oracle-checked fuzz: suffix groups of up to 255 rows, child Nodes, remainder groups (k = 31),
+    every probe mode and residency; presence and branching counts against set arithmetic on the integer form of the k-mers."""
+    from bloomfiltertrie_amd import BFT
+    rng = np.random.default_rng(77 + seed)
+    k = int(rng.choice([27, 31, 18]))
+    n = int(rng.choice([300_000, 1_000_000]))
+    if seed % 2:
+        base = S.low_entropy_kmers(n, k, int(rng.integers(3, 400)), seed=seed, levels=int(rng.integers(1, k // 9 + 1)))
+    else:
+        base = S.distinct(S.kmers_of(S.random_genome(n, 100 + seed), k))
+    t = BFT(k)
+    t.insert_kmers(base[: len(base) // 2], 0)
+    t.insert_kmers(base[len(base) // 3:], 1)
+    keys = np.unique(_keys64(base))
+    q = np.concatenate([base[:: max(1, len(base) // 200_000)], S.snp_mutants(base[:: max(1, len(base) // 200_000)], k, seed),
+                        S.pack_codes(rng.integers(0, 4, (5000, k), dtype=np.uint8))])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    qk = _keys64(q)
+    truth = np.isin(qk, keys)
+    mask = np.uint64((1 << (2 * k)) - 1)
+    succ = np.zeros(len(q), dtype=np.int64)
+    pred = np.zeros(len(q), dtype=np.int64)
+    for nt in range(4):
+        succ += np.isin((qk >> np.uint64(2)) | np.uint64(nt << (2 * (k - 1))), keys)
+        pred += np.isin(((qk << np.uint64(2)) & mask) | np.uint64(nt), keys)
+    exp_counts = ((succ << 4) | pred).astype(np.uint8)
+    for wgs, probe in [(0, 0), (1, 4), (2, 8), (1, 8), (2, 4)]:
+        t.set_option("query_wgs_per_cu", wgs)
+        t.set_option("query_probe", probe)
+        assert (S.from_bits(t.query_presence(q), len(q)).astype(bool) == truth).all(), (k, n, wgs, probe)
+        bb, bc = t.query_branching(q, with_counts=True)
+        assert (bc == exp_counts).all(), (k, n, wgs, probe)
+        assert (S.from_bits(bb, len(q)).astype(bool) == ((succ > 1) | (pred > 1))).all()
+        assert (t.query_branching(q) == bb).all()  # early-exit variant
