@@ -747,6 +747,11 @@ struct bft_gpu {
     uint32_t log_last_gid = 0, store_max_gid = 0;
     bool store_any = false;
 
+    // Small host batches (the per-k-mer calls of <bft/bft.h>, 4096-byte file chunks): a pinned, device-mapped staging
+    // block the kernels read and write directly -- one launch + one stream wait instead of two staged copies around it.
+    uint8_t* pin = nullptr;  // [PIN_IN bytes of k-mers | bits | rows | colour sets]
+    ~bft_gpu() { if (pin) (void)hipHostFree(pin); }
+
     // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
     DevBuf log_k, log_g;
     uint64_t log_n = 0, log_cap = 0;
@@ -1505,10 +1510,47 @@ extern "C" int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint6
     return launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, nullptr, s);
 }
 
+// ---- small host batches through the pinned block -------------------------------------------------------------------------
+#define BFT_PIN_MAX_N 4096u                       // k-mers per call served this way
+#define BFT_PIN_IN (BFT_PIN_MAX_N * 32u)          // B <= 32 bytes per k-mer
+#define BFT_PIN_BITS_OFF BFT_PIN_IN
+#define BFT_PIN_ROWS_OFF (BFT_PIN_BITS_OFF + BFT_PIN_MAX_N / 8u)
+#define BFT_PIN_SETS_OFF (BFT_PIN_ROWS_OFF + BFT_PIN_MAX_N * 4u)
+#define BFT_PIN_BYTES (BFT_PIN_SETS_OFF + BFT_PIN_MAX_N * 4u)
+
+static int pin_block(bft_gpu* h) {
+    if (h->pin) return 0;
+    void* p = nullptr;
+    HIPCK(hipHostMalloc(&p, BFT_PIN_BYTES, hipHostMallocMapped));
+    h->pin = (uint8_t*)p;
+    return 0;
+}
+
+// presence (+ rows, + colour-set ids) of n <= BFT_PIN_MAX_N host k-mers; any output pointer may be NULL
+static int query_small(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint32_t* rows, uint32_t* colorsets) {
+    CK(pin_block(h));
+    uint8_t* pin = h->pin;
+    memcpy(pin, kmers, n * h->B);
+    uint32_t* prow = (uint32_t*)(pin + BFT_PIN_ROWS_OFF);
+    uint32_t* pset = (uint32_t*)(pin + BFT_PIN_SETS_OFF);
+    const bool want_rows = rows || colorsets;
+    CK(launch_query(h, pin, n, (uint64_t*)(pin + BFT_PIN_BITS_OFF), want_rows ? prow : nullptr, h->stream));
+    if (colorsets) {
+        hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((n + 255) / 256)), dim3(256), 0, h->stream, prow, h->im.tcol, n, pset);
+        HIPCK(hipGetLastError());
+    }
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (present_bits) memcpy(present_bits, pin + BFT_PIN_BITS_OFF, (n + 7) / 8);
+    if (rows) memcpy(rows, prow, n * 4);
+    if (colorsets) memcpy(colorsets, pset, n * 4);
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits) {
     if (!h || ((!kmers || !present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     CK(set_device(h));
     CK(ensure_built(h));
+    if (n && n <= BFT_PIN_MAX_N) return query_small(h, kmers, n, present_bits, nullptr, nullptr);
     const uint64_t chunk = 1ull << 26;  // multiple of 64: chunks are byte aligned in the bitmap
     DevBuf dk, db;
     CK(dk.alloc(std::min(n, chunk) * h->B));
@@ -2048,6 +2090,7 @@ extern "C" int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, 
     if (!h || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     CK(set_device(h));
     CK(ensure_built(h));
+    if (n && n <= BFT_PIN_MAX_N) return query_small(h, kmers, n, present_bits, rows, colorsets);
     const uint64_t chunk = 1ull << 24;
     const uint64_t mc = std::min(n, chunk);
     DevBuf dk, db, dr, dc;

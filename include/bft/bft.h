@@ -13,7 +13,7 @@
  *     treshold_compression) and a handle instead of the host trie; resultPresence holds indexes instead of host
  *     pointers (its link_child is still non-NULL exactly when the k-mer is stored, which is what is_kmer_in_cdbg
  *     tests, src/bft.c:246-248);
- *   - every call is one (small) GPU batch, about 45 us; loops over many k-mers should use the batched entry points of
+ *   - every call is one (small) GPU batch, about 24 us; loops over many k-mers should use the batched entry points of
  *     bft_gpu.h on bft_device_index(bft) -- that is the point of the GPU path;
  *   - insertions are collected on the GPU and the containers are rebuilt in bulk by the first query after them;
  *   - there is no CPU fallback: without a usable GPU every function reports the error and exits.

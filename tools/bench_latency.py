@@ -30,4 +30,14 @@ for timing in (1, 0):
             t.query_presence(q)
         dt = (time.perf_counter() - t0) / reps
         out[f"timing={timing},n={n}"] = {"us_per_call": round(dt * 1e6, 1), "M_kmers_per_s": round(n / dt / 1e6, 2)}
+t.set_option("timing", 0)
+for n in (1, 8, 585):  # what get_kmer / get_neighbors of <bft/bft.h> cost: presence + row + colour-set id per k-mer
+    q = np.ascontiguousarray(km[:n])
+    for _ in range(20):
+        t.query_rows(q)
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        t.query_rows(q)
+    dt = (time.perf_counter() - t0) / 2000
+    out[f"query_rows,n={n}"] = {"us_per_call": round(dt * 1e6, 1)}
 print(json.dumps(out))
