@@ -2038,12 +2038,21 @@ extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     return BFT_GPU_OK;
 }
 
+// stored T-form rows -> packed k-mers (the reference's layout), on the GPU: bft_gpu_extract copies bytes, not keys
 template <int W>
-static void unpack_rows(const std::vector<uint64_t>& tk, uint64_t n, int k, int B, uint8_t* out) {
-    for (uint64_t i = 0; i < n; i++) {
-        uint64_t x[W];
-        bft_x_from_tform<W>(&tk[i * W], k, x);
-        for (int b = 0; b < B; b++) out[i * B + b] = (uint8_t)(x[b >> 3] >> (8 * (b & 7)));
+__global__ void k_tform_to_packed(const uint64_t* __restrict__ tk, uint64_t n, int k, int B, uint8_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t t[W], x[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) t[w] = tk[i * W + w];
+        bft_x_from_tform<W>(t, k, x);
+        for (int b = 0; b < B; b++) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++)
+                if (w == (b >> 3)) v = x[w];
+            out[i * B + b] = (uint8_t)(v >> (8 * (b & 7)));
+        }
     }
 }
 
@@ -2056,14 +2065,18 @@ extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorse
     if (cap < h->n_kmers) return fail(BFT_GPU_E_NOSPACE, "extract buffer too small");
     const uint64_t n = h->n_kmers;
     if (kmers_out && n) {
-        std::vector<uint64_t> tk(n * h->W);
-        HIPCK(hipMemcpy(tk.data(), h->d_tk.p, n * h->W * 8, hipMemcpyDeviceToHost));
+        DevBuf packed;
+        CK(packed.alloc(n * h->B));
+        const dim3 grid(grid_for((n + 255) / 256)), block(256);
         switch (h->W) {
-        case 1: unpack_rows<1>(tk, n, h->k, h->B, kmers_out); break;
-        case 2: unpack_rows<2>(tk, n, h->k, h->B, kmers_out); break;
-        case 3: unpack_rows<3>(tk, n, h->k, h->B, kmers_out); break;
-        default: unpack_rows<4>(tk, n, h->k, h->B, kmers_out); break;
+        case 1: hipLaunchKernelGGL(k_tform_to_packed<1>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), n, h->k, h->B, packed.as<uint8_t>()); break;
+        case 2: hipLaunchKernelGGL(k_tform_to_packed<2>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), n, h->k, h->B, packed.as<uint8_t>()); break;
+        case 3: hipLaunchKernelGGL(k_tform_to_packed<3>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), n, h->k, h->B, packed.as<uint8_t>()); break;
+        default: hipLaunchKernelGGL(k_tform_to_packed<4>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), n, h->k, h->B, packed.as<uint8_t>()); break;
         }
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(kmers_out, packed.p, n * h->B, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
     }
     if (colorset_out && n) HIPCK(hipMemcpy(colorset_out, h->d_tcol.p, n * 4, hipMemcpyDeviceToHost));
     return BFT_GPU_OK;
