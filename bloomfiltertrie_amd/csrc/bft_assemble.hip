@@ -777,13 +777,45 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// signature of the sorted genome-id list of each k-mer
-__global__ void k_cs_sig(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint64_t* __restrict__ sig, uint32_t* __restrict__ iota) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
-        uint64_t h = 0x9E3779B97F4A7C15ULL ^ (seg_off[i + 1] - seg_off[i]);
-        for (uint32_t q = seg_off[i]; q < seg_off[i + 1]; q++) h = mix64(h ^ (pg[q] + 0x632BE59BD9B4E019ULL)) * 0x100000001B3ULL + pg[q];
-        sig[i] = h;
-        iota[i] = i;
+// The genome-id lists of the index are bimodal (a k-mer of the shared ancestor sits in most genomes, a k-mer around a SNP in
+// one), so one-thread-per-list loops leave most lanes idle for the length of the longest list of the wavefront.  The lists
+// of 64 consecutive k-mers are ONE contiguous range of pg: the kernels below let the wavefront stream that range coalesced,
+// each element finding its list by a binary search over the lanes' start offsets (6 shuffles).
+// lane s owns the list pg[a_s, ...): the largest lane whose start is <= e (starts are non-decreasing over the lanes)
+__device__ __forceinline__ uint32_t wave_list_of(uint32_t e, uint32_t a) {
+    uint32_t lo = 0, hi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {  // every lane takes part in every shuffle
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        const uint32_t am = __shfl(a, mid);
+        if (am <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// signature of the sorted genome-id list of each k-mer: a sum of mixed ids (order-free, so that the elements can be added
+// in any order by any lane) mixed with the length
+__global__ __launch_bounds__(ABLK) void k_cs_sig(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint64_t* __restrict__ sig,
+                                                 uint32_t* __restrict__ iota) {
+    __shared__ unsigned long long acc[ABLK];
+    const uint32_t lane = threadIdx.x & 63u, w0 = threadIdx.x & ~63u;
+    const uint32_t nblk = (nk + ABLK - 1) / ABLK;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
+        const uint32_t i = blk * ABLK + threadIdx.x;
+        const bool valid = i < nk;
+        const uint32_t a = seg_off[valid ? i : nk], b = seg_off[valid ? i + 1 : nk];
+        const uint32_t base = __shfl(a, 0), end = __shfl(b, 63);
+        acc[threadIdx.x] = 0ull;
+        for (uint32_t e0 = base; e0 < end; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool in = e < end;
+            const uint32_t s = wave_list_of(in ? e : end - 1, a);
+            if (in) atomicAdd(&acc[w0 + s], (unsigned long long)mix64((uint64_t)pg[e] + 0x632BE59BD9B4E019ULL));
+        }
+        if (valid) {
+            sig[i] = mix64((uint64_t)acc[threadIdx.x] ^ ((uint64_t)(b - a) * 0x9E3779B97F4A7C15ULL));
+            iota[i] = i;
+        }
     }
 }
 
@@ -807,29 +839,63 @@ __global__ void k_cs_heads(const uint64_t* __restrict__ sig_s, const uint32_t* _
     }
 }
 
-__global__ void k_cs_assign(const uint32_t* __restrict__ order, const uint32_t* __restrict__ head, const uint32_t* __restrict__ csid_ex,
-                            const uint32_t* __restrict__ off_ex, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk,
-                            uint32_t* __restrict__ tcol, uint32_t* __restrict__ cs_off, uint32_t* __restrict__ cs_ids) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
-        const uint32_t a = order[i];
-        const uint32_t cs = csid_ex[i] + head[i] - 1;
-        tcol[a] = cs;
-        if (head[i]) {
-            cs_off[cs] = off_ex[i];
-            for (uint32_t q = seg_off[a]; q < seg_off[a + 1]; q++) cs_ids[off_ex[i] + (q - seg_off[a])] = pg[q];
+// tcol of every k-mer (position i of the signature order) and, for the first k-mer of every run of equal lists, the
+// dictionary entry: the lanes of a wavefront copy that list together, 64 ids at a time
+__global__ __launch_bounds__(ABLK) void k_cs_assign(const uint32_t* __restrict__ order, const uint32_t* __restrict__ head, const uint32_t* __restrict__ csid_ex,
+                                                    const uint32_t* __restrict__ off_ex, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg,
+                                                    uint32_t nk, uint32_t* __restrict__ tcol, uint32_t* __restrict__ cs_off, uint32_t* __restrict__ cs_ids) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nblk = (nk + ABLK - 1) / ABLK;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint32_t i = blk * ABLK + threadIdx.x;
+        uint32_t hd = 0, src = 0, len = 0, dst = 0;
+        if (i < nk) {
+            const uint32_t a = order[i];
+            hd = head[i];
+            const uint32_t cs = csid_ex[i] + hd - 1;
+            tcol[a] = cs;
+            if (hd) {
+                src = seg_off[a];
+                len = seg_off[a + 1] - src;
+                dst = off_ex[i];
+                cs_off[cs] = dst;
+            }
+        }
+        uint64_t heads = __ballot(hd != 0);
+        while (heads) {
+            const int t = __builtin_ctzll(heads);
+            heads &= heads - 1;
+            const uint32_t s0 = __shfl(src, t), l0 = __shfl(len, t), d0 = __shfl(dst, t);
+            for (uint32_t j = lane; j < l0; j += 64) cs_ids[d0 + j] = pg[s0 + j];
         }
     }
 }
 
-// exactness check: every k-mer's list equals the dictionary entry it was assigned
-__global__ void k_cs_verify(const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids,
-                            const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint32_t* __restrict__ bad) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
-        const uint32_t cs = tcol[i];
-        const uint32_t l = seg_off[i + 1] - seg_off[i];
-        bool ok = (cs_off[cs + 1] - cs_off[cs]) == l;
-        for (uint32_t q = 0; ok && q < l; q++) ok = cs_ids[cs_off[cs] + q] == pg[seg_off[i] + q];
-        if (!ok) atomicAdd(bad, 1u);
+// exactness check: every k-mer's list equals the dictionary entry it was assigned (streamed like k_cs_sig)
+__global__ __launch_bounds__(ABLK) void k_cs_verify(const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids,
+                                                    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint32_t* __restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nblk = (nk + ABLK - 1) / ABLK;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint32_t i = blk * ABLK + threadIdx.x;
+        const bool valid = i < nk;
+        const uint32_t a = seg_off[valid ? i : nk], b = seg_off[valid ? i + 1 : nk];
+        uint32_t co = 0;
+        bool wrong = false;
+        if (valid) {
+            const uint32_t cs = tcol[i];
+            co = cs_off[cs];
+            wrong = (cs_off[cs + 1] - co) != (b - a);
+        }
+        const uint32_t base = __shfl(a, 0), end = __shfl(b, 63);
+        for (uint32_t e0 = base; e0 < end; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool in = e < end;
+            const uint32_t s = wave_list_of(in ? e : end - 1, a);
+            const uint32_t as = __shfl(a, s), cos = __shfl(co, s);
+            if (in && cs_ids[cos + (e - as)] != pg[e]) wrong = true;  // a list of the wrong length is already flagged by its own lane
+        }
+        if (wrong) atomicAdd(bad, 1u);
     }
 }
 

@@ -497,6 +497,7 @@ __global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* 
 // (`stride`) so that the row kernel reads it with aligned dword loads
 __global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t n_sets, uint32_t stride,
                              uint8_t* __restrict__ bm) {
+    // one thread per set (a wavefront-cooperative fill with atomic ORs on the row dwords measured 2x slower)
     for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_sets; c += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t* o = bm + c * stride;
         for (uint32_t q = cs_off[c]; q < cs_off[c + 1]; q++) o[cs_ids[q] >> 3] |= (uint8_t)(1u << (cs_ids[q] & 7));
