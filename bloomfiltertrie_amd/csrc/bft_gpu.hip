@@ -1403,7 +1403,7 @@ static int tune_residency(bft_gpu* h) {
         if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W > BFT_PROBE_MAX_W && probe == 8)) continue;
         h->tuned_wgs = wgs;
         h->im.probe_big = probe == 8;
-        for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches
+        for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second is timed
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
             if (rc == 0) rc = launch_query(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
