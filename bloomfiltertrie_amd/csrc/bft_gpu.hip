@@ -768,7 +768,7 @@ struct bft_gpu {
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
     uint64_t n_f18 = 0, n_fent = 0;
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
-    bool has_cs_bm = false;
+    bool has_cs_bm = false, cs_bm_tried = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
@@ -1079,20 +1079,9 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     im.ccx = h->d_ccx.as<BftCCX>();
     im.f18 = h->d_f18.as<uint64_t>();
     im.fent = h->d_fent.as<uint64_t>();
-    {   // bitmap form of the colour-set dictionary (used by the colour-row queries) when it stays below 4 GiB
-        const uint64_t rowbytes = (im.nb_genomes + 7) / 8, nsets = h->n_sets;
-        h->has_cs_bm = false;
-        h->d_cs_bm.release();
-        if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
-            const uint64_t stride = (rowbytes + 3) & ~3ull;  // dword-aligned dictionary rows (k_color_rows_bm)
-            CK(h->d_cs_bm.alloc_zero(nsets * stride, h->stream));
-            hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, im.cs_off, im.cs_ids, nsets, (uint32_t)stride,
-                               h->d_cs_bm.as<uint8_t>());
-            HIPCK(hipGetLastError());
-            HIPCK(hipStreamSynchronize(h->stream));
-            h->has_cs_bm = true;
-        }
-    }
+    h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
+    h->cs_bm_tried = false;
+    h->d_cs_bm.release();
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
     h->im.probe_big = h->opt_probe == 8;
@@ -1622,7 +1611,26 @@ extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n
     return BFT_GPU_OK;
 }
 
+// Bitmap form of the colour-set dictionary (one dword-aligned row per set), used by the colour-row queries when it stays
+// below 4 GiB; derived on the first such query of an image, on the handle's stream.
+static int ensure_cs_bitmaps(bft_gpu* h) {
+    if (h->cs_bm_tried) return 0;
+    h->cs_bm_tried = true;
+    const uint64_t rowbytes = (h->im.nb_genomes + 7) / 8, nsets = h->n_sets;
+    if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
+        const uint64_t stride = (rowbytes + 3) & ~3ull;  // dword-aligned dictionary rows (k_color_rows_bm)
+        CK(h->d_cs_bm.alloc_zero(nsets * stride, h->stream));
+        hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, h->im.cs_off, h->im.cs_ids, nsets, (uint32_t)stride,
+                           h->d_cs_bm.as<uint8_t>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(h->stream));  // the row kernel may run on a caller's stream
+        h->has_cs_bm = true;
+    }
+    return 0;
+}
+
 static int launch_color_rows(bft_gpu* h, const uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s) {
+    CK(ensure_cs_bitmaps(h));
     if (h->has_cs_bm) {
         // tiles of k-mers whose bytes fit 31 bits; magic number of the division by rowbytes (round-up method, exact on u32)
         const uint32_t tile_rows = std::max<uint32_t>(4u, ((1u << 30) / rowbytes) & ~3u);
