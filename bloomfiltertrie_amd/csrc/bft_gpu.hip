@@ -1,16 +1,16 @@
-// bft_gpu.hip -- HIP kernels (gfx950) and the C-ABI of include/bft_gpu.h.
-//
-// Kernels:
-//   k_pack_to_tform   packed 2-bit k-mers -> T-form words (the per-level rev[]/rotation work of
-//                     src/presenceNode.c:1327-1371 done once per k-mer)
-//   k_query           batched isKmerPresent (src/presenceNode.c:1823-1921): one lane per k-mer,
-//                     coalesced dword loads of the packed batch, hash table + root Bloom block +
-//                     root CC headers staged in LDS, presence bits produced with a wavefront
-//                     __ballot (64 k-mers -> one u64 store)
-//   k_color_*         batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
-//   k_flags/k_scatter de-duplication of sorted (k-mer, genome) pairs for the bulk build
-// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); colour-set interning
-// and container assembly are the kernels of bft_assemble.hip -- see DESIGN.md "Insertion".
+// bft_gpu.hip -- the C-ABI of include/bft_gpu.h: handle, device-memory cache, insertion log, bulk build, query entry points,
+// residency / probe tuning, .bft files, image replication.  One translation unit with its device code:
+//   bft_kernels_query.h  k_pack_to_tform (packed 2-bit k-mers -> T-form words: the per-level rev[]/rotation work of
+//                        src/presenceNode.c:1327-1371 done once per k-mer), k_query / k_query8 (batched isKmerPresent,
+//                        src/presenceNode.c:1823-1921: one lane per k-mer, coalesced dword loads of the batch, hash table + root
+//                        Bloom block + root CC headers staged in LDS, 64 presence bits per wavefront via __ballot),
+//                        k_branching / k_branching8 (src/branchingNode.c)
+//   bft_kernels_seq.h    query_sequence (src/bft.c:1241-1351) around k_query
+//   bft_kernels_build.h  de-duplication of sorted (k-mer, genome) pairs for the bulk build
+//   bft_kernels_color.h  batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
+//   bft_walk.h           the per-k-mer walk itself (shared with the host-side test helper)
+// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); colour-set interning and container
+// assembly are the kernels of bft_assemble.hip -- see DESIGN.md "Insertion".
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -45,583 +45,11 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// ------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------
-
-// Packed k-mer i -> X words, straight from global memory: the 64 lanes of a wavefront read one
-// contiguous 64*B-byte span with aligned dword loads (each lane the <= 2W+1 dwords that cover its
-// B bytes), then funnel-shift.  The last k-mers of a buffer whose window would cross the end of the
-// buffer take a byte path.
-template <int W>
-__device__ __forceinline__ void load_x(const uint8_t* __restrict__ packed, uint64_t i, int B, uint64_t end_aligned, uint64_t* x) {
-    constexpr int NDW = 2 * W + 1;
-    const uint64_t addr = (uint64_t)packed + i * (uint64_t)B;
-    const uint64_t a = addr & ~3ull;
-    const uint32_t mis = (uint32_t)(addr & 3ull), sh = mis * 8;
-    const uint32_t need = (mis + (uint32_t)B + 3u) >> 2;
-    uint32_t dw[NDW];
-    if (a + 4ull * need <= end_aligned) {
-        const uint32_t* p = (const uint32_t*)a;
-#pragma unroll
-        for (int j = 0; j < NDW; j++) dw[j] = ((uint32_t)j < need) ? p[j] : 0u;
-    } else {
-#pragma unroll
-        for (int j = 0; j < NDW; j++) dw[j] = 0;
-        const uint8_t* q = (const uint8_t*)addr;
-        for (int b = 0; b < B; b++) {
-            const uint32_t pos = mis + (uint32_t)b, v = (uint32_t)q[b] << (8 * (pos & 3));
-#pragma unroll
-            for (int j = 0; j < NDW; j++)
-                if ((pos >> 2) == (uint32_t)j) dw[j] |= v;
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < W; w++) {
-        const uint64_t lo = (uint64_t)dw[2 * w] | ((uint64_t)dw[2 * w + 1] << 32);
-        const uint64_t hi = dw[2 * w + 2];
-        x[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-    }
-    const int rem = B - 8 * (W - 1);
-    if (rem < 8) x[W - 1] &= (1ull << (8 * rem)) - 1ull;
-}
-
-template <int W>
-__global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
-                                                             uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
-                                                             uint32_t* __restrict__ gout, uint32_t gid) {
-    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    for (uint64_t i = blockIdx.x * (uint64_t)BFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BFT_BLOCK) {
-        uint64_t x[W], t[W];
-        load_x<W>(packed, i, B, end_aligned, x);
-        bft_tform_from_x<W>(x, k, t);
-#pragma unroll
-        for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + i] = t[w];
-        gout[off + i] = gid;
-    }
-}
-
-// The hash table (64 KiB) and the root node's bit-sliced Bloom block and CC headers live in LDS:
-// every query of a batch reads them, and a divergent LDS read costs a few cycles where a divergent
-// vector-memory read occupies the CU's texture path for ~64.
-template <bool STAGED>
-struct BftRootLds {
-    const BftImage& im;
-    const uint32_t* hm;
-    const uint8_t* bf;
-    const BftCCX* cc;
-    __device__ __forceinline__ uint32_t hashmod(uint32_t key) const { return hm[key]; }
-    __device__ __forceinline__ int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
-        if (STAGED) return bft_first_cc_blk(bf, nd.bf_wb, h1, h2);
-        return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
-    }
-    __device__ __forceinline__ BftCCX root_cc(const BftNode& nd, int c) const {
-        if (STAGED) return cc[c];
-        return im.ccx[nd.cc_first + c];
-    }
-};
-
-#define BFT_LDS_HM_BYTES 65536u
-#define BFT_LDS_ROOT_MAX_CC 64u
-
-template <int W, int BLOCK, bool STAGED, int PROBE>
-__device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    uint32_t* l_hm = (uint32_t*)lds;
-    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
-    const BftNode root = im.nodes[0];
-    const bool stage_root = STAGED;  // host side: root.ncc in [1, 64]
-    const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
-    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
-    {
-        const uint4* g = (const uint4*)im.hashmod;
-        uint4* l = (uint4*)l_hm;
-        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
-        if (stage_root) {
-            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
-            uint64_t* lb = (uint64_t*)l_bf;
-            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;  // 1504*wb is a multiple of 8
-            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
-            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
-        }
-    }
-    __syncthreads();
-    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
-    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BLOCK + threadIdx.x;
-        int present = 0;
-        uint32_t row = BFT_ABSENT_ROW;
-        if (i < n) {
-            uint64_t x[W], t[W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            bft_tform_from_x<W>(x, im.k, t);
-            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
-            present = h.present;
-            if (present) row = (uint32_t)h.row;
-        }
-        const uint64_t mask = __ballot(present);
-        const uint64_t q0 = i & ~63ull;  // first query of this wavefront
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-        if (rows && i < n) rows[i] = row;
-    }
-}
-
-// Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in
-// SGPRs), which caps a SIMD at 7 waves, i.e. ONE 1024-thread workgroup per CU -- the fastest arrangement for a one-level
-// index (4 waves per SIMD keep the beyond-L2 gather path full, more only thrash it).  k_query8: held to 8 waves per SIMD
-// (78 SGPRs) so that two workgroups share a CU -- +10..40 % on deep tries and on L2-resident ones.
-// PROBE: suffix-group probe mode fixed at compile time (0 = 4-row blocks, 1 = 8-row blocks; the 1024-thread kernels) or read
-// from the image (-1; the other workgroup sizes): the 4-row code alone fits the 64 VGPRs of k_query8 without spilling.
-template <int W, int BLOCK, bool STAGED, int PROBE>
-__global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                 uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
-}
-template <int W, int BLOCK, bool STAGED, int PROBE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                                                             uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
-}
-
-// Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
-// successors of a k-mer = present k-mers kmer[1..k-1]+N, predecessors = present k-mers N+kmer[0..k-2], N in ACGT.
-// In T-form the four successors differ only in bits 2..3 of the last digit (n9 of the last prefix) and the four
-// predecessors only in bits 0..1 of the first digit (n1 of the first prefix): one conversion per side, then four walks
-// that share every container down to the last cluster / suffix group (src/presenceNode.c:15-1211 exploits the same).
-// counts[i] = (successors << 4) | predecessors when requested; the bit = successors > 1 || predecessors > 1.
-template <int W, int BLOCK, bool STAGED>
-__device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                               uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    uint32_t* l_hm = (uint32_t*)lds;
-    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
-    const BftNode root = im.nodes[0];
-    const uint32_t bf_bytes = STAGED ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
-    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
-    {
-        const uint4* g = (const uint4*)im.hashmod;
-        uint4* l = (uint4*)l_hm;
-        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
-        if (STAGED) {
-            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
-            uint64_t* lb = (uint64_t*)l_bf;
-            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
-            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
-            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
-        }
-    }
-    __syncthreads();
-    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
-    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
-    const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BLOCK + threadIdx.x;
-        int branching = 0;
-        if (i < n) {
-            uint64_t x[W], y[W], t[W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            // successors: drop the first nucleotide, the last one is the wildcard
-#pragma unroll
-            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
-            bft_tform_from_x<W>(y, k, t);
-            int cl = 0;
-            // the four successors differ in the last nucleotide only: one shared descent, four finishes
-            const int cr = bft_walk_last4<W, BftRootLds<STAGED>>(im, acc, root, t, counts != nullptr);
-            if (counts || cr < 2) {
-                // predecessors: shift in a wildcard first nucleotide, drop the last one
-#pragma unroll
-                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
-                const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
-                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
-                bft_tform_from_x<W>(y, k, t);
-                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
-                for (uint64_t nt = 0; nt < 4 && (counts || cl < 2); nt++) {
-                    uint64_t tt[W];
-#pragma unroll
-                    for (int w = 0; w < W; w++) tt[w] = t[w] | (w == ow ? nt << osh : 0ull);
-                    cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
-                }
-            }
-            branching = cr > 1 || cl > 1;
-            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
-        }
-        const uint64_t mask = __ballot(branching);
-        const uint64_t q0 = i & ~63ull;
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-    }
-}
-
-// the two register budgets of k_query / k_query8 (see there)
-template <int W, int BLOCK, bool STAGED>
-__global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                     uint8_t* __restrict__ counts) {
-    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
-}
-template <int W, int BLOCK, bool STAGED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_branching8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n,
-                                                                                                 int B, uint64_t* __restrict__ bits64,
-                                                                                                 uint8_t* __restrict__ counts) {
-    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
-}
-
-// ---- query_sequence (src/bft.c:1241-1351, harness src/file_io.c:1464-1574): every k-mer of every sequence ----
-__device__ __forceinline__ int nt_code(char c) {
-    switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': case 'U': case 'u': return 3;
-    default: return -1;
-    }
-}
-
-// Sequence queries, step 0.  The ASCII blob -> 2 bits per character (32 characters per u64, character c at bits 2(c%32) of
-// word c/32: the packed layout of src/fasta.c:11-23 continued over the whole blob) + one "not ACGTU" bit per character.
-// One thread per 32 characters; the blob is padded to a multiple of 32 bytes.
-__global__ void k_seq_encode(const char* __restrict__ seqs, uint64_t n_words, uint64_t* __restrict__ codes, uint32_t* __restrict__ bad) {
-    for (uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4* src = (const uint4*)(seqs + wi * 32);
-        const uint4 a = src[0], b = src[1];
-        const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint64_t cw = 0;
-        uint32_t bw = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int code = nt_code((char)((d[j] >> (8 * c)) & 0xFFu));
-                const int i = 4 * j + c;
-                cw |= (uint64_t)(code & 3) << (2 * i);
-                bw |= (code < 0 ? 1u : 0u) << i;
-            }
-        }
-        codes[wi] = cw;
-        bad[wi] = bw;
-    }
-}
-
-// reverse the 32 two-bit fields of a word
-__device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
-    x = __brevll(x);
-    return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
-}
-
-// Step 1.  One thread per k-mer position of the batch: its window is 2k bits of the code stream at a bit offset (W+1 word
-// loads + funnel shifts, O(1) instead of a scan over k characters), valid unless one of its k "bad" bits is set (windows
-// with a character outside ACGTU are skipped by the reference, src/bft.c:1298).  canonical: the reverse complement =
-// complement, reverse the 2-bit fields of the 2k-bit string; strcmp(kmer, revcomp) >= 0 -> the reverse complement is
-// searched (src/bft.c:1290-1296) = comparison of the lowest differing field.  Output: W zero-padded words per position (the
-// record layout k_query reads with a record size of 8W bytes), valid[p], seq_of[p] = the sequence of position p.
-template <int W>
-__global__ void k_seq_pack(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
-                           const uint64_t* __restrict__ pos_off, uint32_t n_seqs, uint64_t P, int k, int canonical, uint64_t* __restrict__ words,
-                           uint8_t* __restrict__ valid, uint32_t* __restrict__ seq_of) {
-    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
-        // the sequence of position p: last s with pos_off[s] <= p.  The 64 positions of a wavefront are consecutive, so the
-        // binary search runs once per wavefront on its first position (uniform values: scalar loads) and every lane
-        // walks forward from there (sequences shorter than k own no position and are stepped over).
-        const uint64_t p0 = p - (threadIdx.x & 63u);
-        const uint64_t p0u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p0 >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p0);
-        uint32_t lo = 0, hi = n_seqs;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (pos_off[mid] <= p0u) lo = mid; else hi = mid;
-        }
-        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
-        const uint64_t c0 = seq_off[lo] + (p - pos_off[lo]);  // first character of the window, as an index into the blob
-        // 2k bits of the code stream from bit 2*c0
-        const uint64_t w0 = c0 >> 5;
-        const uint32_t sh = (uint32_t)(c0 & 31u) * 2u;
-        uint64_t cw[W + 1], xf[W], xr[W];
-#pragma unroll
-        for (int q = 0; q <= W; q++) cw[q] = codes[w0 + q];  // the code array has W+1 words of slack
-#pragma unroll
-        for (int q = 0; q < W; q++) xf[q] = sh ? (cw[q] >> sh) | (cw[q + 1] << (64u - sh)) : cw[q];
-        const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
-        if (top < 64) xf[W - 1] &= (1ull << top) - 1ull;
-        // any bad character in [c0, c0 + k)?
-        bool ok = true;
-        {
-            const uint64_t b0 = c0 >> 5;
-            const uint32_t bs = (uint32_t)(c0 & 31u);
-            int left = k;
-            uint32_t first = bad[b0] >> bs;
-            if (left < 32 - (int)bs) first &= (1u << left) - 1u;
-            ok = first == 0;
-            left -= 32 - (int)bs;
-            for (uint64_t j = b0 + 1; left > 0; j++, left -= 32) {
-                uint32_t m = bad[j];
-                if (left < 32) m &= (1u << left) - 1u;
-                ok = ok && m == 0;
-            }
-        }
-        bool use_rc = false;
-        if (canonical) {
-            // complement, then reverse the fields of the 64W-bit string and shift the 2k bits of interest back down
-            uint64_t rv[W + 1];
-#pragma unroll
-            for (int q = 0; q < W; q++) rv[q] = rev2_64(~xf[W - 1 - q]);
-            rv[W] = 0;
-            const uint32_t dn = (uint32_t)(64 * W - 2 * k);  // < 64
-#pragma unroll
-            for (int q = 0; q < W; q++) xr[q] = dn ? (rv[q] >> dn) | (rv[q + 1] << (64u - dn)) : rv[q];
-            if (top < 64) xr[W - 1] &= (1ull << top) - 1ull;
-            use_rc = true;  // equal strings: the (identical) reverse complement
-#pragma unroll
-            for (int q = W - 1; q >= 0; q--) {  // the lowest differing field decides: word 0 last
-                const uint64_t df = xf[q] ^ xr[q];
-                if (df) {
-                    const int fs = __builtin_ctzll(df) & ~1;
-                    use_rc = ((xf[q] >> fs) & 3ull) > ((xr[q] >> fs) & 3ull);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < W; q++) words[p * W + q] = ok ? (use_rc ? xr[q] : xf[q]) : 0ull;
-        valid[p] = ok ? 1 : 0;
-        seq_of[p] = lo;
-    }
-}
-
-// Step 3 (step 2 is k_query on the word records): per-(sequence, genome) counters.  Consecutive k-mers of a read mostly
-// carry the same colour set, so counting works on runs: the 64 lanes of a wavefront hold 64 consecutive positions, run
-// boundaries come from a shuffle + __ballot, and the first lane of every run of equal (sequence, colour set) adds the run
-// length (up to the end of the wavefront) once per genome of the set -- instead of one atomic per k-mer and genome.
-__global__ void k_seq_count(const uint32_t* __restrict__ rows, const uint8_t* __restrict__ valid, const uint32_t* __restrict__ seq_of,
-                            const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t P, uint32_t G,
-                            uint32_t* __restrict__ counts) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t nblk = (P + blockDim.x - 1) / blockDim.x;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
-        const uint64_t p = blk * blockDim.x + threadIdx.x;
-        uint32_t cs = 0xFFFFFFFFu, sq = 0xFFFFFFFFu;
-        if (p < P) {
-            sq = seq_of[p];
-            const uint32_t r = rows[p];
-            if (r != BFT_ABSENT_ROW && valid[p]) cs = tcol[r];
-        }
-        const uint32_t pcs = __shfl_up(cs, 1), psq = __shfl_up(sq, 1);
-        const bool boundary = lane == 0 || pcs != cs || psq != sq;
-        const uint64_t bmask = __ballot(boundary);
-        if (boundary && cs != 0xFFFFFFFFu) {
-            const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
-            const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-            uint32_t* c = counts + (size_t)sq * G;
-            for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) atomicAdd(&c[cs_ids[q]], len);
-        }
-    }
-}
-
-__global__ void k_seq_threshold(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ minv, uint32_t n_seqs, uint32_t G, uint32_t rowbytes,
-                                uint8_t* __restrict__ out) {
-    const uint64_t total = (uint64_t)n_seqs * rowbytes;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t s = (uint32_t)(i / rowbytes), b = (uint32_t)(i % rowbytes);
-        uint32_t v = 0;
-        for (uint32_t j = 0; j < 8 && b * 8 + j < G; j++) {
-            const uint32_t c = counts[(size_t)s * G + b * 8 + j];
-            if (c && c >= minv[s]) v |= 1u << j;
-        }
-        out[i] = (uint8_t)v;
-    }
-}
-
-__global__ void k_iota(uint32_t* p, uint64_t n) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
-}
-template <class T>
-__global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ perm, T* __restrict__ out, uint64_t n) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
-}
-
-// sorted (T, g) pairs -> head-of-k-mer flag and keep-pair flag
-__global__ void k_flags(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
-                        uint32_t* __restrict__ head, uint32_t* __restrict__ keep) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        bool same = i > 0;
-        if (same)
-            for (int w = 0; w < W; w++) same = same && (keys[(uint64_t)w * stride + i] == keys[(uint64_t)w * stride + i - 1]);
-        head[i] = same ? 0u : 1u;
-        keep[i] = (!same || g[i] != g[i - 1]) ? 1u : 0u;
-    }
-}
-
-__global__ void k_scatter(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
-                          const uint32_t* __restrict__ head, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ posK,
-                          const uint32_t* __restrict__ posP, uint64_t* __restrict__ pk, uint64_t pstride, uint32_t* __restrict__ pg,
-                          uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (keep[i]) {
-            const uint32_t p = posP[i];
-            for (int w = 0; w < W; w++) pk[(uint64_t)w * pstride + p] = keys[(uint64_t)w * stride + i];
-            pg[p] = g[i];
-        }
-        if (head[i]) {
-            const uint32_t q = posK[i];
-            for (int w = 0; w < W; w++) tk[(uint64_t)q * W + w] = keys[(uint64_t)w * stride + i];
-            seg_off[q] = posP[i];
-        }
-    }
-}
-
-__global__ void k_color_counts(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
-                               uint64_t n, uint64_t* __restrict__ counts) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = rows[i];
-        uint64_t c = 0;
-        if (r != BFT_ABSENT_ROW) {
-            const uint32_t cs = tcol[r];
-            c = cs_off[cs + 1] - cs_off[cs];
-        }
-        counts[i] = c;
-    }
-}
-
-__global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
-                             const uint32_t* __restrict__ cs_ids, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* __restrict__ ids) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = rows[i];
-        if (r == BFT_ABSENT_ROW) continue;
-        const uint32_t cs = tcol[r];
-        const uint32_t a = cs_off[cs], b = cs_off[cs + 1];
-        uint64_t o = offsets[i];
-        for (uint32_t q = a; q < b; q++) ids[o++] = cs_ids[q];
-    }
-}
-
-// colour-set dictionary as bitmaps, built once per image: one row per set, CEIL(G/8) bytes padded to a multiple of 4
-// (`stride`) so that the row kernel reads it with aligned dword loads
-__global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t n_sets, uint32_t stride,
-                             uint8_t* __restrict__ bm) {
-    // one thread per set (a wavefront-cooperative fill with atomic ORs on the row dwords measured 2x slower)
-    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_sets; c += (uint64_t)gridDim.x * blockDim.x) {
-        uint8_t* o = bm + c * stride;
-        for (uint32_t q = cs_off[c]; q < cs_off[c + 1]; q++) o[cs_ids[q] >> 3] |= (uint8_t)(1u << (cs_ids[q] & 7));
-    }
-}
-
-// bytes [b, b+4) of a dictionary row (dword-aligned base; the bytes past the row's end are whatever follows: callers mask)
-__device__ __forceinline__ uint32_t bm_dword_at(const uint32_t* __restrict__ row, uint32_t b) {
-    const uint32_t lo = row[b >> 2];
-    const uint32_t sh = 8u * (b & 3u);
-    if (sh == 0) return lo;
-    return (lo >> sh) | (row[(b >> 2) + 1] << (32u - sh));
-}
-
-// One output dword at tile-relative byte offset `byte` (a multiple of 4), which starts at byte b of k-mer q's row and may
-// straddle two or more rows: the bytes come from the bitmap row of each present k-mer.
-__device__ __forceinline__ uint32_t color_dword(const uint32_t* __restrict__ trow, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm,
-                                                uint32_t stride, uint32_t rowbytes, uint32_t nt, uint32_t q, uint32_t b) {
-    uint32_t v = 0, have = 0;  // bytes of the output dword filled so far
-    while (have < 4u && q < nt) {
-        const uint32_t take = min(4u - have, rowbytes - b);
-        const uint32_t r = trow[q];
-        if (r != BFT_ABSENT_ROW) {
-            uint32_t w = bm_dword_at((const uint32_t*)(bm + (uint64_t)tcol[r] * stride), b);
-            if (take < 4u) w &= (1u << (8u * take)) - 1u;
-            v |= w << (8u * have);
-        }
-        have += take;
-        b = 0;
-        q++;
-    }
-    return v;
-}
-
-// Colour rows from the bitmap dictionary.  The rows of consecutive k-mers are contiguous (CEIL(G/8) bytes each); one thread
-// writes aligned dwords of that stream (coalesced 4-byte stores), a wavefront covering 256 consecutive bytes, i.e. mostly one
-// row: its lanes read consecutive dwords of the same dictionary row (one or two aligned loads + a funnel shift each).
-// Every thread works on CR_UNROLL dwords (one per grid stride) at a time, stage by stage (row index -> colour set -> bitmap
-// dwords).  Dwords that straddle rows go through color_dword.  Measured (config 5, 250-byte rows, 10^9 bytes out): 0.83 ms
-// = 1.2 TB/s written; byte gathers from unpadded dictionary rows took 1.2 ms; 16-byte chunks per thread were slower (a
-// wavefront then touches four dictionary rows per load instruction), more chains in flight per thread changed nothing,
-// non-temporal stores neither; without the dictionary reads or without the stores the kernel is only 17 % faster either
-// way; 8 bytes per thread (three source dwords, one 8-byte store) was 30 % slower again, like the 16-byte variant.  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
-// a tile are 32-bit and byte / rowbytes is a multiply-high by the host's magic number (div_m, div_l; exact on u32).
-#define CR_UNROLL 4
-__global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm, uint32_t stride,
-                                uint64_t n, uint32_t rowbytes, uint32_t tile_rows, uint32_t div_m, uint32_t div_l, uint8_t* __restrict__ out) {
-    const uint64_t q0 = (uint64_t)blockIdx.y * tile_rows;
-    const uint32_t nt = (uint32_t)min((uint64_t)tile_rows, n - q0);  // k-mers of this tile
-    const uint32_t total = nt * rowbytes, ndw = (total + 3u) / 4u;
-    const uint32_t* trow = rows + q0;
-    uint8_t* tout = out + q0 * rowbytes;
-    const uint32_t G = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < ndw; i0 += G * CR_UNROLL) {
-        uint32_t q[CR_UNROLL], b[CR_UNROLL], r[CR_UNROLL], lo[CR_UNROLL], hi[CR_UNROLL];
-        const uint32_t* src[CR_UNROLL];
-        bool ok[CR_UNROLL], fast[CR_UNROLL];
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            const uint32_t i = i0 + (uint32_t)u * G;
-            ok[u] = i < ndw;
-            const uint32_t byte = i * 4u;
-            q[u] = byte;
-            if (div_l) {
-                const uint32_t t = __umulhi(byte, div_m);
-                q[u] = (t + ((byte - t) >> 1)) >> (div_l - 1u);
-            }
-            b[u] = byte - q[u] * rowbytes;
-            fast[u] = ok[u] && b[u] + 4u <= rowbytes && byte + 4u <= total;
-        }
-        // unconditional loads on clamped indices (every array has slack behind it): the compiler issues each stage's
-        // CR_UNROLL loads back to back
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) r[u] = trow[min(q[u], nt - 1u)];
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) src[u] = (const uint32_t*)(bm + (uint64_t)tcol[r[u] != BFT_ABSENT_ROW ? r[u] : 0u] * stride) + (b[u] >> 2);
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            lo[u] = src[u][0];
-            hi[u] = src[u][1];
-        }
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++)
-            if (r[u] == BFT_ABSENT_ROW) lo[u] = hi[u] = 0u;
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            if (!ok[u]) continue;
-            const uint32_t byte = (i0 + (uint32_t)u * G) * 4u;
-            if (fast[u]) {
-                const uint32_t sh = 8u * (b[u] & 3u);
-                *(uint32_t*)(tout + byte) = sh ? (lo[u] >> sh) | (hi[u] << (32u - sh)) : lo[u];
-            } else {
-                const uint32_t w = color_dword(trow, tcol, bm, stride, rowbytes, nt, q[u], b[u]);
-                if (byte + 4u <= total) *(uint32_t*)(tout + byte) = w;
-                else
-                    for (uint32_t x = 0; byte + x < total; x++) tout[byte + x] = (uint8_t)(w >> (8u * x));
-            }
-        }
-    }
-}
-
-// colour-set id of every located k-mer (BFT_ABSENT_ROW stays BFT_ABSENT_ROW)
-__global__ void k_row_colorsets(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, uint64_t n, uint32_t* __restrict__ out) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = rows[i];
-        out[i] = r == BFT_ABSENT_ROW ? BFT_ABSENT_ROW : tcol[r];
-    }
-}
-
-__global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
-                             const uint32_t* __restrict__ cs_ids, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint8_t* o = out + i * rowbytes;
-        for (uint32_t b = 0; b < rowbytes; b++) o[b] = 0;
-        const uint32_t r = rows[i];
-        if (r == BFT_ABSENT_ROW) continue;
-        const uint32_t cs = tcol[r];
-        for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) {
-            const uint32_t gid = cs_ids[q];
-            o[gid >> 3] |= (uint8_t)(1u << (gid & 7));
-        }
-    }
-}
-
+// device code, by topic
+#include "bft_kernels_query.h"
+#include "bft_kernels_seq.h"
+#include "bft_kernels_build.h"
+#include "bft_kernels_color.h"
 // ------------------------------------------------------------------------------------------------
 // device-memory cache (see bft_dev.h)
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,41 @@
+// bft_kernels_build.h -- de-duplication of the sorted (k-mer, genome) pairs for the bulk build: k_iota, k_gather, k_flags, k_scatter
+// Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
+// the host code there).
+#pragma once
+__global__ void k_iota(uint32_t* p, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
+template <class T>
+__global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ perm, T* __restrict__ out, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
+}
+
+// sorted (T, g) pairs -> head-of-k-mer flag and keep-pair flag
+__global__ void k_flags(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
+                        uint32_t* __restrict__ head, uint32_t* __restrict__ keep) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool same = i > 0;
+        if (same)
+            for (int w = 0; w < W; w++) same = same && (keys[(uint64_t)w * stride + i] == keys[(uint64_t)w * stride + i - 1]);
+        head[i] = same ? 0u : 1u;
+        keep[i] = (!same || g[i] != g[i - 1]) ? 1u : 0u;
+    }
+}
+
+__global__ void k_scatter(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
+                          const uint32_t* __restrict__ head, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ posK,
+                          const uint32_t* __restrict__ posP, uint64_t* __restrict__ pk, uint64_t pstride, uint32_t* __restrict__ pg,
+                          uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (keep[i]) {
+            const uint32_t p = posP[i];
+            for (int w = 0; w < W; w++) pk[(uint64_t)w * pstride + p] = keys[(uint64_t)w * stride + i];
+            pg[p] = g[i];
+        }
+        if (head[i]) {
+            const uint32_t q = posK[i];
+            for (int w = 0; w < W; w++) tk[(uint64_t)q * W + w] = keys[(uint64_t)w * stride + i];
+            seg_off[q] = posP[i];
+        }
+    }
+}

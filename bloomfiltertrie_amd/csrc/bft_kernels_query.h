@@ -1,0 +1,226 @@
+// bft_kernels_query.h -- batch loads of packed k-mers, T-form conversion into the insert log, k_query / k_query8 (presence) and k_branching / k_branching8
+// Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
+// the host code there).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+
+// Packed k-mer i -> X words, straight from global memory: the 64 lanes of a wavefront read one
+// contiguous 64*B-byte span with aligned dword loads (each lane the <= 2W+1 dwords that cover its
+// B bytes), then funnel-shift.  The last k-mers of a buffer whose window would cross the end of the
+// buffer take a byte path.
+template <int W>
+__device__ __forceinline__ void load_x(const uint8_t* __restrict__ packed, uint64_t i, int B, uint64_t end_aligned, uint64_t* x) {
+    constexpr int NDW = 2 * W + 1;
+    const uint64_t addr = (uint64_t)packed + i * (uint64_t)B;
+    const uint64_t a = addr & ~3ull;
+    const uint32_t mis = (uint32_t)(addr & 3ull), sh = mis * 8;
+    const uint32_t need = (mis + (uint32_t)B + 3u) >> 2;
+    uint32_t dw[NDW];
+    if (a + 4ull * need <= end_aligned) {
+        const uint32_t* p = (const uint32_t*)a;
+#pragma unroll
+        for (int j = 0; j < NDW; j++) dw[j] = ((uint32_t)j < need) ? p[j] : 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NDW; j++) dw[j] = 0;
+        const uint8_t* q = (const uint8_t*)addr;
+        for (int b = 0; b < B; b++) {
+            const uint32_t pos = mis + (uint32_t)b, v = (uint32_t)q[b] << (8 * (pos & 3));
+#pragma unroll
+            for (int j = 0; j < NDW; j++)
+                if ((pos >> 2) == (uint32_t)j) dw[j] |= v;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t lo = (uint64_t)dw[2 * w] | ((uint64_t)dw[2 * w + 1] << 32);
+        const uint64_t hi = dw[2 * w + 2];
+        x[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    }
+    const int rem = B - 8 * (W - 1);
+    if (rem < 8) x[W - 1] &= (1ull << (8 * rem)) - 1ull;
+}
+
+template <int W>
+__global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
+                                                             uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
+                                                             uint32_t* __restrict__ gout, uint32_t gid) {
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)BFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BFT_BLOCK) {
+        uint64_t x[W], t[W];
+        load_x<W>(packed, i, B, end_aligned, x);
+        bft_tform_from_x<W>(x, k, t);
+#pragma unroll
+        for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + i] = t[w];
+        gout[off + i] = gid;
+    }
+}
+
+// The hash table (64 KiB) and the root node's bit-sliced Bloom block and CC headers live in LDS:
+// every query of a batch reads them, and a divergent LDS read costs a few cycles where a divergent
+// vector-memory read occupies the CU's texture path for ~64.
+template <bool STAGED>
+struct BftRootLds {
+    const BftImage& im;
+    const uint32_t* hm;
+    const uint8_t* bf;
+    const BftCCX* cc;
+    __device__ __forceinline__ uint32_t hashmod(uint32_t key) const { return hm[key]; }
+    __device__ __forceinline__ int root_first_cc(const BftNode& nd, uint32_t h1, uint32_t h2) const {
+        if (STAGED) return bft_first_cc_blk(bf, nd.bf_wb, h1, h2);
+        return bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, h1, h2);
+    }
+    __device__ __forceinline__ BftCCX root_cc(const BftNode& nd, int c) const {
+        if (STAGED) return cc[c];
+        return im.ccx[nd.cc_first + c];
+    }
+};
+
+#define BFT_LDS_HM_BYTES 65536u
+#define BFT_LDS_ROOT_MAX_CC 64u
+
+template <int W, int BLOCK, bool STAGED, int PROBE>
+__device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t* l_hm = (uint32_t*)lds;
+    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    const BftNode root = im.nodes[0];
+    const bool stage_root = STAGED;  // host side: root.ncc in [1, 64]
+    const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
+    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
+    {
+        const uint4* g = (const uint4*)im.hashmod;
+        uint4* l = (uint4*)l_hm;
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (stage_root) {
+            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
+            uint64_t* lb = (uint64_t*)l_bf;
+            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;  // 1504*wb is a multiple of 8
+            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
+        }
+    }
+    __syncthreads();
+    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * BLOCK + threadIdx.x;
+        int present = 0;
+        uint32_t row = BFT_ABSENT_ROW;
+        if (i < n) {
+            uint64_t x[W], t[W];
+            load_x<W>(packed, i, B, end_aligned, x);
+            bft_tform_from_x<W>(x, im.k, t);
+            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
+            present = h.present;
+            if (present) row = (uint32_t)h.row;
+        }
+        const uint64_t mask = __ballot(present);
+        const uint64_t q0 = i & ~63ull;  // first query of this wavefront
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        if (rows && i < n) rows[i] = row;
+    }
+}
+
+// Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in
+// SGPRs), which caps a SIMD at 7 waves, i.e. ONE 1024-thread workgroup per CU -- the fastest arrangement for a one-level
+// index (4 waves per SIMD keep the beyond-L2 gather path full, more only thrash it).  k_query8: held to 8 waves per SIMD
+// (78 SGPRs) so that two workgroups share a CU -- +10..40 % on deep tries and on L2-resident ones.
+// PROBE: suffix-group probe mode fixed at compile time (0 = 4-row blocks, 1 = 8-row blocks; the 1024-thread kernels) or read
+// from the image (-1; the other workgroup sizes): the 4-row code alone fits the 64 VGPRs of k_query8 without spilling.
+template <int W, int BLOCK, bool STAGED, int PROBE>
+__global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                 uint32_t* __restrict__ rows) {
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+}
+template <int W, int BLOCK, bool STAGED, int PROBE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                                                             uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+}
+
+// Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
+// successors of a k-mer = present k-mers kmer[1..k-1]+N, predecessors = present k-mers N+kmer[0..k-2], N in ACGT.
+// In T-form the four successors differ only in bits 2..3 of the last digit (n9 of the last prefix) and the four
+// predecessors only in bits 0..1 of the first digit (n1 of the first prefix): one conversion per side, then four walks
+// that share every container down to the last cluster / suffix group (src/presenceNode.c:15-1211 exploits the same).
+// counts[i] = (successors << 4) | predecessors when requested; the bit = successors > 1 || predecessors > 1.
+template <int W, int BLOCK, bool STAGED>
+__device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                               uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t* l_hm = (uint32_t*)lds;
+    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    const BftNode root = im.nodes[0];
+    const uint32_t bf_bytes = STAGED ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
+    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
+    {
+        const uint4* g = (const uint4*)im.hashmod;
+        uint4* l = (uint4*)l_hm;
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (STAGED) {
+            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
+            uint64_t* lb = (uint64_t*)l_bf;
+            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
+            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
+        }
+    }
+    __syncthreads();
+    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * BLOCK + threadIdx.x;
+        int branching = 0;
+        if (i < n) {
+            uint64_t x[W], y[W], t[W];
+            load_x<W>(packed, i, B, end_aligned, x);
+            // successors: drop the first nucleotide, the last one is the wildcard
+#pragma unroll
+            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
+            bft_tform_from_x<W>(y, k, t);
+            int cl = 0;
+            // the four successors differ in the last nucleotide only: one shared descent, four finishes
+            const int cr = bft_walk_last4<W, BftRootLds<STAGED>>(im, acc, root, t, counts != nullptr);
+            if (counts || cr < 2) {
+                // predecessors: shift in a wildcard first nucleotide, drop the last one
+#pragma unroll
+                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
+                const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
+                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
+                bft_tform_from_x<W>(y, k, t);
+                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
+                for (uint64_t nt = 0; nt < 4 && (counts || cl < 2); nt++) {
+                    uint64_t tt[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) tt[w] = t[w] | (w == ow ? nt << osh : 0ull);
+                    cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
+                }
+            }
+            branching = cr > 1 || cl > 1;
+            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
+        }
+        const uint64_t mask = __ballot(branching);
+        const uint64_t q0 = i & ~63ull;
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+    }
+}
+
+// the two register budgets of k_query / k_query8 (see there)
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                     uint8_t* __restrict__ counts) {
+    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
+}
+template <int W, int BLOCK, bool STAGED>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_branching8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n,
+                                                                                                 int B, uint64_t* __restrict__ bits64,
+                                                                                                 uint8_t* __restrict__ counts) {
+    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
+}
