@@ -420,17 +420,20 @@ struct Writer {
     void u32(uint32_t v) { wr(&v, 4); }
     void i32(int32_t v) { wr(&v, 4); }
 
-    // nucleotides [from, k) of the k-mer at T-form row -> packed suffix bytes
+    // nucleotides [from, k) of the k-mer at T-form row -> packed suffix bytes.  In the packed layout nucleotide j sits at bits
+    // 2j, so the suffix is the k-mer shifted right by 2*from bits, little-endian bytes (the bits above 2k are zero).
     template <int WW>
     void suffix_bytes_w(const uint64_t* t, int from, uint8_t* out, int nbytes) const {
-        uint64_t x[WW];
+        uint64_t x[WW + 1];
         bft_x_from_tform<WW>(t, k, x);
-        memset(out, 0, (size_t)nbytes);
-        for (int j = from; j < k; j++) {
-            const uint32_t code = (uint32_t)(x[(2 * j) >> 6] >> ((2 * j) & 63)) & 3u;
-            const int q = j - from;
-            out[q / 4] |= (uint8_t)(code << (2 * (q % 4)));
+        x[WW] = 0;
+        const int ws = (2 * from) >> 6, bs = (2 * from) & 63;
+        uint64_t y[WW];
+        for (int w = 0; w < WW; w++) {
+            const uint64_t lo = w + ws < WW ? x[w + ws] : 0ull, hi = w + ws + 1 < WW ? x[w + ws + 1] : 0ull;
+            y[w] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
         }
+        memcpy(out, y, (size_t)nbytes);  // little-endian host, as the .bft format itself assumes (native ints)
     }
     void suffix_bytes(const uint64_t* t, int from, uint8_t* out, int nbytes) const {
         switch (W) {
@@ -440,40 +443,66 @@ struct Writer {
         default: suffix_bytes_w<4>(t, from, out, nbytes); break;
         }
     }
-    void annot_of_row(uint64_t row, std::vector<uint8_t>& a) {
+    // annotation bytes of a row: encoded once per colour set (many rows share a set)
+    std::vector<std::vector<uint8_t>> cs_annot;
+    std::vector<uint8_t> cs_done;
+    const std::vector<uint8_t>* annot_of_row(uint64_t row) {
         const uint32_t cs = im.tcol[row];
-        annot_encode(&im.cs_ids[im.cs_off[cs]], im.cs_off[cs + 1] - im.cs_off[cs], a);
+        if (cs_done.empty()) {
+            cs_annot.resize(im.cs_off.size());
+            cs_done.assign(im.cs_off.size(), 0);
+        }
+        if (!cs_done[cs]) {
+            annot_encode(&im.cs_ids[im.cs_off[cs]], im.cs_off[cs + 1] - im.cs_off[cs], cs_annot[cs]);
+            cs_done[cs] = 1;
+        }
+        return &cs_annot[cs];
     }
 
-    // rows (given by tk row indices) -> sorted by memcmp of the suffix bytes, with annotations; write_UC layout
-    struct Block { std::vector<uint8_t> data; int size_annot = 0; int count = 0; };
-    void make_rows(const std::vector<uint64_t>& rows, int from_nt, int nbs, std::vector<std::vector<uint8_t>>& suf, std::vector<std::vector<uint8_t>>& ann) {
-        suf.assign(rows.size(), std::vector<uint8_t>(nbs));
-        ann.assign(rows.size(), std::vector<uint8_t>());
-        std::vector<size_t> order(rows.size());
-        for (size_t q = 0; q < rows.size(); q++) {
-            suffix_bytes(&im.tk[rows[q] * W], from_nt, suf[q].data(), nbs);
-            annot_of_row(rows[q], ann[q]);
-            order[q] = q;
+    // rows of one UC block: suffixes in one flat buffer (nbs bytes each), annotations as pointers into the per-colour-set cache
+    struct RowSet {
+        int nbs = 0;
+        std::vector<uint8_t> suf;
+        std::vector<const std::vector<uint8_t>*> ann;
+        size_t size() const { return ann.size(); }
+    };
+    std::vector<uint8_t> tmp_suf;
+    std::vector<uint32_t> tmp_order;
+    // appends the rows [row0, row0 + cnt) of the table (or the listed rows) to `out`, sorted by memcmp of the suffix bytes
+    // (write_UC layout); returns the index of the first appended row
+    size_t append_rows(const uint64_t* rows, uint64_t row0, size_t cnt, int from_nt, int nbs, RowSet& out) {
+        out.nbs = nbs;
+        const size_t first = out.size();
+        tmp_suf.resize(cnt * (size_t)nbs);
+        tmp_order.resize(cnt);
+        for (size_t q = 0; q < cnt; q++) {
+            const uint64_t r = rows ? rows[q] : row0 + q;
+            if (nbs) suffix_bytes(&im.tk[r * W], from_nt, &tmp_suf[q * (size_t)nbs], nbs);
+            tmp_order[q] = (uint32_t)q;
         }
-        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return memcmp(suf[a].data(), suf[b].data(), (size_t)nbs) < 0; });
-        std::vector<std::vector<uint8_t>> s2(rows.size()), a2(rows.size());
-        for (size_t q = 0; q < rows.size(); q++) { s2[q].swap(suf[order[q]]); a2[q].swap(ann[order[q]]); }
-        suf.swap(s2);
-        ann.swap(a2);
+        if (nbs) std::sort(tmp_order.begin(), tmp_order.end(), [&](uint32_t a, uint32_t b) { return memcmp(&tmp_suf[a * (size_t)nbs], &tmp_suf[b * (size_t)nbs], (size_t)nbs) < 0; });
+        out.suf.resize((first + cnt) * (size_t)nbs);
+        for (size_t q = 0; q < cnt; q++) {
+            const uint32_t o = tmp_order[q];
+            if (nbs) memcpy(&out.suf[(first + q) * (size_t)nbs], &tmp_suf[o * (size_t)nbs], (size_t)nbs);
+            out.ann.push_back(annot_of_row(rows ? rows[o] : row0 + o));
+        }
+        return first;
     }
-    void write_block(const std::vector<std::vector<uint8_t>>& suf, const std::vector<std::vector<uint8_t>>& ann, int nbs, int header_field, bool with_header) {
+    std::vector<uint8_t> line;
+    void write_block(const RowSet& rs, int header_field, bool with_header) {
         if (with_header) u16((uint16_t)header_field);
-        if (suf.empty()) return;
+        if (rs.size() == 0) return;
+        const int nbs = rs.nbs;
         size_t sa = 1;
-        for (auto& a : ann) sa = std::max(sa, a.size());
+        for (auto* a : rs.ann) sa = std::max(sa, a->size());
         u16(0);  // nb_extended_annot
         i32((int32_t)sa);
-        std::vector<uint8_t> line(nbs + sa);
-        for (size_t q = 0; q < suf.size(); q++) {
+        line.assign((size_t)nbs + sa, 0);
+        for (size_t q = 0; q < rs.size(); q++) {
             std::fill(line.begin(), line.end(), 0);
-            if (nbs) memcpy(line.data(), suf[q].data(), (size_t)nbs);
-            memcpy(line.data() + nbs, ann[q].data(), ann[q].size());
+            if (nbs) memcpy(line.data(), &rs.suf[q * (size_t)nbs], (size_t)nbs);
+            memcpy(line.data() + nbs, rs.ann[q]->data(), rs.ann[q]->size());
             wr(line.data(), line.size());
         }
     }
@@ -484,9 +513,9 @@ struct Writer {
         {   // node UC (write_Node -> write_UC, src/write_to_disk.c:84-105)
             std::vector<uint64_t> rows;
             for (uint32_t q = 0; q < nd.uc_n; q++) rows.push_back(im.ucrow[nd.uc_first + q]);
-            std::vector<std::vector<uint8_t>> suf, ann;
-            make_rows(rows, 9 * d, nb_bytes(i), suf, ann);
-            write_block(suf, ann, nb_bytes(i), (nd.uc_n << 1) | flag, true);
+            RowSet rs;
+            append_rows(rows.data(), 0, rows.size(), 9 * d, nb_bytes(i), rs);
+            write_block(rs, (nd.uc_n << 1) | flag, true);
         }
         u32(nd.ncc);
         for (uint32_t c = 0; c < nd.ncc && !err; c++) write_cc(im.ccs[nd.cc_first + c], d, c + 1 == nd.ncc);
@@ -547,27 +576,20 @@ struct Writer {
             wr(ct.data(), ct.size());
             const int nbs = nb_bytes(i - 9);
             for (int b = 0; b < nbk && !err; b++) {
-                std::vector<std::vector<uint8_t>> bsuf, bann;
+                RowSet rs;
+                rs.nbs = nbs;
                 for (int j = b * 128; j < std::min(n, b * 128 + 128); j++) {
                     if (!prefs[j].cnt) continue;
-                    std::vector<uint64_t> rows;
-                    for (uint32_t q = 0; q < prefs[j].cnt; q++) rows.push_back(prefs[j].idx + q);
-                    std::vector<std::vector<uint8_t>> suf, ann;
-                    make_rows(rows, 9 * (d + 1), nbs, suf, ann);
-                    if (!lm && prefs[j].start) suf[0][nbs - 1] |= 0x80;  // cluster-start flag, src/CC.c:349-352
-                    for (size_t q = 0; q < suf.size(); q++) { bsuf.push_back(std::move(suf[q])); bann.push_back(std::move(ann[q])); }
+                    const size_t first = append_rows(nullptr, prefs[j].idx, prefs[j].cnt, 9 * (d + 1), nbs, rs);
+                    if (!lm && prefs[j].start) rs.suf[first * (size_t)nbs + nbs - 1] |= 0x80;  // cluster-start flag, src/CC.c:349-352
                 }
-                write_block(bsuf, bann, nbs, (int)bsuf.size(), true);
+                write_block(rs, (int)rs.size(), true);
             }
         } else {
             for (int b = 0; b < nbk && !err; b++) {
-                std::vector<std::vector<uint8_t>> bsuf, bann;
-                for (int j = b * 128; j < std::min(n, b * 128 + 128); j++) {
-                    bsuf.push_back(std::vector<uint8_t>());
-                    bann.push_back(std::vector<uint8_t>());
-                    annot_of_row(prefs[j].idx, bann.back());
-                }
-                write_block(bsuf, bann, 0, 0, false);
+                RowSet rs;
+                for (int j = b * 128; j < std::min(n, b * 128 + 128); j++) rs.ann.push_back(annot_of_row(prefs[j].idx));
+                write_block(rs, 0, false);
             }
         }
         if (!leaf)
