@@ -424,7 +424,7 @@ BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint
     uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
     int dir = 0;
     const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
-    constexpr int NS = W == 1 ? 4 : 2, NB = W == 1 ? 8 : 4;  // 32-byte / 64-byte blocks
+    constexpr int NS = 4, NB = W == 1 ? 8 : 4;  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
 #pragma unroll
     for (int step = 0; step < BFT_PROBE_STEPS; step++) {
         if (big ? bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit) : bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit)) return;
