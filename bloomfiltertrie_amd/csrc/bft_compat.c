@@ -238,6 +238,68 @@ bool is_kmer_in_cdbg(BFT_kmer* bft_kmer) {
     return bft_kmer->res->link_child != NULL;
 }
 
+/* ---------------------------------------------------------------- the harness seam (src/file_io.c loops) */
+
+int parseKmerCount(const char* line, int size_kmer, uint8_t* tab, int pos_tab) { /* src/fasta.c:3-53 */
+    NOT_NULL(line, "parseKmerCount()");
+    NOT_NULL(tab, "parseKmerCount()");
+    uint8_t* t = tab + pos_tab;
+    int j = 0;
+    for (; j < size_kmer; j++) {
+        unsigned c;
+        switch (line[j]) {
+        case 'a': case 'A': c = 0; break;
+        case 'c': case 'C': c = 1; break;
+        case 'g': case 'G': c = 2; break;
+        case 't': case 'T': case 'u': case 'U': c = 3; break;
+        default: /* IUPAC codes, end of line, anything else: the bytes touched so far are cleared (:49) */
+            memset(t, 0, (size_t)((j + 1) / 4));
+            return 0;
+        }
+        t[j >> 2] |= (uint8_t)(c << (2 * (j & 3)));
+    }
+    return 1;
+}
+
+void kmer_comp_to_ascii(const uint8_t* kmer_comp, int k, char* kmer) {
+    NOT_NULL(kmer_comp, "kmer_comp_to_ascii()");
+    NOT_NULL(kmer, "kmer_comp_to_ascii()");
+    unpack_kmer(kmer_comp, k, kmer);
+}
+
+int get_nb_bytes_power2_annot(uint32_t pos) { /* include/log2.h:45-50: CEIL(bits needed for pos, 6), 1 for pos = 0 */
+    const int bits = pos ? 32 - __builtin_clz(pos) : 1;
+    return (bits + 5) / 6;
+}
+
+void add_genomes_BFT_Root(int nb_files, char** filenames, BFT_Root* root) { /* include/CC.h:307-338 */
+    NOT_NULL(root, "add_genomes_BFT_Root()");
+    if (nb_files < 0) DIE("add_genomes_BFT_Root(): the number of genomes to insert cannot be less than 0.\n");
+    if (nb_files > 0) NOT_NULL(filenames, "add_genomes_BFT_Root()");
+    for (int i = 0; i < nb_files; i++) {
+        NOT_NULL(filenames[i], "add_genomes_BFT_Root()");
+        new_genome(root, filenames[i]);
+    }
+}
+
+void insertKmers(BFT_Root* root, uint8_t* array_kmers, int nb_kmers, uint32_t id_genome, int size_id_genome) {
+    (void)size_id_genome; /* width of the id inside the reference's annotation bytes: the colour sets here are id lists */
+    NOT_NULL(root, "insertKmers()");
+    if (nb_kmers <= 0) return;
+    NOT_NULL(array_kmers, "insertKmers()");
+    ck(bft_gpu_insert_kmers(root->gpu, array_kmers, (uint64_t)nb_kmers, id_genome), "insertKmers()");
+}
+
+resultPresence* isKmerPresent(Node* node, BFT_Root* root, int lvl_node, uint8_t* kmer, int size_kmer) {
+    NOT_NULL(root, "isKmerPresent()");
+    NOT_NULL(kmer, "isKmerPresent()");
+    if ((node != NULL && node != &root->node) || size_kmer != root->k || lvl_node != root->k / 9 - 1)
+        DIE("isKmerPresent(): only whole k-mers from the root vertex (&root->node, level k/9-1, size k) can be looked up.\n");
+    BFT_kmer tmp;
+    locate(root, kmer, 1, &tmp, "isKmerPresent()");
+    return tmp.res;
+}
+
 /* ---------------------------------------------------------------- annotations */
 
 BFT_annotation* create_BFT_annotation(void) {

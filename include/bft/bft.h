@@ -38,6 +38,14 @@ extern "C" {
 
 struct BFT_Root;
 
+/* A trie vertex (reference: include/Node.h:55-58, {CC_array, UC_array}).  The index lives in HBM, so a Node is an opaque
+ * placeholder here: the only Node a caller can name is &root->node, which is what the reference's harness passes to
+ * isKmerPresent (src/file_io.c:732,810). */
+typedef struct {
+    void* CC_array; /* always NULL */
+    uint64_t reserved[2];
+} Node;
+
 /* Location of a looked-up k-mer (reference: include/Node.h:60-92, host pointers and positions inside the trie). */
 typedef struct {
     void* link_child;      /* non-NULL iff the k-mer is stored (the test of is_kmer_in_cdbg, src/bft.c:246-248) */
@@ -58,6 +66,7 @@ typedef struct BFT_Root {
     uint8_t compressed; /* always 0, as the reference's CLI and create_cdbg set it */
     uint8_t marked;     /* always 0 here (marking is not provided) */
     bft_gpu* gpu;       /* the index, resident in HBM */
+    Node node;          /* last member as in the reference (include/Node.h:121): the root vertex handed to isKmerPresent */
 } BFT_Root;
 
 typedef BFT_Root BFT; /* include/bft.h:29 */
@@ -90,6 +99,25 @@ void free_cdbg(BFT* bft);
 void insert_genomes_from_files(int nb_files, char** paths, BFT* bft, char* prefix_bft_filename);
 void insert_kmers_new_genome(int nb_kmers, char** kmers, char* genome_name, BFT* bft);
 void insert_kmers_last_genome(int nb_kmers, char** kmers, BFT* bft);
+
+/* ---- the per-k-mer seam the reference's own harness calls directly, not through bft.h: the loops of
+ * src/file_io.c:726-768 / :810 (presence CSV) and :146,166,181 (build) relink against these unchanged ---- */
+/* include/presenceNode.h:57, src/presenceNode.c:1823-1921.  `node` must be &root->node (or NULL), lvl_node the root
+ * level k/9-1 and size_kmer == root->k: the whole-k-mer lookup, which is the only way the harness calls it.  The result
+ * is malloc'd and the caller frees it (src/file_io.c:767). */
+resultPresence* isKmerPresent(Node* node, BFT_Root* root, int lvl_node, uint8_t* kmer, int size_kmer);
+/* include/insertNode.h:26, src/insertNode.c:18-36: nb_kmers packed k-mers (contiguous, parseKmerCount layout) of genome
+ * id_genome; size_id_genome (= get_nb_bytes_power2_annot(id_genome)) is accepted and not needed. */
+void insertKmers(BFT_Root* root, uint8_t* array_kmers, int nb_kmers, uint32_t id_genome, int size_id_genome);
+/* include/CC.h:307-338: appends nb_files genome names (copied) to root->filenames, nb_genomes += nb_files */
+void add_genomes_BFT_Root(int nb_files, char** filenames, BFT_Root* root);
+/* src/fasta.c:3-53: ORs the 2-bit codes of the first size_kmer characters of line into tab[pos_tab..] (the caller
+ * pre-zeroes); 1 when all of them are in ACGTU (either case), else 0 with the bytes written so far cleared. */
+int parseKmerCount(const char* line, int size_kmer, uint8_t* tab, int pos_tab);
+/* src/fasta.c:55-87 */
+void kmer_comp_to_ascii(const uint8_t* kmer_comp, int k, char* kmer);
+/* include/log2.h:45-50: bytes an annotation needs to hold genome id `pos` in its list encodings */
+int get_nb_bytes_power2_annot(uint32_t pos);
 
 /* ---- k-mers (include/bft.h:81-87, :125-126; src/bft.c:125-340) ---- */
 BFT_kmer* create_kmer(const char* kmer, int k);

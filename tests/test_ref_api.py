@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMPAT_HEADER = os.path.join(ROOT, "include", "bft", "bft.h")
 LIBBFT = os.path.join(_lib.CSRC, "libbft.so")
 PROGRAM_SRC = os.path.join(ROOT, "tests", "c", "ref_api_program.c")
+LOOP_SRC = os.path.join(ROOT, "tests", "c", "ref_loop_program.c")
 
 
 @pytest.fixture(scope="session")
@@ -35,9 +36,9 @@ def _declared():
     return set(re.findall(r"\b([a-zA-Z_][a-zA-Z_0-9]*)\s*\([^;{]*\)\s*;", hdr))
 
 
-def _compile(tmp_path):
-    exe = str(tmp_path / "ref_api_program")
-    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, PROGRAM_SRC,
+def _compile(tmp_path, src=PROGRAM_SRC):
+    exe = str(tmp_path / os.path.basename(src)[:-2])
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
                            "-L", _lib.CSRC, "-lbft", f"-Wl,-rpath,{_lib.CSRC}", f"-Wl,-rpath-link,{_lib.CSRC}",
                            "-Wl,-rpath-link,/opt/rocm/lib"])
     return exe
@@ -99,6 +100,46 @@ int main(int argc, char**) {
     subprocess.check_call(["g++", "-fpermissive", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src), "-L", _lib.CSRC, "-lbft",
                            f"-Wl,-rpath,{_lib.CSRC}", f"-Wl,-rpath-link,{_lib.CSRC}", "-Wl,-rpath-link,/opt/rocm/lib"])
     assert subprocess.run([exe]).returncode == 0
+
+
+def test_harness_seam_is_exported_with_the_reference_signatures(built, oracle_mod, tmp_path):
+    """SURVEY 8b "existing per-k-mer entry points to keep": isKmerPresent (include/presenceNode.h:57) and insertKmers
+    (include/insertNode.h:26) plus the helpers the loops of src/file_io.c use around them.  The program below is those
+    two loops written against these names only; here it must compile and link, and the host-only helpers are checked
+    against the oracle (whose get_nb_bytes_power2_annot is pinned to the reference's own log2.c)."""
+    src = open(LOOP_SRC).read()
+    for name in ("isKmerPresent(&(root->node), root, lvl_root", "insertKmers(root, array_kmers", "add_genomes_BFT_Root(1, &str_tmp, root)",
+                 "parseKmerCount(", "get_nb_bytes_power2_annot("):
+        assert name in src, name
+    assert "bft_gpu_" not in src and "get_kmer(" not in src
+    exe = _compile(tmp_path, LOOP_SRC)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    lib = C.CDLL(LIBBFT)
+    lib.get_nb_bytes_power2_annot.argtypes = [C.c_uint32]
+    lib.get_nb_bytes_power2_annot.restype = C.c_int
+    for v in list(range(0, 300)) + [4095, 4096, 4097, (1 << 18) - 1, 1 << 18, (1 << 24) + 5, (1 << 31) - 1]:
+        assert lib.get_nb_bytes_power2_annot(v) == oracle_mod.nb_bytes_id(v), v
+    lib.parseKmerCount.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
+    lib.parseKmerCount.restype = C.c_int
+    lib.kmer_comp_to_ascii.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    rng = np.random.default_rng(5)
+    for k in (9, 27, 31, 63):
+        codes = rng.integers(0, 4, (50, k), dtype=np.uint8)
+        packed = S.pack_codes(codes)
+        for i, line in enumerate(S.packed_to_ascii(packed, k)):
+            buf = (C.c_uint8 * 40)()
+            assert lib.parseKmerCount((line + "\t12\n").encode(), k, buf, 3) == 1
+            assert bytes(buf[3:3 + packed.shape[1]]) == packed[i].tobytes() and not any(buf[:3])
+            ok_o, packed_o = oracle_mod.parse_kmer(line, k)
+            assert ok_o and bytes(buf[3:3 + packed.shape[1]]) == packed_o.tobytes()
+            back = C.create_string_buffer(k + 1)
+            lib.kmer_comp_to_ascii(C.cast(buf, C.c_void_p).value + 3, k, back)
+            assert back.value.decode() == line
+            bad = line[:k // 2] + "N" + line[k // 2 + 1:]
+            buf2 = (C.c_uint8 * 40)()
+            assert lib.parseKmerCount(bad.encode(), k, buf2, 0) == 0
+            assert not any(buf2[: (k // 2 + 1) // 4])  # the bytes written before the bad character are cleared (src/fasta.c:49)
 
 
 def _neighbour_bits(kmer, side, present):
@@ -185,6 +226,51 @@ def test_reference_style_program_against_oracle(built, oracle_mod, tmp_path):
     o2 = oracle_mod.OracleBFT.load_bft(str(tmp_path / "out.bft"))
     b2, off2, ids2 = o2.query_colors(q)
     assert (b2 == bits).all() and (off2 == off).all() and (ids2 == ids).all()
+
+
+@pytest.mark.gpu
+def test_reference_harness_loops_against_oracle(built, oracle_mod, tmp_path):
+    """The build loop (src/file_io.c:116-185) and the presence-CSV loop (:700-895) of the reference's harness, relinked
+    against libbft.so through isKmerPresent / insertKmers: byte-identical CSV to the one the oracle's answers give."""
+    for k, ng in ((27, 5), (63, 3)):
+        d = tmp_path / f"k{k}"
+        d.mkdir()
+        exe = _compile(d, LOOP_SRC)
+        anc = S.random_genome(9000, 7 + k)
+        gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 90 + g), k)) for g in range(ng)]
+        gk[0] = np.concatenate([gk[0], S.low_entropy_kmers(20000, k, 5, seed=3, levels=2)])
+        files = []
+        for g, km in enumerate(gk):
+            p = d / f"g{g}.kmers"
+            lines = S.packed_to_ascii(km, k)
+            if g == 1:
+                lines = lines[:10] + ["", "ACGTNNNN", "N" * k] + lines[10:]  # not k-mers: skipped by parseKmerCount
+            p.write_text("\n".join(x + (" 3" if i % 2 else "") for i, x in enumerate(lines)) + "\n")  # optional count column
+            files.append(str(p))
+        o = oracle_mod.OracleBFT(k)
+        for g, km in enumerate(gk):
+            o.insert_kmers(np.ascontiguousarray(km), g)
+        allk = S.distinct(np.concatenate(gk))
+        rng = np.random.default_rng(4)
+        q = np.concatenate([allk[::7], S.snp_mutants(allk[::13], k, 9), S.pack_codes(rng.integers(0, 4, (200, k), dtype=np.uint8))])
+        q = q[rng.permutation(len(q))]
+        qa = S.packed_to_ascii(q, k)
+        bad_at = {5: "ACGT", 17: qa[17][:-1] + "N", 40: ""}
+        qlines = [bad_at.get(i, x) for i, x in enumerate(qa)]
+        (d / "queries.txt").write_text("\n".join(qlines) + "\n")
+        r = subprocess.run([exe, str(k), str(d / "queries.txt"), str(d / "out.csv")] + files, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        bits, off, ids = o.query_colors(q)
+        pres = S.from_bits(bits, len(q)).astype(bool)
+        exp = [",".join(f"g{g}.kmers" for g in range(ng))]
+        n_present = 0
+        for i in range(len(q)):
+            have = set() if i in bad_at else set(ids[int(off[i]):int(off[i + 1])].tolist())
+            n_present += bool(have)
+            assert i in bad_at or bool(have) == bool(pres[i])
+            exp.append(",".join("1" if g in have else "0" for g in range(ng)))
+        assert (d / "out.csv").read_text() == "\n".join(exp) + "\n"
+        assert r.stdout.strip().split("\n")[-1] == f"Nb k-mers present = {n_present}"
 
 
 @pytest.mark.gpu
