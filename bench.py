@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- batched k-mer presence throughput of the MI355X-native Bloom Filter Trie path.
 
-Metric (BASELINE.json): M k-mers/sec queried (presenceNode / isKmerPresent), 1/2/4/8 MI355X.
-Workload (configs[1], SURVEY.md 8d "Config 2"): 10 synthetic genomes (one 2 Mbp random ancestor, each genome
-= ancestor with 1 % i.i.d. SNPs), BFT resident in HBM, 10^8 batched presence queries per GPU (50 % sampled from
-the union of the genomes' k-mers, 50 % single-SNP mutants of present k-mers, interleaved at random).
-k = 27: the reference rejects k = 31 (k must be a multiple of 9, src/main.c:61-63; SURVEY.md F1), so 27 is the
-oracle-checkable stand-in the survey prescribes.
+Metric (BASELINE.json): M k-mers/sec queried (presenceNode / isKmerPresent), 1/2/4/8 MI355X; HBM GB/s vs peak.
 
-A "step" = one pass of the hot path (one bft_gpu_query_presence_dev launch) over the whole resident batch,
-followed for N > 1 by the RCCL all_gather of the presence bitmaps.  Inputs are resident in HBM before the timed
-region.  One JSON line is printed by rank 0.
+Workloads (generators in bloomfiltertrie_amd/workloads.py and synth.py):
+  N = 1   configs[1] ("config 2"): 10 synthetic genomes (one 2 Mbp random ancestor, 1 % i.i.d. SNPs each), BFT resident
+          in HBM, 10^8 batched presence queries (50 % stored k-mers, 50 % single-SNP mutants).  The same run also
+          measures the per-GPU share of configs[3] ("config 4": 100-genome index, 10^9 / 8 queries, every answer checked)
+          and reports it as `config4_share` -- the index the north-star target is quoted on.
+  N > 1   configs[3]: the 100-genome index replicated in every GPU's HBM (one RCCL broadcast of the image built on rank 0,
+          or every rank builds it: --replicate), 1.25x10^8 queries per GPU, the presence bitmaps all_gathered over xGMI,
+          the gather of step i overlapping the kernel of step i+1.
+k = 27: the reference rejects k = 31 (k must be a multiple of 9, src/main.c:61-63; SURVEY.md F1), so 27 is the
+oracle-checkable stand-in the survey prescribes; k = 31 is measured beside it as an extension (ground truth only).
+
+A "step" = one pass of the hot path (one bft_gpu_query_presence_dev call) over the whole resident batch, followed for
+N > 1 by the RCCL all_gather of the presence bitmaps.  Inputs are resident in HBM before the timed region.  Rank 0 prints
+ONE JSON line.  `python bench.py --gpus N` without torchrun starts the N ranks itself (fresh child processes, before
+this process touches a GPU).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (6.3 TB/s achievable)
 
 
 def parse():
@@ -33,62 +42,142 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=27)
-    ap.add_argument("--genomes", type=int, default=10)
+    ap.add_argument("--workload", choices=["auto", "config2", "config4"], default="auto", help="auto: config2 on one GPU, config4 on several")
+    ap.add_argument("--genomes", type=int, default=0, help="0 = the workload's own (10 / 100)")
     ap.add_argument("--genome-len", type=int, default=2_000_000)
     ap.add_argument("--snp-rate", type=float, default=0.01)
-    ap.add_argument("--queries", type=int, default=100_000_000, help="queries per GPU per step")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (0 = the workload's own: 10^8 / 1.25x10^8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU baseline (0 = auto)")
-    ap.add_argument("--verify", type=int, default=1_000_000, help="queries of the batch checked against ground truth")
+    ap.add_argument("--verify", type=int, default=1_000_000, help="config 2: queries of the batch checked against ground truth")
     ap.add_argument("--no-k31", action="store_true", help="skip the secondary k=31 measurement (extension beyond the reference)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-config4-share", action="store_true", help="N=1: skip the per-GPU share of config 4")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bitmap all_gather even with one rank (path check)")
-    ap.add_argument("--replicate", choices=["rebuild", "broadcast"], default="rebuild",
-                    help="how every rank gets the trie: each rank builds it (default, no collective outside the bitmap gather) "
-                         "or rank 0 builds it and one RCCL broadcast replicates the image")
+    ap.add_argument("--replicate", choices=["rebuild", "broadcast"], default="broadcast",
+                    help="N>1, how every rank gets the trie: rank 0 builds it and one RCCL broadcast replicates the image (default), "
+                         "or each rank builds it from the same seeded input (no collective outside the bitmap gather)")
     return ap.parse_args()
 
 
-def build_genome_kmers(args):
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (this parent never touches a GPU) and
+    return the worst exit code; rank 0's stdout (the JSON line) is this process's stdout."""
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def build_genome_kmers(k, genomes, genome_len, snp_rate):
     from bloomfiltertrie_amd import synth as S
-    anc = S.random_genome(args.genome_len, 1234)
-    out = []
-    for g in range(args.genomes):
-        genome = S.mutate(anc, args.snp_rate, 1000 + g)
-        out.append(S.distinct(S.kmers_of(genome, args.k)))
-    return out
+    anc = S.random_genome(genome_len, 1234)
+    return [S.distinct(S.kmers_of(S.mutate(anc, snp_rate, 1000 + g), k)) for g in range(genomes)]
 
 
 def make_queries_on_device(union_kmers, k, n, seed, device):
     """50 % sampled present k-mers, 50 % single-SNP mutants, interleaved at random; built on the GPU with torch."""
     import torch
+    from bloomfiltertrie_amd import workloads as W
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     U = torch.from_numpy(union_kmers).to(device)
-    nb = U.shape[1]
-    out = torch.empty((n, nb), dtype=torch.uint8, device=device)
+    out = torch.empty((n, U.shape[1]), dtype=torch.uint8, device=device)
     chunk = 1 << 24
     for a in range(0, n, chunk):
         m = min(chunk, n - a)
         idx = torch.randint(0, U.shape[0], (m,), generator=g, device=device)
-        q = U[idx]
-        mut = torch.rand(m, generator=g, device=device) < 0.5
-        pos = torch.randint(0, k, (m,), generator=g, device=device)
-        delta = torch.randint(1, 4, (m,), generator=g, device=device).to(torch.uint8)
-        byte = (pos // 4).long()
-        sh = (2 * (pos % 4)).to(torch.uint8)
-        rows = torch.arange(m, device=device)
-        cur = q[rows, byte]
-        nt = (cur >> sh) & 3
-        new = (nt + delta) & 3
-        newbyte = (cur & ~(torch.full_like(cur, 3) << sh)) | (new << sh)
-        q[rows, byte] = torch.where(mut, newbyte, cur)
-        out[a:a + m] = q
+        out[a:a + m] = W.snp_mutate_packed(U[idx], k, 0.5, g)
     return out
 
 
+def timed_launches(bft, dq_ptr, nq, bits_ptr, stream, reps):
+    """reps launches of the presence kernel on a resident batch; mean kernel time (HIP events on the launch stream)"""
+    import torch
+    bft.query_presence_dev(dq_ptr, nq, bits_ptr, stream)
+    torch.cuda.synchronize()
+    bft.kernel_time(reset=True)
+    for _ in range(reps):
+        bft.query_presence_dev(dq_ptr, nq, bits_ptr, stream)
+    torch.cuda.synchronize()
+    ms, n = bft.kernel_time(reset=True)
+    return ms / max(1, n)
+
+
+def config4_index(k, genomes, genome_len, snp_rate, device, local_rank, build_here=True):
+    """100-genome index through the device insert path; returns (bft or None, sorted distinct keys of the stored k-mers)"""
+    import torch
+    from bloomfiltertrie_amd import BFT, workloads as W
+    dev = torch.device("cuda", local_rank)
+    pan = W.PanGenome(genomes, genome_len, snp_rate, 4242, dev)
+    t0 = time.perf_counter()
+    if build_here:
+        bft = BFT(k, device=local_rank)
+        for gid in range(genomes):
+            bft.add_genome(f"genome_{gid}")
+        keys, n_in = W.build_index(bft, pan, k)
+    else:  # another rank builds the index; this one only needs the key table for its ground truth
+        bft, n_in = None, 0
+        keys = [W.unique_keys(W.keys_of(W.pack_windows(pan.genome(g), k))) for g in range(genomes)]
+    allk = W.union_of(keys)
+    return bft, allk, n_in, time.perf_counter() - t0
+
+
+def load_profile_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+def roofline_block(alg_bytes, nq, avg_ms, launches, kernel, pmc):
+    """`roofline` of the bench contract + the honest companions: `achieved` counts the bytes the REFERENCE
+    algorithm dereferences (SURVEY 8d recipe), `counter_frac` the bytes the chip really moved (PMC), and `gather` the bound
+    that actually binds: L2 misses per second against the measured random-gather ceiling of the chip."""
+    achieved = alg_bytes * nq / (avg_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+           "traffic": None, "kernel": kernel, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "alg_bytes_per_launch": round(alg_bytes * nq),
+           "note": "achieved = algorithmic bytes of the reference's scan (SURVEY 8d) / kernel time; the layout moves fewer bytes than that, "
+                   "see counter_frac (PMC traffic / time / peak) and gather (the binding limit)"}
+    if pmc:
+        per_q = pmc.get("fabric_bytes_per_query")
+        if per_q:
+            traffic = per_q * nq
+            out["traffic"] = round(traffic)
+            out["counter_GBps"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+            out["counter_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        mpq = pmc.get("l2_misses_per_query")
+        if mpq:
+            rate = mpq * nq / (avg_ms * 1e-3) / 1e9
+            ceil = pmc.get("gather_ceiling_G_per_s", 57.0)
+            out["gather"] = {"l2_misses_per_query": mpq, "l2_requests_per_query": pmc.get("l2_requests_per_query"), "G_misses_per_s": round(rate, 1),
+                             "ceiling_G_per_s": ceil, "frac": round(rate / ceil, 3), "ceiling_source": pmc.get("gather_ceiling_source", "profiles/r01_microbench_gather.txt")}
+        out["pmc_source"] = pmc.get("source")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -105,62 +194,61 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from bloomfiltertrie_amd import BFT, synth as S
+    from bloomfiltertrie_amd import BFT, synth as S, workloads as W
+    from bloomfiltertrie_amd.dist import GatherPipeline, replicate_image
 
-    # ---- build the trie (replicated on every rank) through the product insertion path ----
-    t_build0 = time.time()
-    gk = build_genome_kmers(args)
-    t_gen = time.time() - t_build0
-    with BFT(args.k, device=local_rank) as warm:  # loads the code objects and the hipCUB kernels once (not part of any figure)
-        warm.insert_kmers(gk[0][:100000], 0)
+    workload = args.workload if args.workload != "auto" else ("config2" if world == 1 else "config4")
+    genomes = args.genomes or (10 if workload == "config2" else 100)
+    nq = args.queries or (100_000_000 if workload == "config2" else 125_000_000)
+    k = args.k
+
+    with BFT(k, device=local_rank) as warm:  # loads the code objects and the hipCUB kernels once (not part of any figure)
+        wk = S.distinct(S.kmers_of(S.random_genome(120000, 5), k))
+        warm.insert_kmers(wk, 0)
         warm.build()
-        warm.query_presence(gk[0][:1000])
-    t0 = time.time()
-    bft = None
-    if rank == 0 or not (use_dist and args.replicate == "broadcast"):
-        bft = BFT(args.k, device=local_rank)
-        for gid, km in enumerate(gk):
-            bft.add_genome(f"genome_{gid}")
-            bft.insert_kmers(km, gid)
-        bft.build()
-    t_insert = time.time() - t0
-    if use_dist and args.replicate == "broadcast":
-        from bloomfiltertrie_amd.dist import replicate_image
+        warm.query_presence(wk[:1000])
+
+    # ---- the index (replicated on every rank) through the product insertion path, and the resident query batch ----
+    gk = union = allk = None
+    broadcast = use_dist and args.replicate == "broadcast"
+    if workload == "config2":
+        t0 = time.time()
+        gk = build_genome_kmers(k, genomes, args.genome_len, args.snp_rate)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        bft = None
+        if rank == 0 or not broadcast:
+            bft = BFT(k, device=local_rank)
+            for gid, km in enumerate(gk):
+                bft.add_genome(f"genome_{gid}")
+                bft.insert_kmers(km, gid)
+            bft.build()
+        t_insert = time.time() - t0
+        union = S.distinct(np.concatenate(gk))
+        n_pairs_in = sum(len(x) for x in gk)
+    else:
+        t_gen = 0.0
+        bft, allk, n_pairs_in, t_insert = config4_index(k, genomes, args.genome_len, args.snp_rate, device, local_rank, build_here=(rank == 0 or not broadcast))
+    if broadcast:
         bft = replicate_image(bft, local_rank, src=0, always_copy=args.force_dist and world == 1)
     info = bft.info()
-    union = S.distinct(np.concatenate(gk))
-    assert info["kmers"] == len(union), (info["kmers"], len(union))
+    build_times = bft.build_time() if (rank == 0 or not broadcast) else {}
+    n_stored = len(union) if union is not None else int(allk.numel())
+    assert info["kmers"] == n_stored, (info["kmers"], n_stored)
 
-    # ---- the query batch, resident in HBM ----
-    nq = args.queries
-    dq = make_queries_on_device(union, args.k, nq, 99 + rank, device)
-    # two result buffers: the bitmap gather of step i (RCCL, its own stream) overlaps the query kernel of step i+1
-    nbuf = 2 if use_dist else 1
-    bits_buf = [torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-    gath_buf = [torch.empty(bits_buf[0].numel() * world, dtype=torch.uint8, device=device) for _ in range(nbuf)] if use_dist else None
-    pending = [None] * nbuf
+    if workload == "config2":
+        dq = make_queries_on_device(union, k, nq, 99 + rank, device)
+        qk = None
+    else:
+        g = torch.Generator(device=device)
+        g.manual_seed(99 + rank)
+        dq, qk = W.presence_batch(allk, k, nq, g)
     stream = torch.cuda.current_stream().cuda_stream
-    step_no = [0]
-
-    def step():
-        b = step_no[0] % nbuf
-        step_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()  # the gather that last read this buffer
-            pending[b] = None
-        bft.query_presence_dev(dq.data_ptr(), nq, bits_buf[b].data_ptr(), stream)
-        if use_dist:
-            pending[b] = dist.all_gather_into_tensor(gath_buf[b], bits_buf[b], async_op=True)
-
-    def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+    pipe = GatherPipeline(lambda buf: bft.query_presence_dev(dq.data_ptr(), nq, buf.data_ptr(), stream), ((nq + 63) // 64) * 8, world, device, use_dist)
 
     for _ in range(args.warmup):
-        step()
-    drain()
+        pipe.step()
+    pipe.drain()
     torch.cuda.synchronize()
     bft.kernel_time(reset=True)
     if use_dist:
@@ -168,31 +256,39 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    drain()
+        pipe.step()
+    pipe.drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = bft.kernel_time(reset=True)
-    dbits = bits_buf[(step_no[0] - 1) % nbuf]  # the last step's answers
+    dbits, gathered = pipe.last()  # the last step's answers
     if use_dist:
-        gathered = gath_buf[(step_no[0] - 1) % nbuf]
         assert torch.equal(gathered[rank * dbits.numel():(rank + 1) * dbits.numel()], dbits)
-        if nbuf > 1 and step_no[0] > 1:
-            assert torch.equal(bits_buf[0], bits_buf[1])  # every step answers the same batch
+        if pipe.nbuf > 1 and pipe.steps > 1:
+            assert torch.equal(pipe.bits[0], pipe.bits[1])  # every step answers the same batch
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- correctness of the measured batch: ground truth on a slice + popcount property ----
-    nv = min(args.verify, nq)
-    host_q = dq[:nv].cpu().numpy()
-    got = S.from_bits(dbits[: (nv + 7) // 8].cpu().numpy(), nv)
-    truth = S.member(host_q, union)
-    parity_ok = bool((got == truth).all())
-    n_present = int(torch.from_numpy(np.unpackbits(dbits.cpu().numpy(), bitorder="little")[:nq]).sum())
+    # ---- correctness of the measured batch ----
+    if workload == "config2":  # ground truth on a slice + popcount
+        nv = min(args.verify, nq)
+        truth = S.member(dq[:nv].cpu().numpy(), union)
+        parity_ok = bool((S.from_bits(dbits[: (nv + 7) // 8].cpu().numpy(), nv) == truth).all())
+        checked = nv
+    else:                      # every answer of this rank's shard
+        truth_t = W.member(allk, qk)
+        parity_ok = bool((W.bits_to_bool(dbits, nq) == truth_t).all())
+        checked = nq
+        del truth_t
+    n_present = int(W.bits_to_bool(dbits, nq).sum())
+    if use_dist:
+        okt = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        parity_ok = bool(okt.item())
 
     if rank != 0:
         if use_dist:
@@ -200,6 +296,8 @@ def main():
         return
 
     value = nq * world * args.steps / elapsed / 1e6
+    wl_text = (f"k={k} (stand-in for k=31: reference requires k%9==0), {genomes}-genome BFT resident in HBM, {nq:.3g} batched presence queries per GPU "
+               f"(50% present / 50% SNP mutants)" + ("" if workload == "config2" else "; BASELINE configs[3]: index replicated per GPU, query batch sharded, bitmaps all_gathered"))
     out = {
         "metric": "M k-mers/sec queried (presenceNode)",
         "value": round(value, 3),
@@ -214,18 +312,18 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"k={args.k} (stand-in for k=31: reference requires k%9==0), {args.genomes}-genome BFT resident in HBM, "
-                        f"{nq:.0e} batched presence queries per GPU (50% present / 50% SNP mutants)",
-            "k": args.k, "genomes": args.genomes, "genome_len": args.genome_len, "snp_rate": args.snp_rate,
+            "workload": wl_text, "name": workload, "k": k, "genomes": genomes, "genome_len": args.genome_len, "snp_rate": args.snp_rate,
             "queries_per_gpu": nq, "distinct_kmers": info["kmers"], "pairs": info["pairs"],
             "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
             "parallelism": f"query-shard x{world}, trie replicated ({args.replicate if use_dist else 'single copy'})",
         },
         "parity_ok": parity_ok,
+        "answers_checked_per_gpu": checked,
         "present_fraction": round(n_present / nq, 4),
         "build": {"kmer_gen_s": round(t_gen, 2), "insert_build_s": round(t_insert, 2),
-                  "M_pairs_per_s": round(info["pairs"] / t_insert / 1e6, 3), **{k_: round(v, 1) for k_, v in bft.build_time().items()}},
+                  "M_pairs_per_s": round(n_pairs_in / max(t_insert, 1e-9) / 1e6, 3), **{k_: round(v, 1) for k_, v in build_times.items()}},
     }
+    avg_ms = kern_ms / max(1, launches)
 
     # ---- secondary: the host-buffer entry point (H2D + kernel + D2H through bft_gpu_query_presence); never `value` ----
     if world == 1 and not args.no_pcie:
@@ -240,46 +338,17 @@ def main():
                                  "note": "pageable host buffers in and out, one call; for reference only"}
         del hq
 
-    # ---- secondary: the same workload at the k the metric names (k=31), an extension the reference cannot run ----
-    if not args.no_k31 and world == 1:
-        try:
-            k31 = 31
-            anc31 = S.random_genome(args.genome_len, 1234)
-            gk31 = [S.distinct(S.kmers_of(S.mutate(anc31, args.snp_rate, 1000 + g), k31)) for g in range(args.genomes)]
-            b31 = BFT(k31, device=local_rank)
-            for gid, km in enumerate(gk31):
-                b31.insert_kmers(km, gid)
-            b31.build()
-            u31 = S.distinct(np.concatenate(gk31))
-            q31 = make_queries_on_device(u31, k31, nq, 77, device)
-            bits31 = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device)
-            b31.query_presence_dev(q31.data_ptr(), nq, bits31.data_ptr(), stream)
-            torch.cuda.synchronize()
-            b31.kernel_time(reset=True)
-            for _ in range(args.steps):
-                b31.query_presence_dev(q31.data_ptr(), nq, bits31.data_ptr(), stream)
-            torch.cuda.synchronize()
-            ms31, n31 = b31.kernel_time(reset=True)
-            nv31 = min(args.verify, nq)
-            ok31 = bool((S.from_bits(bits31[: (nv31 + 7) // 8].cpu().numpy(), nv31) == S.member(q31[:nv31].cpu().numpy(), u31)).all())
-            out["k31_extension"] = {"value": round(nq / (ms31 / n31) / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms31 / n31, 4),
-                                    "distinct_kmers": int(len(u31)), "parity_vs_ground_truth": ok31,
-                                    "note": "k=31 is rejected by the reference (k % 9 != 0): no oracle exists; checked against set membership"}
-            b31.close()
-            del q31, bits31
-        except Exception as e:  # the headline line must not depend on the extension
-            out["k31_extension"] = {"error": str(e)}
-
-    # ---- CPU baseline (oracle "port") + algorithmic bytes per query from its counting mode ----
+    # ---- CPU baseline (oracle "port") + algorithmic bytes per query from its counting mode (config 2 only: the oracle
+    # builds a 10-genome trie in seconds; config 4's figure comes from profiles/r02_alg_bytes_config4.json) ----
     alg_bytes = None
-    if not args.no_cpu_baseline:
+    if workload == "config2" and not args.no_cpu_baseline:
         from oracle import oracle as O
         cores = os.cpu_count() or 1
         ns = args.cpu_sample or min(nq, 1_500_000 * cores)
         sample = dq[:ns].cpu().numpy()
         if world == 1:  # the timed CPU baseline is an N=1 figure
             t0 = time.time()
-            orc = O.OracleBFT(args.k)
+            orc = O.OracleBFT(k)
             for gid, km in enumerate(gk):
                 orc.insert_kmers(km, gid)
             orc.freeze()
@@ -299,8 +368,7 @@ def main():
                           f"(1 thread: {n1 / t_q1 / 1e6:.3f} M k-mers/s); oracle sequential build {t_obuild:.1f}s",
                 "single_thread": round(n1 / t_q1 / 1e6, 3),
             }
-        # algorithmic bytes per query (the roofline's numerator): the oracle's counting mode on a slice of the same batch
-        cnt = O.OracleBFT(args.k, count=True)
+        cnt = O.OracleBFT(k, count=True)
         for gid, km in enumerate(gk):
             cnt.insert_kmers(km, gid)
         nc = min(ns, 1_000_000)
@@ -308,26 +376,75 @@ def main():
         if world > 1:
             out["oracle_parity_ok"] = bool((np.asarray(cbits)[: nc // 8] == dbits[: nc // 8].cpu().numpy()).all())
         S_mean = c["bytes"] / nc
-        alg_bytes = S.kmer_bytes(args.k) + 1.0 / 8.0 + S_mean
-        out["algorithmic_bytes_per_query"] = {"total": round(alg_bytes, 2), "kmer_in": S.kmer_bytes(args.k), "bit_out": 0.125,
+        alg_bytes = S.kmer_bytes(k) + 1.0 / 8.0 + S_mean
+        out["algorithmic_bytes_per_query"] = {"total": round(alg_bytes, 2), "kmer_in": S.kmer_bytes(k), "bit_out": 0.125,
                                               "trie_S": round(S_mean, 2), "ccs_scanned": round(c["ccs_scanned"] / nc, 2),
                                               "levels": round(c["levels"] / nc, 3)}
+    alg4 = load_profile_json("r02_alg_bytes_config4.json")
+    if alg_bytes is None and workload == "config4" and alg4:
+        alg_bytes = alg4.get("total")
+        out["algorithmic_bytes_per_query"] = dict(alg4, source="profiles/r02_alg_bytes_config4.json (oracle counting mode on the same index and query generator)")
     if alg_bytes is None:
         alg_bytes = float(os.environ.get("BFT_ALG_BYTES_PER_QUERY", "0")) or None
-    avg_ms = kern_ms / max(1, launches)
+    pmc = load_profile_json("r02_pmc_query.json") or {}
     if alg_bytes:
-        achieved = alg_bytes * nq / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("k_query_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "k_query", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-                           "alg_bytes_per_launch": round(alg_bytes * nq)}
+        out["roofline"] = roofline_block(alg_bytes, nq, avg_ms, launches, "k_query", pmc.get(workload))
+
+    # ---- N = 1: the per-GPU share of configs[3] (the index the north-star target names), every answer checked ----
+    if world == 1 and workload == "config2" and not args.no_config4_share:
+        try:
+            del dq
+            torch.cuda.empty_cache()
+            share = {}
+            for kk in ([27] if args.no_k31 else [27, 31]):
+                b4, allk4, n_in4, t_b4 = config4_index(kk, 100, args.genome_len, args.snp_rate, device, local_rank)
+                g = torch.Generator(device=device)
+                g.manual_seed(99)
+                n4 = 125_000_000
+                dq4, qk4 = W.presence_batch(allk4, kk, n4, g)
+                bits4 = torch.zeros(((n4 + 63) // 64) * 8, dtype=torch.uint8, device=device)
+                ms4 = timed_launches(b4, dq4.data_ptr(), n4, bits4.data_ptr(), stream, max(3, args.steps // 2))
+                ok4 = bool((W.bits_to_bool(bits4, n4) == W.member(allk4, qk4)).all())
+                i4 = b4.info()
+                blk = {"value": round(n4 / ms4 / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms4, 4), "queries": n4,
+                       "all_answers_checked": ok4, "insert_build_s": round(t_b4, 2), "M_pairs_per_s": round(n_in4 / t_b4 / 1e6, 1),
+                       "trie": {x: i4[x] for x in ("kmers", "pairs", "colorsets", "nodes", "ccs", "child_nodes", "root_ccs", "image_bytes")},
+                       "tuned": {k_: v for k_, v in b4.build_time().items() if k_.startswith("query_")}}
+                if kk == 27 and alg4 and alg4.get("total"):
+                    blk["roofline"] = roofline_block(alg4["total"], n4, ms4, max(3, args.steps // 2), "k_query", pmc.get("config4"))
+                share[f"k{kk}"] = blk
+                b4.close()
+                del dq4, qk4, bits4, allk4
+                torch.cuda.empty_cache()
+            share["note"] = ("BASELINE configs[3] per-GPU share: 100-genome index (image beyond the 256 MiB Infinity Cache), 10^9/8 queries; "
+                             "k=27 is the oracle-compatible stand-in, k=31 the k the metric names (extension, ground truth only)")
+            out["config4_share"] = share
+        except Exception as e:  # the headline line must not depend on the secondary measurement
+            out["config4_share"] = {"error": repr(e)}
+
+    # ---- secondary: the headline workload at the k the metric names (k=31), an extension the reference cannot run ----
+    if not args.no_k31 and world == 1 and workload == "config2":
+        try:
+            k31 = 31
+            gk31 = build_genome_kmers(k31, genomes, args.genome_len, args.snp_rate)
+            b31 = BFT(k31, device=local_rank)
+            for gid, km in enumerate(gk31):
+                b31.insert_kmers(km, gid)
+            b31.build()
+            u31 = S.distinct(np.concatenate(gk31))
+            q31 = make_queries_on_device(u31, k31, nq, 77, device)
+            bits31 = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=device)
+            ms31 = timed_launches(b31, q31.data_ptr(), nq, bits31.data_ptr(), stream, args.steps)
+            nv31 = min(args.verify, nq)
+            ok31 = bool((S.from_bits(bits31[: (nv31 + 7) // 8].cpu().numpy(), nv31) == S.member(q31[:nv31].cpu().numpy(), u31)).all())
+            out["k31_extension"] = {"value": round(nq / ms31 / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms31, 4),
+                                    "distinct_kmers": int(len(u31)), "parity_vs_ground_truth": ok31,
+                                    "note": "k=31 is rejected by the reference (k % 9 != 0): no oracle exists; checked against set membership"}
+            b31.close()
+            del q31, bits31
+        except Exception as e:  # the headline line must not depend on the extension
+            out["k31_extension"] = {"error": repr(e)}
+
     if use_dist:
         dist.destroy_process_group()
     # RCCL writes its banner through C stdio: flush that first so that the JSON line is the last line of stdout

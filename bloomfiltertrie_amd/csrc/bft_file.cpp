@@ -183,8 +183,14 @@ struct Reader {
         return annot_decode(a, size, ids);
     }
 
+    uint64_t left = 0;  // bytes of the file not read yet: every size taken from the file is checked against it before allocating
+    int nbg = 0;        // genomes declared by the header: no annotation may name an id beyond them
     void fail(const char* m) { if (!err) { err = true; msg = m; } }
-    void rd(void* p, size_t n) { if (!err && n && fread(p, 1, n, f) != n) fail("truncated file"); }
+    bool fits(uint64_t n) { if (!err && n > left) fail("truncated file (a size field exceeds what is left of the file)"); return !err; }
+    void rd(void* p, size_t n) {
+        if (!err && n && (n > left || fread(p, 1, n, f) != n)) fail("truncated file");
+        if (!err) left -= n;
+    }
     uint16_t u16() { uint16_t v = 0; rd(&v, 2); return v; }
     uint32_t u32() { uint32_t v = 0; rd(&v, 4); return v; }
     int32_t i32() { int32_t v = 0; rd(&v, 4); return v; }
@@ -198,6 +204,7 @@ struct Reader {
         if (err) return;
         if (next == 0xffff || sa < 0 || sa > (1 << 24)) { fail("compressed UC or bad size_annot"); return; }
         r.size_annot = sa;
+        if (!fits((uint64_t)count * (uint64_t)(nbs + sa) + 3ull * next)) return;
         r.data.resize((size_t)count * (nbs + sa));
         rd(r.data.data(), r.data.size());
         int pos = 0;
@@ -215,7 +222,7 @@ struct Reader {
         nd.flag = field & 1;
         read_rows(nd.uc, nb_bytes(i), field >> 1);
         const uint32_t ncc = u32();
-        if (err || ncc > (1u << 24)) { fail("bad CC count"); return; }
+        if (err || ncc > (1u << 24) || !fits(6ull * ncc)) { fail("bad CC count"); return; }  // >= 6 header bytes per CC
         nd.ccs.resize(ncc);
         for (uint32_t c = 0; c < ncc && !err; c++) parse_cc(nd.ccs[c], i);
     }
@@ -226,6 +233,7 @@ struct Reader {
         cc.n = n;
         const int p = 18 - cc.s, tbyte = (type >> 6) & 1;
         if (cc.s != 4 && cc.s != 8) { fail("bad CC type"); return; }
+        if (!fits(((uint64_t)1 << p) / 8 + (cc.s == 8 ? n : (n + 1) / 2))) return;
         cc.f2.resize((size_t(1) << p) / 8);
         cc.f3.resize(cc.s == 8 ? n : (n + 1) / 2);
         cc.ex.assign((n + 7) / 8 + 1, 0);
@@ -282,6 +290,7 @@ struct Reader {
         packed.assign(B, 0);
         for (int j = 0; j < k; j++) packed[j / 4] |= (uint8_t)(cur[j] << (2 * (j % 4)));
         for (uint32_t g : ids) {
+            if (g >= (uint32_t)nbg) { fail("an annotation names a genome id beyond nb_genomes"); return; }
             if (g >= out->per_genome.size()) out->per_genome.resize((size_t)g + 1);
             out->per_genome[g].insert(out->per_genome[g].end(), packed.begin(), packed.end());
         }
@@ -363,14 +372,20 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
     Reader R;
     R.f = fopen(path, "rb");
     if (!R.f) { err = std::string("cannot open ") + path; return false; }
+    if (fseek(R.f, 0, SEEK_END) == 0) {
+        const long sz = ftell(R.f);
+        R.left = sz > 0 ? (uint64_t)sz : 0;
+    }
+    rewind(R.f);
     const int lcs = R.i32();
-    if (R.err || lcs < 0 || lcs > (1 << 24)) { fclose(R.f); err = "bad .bft header"; return false; }
+    if (R.err || lcs < 0 || lcs > (1 << 24) || !R.fits(12ull * (uint64_t)lcs)) { fclose(R.f); err = "bad .bft header"; return false; }
     R.comp.resize(lcs);
     for (int e = 0; e < lcs && !R.err; e++) {  // src/write_to_disk.c:283-310
         R.rd(&R.comp[e].last_index, 8);
         R.comp[e].size_annot = R.i32();
         const int64_t cnt = e ? R.comp[e].last_index - R.comp[e - 1].last_index : R.comp[e].last_index + 1;
-        if (R.err || cnt < 0 || R.comp[e].size_annot < 0 || cnt * R.comp[e].size_annot > (int64_t(1) << 32)) { R.fail("bad comp_set_colors"); break; }
+        if (R.err || cnt < 0 || cnt > (int64_t(1) << 32) || R.comp[e].size_annot < 0 || cnt * R.comp[e].size_annot > (int64_t(1) << 32) ||
+            !R.fits((uint64_t)(cnt * R.comp[e].size_annot))) { R.fail("bad comp_set_colors"); break; }
         R.comp[e].bytes.resize((size_t)(cnt * R.comp[e].size_annot));
         R.rd(R.comp[e].bytes.data(), R.comp[e].bytes.size());
     }
@@ -381,7 +396,8 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
     out.k = R.i32();
     uint8_t comp = 0;
     R.rd(&comp, 1);
-    if (R.err || comp != 0 || nbg < 0 || nbg > 100000000 || !bft_reference_k(out.k)) { fclose(R.f); err = "bad .bft header"; return false; }
+    if (R.err || comp != 0 || nbg < 0 || nbg > 100000000 || !bft_reference_k(out.k) || !R.fits(2ull * (uint64_t)nbg)) { fclose(R.f); err = "bad .bft header"; return false; }
+    R.nbg = nbg;
     for (int g = 0; g < nbg && !R.err; g++) {
         const uint16_t len = R.u16();
         std::string name(len, '\0');

@@ -33,6 +33,9 @@
 
 #define BFT_BLOCK 256
 #define BFT_ABSENT_ROW 0xFFFFFFFFu
+// Genome ids index colour rows of CEIL(nb_genomes/8) bytes and bit positions of annotations: ids from 2^24 on are refused
+// (the reference's own annotation codec holds 6 bits per byte, include/log2.h:45-50: 2^24 ids already take 4-byte entries).
+#define BFT_MAX_GENOME_ID (1u << 24)
 
 static thread_local std::string g_err;
 int bft_fail(int code, const std::string& msg) {
@@ -63,7 +66,15 @@ struct PoolBlock {
 std::mutex g_pool_mu;
 std::vector<PoolBlock> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t POOL_MAX_BYTES = 24ull << 30;  // cached, unused memory kept at most (per process)
+// cached, unused memory kept at most (per process): 8 GiB unless BFT_GPU_POOL_MAX_MB says otherwise (0 = no cache);
+// torch's allocator cannot see these blocks, so the cap bounds what the library withholds from it
+size_t pool_max_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("BFT_GPU_POOL_MAX_MB");
+        return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)8 << 30;
+    }();
+    return v;
+}
 constexpr size_t POOL_MAX_BLOCKS = 256;
 thread_local int t_pool_device = -1;
 thread_local hipStream_t t_pool_stream = nullptr;
@@ -137,7 +148,7 @@ void bft_pool_release(void* p, size_t cap) {
     bool keep = t_pool_device >= 0;
     if (keep) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool.size() < POOL_MAX_BLOCKS && g_pool_bytes + cap <= POOL_MAX_BYTES) {
+        if (g_pool.size() < POOL_MAX_BLOCKS && g_pool_bytes + cap <= pool_max_bytes()) {
             g_pool.push_back(b);
             g_pool_bytes += cap;
         } else
@@ -205,11 +216,15 @@ struct bft_gpu {
     uint64_t info[16] = {0};
     double build_ms[5] = {0, 0, 0, 0, 0};
 
-    // kernel timing
+    // kernel timing: off until bft_gpu_kernel_time / set_option("timing", 1) asks for it; events are pooled per handle
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_ev;
+    std::vector<hipEvent_t> free_ev;
     double kernel_ms = 0;
     uint64_t kernel_launches = 0;
-    bool timing = true;
+    bool timing = false;
+    // last work the *_dev entry points put on a caller's stream: image arrays are not released or rewritten before it is done
+    hipEvent_t ext_ev = nullptr;
+    bool ext_pending = false;
     uint32_t root_ncc = 0;
     uint64_t idx_sizes[9] = {0};
     int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
@@ -219,6 +234,7 @@ struct bft_gpu {
     int tuned_probe = 0;
     double tune_ms[2] = {0, 0};
     int opt_grid_mult = 1;    // grid = resident workgroups x this
+    bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
 };
 
 static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
@@ -226,6 +242,33 @@ static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
 static int set_device(bft_gpu* h) {
     HIPCK(hipSetDevice(h->device));
     bft_pool_set_stream(h->device, h->stream);
+    return 0;
+}
+
+// Every ABI call makes the handle's GPU current; the caller's current device is put back when the call returns.
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ENTER(h)     \
+    DeviceScope ds_; \
+    CK(set_device(h))
+
+// A *_dev entry point launched on a caller's stream: remember where that work ends.
+static int note_foreign_stream(bft_gpu* h, hipStream_t s) {
+    if (s == h->stream) return 0;
+    if (!h->ext_ev) HIPCK(hipEventCreateWithFlags(&h->ext_ev, hipEventDisableTiming));
+    HIPCK(hipEventRecord(h->ext_ev, s));
+    h->ext_pending = true;
+    return 0;
+}
+// Before image arrays are released, rewritten or re-derived: the queries the caller still has in flight must have drained.
+static int wait_foreign_stream(bft_gpu* h) {
+    if (h->ext_pending) {
+        HIPCK(hipEventSynchronize(h->ext_ev));
+        h->ext_pending = false;
+    }
     return 0;
 }
 
@@ -244,6 +287,7 @@ extern "C" int bft_gpu_device_count(void) {
 extern "C" int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out) {
     if (!out) return fail(BFT_GPU_E_ARG, "out is NULL");
     *out = nullptr;
+    DeviceScope ds_;
     if (!bft_valid_k(k)) return fail(BFT_GPU_E_ARG, "Length k (for k-mers) must be in [9,126] (a multiple of 9 for reference-compatible indexes, src/main.c:61-63)");
     int ndev = 0;
     HIPCK(hipGetDeviceCount(&ndev));
@@ -283,17 +327,41 @@ static void drain_events(bft_gpu* h) {
             h->kernel_ms += ms;
             h->kernel_launches++;
         }
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        h->free_ev.push_back(pr.first);  // back to the handle's pool
+        h->free_ev.push_back(pr.second);
     }
     h->pending_ev.clear();
 }
 
+// Timed launches: a pair of pooled events around the kernel (no event is created on the launch path once the pool is warm).
+static int timing_begin(bft_gpu* h, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+    *e0 = *e1 = nullptr;
+    if (!h->timing) return 0;
+    if (h->pending_ev.size() >= 4096) drain_events(h);
+    for (hipEvent_t* e : {e0, e1}) {
+        if (!h->free_ev.empty()) { *e = h->free_ev.back(); h->free_ev.pop_back(); }
+        else HIPCK(hipEventCreate(e));
+    }
+    HIPCK(hipEventRecord(*e0, s));
+    return 0;
+}
+static int timing_end(bft_gpu* h, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (!e0) return 0;
+    HIPCK(hipEventRecord(e1, s));
+    h->pending_ev.push_back({e0, e1});
+    return 0;
+}
+
 extern "C" void bft_gpu_free(bft_gpu* h) {
     if (!h) return;
+    DeviceScope ds_;
     (void)hipSetDevice(h->device);
     bft_pool_set_stream(h->device, h->stream);
     drain_events(h);
+    (void)wait_foreign_stream(h);
+    for (hipEvent_t e : h->free_ev) (void)hipEventDestroy(e);
+    h->free_ev.clear();
+    if (h->ext_ev) (void)hipEventDestroy(h->ext_ev);
     const hipStream_t s = h->stream;
     if (s) (void)hipStreamSynchronize(s);
     delete h;                      // its buffers go to the cache under this stream's tag ...
@@ -351,8 +419,9 @@ static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t
 
 extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome) {
     if (!h || (!d_kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (id_genome >= BFT_MAX_GENOME_ID) return fail(BFT_GPU_E_ARG, "id_genome out of range (must be below 2^24)");
     if (n == 0) return BFT_GPU_OK;
-    CK(set_device(h));
+    ENTER(h);
     if (h->log_n + n + h->n_pairs >= 0x7FFFFFFFull) return fail(BFT_GPU_E_LIMIT, "more than 2^31-1 (k-mer, genome) pairs");
     CK(log_reserve(h, h->log_n + n));
     const uint8_t* p = (const uint8_t*)d_kmers;
@@ -373,8 +442,9 @@ extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_
 
 extern "C" int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint32_t id_genome) {
     if (!h || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (id_genome >= BFT_MAX_GENOME_ID) return fail(BFT_GPU_E_ARG, "id_genome out of range (must be below 2^24)");
     if (n == 0) return BFT_GPU_OK;
-    CK(set_device(h));
+    ENTER(h);
     const uint64_t chunk = 1ull << 26;
     DevBuf tmp;
     CK(tmp.alloc(std::min(n, chunk) * h->B));
@@ -481,8 +551,8 @@ static uint64_t image_bytes(const bft_gpu* h) {
 
 static int tune_residency(bft_gpu* h);
 
-// Points h->im at the device arrays of the handle and derives the bitmap form of the colour-set dictionary.
-static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
+// Points h->im at the device arrays of the handle (cannot fail).
+static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     BftImage& im = h->im;
     im.k = h->k;
     im.L = h->L;
@@ -502,8 +572,6 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     im.ucrow = h->d_ucrow.as<uint32_t>();
     im.cs_off = h->d_cs_off.as<uint32_t>();
     im.cs_ids = h->d_cs_ids.as<uint32_t>();
-    CK(bft_flatten_gpu(im.ccs, h->idx_sizes[2] / sizeof(BftCC), im.f2w, im.clus, im.child, h->opt_flat_min, h->stream, h->d_ccx, h->d_f18, h->d_fent,
-                       h->n_f18, h->n_fent));
     im.ccx = h->d_ccx.as<BftCCX>();
     im.f18 = h->d_f18.as<uint64_t>();
     im.fent = h->d_fent.as<uint64_t>();
@@ -513,6 +581,22 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
     h->im.probe_big = h->opt_probe == 8;
+}
+
+// (Re)derives the flat form of the handle's current containers, points the image at everything and tunes the launch.
+// The derived arrays are built aside and swapped in only once complete: a failure leaves the image as it was.
+static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
+    CK(wait_foreign_stream(h));
+    DevBuf ccx, f18, fent;
+    uint64_t n_f18 = 0, n_fent = 0;
+    CK(bft_flatten_gpu(h->d_ccs.as<BftCC>(), h->idx_sizes[2] / sizeof(BftCC), h->d_f2w.as<uint64_t>(), h->d_clus.as<uint64_t>(), h->d_child.as<uint64_t>(),
+                       h->opt_flat_min, h->stream, ccx, f18, fent, n_f18, n_fent));
+    h->d_ccx.swap(ccx);
+    h->d_f18.swap(f18);
+    h->d_fent.swap(fent);
+    h->n_f18 = n_f18;
+    h->n_fent = n_fent;
+    point_image(h, nb_genomes);
     if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     return 0;
 }
@@ -530,7 +614,7 @@ static int host_colorsets(bft_gpu* h) {
 
 extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
-    CK(set_device(h));
+    ENTER(h);
     if (h->built && h->log_n == 0) return BFT_GPU_OK;
     const int W = h->W;
     const uint64_t total = h->n_pairs + h->log_n;
@@ -566,9 +650,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(sort_pairs(h, src_k, src_stride, src_g, total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted));
         ck.release();
         cg.release();
-        h->log_k.release();
-        h->log_g.release();
-        h->log_cap = 0;
+        // (the insertion log stays until the new image is committed below: a failed build loses nothing)
         // 3. flags, scans, compaction
         DevBuf head, keep, posK, posP, tmp;
         CK(head.alloc(total * 4));
@@ -610,12 +692,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(seg_off.alloc_zero(4, h->stream));
         CK(npg.alloc(4));
     }
-    CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, h->d_tcol, h->d_cs_off, h->d_cs_ids, n_sets, n_ids));
-    h->n_sets = n_sets;
-    h->n_ids = n_ids;
-    h->cs_on_host = false;
-    h->cs_off.clear();
-    h->cs_ids.clear();
+    DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
+    CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
     double t2 = now_ms();
 
     // 5. containers, level by level, on the GPU
@@ -623,7 +701,33 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     BftDeviceIndex idx;
     CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx));
     double t3 = now_ms();
+    DevBuf n_ccx, n_f18buf, n_fentbuf;
+    uint64_t n_f18 = 0, n_fent = 0;
+    CK(bft_flatten_gpu(idx.ccs.as<BftCC>(), idx.n_ccs, idx.f2w.as<uint64_t>(), idx.clus.as<uint64_t>(), idx.child.as<uint64_t>(), h->opt_flat_min, h->stream,
+                       n_ccx, n_f18buf, n_fentbuf, n_f18, n_fent));
+    CK(wait_foreign_stream(h));  // queries a caller still has in flight on its own stream read the arrays released below
+    if (h->inject_build_failure) {
+        h->inject_build_failure = false;
+        return fail(BFT_GPU_E_LIMIT, "injected build failure (test hook)");
+    }
 
+    // ---- commit: nothing above touched the handle; from here on nothing can fail before the image is whole ----
+    h->d_tcol.swap(n_tcol);
+    h->d_cs_off.swap(n_cs_off);
+    h->d_cs_ids.swap(n_cs_ids);
+    h->n_sets = n_sets;
+    h->n_ids = n_ids;
+    h->cs_on_host = false;
+    h->cs_off.clear();
+    h->cs_ids.clear();
+    h->d_ccx.swap(n_ccx);
+    h->d_f18.swap(n_f18buf);
+    h->d_fent.swap(n_fentbuf);
+    h->n_f18 = n_f18;
+    h->n_fent = n_fent;
+    h->log_k.release();
+    h->log_g.release();
+    h->log_cap = 0;
     h->d_nodes.swap(idx.nodes);
     h->d_bfT.swap(idx.bfT);
     h->d_ccs.swap(idx.ccs);
@@ -645,11 +749,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
     h->idx_sizes[6] = idx.n_uc * (uint64_t)W * 8; h->idx_sizes[7] = idx.n_uc * 4; h->idx_sizes[8] = nk * (uint64_t)W * 8;
     h->root_ncc = (uint32_t)idx.root_ncc;
-    double t4 = now_ms();
-
-    CK(bind_image(h, std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0)));
+    point_image(h, std::max<uint32_t>((uint32_t)h->genomes.size(), h->any_insert ? h->max_gid_seen + 1 : 0));
     BftImage& im = h->im;
-    double t5 = now_ms();
 
     uint64_t* I = h->info;
     I[0] = h->k;
@@ -671,9 +772,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[0] = t1 - t0;
     h->build_ms[1] = t2 - t1;
     h->build_ms[2] = t3 - t2;
-    h->build_ms[3] = t4 - t3;
-    h->build_ms[4] = t5 - t4;
+    h->build_ms[3] = 0;
     h->built = true;
+    // launch tuning on the committed image (timing runs only: a failure here leaves a complete, queryable index)
+    if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
+    h->build_ms[4] = now_ms() - t3;
     return BFT_GPU_OK;
 }
 
@@ -737,23 +840,15 @@ static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
-        HIPCK(hipEventCreate(&e0));
-        HIPCK(hipEventCreate(&e1));
-        HIPCK(hipEventRecord(e0, s));
-    }
+    hipEvent_t e0, e1;
+    CK(timing_begin(h, s, &e0, &e1));
     switch (h->W) {
     case 1: CK(launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
     case 2: CK(launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
     case 3: CK(launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
     default: CK(launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
     }
-    if (h->timing) {
-        HIPCK(hipEventRecord(e1, s));
-        h->pending_ev.push_back({e0, e1});
-        if (h->pending_ev.size() > 8192) drain_events(h);
-    }
+    CK(timing_end(h, s, e0, e1));
     return 0;
 }
 
@@ -809,7 +904,7 @@ static int tune_residency(bft_gpu* h) {
     const bool timing = h->timing;
     const uint32_t dbg = h->im.debug_stop;
     h->timing = false;
-    h->im.debug_stop = 0;
+    h->im.debug_stop = 0;  // (only read by -DBFT_PERF_PROBE builds)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
@@ -870,12 +965,8 @@ static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, ui
 static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
     if (n == 0) return 0;
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
-        HIPCK(hipEventCreate(&e0));
-        HIPCK(hipEventCreate(&e1));
-        HIPCK(hipEventRecord(e0, s));
-    }
+    hipEvent_t e0, e1;
+    CK(timing_begin(h, s, &e0, &e1));
 #define BR(WW) (staged ? launch_branching_k<WW, true>(h, d_kmers, n, d_bits64, d_counts, s) : launch_branching_k<WW, false>(h, d_kmers, n, d_bits64, d_counts, s))
     switch (h->W) {
     case 1: CK(BR(1)); break;
@@ -884,24 +975,22 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     default: CK(BR(4)); break;
     }
 #undef BR
-    if (h->timing) {
-        HIPCK(hipEventRecord(e1, s));
-        h->pending_ev.push_back({e0, e1});
-    }
+    CK(timing_end(h, s, e0, e1));
     return 0;
 }
 
 extern "C" int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_branching_bits, void* d_counts, void* hip_stream) {
     if (!h || ((!d_kmers || !d_branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    return launch_branching(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_branching_bits, (uint8_t*)d_counts, s);
+    CK(launch_branching(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_branching_bits, (uint8_t*)d_counts, s));
+    return note_foreign_stream(h, s);
 }
 
 extern "C" int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* branching_bits, uint8_t* counts) {
     if (!h || ((!kmers || !branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     const uint64_t chunk = 1ull << 26;
     const uint64_t mc = std::min(n, chunk);
@@ -922,10 +1011,11 @@ extern "C" int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_
 
 extern "C" int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* hip_stream) {
     if (!h || ((!d_kmers || !d_present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    return launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, nullptr, s);
+    CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, nullptr, s));
+    return note_foreign_stream(h, s);
 }
 
 // ---- small host batches through the pinned block -------------------------------------------------------------------------
@@ -966,7 +1056,7 @@ static int query_small(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* pr
 
 extern "C" int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits) {
     if (!h || ((!kmers || !present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     if (n && n <= BFT_PIN_MAX_N) return query_small(h, kmers, n, present_bits, nullptr, nullptr);
     const uint64_t chunk = 1ull << 26;  // multiple of 64: chunks are byte aligned in the bitmap
@@ -994,7 +1084,7 @@ static int query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t m, DevBuf& dk, 
 extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint64_t* offsets,
                                     uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed) {
     if (!h || !offsets || ((!kmers) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     const uint64_t chunk = 1ull << 24;
     const uint64_t mc = std::min(n, chunk);
@@ -1081,19 +1171,19 @@ static int launch_color_rows(bft_gpu* h, const uint32_t* d_rowidx, uint64_t n, u
 extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* d_rows, void* d_scratch_rows_u32,
                                             void* hip_stream) {
     if (!h || ((!d_kmers || !d_present_bits || !d_rows || !d_scratch_rows_u32) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
     CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s));
     CK(launch_color_rows(h, (const uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s));
-    return BFT_GPU_OK;
+    return note_foreign_stream(h, s);
 }
 
 extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint8_t* rows) {
     if (!h || !rows || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (rowbytes == 0) return BFT_GPU_OK;
@@ -1122,7 +1212,7 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
                                        uint8_t* rows) {
     if (!h || ((!seqs || !seq_off || !rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (!(threshold > 0) || threshold > 1) return fail(BFT_GPU_E_ARG, "the threshold must be in (0, 1] (reference src/bft.c:1246-1247)");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
     if (rowbytes == 0 || n_seqs == 0) return BFT_GPU_OK;
@@ -1199,9 +1289,16 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
 extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
     if (!path || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     *out = nullptr;
+    DeviceScope ds_;
     BftFileContent fc;
     std::string err;
-    if (!bft_file_read(path, fc, err)) return fail(BFT_GPU_E_IO, err);
+    try {  // sizes come from an untrusted file: an allocation failure is an I/O error of this call, not the end of the process
+        if (!bft_file_read(path, fc, err)) return fail(BFT_GPU_E_IO, err);
+    } catch (const std::bad_alloc&) {
+        return fail(BFT_GPU_E_IO, "out of host memory while reading the .bft file (corrupt size field?)");
+    } catch (const std::exception& e) {
+        return fail(BFT_GPU_E_IO, std::string("malformed .bft file: ") + e.what());
+    }
     bft_gpu* h = nullptr;
     CK(bft_gpu_create_seeded(fc.k, device, fc.r1, fc.r2, &h));
     int rc = 0;
@@ -1229,7 +1326,7 @@ static int download(const DevBuf& d, uint64_t bytes, std::vector<T>& v) {
 extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     if (!h || !path) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (!bft_reference_k(h->k)) return fail(BFT_GPU_E_ARG, "the .bft format requires k % 9 == 0 (reference src/main.c:61-63)");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     BftHostImage hi;
     hi.k = h->k;
@@ -1249,7 +1346,13 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     hi.cs_off = h->cs_off;
     hi.cs_ids = h->cs_ids;
     std::string err;
-    if (!bft_file_write(path, hi, err)) return fail(BFT_GPU_E_IO, err);
+    try {
+        if (!bft_file_write(path, hi, err)) return fail(BFT_GPU_E_IO, err);
+    } catch (const std::bad_alloc&) {
+        return fail(BFT_GPU_E_LIMIT, "out of host memory while serialising the index");
+    } catch (const std::exception& e) {
+        return fail(BFT_GPU_E_IO, std::string("write_BFT: ") + e.what());
+    }
     return BFT_GPU_OK;
 }
 
@@ -1298,7 +1401,7 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
 
 extern "C" int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes) {
     if (!h || !nbytes) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     BlobPlan p;
     plan_blob(h, p);
@@ -1308,7 +1411,7 @@ extern "C" int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes) {
 
 extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* hip_stream) {
     if (!h || !d_blob) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     BlobPlan p;
     plan_blob(h, p);
@@ -1329,6 +1432,7 @@ extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* 
 extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int device, bft_gpu** out) {
     if (!d_blob || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     *out = nullptr;
+    DeviceScope ds_;
     if (nbytes < BLOB_HDR_WORDS * 8) return fail(BFT_GPU_E_ARG, "blob shorter than its header");
     int ndev = 0;
     HIPCK(hipGetDeviceCount(&ndev));
@@ -1389,7 +1493,7 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
 // Test hook (tests/test_gpu_build.py): raw copy of one index array of the image.
 extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     static const char* names[12] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent"};
     const DevBuf* bufs[12] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
@@ -1420,7 +1524,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
         // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)
         if (value < 0 || value >= 0x7FFFFFFFll) return fail(BFT_GPU_E_ARG, "reserve_pairs must be in [0, 2^31-1)");
-        CK(set_device(h));
+        ENTER(h);
         CK(log_reserve(h, (uint64_t)value));
     } else if (nm == "query_probe") {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
@@ -1429,15 +1533,19 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;
-    } else if (nm == "debug_stop") {
-        h->im.debug_stop = (uint32_t)value;  // perf probing only: truncates the walk, results are wrong
+#if defined(BFT_PERF_PROBE)
+    } else if (nm == "debug_stop") {  // libbft_gpu_probe.so only (make probe): truncates the walk, results are wrong
+        h->im.debug_stop = (uint32_t)value;
+#endif
+    } else if (nm == "inject_build_failure") {  // test hook (tests/test_gpu_build.py): exercises the all-or-nothing build
+        h->inject_build_failure = value != 0;
     } else if (nm == "timing") {
         h->timing = value != 0;
     } else if (nm == "flat_min") {
         if (value < 1 || value > 65536) return fail(BFT_GPU_E_ARG, "flat_min must be in [1,65536]");
         h->opt_flat_min = (uint32_t)value;
         if (h->built) {  // re-derive the flat arrays of the current image
-            CK(set_device(h));
+            ENTER(h);
             CK(bind_image(h, h->im.nb_genomes));
             h->info[12] = image_bytes(h);
         }
@@ -1456,8 +1564,9 @@ extern "C" int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out) {
 
 extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
-    CK(set_device(h));
+    ENTER(h);
     drain_events(h);
+    h->timing = true;  // from the first call on, query launches are bracketed by (pooled) events
     if (ms) *ms = h->kernel_ms;
     if (launches) *launches = h->kernel_launches;
     if (reset) {
@@ -1495,7 +1604,7 @@ __global__ void k_tform_to_packed(const uint64_t* __restrict__ tk, uint64_t n, i
 
 extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorset_out, uint64_t cap, uint64_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     if (n_out) *n_out = h->n_kmers;
     if (!kmers_out && !colorset_out) return BFT_GPU_OK;
@@ -1521,7 +1630,7 @@ extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorse
 
 extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t cap, uint32_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     CK(host_colorsets(h));
     if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
@@ -1538,7 +1647,7 @@ extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t
 // the row of the k-mer in the sorted table (the order of bft_gpu_extract) and the id of its colour set.
 extern "C" int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint32_t* rows, uint32_t* colorsets) {
     if (!h || (!kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     if (n && n <= BFT_PIN_MAX_N) return query_small(h, kmers, n, present_bits, rows, colorsets);
     const uint64_t chunk = 1ull << 24;
@@ -1566,7 +1675,7 @@ extern "C" int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, 
 // src/annotation.c:634-650) -- what get_annotation hands out as BFT_annotation::annot (src/bft.c:363-387).
 extern "C" int bft_gpu_colorset_annot(bft_gpu* h, uint32_t cs, uint8_t* annot, uint32_t cap, uint32_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
-    CK(set_device(h));
+    ENTER(h);
     CK(ensure_built(h));
     CK(host_colorsets(h));
     if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");

@@ -90,7 +90,8 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 struct BftImage {
     int k, L, W;
     uint32_t nb_genomes;
-    uint32_t debug_stop;      // perf probing only (tools/perf_probe.py): 0 = full walk; results are wrong when != 0
+    uint32_t debug_stop;      // read only by -DBFT_PERF_PROBE builds (libbft_gpu_probe.so, tools/perf_probe.py): truncates the
+                              // walk after a stage; the shipped library compiles those checks out (BFT_DBG_STOP == 0)
     uint32_t probe_big;       // suffix-group search (bft_group_probe): 0 = 4-row blocks, step to the adjacent block;
                               // 1 = 8-row blocks, next guess re-interpolated (big groups); same answers either way
     uint64_t n_kmers;

@@ -22,6 +22,14 @@
 #define BFT_WINDOW_PROBE 4
 #endif
 
+// Stage probes of tools/perf_probe.py: compiled in only with -DBFT_PERF_PROBE (make probe); a constant 0 otherwise, so the
+// shipped walk carries none of these branches and no option can make its answers wrong.
+#if defined(BFT_PERF_PROBE)
+#define BFT_DBG_STOP(im) ((im).debug_stop)
+#else
+#define BFT_DBG_STOP(im) 0u
+#endif
+
 // Random 8-byte gathers from the big tables (each touched cache line is used once by the wavefront): on the
 // device they can be issued as non-temporal loads; selected at compile time with -DBFT_NT_LOADS=1.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BFT_NT_LOADS) && BFT_NT_LOADS == 1
@@ -308,7 +316,7 @@ BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint
         // bit r of the prefix bitmap (= filter2 bit of p_u and p_v in that cluster's filter3 run); its rank = the entry
         const uint32_t wi = r / BFT_F2_BITS_PER_WORD, bi = r % BFT_F2_BITS_PER_WORD;
         const uint64_t fw = BFT_GATHER(&im.f18[cc.f18_off + wi]);
-        if (im.debug_stop == 2 || im.debug_stop == 3) { *e = fw; *stop = true; return true; }
+        if (BFT_DBG_STOP(im) == 2 || BFT_DBG_STOP(im) == 3) { *e = fw; *stop = true; return true; }
         if (!((fw >> bi) & 1ull)) return false;
         *e = BFT_GATHER(&im.fent[cc.fent_off + (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull))]);
         return true;
@@ -316,11 +324,11 @@ BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint
     const uint32_t pu = r >> cc.s, pv = r & ((1u << cc.s) - 1u);
     const uint32_t wi = pu / BFT_F2_BITS_PER_WORD, bi = pu % BFT_F2_BITS_PER_WORD;
     const uint64_t fw = im.f2w[cc.f2_off + wi];
-    if (im.debug_stop == 2) { *e = fw; *stop = true; return true; }
+    if (BFT_DBG_STOP(im) == 2) { *e = fw; *stop = true; return true; }
     if (!((fw >> bi) & 1ull)) return false;  // filter2 miss (src/presenceNode.c:1546-1548)
     const uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(fw & ((1ull << bi) - 1ull));
     uint64_t v = BFT_GATHER(&im.clus[cc.clus_off + clu]);
-    if (im.debug_stop == 3) { *e = v; *stop = true; return true; }
+    if (BFT_DBG_STOP(im) == 3) { *e = v; *stop = true; return true; }
     if (v & BFT_CLUS_MULTI) {
         // p_v search inside the cluster (src/presenceNode.c:1399-1410 / :1472-1489) on the fused entries
         const uint64_t* ch = im.child + cc.child_off;
@@ -491,7 +499,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
             if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
             else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
         }
-        if (im.debug_stop == 1) { hit.present = c >= 0; return hit; }
+        if (BFT_DBG_STOP(im) == 1) { hit.present = c >= 0; return hit; }
         uint64_t e = 0;
         bool stop = false, found = false;
         if (c >= 0) {
@@ -515,7 +523,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         if (stop) { hit.present = (int)(e & 1); return hit; }
         uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
         uint64_t idx = e & BFT_CHILD_IDX_MASK;
-        if (im.debug_stop == 4) { hit.present = (int)(cnt & 1); return hit; }
+        if (BFT_DBG_STOP(im) == 4) { hit.present = (int)(cnt & 1); return hit; }
         if (d == L - 1) {
             if (rb == 0) { hit.present = 1; hit.row = idx; return hit; }  // leaf: annotation row
             cnt = BFT_REM_COUNT(e);  // remainder group: count-1 on 16 bits

@@ -31,16 +31,64 @@ def gather_bitmaps(local_bits, n, world_size, rank, per, group=None):
 
 def query_presence_sharded(bft, kmers, group=None):
     """Shard a host batch across the ranks of the default process group, query each slice on this rank's GPU and
-    return the full bitmap on every rank."""
+    return the full bitmap on every rank.  Under RCCL the slice goes to the GPU once (one pinned, asynchronous copy), the
+    query runs device-resident (bft_gpu_query_presence_dev) and its bitmap is gathered straight from HBM; only the
+    gathered result comes back to the host.  Under gloo (CPU unit tests, no GPU) the handle's host entry point is used."""
     import torch
     import torch.distributed as dist
     ws, rk = dist.get_world_size(group), dist.get_rank(group)
     n = len(kmers)
     a, b, per = shard_bounds(n, ws, rk)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", bft.device)
+        local = torch.zeros(per // 8, dtype=torch.uint8, device=dev)
+        if b > a:
+            host = torch.from_numpy(np.ascontiguousarray(kmers[a:b]))
+            dq = host.pin_memory().to(dev, non_blocking=True)
+            bft.query_presence_dev(dq.data_ptr(), b - a, local.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        return gather_bitmaps(local, n, ws, rk, per, group).cpu().numpy()
     bits = bft.query_presence(kmers[a:b]) if b > a else np.zeros(0, np.uint8)
-    dev = torch.device("cuda", bft.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    t = torch.from_numpy(np.ascontiguousarray(bits)).to(dev)
+    t = torch.from_numpy(np.ascontiguousarray(bits))
     return gather_bitmaps(t, n, ws, rk, per, group).cpu().numpy()
+
+
+class GatherPipeline:
+    """The step / drain logic of bench.py's multi-GPU loop: every step answers this rank's resident shard into one of two
+    result buffers and starts the all_gather of that buffer asynchronously (RCCL runs it on its own stream), so the
+    gather of step i overlaps the query kernel of step i+1; a buffer is only reused once the gather that read it has
+    completed.  `query(buf)` must fill the uint8 tensor `buf` (the presence bitmap of the local shard) on the current
+    stream.  With use_dist False there is one buffer and no collective."""
+
+    def __init__(self, query, nbytes_local, world, device, use_dist, group=None):
+        import torch
+        self.query, self.world, self.use_dist, self.group = query, world, use_dist, group
+        self.nbuf = 2 if use_dist else 1
+        self.bits = [torch.zeros(nbytes_local, dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
+        self.gathered = [torch.empty(nbytes_local * world, dtype=torch.uint8, device=device) for _ in range(self.nbuf)] if use_dist else None
+        self.pending = [None] * self.nbuf
+        self.steps = 0
+
+    def step(self):
+        import torch.distributed as dist
+        b = self.steps % self.nbuf
+        self.steps += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()  # the gather that last read this buffer
+            self.pending[b] = None
+        self.query(self.bits[b])
+        if self.use_dist:
+            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.bits[b], group=self.group, async_op=True)
+
+    def drain(self):
+        for b in range(self.nbuf):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def last(self):
+        """(local bitmap, gathered bitmaps or None) of the most recent step"""
+        b = (self.steps - 1) % self.nbuf
+        return self.bits[b], (self.gathered[b] if self.use_dist else None)
 
 
 def replicate_image(bft, device, src=0, group=None, always_copy=False):

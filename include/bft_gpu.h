@@ -77,7 +77,10 @@ int bft_gpu_build(bft_gpu* h);
  * src/presenceNode.c:1823): one bit per k-mer.  Host buffers in, host bitmap out. */
 int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits);
 /* Same with inputs and outputs resident in HBM; runs on `hip_stream` (a hipStream_t, NULL = the
- * handle's own stream) and does not synchronise. d_present_bits: CEIL(n/64)*8 bytes. */
+ * handle's own stream) and does not synchronise. d_present_bits: CEIL(n/64)*8 bytes.
+ * Every *_dev entry point records where its work ends on a caller's stream; a later rebuild (insert + query), option
+ * change or bft_gpu_free waits for that point before it releases or rewrites image arrays, so the caller need not
+ * synchronise its stream first.  Every ABI call restores the calling thread's current HIP device before it returns. */
 int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_present_bits,
                                void* hip_stream);
 
@@ -131,7 +134,8 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
  * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
  * (grid = resident workgroups x value), "reserve_pairs" (room in the insertion log for this many
- * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels), "flat_min" (CCs with at
+ * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels;
+ * off until this option or the first bft_gpu_kernel_time call turns it on), "flat_min" (CCs with at
  * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
@@ -140,7 +144,8 @@ int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes);
 
 /* HIP-event timing of the query kernels launched through this handle since the last reset:
- * *ms = summed kernel time, *launches = number of launches. */
+ * *ms = summed kernel time, *launches = number of launches.  Timing is off by default (no event on the launch path); the
+ * first call of this function turns it on, so call it once (reset = 1) before the region to be timed. */
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
  * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, colour-set bitmaps) + k_query residency tuning, ms[5]=resident

@@ -37,6 +37,13 @@ def main():
          "from kernels where name like '%k_query%' or name like '%k_branching%' group by name, cls order by name, cls")
     for name, cls, n, avg, mn, mx in cur.execute(q):
         print(f"{short(name, 90):92s} {cls:6s} n={n:4d} avg_us={avg / 1e3:10.2f} min/max_us={mn / 1e3:.1f}/{mx / 1e3:.1f}")
+    # one line per (kernel, grid size): the full-batch launches of a persistent kernel have the full grid, tuning / warm-up
+    # launches a smaller one or a much shorter duration -- the per-launch figure bench.py reports can be read off here
+    print("\n# product kernels per (kernel, grid, workgroup): n, avg / min / max us")
+    q = ("select name, grid_x, workgroup_x, count(*), avg(duration), min(duration), max(duration), sum(duration) from kernels "
+         "where name like '%k_%' and name not like '%at::native%' and name not like '%rocprim%' group by name, grid_x, workgroup_x order by sum(duration) desc")
+    for name, gx, wx, n, avg, mn, mx, tot in cur.execute(q):
+        print(f"{short(name, 90):92s} grid={gx:<9d} wg={wx:<5d} n={n:4d} avg_us={avg / 1e3:10.2f} min/max_us={mn / 1e3:.1f}/{mx / 1e3:.1f} total_us={tot / 1e3:.1f}")
     if "--pmc" in sys.argv:
         tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
         print("\n# tables:", [t for t in tabs if "pmc" in t.lower() or "counter" in t.lower()])

@@ -193,3 +193,49 @@ def test_flat_form_matches_host_restatement(hostlib, flat_min):
                 assert n.value == 0
     finally:
         hostlib.bft_hosttest_free(h)
+
+
+def test_failed_build_leaves_the_previous_image_and_the_pending_insertions_intact():
+    """bft_gpu_build is all-or-nothing: a failure after sorting, colour interning and assembly -- injected right
+    before the commit point -- must leave the old image answering as before and the pending k-mers in the log; the next
+    build then succeeds with everything."""
+    from bloomfiltertrie_amd._lib import BFTError
+    k = 27
+    anc = S.random_genome(60000, 5)
+    g0 = S.distinct(S.kmers_of(anc, k))
+    g1 = S.distinct(S.kmers_of(S.mutate(anc, 0.03, 6), k))
+    t = BFT(k)
+    t.insert_kmers(g0, 0)
+    t.build()
+    q = np.concatenate([g0[::3], g1[::3], S.snp_mutants(g0[::7], k, 2)])
+    before_bits, before_off, before_ids = t.query_colors(q)
+    info0 = t.info()
+    t.insert_kmers(g1, 1)
+    assert t.info()["pending_pairs"] == len(g1)
+    t.set_option("inject_build_failure", 1)
+    with pytest.raises(BFTError, match="injected"):
+        t.build()
+    info1 = t.info()
+    assert info1["pending_pairs"] == len(g1) and info1["kmers"] == info0["kmers"] and info1["pairs"] == info0["pairs"]
+    t.build()  # the hook is one-shot: this build commits old + pending
+    allk = S.distinct(np.concatenate([g0, g1]))
+    info2 = t.info()
+    assert info2["kmers"] == len(allk) and info2["pairs"] == len(g0) + len(g1) and info2["pending_pairs"] == 0
+    bits, off, ids = t.query_colors(q)
+    m0, m1 = S.member(q, g0), S.member(q, g1)
+    assert (S.from_bits(bits, len(q)).astype(bool) == (m0 | m1)).all()
+    for i in range(0, len(q), 97):
+        assert ids[int(off[i]):int(off[i + 1])].tolist() == [g for g, m in ((0, m0[i]), (1, m1[i])) if m]
+    # and the answers of the old image were those of genome 0 alone
+    assert (S.from_bits(before_bits, len(q)).astype(bool) == m0).all() and len(before_ids) == int(m0.sum()) and before_off[-1] == len(before_ids)
+
+
+def test_rejects_out_of_range_genome_ids():
+    from bloomfiltertrie_amd._lib import BFTError
+    t = BFT(27)
+    km = S.distinct(S.kmers_of(S.random_genome(2000, 1), 27))
+    for bad in (0xFFFFFFFF, 1 << 24):
+        with pytest.raises(BFTError, match="id_genome"):
+            t.insert_kmers(km, bad)
+    t.insert_kmers(km, (1 << 24) - 1)  # the largest id accepted
+    assert t.info()["pending_pairs"] == len(km)

@@ -174,12 +174,18 @@ def test_device_resident_api_matches_host_api(oracle_mod):
     dq = torch.from_numpy(q).cuda()
     dbits = torch.zeros(((len(q) + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    assert t.kernel_time(reset=True) == (0.0, 0)  # timing is off until asked for: this call turns it on
     t.query_presence_dev(dq.data_ptr(), len(q), dbits.data_ptr(), stream)
     torch.cuda.synchronize()
     got = dbits.cpu().numpy()[: (len(q) + 7) // 8]
     assert (got == t.query_presence(q)).all()
     ms, launches = t.kernel_time()
     assert launches >= 2 and ms > 0
+    t.set_option("timing", 0)
+    t.query_presence_dev(dq.data_ptr(), len(q), dbits.data_ptr(), stream)
+    torch.cuda.synchronize()
+    with pytest.raises(Exception):
+        t.set_option("debug_stop", 2)  # exists in the perf-probe build only (make probe), never in the shipped library
 
 
 def test_rejects_bad_k():

@@ -103,7 +103,7 @@ def main():
                 torch.cuda.synchronize()
                 ms, n = t.kernel_time(reset=True)
                 print(json.dumps({"workload": wl, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
-        if args.stops:
+        if args.stops:  # needs BFT_GPU_LIB=bloomfiltertrie_amd/csrc/libbft_gpu_probe.so (make -C bloomfiltertrie_amd/csrc probe)
             t.set_option("query_block", 1024)
             t.set_option("query_grid_mult", 1)
             for stop in (1, 2, 3, 4, 0):

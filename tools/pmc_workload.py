@@ -25,7 +25,7 @@ union = S.distinct(np.concatenate(gk)) if len(gk) > 1 else gk[0]
 dev = torch.device("cuda", 0)
 dq = make_queries_on_device(union, k, nq, 99, dev)
 dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
-if stop:
+if stop:  # needs BFT_GPU_LIB=bloomfiltertrie_amd/csrc/libbft_gpu_probe.so (make -C bloomfiltertrie_amd/csrc probe)
     t.set_option("debug_stop", stop)
 for _ in range(reps):
     t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), torch.cuda.current_stream().cuda_stream)
