@@ -50,6 +50,7 @@ static double now_ms() {
 
 // device code, by topic
 #include "bft_kernels_query.h"
+#include "bft_kernels_bucket.h"
 #include "bft_kernels_seq.h"
 #include "bft_kernels_build.h"
 #include "bft_kernels_color.h"
@@ -205,6 +206,8 @@ struct bft_gpu {
     uint64_t n_kmers = 0;
     DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
+    DevBuf d_rdir;                // derived: root direct table (BFT_RDIR_*, k_root_direct), optional
+    bool opt_root_direct = true;  // "root_direct"
     uint64_t n_f18 = 0, n_fent = 0;
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
@@ -234,6 +237,13 @@ struct bft_gpu {
     int tuned_probe = 0;
     double tune_ms[2] = {0, 0};
     int opt_grid_mult = 1;    // grid = resident workgroups x this
+    // prefix-bucketed batches (bft_kernels_bucket.h): scratch grown on demand, reused across calls
+    int opt_bucket_bits = -1;   // "query_bucket_bits": -1 = measured on the first large batch, 0 = off, 4..10 = on with that many bits
+    int tuned_bucket_bits = -1; // result of that measurement (-1 = none yet)
+    double bucket_tune_ms[2] = {0, 0};  // plain / bucketed time of the tuning batch
+    DevBuf bk_trec, bk_pos, bk_hist, bk_off, bk_pbits, bk_prow, bk_plan, bk_tmp;
+    hipStream_t bk_stream = nullptr;  // the stream that last used the scratch
+    bool bk_used = false;
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
 };
 
@@ -546,7 +556,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -575,12 +585,36 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.ccx = h->d_ccx.as<BftCCX>();
     im.f18 = h->d_f18.as<uint64_t>();
     im.fent = h->d_fent.as<uint64_t>();
+    im.rdir = nullptr;  // derived after this call (derive_root_direct)
     h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
     h->cs_bm_tried = false;
     h->d_cs_bm.release();
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
+    h->tuned_bucket_bits = -1;  // measured again on the first large batch of the new image
     h->im.probe_big = h->opt_probe == 8;
+}
+
+// Root direct table: one thread per 18-bit prefix evaluates the root level's Bloom probe + CC lookup on the bound image.
+__global__ void k_root_direct(BftImage im, uint64_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << 18)) return;
+    const BftRootGlobal root(im);
+    out[r] = bft_root_direct_entry(im, root, im.nodes[0], r);
+}
+
+// Derives the table for the image h->im points at (after point_image).  An accelerator only: on any failure the walk simply
+// keeps the container path (im.rdir == NULL).
+static void derive_root_direct(bft_gpu* h) {
+    h->im.rdir = nullptr;
+    if (!h->opt_root_direct || h->root_ncc == 0 || h->n_kmers == 0) return;
+    if (h->d_rdir.bytes < (8u << 18) && h->d_rdir.alloc(8u << 18) != 0) return;
+    BftImage tmp = h->im;
+    tmp.rdir = nullptr;
+    tmp.debug_stop = 0;
+    hipLaunchKernelGGL(k_root_direct, dim3((1u << 18) / 256), dim3(256), 0, h->stream, tmp, h->d_rdir.as<uint64_t>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    h->im.rdir = h->d_rdir.as<uint64_t>();
 }
 
 // (Re)derives the flat form of the handle's current containers, points the image at everything and tunes the launch.
@@ -597,6 +631,7 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     h->n_f18 = n_f18;
     h->n_fent = n_fent;
     point_image(h, nb_genomes);
+    derive_root_direct(h);
     if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     return 0;
 }
@@ -774,6 +809,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[2] = t3 - t2;
     h->build_ms[3] = 0;
     h->built = true;
+    derive_root_direct(h);
+    I[12] = image_bytes(h);
     // launch tuning on the committed image (timing runs only: a failure here leaves a complete, queryable index)
     if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     h->build_ms[4] = now_ms() - t3;
@@ -837,7 +874,7 @@ static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s, rec) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
-static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
+static int launch_query_plain(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
     hipEvent_t e0, e1;
@@ -850,6 +887,131 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
     }
     CK(timing_end(h, s, e0, e1));
     return 0;
+}
+
+// ---- prefix-bucketed batches (bft_kernels_bucket.h) ------------------------------------------------------------------------
+#define BK_MIN_N (1ull << 22)       // smaller batches keep the direct kernel: the passes would cost more than they save
+#define BK_MAX_CHUNK (1ull << 28)   // queries per pass (bounds the scratch: (8W + 8) bytes per query)
+#define BK_DEFAULT_BITS 8
+#define BK_PROBE 2
+
+template <int W, bool STAGED>
+static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec, int bits) {
+    constexpr uint64_t TILE = BkTile<W>::value;
+    const uint32_t nb = 1u << bits;
+    const uint64_t ntiles64 = (n + TILE - 1) / TILE;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    const uint64_t padded = n + 64ull * nb;
+    const uint64_t nh = (uint64_t)nb * ntiles;
+    // scratch (grown, never shrunk)
+    if (h->bk_used && h->bk_stream != s) HIPCK(hipStreamSynchronize(h->bk_stream));  // one scratch: calls on different streams take turns
+    const size_t tb = BK_MAX_BUCKETS * 4;  // per-bucket totals
+    auto need = [&](DevBuf& b, size_t bytes) -> int {
+        if (b.bytes >= bytes) return 0;
+        if (h->bk_used) HIPCK(hipStreamSynchronize(s));  // the block being replaced may still be read by the previous call
+        return b.alloc(bytes + bytes / 8);
+    };
+    CK(need(h->bk_trec, padded * W * 8));
+    CK(need(h->bk_pos, ntiles64 * TILE * 2));  // lrank: u16 per query
+    CK(need(h->bk_hist, nh * 4));
+    CK(need(h->bk_off, nh * 4));
+    CK(need(h->bk_pbits, (padded / 64 + 1) * 8));
+    if (d_rows) CK(need(h->bk_prow, padded * 4));
+    CK(need(h->bk_plan, sizeof(BkPlan)));
+    CK(need(h->bk_tmp, tb));
+    h->bk_used = true;
+    h->bk_stream = s;
+    const int wgs = 2;
+    const dim3 pgrid((unsigned)std::min<uint64_t>(ntiles64, 256ull * wgs)), blk(BK_BLOCK);
+    hipLaunchKernelGGL(k_bucket_hist<W>, pgrid, blk, 0, s, d_kmers, n, rec, bits, ntiles, h->bk_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_rowsum, dim3(nb), blk, 0, s, h->bk_hist.as<uint32_t>(), ntiles, h->bk_tmp.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_plan, dim3(1), blk, 0, s, h->bk_tmp.as<uint32_t>(), bits, h->bk_plan.as<BkPlan>());
+    hipLaunchKernelGGL(k_bucket_rowscan, dim3(nb), blk, 0, s, h->bk_hist.as<uint32_t>(), ntiles, h->bk_plan.as<BkPlan>(), h->bk_off.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_scatter<W>, pgrid, blk, 0, s, d_kmers, n, rec, h->k, bits, ntiles, h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
+                       h->bk_trec.as<uint64_t>(), h->bk_pos.as<uint16_t>());
+    HIPCK(hipGetLastError());
+    // the walk, XCD by XCD over the plan: two workgroups per CU (L2-resident slices gain from 8 waves per SIMD)
+    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    static std::atomic<uint64_t> attr_devs{0};
+    const uint64_t dev_bit = 1ull << (h->device & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
+        HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, BK_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        attr_devs.fetch_or(dev_bit, std::memory_order_release);
+    }
+    const dim3 qgrid((unsigned)std::max<uint64_t>(8, std::min<uint64_t>((n + BK_BLOCK - 1) / BK_BLOCK, 256ull * wgs)));
+    uint32_t* prow = d_rows ? h->bk_prow.as<uint32_t>() : nullptr;
+    // suffix groups by one-load probes (bft_group_probe, PROBE 2): the bucket's slice of the table sits in the L2, where a probe
+    // costs per load instruction, not per line missed
+    hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
+    if (d_rows)
+        hipLaunchKernelGGL((k_unpermute<(int)TILE, true>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
+                           bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);
+    else
+        hipLaunchKernelGGL((k_unpermute<(int)TILE, false>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
+                           bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+static int launch_query_bucketed(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec, int bits) {
+    const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
+    hipEvent_t e0, e1;
+    CK(timing_begin(h, s, &e0, &e1));
+    for (uint64_t a = 0; a < n; a += BK_MAX_CHUNK) {  // BK_MAX_CHUNK is a multiple of 64: chunks are word aligned in the bitmap
+        const uint64_t m = std::min<uint64_t>(BK_MAX_CHUNK, n - a);
+        const uint8_t* q = d_kmers + a * (uint64_t)rec;
+        uint64_t* ob = d_bits64 + a / 64;
+        uint32_t* orow = d_rows ? d_rows + a : nullptr;
+#define BK(WW) (staged ? launch_bk_k<WW, true>(h, q, m, ob, orow, s, rec, bits) : launch_bk_k<WW, false>(h, q, m, ob, orow, s, rec, bits))
+        switch (h->W) {
+        case 1: CK(BK(1)); break;
+        case 2: CK(BK(2)); break;
+        case 3: CK(BK(3)); break;
+        default: CK(BK(4)); break;
+        }
+#undef BK
+    }
+    CK(timing_end(h, s, e0, e1));
+    return 0;
+}
+
+// Which path a batch takes.  Small batches: the direct kernel.  Large ones: bucketed when "query_bucket_bits" says so, or
+// -- by default -- when it measured faster on the first large batch of this image (both paths run twice on that batch, which
+// makes that one call synchronise; same answers either way).  Whether bucketing pays depends on the index (a table that fits
+// the L2 gains nothing) and on the batch, so it is measured rather than guessed, like the residency.
+static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
+    if (n == 0) return 0;
+    const int rec = rec_bytes ? rec_bytes : h->B;
+    if (h->opt_bucket_bits > 0) return launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, h->opt_bucket_bits);  // forced: any batch size
+    if (n < BK_MIN_N || h->opt_bucket_bits == 0) return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (h->tuned_bucket_bits < 0) {
+        if (n < (1ull << 24)) return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);  // too small to judge: decide on a bigger batch
+        const bool timing = h->timing;
+        h->timing = false;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        int rc = 0;
+        if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
+        float best[2] = {1e30f, 1e30f};
+        for (int rep = 0; rep < 2 && rc == 0; rep++)
+            for (int mode = 0; mode < 2 && rc == 0; mode++) {
+                if (hipEventRecord(ev[0], s) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
+                if (rc == 0) rc = mode ? launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, BK_DEFAULT_BITS) : launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
+                if (rc == 0 && (hipEventRecord(ev[1], s) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "query failed while tuning");
+                float ms = 0;
+                if (rc == 0 && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
+                if (rc == 0 && ms < best[mode]) best[mode] = ms;
+            }
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        h->timing = timing;
+        CK(rc);
+        h->bucket_tune_ms[0] = best[0];
+        h->bucket_tune_ms[1] = best[1];
+        h->tuned_bucket_bits = best[1] < 0.95f * best[0] ? BK_DEFAULT_BITS : 0;
+        return 0;  // the caller's buffers hold the answers of the last run
+    }
+    if (h->tuned_bucket_bits > 0) return launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, h->tuned_bucket_bits);
+    return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
 // Synthetic batch for tune_residency: k-mers of the index itself (pseudo-random rows of tk), every other one with a
@@ -917,7 +1079,7 @@ static int tune_residency(bft_gpu* h) {
         h->im.probe_big = probe == 8;
         for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second is timed
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
-            if (rc == 0) rc = launch_query(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
+            if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
             float ms = 0;
             if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
@@ -1530,6 +1692,18 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;
         h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+    } else if (nm == "root_direct") {  // 1 (default): root level through the derived direct table; 0: through the containers
+        h->opt_root_direct = value != 0;
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            derive_root_direct(h);
+            h->info[12] = image_bytes(h);
+        }
+    } else if (nm == "query_bucket_bits") {
+        if (value != -1 && value != 0 && (value < 4 || value > 10)) return fail(BFT_GPU_E_ARG, "query_bucket_bits must be -1 (automatic), 0 (off) or 4..10");
+        h->opt_bucket_bits = (int)value;
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;
@@ -1578,9 +1752,10 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[9] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
-                         h->im.probe_big ? 8.0 : 4.0};
-    for (int i = 0; i < n_out && i < 9; i++) ms[i] = v[i];
+    const double v[12] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+                          h->im.probe_big ? 8.0 : 4.0, (double)(h->opt_bucket_bits >= 0 ? h->opt_bucket_bits : h->tuned_bucket_bits), h->bucket_tune_ms[0],
+                          h->bucket_tune_ms[1]};
+    for (int i = 0; i < n_out && i < 12; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

@@ -18,8 +18,10 @@ struct HostTrie {
     std::vector<uint32_t> hashmod;
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
+    std::vector<uint64_t> rdir;
     BftHostIndex idx;
     BftImage im;
+    bool probe2 = false;
 };
 
 template <int W>
@@ -88,15 +90,32 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
     uint64_t cnt = 0;
     memset(bits, 0, (nq + 7) / 8);
     for (uint64_t i = 0; i < nq; i++) {
-        BftHit h = bft_walk<W>(t->im, BftRootGlobal(t->im), t->im.nodes[0], &tq[i * W]);
+        const BftRootGlobal root(t->im);
+        BftHit h = t->probe2 ? bft_walk<W, BftRootGlobal, 2>(t->im, root, t->im.nodes[0], &tq[i * W])   // one-load probes (bucketed kernel)
+                             : bft_walk<W, BftRootGlobal, -1>(t->im, root, t->im.nodes[0], &tq[i * W]);
         if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
         if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
     }
     return cnt;
 }
 
+// root direct table (BFT_RDIR_*): derived with the same per-prefix function as the GPU kernel k_root_direct; on / off
+extern "C" void bft_hosttest_root_direct(void* hv, int on) {
+    HostTrie* t = (HostTrie*)hv;
+    t->im.rdir = nullptr;
+    if (!on || t->idx.nodes.empty() || !t->idx.nodes[0].ncc) return;
+    t->rdir.assign(1u << 18, 0);
+    const BftRootGlobal root(t->im);
+    const BftNode nd = t->im.nodes[0];
+    for (uint32_t r = 0; r < (1u << 18); r++) t->rdir[r] = bft_root_direct_entry(t->im, root, nd, r);
+    t->im.rdir = t->rdir.data();
+}
+
 // suffix-group probe mode of the walk (BftImage::probe_big): same answers either way
-extern "C" void bft_hosttest_set_probe(void* hv, int big) { ((HostTrie*)hv)->im.probe_big = big ? 1u : 0u; }
+extern "C" void bft_hosttest_set_probe(void* hv, int big) {  // 0: 4-row blocks, 1: 8-row blocks, 2: one-load probes
+    ((HostTrie*)hv)->im.probe_big = big == 1 ? 1u : 0u;
+    ((HostTrie*)hv)->probe2 = big == 2;
+}
 
 extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
     HostTrie* t = (HostTrie*)hv;

@@ -85,6 +85,14 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 #define BFT_REM_COUNT(e) ((uint32_t)((((e) >> BFT_CHILD_CNT_SHIFT) & 0xFFull) | ((((e) >> 56) & 0x7Full) << 8) | ((((e) >> 39) & 1ull) << 15)) + 1u)
 #define BFT_REM_ROW(e) ((e) & 0x7FFFFFFFFFull)
 #define BFT_CLUS_MULTI (1ull << 63)
+// Root direct table (derived, optional): one u64 per 18-bit rotated prefix r of the ROOT node = the outcome of the root
+// level's Bloom probe + CC lookup for r.  A prefix lives in the first CC whose Bloom filter holds its key, so
+// the outcome is a function of r alone: BFT_RDIR_NO_CC (no Bloom-positive CC: search the node's UC), BFT_RDIR_ABSENT (a CC
+// claims the key but does not hold r: absent, src/presenceNode.c:1546-1548), or the prefix entry of r with bit 63 set.
+// 2 MiB for the root of any index; child nodes keep the container walk.
+#define BFT_RDIR_NO_CC 0ull
+#define BFT_RDIR_ABSENT 1ull
+#define BFT_RDIR_VALID (1ull << 63)
 #define BFT_CLUS_LEN_SHIFT 32
 
 struct BftImage {
@@ -102,6 +110,7 @@ struct BftImage {
     const BftCCX* ccx;        // [n_ccs] extended headers (derived, see above)
     const uint64_t* f18;      // flat prefix bitmaps + ranks of the s = 4 CCs
     const uint64_t* fent;     // flat prefix entries of the s = 4 CCs
+    const uint64_t* rdir;     // [2^18] root direct table (see BFT_RDIR_*), or NULL
     const uint64_t* f2w;
     const uint64_t* clus;
     const uint64_t* child;

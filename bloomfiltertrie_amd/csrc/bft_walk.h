@@ -348,6 +348,21 @@ BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint
     return true;
 }
 
+// One entry of the root direct table (BFT_RDIR_*, bft_image.h): the root level's Bloom probe + CC lookup for prefix r, i.e.
+// steps (2)-(6) of presenceKmer (src/presenceNode.c:1341-1489) evaluated for one of the 2^18 possible prefixes.
+template <class Root>
+BFT_HD uint64_t bft_root_direct_entry(const BftImage& im, const Root& root, const BftNode& nd, uint32_t r) {
+    if (!nd.ncc) return BFT_RDIR_NO_CC;
+    const uint32_t hm = root.hashmod(r >> 4);
+    const int c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
+    if (c < 0) return BFT_RDIR_NO_CC;
+    uint64_t e = 0;
+    bool stop = false;
+    const BftCCX cc = root.root_cc(nd, c);
+    if (!bft_cc_lookup(im, cc, r, &e, &stop)) return BFT_RDIR_ABSENT;
+    return e | BFT_RDIR_VALID;
+}
+
 // Two adjacent one-word rows of the table, first one at an even index: one 16-byte load.  Device buffers carry 256 bytes
 // of slack (bft_pool_alloc), so a pair that straddles the end of the table is still readable; the host copy is clamped.
 BFT_HD void bft_load_pair(const BftImage& im, uint64_t gi, uint64_t* a, uint64_t* b) {
@@ -426,13 +441,15 @@ BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, const uint64_t* 
 
 // d = the level that owns the group (its rows differ only in the key bits below that level)
 // PROBE: 0 / 1 fixes the mode at compile time (k_query: the 4-row code needs fewer registers than the 8-row one), -1 reads
-// im.probe_big.
+// im.probe_big.  PROBE 2 = ONE 16-byte load per probe (two one-word rows, or one two-word row) with a re-interpolated guess:
+// the mode of the bucketed kernel, whose table slice sits in the L2 -- there a probe costs per load instruction, not per
+// cache line missed, so wide blocks lose (measured: 8-row blocks 5.4 ms) and interpolation converges in 2-3 loads.
 template <int W, int PROBE>
 BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
     uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
     int dir = 0;
     const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
-    constexpr int NS = 4, NB = W == 1 ? 8 : 4;  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
+    constexpr int NS = 4, NB = PROBE == 2 ? (W == 1 ? 2 : 1) : (W == 1 ? 8 : 4);  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
 #pragma unroll
     for (int step = 0; step < BFT_PROBE_STEPS; step++) {
         if (big ? bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit) : bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit)) return;
@@ -494,14 +511,28 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         const bool single = d > 0 && nd.ncc == 1;
 #endif
         int c = single ? 0 : -1;
-        if (nd.ncc && !single) {
+        uint64_t e = 0;
+        bool stop = false, found = false;
+        if (d == 0 && im.rdir != nullptr) {
+            // Root level through the derived direct table (bft_image.h): rdir[r] is what "first Bloom-positive CC, then filter2
+            // / cluster / filter3 of that CC" (src/presenceNode.c:1353-1489) yields for r, evaluated once per prefix when the
+            // image is bound: one gather instead of hash + Bloom + header + bitmap word + entry.
+            const uint64_t v = BFT_GATHER(&im.rdir[r]);
+            if (BFT_DBG_STOP(im) >= 1 && BFT_DBG_STOP(im) <= 3) { hit.present = (int)(v & 1); return hit; }
+            if (v == BFT_RDIR_ABSENT) return hit;        // a CC's Bloom filter holds the key but the CC not the prefix (:1546-1548)
+            if (v == BFT_RDIR_NO_CC) {                    // no Bloom-positive CC: the node's UC (:1554-1573)
+                bft_uc_search<W>(im, nd, t, hit);
+                return hit;
+            }
+            e = v & ~BFT_RDIR_VALID;
+            found = true;
+            c = -1;
+        } else if (nd.ncc && !single) {
             const uint32_t hm = root.hashmod(r >> 4);  // Bloom key = n2..n8 (src/presenceNode.c:1341-1343)
             if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
             else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
         }
         if (BFT_DBG_STOP(im) == 1) { hit.present = c >= 0; return hit; }
-        uint64_t e = 0;
-        bool stop = false, found = false;
         if (c >= 0) {
             BftCCX cc;
             if (d == 0) cc = root.root_cc(nd, c);
@@ -642,13 +673,18 @@ BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& r
         const bool single = d > 0 && nd.ncc == 1;
 #endif
         int c = single ? 0 : -1;
-        if (nd.ncc && !single) {
+        uint64_t e = 0;
+        bool stop = false, found = false;
+        if (d == 0 && im.rdir != nullptr) {  // root level through the derived direct table, as in bft_walk
+            const uint64_t v = BFT_GATHER(&im.rdir[r]);
+            if (v == BFT_RDIR_ABSENT) return 0;
+            c = -1;
+            if (v != BFT_RDIR_NO_CC) { e = v & ~BFT_RDIR_VALID; found = true; }  // else: the UC branch below
+        } else if (nd.ncc && !single) {
             const uint32_t hm = root.hashmod(r >> 4);
             if (d == 0) c = root.root_first_cc(nd, hm & 0xFFFFu, hm >> 16);
             else c = bft_first_cc_blk(im.bfT + (size_t)nd.bf_off * 8, nd.bf_wb, hm & 0xFFFFu, hm >> 16);
         }
-        uint64_t e = 0;
-        bool stop = false, found = false;
         if (c >= 0) {
             BftCCX cc;
             if (d == 0) cc = root.root_cc(nd, c);

@@ -133,7 +133,9 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
  * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
- * (grid = resident workgroups x value), "reserve_pairs" (room in the insertion log for this many
+ * (grid = resident workgroups x value), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
+ * root prefix so that every XCD walks its own slices of the index out of its L2: -1 = measured on the first batch of 2^24 queries or more of an image,
+ * which makes that one call synchronise; 0 = never; 4..10 = always, with that many bits; answers are identical either way), "reserve_pairs" (room in the insertion log for this many
  * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels;
  * off until this option or the first bft_gpu_kernel_time call turns it on), "flat_min" (CCs with at
  * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
@@ -149,7 +151,8 @@ int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t ca
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
  * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, colour-set bitmaps) + k_query residency tuning, ms[5]=resident
- * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8). */
+ * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8),
+ * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

@@ -71,6 +71,7 @@ def hostlib(built):
     lib.bft_hosttest_query.restype = C.c_uint64
     lib.bft_hosttest_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_set_probe.argtypes = [C.c_void_p, C.c_int]
+    lib.bft_hosttest_root_direct.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_hashmod.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -133,7 +134,14 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     bits8, rows8 = np.zeros_like(bits), np.zeros_like(rows)
     hostlib.bft_hosttest_set_probe(h, 1)  # 8-row blocks + re-interpolated guesses: a tuning mode, same answers
     hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+    hostlib.bft_hosttest_set_probe(h, 2)  # one 16-byte load per probe, re-interpolated: the bucketed kernel's mode
+    bits2, rows2 = np.zeros_like(bits), np.zeros_like(rows)
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits2.ctypes.data, rows2.ctypes.data)
     hostlib.bft_hosttest_set_probe(h, 0)
+    assert (bits8 == bits).all() and (rows8 == rows).all() and (bits2 == bits).all() and (rows2 == rows).all()
+    hostlib.bft_hosttest_root_direct(h, 1)  # root level through the derived direct table: same answers, same rows
+    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+    hostlib.bft_hosttest_root_direct(h, 0)
     assert (bits8 == bits).all() and (rows8 == rows).all()
     o = oracle_mod.OracleBFT(k)
     o.insert_kmers(km, 0)

@@ -383,18 +383,106 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
-    for blk, wgs, mult, probe in [(1024, 0, 1, 0), (1024, 1, 1, 4), (1024, 2, 1, 8), (768, 2, 1, 4), (512, 1, 3, 8), (512, 2, 1, 0), (256, 2, 2, 8)]:
+    # (block, workgroups per CU, grid multiplier, probe rows, root direct table, prefix-bucket bits)
+    for blk, wgs, mult, probe, rdir, bkb in [(1024, 0, 1, 0, 1, 0), (1024, 1, 1, 4, 0, 0), (1024, 2, 1, 8, 1, 8), (768, 2, 1, 4, 0, 6), (512, 1, 3, 8, 1, 0),
+                                             (512, 2, 1, 0, 0, 10), (256, 2, 2, 8, 1, 4)]:
         t.set_option("query_block", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)
         t.set_option("query_probe", probe)
+        t.set_option("root_direct", rdir)
+        t.set_option("query_bucket_bits", bkb)
         bits, off, ids = t.query_colors(q)
-        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, bkb)
         bb, bc = t.query_branching(q[:20000], with_counts=True)
-        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult)
+        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult, probe, rdir, bkb)
     with pytest.raises(Exception):
         t.set_option("query_block", 100)
     with pytest.raises(Exception):
         t.set_option("query_wgs_per_cu", 3)
     with pytest.raises(Exception):
         t.set_option("query_probe", 16)
+    with pytest.raises(Exception):
+        t.set_option("query_bucket_bits", 11)
+
+
+@pytest.mark.parametrize("k,levels", [(27, 0), (27, 2), (31, 0), (36, 0), (63, 2), (72, 0), (126, 0)])
+def test_bucketed_batches_answer_like_the_direct_kernel(oracle_mod, k, levels):
+    """Prefix-bucketed batches (bft_kernels_bucket.h: partition by the top bits of the rotated root prefix, per-XCD sweep,
+    un-permutation) give bit-identical presence bitmaps, rows and colour rows to the direct kernel, for every bucket width,
+    ragged batch sizes (not a multiple of 64 / of the tile), all-absent and all-one-bucket batches; and both agree with
+    the oracle where it exists (k % 9 == 0)."""
+    from bloomfiltertrie_amd import BFT
+    anc = S.random_genome(150000, 3 + k)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 50 + g), k)) for g in range(3)]
+    if levels:
+        gk[0] = np.concatenate([gk[0], S.low_entropy_kmers(60000, k, 12, seed=9, levels=levels)])
+    t = BFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+    t.build()
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(k)
+    base = np.concatenate([allk, S.snp_mutants(allk, k, 1), S.pack_codes(rng.integers(0, 4, (5000, k), dtype=np.uint8))])
+    one_bucket = base[(base[:, 0] == base[0, 0]) & (base[:, 1] == base[0, 1])]  # same first 8 nucleotides: one bucket at any width
+    for n, src in ((300_007, base), (64, base), (1, base), (8192, base), (8193, base), (len(one_bucket), one_bucket)):
+        q = np.ascontiguousarray(src[rng.integers(0, len(src), n)])
+        t.set_option("query_bucket_bits", 0)
+        ref_bits, ref_rows, ref_sets = t.query_rows(q) if n > 4096 else (t.query_presence(q), None, None)
+        truth = S.member(q, allk)
+        assert (S.from_bits(ref_bits, n).astype(bool) == truth).all()
+        for bits in (4, 8, 10):
+            t.set_option("query_bucket_bits", bits)
+            t.set_option("root_direct", 1 if bits != 4 else 0)
+            if n > 4096:  # (batches of <= 4096 host k-mers go through the pinned small-batch path: presence only below)
+                b2, r2, s2 = t.query_rows(q)
+                assert (b2 == ref_bits).all() and (r2 == ref_rows).all() and (s2 == ref_sets).all(), (k, n, bits)
+                b3, crows = t.query_color_rows(q)
+                unp = np.unpackbits(crows, axis=1, bitorder="little")[:, :3].astype(bool)
+                assert (b3 == ref_bits).all() and (unp.any(axis=1) == truth).all()
+            else:
+                assert (t.query_presence(q) == ref_bits).all(), (k, n, bits)
+    if k % 9 == 0:
+        o = oracle_mod.OracleBFT(k)
+        for g, km in enumerate(gk):
+            o.insert_kmers(np.ascontiguousarray(km), g)
+        q = np.ascontiguousarray(base[rng.integers(0, len(base), 50_000)])
+        t.set_option("query_bucket_bits", 8)
+        bits, off, ids = t.query_colors(q)
+        obits, ooff, oids = o.query_colors(q)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+    t.close()
+
+
+def test_bucketed_path_is_chosen_by_measurement_and_keeps_answers():
+    """The automatic mode measures both paths on the first batch of >= 2^24 queries and keeps the faster; answers before,
+    during and after that measurement are the same."""
+    import torch
+    from bloomfiltertrie_amd import BFT, workloads as W
+    k = 27
+    dev = torch.device("cuda", 0)
+    pan = W.PanGenome(8, 1_000_000, 0.01, 5, dev)
+    t = BFT(k)
+    keys, _ = W.build_index(t, pan, k)
+    allk = W.union_of(keys)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    nq = (1 << 24) + 12345
+    dq, qk = W.presence_batch(allk, k, nq, g)
+    dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert t.build_time()["query_bucket_bits"] == -1
+    t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)  # tunes
+    torch.cuda.synchronize()
+    truth = W.member(allk, qk)
+    assert bool((W.bits_to_bool(dbits, nq) == truth).all())
+    bt = t.build_time()
+    assert bt["query_bucket_bits"] in (0, 8) and bt["bucket_tune_plain_ms"] > 0 and bt["bucket_tune_bucketed_ms"] > 0
+    first = dbits.clone()
+    for mode in (0, 8, -1):
+        t.set_option("query_bucket_bits", mode)
+        dbits.zero_()
+        t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(first, dbits)
+    t.close()
