@@ -326,6 +326,22 @@ __global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __r
     }
 }
 
+// Hashed form of the suffix groups of one depth (BFT_GH_*): one thread per prefix that owns a group of BFT_GH_MIN..BFT_GH_MAX
+// rows inserts them in row order with the function the host restatement uses (bft_gh_build_group) -- groups own disjoint
+// regions of tkh, so threads never meet.  stats[0] += groups, stats[1] += groups left unhashed.
+template <int W>
+__global__ void k_group_hash(const uint64_t* __restrict__ tk, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp,
+                             const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, const uint32_t* __restrict__ pend, uint32_t P,
+                             uint64_t* __restrict__ tkh, uint8_t* __restrict__ tkrank, unsigned long long* __restrict__ stats) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
+        if ((uint32_t)(skey[q] & 0x1FFFFu) == 0 || pend[q]) continue;  // UC prefixes and child nodes own no group
+        const uint32_t p = sp[q], cnt = pref_cnt[p];
+        if (!bft_gh_group(cnt)) continue;
+        atomicAdd(&stats[0], 1ull);
+        if (!bft_gh_build_group<W>(tk, tkh, tkrank, pref_row[p], cnt)) atomicAdd(&stats[1], 1ull);
+    }
+}
+
 __global__ void k_ranks(const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ cc_nwords, uint32_t C, uint64_t* __restrict__ f2w) {
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
         uint64_t* f2 = f2w + cc_f2[c];
@@ -407,9 +423,18 @@ struct Seg {  // per-depth output segments, concatenated at the end
 };
 
 template <int W>
-int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out) {
+int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out, bool group_hash) {
     const int L = k / 9, rb = 2 * (k - 9 * L);
     Scan scan(s);
+    DevBuf gh_stats;
+    const bool gh = group_hash && W <= 2 && bft_gh_usable(k, W) && n > 0;
+    if (gh) {  // two slots per row, all free (BFT_GH_EMPTY = all ones)
+        CK(out.tkh.alloc(2 * n * W * 8 + 64));
+        CK(out.tkrank.alloc(2 * n + 64));
+        CK(gh_stats.alloc_zero(16, s));
+        HIPCK(hipMemsetAsync(out.tkh.p, 0xFF, out.tkh.bytes, s));
+        HIPCK(hipMemsetAsync(out.tkrank.p, 0, out.tkrank.bytes, s));
+    }
     std::vector<Seg> segs;
     DevBuf nd_lo, nd_hi;
     CK(nd_lo.alloc(4));
@@ -605,6 +630,10 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                nrank.as<uint32_t>(), last_level, rb, (uint32_t)(T_nodes + M), sg.f2w.as<uint64_t>(), sg.clus.as<uint64_t>(),
                                sg.child.as<uint64_t>(), next_lo.as<uint32_t>(), next_hi.as<uint32_t>());
             hipLaunchKernelGGL(k_ranks, G(C), cc_f2.as<uint32_t>(), cc_nwords.as<uint32_t>(), (uint32_t)C, sg.f2w.as<uint64_t>());
+            // suffix groups of this depth (not the one-row leaves of a k % 9 == 0 index) -> hashed form
+            if (gh && !(last_level && rb == 0))
+                hipLaunchKernelGGL((k_group_hash<(W <= 2 ? W : 1)>), G(P), tk, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
+                                   pend.as<uint32_t>(), (uint32_t)P, out.tkh.as<uint64_t>(), out.tkrank.as<uint8_t>(), gh_stats.as<unsigned long long>());
         }
         if (UCR) hipLaunchKernelGGL(k_uc_rows, G(P), tk, W, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
                                     ucpos.as<uint32_t>(), (uint32_t)P, 0u, sg.uck.as<uint64_t>(), sg.ucrow.as<uint32_t>());
@@ -664,6 +693,13 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CP(out.ucrow, g.ucrow, o_u * 4, g.n_uc * 4);
 #undef CP
         o_n += g.n_nodes; o_b += g.n_bf8; o_c += g.n_ccs; o_f += g.n_f2w; o_q += g.n_clus; o_e += g.n_child; o_u += g.n_uc;
+    }
+    if (gh) {
+        unsigned long long st[2] = {0, 0};
+        HIPCK(hipMemcpyAsync(st, gh_stats.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        out.n_gh_groups = st[0];
+        out.n_gh_unhashed = st[1];
     }
     HIPCK(hipStreamSynchronize(s));
     out.n_nodes = T_nodes; out.n_ccs = T_ccs; out.n_f2w = T_f2w; out.n_clus = T_clus; out.n_child = T_child; out.n_bf8 = T_bf8; out.n_uc = T_uc;
@@ -901,14 +937,14 @@ __global__ __launch_bounds__(ABLK) void k_cs_verify(const uint32_t* __restrict__
 
 }  // namespace
 
-int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out, bool group_hash) {
     if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be in [9, 126]");
     if (n >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 k-mers");
     switch (bft_words_for_k(k)) {
-    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out);
-    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out);
-    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out);
-    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out);
+    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out, group_hash);
+    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out, group_hash);
+    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out, group_hash);
+    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out, group_hash);
     }
 }
 

@@ -206,8 +206,15 @@ struct bft_gpu {
     uint64_t n_kmers = 0;
     DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
-    DevBuf d_rdir;                // derived: root direct table (BFT_RDIR_*, k_root_direct), optional
-    bool opt_root_direct = true;  // "root_direct"
+    DevBuf d_rdir, d_rstart;      // derived: root direct table (BFT_RDIR_*, k_root_direct) and root range table (BFT_RSTART_*), optional
+    DevBuf d_tkh, d_tkrank;       // hashed form of the suffix groups (BFT_GH_*), built with the containers when "group_hash" is on
+    uint64_t n_tkh_bytes = 0, n_tkrank_bytes = 0, n_gh_groups = 0, n_gh_unhashed = 0;
+    bool opt_group_hash = true;   // "group_hash": build (next build) and use the hashed form
+    int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
+                                  // measured faster on this image (tune_residency)
+    bool rstart_ok = false;       // d_rstart holds the range table of the current image
+    int tuned_rstart = -1;        // result of that measurement (-1 = none)
+    double rstart_tune_ms[2] = {0, 0};
     uint64_t n_f18 = 0, n_fent = 0;
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
@@ -556,7 +563,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->n_tkh_bytes + h->n_tkrank_bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -577,6 +584,8 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.clus = h->d_clus.as<uint64_t>();
     im.child = h->d_child.as<uint64_t>();
     im.tk = h->d_tk.as<uint64_t>();
+    im.tkh = (h->opt_group_hash && h->n_tkh_bytes) ? h->d_tkh.as<uint64_t>() : nullptr;
+    im.tkrank = (h->opt_group_hash && h->n_tkh_bytes) ? h->d_tkrank.as<uint8_t>() : nullptr;
     im.tcol = h->d_tcol.as<uint32_t>();
     im.uck = h->d_uck.as<uint64_t>();
     im.ucrow = h->d_ucrow.as<uint32_t>();
@@ -603,10 +612,26 @@ __global__ void k_root_direct(BftImage im, uint64_t* __restrict__ out) {
     out[r] = bft_root_direct_entry(im, root, im.nodes[0], r);
 }
 
+template <int W>
+__global__ void k_root_ranges(BftImage im, uint32_t root_uc_n, uint32_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > (1u << 18)) return;
+    out[r] = bft_root_range_entry<W>(im, r, r < (1u << 18) ? im.rdir[r] : 0ull, root_uc_n);
+}
+__global__ void k_root_ranges_check(const uint64_t* __restrict__ rdir, uint32_t* __restrict__ rs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << 18)) return;
+    const uint32_t a = rs[r];
+    if (!(a & BFT_RSTART_SPECIAL) && !bft_root_range_ok(a, rs[r + 1], rdir[r])) rs[r] = a | BFT_RSTART_SPECIAL;  // (readers mask the flag)
+}
+
 // Derives the table for the image h->im points at (after point_image).  An accelerator only: on any failure the walk simply
 // keeps the container path (im.rdir == NULL).
 static void derive_root_direct(bft_gpu* h) {
     h->im.rdir = nullptr;
+    h->im.rstart = nullptr;
+    h->rstart_ok = false;
+    h->tuned_rstart = -1;
     if (!h->opt_root_direct || h->root_ncc == 0 || h->n_kmers == 0) return;
     if (h->d_rdir.bytes < (8u << 18) && h->d_rdir.alloc(8u << 18) != 0) return;
     BftImage tmp = h->im;
@@ -615,6 +640,27 @@ static void derive_root_direct(bft_gpu* h) {
     hipLaunchKernelGGL(k_root_direct, dim3((1u << 18) / 256), dim3(256), 0, h->stream, tmp, h->d_rdir.as<uint64_t>());
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
     h->im.rdir = h->d_rdir.as<uint64_t>();
+    if (h->opt_root_direct < 2) return;
+    const size_t rs_bytes = ((1u << 18) + 2) * 4;
+    if (h->d_rstart.bytes < rs_bytes && h->d_rstart.alloc(rs_bytes) != 0) return;
+    tmp.rdir = h->im.rdir;
+    uint32_t root_uc_n = 0;  // rows of the root's UC (BftNode::uc_n of node 0)
+    {
+        BftNode nd0;
+        if (hipMemcpy(&nd0, h->d_nodes.p, sizeof(nd0), hipMemcpyDeviceToHost) != hipSuccess) return;
+        root_uc_n = nd0.uc_n;
+    }
+    const dim3 g((1u << 18) / 256 + 1), b(256);
+    switch (h->W) {
+    case 1: hipLaunchKernelGGL(k_root_ranges<1>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
+    case 2: hipLaunchKernelGGL(k_root_ranges<2>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
+    case 3: hipLaunchKernelGGL(k_root_ranges<3>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
+    default: hipLaunchKernelGGL(k_root_ranges<4>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
+    }
+    hipLaunchKernelGGL(k_root_ranges_check, g, b, 0, h->stream, h->im.rdir, h->d_rstart.as<uint32_t>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    h->rstart_ok = true;
+    h->im.rstart = h->d_rstart.as<uint32_t>();  // (mode 3: tune_residency decides whether it stays)
 }
 
 // (Re)derives the flat form of the handle's current containers, points the image at everything and tunes the launch.
@@ -734,7 +780,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     // 5. containers, level by level, on the GPU
     if (!tk.p) CK(tk.alloc(8));
     BftDeviceIndex idx;
-    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx));
+    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx, h->opt_group_hash));
     double t3 = now_ms();
     DevBuf n_ccx, n_f18buf, n_fentbuf;
     uint64_t n_f18 = 0, n_fent = 0;
@@ -763,6 +809,12 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->log_k.release();
     h->log_g.release();
     h->log_cap = 0;
+    h->d_tkh.swap(idx.tkh);
+    h->d_tkrank.swap(idx.tkrank);
+    h->n_tkh_bytes = h->d_tkh.p ? h->d_tkh.bytes : 0;
+    h->n_tkrank_bytes = h->d_tkrank.p ? h->d_tkrank.bytes : 0;
+    h->n_gh_groups = idx.n_gh_groups;
+    h->n_gh_unhashed = idx.n_gh_unhashed;
     h->d_nodes.swap(idx.nodes);
     h->d_bfT.swap(idx.bfT);
     h->d_ccs.swap(idx.ccs);
@@ -838,7 +890,8 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
     // one workgroup per CU the request is padded past half the LDS so that the dispatcher cannot pair two on a CU.
     const int wgs = query_residency(h);
-    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
+    size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
     const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
@@ -931,7 +984,8 @@ static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
                        h->bk_trec.as<uint64_t>(), h->bk_pos.as<uint16_t>());
     HIPCK(hipGetLastError());
     // the walk, XCD by XCD over the plan: two workgroups per CU (L2-resident slices gain from 8 waves per SIMD)
-    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
+    size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     static std::atomic<uint64_t> attr_devs{0};
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
@@ -1086,6 +1140,32 @@ static int tune_residency(bft_gpu* h) {
             if (rep > 0 && ms < best[cfg]) best[cfg] = ms;
         }
     }
+    int win = 0;
+    for (int cfg = 1; cfg < 4; cfg++)
+        if (best[cfg] < best[win]) win = cfg;
+    // root level: range table + direct table, or the direct table alone ("root_direct" 3).  The range table halves the L2
+    // footprint of the root level; its special prefixes (child Nodes) pay one more dependent load -- which side wins depends
+    // on how many there are, so both are timed with the residency / probe mode just chosen.
+    if (rc == 0 && h->opt_root_direct == 3 && h->rstart_ok) {
+        h->tuned_wgs = 1 + (win & 1);
+        h->im.probe_big = (h->opt_probe ? h->opt_probe == 8 : (win & 2) != 0);
+        float rs[2] = {1e30f, 1e30f};
+        for (int mode = 0; mode < 2 && rc == 0; mode++) {
+            h->im.rstart = mode ? h->d_rstart.as<uint32_t>() : nullptr;
+            for (int rep = 0; rep < 3 && rc == 0; rep++) {
+                if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
+                if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
+                if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
+                float ms = 0;
+                if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
+                if (rep > 0 && ms < rs[mode]) rs[mode] = ms;
+            }
+        }
+        h->rstart_tune_ms[0] = rs[0];
+        h->rstart_tune_ms[1] = rs[1];
+        h->tuned_rstart = rs[1] < rs[0] ? 1 : 0;
+        h->im.rstart = h->tuned_rstart ? h->d_rstart.as<uint32_t>() : nullptr;
+    }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     h->timing = timing;
@@ -1093,9 +1173,6 @@ static int tune_residency(bft_gpu* h) {
     h->tuned_wgs = 0;
     h->im.probe_big = h->opt_probe == 8;
     CK(rc);
-    int win = 0;
-    for (int cfg = 1; cfg < 4; cfg++)
-        if (best[cfg] < best[win]) win = cfg;
     h->tune_ms[0] = std::min(best[0], best[2]) < 1e29f ? std::min(best[0], best[2]) : 0;
     h->tune_ms[1] = std::min(best[1], best[3]) < 1e29f ? std::min(best[1], best[3]) : 0;
     h->tuned_wgs = 1 + (win & 1);
@@ -1107,7 +1184,8 @@ static int tune_residency(bft_gpu* h) {
 template <int W, bool STAGED>
 static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
     const int wgs = query_residency(h);  // eight walks per k-mer: the residency measured for k_query applies
-    size_t lds = BFT_LDS_HM_BYTES + (STAGED ? ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX) : 0);
+    // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
+    size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
     const uint64_t nblk = (n + 1023) / 1024;
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * (uint64_t)wgs)));
@@ -1523,7 +1601,7 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr uint64_t BLOB_MAGIC = 0x3130555047544642ull;  // "BFTGPU01"
-constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 15;
+constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 17;
 enum { H_MAGIC, H_TOTAL, H_K, H_R1, H_R2, H_NKMERS, H_NPAIRS, H_NSETS, H_NIDS, H_ROOTNCC, H_MAXGID, H_ANYINS, H_NBGEN, H_NNAMES,
        H_STOREMAX, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
 
@@ -1542,9 +1620,9 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     for (const std::string& g : h->genomes) { p.names += g; p.names.push_back('\0'); }
     const uint64_t sz[BLOB_SECTIONS] = {h->idx_sizes[0], h->idx_sizes[1], h->idx_sizes[2], h->idx_sizes[3], h->idx_sizes[4], h->idx_sizes[5], h->idx_sizes[6],
                                         h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * 4,
-                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size()};
+                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size(), h->n_tkh_bytes, h->n_tkrank_bytes};
     const void* src[BLOB_SECTIONS] = {h->d_nodes.p, h->d_bfT.p, h->d_ccs.p, h->d_f2w.p, h->d_clus.p, h->d_child.p, h->d_uck.p, h->d_ucrow.p,
-                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr};
+                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr, h->d_tkh.p, h->d_tkrank.p};
     uint64_t o = BLOB_HDR_WORDS * 8;
     for (int i = 0; i < BLOB_SECTIONS; i++) {
         p.off[i] = o;
@@ -1584,8 +1662,8 @@ extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* 
     for (int i = 0; i < BLOB_SECTIONS; i++) {
         const uint64_t n = p.hdr[H_SEC + i];
         if (!n) continue;
-        if (p.src[i]) HIPCK(hipMemcpyAsync(d + p.off[i], p.src[i], n, hipMemcpyDeviceToDevice, s));
-        else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));
+        if (i != 14) HIPCK(hipMemcpyAsync(d + p.off[i], p.src[i], n, hipMemcpyDeviceToDevice, s));
+        else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));  // section 14: the genome names (host)
     }
     HIPCK(hipStreamSynchronize(s));  // the header and the names are host temporaries
     return BFT_GPU_OK;
@@ -1613,10 +1691,11 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
     bft_gpu* h = nullptr;
     CK(bft_gpu_create_seeded((int)H[H_K], device, (int)H[H_R1], (int)H[H_R2], &h));
     const uint8_t* d = (const uint8_t*)d_blob;
-    DevBuf* dst[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow,
-                       &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g};
+    DevBuf* dst[BLOB_SECTIONS] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow,
+                                  &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g, nullptr, &h->d_tkh, &h->d_tkrank};
     int rc = 0;
-    for (int i = 0; i < 14 && rc == 0; i++) {
+    for (int i = 0; i < BLOB_SECTIONS && rc == 0; i++) {
+        if (i == 14 || ((i == 15 || i == 16) && H[H_SEC + i] == 0)) continue;  // names: below; no hashed form in the blob
         rc = dst[i]->alloc(H[H_SEC + i]);
         if (rc == 0 && H[H_SEC + i] &&
             hipMemcpyAsync(dst[i]->p, d + off[i], H[H_SEC + i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
@@ -1639,6 +1718,8 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
         for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
         h->cs_on_host = false;
+        h->n_tkh_bytes = H[H_SEC + 15];
+        h->n_tkrank_bytes = H[H_SEC + 16];
         rc = bind_image(h, (uint32_t)H[H_NBGEN]);
     }
     if (rc != 0) {
@@ -1657,11 +1738,13 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
     CK(ensure_built(h));
-    static const char* names[12] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent"};
-    const DevBuf* bufs[12] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
-                              &h->d_ccx, &h->d_f18, &h->d_fent};
-    const uint64_t derived[3] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8};
-    for (int i = 0; i < 12; i++)
+    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "tkh", "tkrank"};
+    const DevBuf* bufs[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
+                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_tkh, &h->d_tkrank};
+    // (the hashed form: the 2 n W words / 2 n bytes that are defined, without the allocation slack)
+    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8,
+                                 h->n_tkh_bytes ? 2 * h->n_kmers * (uint64_t)h->W * 8 : 0, h->n_tkh_bytes ? 2 * h->n_kmers : 0};
+    for (int i = 0; i < 14; i++)
         if (std::string(name) == names[i]) {
             const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
             if (nbytes) *nbytes = sz;
@@ -1692,14 +1775,26 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;
         h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
-    } else if (nm == "root_direct") {  // 1 (default): root level through the derived direct table; 0: through the containers
-        h->opt_root_direct = value != 0;
+    } else if (nm == "group_hash") {  // 1 (default): suffix groups through their hashed form; 0: through the sorted table only.  Takes
+        h->opt_group_hash = value != 0;  // effect at once when the image has the form (it is built with the containers when the option is on)
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            const bool on = h->opt_group_hash && h->n_tkh_bytes;
+            h->im.tkh = on ? h->d_tkh.as<uint64_t>() : nullptr;
+            h->im.tkrank = on ? h->d_tkrank.as<uint8_t>() : nullptr;
+        }
+    } else if (nm == "root_direct") {  // 2 (default): root level through the derived range + direct tables; 1: direct table only; 0: containers
+        if (value < 0 || value > 3) return fail(BFT_GPU_E_ARG, "root_direct must be 0, 1, 2 or 3");
+        h->opt_root_direct = (int)value;
         if (h->built) {
             ENTER(h);
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
             derive_root_direct(h);
             h->info[12] = image_bytes(h);
+            if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0 || h->opt_root_direct == 3) CK(tune_residency(h));  // the launch shape was measured with the other tables
         }
     } else if (nm == "query_bucket_bits") {
         if (value != -1 && value != 0 && (value < 4 || value > 10)) return fail(BFT_GPU_E_ARG, "query_bucket_bits must be -1 (automatic), 0 (off) or 4..10");
@@ -1752,10 +1847,11 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[12] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+    const double v[17] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
                           h->im.probe_big ? 8.0 : 4.0, (double)(h->opt_bucket_bits >= 0 ? h->opt_bucket_bits : h->tuned_bucket_bits), h->bucket_tune_ms[0],
-                          h->bucket_tune_ms[1]};
-    for (int i = 0; i < n_out && i < 12; i++) ms[i] = v[i];
+                          h->bucket_tune_ms[1], (double)h->n_gh_groups, (double)h->n_gh_unhashed,
+                          (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1]};
+    for (int i = 0; i < n_out && i < 17; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

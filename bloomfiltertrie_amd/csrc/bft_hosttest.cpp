@@ -19,6 +19,8 @@ struct HostTrie {
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
     std::vector<uint64_t> rdir;
+    std::vector<uint32_t> rstart;
+    uint64_t rstart_plain = 0;
     BftHostIndex idx;
     BftImage im;
     bool probe2 = false;
@@ -94,22 +96,49 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
         BftHit h = t->probe2 ? bft_walk<W, BftRootGlobal, 2>(t->im, root, t->im.nodes[0], &tq[i * W])   // one-load probes (bucketed kernel)
                              : bft_walk<W, BftRootGlobal, -1>(t->im, root, t->im.nodes[0], &tq[i * W]);
         if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
-        if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
+        if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(t->im, h) : 0xFFFFFFFFu;
     }
     return cnt;
+}
+
+// hashed form of the suffix groups (BFT_GH_*): built by bft_build_index with the function the GPU kernel uses; on / off
+extern "C" void bft_hosttest_group_hash(void* hv, int on) {
+    HostTrie* t = (HostTrie*)hv;
+    const bool have = on && !t->idx.tkh.empty();
+    t->im.tkh = have ? t->idx.tkh.data() : nullptr;
+    t->im.tkrank = have ? t->idx.tkrank.data() : nullptr;
 }
 
 // root direct table (BFT_RDIR_*): derived with the same per-prefix function as the GPU kernel k_root_direct; on / off
 extern "C" void bft_hosttest_root_direct(void* hv, int on) {
     HostTrie* t = (HostTrie*)hv;
     t->im.rdir = nullptr;
+    t->im.rstart = nullptr;
     if (!on || t->idx.nodes.empty() || !t->idx.nodes[0].ncc) return;
     t->rdir.assign(1u << 18, 0);
     const BftRootGlobal root(t->im);
     const BftNode nd = t->im.nodes[0];
     for (uint32_t r = 0; r < (1u << 18); r++) t->rdir[r] = bft_root_direct_entry(t->im, root, nd, r);
     t->im.rdir = t->rdir.data();
+    if (on < 2) return;  // 2: also the root range table (BFT_RSTART_*), the two passes of k_root_ranges / k_root_ranges_check
+    t->rstart.assign((1u << 18) + 2, 0);
+    for (uint32_t r = 0; r <= (1u << 18); r++) {
+        const uint64_t v = r < (1u << 18) ? t->rdir[r] : 0ull;
+        switch (t->W) {
+        case 1: t->rstart[r] = bft_root_range_entry<1>(t->im, r, v, nd.uc_n); break;
+        case 2: t->rstart[r] = bft_root_range_entry<2>(t->im, r, v, nd.uc_n); break;
+        case 3: t->rstart[r] = bft_root_range_entry<3>(t->im, r, v, nd.uc_n); break;
+        default: t->rstart[r] = bft_root_range_entry<4>(t->im, r, v, nd.uc_n); break;
+        }
+    }
+    for (uint32_t r = 0; r < (1u << 18); r++)
+        if (!(t->rstart[r] & BFT_RSTART_SPECIAL) && !bft_root_range_ok(t->rstart[r], t->rstart[r + 1], t->rdir[r])) t->rstart[r] |= BFT_RSTART_SPECIAL;
+    t->im.rstart = t->rstart.data();
+    uint64_t plain = 0;
+    for (uint32_t r = 0; r < (1u << 18); r++) plain += !(t->rstart[r] & BFT_RSTART_SPECIAL);
+    t->rstart_plain = plain;
 }
+extern "C" uint64_t bft_hosttest_root_plain(void* hv) { return ((HostTrie*)hv)->rstart_plain; }
 
 // suffix-group probe mode of the walk (BftImage::probe_big): same answers either way
 extern "C" void bft_hosttest_set_probe(void* hv, int big) {  // 0: 4-row blocks, 1: 8-row blocks, 2: one-load probes
@@ -127,12 +156,14 @@ extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, 
     }
 }
 
+// out[10]=groups in the hashed form [11]=of which left unhashed
 // out[0]=k-mers [1]=nodes [2]=CCs [3]=UC rows [4]=child nodes [5]=prefixes [6]=CCs s=4 [7]=max CCs/node [8]=root CCs [9]=root UC rows
 extern "C" void bft_hosttest_stats(void* hv, uint64_t* out) {
     HostTrie* t = (HostTrie*)hv;
     out[0] = t->tk.size() / t->W; out[1] = t->idx.nodes.size(); out[2] = t->idx.ccs.size(); out[3] = t->idx.ucrow.size();
     out[4] = t->idx.n_child_nodes; out[5] = t->idx.n_prefixes; out[6] = t->idx.n_ccs_s4; out[7] = t->idx.max_ccs_per_node;
     out[8] = t->idx.nodes[0].ncc; out[9] = t->idx.nodes[0].uc_n;
+    out[10] = t->idx.n_gh_groups; out[11] = t->idx.n_gh_unhashed;
 }
 
 // T-form round trip: packed -> T -> packed
@@ -181,6 +212,8 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     else if (nm == "uck") { p = t->idx.uck.data(); n = t->idx.uck.size() * 8; }
     else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }
     else if (nm == "tk") { p = t->tk.data(); n = t->tk.size() * 8; }
+    else if (nm == "tkh") { p = t->idx.tkh.data(); n = t->idx.tkh.empty() ? 0 : 2 * (t->tk.size() / t->W) * (uint64_t)t->W * 8; }  // without the slack words
+    else if (nm == "tkrank") { p = t->idx.tkrank.data(); n = t->idx.tkrank.empty() ? 0 : 2 * (t->tk.size() / t->W); }
     else return -1;
     if (nbytes) *nbytes = n;
     if (out) { if (cap < n) return -6; memcpy(out, p, n); }

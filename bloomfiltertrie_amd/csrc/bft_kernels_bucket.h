@@ -243,24 +243,26 @@ __device__ __forceinline__ uint32_t bk_xcc_id() {
 }
 
 // Presence (and row) of the bucketed T-form records.  Work = the chunks (BK_BLOCK records) of the buckets dealt to each XCD
-// by k_bucket_plan; each list has a cursor.  A workgroup reads which XCD it sits on and claims chunks of THAT list, one
-// atomicAdd per chunk issued a chunk ahead (its latency hides behind the walk of the current chunk); when the list is
-// exhausted it moves on to the next XCD's list (the tail only: lists are balanced to within one bucket).  All workgroups of
-// an XCD therefore sweep the same bucket at the same time and the bucket's slice of the index stays in that XCD's L2.
-// Every chunk is claimed exactly once whatever the placement of the workgroups: placement changes speed, never answers.
+// by k_bucket_plan; each list has a cursor.  Every WAVEFRONT claims chunks on its own -- no workgroup barrier in the loop, a
+// slow lane only holds up its own 64 -- from the list of the XCD its workgroup sits on: one atomicAdd per chunk, issued a
+// chunk ahead so that its latency hides behind the 16 x 64 walks of the current chunk; when the list is exhausted the
+// wavefront moves on to the next XCD's list (the tail only).  All wavefronts of an XCD therefore sweep the same bucket at
+// the same time and the bucket's slice of the index stays in that XCD's L2 (measured: 0.13 L2 misses per query on the 1.8 GB
+// image of config 4).  Every chunk is claimed exactly once whatever the placement: placement changes speed, never answers.
 // Answers are written in permuted order: bit p%64 of word p/64, row at prow[p].
 template <int W, bool STAGED, int PROBE>
 __device__ __forceinline__ void query_bk_body(const BftImage& im, const uint64_t* __restrict__ trec, BkPlan* __restrict__ plan,
                                               uint64_t* __restrict__ pbits, uint32_t* __restrict__ prow) {
     extern __shared__ __align__(16) uint8_t lds[];
-    __shared__ uint32_t s_next;
     uint32_t* l_hm = (uint32_t*)lds;
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
     const BftNode root = im.nodes[0];
     const uint32_t bf_bytes = STAGED ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
     BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
     const uint32_t my_xcd = bk_xcc_id();
-    if (threadIdx.x == 0) s_next = atomicAdd(&plan->cursor[my_xcd], 1u);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t claim = 0;
+    if (lane == 0) claim = atomicAdd(&plan->cursor[my_xcd], 1u);  // in flight during the staging below
     {
         const uint4* g = (const uint4*)im.hashmod;
         uint4* l = (uint4*)l_hm;
@@ -279,34 +281,31 @@ __device__ __forceinline__ void query_bk_body(const BftImage& im, const uint64_t
         const uint32_t y = (my_xcd + step) & 7u;
         const uint32_t nseg = plan->xl_n[y];
         const uint32_t nchunks = plan->xl_chunk0[y][nseg];
-        if (step > 0) {  // first claim on a list this workgroup moves on to
-            if (threadIdx.x == 0) s_next = atomicAdd(&plan->cursor[y], 1u);
-            __syncthreads();
-        }
+        if (step > 0 && lane == 0) claim = atomicAdd(&plan->cursor[y], 1u);  // first claim on a list this wavefront moves on to
         uint32_t seg = 0;
         for (;;) {
-            const uint32_t c = s_next;
-            __syncthreads();  // everyone has read the claim before thread 0 overwrites it
+            const uint32_t c = (uint32_t)__shfl((int)claim, 0, 64);
             if (c >= nchunks) break;
-            uint32_t nxt = 0;
-            if (threadIdx.x == 0) nxt = atomicAdd(&plan->cursor[y], 1u);  // the next claim, in flight during this chunk
-            while (plan->xl_chunk0[y][seg + 1] <= c) seg++;  // claims of a list only grow: forward scan (uniform, scalar loads)
+            if (lane == 0) claim = atomicAdd(&plan->cursor[y], 1u);  // the next claim: used after this chunk
+            while (plan->xl_chunk0[y][seg + 1] <= c) seg++;  // the claims a wavefront gets from a list only grow: forward scan
             const uint32_t b = plan->xl_bucket[y][seg];
             const uint32_t size = plan->size[b];
-            const uint32_t inb = (c - plan->xl_chunk0[y][seg]) * BK_BLOCK + threadIdx.x;  // position inside the bucket
-            const uint64_t p = (uint64_t)plan->base[b] + inb;
-            int present = 0;
-            if (inb < size) {
-                uint64_t t[W];
-                bft_load_row<W>(trec + p * W, t);
-                const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
-                present = h.present;
-                if (prow) prow[p] = present ? (uint32_t)h.row : BFT_ABSENT_ROW;
+            const uint32_t in0 = (c - plan->xl_chunk0[y][seg]) * BK_BLOCK;  // first position of the chunk inside the bucket
+            const uint64_t p0 = (uint64_t)plan->base[b] + in0;
+            for (uint32_t it = 0; it < BK_BLOCK / 64 && in0 + it * 64 < size; it++) {
+                const uint32_t inb = in0 + it * 64 + lane;
+                const uint64_t p = p0 + it * 64 + lane;
+                int present = 0;
+                if (inb < size) {
+                    uint64_t t[W];
+                    bft_load_row<W>(trec + p * W, t);
+                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
+                    present = h.present;
+                    if (prow) prow[p] = present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+                }
+                const uint64_t mask = __ballot(present);
+                if (lane == 0) pbits[p >> 6] = mask;
             }
-            const uint64_t mask = __ballot(present);
-            if ((threadIdx.x & 63u) == 0 && (inb & ~63u) < size) pbits[p >> 6] = mask;
-            if (threadIdx.x == 0) s_next = nxt;
-            __syncthreads();
         }
     }
 }

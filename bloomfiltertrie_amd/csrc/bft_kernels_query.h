@@ -88,7 +88,9 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     uint32_t* l_hm = (uint32_t*)lds;
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
     const BftNode root = im.nodes[0];
-    const bool stage_root = STAGED;  // host side: root.ncc in [1, 64]
+    // the root's Bloom block and CC headers are only read when the root level goes through the containers: with the derived
+    // root tables (im.rdir) that LDS space holds the queue of deferred lanes instead (below)
+    const bool stage_root = STAGED && im.rdir == nullptr;  // host side: root.ncc in [1, 64]
     const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
     BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
     {
@@ -107,23 +109,93 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    if (im.rstart == nullptr) {
+        // no range table: every lane walks its k-mer to the end
+        for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+            const uint64_t i = blk * BLOCK + threadIdx.x;
+            int present = 0;
+            uint32_t row = BFT_ABSENT_ROW;
+            if (i < n) {
+                uint64_t x[W], t[W];
+                load_x<W>(packed, i, B, end_aligned, x);
+                bft_tform_from_x<W>(x, im.k, t);
+                const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
+                present = h.present;
+                if (present && rows) row = (uint32_t)bft_hit_row(im, h);
+            }
+            const uint64_t mask = __ballot(present);
+            const uint64_t q0 = i & ~63ull;  // first query of this wavefront
+            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+            if (rows && i < n) rows[i] = row;
+        }
+        return;
+    }
+    // With the range table: every lane takes the short path (range table -> suffix group); a lane whose root prefix is "special"
+    // (child Node, UC rows: the long container path) only parks its k-mer in its wavefront's queue in LDS, and the wavefront walks
+    // the queue when it is full.  A wavefront is as slow as its slowest lane, and with ~5 % special prefixes (config 4) nearly
+    // every wavefront had one: parked, the long path is walked by (nearly) full wavefronts, once per ~20 passes.  No workgroup
+    // barrier is involved (measured: two barriers per pass cost this miss-bound kernel 10-30 %); a parked lane's answer is OR-ed
+    // into the word its own wavefront stored earlier (same wavefront, same address: in order).
+    constexpr uint32_t QCAP = W == 1 ? 64u : (W == 2 ? 32u : 16u);   // entries per wavefront: 16 x QCAP x (8 W + 4) bytes <= the 14 KiB root area
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint64_t* q_t = (uint64_t*)l_bf + (size_t)wave * QCAP * W;                          // [QCAP * W] parked T-forms of this wavefront
+    uint32_t* q_i = (uint32_t*)((uint64_t*)l_bf + (size_t)(BLOCK / 64) * QCAP * W) + (size_t)wave * QCAP;  // [QCAP] their query (offset from qbase)
+    uint32_t qn = 0;          // entries parked (wavefront-uniform)
+    uint64_t qbase = 0;       // queries are parked as 32-bit offsets from the first query of the pass the queue was last empty in
+    auto drain = [&]() {
+        if (lane < qn) {
+            uint64_t t[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) t[w] = q_t[(size_t)lane * W + w];
+            const uint64_t i = qbase + q_i[lane];
+            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
+            if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
+            if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+        }
+        qn = 0;
+    };
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const uint64_t i = blk * BLOCK + threadIdx.x;
         int present = 0;
-        uint32_t row = BFT_ABSENT_ROW;
+        bool parked = false;
+        uint64_t t[W];
         if (i < n) {
-            uint64_t x[W], t[W];
+            uint64_t x[W];
             load_x<W>(packed, i, B, end_aligned, x);
             bft_tform_from_x<W>(x, im.k, t);
-            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
-            present = h.present;
-            if (present) row = (uint32_t)h.row;
+            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 1>(im, acc, root, t);
+            if (h.present == BFT_HIT_DEFERRED) parked = true;
+            else {
+                present = h.present;
+                if (rows) rows[i] = present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+            }
         }
         const uint64_t mask = __ballot(present);
         const uint64_t q0 = i & ~63ull;  // first query of this wavefront
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-        if (rows && i < n) rows[i] = row;
+        if (lane == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        const uint64_t pm = __ballot(parked);
+        if (pm) {
+            const uint32_t np = (uint32_t)__popcll(pm);
+            if (qn == 0) qbase = q0;
+            if (qn + np > QCAP || q0 + 64 - qbase > 0xFFFFFFFFull) { drain(); qbase = q0; }
+            if (np > QCAP) {  // more special lanes than the queue holds (a deep trie: every prefix is a child Node): walk them here
+                if (parked) {
+                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
+                    if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
+                    if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+                }
+            } else {
+                if (parked) {
+                    const uint32_t qp = qn + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+#pragma unroll
+                    for (int w = 0; w < W; w++) q_t[(size_t)qp * W + w] = t[w];
+                    q_i[qp] = (uint32_t)(i - qbase);
+                }
+                qn += np;
+            }
+        }
     }
+    if (qn) drain();
 }
 
 // Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in

@@ -291,8 +291,100 @@ struct BftRootGlobal {
 
 struct BftHit {
     int present;
-    uint64_t row;  // row of the k-mer in tk (valid when present)
+    uint64_t row;      // row of the k-mer in tk (valid when present and gh_slot < 0)
+    int64_t gh_slot;   // >= 0: found in slot gh_slot of the hashed groups; its row is `row` (the group's first row) + tkrank[gh_slot]
 };
+// the row of a found k-mer (one more byte load when it was found through the hashed form: only callers that return rows pay it)
+BFT_HD uint64_t bft_hit_row(const BftImage& im, const BftHit& h) { return h.gh_slot >= 0 ? h.row + im.tkrank[h.gh_slot] : h.row; }
+
+// ---- hashed form of the suffix groups (bft_image.h, BFT_GH_*) ----
+BFT_HD bool bft_gh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }
+BFT_HD bool bft_gh_group(uint32_t cnt) { return cnt >= BFT_GH_MIN && cnt <= BFT_GH_MAX; }
+template <int W>
+BFT_HD uint32_t bft_gh_home(const uint64_t* t, uint32_t nbk) {
+    uint64_t h = t[0];
+#pragma unroll
+    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + t[w];
+    h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;  // 64-bit finalizer (murmur3)
+    return (uint32_t)(((h >> 32) * (uint64_t)nbk) >> 32);
+}
+BFT_HD void bft_gh_region(uint64_t idx, uint32_t cnt, uint64_t* b0, uint32_t* nbk) {
+    *b0 = (idx + 1) >> 1;                        // first 4-slot bucket inside the slots [2 idx, 2 (idx + cnt))
+    *nbk = (uint32_t)(((idx + cnt) >> 1) - *b0);  // >= 3 for cnt >= BFT_GH_MIN
+}
+// Builds the hashed form of one group (rows in order: deterministic); tkh must hold BFT_GH_EMPTY in every word of the region.
+// Returns false when a row found no slot within BFT_GH_MAXD buckets of its home: the region is then marked unhashed.
+template <int W>
+BFT_HD bool bft_gh_build_group(const uint64_t* tk, uint64_t* tkh, uint8_t* tkrank, uint64_t idx, uint32_t cnt) {
+    uint64_t b0;
+    uint32_t nbk;
+    bft_gh_region(idx, cnt, &b0, &nbk);
+    for (uint32_t i = 0; i < cnt; i++) {
+        uint64_t t[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) t[w] = tk[(idx + i) * W + w];
+        uint32_t b = bft_gh_home<W>(t, nbk);
+        bool placed = false;
+        for (uint32_t d = 0; d <= BFT_GH_MAXD && d < nbk && !placed; d++) {
+            for (uint32_t s = 0; s < BFT_GH_SLOTS && !placed; s++) {
+                const uint64_t slot = (b0 + b) * BFT_GH_SLOTS + s;
+                if (tkh[slot * W] == BFT_GH_EMPTY) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) tkh[slot * W + w] = t[w];
+                    tkrank[slot] = (uint8_t)i;
+                    placed = true;
+                }
+            }
+            b = b + 1 == nbk ? 0 : b + 1;
+        }
+        if (!placed) {
+            for (uint64_t slot = b0 * BFT_GH_SLOTS; slot < (b0 + nbk) * BFT_GH_SLOTS; slot++) {
+                tkh[slot * W] = BFT_GH_UNHASHED;
+#pragma unroll
+                for (int w = 1; w < W; w++) tkh[slot * W + w] = BFT_GH_EMPTY;
+                tkrank[slot] = 0;
+            }
+            return false;
+        }
+    }
+    return true;
+}
+// Lookup.  Returns true when the hashed form decided (hit filled when found), false when the group is unhashed.
+template <int W>
+BFT_HD bool bft_gh_lookup(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, BftHit& hit) {
+    uint64_t b0;
+    uint32_t nbk;
+    bft_gh_region(idx, cnt, &b0, &nbk);
+    uint32_t b = bft_gh_home<W>(t, nbk);
+    for (uint32_t d = 0; d <= BFT_GH_MAXD; d++) {  // (the first bucket decides ~85 % of the lookups: not unrolled)
+        const uint64_t s0 = (b0 + b) * BFT_GH_SLOTS;
+        uint64_t v[BFT_GH_SLOTS][W];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (W == 1) {
+#pragma unroll
+            for (uint32_t s = 0; s < BFT_GH_SLOTS; s += 2) {  // 16-byte loads of one 32-byte aligned bucket
+                const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(im.tkh + s0 + s);
+                v[s][0] = q.x;
+                v[s + 1][0] = q.y;
+            }
+        } else
+#endif
+        {
+#pragma unroll
+            for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) bft_load_row<W>(im.tkh + (s0 + s) * W, v[s]);
+        }
+        bool free_slot = false;
+#pragma unroll
+        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) {
+            if (v[s][0] == BFT_GH_UNHASHED) return false;
+            if (bft_cmp<W>(v[s], t) == 0) { hit.present = 1; hit.row = idx; hit.gh_slot = (int64_t)(s0 + s); return true; }
+            free_slot = free_slot || v[s][0] == BFT_GH_EMPTY;
+        }
+        if (free_slot || d + 1 >= nbk) return true;  // the row would sit here or earlier: absent
+        b = b + 1 == nbk ? 0 : b + 1;
+    }
+    return true;
+}
 
 // The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
 template <int W>
@@ -361,6 +453,37 @@ BFT_HD uint64_t bft_root_direct_entry(const BftImage& im, const Root& root, cons
     const BftCCX cc = root.root_cc(nd, c);
     if (!bft_cc_lookup(im, cc, r, &e, &stop)) return BFT_RDIR_ABSENT;
     return e | BFT_RDIR_VALID;
+}
+
+// rstart[r] (bft_image.h) for one r in [0, 2^18]: lower bound of r among the root prefixes of the sorted table, tagged special
+// unless the rdir entry v of r says "plain suffix group of exactly these rows" or the range is empty and the prefix absent.
+template <int W>
+BFT_HD uint32_t bft_root_range_entry(const BftImage& im, uint32_t r, uint64_t v /* rdir[r], ignored for r == 2^18 */, uint32_t root_uc_n) {
+    uint64_t lo = 0, hi = im.n_kmers;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        uint64_t row[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) row[w] = im.tk[mid * W + w];
+        if (bft_digit<W>(row, im.k, 0) < r) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t s = (uint32_t)lo;
+    if (r >= (1u << 18)) return s;
+    bool plain = false;
+    if (v == BFT_RDIR_ABSENT || (v == BFT_RDIR_NO_CC && root_uc_n == 0)) plain = true;  // no k-mer under r (bft_root_range_check verifies the range is empty)
+    else if (v & BFT_RDIR_VALID) {
+        const uint64_t e = v & ~BFT_RDIR_VALID;
+        const uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
+        plain = im.L > 1 && cnt >= 1 && (e & BFT_CHILD_IDX_MASK) == lo;  // a suffix group (count 0 = child Node) that starts at this row
+    }
+    return plain ? s : (s | BFT_RSTART_SPECIAL);
+}
+// second pass, once every rstart word is written: a plain prefix must own exactly the rows its rdir entry says (none for an
+// absent prefix); anything else is demoted to special -- the tables can then only ever send a lookup down a path that is exact.
+BFT_HD bool bft_root_range_ok(uint32_t a, uint32_t b, uint64_t v) {
+    const uint32_t cnt = (b & ~BFT_RSTART_SPECIAL) - (a & ~BFT_RSTART_SPECIAL);
+    if (v & BFT_RDIR_VALID) return cnt == ((uint32_t)((v & ~BFT_RDIR_VALID) >> BFT_CHILD_CNT_SHIFT) & 0xFFu);
+    return cnt == 0;
 }
 
 // Two adjacent one-word rows of the table, first one at an even index: one 16-byte load.  Device buffers carry 256 bytes
@@ -475,6 +598,7 @@ BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint
 // prefixes, then block probes (groups of >= BFT_WINDOW_PROBE rows of one or two words) or a galloping search.
 template <int W, int PROBE>
 BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit) {
+    if (W <= 2 && im.tkh != nullptr && bft_gh_group(cnt) && bft_gh_lookup<W>(im, idx, cnt, t, hit)) return;
     const uint64_t next36 = bft_next36<W>(t, im.k, d);
     const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
@@ -490,11 +614,17 @@ BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, con
 
 // start_node / d0: the walk normally starts at the root (level 0); bft_walk_last4 resumes it at the last level of a node
 // it has already reached.
-template <int W, class Root, int PROBE = -1>
+// ROOTMODE (root level with the derived tables): 0 = range table when the prefix is plain, else its rdir entry, inline;
+// 1 = as 0, but a special prefix is NOT walked: the hit comes back with present == BFT_HIT_DEFERRED and the caller runs it
+// again later with mode 2 (k_query queues those lanes and walks them together: a wavefront no longer pays the long
+// container path for its few special lanes); 2 = rdir entry for every prefix (skips the range table).
+#define BFT_HIT_DEFERRED 2
+template <int W, class Root, int PROBE = -1, int ROOTMODE = 0>
 BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& start_node, const uint64_t* t, const int d0 = 0) {
     BftHit hit;
     hit.present = 0;
     hit.row = 0;
+    hit.gh_slot = -1;
     uint32_t node = 0;
     const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
     for (int d = d0; d < L; d++) {
@@ -514,9 +644,25 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         uint64_t e = 0;
         bool stop = false, found = false;
         if (d == 0 && im.rdir != nullptr) {
-            // Root level through the derived direct table (bft_image.h): rdir[r] is what "first Bloom-positive CC, then filter2
-            // / cluster / filter3 of that CC" (src/presenceNode.c:1353-1489) yields for r, evaluated once per prefix when the
-            // image is bound: one gather instead of hash + Bloom + header + bitmap word + entry.
+            // Root level through the derived tables (bft_image.h).  Plain suffix groups: two adjacent words of the 1 MiB range
+            // table give {first row, count}.
+            if (ROOTMODE != 2 && im.rstart != nullptr) {
+                // rstart[r] and rstart[r + 1] in ONE 8-byte load (4-byte aligned: the hardware takes unaligned dwordx2 loads); a
+                // gather costs per load instruction, and loading the second word only after testing the first would add a round trip
+                struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+                const Pair pr = *reinterpret_cast<const Pair*>(im.rstart + r);
+                const uint32_t a = pr.a;
+                if (!(a & BFT_RSTART_SPECIAL)) {
+                    const uint32_t b = pr.b & ~BFT_RSTART_SPECIAL;
+                    if (BFT_DBG_STOP(im) >= 1 && BFT_DBG_STOP(im) <= 4) { hit.present = (int)(b & 1); return hit; }
+                    if (b != a) bft_group_search<W, PROBE>(im, a, b - a, t, 0, hit);
+                    return hit;
+                }
+                if (ROOTMODE == 1) { hit.present = BFT_HIT_DEFERRED; return hit; }
+            }
+            // rdir[r] is what "first Bloom-positive CC, then filter2 / cluster / filter3 of that CC" (src/presenceNode.c:1353-1489)
+            // yields for r, evaluated once per prefix when the image is bound: one gather instead of hash + Bloom + header +
+            // bitmap word + entry.
             const uint64_t v = BFT_GATHER(&im.rdir[r]);
             if (BFT_DBG_STOP(im) >= 1 && BFT_DBG_STOP(im) <= 3) { hit.present = (int)(v & 1); return hit; }
             if (v == BFT_RDIR_ABSENT) return hit;        // a CC's Bloom filter holds the key but the CC not the prefix (:1546-1548)
@@ -703,6 +849,7 @@ BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& r
                 BftHit hit;
                 hit.present = 0;
                 hit.row = 0;
+                hit.gh_slot = -1;
                 tt[W - 1] = t[W - 1] | (v << vo);
                 bft_uc_search<W>(im, nd, tt, hit);
                 count += hit.present;
@@ -720,6 +867,7 @@ BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& r
             BftHit hit;
             hit.present = 0;
             hit.row = 0;
+            hit.gh_slot = -1;
             tt[W - 1] = t[W - 1] | (v << vo);
             bft_group_search<W, 0>(im, idx, cnt, tt, d, hit);
             count += hit.present;

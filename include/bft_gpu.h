@@ -133,7 +133,10 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
  * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
- * (grid = resident workgroups x value), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
+ * (grid = resident workgroups x value), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte
+ * buckets, one cache line per lookup -- built with the containers and used by every query; 0: sorted table only), "root_direct" (the root level goes through tables derived from the containers:
+ * 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain suffix groups, backed by the 2 MiB table; 3, default = 1 or 2,
+ * whichever measured faster on the image; 0 = the containers), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
  * root prefix so that every XCD walks its own slices of the index out of its L2: -1 = measured on the first batch of 2^24 queries or more of an image,
  * which makes that one call synchronise; 0 = never; 4..10 = always, with that many bits; answers are identical either way), "reserve_pairs" (room in the insertion log for this many
  * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels;
@@ -142,7 +145,7 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
 /* Test hook: raw device->host copy of one array of the image ("nodes", "bfT", "ccs", "f2w", "clus",
- * "child", "uck", "ucrow", "tk", and the derived "ccx", "f18", "fent"); out may be NULL to query the size. */
+ * "child", "uck", "ucrow", "tk", and the derived "ccx", "f18", "fent", "tkh", "tkrank"); out may be NULL to query the size. */
 int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes);
 
 /* HIP-event timing of the query kernels launched through this handle since the last reset:
@@ -152,7 +155,9 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
  * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, colour-set bitmaps) + k_query residency tuning, ms[5]=resident
  * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8),
- * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing. */
+ * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing,
+ * ms[12]=suffix groups that own a hashed form, ms[13]=of which left unhashed (searched in the sorted table), ms[14]=root tables in use (0 / 1 / 2, see "root_direct"),
+ * ms[15..16]=time of the tuning batch with the direct table alone / with the range table. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

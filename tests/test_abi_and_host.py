@@ -72,6 +72,7 @@ def hostlib(built):
     lib.bft_hosttest_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_set_probe.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_root_direct.argtypes = [C.c_void_p, C.c_int]
+    lib.bft_hosttest_group_hash.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_hashmod.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -139,15 +140,23 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits2.ctypes.data, rows2.ctypes.data)
     hostlib.bft_hosttest_set_probe(h, 0)
     assert (bits8 == bits).all() and (rows8 == rows).all() and (bits2 == bits).all() and (rows2 == rows).all()
-    hostlib.bft_hosttest_root_direct(h, 1)  # root level through the derived direct table: same answers, same rows
-    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
-    hostlib.bft_hosttest_root_direct(h, 0)
-    assert (bits8 == bits).all() and (rows8 == rows).all()
+    for rd in (1, 2):  # root level through the derived direct table (1) and through range + direct tables (2): same answers, same rows
+        hostlib.bft_hosttest_root_direct(h, rd)
+        hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+        hostlib.bft_hosttest_root_direct(h, 0)
+        assert (bits8 == bits).all() and (rows8 == rows).all()
+    for rd in (0, 1, 2):  # suffix groups through their hashed form (with and without the root direct table): same answers, same rows
+        hostlib.bft_hosttest_group_hash(h, 1)
+        hostlib.bft_hosttest_root_direct(h, rd)
+        hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+        hostlib.bft_hosttest_group_hash(h, 0)
+        hostlib.bft_hosttest_root_direct(h, 0)
+        assert (bits8 == bits).all() and (rows8 == rows).all()
     o = oracle_mod.OracleBFT(k)
     o.insert_kmers(km, 0)
     assert (bits == o.query_presence(q)).all()
     assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
-    st = np.zeros(10, np.uint64)
+    st = np.zeros(12, np.uint64)
     hostlib.bft_hosttest_stats(h, st.ctypes.data)
     hostlib.bft_hosttest_free(h)
     return st.tolist()

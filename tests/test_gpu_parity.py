@@ -383,9 +383,10 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
-    # (block, workgroups per CU, grid multiplier, probe rows, root direct table, prefix-bucket bits)
-    for blk, wgs, mult, probe, rdir, bkb in [(1024, 0, 1, 0, 1, 0), (1024, 1, 1, 4, 0, 0), (1024, 2, 1, 8, 1, 8), (768, 2, 1, 4, 0, 6), (512, 1, 3, 8, 1, 0),
-                                             (512, 2, 1, 0, 0, 10), (256, 2, 2, 8, 1, 4)]:
+    # (block, workgroups per CU, grid multiplier, probe rows, root direct table, prefix-bucket bits, hashed suffix groups)
+    for blk, wgs, mult, probe, rdir, bkb, gh in [(1024, 0, 1, 0, 1, 0, 1), (1024, 1, 1, 4, 0, 0, 0), (1024, 2, 1, 8, 1, 8, 1), (768, 2, 1, 4, 0, 6, 0), (512, 1, 3, 8, 1, 0, 0),
+                                                 (512, 2, 1, 0, 0, 10, 1), (256, 2, 2, 8, 1, 4, 1)]:
+        t.set_option("group_hash", gh)
         t.set_option("query_block", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)
@@ -393,9 +394,9 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
         t.set_option("root_direct", rdir)
         t.set_option("query_bucket_bits", bkb)
         bits, off, ids = t.query_colors(q)
-        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, bkb)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, bkb, gh)
         bb, bc = t.query_branching(q[:20000], with_counts=True)
-        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult, probe, rdir, bkb)
+        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult, probe, rdir, bkb, gh)
     with pytest.raises(Exception):
         t.set_option("query_block", 100)
     with pytest.raises(Exception):
@@ -434,6 +435,7 @@ def test_bucketed_batches_answer_like_the_direct_kernel(oracle_mod, k, levels):
         for bits in (4, 8, 10):
             t.set_option("query_bucket_bits", bits)
             t.set_option("root_direct", 1 if bits != 4 else 0)
+            t.set_option("group_hash", 1 if bits != 10 else 0)
             if n > 4096:  # (batches of <= 4096 host k-mers go through the pinned small-batch path: presence only below)
                 b2, r2, s2 = t.query_rows(q)
                 assert (b2 == ref_bits).all() and (r2 == ref_rows).all() and (s2 == ref_sets).all(), (k, n, bits)
@@ -485,4 +487,53 @@ def test_bucketed_path_is_chosen_by_measurement_and_keeps_answers():
         t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
         torch.cuda.synchronize()
         assert torch.equal(first, dbits)
+    t.close()
+
+
+@pytest.mark.parametrize("k,per_prefix", [(18, 20), (27, 12), (27, 120), (36, 30), (63, 200), (31, 40)])
+def test_hashed_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_prefix):
+    """Suffix groups of 8..255 rows through their hashed form (BFT_GH_*) and the root level through the derived range /
+    direct tables: presence, rows and colour sets equal the oracle's (k % 9 == 0) and ground truth, with each accelerator on
+    and off; the hashed form really is in use (groups counted) and 'unhashed' groups (fallback to the sorted table) answer too."""
+    from bloomfiltertrie_amd import BFT
+    n_pref = 1500
+    km = S.low_entropy_kmers(n_pref * per_prefix, k, n_pref, seed=k + per_prefix, levels=1)
+    rng = np.random.default_rng(5)
+    parts = np.array_split(km[rng.permutation(len(km))], 3)
+    t = BFT(k)
+    o = k % 9 == 0
+    for g, part in enumerate(parts):
+        t.insert_kmers(np.ascontiguousarray(part), g)
+        t.insert_kmers(np.ascontiguousarray(part[::7]), (g + 1) % 3)
+    t.build()
+    bt = t.build_time()
+    assert bt["hashed_groups"] > n_pref // 2 and bt["unhashed_groups"] <= bt["hashed_groups"]
+    q = np.concatenate([km, S.snp_mutants(km, k, 3), S.snp_mutants(km[::2], k, 4), S.pack_codes(rng.integers(0, 4, (20000, k), dtype=np.uint8))])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    truth = S.member(q, km)
+    ref = None
+    for gh, rd in ((1, 2), (0, 2), (1, 1), (1, 0), (0, 0)):
+        t.set_option("group_hash", gh)
+        t.set_option("root_direct", rd)
+        bits, rows, sets = t.query_rows(q)
+        assert (S.from_bits(bits, len(q)).astype(bool) == truth).all(), (gh, rd)
+        if ref is None:
+            ref = (bits, rows, sets)
+            stored, cs = t.extract()
+            assert (stored[rows[truth]] == q[truth]).all() and (cs[rows[truth]] == sets[truth]).all()
+        else:
+            assert (bits == ref[0]).all() and (rows == ref[1]).all() and (sets == ref[2]).all(), (gh, rd)
+    t.set_option("group_hash", 1)
+    t.set_option("root_direct", 2)
+    if o:
+        o2 = oracle_mod.OracleBFT(k)
+        for g, part in enumerate(parts):
+            both = np.concatenate([part, parts[(g + 2) % 3][::7]])  # genome g also holds every 7th k-mer of part g-1 (as inserted above)
+            o2.insert_kmers(np.ascontiguousarray(both), g)
+        bits, off, ids = t.query_colors(q[:60000])
+        obits, ooff, oids = o2.query_colors(q[:60000])
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+        bb, bc = t.query_branching(q[:20000], with_counts=True)
+        ob, oc, _ = o2.query_branching(q[:20000])
+        assert (bb == ob).all() and (bc == oc).all()
     t.close()
