@@ -1387,19 +1387,25 @@ static int ensure_cs_bitmaps(bft_gpu* h) {
     return 0;
 }
 
-static int launch_color_rows(bft_gpu* h, const uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s) {
+// d_rowidx: the row of every k-mer (scratch: overwritten with the colour-set ids when the bitmap dictionary is used)
+static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s) {
     CK(ensure_cs_bitmaps(h));
     if (h->has_cs_bm) {
-        // tiles of k-mers whose bytes fit 31 bits; magic number of the division by rowbytes (round-up method, exact on u32)
-        const uint32_t tile_rows = std::max<uint32_t>(4u, ((1u << 30) / rowbytes) & ~3u);
+        hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, n, d_rowidx);  // row -> colour set, in place
+        // tiles of ~32 KiB of output (a multiple of 4 k-mers: tiles start dword aligned); magic number of the division by rowbytes
+        // (round-up method, exact on u32)
+        const uint32_t tile_rows = std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(4u, ((32768u / rowbytes) + 3u) & ~3u));
         uint32_t div_l = 0;
         while ((1ull << div_l) < rowbytes) div_l++;
         const uint32_t div_m = div_l ? (uint32_t)(((1ull << 32) * ((1ull << div_l) - rowbytes)) / rowbytes + 1ull) : 0u;
         const uint64_t tiles = (n + tile_rows - 1) / tile_rows;
-        const uint64_t dw_per_tile = ((uint64_t)std::min<uint64_t>(n, tile_rows) * rowbytes + 3) / 4;
-        if (tiles > 65535) return fail(BFT_GPU_E_LIMIT, "colour-row batch too large for one launch");
-        hipLaunchKernelGGL(k_color_rows_bm, dim3(grid_for((dw_per_tile + 256 * CR_UNROLL - 1) / (256 * CR_UNROLL)), (unsigned)tiles), dim3(256), 0, s, d_rowidx, h->im.tcol,
-                           h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m, div_l, d_out);
+        const dim3 cgrid((unsigned)std::min<uint64_t>(tiles, 256ull * 8));
+        if (rowbytes >= 4)
+            hipLaunchKernelGGL(k_color_rows_bm<true>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+                               div_l, d_out);
+        else
+            hipLaunchKernelGGL(k_color_rows_bm<false>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+                               div_l, d_out);
     }
     else
         hipLaunchKernelGGL(k_color_rows, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, h->im.cs_off, h->im.cs_ids, n, rowbytes, d_out);
@@ -1417,7 +1423,7 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
     CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s));
-    CK(launch_color_rows(h, (const uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s));
+    CK(launch_color_rows(h, (uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s));
     return note_foreign_stream(h, s);
 }
 

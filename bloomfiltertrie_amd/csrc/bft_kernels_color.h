@@ -47,15 +47,15 @@ __device__ __forceinline__ uint32_t bm_dword_at(const uint32_t* __restrict__ row
 }
 
 // One output dword at tile-relative byte offset `byte` (a multiple of 4), which starts at byte b of k-mer q's row and may
-// straddle two or more rows: the bytes come from the bitmap row of each present k-mer.
-__device__ __forceinline__ uint32_t color_dword(const uint32_t* __restrict__ trow, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm,
-                                                uint32_t stride, uint32_t rowbytes, uint32_t nt, uint32_t q, uint32_t b) {
+// straddle two or more rows: the bytes come from the bitmap row of each present k-mer (colour sets of the tile: cs[]).
+__device__ __forceinline__ uint32_t color_dword_cs(const uint32_t* cs, const uint8_t* __restrict__ bm, uint32_t stride, uint32_t rowbytes, uint32_t nt,
+                                                   uint32_t q, uint32_t b) {
     uint32_t v = 0, have = 0;  // bytes of the output dword filled so far
     while (have < 4u && q < nt) {
         const uint32_t take = min(4u - have, rowbytes - b);
-        const uint32_t r = trow[q];
-        if (r != BFT_ABSENT_ROW) {
-            uint32_t w = bm_dword_at((const uint32_t*)(bm + (uint64_t)tcol[r] * stride), b);
+        const uint32_t c = cs[q];
+        if (c != BFT_ABSENT_ROW) {
+            uint32_t w = bm_dword_at((const uint32_t*)(bm + (uint64_t)c * stride), b);
             if (take < 4u) w &= (1u << (8u * take)) - 1u;
             v |= w << (8u * have);
         }
@@ -66,75 +66,96 @@ __device__ __forceinline__ uint32_t color_dword(const uint32_t* __restrict__ tro
     return v;
 }
 
-// Colour rows from the bitmap dictionary.  The rows of consecutive k-mers are contiguous (CEIL(G/8) bytes each); one thread
-// writes aligned dwords of that stream (coalesced 4-byte stores), a wavefront covering 256 consecutive bytes, i.e. mostly one
-// row: its lanes read consecutive dwords of the same dictionary row (one or two aligned loads + a funnel shift each).
-// Every thread works on CR_UNROLL dwords (one per grid stride) at a time, stage by stage (row index -> colour set -> bitmap
-// dwords).  Dwords that straddle rows go through color_dword.  Measured (config 5, 250-byte rows, 10^9 bytes out): 0.83 ms
-// = 1.2 TB/s written; byte gathers from unpadded dictionary rows took 1.2 ms; 16-byte chunks per thread were slower (a
-// wavefront then touches four dictionary rows per load instruction), more chains in flight per thread changed nothing,
-// non-temporal stores neither; without the dictionary reads or without the stores the kernel is only 17 % faster either
-// way; 8 bytes per thread (three source dwords, one 8-byte store) was 30 % slower again, like the 16-byte variant.  blockIdx.y selects a tile of `tile_rows` k-mers (a multiple of 4, tile bytes < 2^31) so that offsets inside
-// a tile are 32-bit and byte / rowbytes is a multiply-high by the host's magic number (div_m, div_l; exact on u32).
-#define CR_UNROLL 4
-__global__ void k_color_rows_bm(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint8_t* __restrict__ bm, uint32_t stride,
-                                uint64_t n, uint32_t rowbytes, uint32_t tile_rows, uint32_t div_m, uint32_t div_l, uint8_t* __restrict__ out) {
-    const uint64_t q0 = (uint64_t)blockIdx.y * tile_rows;
-    const uint32_t nt = (uint32_t)min((uint64_t)tile_rows, n - q0);  // k-mers of this tile
-    const uint32_t total = nt * rowbytes, ndw = (total + 3u) / 4u;
-    const uint32_t* trow = rows + q0;
-    uint8_t* tout = out + q0 * rowbytes;
-    const uint32_t G = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < ndw; i0 += G * CR_UNROLL) {
-        uint32_t q[CR_UNROLL], b[CR_UNROLL], r[CR_UNROLL], lo[CR_UNROLL], hi[CR_UNROLL];
-        const uint32_t* src[CR_UNROLL];
-        bool ok[CR_UNROLL], fast[CR_UNROLL];
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            const uint32_t i = i0 + (uint32_t)u * G;
-            ok[u] = i < ndw;
-            const uint32_t byte = i * 4u;
-            q[u] = byte;
-            if (div_l) {
-                const uint32_t t = __umulhi(byte, div_m);
-                q[u] = (t + ((byte - t) >> 1)) >> (div_l - 1u);
-            }
-            b[u] = byte - q[u] * rowbytes;
-            fast[u] = ok[u] && b[u] + 4u <= rowbytes && byte + 4u <= total;
+// Colour rows from the bitmap dictionary, row-cooperative (retrieveAnnotation for a batch: src/annotation.c:2134-2144 decodes one
+// bitmap annotation, the loop of src/file_io.c:744-765 one row per k-mer).  The rows of consecutive k-mers are contiguous
+// (CEIL(G/8) bytes each), so a workgroup owns a TILE of `tile_rows` consecutive k-mers = one contiguous, dword-aligned stretch of
+// the output:
+//   (before) k_row_colorsets turns the row of every k-mer into its colour-set id, in place (one gather per k-mer, its own launch);
+//   step A  the tile's colour-set ids: one coalesced load into LDS;
+//   step B  every thread produces aligned output dwords of the stretch: k-mer = byte / rowbytes (multiply-high by the host's
+//           magic number), dictionary row from LDS, one or two aligned source dwords + a funnel shift, one coalesced 4-byte store;
+//           CR_UNROLL independent dwords per thread are in flight at a time (a 32 KiB tile = two rounds of a 256-thread workgroup) --
+//           no dependent global load is left in the loop.
+// The first version resolved row -> colour set -> dictionary row per output DWORD (three dependent loads per 4 bytes) and was
+// latency-bound at 1.2 TB/s written; dwords that straddle two rows (rowbytes % 4 != 0) go through color_dword.
+#define CR_UNROLL 8
+#define CR_MAX_TILE_ROWS 2048
+// WIDE: rowbytes >= 4 -- an output dword touches at most two rows, handled without a branch (the second row's first dword is
+// loaded only by the lanes that straddle).  Rows of 1-3 bytes (<= 24 genomes) take the generic per-byte path.
+// The straddling dwords matter: with 250-byte rows one lane in 62 straddles, i.e. nearly every wavefront holds one, and a
+// branchy slow path there was executed by every wavefront for every dword (measured: ~250 VALU instructions per output dword,
+// 1.2 TB/s written whatever was done to the loads and stores).
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_color_rows_bm(const uint32_t* __restrict__ csid, const uint8_t* __restrict__ bm, uint32_t stride, uint64_t n,
+                                                       uint32_t rowbytes, uint32_t tile_rows, uint32_t div_m, uint32_t div_l, uint8_t* __restrict__ out) {
+    __shared__ uint32_t s_cs[CR_MAX_TILE_ROWS + 1];  // colour set of each k-mer of the tile (BFT_ABSENT_ROW: absent)
+    const uint64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * tile_rows;
+        const uint32_t nt = (uint32_t)min((uint64_t)tile_rows, n - q0);  // k-mers of this tile
+        // (WIDE: the dictionary row as a dword offset -- the dictionary stays below 4 GiB -- so that the loop needs no 64-bit multiply)
+        for (uint32_t j = threadIdx.x; j <= nt; j += blockDim.x) {
+            const uint32_t c = j < nt ? csid[q0 + j] : BFT_ABSENT_ROW;
+            s_cs[j] = (WIDE && c != BFT_ABSENT_ROW) ? c * (stride >> 2) : c;
         }
-        // unconditional loads on clamped indices (every array has slack behind it): the compiler issues each stage's
-        // CR_UNROLL loads back to back
+        __syncthreads();
+        const uint32_t* bmw = (const uint32_t*)bm;
+        const uint32_t total = nt * rowbytes, ndw = (total + 3u) / 4u;
+        uint8_t* tout = out + q0 * rowbytes;  // dword aligned: tile_rows is a multiple of 4
+        for (uint32_t i0 = threadIdx.x; i0 < ndw; i0 += blockDim.x * CR_UNROLL) {
+            if (WIDE) {
+                uint32_t b[CR_UNROLL], c0[CR_UNROLL], lo[CR_UNROLL], hi[CR_UNROLL], nx[CR_UNROLL];
 #pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) r[u] = trow[min(q[u], nt - 1u)];
+                for (int u = 0; u < CR_UNROLL; u++) {
+                    const uint32_t i = min(i0 + (uint32_t)u * blockDim.x, ndw - 1u), byte = i * 4u;
+                    const uint32_t t = __umulhi(byte, div_m);
+                    const uint32_t q = div_l ? (t + ((byte - t) >> 1)) >> (div_l - 1u) : byte;
+                    b[u] = byte - q * rowbytes;
+                    c0[u] = s_cs[q];
+                    const uint32_t c1 = b[u] + 4u > rowbytes ? s_cs[q + 1] : BFT_ABSENT_ROW;  // straddles into the next k-mer's row
+                    const uint32_t* src = bmw + (c0[u] != BFT_ABSENT_ROW ? c0[u] : 0u) + (b[u] >> 2);
+                    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };  // ONE 8-byte load at 4-byte alignment
+                    const Pair pr = *reinterpret_cast<const Pair*>(src);                  // (the dictionary carries slack behind its last row)
+                    lo[u] = pr.a;
+                    hi[u] = pr.b;
+                    nx[u] = c1 != BFT_ABSENT_ROW ? bmw[c1] : 0u;
+                }
 #pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) src[u] = (const uint32_t*)(bm + (uint64_t)tcol[r[u] != BFT_ABSENT_ROW ? r[u] : 0u] * stride) + (b[u] >> 2);
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            lo[u] = src[u][0];
-            hi[u] = src[u][1];
-        }
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++)
-            if (r[u] == BFT_ABSENT_ROW) lo[u] = hi[u] = 0u;
-#pragma unroll
-        for (int u = 0; u < CR_UNROLL; u++) {
-            if (!ok[u]) continue;
-            const uint32_t byte = (i0 + (uint32_t)u * G) * 4u;
-            if (fast[u]) {
-                const uint32_t sh = 8u * (b[u] & 3u);
-                *(uint32_t*)(tout + byte) = sh ? (lo[u] >> sh) | (hi[u] << (32u - sh)) : lo[u];
+                for (int u = 0; u < CR_UNROLL; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                    if (i >= ndw) continue;
+                    const uint32_t byte = i * 4u, sh = 8u * (b[u] & 3u), take = rowbytes - b[u];
+                    uint32_t v = sh ? (lo[u] >> sh) | (hi[u] << (32u - sh)) : lo[u];
+                    if (c0[u] == BFT_ABSENT_ROW) v = 0u;
+                    if (take < 4u) v = (v & ((1u << (8u * take)) - 1u)) | (nx[u] << (8u * take));
+                    if (byte + 4u <= total) __builtin_nontemporal_store(v, (uint32_t*)(tout + byte));  // written once, read by nobody here
+                    else
+                        for (uint32_t x = 0; byte + x < total; x++) tout[byte + x] = (uint8_t)(v >> (8u * x));  // the last dword of the whole batch
+                }
             } else {
-                const uint32_t w = color_dword(trow, tcol, bm, stride, rowbytes, nt, q[u], b[u]);
-                if (byte + 4u <= total) *(uint32_t*)(tout + byte) = w;
-                else
-                    for (uint32_t x = 0; byte + x < total; x++) tout[byte + x] = (uint8_t)(w >> (8u * x));
+#pragma unroll 2
+                for (int u = 0; u < CR_UNROLL; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                    if (i >= ndw) continue;
+                    const uint32_t byte = i * 4u;
+                    uint32_t q = byte;
+                    if (div_l) {
+                        const uint32_t t = __umulhi(byte, div_m);
+                        q = (t + ((byte - t) >> 1)) >> (div_l - 1u);
+                    }
+                    const uint32_t w = color_dword_cs(s_cs, bm, stride, rowbytes, nt, q, byte - q * rowbytes);
+                    if (byte + 4u <= total) *(uint32_t*)(tout + byte) = w;
+                    else
+                        for (uint32_t x = 0; byte + x < total; x++) tout[byte + x] = (uint8_t)(w >> (8u * x));
+                }
             }
         }
+        __syncthreads();
     }
 }
 
 // colour-set id of every located k-mer (BFT_ABSENT_ROW stays BFT_ABSENT_ROW)
-__global__ void k_row_colorsets(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, uint64_t n, uint32_t* __restrict__ out) {
+__global__ void k_row_colorsets(const uint32_t* rows, const uint32_t* __restrict__ tcol, uint64_t n, uint32_t* out) {  // out may be rows (in place)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = rows[i];
         out[i] = r == BFT_ABSENT_ROW ? BFT_ABSENT_ROW : tcol[r];
