@@ -36,23 +36,33 @@ int put_id(uint8_t* out, uint32_t id, uint8_t start_flag, uint8_t cont_flag) {
     return nb;
 }
 
-// smallest of the three live encodings (tie rules of compute_best_mode, src/annotation.c:634-650)
+// The bytes the reference holds for a colour set.  It picks the encoding anew at every insertion of a genome id
+// (compute_best_mode, src/annotation.c:416-656, called from modify_annotations, src/retrieveAnnotation.c:232-314): the smallest
+// of modes 0 (bitmap) / 1 (ranges) / 2 (id list) for the set as it then is -- mode 2 over 1 on equality, mode 0 when it is no
+// larger (:638-650) -- EXCEPT that on a tie with the mode the annotation is already in, it stays in that mode (:652-653).  The
+// result therefore depends on the order the ids arrived in; they arrive in ascending order (a k-mer meets genome ids in
+// increasing order), so the sorted id list IS the history and the rule is replayed over it, one id at a time, with the sizes of
+// :621-633 (mode 1: a new range costs two ids, extending the last one swaps its end).  disabled_flags (:622) is never set by the
+// reference and is not modelled; nor is the one-byte over-estimate of a run's end at id 4095 / 262143 while in bitmap mode
+// (:515-523), which needs > 4096 genomes in mode 0 to matter.  E.g. {6,7}: 6 enters in mode 2 (1 byte < 2 bytes of bitmap), at 7
+// all three modes cost 2 bytes and the annotation STAYS in mode 2 (a fresh decision would pick the bitmap).
 void annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) {
     out.clear();
     if (n == 0) { out.push_back(0); return; }
-    size_t s1 = 0, s2 = 0;
-    for (uint32_t a = 0; a < n;) {
-        uint32_t b = a;
-        while (b + 1 < n && ids[b + 1] == ids[b] + 1) b++;
-        s1 += nb_bytes_id(ids[a]) + nb_bytes_id(ids[b]);
-        a = b + 1;
+    size_t s0 = 0, s1 = 0, s2 = 0, sz = 0;
+    int mode = -1;
+    for (uint32_t a = 0; a < n; a++) {
+        const size_t b = (size_t)nb_bytes_id(ids[a]);
+        s0 = (3 + (size_t)ids[a] + 7) / 8;
+        s2 += b;
+        if (a > 0 && ids[a] == ids[a - 1] + 1) s1 = s1 + b - (size_t)nb_bytes_id(ids[a - 1]);
+        else s1 += 2 * b;
+        int m;
+        if (s2 <= s1) { m = 2; sz = s2; } else { m = 1; sz = s1; }
+        if (sz >= s0) { m = 0; sz = s0; }
+        if (mode >= 0 && m != mode && (mode == 0 ? s0 : (mode == 1 ? s1 : s2)) == sz) m = mode;  // tie: the current mode stays
+        mode = m;
     }
-    for (uint32_t a = 0; a < n; a++) s2 += nb_bytes_id(ids[a]);
-    const size_t s0 = (3 + (size_t)ids[n - 1] + 7) / 8;
-    int mode;
-    size_t sz;
-    if (s2 <= s1) { mode = 2; sz = s2; } else { mode = 1; sz = s1; }
-    if (sz >= s0) { mode = 0; sz = s0; }
     out.assign(sz, 0);
     if (mode == 0) {
         for (uint32_t a = 0; a < n; a++) out[(ids[a] + 2) / 8] |= (uint8_t)(1u << ((ids[a] + 2) % 8));

@@ -251,3 +251,12 @@ extern "C" uint64_t bft_hosttest_read_genome(void* fv, int g, uint8_t* out) {
     return v.size();
 }
 extern "C" void bft_hosttest_read_free(void* fv) { delete (BftFileContent*)fv; }
+
+// the product's annotation encoder (bft_file.cpp: what bft_gpu_colorset_annot and the .bft writer emit), for the CPU tests
+extern "C" int bft_hosttest_annot_encode(const uint32_t* ids, uint32_t n, uint8_t* out, uint32_t cap) {
+    std::vector<uint8_t> enc;
+    bft_annot_encode(ids, n, enc);
+    if (enc.size() > cap) return -1;
+    memcpy(out, enc.data(), enc.size());
+    return (int)enc.size();
+}

@@ -173,8 +173,12 @@ int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint
                        uint32_t* colorsets);
 
 /* A colour set as the reference's annotation bytes -- BFT_annotation::annot as get_annotation returns it
- * (include/bft.h:97, src/bft.c:363-387): the smallest of modes 0 (bitmap, genome g <-> bit g+2), 1 (ranges) and
- * 2 (id list) with the tie rules of compute_best_mode (src/annotation.c:634-650).  annot may be NULL to query the size. */
+ * (include/bft.h:97, src/bft.c:363-387): mode 0 (bitmap, genome g <-> bit g+2), 1 (ranges) or 2 (id list), chosen the way the
+ * reference chooses it: compute_best_mode re-decides at every insertion of a genome id and keeps the current mode on a size tie
+ * (src/annotation.c:621-653), so the bytes depend on the order the ids arrived in -- ascending -- and the rule is replayed over the
+ * sorted id list (e.g. {6,7} stays the id list 1a 1e it started as, although a bitmap would be no longer).  Not modelled: the
+ * never-set disabled_flags (:622) and the run-end size estimate in bitmap mode beyond 4096 genomes (:515-523).  The same bytes go
+ * into the .bft files bft_gpu_write_bft writes.  annot may be NULL to query the size. */
 int bft_gpu_colorset_annot(bft_gpu* h, uint32_t colorset, uint8_t* annot, uint32_t cap, uint32_t* n_out);
 
 /* Replication of a built index on another GPU (the query path shards over GPUs with the trie image

@@ -203,13 +203,39 @@ static void annot_sizes(const uint32_t *ids, int n, int *sz0, int *sz1, int *sz2
     *sz2 = s2;
 }
 
+/* The mode an annotation ends up in depends on its history: the reference re-decides at EVERY insertion of a genome id
+ * (modify_annotations -> compute_best_mode, src/retrieveAnnotation.c:232-314, src/annotation.c:416-656), and on a size tie
+ * it keeps the mode the annotation is already in (:652-653).  Ids reach a k-mer in ascending order, so the history of a
+ * colour set is its sorted id list: replay it.  Per step, with g the id being added (src/annotation.c:621-653):
+ *   size0 = CEIL(3 + g, 8)                      (disabled_flags is never set anywhere in the reference: bit 0 is always clear)
+ *   size2 = previous size2 + bytes(g)
+ *   size1 = previous size1 + 2 bytes(g) when g opens a new range, else + bytes(g) - bytes(previous id)   (:628-633)
+ *   min  = mode 2 if size2 <= size1 else mode 1; mode 0 if that minimum is >= size0            (:638-650)
+ *   if the current mode's new size equals the minimum, the current mode stays                   (:652-653)
+ * Not replayed: while an annotation is in mode 0 with ids >= 64 the reference prices the END of a run with the byte count of
+ * the id that FOLLOWS it (:515-523), one byte too many when a run ends at id 4095 or 262143 -- an estimate quirk that needs
+ * more than 4096 genomes in bitmap mode to show. */
 static int annot_best(const uint32_t *ids, int n, int *mode) {
-    int s0, s1, s2, m, sz;
-    annot_sizes(ids, n, &s0, &s1, &s2);
-    if (s2 <= s1) { m = 2; sz = s2; } else { m = 1; sz = s1; }
-    if (sz >= s0) { m = 0; sz = s0; }
-    *mode = m;
-    return sz;
+    int s1 = 0, s2 = 0, cur = -1, cur_sz = 1;
+    for (int a = 0; a < n; a++) {
+        const int b = orc_nb_bytes_id(ids[a]);
+        const int s0 = CEIL(3 + (int)ids[a], 8);
+        s2 += b;
+        if (a > 0 && ids[a] == ids[a - 1] + 1) s1 += b - orc_nb_bytes_id(ids[a - 1]);
+        else s1 += 2 * b;
+        int m, sz;
+        if (s2 <= s1) { m = 2; sz = s2; } else { m = 1; sz = s1; }
+        if (sz >= s0) { m = 0; sz = s0; }
+        if (cur >= 0 && m != cur) {
+            const int same = cur == 0 ? s0 : (cur == 1 ? s1 : s2);
+            if (same == sz) m = cur;
+        }
+        cur = m;
+        cur_sz = sz;
+    }
+    if (n == 0) { int s0; annot_sizes(ids, n, &s0, &s1, &s2); cur = 0; cur_sz = s0; }
+    *mode = cur;
+    return cur_sz;
 }
 
 int orc_annot_encode(const uint32_t *ids, int n, uint8_t *out, int cap) {

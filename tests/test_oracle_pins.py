@@ -100,3 +100,52 @@ def test_config1_trie_shape_matches_reference_run(oracle_mod):
     bits, cnt = t.query_presence_count(q)
     assert S.from_bits(bits, len(q)).all()
     assert abs(cnt["ccs_scanned"] / len(q) - pin["mean_ccs_scanned_per_present_query"]) < 0.1
+
+
+def test_annotation_mode_follows_the_insertion_history(oracle_mod):
+    """a15: compute_best_mode (src/annotation.c:416-656) is applied at every insertion and keeps the current mode on a size tie
+    (:652-653), so an annotation's bytes depend on the order its ids arrived in -- ascending, i.e. the sorted list replayed.
+    The expected bytes below are derived by hand from the reference's rule (sizes of :621-633, choice of :638-653), NOT from
+    either encoder:
+      {6}      6 alone: mode 2 costs 1 byte, the bitmap CEIL(3+6, 8) = 2            -> mode 2: (6<<2)|2 = 0x1a
+      {6,7}    at 7: list 2, ranges 1+1 = 2, bitmap CEIL(10/8) = 2: three-way tie, current mode 2 stays -> 0x1a 0x1e
+               (a decision from scratch takes mode 0 on that tie: the bytes would be 00 03)
+      {5,6}    5 alone: bitmap CEIL(8/8) = 1 <= list 1 -> mode 0; at 6: all three cost 2, mode 0 stays -> bits 7 and 8: 0x80 0x01
+      {6,7,8}  at 8: list 3, ranges 2, bitmap 2: the current mode (2) is not minimal, mode 0 wins the 1-vs-0 tie -> bits 8,9,10: 00 07
+      {6,8}    at 8: list 2, ranges 4, bitmap 2: tie between 2 and 0, current mode 2 stays -> 0x1a 0x22
+      {70..73} two-byte ids: list 8 vs ranges 2+2 = 4 vs bitmap 10 -> mode 1: start 70 = 0x05 0x1a, end 73 = 0x05 0x26
+    Both encoders (the oracle's and the product's, through libbft_hosttest.so) must give exactly these bytes, and every
+    encoding must decode back to its id list."""
+    import ctypes as C
+    import os
+    from bloomfiltertrie_amd import _lib
+    lib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
+    lib.bft_hosttest_annot_encode.restype = C.c_int
+    lib.bft_hosttest_annot_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    vectors = {(6,): "1a", (6, 7): "1a1e", (5, 6): "8001", (6, 7, 8): "0007", (6, 8): "1a22", (70, 71, 72, 73): "051a0526", (0,): "04", (5,): "80"}
+    for ids, hexbytes in vectors.items():
+        assert oracle_mod.annot_encode(list(ids)).hex() == hexbytes, ids
+        a = np.array(ids, dtype=np.uint32)
+        buf = np.zeros(64, np.uint8)
+        n = lib.bft_hosttest_annot_encode(a.ctypes.data, len(a), buf.ctypes.data, 64)
+        assert buf[:n].tobytes().hex() == hexbytes, ids
+    rng = np.random.default_rng(11)
+    for trial in range(400):  # round trips + agreement of the two encoders on random sets (dense, sparse, runs, ids up to 5000)
+        kind = trial % 4
+        if kind == 0:
+            ids = np.flatnonzero(rng.random(rng.integers(1, 200)) < 0.6)
+        elif kind == 1:
+            ids = np.unique(rng.integers(0, 5000, rng.integers(1, 12)))
+        elif kind == 2:
+            a0 = int(rng.integers(0, 4200))
+            ids = np.arange(a0, a0 + int(rng.integers(1, 90)))
+        else:
+            ids = np.unique(np.concatenate([np.arange(3, 3 + rng.integers(1, 9)), rng.integers(60, 300, 3)]))
+        ids = ids.astype(np.uint32)
+        if len(ids) == 0:
+            continue
+        enc = oracle_mod.annot_encode(ids.tolist())
+        assert oracle_mod.annot_decode(enc) == ids.tolist()
+        buf = np.zeros(16 + 4 * len(ids) + int(ids.max()) // 8, np.uint8)
+        n = lib.bft_hosttest_annot_encode(ids.ctypes.data, len(ids), buf.ctypes.data, len(buf))
+        assert n == len(enc) and buf[:n].tobytes() == enc
