@@ -257,9 +257,20 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
 #pragma unroll
             for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
             bft_tform_from_x<W>(y, k, t);
-            int cl = 0;
-            // the four successors differ in the last nucleotide only: one shared descent, four finishes
-            const int cr = bft_walk_last4<W, BftRootLds<STAGED>>(im, acc, root, t, counts != nullptr);
+            int cl = 0, cr = 0;
+            // the four successors differ in the last nucleotide only (bits vo.. of the T-form's last word)
+            const int vo = rb ? 0 : 2;
+            uint64_t cand[4][W];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+#pragma unroll
+                for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == W - 1 ? (uint64_t)v << vo : 0ull);
+            }
+            uint32_t pres = 0;
+            uint32_t dec = bft_fast4<W>(im, cand, &pres);  // all four through the derived tables at once, when those settle them
+            if (dec == 0xFu) cr = __popc(pres);
+            else  // one shared descent, four finishes (any index, any level)
+                cr = bft_walk_last4<W, BftRootLds<STAGED>>(im, acc, root, t, counts != nullptr);
             if (counts || cr < 2) {
                 // predecessors: shift in a wildcard first nucleotide, drop the last one
 #pragma unroll
@@ -268,12 +279,15 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
                 if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
                 bft_tform_from_x<W>(y, k, t);
                 const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;  // digit 0 starts at bit o of the T-form integer
-                for (uint64_t nt = 0; nt < 4 && (counts || cl < 2); nt++) {
-                    uint64_t tt[W];
 #pragma unroll
-                    for (int w = 0; w < W; w++) tt[w] = t[w] | (w == ow ? nt << osh : 0ull);
-                    cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, tt).present;
+                for (int v = 0; v < 4; v++) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == ow ? (uint64_t)v << osh : 0ull);
                 }
+                dec = bft_fast4<W>(im, cand, &pres);
+                cl = __popc(pres & dec);
+                for (int v = 0; v < 4 && (counts || cl < 2); v++)
+                    if (!((dec >> v) & 1u)) cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, cand[v]).present;
             }
             branching = cr > 1 || cl > 1;
             if (counts) counts[i] = (uint8_t)((cr << 4) | cl);

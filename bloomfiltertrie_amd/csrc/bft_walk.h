@@ -712,6 +712,60 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
     return hit;
 }
 
+// Four k-mers at once through the derived tables (branching: the four successors / predecessors of a k-mer): root range table
+// -> hashed suffix group, with the loads of all four issued before any is used -- four independent two-load chains in flight
+// instead of four walks one after the other.  Decides a candidate only when its root prefix is plain and its group hashed (or
+// empty) and the home bucket settles it; returns a 4-bit mask of the decided candidates and sets bit v of *present for those
+// found.  The caller walks the others (bft_walk gives the same answer for any candidate, decided here or not).
+template <int W>
+BFT_HD uint32_t bft_fast4(const BftImage& im, const uint64_t (*t)[W], uint32_t* present) {
+    *present = 0;
+    // one-word rows only: sixteen two-word slots in flight do not fit the 64 VGPRs of the 8-waves-per-SIMD kernels (measured: spills)
+    if (W > 1 || im.rstart == nullptr || im.tkh == nullptr || im.L < 2) return 0u;
+    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+    uint32_t a[4], cnt[4], decided = 0;
+    uint64_t s0[4];
+    bool go[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const uint32_t r = bft_digit<W>(t[v], im.k, 0);
+        const Pair pr = *reinterpret_cast<const Pair*>(im.rstart + r);
+        a[v] = pr.a;
+        cnt[v] = (pr.b & ~BFT_RSTART_SPECIAL) - (pr.a & ~BFT_RSTART_SPECIAL);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const bool plain = !(a[v] & BFT_RSTART_SPECIAL);
+        if (plain && cnt[v] == 0) decided |= 1u << v;  // no k-mer under that root prefix
+        go[v] = plain && bft_gh_group(cnt[v]);
+        uint64_t b0 = 0;
+        uint32_t nbk = 1;
+        if (go[v]) bft_gh_region(a[v], cnt[v], &b0, &nbk);
+        s0[v] = go[v] ? (b0 + bft_gh_home<W>(t[v], nbk)) * BFT_GH_SLOTS : 0;
+    }
+    uint64_t sl[4][BFT_GH_SLOTS][W];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+#pragma unroll
+        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) bft_load_row<W>(im.tkh + (s0[v] + s) * W, sl[v][s]);  // (slot 0.. of the table when !go: harmless)
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        if (!go[v]) continue;
+        bool hit = false, free_slot = false, unhashed = false;
+#pragma unroll
+        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) {
+            unhashed = unhashed || sl[v][s][0] == BFT_GH_UNHASHED;
+            hit = hit || bft_cmp<W>(sl[v][s], t[v]) == 0;
+            free_slot = free_slot || sl[v][s][0] == BFT_GH_EMPTY;
+        }
+        if (unhashed) continue;
+        if (hit) { *present |= 1u << v; decided |= 1u << v; }
+        else if (free_slot) decided |= 1u << v;  // the row would sit in this bucket: absent
+    }
+    return decided;
+}
+
 // How many of the four rows t | v << vo (v = 0..3; t has those two bits clear) the suffix group [idx, idx+cnt) holds.  The
 // four values lie within 13 consecutive integers, so their rows are neighbours in the sorted group: ONE search for the
 // first row >= t (64-byte block probes from the interpolated guess, as in bft_group_probe, then a binary search), then a

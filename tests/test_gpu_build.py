@@ -239,3 +239,19 @@ def test_rejects_out_of_range_genome_ids():
             t.insert_kmers(km, bad)
     t.insert_kmers(km, (1 << 24) - 1)  # the largest id accepted
     assert t.info()["pending_pairs"] == len(km)
+
+
+def test_pair_limit_is_reported_not_overrun():
+    """< 2^31 (k-mer, genome) pairs per handle (DESIGN.md limits): the call that would cross it fails with BFT_GPU_E_LIMIT before
+    it allocates or touches anything, and the handle stays usable."""
+    import torch
+    from bloomfiltertrie_amd._lib import BFTError
+    t = BFT(27)
+    small = torch.zeros((1024, 7), dtype=torch.uint8, device="cuda")
+    with pytest.raises(BFTError, match="2\\^31"):
+        t.insert_kmers_dev(small.data_ptr(), (1 << 31) - 1, 0)   # (never dereferenced: the limit check comes first)
+    with pytest.raises(BFTError, match="reserve_pairs"):
+        t.set_option("reserve_pairs", 1 << 31)
+    km = S.distinct(S.kmers_of(S.random_genome(5000, 1), 27))
+    t.insert_kmers(km, 0)
+    assert (S.from_bits(t.query_presence(km), len(km))).all()
