@@ -207,6 +207,9 @@ struct bft_gpu {
     DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
     DevBuf d_rdir, d_rstart;      // derived: root direct table (BFT_RDIR_*, k_root_direct) and root range table (BFT_RSTART_*), optional
+    DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
+    bool opt_node_hash = true;    // "node_hash"
+    uint64_t nph_inserted = 0, nph_dropped = 0;
     DevBuf d_tkh, d_tkrank;       // hashed form of the suffix groups (BFT_GH_*), built with the containers when "group_hash" is on
     uint64_t n_tkh_bytes = 0, n_tkrank_bytes = 0, n_gh_groups = 0, n_gh_unhashed = 0;
     bool opt_group_hash = true;   // "group_hash": build (next build) and use the hashed form
@@ -563,7 +566,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->n_tkh_bytes + h->n_tkrank_bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_nph.bytes + h->n_tkh_bytes + h->n_tkrank_bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -595,6 +598,10 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.f18 = h->d_f18.as<uint64_t>();
     im.fent = h->d_fent.as<uint64_t>();
     im.rdir = nullptr;  // derived after this call (derive_root_direct)
+    im.rstart = nullptr;
+    im.nph = nullptr;   // (derive_node_hash)
+    im.nph_mask = 0;
+    im.nph_no_uc = 0;
     h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
     h->cs_bm_tried = false;
     h->d_cs_bm.release();
@@ -623,6 +630,85 @@ __global__ void k_root_ranges_check(const uint64_t* __restrict__ rdir, uint32_t*
     if (r >= (1u << 18)) return;
     const uint32_t a = rs[r];
     if (!(a & BFT_RSTART_SPECIAL) && !bft_root_range_ok(a, rs[r + 1], rdir[r])) rs[r] = a | BFT_RSTART_SPECIAL;  // (readers mask the flag)
+}
+
+// Node prefix hash: one thread per node below the root walks its CCs (filter2 bits -> clusters -> entries, as k_flat_fill does) and
+// claims a slot of the (node, prefix) bucket with atomicCAS; keys whose bucket is full are dropped (the lookup then takes the
+// container path).  stats: [0] inserted, [1] dropped, [2] nodes below the root that hold UC rows.
+__global__ void k_nph_fill(BftImage im, uint32_t n_nodes, uint64_t* __restrict__ tab, uint64_t mask, unsigned long long* __restrict__ stats) {
+    for (uint32_t m = 1 + blockIdx.x * blockDim.x + threadIdx.x; m < n_nodes; m += gridDim.x * blockDim.x) {
+        const BftNode nd = im.nodes[m];
+        if (nd.uc_n) atomicAdd(&stats[2], 1ull);
+        for (uint32_t c = 0; c < nd.ncc; c++) {
+            const BftCC cc = im.ccs[nd.cc_first + c];
+            const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+            uint32_t clu = 0;
+            for (uint32_t w = 0; w < nw; w++) {
+                uint64_t bits = im.f2w[cc.f2_off + w] & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+                while (bits) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    const uint32_t pu = w * BFT_F2_BITS_PER_WORD + b;
+                    const uint64_t ce = im.clus[cc.clus_off + clu++];
+                    const uint32_t len = (ce & BFT_CLUS_MULTI) ? (uint32_t)((ce >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+                    for (uint32_t j = 0; j < len; j++) {
+                        const uint64_t ent = (ce & BFT_CLUS_MULTI) ? im.child[cc.child_off + (uint32_t)ce + j] : ce;
+                        const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
+                        const uint64_t key = bft_nph_key(m, r);
+                        unsigned long long* bk = (unsigned long long*)(tab + bft_nph_bucket(key, mask) * (2 * BFT_NPH_SLOTS));
+                        bool placed = false;
+                        for (int s = 0; s < BFT_NPH_SLOTS && !placed; s++)
+                            if (atomicCAS(&bk[2 * s], (unsigned long long)BFT_NPH_EMPTY, (unsigned long long)key) == BFT_NPH_EMPTY) {
+                                bk[2 * s + 1] = ent;
+                                placed = true;
+                            }
+                        atomicAdd(&stats[placed ? 0 : 1], 1ull);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Derives the node prefix hash of the image h->im points at.  An accelerator only: without it the walk keeps the container path.
+static void derive_node_hash(bft_gpu* h) {
+    h->im.nph = nullptr;
+    h->im.nph_mask = 0;
+    h->im.nph_no_uc = 0;
+    h->nph_inserted = h->nph_dropped = 0;
+    const uint64_t n_nodes = h->idx_sizes[0] / sizeof(BftNode);
+    if (!h->opt_node_hash || n_nodes <= 1 || h->info[6] == 0) {
+        h->d_nph.release();
+        return;
+    }
+    // keys = the prefixes of the nodes below the root = all prefixes (info[6]) minus the root's (nb_elem of its CCs)
+    uint64_t root_prefixes = 0;
+    {
+        std::vector<BftCC> rc(h->root_ncc);
+        if (h->root_ncc && hipMemcpy(rc.data(), h->d_ccs.p, rc.size() * sizeof(BftCC), hipMemcpyDeviceToHost) != hipSuccess) return;  // (the root's CCs come first)
+        for (const BftCC& c : rc) root_prefixes += c.nb_elem;
+    }
+    const uint64_t keys = h->info[6] > root_prefixes ? h->info[6] - root_prefixes : 0;
+    uint64_t nbk = 1024;
+    while (nbk < keys) nbk <<= 1;  // <= 1 key per 4-slot bucket on average
+    const size_t bytes = nbk * BFT_NPH_SLOTS * 16;
+    DevBuf stats;
+    if (h->d_nph.alloc(bytes) != 0 || stats.alloc_zero(24, h->stream) != 0) { h->d_nph.release(); return; }
+    if (hipMemsetAsync(h->d_nph.p, 0xFF, bytes, h->stream) != hipSuccess) { h->d_nph.release(); return; }
+    BftImage tmp = h->im;
+    hipLaunchKernelGGL(k_nph_fill, dim3(grid_for((n_nodes + 255) / 256)), dim3(256), 0, h->stream, tmp, (uint32_t)n_nodes, h->d_nph.as<uint64_t>(), nbk - 1,
+                       stats.as<unsigned long long>());
+    unsigned long long st[3] = {0, 0, 0};
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(st, stats.p, 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->d_nph.release();
+        return;
+    }
+    h->nph_inserted = st[0];
+    h->nph_dropped = st[1];
+    h->im.nph = h->d_nph.as<uint64_t>();
+    h->im.nph_mask = nbk - 1;
+    h->im.nph_no_uc = st[2] == 0 ? 1u : 0u;
 }
 
 // Derives the table for the image h->im points at (after point_image).  An accelerator only: on any failure the walk simply
@@ -678,6 +764,7 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     h->n_fent = n_fent;
     point_image(h, nb_genomes);
     derive_root_direct(h);
+    derive_node_hash(h);
     if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     return 0;
 }
@@ -862,6 +949,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[3] = 0;
     h->built = true;
     derive_root_direct(h);
+    derive_node_hash(h);
     I[12] = image_bytes(h);
     // launch tuning on the committed image (timing runs only: a failure here leaves a complete, queryable index)
     if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
@@ -1781,6 +1869,16 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;
         h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+    } else if (nm == "node_hash") {  // 1 (default): levels below the root through the node prefix hash; 0: through the containers
+        h->opt_node_hash = value != 0;
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            derive_node_hash(h);
+            h->info[12] = image_bytes(h);
+            if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0 || h->opt_root_direct == 3) CK(tune_residency(h));
+        }
     } else if (nm == "group_hash") {  // 1 (default): suffix groups through their hashed form; 0: through the sorted table only.  Takes
         h->opt_group_hash = value != 0;  // effect at once when the image has the form (it is built with the containers when the option is on)
         if (h->built) {
@@ -1853,11 +1951,12 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[17] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+    const double v[19] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
                           h->im.probe_big ? 8.0 : 4.0, (double)(h->opt_bucket_bits >= 0 ? h->opt_bucket_bits : h->tuned_bucket_bits), h->bucket_tune_ms[0],
                           h->bucket_tune_ms[1], (double)h->n_gh_groups, (double)h->n_gh_unhashed,
-                          (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1]};
-    for (int i = 0; i < n_out && i < 17; i++) ms[i] = v[i];
+                          (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
+                          (double)h->nph_inserted, (double)h->nph_dropped};
+    for (int i = 0; i < n_out && i < 19; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

@@ -18,7 +18,7 @@ struct HostTrie {
     std::vector<uint32_t> hashmod;
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
-    std::vector<uint64_t> rdir;
+    std::vector<uint64_t> rdir, nph;
     std::vector<uint32_t> rstart;
     uint64_t rstart_plain = 0;
     BftHostIndex idx;
@@ -107,6 +107,46 @@ extern "C" void bft_hosttest_group_hash(void* hv, int on) {
     const bool have = on && !t->idx.tkh.empty();
     t->im.tkh = have ? t->idx.tkh.data() : nullptr;
     t->im.tkrank = have ? t->idx.tkrank.data() : nullptr;
+}
+
+// node prefix hash (BFT_NPH_*): the enumeration of k_nph_fill, sequential; on / off.  tiny != 0 sizes the table far too small so
+// that most buckets fill up and the "full bucket -> container path" branch is exercised.
+extern "C" void bft_hosttest_node_hash(void* hv, int on, int tiny) {
+    HostTrie* t = (HostTrie*)hv;
+    BftImage& im = t->im;
+    im.nph = nullptr; im.nph_mask = 0; im.nph_no_uc = 0;
+    if (!on || t->idx.nodes.size() <= 1) return;
+    uint64_t nbk = tiny ? 8 : 1024;
+    while (!tiny && nbk < t->idx.n_prefixes) nbk <<= 1;
+    t->nph.assign(nbk * BFT_NPH_SLOTS * 2, BFT_NPH_EMPTY);
+    bool any_uc = false;
+    for (uint32_t m = 1; m < t->idx.nodes.size(); m++) {
+        const BftNode nd = t->idx.nodes[m];
+        any_uc = any_uc || nd.uc_n;
+        for (uint32_t c = 0; c < nd.ncc; c++) {
+            const BftCC cc = t->idx.ccs[nd.cc_first + c];
+            const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+            uint32_t clu = 0;
+            for (uint32_t w = 0; w < nw; w++) {
+                uint64_t bits = t->idx.f2w[cc.f2_off + w] & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+                while (bits) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    const uint32_t pu = w * BFT_F2_BITS_PER_WORD + b;
+                    const uint64_t ce = t->idx.clus[cc.clus_off + clu++];
+                    const uint32_t len = (ce & BFT_CLUS_MULTI) ? (uint32_t)((ce >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+                    for (uint32_t j = 0; j < len; j++) {
+                        const uint64_t ent = (ce & BFT_CLUS_MULTI) ? t->idx.child[cc.child_off + (uint32_t)ce + j] : ce;
+                        const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
+                        bft_nph_insert_seq(t->nph.data(), nbk - 1, m, r, ent);
+                    }
+                }
+            }
+        }
+    }
+    im.nph = t->nph.data();
+    im.nph_mask = nbk - 1;
+    im.nph_no_uc = any_uc ? 0u : 1u;
 }
 
 // root direct table (BFT_RDIR_*): derived with the same per-prefix function as the GPU kernel k_root_direct; on / off

@@ -118,6 +118,16 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 #define BFT_GH_EMPTY (~0ull)
 #define BFT_GH_UNHASHED (~0ull - 1ull)
 
+// Node prefix hash (derived when the image is bound, optional): the prefix entries of every node BELOW the root in one hash table
+// keyed by (node id, rotated prefix) -- 64-byte buckets of four {key, entry} pairs, sized for <= 1 key per bucket on average.  On a
+// deep trie a level then costs one cache line (the bucket) instead of four dependent ones (node record, CC header, filter2 word,
+// cluster entry).  A key that found its bucket full is simply not in the table: a lookup that meets a full bucket without its key
+// takes the container path, so the table never changes an answer.  A bucket with a free slot and no such key means no CC of the
+// node holds the prefix; that is "absent" outright when no node below the root holds UC rows (nph_no_uc), else the container
+// path (-> the node's UC).
+#define BFT_NPH_SLOTS 4
+#define BFT_NPH_EMPTY (~0ull)
+
 struct BftImage {
     int k, L, W;
     uint32_t nb_genomes;
@@ -135,6 +145,9 @@ struct BftImage {
     const uint64_t* fent;     // flat prefix entries of the s = 4 CCs
     const uint64_t* rdir;     // [2^18] root direct table (see BFT_RDIR_*), or NULL
     const uint32_t* rstart;   // [2^18 + 1] root range table (see BFT_RSTART_SPECIAL), or NULL; only with rdir
+    const uint64_t* nph;      // node prefix hash (see BFT_NPH_*): (nph_mask + 1) buckets of 4 {key, entry}, or NULL
+    uint64_t nph_mask;
+    uint32_t nph_no_uc;       // 1: no node below the root holds UC rows
     const uint64_t* f2w;
     const uint64_t* clus;
     const uint64_t* child;

@@ -440,6 +440,37 @@ BFT_HD bool bft_cc_lookup(const BftImage& im, const BftCCX& cc, uint32_t r, uint
     return true;
 }
 
+// ---- node prefix hash (bft_image.h): prefix entries of the nodes below the root, keyed by (node, rotated prefix) ----
+BFT_HD uint64_t bft_nph_key(uint32_t node, uint32_t r) { return ((uint64_t)node << 18) | r; }
+BFT_HD uint64_t bft_nph_bucket(uint64_t key, uint64_t mask) {
+    uint64_t h = key * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+    return h & mask;
+}
+// 1: found (*e = the entry); 0: the bucket has a free slot and no such key -- no CC of the node holds r; -1: full bucket, undecided
+BFT_HD int bft_nph_lookup(const BftImage& im, uint32_t node, uint32_t r, uint64_t* e) {
+    const uint64_t key = bft_nph_key(node, r);
+    const uint64_t* b = im.nph + bft_nph_bucket(key, im.nph_mask) * (2 * BFT_NPH_SLOTS);
+    uint64_t kv[BFT_NPH_SLOTS][2];
+#pragma unroll
+    for (int s = 0; s < BFT_NPH_SLOTS; s++) bft_load_row<2>(b + 2 * s, kv[s]);  // four 16-byte loads of one 64-byte line
+    bool free_slot = false;
+#pragma unroll
+    for (int s = 0; s < BFT_NPH_SLOTS; s++) {
+        if (kv[s][0] == key) { *e = kv[s][1]; return 1; }
+        free_slot = free_slot || kv[s][0] == BFT_NPH_EMPTY;
+    }
+    return free_slot ? 0 : -1;
+}
+// Host-side / single-thread insertion (the GPU kernel k_nph_fill claims slots with atomicCAS instead): false when the bucket is full.
+BFT_HD bool bft_nph_insert_seq(uint64_t* tab, uint64_t mask, uint32_t node, uint32_t r, uint64_t ent) {
+    const uint64_t key = bft_nph_key(node, r);
+    uint64_t* b = tab + bft_nph_bucket(key, mask) * (2 * BFT_NPH_SLOTS);
+    for (int s = 0; s < BFT_NPH_SLOTS; s++)
+        if (b[2 * s] == BFT_NPH_EMPTY) { b[2 * s] = key; b[2 * s + 1] = ent; return true; }
+    return false;
+}
+
 // One entry of the root direct table (BFT_RDIR_*, bft_image.h): the root level's Bloom probe + CC lookup for prefix r, i.e.
 // steps (2)-(6) of presenceKmer (src/presenceNode.c:1341-1489) evaluated for one of the 2^18 possible prefixes.
 template <class Root>
@@ -629,9 +660,19 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
     const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
     for (int d = d0; d < L; d++) {
         BftNode nd;
+        const uint32_t r = bft_digit<W>(t, im.k, d);
+        uint64_t e = 0;
+        bool stop = false, found = false;
+        // Below the root: the node prefix hash (bft_image.h) answers "which entry does prefix r have in node `node`" with one
+        // 64-byte bucket instead of node record -> CC header -> filter2 word -> cluster entry.
+        if (d > d0 && im.nph != nullptr) {
+            const int res = bft_nph_lookup(im, node, r, &e);
+            if (res > 0) found = true;
+            else if (res == 0 && im.nph_no_uc) return hit;  // in no CC of the node, and no node below the root holds UC rows: absent
+        }
+        if (!found) {
         if (d == d0) nd = start_node;
         else nd = im.nodes[node];
-        const uint32_t r = bft_digit<W>(t, im.k, d);
         // Which CC: the first one whose Bloom filter holds the key (src/presenceNode.c:1353-1362).  A node with ONE CC needs
         // no filter below the root: every prefix of a CC is Bloom-positive in it and every UC row is Bloom-negative
         // (SURVEY A.7/A.8), so "CC first, then the UC" gives what "Bloom, then CC or UC" gives, two gathers earlier.
@@ -641,8 +682,6 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         const bool single = d > 0 && nd.ncc == 1;
 #endif
         int c = single ? 0 : -1;
-        uint64_t e = 0;
-        bool stop = false, found = false;
         if (d == 0 && im.rdir != nullptr) {
             // Root level through the derived tables (bft_image.h).  Plain suffix groups: two adjacent words of the 1 MiB range
             // table give {first row, count}.
@@ -697,6 +736,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
             bft_uc_search<W>(im, nd, t, hit);   // no Bloom-positive CC (or a single CC without the prefix): the node's UC
             return hit;
         }
+        }  // (!found by the node prefix hash)
         if (stop) { hit.present = (int)(e & 1); return hit; }
         uint32_t cnt = (uint32_t)(e >> BFT_CHILD_CNT_SHIFT) & 0xFFu;
         uint64_t idx = e & BFT_CHILD_IDX_MASK;

@@ -133,7 +133,8 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
  * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
- * (grid = resident workgroups x value), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte
+ * (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into one
+ * hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte
  * buckets, one cache line per lookup -- built with the containers and used by every query; 0: sorted table only), "root_direct" (the root level goes through tables derived from the containers:
  * 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain suffix groups, backed by the 2 MiB table; 3, default = 1 or 2,
  * whichever measured faster on the image; 0 = the containers), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
@@ -157,7 +158,8 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
  * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8),
  * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing,
  * ms[12]=suffix groups that own a hashed form, ms[13]=of which left unhashed (searched in the sorted table), ms[14]=root tables in use (0 / 1 / 2, see "root_direct"),
- * ms[15..16]=time of the tuning batch with the direct table alone / with the range table. */
+ * ms[15..16]=time of the tuning batch with the direct table alone / with the range table, ms[17]=keys in the node prefix hash, ms[18]=keys it dropped (full bucket:
+ * those lookups take the container path). */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

@@ -73,6 +73,7 @@ def hostlib(built):
     lib.bft_hosttest_set_probe.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_root_direct.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_group_hash.argtypes = [C.c_void_p, C.c_int]
+    lib.bft_hosttest_node_hash.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_hashmod.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -156,6 +157,13 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     o.insert_kmers(km, 0)
     assert (bits == o.query_presence(q)).all()
     assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
+    for tiny in (0, 1):  # levels below the root through the node prefix hash (full-size table; 8-bucket table: nearly every bucket full)
+        hostlib.bft_hosttest_node_hash(h, 1, tiny)
+        hostlib.bft_hosttest_group_hash(h, tiny)
+        hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+        hostlib.bft_hosttest_node_hash(h, 0, 0)
+        hostlib.bft_hosttest_group_hash(h, 0)
+        assert (bits8 == bits).all() and (rows8 == rows).all()
     st = np.zeros(12, np.uint64)
     hostlib.bft_hosttest_stats(h, st.ctypes.data)
     hostlib.bft_hosttest_free(h)

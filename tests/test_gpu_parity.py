@@ -384,9 +384,10 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     assert tuned in (1.0, 2.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
     # (block, workgroups per CU, grid multiplier, probe rows, root direct table, prefix-bucket bits, hashed suffix groups)
-    for blk, wgs, mult, probe, rdir, bkb, gh in [(1024, 0, 1, 0, 1, 0, 1), (1024, 1, 1, 4, 0, 0, 0), (1024, 2, 1, 8, 1, 8, 1), (768, 2, 1, 4, 0, 6, 0), (512, 1, 3, 8, 1, 0, 0),
+    for blk, wgs, mult, probe, rdir, bkb, gh in [(1024, 0, 1, 0, 1, 0, 1), (1024, 1, 1, 4, 0, 0, 0), (1024, 2, 1, 8, 2, 8, 1), (768, 2, 1, 4, 0, 6, 0), (512, 1, 3, 8, 3, 0, 0),
                                                  (512, 2, 1, 0, 0, 10, 1), (256, 2, 2, 8, 1, 4, 1)]:
         t.set_option("group_hash", gh)
+        t.set_option("node_hash", (blk // 256 + gh) % 2)
         t.set_option("query_block", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)

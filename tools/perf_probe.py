@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--probes", default="0", help="comma list of query_probe settings (0 = automatic, 4, 8)")
     ap.add_argument("--flat-mins", default="3584", help="comma list of flat_min settings to time (65536 = flat form off)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="experiment: stable-sort the query batch by the top bits of its rotated root prefix (n2..) before timing")
+    ap.add_argument("--node-hash", default="1", help="comma list of 0/1: node prefix hash below the root")
     ap.add_argument("--stops", action="store_true", help="time the walk truncated after each stage (results wrong)")
     args = ap.parse_args()
     import torch
@@ -84,10 +85,12 @@ def main():
         nv = 500_000
         truth = S.member(dq[:nv].cpu().numpy(), union)
         print(json.dumps({"workload": wl, "k": k, "build_s": round(time.time() - t0, 2), **{x: info[x] for x in ("kmers", "nodes", "ccs", "child_nodes", "uc_rows", "root_ccs", "image_bytes")}}), flush=True)
-        for fm, blk, mult, wg, pr in [(f, b, m, w, p) for f in [int(x) for x in args.flat_mins.split(",")] for b in [int(x) for x in args.blocks.split(",")]
-                                      for m in [int(x) for x in args.mults.split(",")] for w in [int(x) for x in args.wgs.split(",")]
-                                      for p in [int(x) for x in args.probes.split(",")]]:
+        for nh, fm, blk, mult, wg, pr in [(n_, f, b, m, w, p) for n_ in [int(x) for x in args.node_hash.split(",")] for f in [int(x) for x in args.flat_mins.split(",")]
+                                          for b in [int(x) for x in args.blocks.split(",")]
+                                          for m in [int(x) for x in args.mults.split(",")] for w in [int(x) for x in args.wgs.split(",")]
+                                          for p in [int(x) for x in args.probes.split(",")]]:
             if True:
+                t.set_option("node_hash", nh)
                 t.set_option("query_probe", pr)
                 t.set_option("flat_min", fm)
                 t.set_option("query_wgs_per_cu", wg)
@@ -102,7 +105,7 @@ def main():
                     t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
                 torch.cuda.synchronize()
                 ms, n = t.kernel_time(reset=True)
-                print(json.dumps({"workload": wl, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
+                print(json.dumps({"workload": wl, "node_hash": nh, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
         if args.stops:  # needs BFT_GPU_LIB=bloomfiltertrie_amd/csrc/libbft_gpu_probe.so (make -C bloomfiltertrie_amd/csrc probe)
             t.set_option("query_block", 1024)
             t.set_option("query_grid_mult", 1)
