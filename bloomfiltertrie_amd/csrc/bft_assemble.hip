@@ -326,19 +326,95 @@ __global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __r
     }
 }
 
-// Hashed form of the suffix groups of one depth (BFT_GH_*): one thread per prefix that owns a group of BFT_GH_MIN..BFT_GH_MAX
-// rows inserts them in row order with the function the host restatement uses (bft_gh_build_group) -- groups own disjoint
-// regions of tkh, so threads never meet.  stats[0] += groups, stats[1] += groups left unhashed.
+// Hashed form of the suffix groups of one depth (BFT_GH_*).  k_gh_flags marks the prefixes that own a group of BFT_GH_MIN..
+// BFT_GH_MAX rows, k_gh_list compacts them, k_group_hash builds one group per WAVEFRONT with the group's region of tkh staged in
+// LDS: the rows are loaded coalesced (64 at a time), then placed one after the other -- lane l looks at slot l % 4 of the
+// (l / 4)-th bucket of the row's probe sequence, a ballot finds the first free one -- which is exactly the order of
+// bft_gh_build_group (the host restatement: arrays bit-identical), at LDS latency instead of a dependent chain of global loads per
+// row (one thread per group took 3.5 ms on the 3x10^5 groups of config 3).  stats[0] += groups, stats[1] += groups left unhashed.
+__global__ void k_gh_flags(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ pref_cnt,
+                           const uint32_t* __restrict__ pend, uint32_t P, uint32_t* __restrict__ flag) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x)
+        flag[q] = ((uint32_t)(skey[q] & 0x1FFFFu) != 0 && !pend[q] && bft_gh_group(pref_cnt[sp[q]])) ? 1u : 0u;  // UC prefixes and child nodes own no group
+}
+__global__ void k_gh_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ sp,
+                          const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, uint32_t P, uint2* __restrict__ list) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x)
+        if (flag[q]) list[pos[q]] = make_uint2(pref_row[sp[q]], pref_cnt[sp[q]]);
+}
+#define GH_WAVES 4  // wavefronts (groups in flight) per workgroup
 template <int W>
-__global__ void k_group_hash(const uint64_t* __restrict__ tk, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp,
-                             const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, const uint32_t* __restrict__ pend, uint32_t P,
-                             uint64_t* __restrict__ tkh, uint8_t* __restrict__ tkrank, unsigned long long* __restrict__ stats) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
-        if ((uint32_t)(skey[q] & 0x1FFFFu) == 0 || pend[q]) continue;  // UC prefixes and child nodes own no group
-        const uint32_t p = sp[q], cnt = pref_cnt[p];
-        if (!bft_gh_group(cnt)) continue;
-        atomicAdd(&stats[0], 1ull);
-        if (!bft_gh_build_group<W>(tk, tkh, tkrank, pref_row[p], cnt)) atomicAdd(&stats[1], 1ull);
+__global__ __launch_bounds__(64 * GH_WAVES) void k_group_hash(const uint64_t* __restrict__ tk, const uint2* __restrict__ list, uint32_t n_groups,
+                                                              uint64_t* __restrict__ tkh, uint8_t* __restrict__ tkrank, unsigned long long* __restrict__ stats) {
+    constexpr uint32_t MAXBK = 128;  // buckets of a group of <= 255 rows
+    __shared__ uint64_t s_slot[GH_WAVES][MAXBK * BFT_GH_SLOTS * W];
+    __shared__ uint8_t s_rank[GH_WAVES][MAXBK * BFT_GH_SLOTS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint64_t* slot = s_slot[wave];
+    uint8_t* rank = s_rank[wave];
+    for (uint32_t g = blockIdx.x * GH_WAVES + wave; g < n_groups; g += gridDim.x * GH_WAVES) {
+        // (wavefront-uniform values, told so: a loop bound the compiler takes for divergent turns every v_readlane below into a
+        // waterfall loop -- the first version of this kernel ran 6x slower for it)
+        const uint64_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[g].x);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[g].y);
+        uint64_t b0;
+        uint32_t nbk;
+        bft_gh_region(idx, cnt, &b0, &nbk);
+        const uint32_t nslots = nbk * BFT_GH_SLOTS;
+        for (uint32_t j = lane; j < nslots * W; j += 64) slot[j] = BFT_GH_EMPTY;
+        for (uint32_t j = lane; j < nslots; j += 64) rank[j] = 0;
+        bool gave_up = false;
+        for (uint32_t base = 0; base < cnt && !gave_up; base += 64) {
+            uint64_t t[W];
+            uint32_t home = 0;
+            if (base + lane < cnt) {
+#pragma unroll
+                for (int w = 0; w < W; w++) t[w] = tk[(idx + base + lane) * W + w];
+                home = bft_gh_home<W>(t, nbk);
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; w++) t[w] = 0;
+            }
+            const uint32_t m = min(64u, cnt - base);
+            for (uint32_t j = 0; j < m; j++) {  // j, m: scalar registers
+                uint64_t tj[W];
+#pragma unroll
+                for (int w = 0; w < W; w++)
+                    tj[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(t[w] >> 32), (int)j) << 32) |  // j is wavefront-uniform: v_readlane,
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t[w], (int)j);                   // not a trip through the LDS crossbar
+                const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)home, (int)j);
+                // lane l: slot l % 4 of the (l / 4)-th bucket of the probe sequence (BFT_GH_MAXD + 1 = 8 buckets at most, fewer in a small region)
+                const uint32_t d = lane / BFT_GH_SLOTS;
+                uint32_t b = hj + d;
+                if (b >= nbk) b -= nbk;
+                const uint32_t sidx = b * BFT_GH_SLOTS + lane % BFT_GH_SLOTS;
+                const bool active = d <= BFT_GH_MAXD && d < nbk;
+                const bool is_free = active && slot[(size_t)sidx * W] == BFT_GH_EMPTY;
+                const uint64_t fm = __ballot(is_free);
+                if (!fm) { gave_up = true; break; }
+                if (lane == (uint32_t)__builtin_ctzll(fm)) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) slot[(size_t)sidx * W + w] = tj[w];
+                    rank[sidx] = (uint8_t)(base + j);
+                }
+            }
+        }
+        if (gave_up) {  // the whole region says "unhashed": lookups fall back to the sorted table
+            for (uint32_t j = lane; j < nslots; j += 64) {
+                slot[(size_t)j * W] = BFT_GH_UNHASHED;
+#pragma unroll
+                for (int w = 1; w < W; w++) slot[(size_t)j * W + w] = BFT_GH_EMPTY;
+                rank[j] = 0;
+            }
+        }
+        uint64_t* out = tkh + b0 * BFT_GH_SLOTS * W;
+        for (uint32_t j = lane; j < nslots * W; j += 64) out[j] = slot[j];
+        uint8_t* orank = tkrank + b0 * BFT_GH_SLOTS;
+        for (uint32_t j = lane; j < nslots; j += 64) orank[j] = rank[j];
+        if (lane == 0) {
+            atomicAdd(&stats[0], 1ull);
+            if (gave_up) atomicAdd(&stats[1], 1ull);
+        }
     }
 }
 
@@ -631,9 +707,23 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                sg.child.as<uint64_t>(), next_lo.as<uint32_t>(), next_hi.as<uint32_t>());
             hipLaunchKernelGGL(k_ranks, G(C), cc_f2.as<uint32_t>(), cc_nwords.as<uint32_t>(), (uint32_t)C, sg.f2w.as<uint64_t>());
             // suffix groups of this depth (not the one-row leaves of a k % 9 == 0 index) -> hashed form
-            if (gh && !(last_level && rb == 0))
-                hipLaunchKernelGGL((k_group_hash<(W <= 2 ? W : 1)>), G(P), tk, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
-                                   pend.as<uint32_t>(), (uint32_t)P, out.tkh.as<uint64_t>(), out.tkrank.as<uint8_t>(), gh_stats.as<unsigned long long>());
+            if (gh && !(last_level && rb == 0)) {
+                DevBuf gflag, gpos, glist;
+                CK(gflag.alloc(P * 4));
+                CK(gpos.alloc(P * 4));
+                hipLaunchKernelGGL(k_gh_flags, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_cnt.as<uint32_t>(), pend.as<uint32_t>(), (uint32_t)P, gflag.as<uint32_t>());
+                uint64_t NG = 0;
+                CK(scan.run(gflag.as<uint32_t>(), gpos.as<uint32_t>(), P, &NG));
+                if (NG) {
+                    CK(glist.alloc(NG * sizeof(uint2)));
+                    hipLaunchKernelGGL(k_gh_list, G(P), gflag.as<uint32_t>(), gpos.as<uint32_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
+                                       (uint32_t)P, glist.as<uint2>());
+                    const dim3 ggrid((unsigned)std::min<uint64_t>((NG + GH_WAVES - 1) / GH_WAVES, 256ull * 8));
+                    hipLaunchKernelGGL((k_group_hash<(W <= 2 ? W : 1)>), ggrid, dim3(64 * GH_WAVES), 0, s, tk, glist.as<uint2>(), (uint32_t)NG, out.tkh.as<uint64_t>(),
+                                       out.tkrank.as<uint8_t>(), gh_stats.as<unsigned long long>());
+                    HIPCK(hipStreamSynchronize(s));  // (the list lives until the kernel is done)
+                }
+            }
         }
         if (UCR) hipLaunchKernelGGL(k_uc_rows, G(P), tk, W, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
                                     ucpos.as<uint32_t>(), (uint32_t)P, 0u, sg.uck.as<uint64_t>(), sg.ucrow.as<uint32_t>());

@@ -632,41 +632,55 @@ __global__ void k_root_ranges_check(const uint64_t* __restrict__ rdir, uint32_t*
     if (!(a & BFT_RSTART_SPECIAL) && !bft_root_range_ok(a, rs[r + 1], rdir[r])) rs[r] = a | BFT_RSTART_SPECIAL;  // (readers mask the flag)
 }
 
-// Node prefix hash: one thread per node below the root walks its CCs (filter2 bits -> clusters -> entries, as k_flat_fill does) and
-// claims a slot of the (node, prefix) bucket with atomicCAS; keys whose bucket is full are dropped (the lookup then takes the
-// container path).  stats: [0] inserted, [1] dropped, [2] nodes below the root that hold UC rows.
-__global__ void k_nph_fill(BftImage im, uint32_t n_nodes, uint64_t* __restrict__ tab, uint64_t mask, unsigned long long* __restrict__ stats) {
-    for (uint32_t m = 1 + blockIdx.x * blockDim.x + threadIdx.x; m < n_nodes; m += gridDim.x * blockDim.x) {
-        const BftNode nd = im.nodes[m];
-        if (nd.uc_n) atomicAdd(&stats[2], 1ull);
-        for (uint32_t c = 0; c < nd.ncc; c++) {
-            const BftCC cc = im.ccs[nd.cc_first + c];
-            const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
-            uint32_t clu = 0;
-            for (uint32_t w = 0; w < nw; w++) {
-                uint64_t bits = im.f2w[cc.f2_off + w] & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
-                while (bits) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(bits);
-                    bits &= bits - 1ull;
-                    const uint32_t pu = w * BFT_F2_BITS_PER_WORD + b;
-                    const uint64_t ce = im.clus[cc.clus_off + clu++];
-                    const uint32_t len = (ce & BFT_CLUS_MULTI) ? (uint32_t)((ce >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
-                    for (uint32_t j = 0; j < len; j++) {
-                        const uint64_t ent = (ce & BFT_CLUS_MULTI) ? im.child[cc.child_off + (uint32_t)ce + j] : ce;
-                        const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
-                        const uint64_t key = bft_nph_key(m, r);
-                        unsigned long long* bk = (unsigned long long*)(tab + bft_nph_bucket(key, mask) * (2 * BFT_NPH_SLOTS));
-                        bool placed = false;
-                        for (int s = 0; s < BFT_NPH_SLOTS && !placed; s++)
-                            if (atomicCAS(&bk[2 * s], (unsigned long long)BFT_NPH_EMPTY, (unsigned long long)key) == BFT_NPH_EMPTY) {
-                                bk[2 * s + 1] = ent;
-                                placed = true;
-                            }
-                        atomicAdd(&stats[placed ? 0 : 1], 1ull);
-                    }
+// Node prefix hash.  k_nph_ccnode: the node of every CC (one thread per node).  k_nph_fill: one WAVEFRONT per CC below the root,
+// one lane per filter2 word (48 bits + the running rank of the bits before it, so a word knows its first cluster without
+// looking at the others): set bits -> clusters -> entries, each entry claims a slot of its (node, prefix) bucket with atomicCAS;
+// keys whose bucket is full are dropped (the lookup then takes the container path).  (One thread per node -- a few thousand
+// threads, each a chain of ~10^3 dependent loads -- took 16 ms on config 3.)
+// stats: [0] inserted, [1] dropped, [2] nodes below the root that hold UC rows.
+__global__ void k_nph_ccnode(const BftNode* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ cc_node, unsigned long long* __restrict__ stats) {
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < n_nodes; m += gridDim.x * blockDim.x) {
+        const BftNode nd = nodes[m];
+        if (m > 0 && nd.uc_n) atomicAdd(&stats[2], 1ull);
+        for (uint32_t c = 0; c < nd.ncc; c++) cc_node[nd.cc_first + c] = m;
+    }
+}
+__global__ __launch_bounds__(256) void k_nph_fill(BftImage im, const uint32_t* __restrict__ cc_node, uint32_t first_cc, uint32_t n_ccs, uint64_t* __restrict__ tab,
+                                                  uint64_t mask, unsigned long long* __restrict__ stats) {
+    const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
+    for (uint32_t c = first_cc + blockIdx.x * wpb + (threadIdx.x >> 6); c < n_ccs; c += gridDim.x * wpb) {
+        const BftCC cc = im.ccs[c];
+        const uint32_t m = cc_node[c];
+        const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
+        uint32_t placed_n = 0, dropped_n = 0;
+        for (uint32_t w = lane; w < nw; w += 64) {
+            const uint64_t fw = im.f2w[cc.f2_off + w];
+            uint64_t bits = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+            uint32_t clu = (uint32_t)(fw >> BFT_F2_BITS_PER_WORD);  // clusters before this word
+            while (bits) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+                bits &= bits - 1ull;
+                const uint32_t pu = w * BFT_F2_BITS_PER_WORD + b;
+                const uint64_t ce = im.clus[cc.clus_off + clu++];
+                const uint32_t len = (ce & BFT_CLUS_MULTI) ? (uint32_t)((ce >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
+                for (uint32_t j = 0; j < len; j++) {
+                    const uint64_t ent = (ce & BFT_CLUS_MULTI) ? im.child[cc.child_off + (uint32_t)ce + j] : ce;
+                    const uint32_t r = (pu << cc.s) | ((uint32_t)(ent >> BFT_CHILD_PV_SHIFT) & 0xFFu);
+                    const uint64_t key = bft_nph_key(m, r);
+                    unsigned long long* bk = (unsigned long long*)(tab + bft_nph_bucket(key, mask) * (2 * BFT_NPH_SLOTS));
+                    bool placed = false;
+                    for (int s = 0; s < BFT_NPH_SLOTS && !placed; s++)
+                        if (atomicCAS(&bk[2 * s], (unsigned long long)BFT_NPH_EMPTY, (unsigned long long)key) == BFT_NPH_EMPTY) {
+                            bk[2 * s + 1] = ent;
+                            placed = true;
+                        }
+                    placed_n += placed;
+                    dropped_n += !placed;
                 }
             }
         }
+        if (placed_n) atomicAdd(&stats[0], (unsigned long long)placed_n);
+        if (dropped_n) atomicAdd(&stats[1], (unsigned long long)dropped_n);
     }
 }
 
@@ -696,8 +710,13 @@ static void derive_node_hash(bft_gpu* h) {
     if (h->d_nph.alloc(bytes) != 0 || stats.alloc_zero(24, h->stream) != 0) { h->d_nph.release(); return; }
     if (hipMemsetAsync(h->d_nph.p, 0xFF, bytes, h->stream) != hipSuccess) { h->d_nph.release(); return; }
     BftImage tmp = h->im;
-    hipLaunchKernelGGL(k_nph_fill, dim3(grid_for((n_nodes + 255) / 256)), dim3(256), 0, h->stream, tmp, (uint32_t)n_nodes, h->d_nph.as<uint64_t>(), nbk - 1,
+    const uint64_t n_ccs = h->idx_sizes[2] / sizeof(BftCC);
+    DevBuf cc_node;
+    if (cc_node.alloc(n_ccs * 4) != 0) { h->d_nph.release(); return; }
+    hipLaunchKernelGGL(k_nph_ccnode, dim3(grid_for((n_nodes + 255) / 256)), dim3(256), 0, h->stream, h->d_nodes.as<BftNode>(), (uint32_t)n_nodes, cc_node.as<uint32_t>(),
                        stats.as<unsigned long long>());
+    hipLaunchKernelGGL(k_nph_fill, dim3(grid_for((n_ccs + 3) / 4)), dim3(256), 0, h->stream, tmp, cc_node.as<uint32_t>(), h->root_ncc, (uint32_t)n_ccs,
+                       h->d_nph.as<uint64_t>(), nbk - 1, stats.as<unsigned long long>());
     unsigned long long st[3] = {0, 0, 0};
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(st, stats.p, 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -1001,6 +1020,7 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
 template <int W, bool STAGED>
 static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     if (h->opt_block == 1024) {
+        if (W <= 2 && h->im.tkh != nullptr) return launch_query_k<W <= 2 ? W : 1, 1024, STAGED, 3>(h, d_kmers, n, d_bits64, d_rows, s, rec);  // hashed groups: no block probes
         if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, 1024, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
         return launch_query_k<W, 1024, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
     }
@@ -1078,13 +1098,17 @@ static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
         HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, BK_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     const dim3 qgrid((unsigned)std::max<uint64_t>(8, std::min<uint64_t>((n + BK_BLOCK - 1) / BK_BLOCK, 256ull * wgs)));
     uint32_t* prow = d_rows ? h->bk_prow.as<uint32_t>() : nullptr;
     // suffix groups by one-load probes (bft_group_probe, PROBE 2): the bucket's slice of the table sits in the L2, where a probe
     // costs per load instruction, not per line missed
-    hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
+    if (W <= 2 && h->im.tkh != nullptr)
+        hipLaunchKernelGGL((k_query_bk8<W, STAGED, 3>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
+    else
+        hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
     if (d_rows)
         hipLaunchKernelGGL((k_unpermute<(int)TILE, true>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
                            bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);
@@ -1269,7 +1293,7 @@ static int tune_residency(bft_gpu* h) {
     return 0;
 }
 
-template <int W, bool STAGED>
+template <int W, bool STAGED, int PROBE>
 static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
     const int wgs = query_residency(h);  // eight walks per k-mer: the residency measured for k_query applies
     // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
@@ -1280,12 +1304,12 @@ static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, ui
     static std::atomic<uint64_t> attr_devs{0};
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        HIPCK(hipFuncSetAttribute((const void*)k_branching8<W, 1024, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_branching8<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    if (wgs == 1) hipLaunchKernelGGL((k_branching<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
-    else hipLaunchKernelGGL((k_branching8<W, 1024, STAGED>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    if (wgs == 1) hipLaunchKernelGGL((k_branching<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    else hipLaunchKernelGGL((k_branching8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1295,12 +1319,13 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-#define BR(WW) (staged ? launch_branching_k<WW, true>(h, d_kmers, n, d_bits64, d_counts, s) : launch_branching_k<WW, false>(h, d_kmers, n, d_bits64, d_counts, s))
+#define BR(WW, PP) (staged ? launch_branching_k<WW, true, PP>(h, d_kmers, n, d_bits64, d_counts, s) : launch_branching_k<WW, false, PP>(h, d_kmers, n, d_bits64, d_counts, s))
+    const bool hashed = h->im.tkh != nullptr;  // images with the hashed groups: kernels without the block-probe code (W <= 2)
     switch (h->W) {
-    case 1: CK(BR(1)); break;
-    case 2: CK(BR(2)); break;
-    case 3: CK(BR(3)); break;
-    default: CK(BR(4)); break;
+    case 1: CK(hashed ? BR(1, 3) : BR(1, 0)); break;
+    case 2: CK(hashed ? BR(2, 3) : BR(2, 0)); break;
+    case 3: CK(BR(3, 0)); break;
+    default: CK(BR(4, 0)); break;
     }
 #undef BR
     CK(timing_end(h, s, e0, e1));

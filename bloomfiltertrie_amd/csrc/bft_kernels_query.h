@@ -221,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // predecessors only in bits 0..1 of the first digit (n1 of the first prefix): one conversion per side, then four walks
 // that share every container down to the last cluster / suffix group (src/presenceNode.c:15-1211 exploits the same).
 // counts[i] = (successors << 4) | predecessors when requested; the bit = successors > 1 || predecessors > 1.
-template <int W, int BLOCK, bool STAGED>
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                                uint64_t* __restrict__ bits64, uint8_t* __restrict__ counts) {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -287,7 +287,7 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
                 dec = bft_fast4<W>(im, cand, &pres);
                 cl = __popc(pres & dec);
                 for (int v = 0; v < 4 && (counts || cl < 2); v++)
-                    if (!((dec >> v) & 1u)) cl += bft_walk<W, BftRootLds<STAGED>, 0>(im, acc, root, cand[v]).present;
+                    if (!((dec >> v) & 1u)) cl += bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, cand[v]).present;
             }
             branching = cr > 1 || cl > 1;
             if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
@@ -299,14 +299,15 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
 }
 
 // the two register budgets of k_query / k_query8 (see there)
-template <int W, int BLOCK, bool STAGED>
+// PROBE: 0 = block probes in the sorted table, 3 = images with the hashed groups (bft_group_search)
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                      uint8_t* __restrict__ counts) {
-    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
+    branching_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, counts);
 }
-template <int W, int BLOCK, bool STAGED>
+template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_branching8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n,
                                                                                                  int B, uint64_t* __restrict__ bits64,
                                                                                                  uint8_t* __restrict__ counts) {
-    branching_body<W, BLOCK, STAGED>(im, packed, n, B, bits64, counts);
+    branching_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, counts);
 }

@@ -11,8 +11,13 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BFT_HD __host__ __device__ __forceinline__
+// (Tried: the rare paths -- sorted-table searches behind the hashed groups, node UC -- as real calls, __attribute__((noinline)).
+// The calling convention cost more scratch than the inlined arrays: 84-150 spilled VGPRs instead of 0-30.  PROBE 3 below removes
+// the block-probe code from the kernels that have the hashed groups instead.)
+#define BFT_HD_RARE __host__ __device__ __forceinline__
 #else
 #define BFT_HD inline
+#define BFT_HD_RARE inline
 #endif
 
 // Suffix groups of at least this many rows are searched with aligned block probes (bft_group_probe), smaller ones by
@@ -211,7 +216,7 @@ BFT_HD uint32_t bft_rows_lower_bound(const uint64_t* rows, uint32_t n, const uin
 // binary_search_UC + memcmp (src/UC.c:81-124, src/presenceNode.c:1886-1913), ~1-2 cache lines instead
 // of ~log2(n).  Returns the row index or -1.
 template <int W>
-BFT_HD int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, uint32_t g) {
+BFT_HD_RARE int bft_rows_find(const uint64_t* rows, uint32_t n, const uint64_t* t, uint32_t g) {
     uint64_t r[W];
     if (g >= n) g = n - 1;
     uint32_t lo = 0, hi = n;
@@ -388,7 +393,7 @@ BFT_HD bool bft_gh_lookup(const BftImage& im, uint64_t idx, uint32_t cnt, const 
 
 // The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
 template <int W>
-BFT_HD void bft_uc_search(const BftImage& im, const BftNode& nd, const uint64_t* t, BftHit& hit) {
+BFT_HD_RARE void bft_uc_search(const BftImage& im, const BftNode& nd, const uint64_t* t, BftHit& hit) {
     if (!nd.uc_n) return;
     const uint64_t* rows = im.uck + (size_t)nd.uc_first * W;
     const uint32_t z = bft_rows_lower_bound<W>(rows, nd.uc_n, t);
@@ -599,7 +604,7 @@ BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, const uint64_t* 
 // the mode of the bucketed kernel, whose table slice sits in the L2 -- there a probe costs per load instruction, not per
 // cache line missed, so wide blocks lose (measured: 8-row blocks 5.4 ms) and interpolation converges in 2-3 loads.
 template <int W, int PROBE>
-BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
+BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
     uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
     int dir = 0;
     const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
@@ -630,6 +635,19 @@ BFT_HD void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint
 template <int W, int PROBE>
 BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit) {
     if (W <= 2 && im.tkh != nullptr && bft_gh_group(cnt) && bft_gh_lookup<W>(im, idx, cnt, t, hit)) return;
+    if (PROBE == 3) {
+        // kernels launched on an image WITH the hashed groups: what is left for the sorted table are groups of fewer than 8 rows
+        // (<= 3 steps), the 0.02 % unhashed groups and remainder groups beyond 255 rows -- a plain binary search, and none of the
+        // block-probe code (its row arrays cost the 64-VGPR kernels their registers: 28-30 spilled VGPRs on two-word rows)
+        const uint64_t* rows = im.tk + idx * W;
+        const uint32_t z = bft_rows_lower_bound<W>(rows, cnt, t);
+        if (z < cnt) {
+            uint64_t q[W];
+            bft_load_row<W>(rows + (size_t)z * W, q);
+            if (bft_cmp<W>(q, t) == 0) { hit.present = 1; hit.row = idx + z; }
+        }
+        return;
+    }
     const uint64_t next36 = bft_next36<W>(t, im.k, d);
     const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
