@@ -1082,8 +1082,8 @@ static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
     CK(need(h->bk_tmp, tb));
     h->bk_used = true;
     h->bk_stream = s;
-    const int wgs = 2;
-    const dim3 pgrid((unsigned)std::min<uint64_t>(ntiles64, 256ull * wgs)), blk(BK_BLOCK);
+    const int wgs = h->opt_wgs_per_cu == 1 ? 1 : 2;  // the walk: two workgroups per CU (64-VGPR build) unless "query_wgs_per_cu" says one
+    const dim3 pgrid((unsigned)std::min<uint64_t>(ntiles64, 256ull * 2)), blk(BK_BLOCK);
     hipLaunchKernelGGL(k_bucket_hist<W>, pgrid, blk, 0, s, d_kmers, n, rec, bits, ntiles, h->bk_hist.as<uint32_t>());
     hipLaunchKernelGGL(k_bucket_rowsum, dim3(nb), blk, 0, s, h->bk_hist.as<uint32_t>(), ntiles, h->bk_tmp.as<uint32_t>());
     hipLaunchKernelGGL(k_bucket_plan, dim3(1), blk, 0, s, h->bk_tmp.as<uint32_t>(), bits, h->bk_plan.as<BkPlan>());
@@ -1099,16 +1099,21 @@ static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
         HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, BK_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query_bk<W, STAGED, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     const dim3 qgrid((unsigned)std::max<uint64_t>(8, std::min<uint64_t>((n + BK_BLOCK - 1) / BK_BLOCK, 256ull * wgs)));
     uint32_t* prow = d_rows ? h->bk_prow.as<uint32_t>() : nullptr;
     // suffix groups by one-load probes (bft_group_probe, PROBE 2): the bucket's slice of the table sits in the L2, where a probe
     // costs per load instruction, not per line missed
-    if (W <= 2 && h->im.tkh != nullptr)
-        hipLaunchKernelGGL((k_query_bk8<W, STAGED, 3>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
+    const dim3 wblk(BK_WALK_BLOCK);
+    if (W <= 2 && h->im.tkh != nullptr && wgs == 1)
+        hipLaunchKernelGGL((k_query_bk<W, STAGED, 3>), qgrid, blk, std::max<size_t>(lds, 84u << 10), s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(),
+                           h->bk_pbits.as<uint64_t>(), prow);
+    else if (W <= 2 && h->im.tkh != nullptr)
+        hipLaunchKernelGGL((k_query_bk8<W, STAGED, 3>), qgrid, wblk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
     else
-        hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, blk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
+        hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, wblk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
     if (d_rows)
         hipLaunchKernelGGL((k_unpermute<(int)TILE, true>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
                            bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);

@@ -266,13 +266,13 @@ __device__ __forceinline__ void query_bk_body(const BftImage& im, const uint64_t
     {
         const uint4* g = (const uint4*)im.hashmod;
         uint4* l = (uint4*)l_hm;
-        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BK_BLOCK) l[i] = g[i];
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += blockDim.x) l[i] = g[i];
         if (STAGED) {
             const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
             uint64_t* lb = (uint64_t*)l_bf;
             const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
-            for (uint32_t i = threadIdx.x; i < nb8; i += BK_BLOCK) lb[i] = gb[i];
-            for (uint32_t i = threadIdx.x; i < root.ncc; i += BK_BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
+            for (uint32_t i = threadIdx.x; i < nb8; i += blockDim.x) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += blockDim.x) l_cc[i] = im.ccx[root.cc_first + i];
         }
     }
     __syncthreads();
@@ -315,8 +315,12 @@ __global__ __launch_bounds__(BK_BLOCK) void k_query_bk(BftImage im, const uint64
                                                        uint32_t* __restrict__ prow) {
     query_bk_body<W, STAGED, PROBE>(im, trec, plan, pbits, prow);
 }
+// k_query_bk8: two 768-thread workgroups per CU = 6 wavefronts per SIMD, 84 VGPRs each: with 1024 threads and the 64 VGPRs of 8
+// per SIMD the walk spills two registers inside the chunk loop once the node prefix hash is part of it.  The wavefronts claim
+// their chunks on their own, so the workgroup size is free.
+#define BK_WALK_BLOCK 768
 template <int W, bool STAGED, int PROBE>
-__global__ __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query_bk8(BftImage im, const uint64_t* __restrict__ trec,
+__global__ __launch_bounds__(BK_WALK_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query_bk8(BftImage im, const uint64_t* __restrict__ trec,
                                                                                                    BkPlan* __restrict__ plan, uint64_t* __restrict__ pbits,
                                                                                                    uint32_t* __restrict__ prow) {
     query_bk_body<W, STAGED, PROBE>(im, trec, plan, pbits, prow);

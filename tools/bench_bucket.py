@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--root-direct", default="1", help="comma list of 0/1: root level through the derived direct table")
+    ap.add_argument("--wgs", default="0", help="comma list of query_wgs_per_cu settings (0 = automatic)")
     ap.add_argument("--group-hash", default="1", help="comma list of 0/1: suffix groups through their hashed form")
     args = ap.parse_args()
     import torch
@@ -39,7 +40,9 @@ def main():
         truth = W.member(allk, qk)
         dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
         info = t.info()
-        for gh, rd, bits in [(int(g_), int(r), int(x)) for g_ in args.group_hash.split(",") for r in args.root_direct.split(",") for x in args.bits.split(",")]:
+        for wg, gh, rd, bits in [(int(w_), int(g_), int(r), int(x)) for w_ in args.wgs.split(",") for g_ in args.group_hash.split(",") for r in args.root_direct.split(",")
+                                 for x in args.bits.split(",")]:
+            t.set_option("query_wgs_per_cu", wg)
             t.set_option("group_hash", gh)
             t.set_option("root_direct", rd)
             t.set_option("query_bucket_bits", bits)
@@ -56,7 +59,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
             kms, kn = t.kernel_time(reset=True)
-            print(json.dumps({"workload": wl, "k": k, "bucket_bits": bits, "root_direct": rd, "group_hash": gh, "hashed_groups": t.build_time()["hashed_groups"], "unhashed_groups": t.build_time()["unhashed_groups"], "ms": round(ms, 3), "ms_events_in_lib": round(kms / max(1, kn), 3), "G_kmers_per_s": round(nq / ms / 1e6, 2),
+            print(json.dumps({"workload": wl, "k": k, "bucket_bits": bits, "wgs": wg, "root_direct": rd, "group_hash": gh, "hashed_groups": t.build_time()["hashed_groups"], "unhashed_groups": t.build_time()["unhashed_groups"], "ms": round(ms, 3), "ms_events_in_lib": round(kms / max(1, kn), 3), "G_kmers_per_s": round(nq / ms / 1e6, 2),
                               "all_answers_ok": ok, "image_bytes": info["image_bytes"], "kmers": info["kmers"], "queries": nq}), flush=True)
         t.close()
         del dq, qk, truth, dbits, allk
