@@ -228,11 +228,11 @@ class BFT:
         return ms.value, n.value
 
     def build_time(self):
-        out = (C.c_double * 19)()
-        _lib.check(self._lib.bft_gpu_build_time(self._h, out, 19))
+        out = (C.c_double * 20)()
+        _lib.check(self._lib.bft_gpu_build_time(self._h, out, 20))
         return dict(zip(["gpu_sort_dedupe_ms", "color_intern_ms", "assemble_ms", "bookkeeping_ms", "derive_and_tune_ms",
                          "query_wgs_per_cu", "tune_1wg_ms", "tune_2wg_ms", "query_probe_rows", "query_bucket_bits", "bucket_tune_plain_ms",
-                         "bucket_tune_bucketed_ms", "hashed_groups", "unhashed_groups", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped"], list(out)))
+                         "bucket_tune_bucketed_ms", "hashed_groups", "unhashed_groups", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms"], list(out)))
 
     def debug_array(self, name, dtype=np.uint8):
         n = C.c_uint64()

@@ -240,12 +240,11 @@ struct bft_gpu {
     bool ext_pending = false;
     uint32_t root_ncc = 0;
     uint64_t idx_sizes[9] = {0};
-    int opt_block = 1024;     // k_query workgroup size (256 / 512 / 768 / 1024)
-    int opt_wgs_per_cu = 0;   // resident k_query workgroups per CU: 1, 2, or 0 = measured when the image is bound (tune_residency)
+    int opt_wgs_per_cu = 0;   // k_query residency: 1 / 2 workgroups of 1024 threads per CU, 3 = two of 768, 0 = measured when the image is bound (tune_residency)
     int tuned_wgs = 0;        // result of that measurement (0 = none yet)
     int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big), 0 = measured with the residency
     int tuned_probe = 0;
-    double tune_ms[2] = {0, 0};
+    double tune_ms[3] = {0, 0, 0};  // best time of the tuning batch per residency 1 / 2 / 3
     int opt_grid_mult = 1;    // grid = resident workgroups x this
     // prefix-bucketed batches (bft_kernels_bucket.h): scratch grown on demand, reused across calls
     int opt_bucket_bits = -1;   // "query_bucket_bits": -1 = measured on the first large batch, 0 = off, 4..10 = on with that many bits
@@ -992,41 +991,40 @@ static int query_residency(const bft_gpu* h) {
     return h->tuned_wgs ? h->tuned_wgs : 2;
 }
 
-template <int W, int BLOCK, bool STAGED, int PROBE>
+template <int W, bool STAGED, int PROBE>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
     // one workgroup per CU the request is padded past half the LDS so that the dispatcher cannot pair two on a CU.
-    const int wgs = query_residency(h);
+    const int res = query_residency(h);  // 1: one 1024-thread workgroup per CU, 2: two (8 wavefronts per SIMD), 3: two of 768 threads (6 per SIMD)
+    const int wgs = res == 1 ? 1 : 2;
+    const uint32_t block = res == 3 ? BFT_BLOCK6 : 1024;
     // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
     size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
-    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
+    const uint64_t nblk = (n + block - 1) / block;
     const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
     static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_query<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        HIPCK(hipFuncSetAttribute((const void*)k_query8<W, BLOCK, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query8<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_query6<W, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     // rec: bytes per input record (B, or 8W for the zero-padded word records of the sequence path); load_x reads that many
-    if (wgs == 1) hipLaunchKernelGGL((k_query<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
-    else hipLaunchKernelGGL((k_query8<W, BLOCK, STAGED, PROBE>), grid, dim3(BLOCK), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
+    if (res == 1) hipLaunchKernelGGL((k_query<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
+    else if (res == 3) hipLaunchKernelGGL((k_query6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
+    else hipLaunchKernelGGL((k_query8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
     HIPCK(hipGetLastError());
     return 0;
 }
 
 template <int W, bool STAGED>
 static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
-    if (h->opt_block == 1024) {
-        if (W <= 2 && h->im.tkh != nullptr) return launch_query_k<W <= 2 ? W : 1, 1024, STAGED, 3>(h, d_kmers, n, d_bits64, d_rows, s, rec);  // hashed groups: no block probes
-        if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, 1024, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
-        return launch_query_k<W, 1024, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
-    }
-    if (h->opt_block == 768) return launch_query_k<W, 768, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
-    if (h->opt_block == 512) return launch_query_k<W, 512, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
-    return launch_query_k<W, 256, STAGED, -1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (W <= 2 && h->im.tkh != nullptr) return launch_query_k<W <= 2 ? W : 1, STAGED, 3>(h, d_kmers, n, d_bits64, d_rows, s, rec);  // hashed groups: no block probes
+    if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    return launch_query_k<W, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
 template <int W>
@@ -1241,14 +1239,18 @@ static int tune_residency(bft_gpu* h) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
-    // (workgroups per CU) x (probe block): 1/4, 2/4, 1/8, 2/8; options fixed by the caller are not varied
-    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-    for (int cfg = 0; cfg < 4 && rc == 0; cfg++) {
-        const int wgs = 1 + (cfg & 1), probe = (cfg & 2) ? 8 : 4;
-        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W > BFT_PROBE_MAX_W && probe == 8)) continue;
+    // (residency 1 / 2 / 3) x (probe block 4 / 8 rows); options fixed by the caller are not varied, and an image with the hashed
+    // groups has no block probes to choose between (W <= 2: the PROBE 3 kernels)
+    const bool no_probe_choice = (h->W <= 2 && h->im.tkh != nullptr) || h->W > BFT_PROBE_MAX_W;
+    float best[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    for (int cfg = 0; cfg < 6 && rc == 0; cfg++) {
+        const int wgs = 1 + cfg % 3, probe = cfg >= 3 ? 8 : 4;
+        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (no_probe_choice && !h->opt_probe && probe == 8) ||
+            (h->W > BFT_PROBE_MAX_W && probe == 8))
+            continue;
         h->tuned_wgs = wgs;
         h->im.probe_big = probe == 8;
-        for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second is timed
+        for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches, the faster of the next two counts
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
             if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
@@ -1257,15 +1259,24 @@ static int tune_residency(bft_gpu* h) {
             if (rep > 0 && ms < best[cfg]) best[cfg] = ms;
         }
     }
-    int win = 0;
-    for (int cfg = 1; cfg < 4; cfg++)
-        if (best[cfg] < best[win]) win = cfg;
+    // Residency 3 is the incumbent: on full batches and on the eight walks per k-mer of k_branching it is as fast as the better of
+    // the other two or 5-15 % faster (k = 36..63, config 5), and the 2^22-query tuning batch resolves differences of a few per
+    // cent poorly -- another arrangement has to win by more than 4 %.
+    int win = -1;
+    float win_score = 1e30f;
+    for (int cfg = 0; cfg < 6; cfg++) {
+        if (best[cfg] >= 1e29f) continue;
+        const float score = best[cfg] * (cfg % 3 == 2 ? 0.96f : 1.0f);
+        if (score < win_score) { win_score = score; win = cfg; }
+    }
+    if (win < 0) win = 1;
+    const int win_wgs = 1 + win % 3, win_probe = win >= 3 ? 8 : 4;
     // root level: range table + direct table, or the direct table alone ("root_direct" 3).  The range table halves the L2
     // footprint of the root level; its special prefixes (child Nodes) pay one more dependent load -- which side wins depends
     // on how many there are, so both are timed with the residency / probe mode just chosen.
     if (rc == 0 && h->opt_root_direct == 3 && h->rstart_ok) {
-        h->tuned_wgs = 1 + (win & 1);
-        h->im.probe_big = (h->opt_probe ? h->opt_probe == 8 : (win & 2) != 0);
+        h->tuned_wgs = win_wgs;
+        h->im.probe_big = (h->opt_probe ? h->opt_probe : win_probe) == 8;
         float rs[2] = {1e30f, 1e30f};
         for (int mode = 0; mode < 2 && rc == 0; mode++) {
             h->im.rstart = mode ? h->d_rstart.as<uint32_t>() : nullptr;
@@ -1290,30 +1301,33 @@ static int tune_residency(bft_gpu* h) {
     h->tuned_wgs = 0;
     h->im.probe_big = h->opt_probe == 8;
     CK(rc);
-    h->tune_ms[0] = std::min(best[0], best[2]) < 1e29f ? std::min(best[0], best[2]) : 0;
-    h->tune_ms[1] = std::min(best[1], best[3]) < 1e29f ? std::min(best[1], best[3]) : 0;
-    h->tuned_wgs = 1 + (win & 1);
-    h->tuned_probe = (win & 2) ? 8 : 4;
+    for (int r = 0; r < 3; r++) h->tune_ms[r] = std::min(best[r], best[r + 3]) < 1e29f ? std::min(best[r], best[r + 3]) : 0;
+    h->tuned_wgs = win_wgs;
+    h->tuned_probe = win_probe;
     h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
     return 0;
 }
 
 template <int W, bool STAGED, int PROBE>
 static int launch_branching_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
-    const int wgs = query_residency(h);  // eight walks per k-mer: the residency measured for k_query applies
+    const int res = query_residency(h);  // eight walks per k-mer: the residency measured for k_query applies
+    const int wgs = res == 1 ? 1 : 2;
+    const uint32_t block = res == 3 ? BFT_BLOCK6 : 1024;
     // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
     size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
-    const uint64_t nblk = (n + 1023) / 1024;
+    const uint64_t nblk = (n + block - 1) / block;
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * (uint64_t)wgs)));
     static std::atomic<uint64_t> attr_devs{0};
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
         HIPCK(hipFuncSetAttribute((const void*)k_branching<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         HIPCK(hipFuncSetAttribute((const void*)k_branching8<W, 1024, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_branching6<W, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
-    if (wgs == 1) hipLaunchKernelGGL((k_branching<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    if (res == 1) hipLaunchKernelGGL((k_branching<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+    else if (res == 3) hipLaunchKernelGGL((k_branching6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
     else hipLaunchKernelGGL((k_branching8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
     HIPCK(hipGetLastError());
     return 0;
@@ -1512,13 +1526,19 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
         hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, n, d_rowidx);  // row -> colour set, in place
         // tiles of ~32 KiB of output (a multiple of 4 k-mers: tiles start dword aligned); magic number of the division by rowbytes
         // (round-up method, exact on u32)
-        const uint32_t tile_rows = std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(4u, ((32768u / rowbytes) + 3u) & ~3u));
+        // (16-byte rows and up, 16-byte aligned output: the 16-bytes-per-lane kernel, whose tiles are a multiple of 16 k-mers)
+        const bool wide16 = rowbytes >= 16 && ((uintptr_t)d_out & 15u) == 0;
+        const uint32_t tile_rows = wide16 ? std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(16u, ((32768u / rowbytes) + 15u) & ~15u))
+                                          : std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(4u, ((32768u / rowbytes) + 3u) & ~3u));
         uint32_t div_l = 0;
         while ((1ull << div_l) < rowbytes) div_l++;
         const uint32_t div_m = div_l ? (uint32_t)(((1ull << 32) * ((1ull << div_l) - rowbytes)) / rowbytes + 1ull) : 0u;
         const uint64_t tiles = (n + tile_rows - 1) / tile_rows;
         const dim3 cgrid((unsigned)std::min<uint64_t>(tiles, 256ull * 8));
-        if (rowbytes >= 4)
+        if (wide16)
+            hipLaunchKernelGGL(k_color_rows_bm16, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+                               div_l, d_out);
+        else if (rowbytes >= 4)
             hipLaunchKernelGGL(k_color_rows_bm<true>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
                                div_l, d_out);
         else
@@ -1883,11 +1903,8 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
 extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     const std::string nm(name);
-    if (nm == "query_block") {
-        if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(BFT_GPU_E_ARG, "query_block must be 256, 512, 768 or 1024");
-        h->opt_block = (int)value;
-    } else if (nm == "query_wgs_per_cu") {
-        if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1 or 2");
+    if (nm == "query_wgs_per_cu") {
+        if (value < 0 || value > 3) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1, 2 or 3");
         h->opt_wgs_per_cu = (int)value;
     } else if (nm == "reserve_pairs") {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
@@ -1981,12 +1998,12 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[19] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+    const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
                           h->im.probe_big ? 8.0 : 4.0, (double)(h->opt_bucket_bits >= 0 ? h->opt_bucket_bits : h->tuned_bucket_bits), h->bucket_tune_ms[0],
                           h->bucket_tune_ms[1], (double)h->n_gh_groups, (double)h->n_gh_unhashed,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
-                          (double)h->nph_inserted, (double)h->nph_dropped};
-    for (int i = 0; i < n_out && i < 19; i++) ms[i] = v[i];
+                          (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
+    for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

@@ -154,6 +154,85 @@ __global__ __launch_bounds__(256) void k_color_rows_bm(const uint32_t* __restric
     }
 }
 
+// The same rows, 16 output bytes per lane (rowbytes >= 16, `out` 16-byte aligned, tile_rows a multiple of 16: tiles start 16-byte
+// aligned): a quarter of the address arithmetic per byte and 16-byte stores.  The chunk starts at byte b of k-mer q's row: five
+// source dwords (one 16-byte + one 4-byte load at 4-byte alignment) and four funnel shifts; a chunk that straddles into the next
+// k-mer's row (one in rowbytes / 16) takes that row's first 16 bytes and a 128-bit byte shift -- selects and 64-bit shifts,
+// executed by every lane: no branch.
+#define CR16_UNROLL 4
+__global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restrict__ csid, const uint8_t* __restrict__ bm, uint32_t stride, uint64_t n,
+                                                         uint32_t rowbytes, uint32_t tile_rows, uint32_t div_m, uint32_t div_l, uint8_t* __restrict__ out) {
+    __shared__ uint32_t s_cs[CR_MAX_TILE_ROWS + 1];  // dictionary row (dword offset) of each k-mer of the tile (BFT_ABSENT_ROW: absent)
+    struct __attribute__((packed, aligned(4))) Quad { uint32_t a, b, c, d; };
+    const uint64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const uint32_t* bmw = (const uint32_t*)bm;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * tile_rows;
+        const uint32_t nt = (uint32_t)min((uint64_t)tile_rows, n - q0);
+        for (uint32_t j = threadIdx.x; j <= nt; j += blockDim.x) {
+            const uint32_t c = j < nt ? csid[q0 + j] : BFT_ABSENT_ROW;
+            s_cs[j] = c != BFT_ABSENT_ROW ? c * (stride >> 2) : c;
+        }
+        __syncthreads();
+        const uint32_t total = nt * rowbytes, nch = (total + 15u) / 16u;
+        uint8_t* tout = out + q0 * rowbytes;
+        for (uint32_t i0 = threadIdx.x; i0 < nch; i0 += blockDim.x * CR16_UNROLL) {
+            uint32_t take[CR16_UNROLL], sh[CR16_UNROLL], c0[CR16_UNROLL], s4[CR16_UNROLL];
+            Quad sq[CR16_UNROLL], nx[CR16_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CR16_UNROLL; u++) {
+                const uint32_t i = min(i0 + (uint32_t)u * blockDim.x, nch - 1u), byte = i * 16u;
+                const uint32_t t = __umulhi(byte, div_m);
+                const uint32_t q = (t + ((byte - t) >> 1)) >> (div_l - 1u);  // rowbytes >= 16: div_l >= 4
+                const uint32_t b = byte - q * rowbytes;
+                take[u] = rowbytes - b;  // bytes of the chunk that belong to k-mer q (>= 16: all of it)
+                sh[u] = 8u * (b & 3u);
+                c0[u] = s_cs[q];
+                const uint32_t c1 = take[u] < 16u ? s_cs[q + 1] : BFT_ABSENT_ROW;
+                const uint32_t* src = bmw + (c0[u] != BFT_ABSENT_ROW ? c0[u] : 0u) + (b >> 2);
+                sq[u] = *reinterpret_cast<const Quad*>(src);  // (the dictionary carries slack behind its last row)
+                s4[u] = src[4];
+                if (c1 != BFT_ABSENT_ROW) nx[u] = *reinterpret_cast<const Quad*>(bmw + c1);
+                else nx[u] = Quad{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < CR16_UNROLL; u++) {
+                const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                if (i >= nch) continue;
+                const uint32_t byte = i * 16u;
+                // the chunk out of k-mer q's row: 128 bits from bit sh of the five source dwords
+                uint32_t v0 = __funnelshift_r(sq[u].a, sq[u].b, sh[u]), v1 = __funnelshift_r(sq[u].b, sq[u].c, sh[u]);
+                uint32_t v2 = __funnelshift_r(sq[u].c, sq[u].d, sh[u]), v3 = __funnelshift_r(sq[u].d, s4[u], sh[u]);
+                if (c0[u] == BFT_ABSENT_ROW) v0 = v1 = v2 = v3 = 0u;
+                const uint32_t tk = min(take[u], 16u);
+                // the next row's first bytes moved up by tk bytes: whole dwords by selects, the rest by 64-bit shifts
+                const uint32_t d = tk >> 2, r = 8u * (tk & 3u);
+                uint32_t y0 = nx[u].a, y1 = nx[u].b, y2 = nx[u].c, y3 = nx[u].d;
+                if (d & 1u) { y3 = y2; y2 = y1; y1 = y0; y0 = 0u; }
+                if (d & 2u) { y3 = y1; y2 = y0; y1 = 0u; y0 = 0u; }
+                if (d & 4u) { y3 = y2 = y1 = y0 = 0u; }
+                const uint32_t z3 = (uint32_t)((((uint64_t)y3 << 32) | y2) >> (32u - r)), z2 = (uint32_t)((((uint64_t)y2 << 32) | y1) >> (32u - r));
+                const uint32_t z1 = (uint32_t)((((uint64_t)y1 << 32) | y0) >> (32u - r)), z0 = y0 << r;
+                // bytes [0, tk) from this row, [tk, 16) from the next: per-dword masks
+                const uint64_t keep_lo = tk >= 8u ? ~0ull : (1ull << (8u * tk)) - 1ull;                  // bytes 0..7
+                const uint64_t keep_hi = tk >= 16u ? ~0ull : (tk <= 8u ? 0ull : (1ull << (8u * (tk - 8u))) - 1ull);  // bytes 8..15
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 o;
+                o.x = (v0 & (uint32_t)keep_lo) | z0;
+                o.y = (v1 & (uint32_t)(keep_lo >> 32)) | z1;
+                o.z = (v2 & (uint32_t)keep_hi) | z2;
+                o.w = (v3 & (uint32_t)(keep_hi >> 32)) | z3;
+                if (byte + 16u <= total) __builtin_nontemporal_store(o, (u32x4*)(tout + byte));
+                else {
+                    const uint32_t w[4] = {o.x, o.y, o.z, o.w};  // the last chunk of the whole batch
+                    for (uint32_t x = 0; byte + x < total; x++) tout[byte + x] = (uint8_t)(w[x >> 2] >> (8u * (x & 3u)));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // colour-set id of every located k-mer (BFT_ABSENT_ROW stays BFT_ABSENT_ROW)
 __global__ void k_row_colorsets(const uint32_t* rows, const uint32_t* __restrict__ tcol, uint64_t n, uint32_t* out) {  // out may be rows (in place)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {

@@ -214,6 +214,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                                                              uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
     query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
 }
+// k_query6: the arrangement in between -- two 768-thread workgroups per CU, 6 wavefronts per SIMD with 84 VGPRs each.  The walk
+// of the two-word rows (k = 36..63) needs 73-81 VGPRs: k_query8 spills 20-40 of them, k_query runs 4 wavefronts per SIMD.
+#define BFT_BLOCK6 768
+template <int W, bool STAGED, int PROBE>
+__global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                                                                 uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+    query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+}
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):
 // successors of a k-mer = present k-mers kmer[1..k-1]+N, predecessors = present k-mers N+kmer[0..k-2], N in ACGT.
@@ -298,7 +306,7 @@ __device__ __forceinline__ void branching_body(const BftImage& im, const uint8_t
     }
 }
 
-// the two register budgets of k_query / k_query8 (see there)
+// the three register budgets of k_query / k_query8 / k_query6 (see there)
 // PROBE: 0 = block probes in the sorted table, 3 = images with the hashed groups (bft_group_search)
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) void k_branching(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
@@ -310,4 +318,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                                                                  int B, uint64_t* __restrict__ bits64,
                                                                                                  uint8_t* __restrict__ counts) {
     branching_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, counts);
+}
+template <int W, bool STAGED, int PROBE>
+__global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_branching6(BftImage im, const uint8_t* __restrict__ packed, uint64_t n,
+                                                                                                     int B, uint64_t* __restrict__ bits64,
+                                                                                                     uint8_t* __restrict__ counts) {
+    branching_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, counts);
 }

@@ -130,8 +130,9 @@ int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_km
  * [12]=image bytes in HBM, [13]=root CCs, [14]=root UC rows, [15]=pending (unbuilt) pairs. */
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 
-/* Tuning knobs: "query_block" (k_query workgroup size: 256, 512, 768 or 1024), "query_wgs_per_cu" (resident workgroups
- * per CU: 1, 2, 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
+/* Tuning knobs: "query_wgs_per_cu" (how k_query sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per SIMD
+ * with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each -- the two-word rows of k = 36..63 fit that budget and not the one
+ * of 2; 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
  * (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into one
  * hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte
@@ -159,7 +160,7 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
  * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing,
  * ms[12]=suffix groups that own a hashed form, ms[13]=of which left unhashed (searched in the sorted table), ms[14]=root tables in use (0 / 1 / 2, see "root_direct"),
  * ms[15..16]=time of the tuning batch with the direct table alone / with the range table, ms[17]=keys in the node prefix hash, ms[18]=keys it dropped (full bucket:
- * those lookups take the container path). */
+ * those lookups take the container path), ms[19]=time of the tuning batch with residency 3 (ms[5] reports 1, 2 or 3). */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

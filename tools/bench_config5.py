@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--snp-rate", type=float, default=0.01)
     ap.add_argument("--queries", type=int, default=10_000_000)
     ap.add_argument("--check", type=int, default=3000)
+    ap.add_argument("--residencies", action="store_true", help="also time branching / presence under each query_wgs_per_cu setting")
     args = ap.parse_args()
     import torch
     from bloomfiltertrie_amd import BFT, synth as S
@@ -69,6 +70,21 @@ def main():
         t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
     torch.cuda.synchronize()
     ms_p, n_p = t.kernel_time(reset=True)
+    per_res = {}
+    if args.residencies:
+        for r in (1, 2, 3):
+            t.set_option("query_wgs_per_cu", r)
+            for fn, name in ((lambda: L.check(lib.bft_gpu_query_branching_dev(t._h, dq.data_ptr(), nq, dbits.data_ptr(), None, stream)), "branching"),
+                             (lambda: t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream), "presence")):
+                fn()
+                torch.cuda.synchronize()
+                t.kernel_time(reset=True)
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                ms_r, n_r = t.kernel_time(reset=True)
+                per_res[f"{name}_ms_residency{r}"] = round(ms_r / n_r, 3)
+        t.set_option("query_wgs_per_cu", 0)
     # colour rows, device resident: presence + ceil(G/8)-byte bitmap row per k-mer
     rowbytes = (args.genomes + 7) // 8
     nqc = min(nq, 4_000_000)
@@ -124,6 +140,7 @@ def main():
         "colors_host_api": {"queries": ns, "ids_returned": int(len(ids)), "s": round(t_col, 3), "M_kmers_per_s": round(ns / t_col / 1e6, 3),
                             "rows_s": round(t_rows, 3), "rows_M_kmers_per_s": round(ns / t_rows / 1e6, 3)},
         "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
+        **per_res,
         "parity": {"colors_sample": bool(ok_col), "branching_sample": bool(ok_br), "sample": nc},
     }
     print(json.dumps(out))

@@ -46,7 +46,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, default=50_000_000)
     ap.add_argument("--workloads", default="cfg2,deep,deep2,k63")
-    ap.add_argument("--blocks", default="256,512,1024")
     ap.add_argument("--mults", default="1,2,4")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--wgs", default="0", help="comma list of query_wgs_per_cu settings (0 = automatic)")
@@ -85,8 +84,7 @@ def main():
         nv = 500_000
         truth = S.member(dq[:nv].cpu().numpy(), union)
         print(json.dumps({"workload": wl, "k": k, "build_s": round(time.time() - t0, 2), **{x: info[x] for x in ("kmers", "nodes", "ccs", "child_nodes", "uc_rows", "root_ccs", "image_bytes")}}), flush=True)
-        for nh, fm, blk, mult, wg, pr in [(n_, f, b, m, w, p) for n_ in [int(x) for x in args.node_hash.split(",")] for f in [int(x) for x in args.flat_mins.split(",")]
-                                          for b in [int(x) for x in args.blocks.split(",")]
+        for nh, fm, mult, wg, pr in [(n_, f, m, w, p) for n_ in [int(x) for x in args.node_hash.split(",")] for f in [int(x) for x in args.flat_mins.split(",")]
                                           for m in [int(x) for x in args.mults.split(",")] for w in [int(x) for x in args.wgs.split(",")]
                                           for p in [int(x) for x in args.probes.split(",")]]:
             if True:
@@ -94,7 +92,6 @@ def main():
                 t.set_option("query_probe", pr)
                 t.set_option("flat_min", fm)
                 t.set_option("query_wgs_per_cu", wg)
-                t.set_option("query_block", blk)
                 t.set_option("query_grid_mult", mult)
                 dbits.zero_()
                 t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
@@ -105,9 +102,8 @@ def main():
                     t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
                 torch.cuda.synchronize()
                 ms, n = t.kernel_time(reset=True)
-                print(json.dumps({"workload": wl, "node_hash": nh, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "block": blk, "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
+                print(json.dumps({"workload": wl, "node_hash": nh, "flat_min": fm, "image_bytes": t.info()["image_bytes"], "wgs_per_cu": wg, "probe": pr, "in_use": [int(t.build_time()["query_wgs_per_cu"]), int(t.build_time()["query_probe_rows"])], "grid_mult": mult, "ms": round(ms / n, 3), "Gq_s": round(nq / (ms / n) / 1e6, 2), "ok": ok}), flush=True)
         if args.stops:  # needs BFT_GPU_LIB=bloomfiltertrie_amd/csrc/libbft_gpu_probe.so (make -C bloomfiltertrie_amd/csrc probe)
-            t.set_option("query_block", 1024)
             t.set_option("query_grid_mult", 1)
             for stop in (1, 2, 3, 4, 0):
                 t.set_option("debug_stop", stop)
