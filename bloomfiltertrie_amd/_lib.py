@@ -34,6 +34,7 @@ SIGNATURES = {
     "bft_gpu_query_branching": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_query_branching_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P]),
     "bft_gpu_query_sequences": (C.c_int, [_P, C.c_char_p, _P, C.c_uint64, C.c_double, C.c_int, _P]),
+    "bft_gpu_query_sequences_dev": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_int, _P, _P]),
     "bft_gpu_load_bft": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     "bft_gpu_write_bft": (C.c_int, [_P, C.c_char_p]),
     "bft_gpu_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),

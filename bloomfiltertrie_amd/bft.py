@@ -213,6 +213,11 @@ class BFT:
         unp = np.unpackbits(rows, axis=1, bitorder="little")[:, :g] if g else np.zeros((len(enc), 0), np.uint8)
         return [np.flatnonzero(r).tolist() for r in unp]
 
+    def query_sequences_dev(self, d_seqs_ptr, d_seq_off_ptr, n_seqs, total_chars, threshold, d_rows_ptr, canonical=False, stream=None):
+        """Device-resident variant of query_sequences (raw pointers; rows of CEIL(genomes/8) bytes): asynchronous on `stream`."""
+        _lib.check(self._lib.bft_gpu_query_sequences_dev(self._h, d_seqs_ptr, d_seq_off_ptr, n_seqs, total_chars, float(threshold), int(canonical),
+                                                         d_rows_ptr, stream))
+
     def set_option(self, name, value):
         _lib.check(self._lib.bft_gpu_set_option(self._h, name.encode(), int(value)))
 

@@ -221,6 +221,8 @@ struct bft_gpu {
     uint64_t n_f18 = 0, n_fent = 0;
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
+    DevBuf d_tcolh;
+    bool tcolh_tried = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
@@ -251,6 +253,9 @@ struct bft_gpu {
     int tuned_bucket_bits = -1; // result of that measurement (-1 = none yet)
     double bucket_tune_ms[2] = {0, 0};  // plain / bucketed time of the tuning batch
     DevBuf bk_trec, bk_pos, bk_hist, bk_off, bk_pbits, bk_prow, bk_plan, bk_tmp;
+    DevBuf sq_codes, sq_bad, sq_npos, sq_poff, sq_tmp, sq_cs, sq_tile;  // scratch of the sequence queries (grown, never shrunk)
+    hipStream_t sq_stream = nullptr;
+    bool sq_used = false;
     hipStream_t bk_stream = nullptr;  // the stream that last used the scratch
     bool bk_used = false;
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
@@ -604,6 +609,9 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
     h->cs_bm_tried = false;
     h->d_cs_bm.release();
+    im.tcolh = nullptr;  // colour set per hashed slot: derived by the first sequence query (ensure_tcolh)
+    h->tcolh_tried = false;
+    h->d_tcolh.release();
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
     h->tuned_bucket_bits = -1;  // measured again on the first large batch of the new image
@@ -1592,6 +1600,131 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
 // query_sequence (src/bft.c:1241-1351) for a batch of ASCII sequences
+// Colour set per slot of the hashed groups (BftImage::tcolh): with it a found k-mer's colour set is ONE gather behind the bucket
+// (slot -> colour set) instead of two (slot -> rank -> row -> colour set).  Derived on the first sequence query of an image by
+// looking every stored k-mer up in the image itself; 8 bytes per k-mer, not part of the packed image (a replica derives its own).
+template <int W>
+__global__ void k_tcolh_fill(BftImage im, uint64_t n, uint32_t* __restrict__ tcolh) {
+    const BftNode root = im.nodes[0];
+    const BftRootGlobal acc(im);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t t[W];
+        bft_load_row<W>(im.tk + i * W, t);
+        const BftHit h = bft_walk<W, BftRootGlobal, 3>(im, acc, root, t);
+        if (h.present && h.gh_slot >= 0) tcolh[h.gh_slot] = im.tcol[i];
+    }
+}
+static int ensure_tcolh(bft_gpu* h) {
+    if (h->tcolh_tried) return 0;
+    h->tcolh_tried = true;
+    if (!h->im.tkh || h->W > 2 || h->n_kmers == 0) return 0;
+    CK(wait_foreign_stream(h));
+    CK(h->d_tcolh.alloc(2 * h->n_kmers * 4));
+    HIPCK(hipMemsetAsync(h->d_tcolh.p, 0xFF, 2 * h->n_kmers * 4, h->stream));
+    const dim3 grid(grid_for((h->n_kmers + 255) / 256)), block(256);
+    if (h->W == 1) hipLaunchKernelGGL(k_tcolh_fill<1>, grid, block, 0, h->stream, h->im, h->n_kmers, h->d_tcolh.as<uint32_t>());
+    else hipLaunchKernelGGL(k_tcolh_fill<2>, grid, block, 0, h->stream, h->im, h->n_kmers, h->d_tcolh.as<uint32_t>());
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));  // the sequence kernels may run on a caller's stream
+    h->im.tcolh = h->d_tcolh.as<uint32_t>();
+    return 0;
+}
+
+// Sequence queries on device-resident input.  Scratch (codes, plan, colour set per position) belongs to the handle and only grows; calls on
+// different streams take turns on it.  Nothing here waits for the GPU: the positions of a chunk are counted on the device
+// (k_seq_plan + scan) and the kernels read the total from there.
+template <int W, bool STAGED, int PROBE>
+static int launch_seq_walk_k(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
+    size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
+    static std::atomic<uint64_t> attr_devs{0};
+    const uint64_t dev_bit = 1ull << (h->device & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
+        HIPCK(hipFuncSetAttribute((const void*)k_seq_walk8<W, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        HIPCK(hipFuncSetAttribute((const void*)k_seq_walk6<W, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+        attr_devs.fetch_or(dev_bit, std::memory_order_release);
+    }
+    if (W != 2)
+        hipLaunchKernelGGL((k_seq_walk8<W, STAGED, PROBE>), dim3(512), dim3(1024), lds, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
+                           h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
+    else
+        hipLaunchKernelGGL((k_seq_walk6<W, STAGED, PROBE>), dim3(512), dim3(BFT_BLOCK6), lds, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
+                           h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+template <int W>
+static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
+    const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
+    constexpr int W12 = W <= 2 ? W : 1;
+    if (W <= 2 && h->im.tkh != nullptr)
+        return staged ? launch_seq_walk_k<W12, true, 3>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W12, false, 3>(h, ns, canonical, d_soff, s);
+    return staged ? launch_seq_walk_k<W, true, 0>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W, false, 0>(h, ns, canonical, d_soff, s);
+}
+
+static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* d_seq_off, uint64_t n_seqs, uint64_t total_chars, double threshold,
+                                int canonical, uint8_t* d_rows, hipStream_t s) {
+    const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
+    if (rowbytes == 0 || n_seqs == 0) return 0;
+    CK(ensure_tcolh(h));
+    if (h->sq_used && h->sq_stream != s) HIPCK(hipStreamSynchronize(h->sq_stream));
+    auto need = [&](DevBuf& b, size_t bytes) -> int {
+        if (b.bytes >= bytes) return 0;
+        if (h->sq_used) HIPCK(hipStreamSynchronize(s));  // the block being replaced may still be read by the previous call
+        return b.alloc(bytes + bytes / 8);
+    };
+    // sequences per chunk: 32-bit sequence numbers
+    const uint64_t chunk = 1ull << 30;
+    const uint64_t cmax = std::min(chunk, n_seqs);
+    const uint64_t n_cw = (total_chars + 31) / 32;  // code words of the blob (32 characters each)
+    size_t scan_bytes = 0;
+    HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(cmax + 1), s));
+    CK(need(h->sq_codes, (n_cw + BFT_MAX_W + 2) * 8));
+    CK(need(h->sq_bad, (n_cw + BFT_MAX_W + 2) * 4));
+    CK(need(h->sq_npos, (cmax + 1) * 8));
+    CK(need(h->sq_poff, (cmax + 1) * 8));
+    CK(need(h->sq_tmp, scan_bytes));
+    CK(need(h->sq_tile, (total_chars / 64 + 2) * 4));
+    CK(need(h->sq_cs, (total_chars + 64) * 4));  // colour set of every k-mer position of a chunk (positions <= characters)
+    h->sq_used = true;
+    h->sq_stream = s;
+    // (the slack words behind the codes are read by windows at the very end of the blob: keep them defined)
+    HIPCK(hipMemsetAsync(h->sq_codes.as<uint64_t>() + n_cw, 0, (BFT_MAX_W + 2) * 8, s));
+    HIPCK(hipMemsetAsync(h->sq_bad.as<uint32_t>() + n_cw, 0, (BFT_MAX_W + 2) * 4, s));
+    if (n_cw)
+        hipLaunchKernelGGL(k_seq_encode, dim3(grid_for((n_cw + 255) / 256)), dim3(256), 0, s, d_seqs, total_chars, n_cw, h->sq_codes.as<uint64_t>(),
+                           h->sq_bad.as<uint32_t>());
+    for (uint64_t a = 0; a < n_seqs; a += chunk) {
+        const uint64_t ns = std::min(chunk, n_seqs - a);
+        const uint64_t* soff = d_seq_off + a;
+        hipLaunchKernelGGL(k_seq_plan, dim3(grid_for((ns + 256) / 256)), dim3(256), 0, s, soff, ns, h->k, h->sq_npos.as<uint64_t>());
+        size_t tb = h->sq_tmp.bytes;
+        HIPCK(hipcub::DeviceScan::ExclusiveSum(h->sq_tmp.p, tb, h->sq_npos.as<uint64_t>(), h->sq_poff.as<uint64_t>(), (int)(ns + 1), s));
+        hipLaunchKernelGGL(k_seq_tiles, dim3(256 * 4), dim3(256), 0, s, h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->sq_tile.as<uint32_t>());
+        switch (h->W) {
+        case 1: CK(launch_seq_walk_w<1>(h, (uint32_t)ns, canonical, soff, s)); break;
+        case 2: CK(launch_seq_walk_w<2>(h, (uint32_t)ns, canonical, soff, s)); break;
+        case 3: CK(launch_seq_walk_w<3>(h, (uint32_t)ns, canonical, soff, s)); break;
+        default: CK(launch_seq_walk_w<4>(h, (uint32_t)ns, canonical, soff, s)); break;
+        }
+        hipLaunchKernelGGL(k_seq_tally, dim3((unsigned)std::min<uint64_t>((ns + SEQ_TALLY_WAVES - 1) / SEQ_TALLY_WAVES, 256ull * 16)), dim3(64 * SEQ_TALLY_WAVES), 0, s,
+                           h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, G, rowbytes, threshold, d_rows + a * rowbytes);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int bft_gpu_query_sequences_dev(bft_gpu* h, const void* d_seqs, const void* d_seq_off, uint64_t n_seqs, uint64_t total_chars, double threshold,
+                                           int canonical, void* d_rows, void* hip_stream) {
+    if (!h || ((!d_seqs || !d_seq_off || !d_rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    if (!(threshold > 0) || threshold > 1) return fail(BFT_GPU_E_ARG, "the threshold must be in (0, 1] (reference src/bft.c:1246-1247)");
+    ENTER(h);
+    CK(ensure_built(h));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    CK(query_sequences_core(h, (const char*)d_seqs, (const uint64_t*)d_seq_off, n_seqs, total_chars, threshold, canonical, (uint8_t*)d_rows, s));
+    return note_foreign_stream(h, s);
+}
+
 extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint64_t* seq_off, uint64_t n_seqs, double threshold, int canonical,
                                        uint8_t* rows) {
     if (!h || ((!seqs || !seq_off || !rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
@@ -1600,66 +1733,21 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
     CK(ensure_built(h));
     const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
     if (rowbytes == 0 || n_seqs == 0) return BFT_GPU_OK;
-    const int k = h->k;
+    // host buffers: the blob and its offsets (rebased to the first sequence) go up in pieces of at most 2^30 characters
     uint64_t a = 0;
     while (a < n_seqs) {
-        // chunk: bounded k-mer positions and counter matrix
-        uint64_t b = a, P = 0;
-        std::vector<uint64_t> pos_off, minv;
-        while (b < n_seqs) {
-            const uint64_t len = seq_off[b + 1] - seq_off[b];
-            const uint64_t m = len >= (uint64_t)k ? len - k + 1 : 0;
-            if (b > a && (P + m > (1ull << 26) || (b - a + 1) * (uint64_t)G > (1ull << 28))) break;
-            pos_off.push_back(P);
-            minv.push_back((uint64_t)(int64_t)ceil((double)m * threshold));  // nb_kmers_query_min, src/bft.c:1281
-            P += m;
-            b++;
-        }
-        pos_off.push_back(P);
+        uint64_t b = a + 1;
+        while (b < n_seqs && seq_off[b + 1] - seq_off[a] <= (1ull << 30)) b++;
         const uint64_t ns = b - a, nchars = seq_off[b] - seq_off[a];
-        DevBuf d_seq, d_soff, d_poff, d_min, d_rows, d_sof, d_cnt, d_out, d_words, d_valid, d_bits, d_codes, d_bad;
         std::vector<uint64_t> soff(ns + 1);
         for (uint64_t i = 0; i <= ns; i++) soff[i] = seq_off[a + i] - seq_off[a];
-        const uint64_t n_cw = (nchars + 31) / 32;  // code words of the blob (32 characters each)
-        CK(d_seq.alloc_zero(n_cw * 32 + 32, h->stream));  // zero padding: k_seq_encode reads whole 32-byte groups
-        CK(d_codes.alloc_zero((n_cw + BFT_MAX_W + 2) * 8, h->stream));
-        CK(d_bad.alloc_zero((n_cw + BFT_MAX_W + 2) * 4, h->stream));
+        DevBuf d_seq, d_soff, d_out;
+        CK(d_seq.alloc(nchars + 16));
         CK(d_soff.alloc((ns + 1) * 8));
-        CK(d_poff.alloc((ns + 1) * 8));
-        CK(d_min.alloc(ns * 8));
-        CK(d_rows.alloc(P * 4));
-        CK(d_sof.alloc(P * 4));
-        CK(d_words.alloc(P * (uint64_t)h->W * 8));
-        CK(d_valid.alloc(P));
-        CK(d_bits.alloc(((P + 63) / 64) * 8));
-        CK(d_cnt.alloc_zero(ns * (uint64_t)G * 4, h->stream));
         CK(d_out.alloc(ns * rowbytes));
         HIPCK(hipMemcpyAsync(d_seq.p, seqs + seq_off[a], nchars, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipMemcpyAsync(d_soff.p, soff.data(), (ns + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCK(hipMemcpyAsync(d_poff.p, pos_off.data(), (ns + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCK(hipMemcpyAsync(d_min.p, minv.data(), ns * 8, hipMemcpyHostToDevice, h->stream));
-        if (P) {
-            const dim3 grid(grid_for((P + 255) / 256)), block(256);
-            hipLaunchKernelGGL(k_seq_encode, dim3(grid_for((n_cw + 255) / 256)), dim3(256), 0, h->stream, d_seq.as<char>(), n_cw, d_codes.as<uint64_t>(),
-                               d_bad.as<uint32_t>());
-#define SEQ(WW) hipLaunchKernelGGL(k_seq_pack<WW>, grid, block, 0, h->stream, d_codes.as<uint64_t>(), d_bad.as<uint32_t>(), d_soff.as<uint64_t>(), \
-                                   d_poff.as<uint64_t>(), (uint32_t)ns, P, k, canonical, d_words.as<uint64_t>(), d_valid.as<uint8_t>(), d_sof.as<uint32_t>())
-            switch (h->W) {
-            case 1: SEQ(1); break;
-            case 2: SEQ(2); break;
-            case 3: SEQ(3); break;
-            default: SEQ(4); break;
-            }
-#undef SEQ
-            HIPCK(hipGetLastError());
-            // the presence kernel of the k-mer queries, on records of W words (8W bytes, zero padded) instead of B bytes
-            CK(launch_query(h, d_words.as<uint8_t>(), P, d_bits.as<uint64_t>(), d_rows.as<uint32_t>(), h->stream, 8 * h->W));
-            hipLaunchKernelGGL(k_seq_count, grid, block, 0, h->stream, d_rows.as<uint32_t>(), d_valid.as<uint8_t>(), d_sof.as<uint32_t>(), h->im.tcol, h->im.cs_off,
-                               h->im.cs_ids, P, G, d_cnt.as<uint32_t>());
-        }
-        hipLaunchKernelGGL(k_seq_threshold, dim3(grid_for((ns * rowbytes + 255) / 256)), dim3(256), 0, h->stream, d_cnt.as<uint32_t>(), d_min.as<uint64_t>(),
-                           (uint32_t)ns, G, rowbytes, d_out.as<uint8_t>());
-        HIPCK(hipGetLastError());
+        CK(query_sequences_core(h, d_seq.as<char>(), d_soff.as<uint64_t>(), ns, nchars, threshold, canonical, d_out.as<uint8_t>(), h->stream));
         HIPCK(hipMemcpyAsync(rows + a * rowbytes, d_out.p, ns * rowbytes, hipMemcpyDeviceToHost, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
         a = b;

@@ -1,4 +1,4 @@
-// bft_kernels_seq.h -- sequence queries around k_query: k_seq_encode / k_seq_pack / k_seq_count / k_seq_threshold
+// bft_kernels_seq.h -- sequence queries: k_seq_encode / k_seq_plan / k_seq_walk (window + walk + colour set) / k_seq_tally (counters + threshold per sequence)
 // Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
 // the host code there).
 #pragma once
@@ -15,12 +15,27 @@ __device__ __forceinline__ int nt_code(char c) {
 
 // Sequence queries, step 0.  The ASCII blob -> 2 bits per character (32 characters per u64, character c at bits 2(c%32) of
 // word c/32: the packed layout of src/fasta.c:11-23 continued over the whole blob) + one "not ACGTU" bit per character.
-// One thread per 32 characters; the blob is padded to a multiple of 32 bytes.
-__global__ void k_seq_encode(const char* __restrict__ seqs, uint64_t n_words, uint64_t* __restrict__ codes, uint32_t* __restrict__ bad) {
+// One thread per 32 characters; characters past n_chars count as 'A' / good (no window of a sequence reaches them).  A blob that
+// is 16-byte aligned is read 32 bytes at a time, any other one byte by byte.
+__global__ void k_seq_encode(const char* __restrict__ seqs, uint64_t n_chars, uint64_t n_words, uint64_t* __restrict__ codes, uint32_t* __restrict__ bad) {
+    const bool aligned = ((uintptr_t)seqs & 15u) == 0;
     for (uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4* src = (const uint4*)(seqs + wi * 32);
-        const uint4 a = src[0], b = src[1];
-        const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t d[8];
+        if (aligned && wi * 32 + 32 <= n_chars) {
+            const uint4* src = (const uint4*)(seqs + wi * 32);
+            const uint4 a = src[0], b = src[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t v = 0;
+                for (int c = 0; c < 4; c++) {
+                    const uint64_t at = wi * 32 + 4 * j + c;
+                    v |= (uint32_t)(uint8_t)(at < n_chars ? seqs[at] : 'A') << (8 * c);
+                }
+                d[j] = v;
+            }
+        }
         uint64_t cw = 0;
         uint32_t bw = 0;
 #pragma unroll
@@ -44,122 +59,206 @@ __device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
     return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
 }
 
-// Step 1.  One thread per k-mer position of the batch: its window is 2k bits of the code stream at a bit offset (W+1 word
-// loads + funnel shifts, O(1) instead of a scan over k characters), valid unless one of its k "bad" bits is set (windows
-// with a character outside ACGTU are skipped by the reference, src/bft.c:1298).  canonical: the reverse complement =
-// complement, reverse the 2-bit fields of the 2k-bit string; strcmp(kmer, revcomp) >= 0 -> the reverse complement is
-// searched (src/bft.c:1290-1296) = comparison of the lowest differing field.  Output: W zero-padded words per position (the
-// record layout k_query reads with a record size of 8W bytes), valid[p], seq_of[p] = the sequence of position p.
+// ---- plan (positions per sequence) -> window + walk + colour set -> counters ------------------------------------------------
+// k_seq_plan: k-mer positions of every sequence of a chunk, on the device (the device-resident entry point never sees the offsets
+// on the host): npos[s] = max(len - k + 1, 0).  An exclusive scan of npos gives pos_off.
+__global__ void k_seq_plan(const uint64_t* __restrict__ seq_off, uint64_t n_seqs, int k, uint64_t* __restrict__ npos) {
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s <= n_seqs; s += (uint64_t)gridDim.x * blockDim.x) {
+        if (s == n_seqs) { npos[s] = 0; continue; }  // the scan's last element: the total
+        const uint64_t len = seq_off[s + 1] - seq_off[s];
+        npos[s] = len >= (uint64_t)k ? len - (uint64_t)k + 1 : 0;
+    }
+}
+
+// The window of one k-mer position: 2k bits of the code stream at a bit offset (W+1 word loads + funnel shifts, O(1) instead of a
+// scan over k characters) -> packed words x[W]; false when one of its k "bad" bits is set (windows with a character outside ACGTU
+// are skipped by the reference, src/bft.c:1298).  canonical: the reverse complement = complement, reverse the 2-bit fields of the
+// 2k-bit string; strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296) = comparison of the
+// lowest differing field.  c0 = index of the window's first character in the blob.
 template <int W>
-__global__ void k_seq_pack(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
-                           const uint64_t* __restrict__ pos_off, uint32_t n_seqs, uint64_t P, int k, int canonical, uint64_t* __restrict__ words,
-                           uint8_t* __restrict__ valid, uint32_t* __restrict__ seq_of) {
-    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
-        // the sequence of position p: last s with pos_off[s] <= p.  The 64 positions of a wavefront are consecutive, so the
-        // binary search runs once per wavefront on its first position (uniform values: scalar loads) and every lane
-        // walks forward from there (sequences shorter than k own no position and are stepped over).
-        const uint64_t p0 = p - (threadIdx.x & 63u);
-        const uint64_t p0u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p0 >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p0);
+__device__ __forceinline__ bool seq_window(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, uint64_t c0, int k, int canonical, uint64_t* x) {
+    const uint64_t w0 = c0 >> 5;
+    const uint32_t sh = (uint32_t)(c0 & 31u) * 2u;
+    uint64_t cw[W + 1], xf[W];
+#pragma unroll
+    for (int q = 0; q <= W; q++) cw[q] = codes[w0 + q];  // the code array has W+1 words of slack
+#pragma unroll
+    for (int q = 0; q < W; q++) xf[q] = sh ? (cw[q] >> sh) | (cw[q + 1] << (64u - sh)) : cw[q];
+    const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
+    if (top < 64) xf[W - 1] &= (1ull << top) - 1ull;
+    bool ok = true;
+    {
+        const uint32_t bs = (uint32_t)(c0 & 31u);
+        int left = k;
+        uint32_t first = bad[w0] >> bs;
+        if (left < 32 - (int)bs) first &= (1u << left) - 1u;
+        ok = first == 0;
+        left -= 32 - (int)bs;
+        for (uint64_t j = w0 + 1; left > 0; j++, left -= 32) {
+            uint32_t m = bad[j];
+            if (left < 32) m &= (1u << left) - 1u;
+            ok = ok && m == 0;
+        }
+    }
+    bool use_rc = false;
+    uint64_t xr[W];
+    if (canonical) {
+        uint64_t rv[W + 1];
+#pragma unroll
+        for (int q = 0; q < W; q++) rv[q] = rev2_64(~xf[W - 1 - q]);
+        rv[W] = 0;
+        const uint32_t dn = (uint32_t)(64 * W - 2 * k);  // < 64
+#pragma unroll
+        for (int q = 0; q < W; q++) xr[q] = dn ? (rv[q] >> dn) | (rv[q + 1] << (64u - dn)) : rv[q];
+        if (top < 64) xr[W - 1] &= (1ull << top) - 1ull;
+        use_rc = true;
+#pragma unroll
+        for (int q = W - 1; q >= 0; q--) {  // the lowest differing field decides: word 0 last
+            const uint64_t df = xf[q] ^ xr[q];
+            if (df) {
+                const int fs = __builtin_ctzll(df) & ~1;
+                use_rc = ((xf[q] >> fs) & 3ull) > ((xr[q] >> fs) & 3ull);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; q++) x[q] = (canonical && use_rc) ? xr[q] : xf[q];
+    return ok;
+}
+
+// k_seq_tiles: the sequence of the first position of every 64-position tile (last s with pos_off[s] <= 64 t), one binary search
+// per tile, once -- the wavefronts of k_seq_walk start from there with one load.  (A search per wavefront pass
+// in that kernel was measured: a scalar binary search costs 20 dependent loads on the critical path of every pass, a 64-ary
+// wavefront-wide search 256 L2 requests per pass -- the path went from 4.9 to 8 ms per 10^6 reads with it.)
+__global__ void k_seq_tiles(const uint64_t* __restrict__ pos_off, uint32_t n_seqs, uint32_t* __restrict__ tile_seq) {
+    const uint64_t P = pos_off[n_seqs], ntiles = (P + 63) / 64;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < ntiles; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = t * 64;
         uint32_t lo = 0, hi = n_seqs;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (pos_off[mid] <= p0u) lo = mid; else hi = mid;
+            if (pos_off[mid] <= p0) lo = mid; else hi = mid;
         }
-        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
-        const uint64_t c0 = seq_off[lo] + (p - pos_off[lo]);  // first character of the window, as an index into the blob
-        // 2k bits of the code stream from bit 2*c0
-        const uint64_t w0 = c0 >> 5;
-        const uint32_t sh = (uint32_t)(c0 & 31u) * 2u;
-        uint64_t cw[W + 1], xf[W], xr[W];
-#pragma unroll
-        for (int q = 0; q <= W; q++) cw[q] = codes[w0 + q];  // the code array has W+1 words of slack
-#pragma unroll
-        for (int q = 0; q < W; q++) xf[q] = sh ? (cw[q] >> sh) | (cw[q + 1] << (64u - sh)) : cw[q];
-        const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
-        if (top < 64) xf[W - 1] &= (1ull << top) - 1ull;
-        // any bad character in [c0, c0 + k)?
-        bool ok = true;
-        {
-            const uint64_t b0 = c0 >> 5;
-            const uint32_t bs = (uint32_t)(c0 & 31u);
-            int left = k;
-            uint32_t first = bad[b0] >> bs;
-            if (left < 32 - (int)bs) first &= (1u << left) - 1u;
-            ok = first == 0;
-            left -= 32 - (int)bs;
-            for (uint64_t j = b0 + 1; left > 0; j++, left -= 32) {
-                uint32_t m = bad[j];
-                if (left < 32) m &= (1u << left) - 1u;
-                ok = ok && m == 0;
-            }
+        tile_seq[t] = lo;
+    }
+}
+
+// k_seq_walk8 / k_seq_walk6: one lane per k-mer position of the chunk, persistent grid like k_query (same LDS staging).
+// A wavefront holds 64 consecutive positions: sequence of its first position from k_seq_tiles, then each lane steps forward;
+// window from the code stream; bft_walk; slot / row -> colour set (one gather); the colour set of the position (0xFFFFFFFF: no
+// k-mer there, or absent) goes to csout[p] -- 4 bytes per position, the only per-position array of the path.
+// (Counting inside this kernel was tried: the counter lines and the range table are pushed out of the L2 by the walk's gathers,
+// 2.4 L2 misses per position instead of ~1.9, 6.0 ms instead of 4.2 per 10^6 reads of 150 nt.)
+template <int W, int BLOCK, bool STAGED, int PROBE>
+__device__ __forceinline__ void seq_walk_body(const BftImage& im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad,
+                                              const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq,
+                                              uint32_t n_seqs, int canonical, uint32_t* __restrict__ csout) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint32_t* l_hm = (uint32_t*)lds;
+    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    const BftNode root = im.nodes[0];
+    const bool stage_root = STAGED && im.rdir == nullptr;
+    const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
+    BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
+    {
+        const uint4* g = (const uint4*)im.hashmod;
+        uint4* l = (uint4*)l_hm;
+        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (stage_root) {
+            const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
+            uint64_t* lb = (uint64_t*)l_bf;
+            const uint32_t nb8 = (BFT_MODULO_HASH * (uint32_t)root.bf_wb) / 8;
+            for (uint32_t i = threadIdx.x; i < nb8; i += BLOCK) lb[i] = gb[i];
+            for (uint32_t i = threadIdx.x; i < root.ncc; i += BLOCK) l_cc[i] = im.ccx[root.cc_first + i];
         }
-        bool use_rc = false;
-        if (canonical) {
-            // complement, then reverse the fields of the 64W-bit string and shift the 2k bits of interest back down
-            uint64_t rv[W + 1];
+    }
+    __syncthreads();
+    const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
+    const uint64_t P = pos_off[n_seqs];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nblk = (P + BLOCK - 1) / BLOCK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
+        const uint64_t p = blk * BLOCK + threadIdx.x;
+        if (p >= P) continue;
+        uint32_t lo = tile_seq[p >> 6];
+        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;  // (sequences shorter than k own no position and are stepped over)
+        uint32_t cs = 0xFFFFFFFFu;
+        uint64_t x[W], t[W];
+        if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
+            bft_tform_from_x<W>(x, im.k, t);
+            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
+            if (h.present) cs = (h.gh_slot >= 0 && im.tcolh) ? im.tcolh[h.gh_slot] : im.tcol[bft_hit_row(im, h)];
+        }
+        csout[p] = cs;
+    }
+}
+
+// Two builds (k_query8 / k_query6): the walk of the two-word rows needs 70 VGPRs (6 wavefronts per SIMD), the others fit 8 x 64.
+template <int W, bool STAGED, int PROBE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seq_walk8(
+    BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
+    const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical, uint32_t* __restrict__ csout) {
+    seq_walk_body<W, 1024, STAGED, PROBE>(im, codes, bad, seq_off, pos_off, tile_seq, n_seqs, canonical, csout);
+}
+template <int W, bool STAGED, int PROBE>
+__global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_seq_walk6(
+    BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
+    const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical, uint32_t* __restrict__ csout) {
+    seq_walk_body<W, BFT_BLOCK6, STAGED, PROBE>(im, codes, bad, seq_off, pos_off, tile_seq, n_seqs, canonical, csout);
+}
+
+// Per-(sequence, genome) counters and the threshold, one WAVEFRONT per sequence, counters in LDS: no counter matrix in HBM, no
+// global atomics (the first version added run lengths into an n_seqs x G matrix with device-scope atomics -- 0.8 per k-mer
+// position, 98 M per 10^6 reads, half of the path's time -- and thresholded it in another pass).  Consecutive k-mers of a read
+// mostly carry the same colour set, so counting works on runs: the 64 lanes hold 64 consecutive positions, run boundaries come
+// from a shuffle + __ballot, and the first lane of every run adds the run length once per genome of the set.  Genomes are
+// handled SEQ_TALLY_G at a time (one pass over the sequence's positions per window: one pass up to 2048 genomes).
+// Row s of `out` (rowbytes bytes): bit g set iff genome g holds at least ceil(npos(s) * threshold) > 0 of the sequence's k-mers
+// (src/bft.c:1281, :1320-1340).
+#define SEQ_TALLY_G 2048u
+#define SEQ_TALLY_WAVES 4
+__global__ __launch_bounds__(64 * SEQ_TALLY_WAVES) void k_seq_tally(const uint32_t* __restrict__ csin, const uint64_t* __restrict__ pos_off, uint32_t n_seqs,
+                                                                   const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint32_t G,
+                                                                   uint32_t rowbytes, double threshold, uint8_t* __restrict__ out) {
+    __shared__ uint32_t s_cnt[SEQ_TALLY_WAVES][SEQ_TALLY_G];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* cnt = s_cnt[wave];
+    for (uint64_t s = (uint64_t)blockIdx.x * SEQ_TALLY_WAVES + wave; s < n_seqs; s += (uint64_t)gridDim.x * SEQ_TALLY_WAVES) {
+        const uint64_t pa = pos_off[s], m = pos_off[s + 1] - pa;
+        const uint64_t minv = (uint64_t)(int64_t)ceil((double)m * threshold);  // nb_kmers_query_min
+        for (uint32_t win0 = 0; win0 < G; win0 += SEQ_TALLY_G) {
+            const uint32_t wn = min(SEQ_TALLY_G, G - win0);
+            for (uint32_t j = lane; j < wn; j += 64) cnt[j] = 0;
+            for (uint64_t base = 0; base < m; base += 64) {  // m is wavefront-uniform: every lane takes every turn
+                const uint32_t cs = base + lane < m ? csin[pa + base + lane] : 0xFFFFFFFFu;
+                const uint32_t pcs = __shfl_up(cs, 1);
+                const bool boundary = lane == 0 || pcs != cs;
+                const uint64_t bmask = __ballot(boundary);
+                if (boundary && cs != 0xFFFFFFFFu) {
+                    const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
+                    const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+                    const uint32_t q1 = cs_off[cs + 1];
+                    for (uint32_t q = cs_off[cs]; q < q1; q += 8) {  // eight ids per step, loaded together
+                        uint32_t id[8];
 #pragma unroll
-            for (int q = 0; q < W; q++) rv[q] = rev2_64(~xf[W - 1 - q]);
-            rv[W] = 0;
-            const uint32_t dn = (uint32_t)(64 * W - 2 * k);  // < 64
+                        for (int j = 0; j < 8; j++) id[j] = cs_ids[min(q + (uint32_t)j, q1 - 1u)];
 #pragma unroll
-            for (int q = 0; q < W; q++) xr[q] = dn ? (rv[q] >> dn) | (rv[q + 1] << (64u - dn)) : rv[q];
-            if (top < 64) xr[W - 1] &= (1ull << top) - 1ull;
-            use_rc = true;  // equal strings: the (identical) reverse complement
-#pragma unroll
-            for (int q = W - 1; q >= 0; q--) {  // the lowest differing field decides: word 0 last
-                const uint64_t df = xf[q] ^ xr[q];
-                if (df) {
-                    const int fs = __builtin_ctzll(df) & ~1;
-                    use_rc = ((xf[q] >> fs) & 3ull) > ((xr[q] >> fs) & 3ull);
+                        for (int j = 0; j < 8; j++)
+                            if (q + (uint32_t)j < q1 && id[j] - win0 < wn) atomicAdd(&cnt[id[j] - win0], len);
+                    }
                 }
             }
+            // (LDS operations of one wavefront complete in order: the adds above are visible to the reads below)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t b = lane; b < (wn + 7u) / 8u; b += 64) {
+                uint32_t v = 0;
+                for (uint32_t j = 0; j < 8 && b * 8 + j < wn; j++) {
+                    const uint32_t c = cnt[b * 8 + j];
+                    if (c && c >= minv) v |= 1u << j;
+                }
+                out[s * rowbytes + win0 / 8 + b] = (uint8_t)v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-#pragma unroll
-        for (int q = 0; q < W; q++) words[p * W + q] = ok ? (use_rc ? xr[q] : xf[q]) : 0ull;
-        valid[p] = ok ? 1 : 0;
-        seq_of[p] = lo;
-    }
-}
-
-// Step 3 (step 2 is k_query on the word records): per-(sequence, genome) counters.  Consecutive k-mers of a read mostly
-// carry the same colour set, so counting works on runs: the 64 lanes of a wavefront hold 64 consecutive positions, run
-// boundaries come from a shuffle + __ballot, and the first lane of every run of equal (sequence, colour set) adds the run
-// length (up to the end of the wavefront) once per genome of the set -- instead of one atomic per k-mer and genome.
-__global__ void k_seq_count(const uint32_t* __restrict__ rows, const uint8_t* __restrict__ valid, const uint32_t* __restrict__ seq_of,
-                            const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t P, uint32_t G,
-                            uint32_t* __restrict__ counts) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t nblk = (P + blockDim.x - 1) / blockDim.x;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
-        const uint64_t p = blk * blockDim.x + threadIdx.x;
-        uint32_t cs = 0xFFFFFFFFu, sq = 0xFFFFFFFFu;
-        if (p < P) {
-            sq = seq_of[p];
-            const uint32_t r = rows[p];
-            if (r != BFT_ABSENT_ROW && valid[p]) cs = tcol[r];
-        }
-        const uint32_t pcs = __shfl_up(cs, 1), psq = __shfl_up(sq, 1);
-        const bool boundary = lane == 0 || pcs != cs || psq != sq;
-        const uint64_t bmask = __ballot(boundary);
-        if (boundary && cs != 0xFFFFFFFFu) {
-            const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
-            const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-            uint32_t* c = counts + (size_t)sq * G;
-            for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) atomicAdd(&c[cs_ids[q]], len);
-        }
-    }
-}
-
-__global__ void k_seq_threshold(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ minv, uint32_t n_seqs, uint32_t G, uint32_t rowbytes,
-                                uint8_t* __restrict__ out) {
-    const uint64_t total = (uint64_t)n_seqs * rowbytes;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t s = (uint32_t)(i / rowbytes), b = (uint32_t)(i % rowbytes);
-        uint32_t v = 0;
-        for (uint32_t j = 0; j < 8 && b * 8 + j < G; j++) {
-            const uint32_t c = counts[(size_t)s * G + b * 8 + j];
-            if (c && c >= minv[s]) v |= 1u << j;
-        }
-        out[i] = (uint8_t)v;
     }
 }

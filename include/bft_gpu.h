@@ -110,6 +110,12 @@ int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kme
  * has bit g set iff genome g holds at least ceil(nb_kmers(i) * threshold) of the sequence's k-mers. */
 int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint64_t* seq_off, uint64_t nb_seqs, double threshold,
                             int canonical, uint8_t* rows);
+/* The same on device-resident buffers, without synchronisation: d_seqs (total_chars ASCII bytes; any alignment, 16-byte aligned
+ * blobs are read faster), d_seq_off (nb_seqs + 1 uint64 offsets into d_seqs, d_seq_off[nb_seqs] <= total_chars), d_rows
+ * (nb_seqs x CEIL(nb_genomes/8) bytes).  The k-mer positions of the batch are counted on the device, so the call returns
+ * as soon as its kernels are enqueued on hip_stream (NULL = the handle's stream); scratch belongs to the handle. */
+int bft_gpu_query_sequences_dev(bft_gpu* h, const void* d_seqs, const void* d_seq_off, uint64_t nb_seqs, uint64_t total_chars,
+                                double threshold, int canonical, void* d_rows, void* hip_stream);
 
 /* load_BFT / read_BFT_Root (include/bft.h:176, src/write_to_disk.c:260-776): parse a reference .bft file
  * (compressed == 0; annotation modes 0/1/2 and extended-annotation bytes) and build the GPU image from its

@@ -296,6 +296,24 @@ def test_query_sequences(oracle_mod, k, canonical):
         got = t.query_sequences(reads, thr, canonical)
         for r, gl in zip(reads, got):
             assert gl == o.query_sequence(r, thr, canonical, ngen), (r, thr)
+    # the device-resident entry point: same rows, also from a blob that is not 16-byte aligned and without any padding behind it
+    import torch
+    dev = torch.device("cuda", 0)
+    enc = [r.encode() for r in reads]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    blob = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    exp = t.query_sequences(reads, 0.75, canonical)
+    for shift in (0, 3):
+        d_blob = torch.zeros(len(blob) + shift, dtype=torch.uint8, device=dev)
+        d_blob[shift:] = torch.from_numpy(blob.copy()).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        d_rows = torch.full((len(enc), 1), 0xFF, dtype=torch.uint8, device=dev)
+        t.query_sequences_dev(d_blob.data_ptr() + shift, d_off.data_ptr(), len(enc), len(blob), 0.75, d_rows.data_ptr(), canonical,
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        unp = np.unpackbits(d_rows.cpu().numpy(), axis=1, bitorder="little")[:, :ngen]
+        assert [np.flatnonzero(r).tolist() for r in unp] == exp, shift
 
 
 def test_load_reference_shaped_file(oracle_mod, tmp_path):
