@@ -1155,7 +1155,9 @@ static int launch_query_bucketed(bft_gpu* h, const uint8_t* d_kmers, uint64_t n,
 // Which path a batch takes.  Small batches: the direct kernel.  Large ones: bucketed when "query_bucket_bits" says so, or
 // -- by default -- when it measured faster on the first large batch of this image (both paths run twice on that batch, which
 // makes that one call synchronise; same answers either way).  Whether bucketing pays depends on the index (a table that fits
-// the L2 gains nothing) and on the batch, so it is measured rather than guessed, like the residency.
+// the L2 gains nothing) and on the batch, so it is measured rather than guessed, like the residency -- and the residency itself
+// is measured again on that batch when it is automatic (the three arrangements of k_query: the build-time choice comes from a
+// 2^22-query synthetic batch, the real one separates arrangements 5-10 % apart).
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
@@ -1168,11 +1170,17 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         hipEvent_t ev[2] = {nullptr, nullptr};
         int rc = 0;
         if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
-        float best[2] = {1e30f, 1e30f};
+        // modes 0..2: the direct kernel under residency 1 / 2 / 3 (only when the residency is automatic: the build-time choice was
+        // made on a 2^22-query batch, which resolves differences below ~10 % poorly -- this is the real batch); mode 3: bucketed
+        float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+        const int res0 = query_residency(h);
+        const bool auto_res = h->opt_wgs_per_cu == 0;
         for (int rep = 0; rep < 2 && rc == 0; rep++)
-            for (int mode = 0; mode < 2 && rc == 0; mode++) {
+            for (int mode = 0; mode < 4 && rc == 0; mode++) {
+                if (mode < 3 && !auto_res && mode + 1 != res0) continue;
+                if (mode < 3) h->tuned_wgs = mode + 1;
                 if (hipEventRecord(ev[0], s) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
-                if (rc == 0) rc = mode ? launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, BK_DEFAULT_BITS) : launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
+                if (rc == 0) rc = mode == 3 ? launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, BK_DEFAULT_BITS) : launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
                 if (rc == 0 && (hipEventRecord(ev[1], s) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "query failed while tuning");
                 float ms = 0;
                 if (rc == 0 && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
@@ -1181,10 +1189,18 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
         for (hipEvent_t e : ev)
             if (e) (void)hipEventDestroy(e);
         h->timing = timing;
+        h->tuned_wgs = res0;
         CK(rc);
-        h->bucket_tune_ms[0] = best[0];
-        h->bucket_tune_ms[1] = best[1];
-        h->tuned_bucket_bits = best[1] < 0.95f * best[0] ? BK_DEFAULT_BITS : 0;
+        int rbest = res0 - 1;
+        for (int r = 0; r < 3; r++)
+            if (best[r] < best[rbest]) rbest = r;
+        if (auto_res) {
+            h->tuned_wgs = rbest + 1;
+            for (int r = 0; r < 3; r++) h->tune_ms[r] = best[r] < 1e29f ? best[r] : 0;
+        }
+        h->bucket_tune_ms[0] = best[rbest];
+        h->bucket_tune_ms[1] = best[3];
+        h->tuned_bucket_bits = best[3] < 0.95f * best[rbest] ? BK_DEFAULT_BITS : 0;
         return 0;  // the caller's buffers hold the answers of the last run
     }
     if (h->tuned_bucket_bits > 0) return launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, h->tuned_bucket_bits);

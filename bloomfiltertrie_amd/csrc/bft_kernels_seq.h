@@ -3,14 +3,13 @@
 // the host code there).
 #pragma once
 // ---- query_sequence (src/bft.c:1241-1351, harness src/file_io.c:1464-1574): every k-mer of every sequence ----
-__device__ __forceinline__ int nt_code(char c) {
-    switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': case 'U': case 'u': return 3;
-    default: return -1;
-    }
+// ASCII -> 2-bit code (A C G T/U = 0 1 2 3, either case), -1 for anything else; branch-free: bits 1 and 2 of the character code
+// already separate the four letters ((c >> 1) ^ (c >> 2)) & 3, and a 21-bit mask over 'A'..'U' says which letters count.
+__device__ __forceinline__ int nt_code(char ch) {
+    const uint32_t c = (uint8_t)ch, idx = (c & 0xDFu) - 0x41u;  // upper-cased, 'A' = 0
+    const uint32_t valid_mask = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 19) | (1u << 20);  // A C G T U
+    const bool ok = idx < 21u && ((valid_mask >> idx) & 1u);
+    return ok ? (int)(((c >> 1) ^ (c >> 2)) & 3u) : -1;
 }
 
 // Sequence queries, step 0.  The ASCII blob -> 2 bits per character (32 characters per u64, character c at bits 2(c%32) of

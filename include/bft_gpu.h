@@ -138,7 +138,7 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 
 /* Tuning knobs: "query_wgs_per_cu" (how k_query sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per SIMD
  * with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each -- the two-word rows of k = 36..63 fit that budget and not the one
- * of 2; 0 = measured on the index when it is built), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
+ * of 2; 0 = measured on the index when it is built and once more on the first batch of 2^24 queries or more, see "query_bucket_bits"), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
  * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
  * (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into one
  * hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte

@@ -44,6 +44,27 @@ def main():
          "where name like '%k_%' and name not like '%at::native%' and name not like '%rocprim%' group by name, grid_x, workgroup_x order by sum(duration) desc")
     for name, gx, wx, n, avg, mn, mx, tot in cur.execute(q):
         print(f"{short(name, 90):92s} grid={gx:<9d} wg={wx:<5d} n={n:4d} avg_us={avg / 1e3:10.2f} min/max_us={mn / 1e3:.1f}/{mx / 1e3:.1f} total_us={tot / 1e3:.1f}")
+    # the same persistent grid serves several batches in one run (bench.py: the config-2 batch, the config-4 shares, the k=31
+    # index, tuning batches): launches of one (kernel, grid) in dispatch order, consecutive launches whose durations stay within
+    # 12 % of the run's first one form a run -- the K timed steps of the bench are one such run of >= K equal launches
+    print("\n# query kernels: runs of consecutive launches of similar duration (kernel, grid): n, avg / min / max us")
+    q = ("select name, grid_x, duration from kernels where (name like '%k_query%' or name like '%k_branching%' or name like '%k_seq_walk%') "
+         "order by name, grid_x, start")
+    runs, cur_key, cur_run = [], None, []
+    def flush():
+        if len(cur_run) >= 3:
+            runs.append((cur_key, list(cur_run)))
+    for name, gx, dur in cur.execute(q):
+        key = (name, gx)
+        if key != cur_key or not cur_run or abs(dur - cur_run[0]) > 0.12 * cur_run[0]:
+            flush()
+            cur_key, cur_run = key, []
+        cur_run.append(dur)
+    flush()
+    for (name, gx), r in runs:
+        if sum(r) / len(r) < 200000:  # (runs of sub-0.2 ms launches: warm-up and tuning)
+            continue
+        print(f"{short(name, 90):92s} grid={gx:<9d} n={len(r):4d} avg_us={sum(r) / len(r) / 1e3:10.2f} min/max_us={min(r) / 1e3:.1f}/{max(r) / 1e3:.1f}")
     if "--pmc" in sys.argv:
         tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
         print("\n# tables:", [t for t in tabs if "pmc" in t.lower() or "counter" in t.lower()])
