@@ -367,7 +367,9 @@ BFT_HD bool bft_gh_lookup(const BftImage& im, uint64_t idx, uint32_t cnt, const 
 #if defined(__HIP_DEVICE_COMPILE__)
         if (W == 1) {
 #pragma unroll
-            for (uint32_t s = 0; s < BFT_GH_SLOTS; s += 2) {  // 16-byte loads of one 32-byte aligned bucket
+            // 16-byte loads of one 32-byte aligned bucket.  (Non-temporal loads here, meant to keep the range table in the L2, were
+            // measured: config 2 2.33 -> 3.63 ms, config 4 3.70 -> 4.55 ms per launch -- they also bypass the Infinity Cache.)
+            for (uint32_t s = 0; s < BFT_GH_SLOTS; s += 2) {
                 const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(im.tkh + s0 + s);
                 v[s][0] = q.x;
                 v[s + 1][0] = q.y;

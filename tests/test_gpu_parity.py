@@ -316,6 +316,50 @@ def test_query_sequences(oracle_mod, k, canonical):
         assert [np.flatnonzero(r).tolist() for r in unp] == exp, shift
 
 
+def test_query_sequences_many_genomes_against_ground_truth():
+    """Sequence queries with more genomes than one counter window of k_seq_tally holds (2048): every genome bit of every read
+    against counts taken from the inserted sets, host call and device-resident call."""
+    import math
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k, ngen, glen = 27, 2100, 3000
+    g = S.random_genome(glen, 77)
+    s = "".join("ACGT"[c] for c in g)
+    packed, _ = S.ascii_to_packed([s[i:i + k] for i in range(glen - k + 1)], k)
+    npos = glen - k + 1
+    assert len(S.distinct(packed)) == npos
+    rng = np.random.default_rng(3)
+    member = rng.random((ngen, npos)) < 0.3
+    member[5, :] = True
+    member[2070, ::2] = True
+    t = BFT(k)
+    for gi in range(ngen):
+        t.insert_kmers(np.ascontiguousarray(packed[member[gi]]), gi)
+    reads, spans = [], []
+    for _ in range(60):
+        a = int(rng.integers(0, glen - 200))
+        n = int(rng.integers(k, 200))
+        reads.append(s[a:a + n])
+        spans.append((a, n - k + 1))
+    thr = 0.4
+    got = t.query_sequences(reads, thr)
+    for (a, m), gl in zip(spans, got):
+        cnt = member[:, a:a + m].sum(axis=1)
+        need = math.ceil(m * thr)
+        assert gl == np.flatnonzero((cnt >= need) & (cnt > 0)).tolist()
+    dev = torch.device("cuda", 0)
+    enc = [r.encode() for r in reads]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    d_blob = torch.from_numpy(np.frombuffer(b"".join(enc), dtype=np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_rows = torch.zeros((len(enc), (ngen + 7) // 8), dtype=torch.uint8, device=dev)
+    t.query_sequences_dev(d_blob.data_ptr(), d_off.data_ptr(), len(enc), int(off[-1]), thr, d_rows.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    unp = np.unpackbits(d_rows.cpu().numpy(), axis=1, bitorder="little")[:, :ngen]
+    assert [np.flatnonzero(r).tolist() for r in unp] == got
+
+
 def test_load_reference_shaped_file(oracle_mod, tmp_path):
     """load_BFT of a file with mode-3 annotations (comp_set_colors) and extended-annotation bytes."""
     from bloomfiltertrie_amd import BFT
