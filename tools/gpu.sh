@@ -3,6 +3,6 @@
 # snapshot's prebuilt .so files, so a stale library would silently test old code.   usage: tools/gpu.sh <timeout_s> '<command>'
 set -e
 cd "$(dirname "$0")/.."
-make -s -C bloomfiltertrie_amd/csrc all
+make -s -j4 -C bloomfiltertrie_amd/csrc all
 make -s -C oracle all >/dev/null
 exec /usr/local/graft/bin/gpurun --timeout "$1" -- "$2"
