@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU baseline (0 = auto)")
     ap.add_argument("--verify", type=int, default=1_000_000, help="config 2: queries of the batch checked against ground truth")
     ap.add_argument("--no-k31", action="store_true", help="skip the secondary k=31 measurement (extension beyond the reference)")
+    ap.add_argument("--no-sequences", action="store_true", help="skip the secondary sequence-query measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-config4-share", action="store_true", help="N=1: skip the per-GPU share of config 4")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bitmap all_gather even with one rank (path check)")
@@ -444,6 +445,44 @@ def main():
             del q31, bits31
         except Exception as e:  # the headline line must not depend on the extension
             out["k31_extension"] = {"error": repr(e)}
+
+    # ---- secondary: sequence queries on the same index, device-resident reads ----
+    if world == 1 and workload == "config2" and not args.no_sequences:
+        try:
+            n_reads, rl = 200_000, 150
+            rng = np.random.default_rng(11)
+            anc = S.random_genome(args.genome_len, 1234)
+            gs = np.stack([S.mutate(anc, args.snp_rate, 1000 + g) for g in range(genomes)])
+            src = rng.integers(0, genomes, n_reads)
+            start = rng.integers(0, args.genome_len - rl, n_reads)
+            reads = gs[src[:, None], start[:, None] + np.arange(rl)[None, :]].astype(np.uint8)
+            blob = np.frombuffer(b"ACGT", dtype=np.uint8)[reads]
+            d_blob = torch.from_numpy(np.ascontiguousarray(blob).reshape(-1)).to(device)
+            d_off = torch.from_numpy(np.arange(n_reads + 1, dtype=np.int64) * rl).to(device)
+            rowbytes = (genomes + 7) // 8
+            d_rows = torch.zeros((n_reads, rowbytes), dtype=torch.uint8, device=device)
+            call = lambda: bft.query_sequences_dev(d_blob.data_ptr(), d_off.data_ptr(), n_reads, n_reads * rl, 1.0, d_rows.data_ptr(), False, stream)
+            call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_s = e0.elapsed_time(e1) / 5
+            rows = np.unpackbits(d_rows.cpu().numpy(), axis=1, bitorder="little")[:, :genomes]
+            # every k-mer of a read cut out of genome g is in genome g: bit g must be set at threshold 1.0; the host-buffer call must agree
+            own = bool(rows[np.arange(n_reads), src].all())
+            host = bft.query_sequences([bytes(r) for r in blob[:2000]], 1.0)
+            same = host == [np.flatnonzero(r).tolist() for r in rows[:2000]]
+            out["sequence_queries"] = {"value": round(n_reads / ms_s / 1e3, 2), "unit": "M reads/s", "M_kmers_per_s": round(n_reads * (rl - k + 1) / ms_s / 1e3, 1),
+                                       "reads": n_reads, "read_len": rl, "threshold": 1.0, "ms": round(ms_s, 3), "source_genome_bit_set": own,
+                                       "host_call_agrees_on_2000": bool(same),
+                                       "note": "bft_gpu_query_sequences_dev: reads resident in HBM, error-free substrings of the indexed genomes"}
+            del d_blob, d_off, d_rows
+        except Exception as e:
+            out["sequence_queries"] = {"error": repr(e)}
 
     if use_dist:
         dist.destroy_process_group()
