@@ -13,6 +13,7 @@
 // assembly are the kernels of bft_assemble.hip -- see DESIGN.md "Insertion".
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -222,6 +223,7 @@ struct bft_gpu {
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
     DevBuf d_tcolh;
+    bool opt_no_composite = false;  // test hook ("build_composite" 0): the general sort + flag-array path also for ordered one-word keys
     bool tcolh_tried = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
@@ -838,6 +840,45 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             src_g = cg.as<uint32_t>();
             src_stride = total;
         }
+        const int gb = bits_for(h->max_gid_seen);
+        // (composites of up to 63 bits: rocPRIM's radix sort mis-sorts the bit range [2, 64) -- found by test_any_k_against_ground_truth[31-0])
+        if (W == 1 && h->log_g_sorted && 2 * h->k + gb <= 63 && !h->opt_no_composite) {
+            // 2c + 3c. composite path (bft_kernels_build.h): sort (T << gb | genome) on the T bits, flags on the fly, one scan
+            DevBuf cs, tmp, pos;
+            CK(cs.alloc(total * 8));
+            CK(pos.alloc(total * 8));
+            const BftCompose comp{src_k, src_g, (uint32_t)gb};
+            auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), comp);
+            size_t tb = 0, tb2 = 0;
+            HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
+            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
+            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            CK(tmp.alloc(std::max(tb, tb2)));
+            tb = tb2 = tmp.bytes;
+            HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            ck.release();
+            cg.release();
+            HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            uint64_t last_pos = 0, last_c[2] = {0, 0};
+            HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipMemcpyAsync(&last_c[1], cs.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+            if (total > 1) HIPCK(hipMemcpyAsync(&last_c[0], cs.as<uint64_t>() + total - 2, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipStreamSynchronize(h->stream));
+            const bool last_head = total == 1 || (last_c[1] >> gb) != (last_c[0] >> gb), last_keep = total == 1 || last_c[1] != last_c[0];
+            nk = (last_pos >> 32) + (last_head ? 1 : 0);
+            np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
+            CK(tk.alloc(nk * 8));
+            CK(seg_off.alloc((nk + 1) * 4));
+            CK(npk.alloc(np * 8));
+            CK(npg.alloc(np * 4));
+            hipLaunchKernelGGL(k_scatter_c, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, cs.as<uint64_t>(), (uint32_t)gb, total, pos.as<uint64_t>(),
+                               npk.as<uint64_t>(), npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+            const uint32_t np32 = (uint32_t)np;
+            HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
+            HIPCK(hipGetLastError());
+            HIPCK(hipStreamSynchronize(h->stream));
+        } else {
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
         CK(sg.alloc(total * 4));
@@ -877,6 +918,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));
+        }
     }
     double t1 = now_ms();
 
@@ -2010,6 +2052,9 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     if (nm == "query_wgs_per_cu") {
         if (value < 0 || value > 3) return fail(BFT_GPU_E_ARG, "query_wgs_per_cu must be 0 (automatic), 1, 2 or 3");
         h->opt_wgs_per_cu = (int)value;
+    } else if (nm == "build_composite") {
+        if (value != 0 && value != 1) return fail(BFT_GPU_E_ARG, "build_composite must be 0 or 1");
+        h->opt_no_composite = value == 0;
     } else if (nm == "reserve_pairs") {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
         // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)

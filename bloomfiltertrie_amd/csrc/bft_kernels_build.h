@@ -39,3 +39,40 @@ __global__ void k_scatter(const uint64_t* __restrict__ keys, uint64_t stride, in
         }
     }
 }
+
+// ---- composite path: one-word keys whose genome ids arrive in ascending order and fit the key's spare low bits ----------------
+// c = (T << gb) | genome: ONE 8-byte array is sorted (on the T bits only: the sort is stable, so the ids keep their ascending
+// order inside a k-mer) instead of 8-byte keys + 4-byte values -- a third less traffic in each of the seven radix passes -- and the
+// de-duplication flags come out of neighbouring composites on the fly instead of through two flag arrays and two scans.
+struct BftCompose {  // input "iterator" of the sort: composite i from the insertion log
+    const uint64_t* k;
+    const uint32_t* g;
+    uint32_t gb;
+    __host__ __device__ uint64_t operator()(uint32_t i) const { return (k[i] << gb) | (uint64_t)g[i]; }
+};
+struct BftPairFlags {  // input of the scan: (first pair of its k-mer) << 32 | (first pair of its (k-mer, genome))
+    const uint64_t* c;
+    uint32_t gb;
+    __host__ __device__ uint64_t operator()(uint32_t i) const {
+        const uint64_t a = c[i], b = i ? c[i - 1] : ~a;
+        const uint64_t head = (a >> gb) != (b >> gb), keep = a != b;
+        return (head << 32) | keep;
+    }
+};
+__global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_t n, const uint64_t* __restrict__ pos, uint64_t* __restrict__ pk,
+                            uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+    const uint64_t gmask = (1ull << gb) - 1ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = c[i], b = i ? c[i - 1] : ~a, ps = pos[i];
+        if (a != b) {
+            const uint32_t p = (uint32_t)ps;
+            pk[p] = a >> gb;
+            pg[p] = (uint32_t)(a & gmask);
+        }
+        if ((a >> gb) != (b >> gb)) {
+            const uint32_t q = (uint32_t)(ps >> 32);
+            tk[q] = a >> gb;
+            seg_off[q] = (uint32_t)ps;
+        }
+    }
+}

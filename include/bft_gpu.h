@@ -146,7 +146,8 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
  * 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain suffix groups, backed by the 2 MiB table; 3, default = 1 or 2,
  * whichever measured faster on the image; 0 = the containers), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
  * root prefix so that every XCD walks its own slices of the index out of its L2: -1 = measured on the first batch of 2^24 queries or more of an image,
- * which makes that one call synchronise; 0 = never; 4..10 = always, with that many bits; answers are identical either way), "reserve_pairs" (room in the insertion log for this many
+ * which makes that one call synchronise; 0 = never; 4..10 = always, with that many bits; answers are identical either way), "build_composite" (1, default: one-word keys whose genome ids arrive ascending and fit the key's spare low bits are sorted as one 8-byte composite
+ * array; 0: the general key + value sort -- same image either way, a test hook), "reserve_pairs" (room in the insertion log for this many
  * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels;
  * off until this option or the first bft_gpu_kernel_time call turns it on), "flat_min" (CCs with at
  * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
