@@ -886,6 +886,40 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         ck.release();
         cg.release();
         // (the insertion log stays until the new image is committed below: a failed build loses nothing)
+        if (W == 1) {
+            // 3'. one-word keys: flags on the fly, one 64-bit scan (as on the composite path)
+            DevBuf tmp, pos;
+            CK(pos.alloc(total * 8));
+            const BftPairFlags2 pf{sk.as<uint64_t>(), sg.as<uint32_t>()};
+            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
+            size_t tb2 = 0;
+            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            CK(tmp.alloc(tb2));
+            HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            uint64_t last_pos = 0, last_k[2] = {0, 0};
+            uint32_t last_g[2] = {0, 0};
+            HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipMemcpyAsync(&last_k[1], sk.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipMemcpyAsync(&last_g[1], sg.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
+            if (total > 1) {
+                HIPCK(hipMemcpyAsync(&last_k[0], sk.as<uint64_t>() + total - 2, 8, hipMemcpyDeviceToHost, h->stream));
+                HIPCK(hipMemcpyAsync(&last_g[0], sg.as<uint32_t>() + total - 2, 4, hipMemcpyDeviceToHost, h->stream));
+            }
+            HIPCK(hipStreamSynchronize(h->stream));
+            const bool last_head = total == 1 || last_k[1] != last_k[0], last_keep = last_head || last_g[1] != last_g[0];
+            nk = (last_pos >> 32) + (last_head ? 1 : 0);
+            np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
+            CK(tk.alloc(nk * 8));
+            CK(seg_off.alloc((nk + 1) * 4));
+            CK(npk.alloc(np * 8));
+            CK(npg.alloc(np * 4));
+            hipLaunchKernelGGL(k_scatter_2, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, sk.as<uint64_t>(), sg.as<uint32_t>(), total, pos.as<uint64_t>(),
+                               npk.as<uint64_t>(), npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+            const uint32_t np32 = (uint32_t)np;
+            HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
+            HIPCK(hipGetLastError());
+            HIPCK(hipStreamSynchronize(h->stream));
+        } else {
         // 3. flags, scans, compaction
         DevBuf head, keep, posK, posP, tmp;
         CK(head.alloc(total * 4));
@@ -918,6 +952,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));
+        }
         }
     }
     double t1 = now_ms();
