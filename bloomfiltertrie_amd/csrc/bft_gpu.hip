@@ -1800,8 +1800,10 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
         case 3: CK(launch_seq_walk_w<3>(h, (uint32_t)ns, canonical, soff, s)); break;
         default: CK(launch_seq_walk_w<4>(h, (uint32_t)ns, canonical, soff, s)); break;
         }
-        hipLaunchKernelGGL(k_seq_tally, dim3((unsigned)std::min<uint64_t>((ns + SEQ_TALLY_WAVES - 1) / SEQ_TALLY_WAVES, 256ull * 16)), dim3(64 * SEQ_TALLY_WAVES), 0, s,
-                           h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, G, rowbytes, threshold, d_rows + a * rowbytes);
+        const uint32_t win = std::min<uint32_t>(SEQ_TALLY_G, (G + 63u) & ~63u);  // counters per wavefront: all genomes up to 2048
+        hipLaunchKernelGGL(k_seq_tally, dim3((unsigned)std::min<uint64_t>((ns + SEQ_TALLY_WAVES - 1) / SEQ_TALLY_WAVES, 256ull * 16)), dim3(64 * SEQ_TALLY_WAVES),
+                           (size_t)SEQ_TALLY_WAVES * win * 4, s, h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, G, rowbytes,
+                           threshold, win, d_rows + a * rowbytes);
         HIPCK(hipGetLastError());
     }
     return 0;

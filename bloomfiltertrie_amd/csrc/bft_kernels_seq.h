@@ -211,22 +211,22 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
 // position, 98 M per 10^6 reads, half of the path's time -- and thresholded it in another pass).  Consecutive k-mers of a read
 // mostly carry the same colour set, so counting works on runs: the 64 lanes hold 64 consecutive positions, run boundaries come
 // from a shuffle + __ballot, and the first lane of every run adds the run length once per genome of the set.  Genomes are
-// handled SEQ_TALLY_G at a time (one pass over the sequence's positions per window: one pass up to 2048 genomes).
+// handled a window at a time (at most SEQ_TALLY_G = 2048, a multiple of 8; one pass over the sequence's positions per window).
 // Row s of `out` (rowbytes bytes): bit g set iff genome g holds at least ceil(npos(s) * threshold) > 0 of the sequence's k-mers
 // (src/bft.c:1281, :1320-1340).
 #define SEQ_TALLY_G 2048u
 #define SEQ_TALLY_WAVES 4
 __global__ __launch_bounds__(64 * SEQ_TALLY_WAVES) void k_seq_tally(const uint32_t* __restrict__ csin, const uint64_t* __restrict__ pos_off, uint32_t n_seqs,
                                                                    const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint32_t G,
-                                                                   uint32_t rowbytes, double threshold, uint8_t* __restrict__ out) {
-    __shared__ uint32_t s_cnt[SEQ_TALLY_WAVES][SEQ_TALLY_G];
+                                                                   uint32_t rowbytes, double threshold, uint32_t win, uint8_t* __restrict__ out) {
+    extern __shared__ uint32_t s_cnt[];  // [SEQ_TALLY_WAVES][win]: win = the genome window, sized by the host (few genomes: more workgroups per CU)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* cnt = s_cnt[wave];
+    uint32_t* cnt = s_cnt + (size_t)wave * win;
     for (uint64_t s = (uint64_t)blockIdx.x * SEQ_TALLY_WAVES + wave; s < n_seqs; s += (uint64_t)gridDim.x * SEQ_TALLY_WAVES) {
         const uint64_t pa = pos_off[s], m = pos_off[s + 1] - pa;
         const uint64_t minv = (uint64_t)(int64_t)ceil((double)m * threshold);  // nb_kmers_query_min
-        for (uint32_t win0 = 0; win0 < G; win0 += SEQ_TALLY_G) {
-            const uint32_t wn = min(SEQ_TALLY_G, G - win0);
+        for (uint32_t win0 = 0; win0 < G; win0 += win) {
+            const uint32_t wn = min(win, G - win0);
             for (uint32_t j = lane; j < wn; j += 64) cnt[j] = 0;
             for (uint64_t base = 0; base < m; base += 64) {  // m is wavefront-uniform: every lane takes every turn
                 const uint32_t cs = base + lane < m ? csin[pa + base + lane] : 0xFFFFFFFFu;
