@@ -8,6 +8,8 @@ an exact index, so presence == set membership and colour set == the genomes that
            10^9 / 8 = 1.25x10^8 presence queries, ALL answers checked, host bitmap == device bitmap on a slice
  config 5  k = 63, 2000 colours x 20 kbp: -query_branching (10^7 k-mers: bit == counts rule, counts vs neighbours'
            membership on a sample), presence of all 10^7, colour rows of 4x10^6 k-mers (1 GB) vs the inserting genomes
+ f-4       sequence queries: 10^6 reads x 150 nt on the 10-genome index, device-resident, per-genome counts of a 2x10^4-read
+           slice against set membership of every k-mer position
 """
 import numpy as np
 import pytest
@@ -181,3 +183,59 @@ def test_config5_branching_and_colour_rows_full_size(torch_dev):
     for i in range(0, nh, 211):
         assert ids[int(off[i]):int(off[i + 1])].tolist() == np.flatnonzero(unp[i]).tolist()
     t.close()
+
+
+def test_sequence_queries_full_size(torch_dev):
+    """SURVEY 8 f-4 at size: 10^6 reads x 150 nt on the 10-genome index, device-resident (bft_gpu_query_sequences_dev).  Ground truth
+    without an oracle: per read and genome, the number of its k-mers that genome holds (set membership of every k-mer position) against
+    ceil(positions x threshold); error-free reads must name their source genome at threshold 1, random reads nobody."""
+    torch, dev = torch_dev
+    import math
+    from bloomfiltertrie_amd import BFT, workloads as W
+    k, ngen, n_reads, rl = 27, 10, 1_000_000, 150
+    pan = W.PanGenome(ngen, 2_000_000, 0.01, 4242, dev)
+    t = BFT(k)
+    keys, _ = W.build_index(t, pan, k)
+    g = _gen(torch, dev, 5)
+    src = torch.randint(0, ngen, (n_reads,), generator=g, device=dev)
+    start = torch.randint(0, 2_000_000 - rl, (n_reads,), generator=g, device=dev)
+    genomes = torch.stack([pan.genome(i) for i in range(ngen)])
+    codes = genomes[src[:, None], start[:, None] + torch.arange(rl, device=dev)[None, :]]
+    n_err = n_reads // 2  # the second half: 2 % substitutions; the last 5 %: random reads
+    err = torch.rand((n_reads, rl), generator=g, device=dev) < 0.02
+    err[:n_reads - n_err] = False
+    codes = torch.where(err, (codes + torch.randint(1, 4, codes.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, codes)
+    n_rand = n_reads // 20
+    codes[n_reads - n_rand:] = torch.randint(0, 4, (n_rand, rl), generator=g, device=dev, dtype=torch.uint8)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    blob = lut[codes.long()].contiguous().reshape(-1)
+    off = (torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * rl).contiguous()
+    rows = torch.zeros((n_reads, 2), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    m = rl - k + 1
+    # ground truth on a slice: membership of every k-mer position in every genome's key table
+    ns = 20_000
+    sel = torch.cat([torch.arange(0, ns // 2, device=dev), torch.arange(n_reads - ns // 2, n_reads, device=dev)])
+    win = codes[sel].unfold(1, k, 1).reshape(-1, k)  # [ns * m, k] codes, first nucleotide first
+    sh = (2 * torch.arange(k, device=dev, dtype=torch.int64))[None, :]
+    qk = (win.to(torch.int64) << sh).sum(dim=1)  # the packed layout: nucleotide j at bits 2j (src/fasta.c:11-23) = keys_of(pack_windows(...))
+    cnt = torch.stack([W.member(keys[gi], qk).reshape(ns, m).sum(dim=1) for gi in range(ngen)], dim=1)  # [ns, ngen]
+    for thr in (1.0, 0.8, 0.3):
+        rows.fill_(0xFF)
+        t.query_sequences_dev(blob.data_ptr(), off.data_ptr(), n_reads, n_reads * rl, thr, rows.data_ptr(), False, st)
+        torch.cuda.synchronize()
+        bits = torch.from_numpy(np.unpackbits(rows.cpu().numpy(), axis=1, bitorder="little")[:, :ngen].astype(bool)).to(dev)
+        need = math.ceil(m * thr)
+        assert bool((bits[sel] == ((cnt >= need) & (cnt > 0))).all()), thr
+        if thr == 1.0:
+            clean = n_reads - n_err
+            assert bool(bits[torch.arange(clean, device=dev), src[:clean]].all())  # an error-free read names its source genome
+        assert not bool(bits[n_reads - n_rand:].any())  # random reads: nobody holds 30 % of their k-mers
+        assert not bool(np.unpackbits(rows.cpu().numpy(), axis=1, bitorder="little")[:, ngen:].any())  # padding bits stay zero
+    # the host-buffer call gives the same rows
+    some = [bytes(b) for b in blob.reshape(n_reads, rl)[:3000].cpu().numpy()]
+    rows.fill_(0)
+    t.query_sequences_dev(blob.data_ptr(), off.data_ptr(), n_reads, n_reads * rl, 0.8, rows.data_ptr(), False, st)
+    torch.cuda.synchronize()
+    dev_lists = [np.flatnonzero(r).tolist() for r in np.unpackbits(rows[:3000].cpu().numpy(), axis=1, bitorder="little")[:, :ngen]]
+    assert t.query_sequences(some, 0.8) == dev_lists
