@@ -576,6 +576,7 @@ static uint64_t image_bytes(const bft_gpu* h) {
 }
 
 static int tune_residency(bft_gpu* h);
+static int ensure_tcolh(bft_gpu* h);
 
 // Points h->im at the device arrays of the handle (cannot fail).
 static void point_image(bft_gpu* h, uint32_t nb_genomes) {
@@ -611,7 +612,8 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
     h->cs_bm_tried = false;
     h->d_cs_bm.release();
-    im.tcolh = nullptr;  // colour set per hashed slot: derived by the first sequence query (ensure_tcolh)
+    im.tcolh = nullptr;  // colour set per hashed slot: derived by the first sequence / colour-row query (ensure_tcolh)
+    im.emit_cs = 0;
     h->tcolh_tried = false;
     h->d_tcolh.release();
     h->tuned_wgs = 0;
@@ -1621,10 +1623,11 @@ static int ensure_cs_bitmaps(bft_gpu* h) {
 }
 
 // d_rowidx: the row of every k-mer (scratch: overwritten with the colour-set ids when the bitmap dictionary is used)
-static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s) {
+static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_t rowbytes, uint8_t* d_out, hipStream_t s, bool are_colorsets = false) {
     CK(ensure_cs_bitmaps(h));
     if (h->has_cs_bm) {
-        hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, n, d_rowidx);  // row -> colour set, in place
+        if (!are_colorsets)
+            hipLaunchKernelGGL(k_row_colorsets, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, n, d_rowidx);  // row -> colour set, in place
         // tiles of ~32 KiB of output (a multiple of 4 k-mers: tiles start dword aligned); magic number of the division by rowbytes
         // (round-up method, exact on u32)
         // (16-byte rows and up, 16-byte aligned output: the 16-bytes-per-lane kernel, whose tiles are a multiple of 16 k-mers)
@@ -1661,8 +1664,17 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
-    CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s));
-    CK(launch_color_rows(h, (uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s));
+    // with the bitmap dictionary the walk writes colour sets straight away (bft_hit_out): no rank gather, no row -> colour set pass
+    CK(ensure_cs_bitmaps(h));
+    const bool direct = h->has_cs_bm;
+    if (direct) {
+        CK(ensure_tcolh(h));
+        h->im.emit_cs = 1;
+    }
+    const int rc = launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s);
+    h->im.emit_cs = 0;
+    CK(rc);
+    CK(launch_color_rows(h, (uint32_t*)d_scratch_rows_u32, n, rowbytes, (uint8_t*)d_rows, s, direct));
     return note_foreign_stream(h, s);
 }
 
@@ -1736,11 +1748,13 @@ static int launch_seq_walk_k(bft_gpu* h, uint32_t ns, int canonical, const uint6
         HIPCK(hipFuncSetAttribute((const void*)k_seq_walk6<W, STAGED, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
+    BftImage im = h->im;
+    im.emit_cs = 1;
     if (W != 2)
-        hipLaunchKernelGGL((k_seq_walk8<W, STAGED, PROBE>), dim3(512), dim3(1024), lds, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
+        hipLaunchKernelGGL((k_seq_walk8<W, STAGED, PROBE>), dim3(512), dim3(1024), lds, s, im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
                            h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
     else
-        hipLaunchKernelGGL((k_seq_walk6<W, STAGED, PROBE>), dim3(512), dim3(BFT_BLOCK6), lds, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
+        hipLaunchKernelGGL((k_seq_walk6<W, STAGED, PROBE>), dim3(512), dim3(BFT_BLOCK6), lds, s, im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff,
                            h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
     HIPCK(hipGetLastError());
     return 0;

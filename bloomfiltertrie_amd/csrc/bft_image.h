@@ -156,6 +156,7 @@ struct BftImage {
     const uint8_t* tkrank;    // [2 * n_kmers] row of a hashed slot, relative to its group's first row
     const uint32_t* tcol;     // [n_kmers] colour-set id per row
     const uint32_t* tcolh;    // [2 * n_kmers] colour-set id per slot of the hashed groups (derived on demand: sequence queries), or NULL
+    uint32_t emit_cs;         // per launch: the query kernels write the colour set of a found k-mer where they otherwise write its row
     const uint64_t* uck;      // [n_uc_rows * W] node-UC rows (T-form)
     const uint32_t* ucrow;    // [n_uc_rows] row of that k-mer in tk
     const uint32_t* cs_off;   // [n_cs + 1] colour-set dictionary (sorted genome ids)

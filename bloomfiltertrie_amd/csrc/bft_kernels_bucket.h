@@ -301,7 +301,7 @@ __device__ __forceinline__ void query_bk_body(const BftImage& im, const uint64_t
                     bft_load_row<W>(trec + p * W, t);
                     const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
                     present = h.present;
-                    if (prow) prow[p] = present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+                    if (prow) prow[p] = present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
                 }
                 const uint64_t mask = __ballot(present);
                 if (lane == 0) pbits[p >> 6] = mask;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
                 bft_tform_from_x<W>(x, im.k, t);
                 const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
                 present = h.present;
-                if (present && rows) row = (uint32_t)bft_hit_row(im, h);
+                if (present && rows) row = bft_hit_out(im, h);
             }
             const uint64_t mask = __ballot(present);
             const uint64_t q0 = i & ~63ull;  // first query of this wavefront
@@ -150,7 +150,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
             const uint64_t i = qbase + q_i[lane];
             const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
             if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
-            if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+            if (rows) rows[i] = h.present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
         }
         qn = 0;
     };
@@ -167,7 +167,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
             if (h.present == BFT_HIT_DEFERRED) parked = true;
             else {
                 present = h.present;
-                if (rows) rows[i] = present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+                if (rows) rows[i] = present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
             }
         }
         const uint64_t mask = __ballot(present);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
                 if (parked) {
                     const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
                     if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
-                    if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(im, h) : BFT_ABSENT_ROW;
+                    if (rows) rows[i] = h.present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
                 }
             } else {
                 if (parked) {

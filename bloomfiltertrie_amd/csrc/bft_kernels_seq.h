@@ -186,7 +186,7 @@ __device__ __forceinline__ void seq_walk_body(const BftImage& im, const uint64_t
         if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
             bft_tform_from_x<W>(x, im.k, t);
             const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
-            if (h.present) cs = (h.gh_slot >= 0 && im.tcolh) ? im.tcolh[h.gh_slot] : im.tcol[bft_hit_row(im, h)];
+            if (h.present) cs = bft_hit_out(im, h);  // (im.emit_cs is set for this launch)
         }
         csout[p] = cs;
     }

@@ -301,6 +301,12 @@ struct BftHit {
 };
 // the row of a found k-mer (one more byte load when it was found through the hashed form: only callers that return rows pay it)
 BFT_HD uint64_t bft_hit_row(const BftImage& im, const BftHit& h) { return h.gh_slot >= 0 ? h.row + im.tkrank[h.gh_slot] : h.row; }
+// what a query kernel writes for a found k-mer: its row, or -- im.emit_cs, the colour-row and sequence paths -- its colour set, which for
+// a hit in the hashed groups is ONE gather (slot -> colour set) instead of three (slot -> rank, row -> colour set in a later pass)
+BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) {
+    if (im.emit_cs) return (h.gh_slot >= 0 && im.tcolh) ? im.tcolh[h.gh_slot] : im.tcol[bft_hit_row(im, h)];
+    return (uint32_t)bft_hit_row(im, h);
+}
 
 // ---- hashed form of the suffix groups (bft_image.h, BFT_GH_*) ----
 BFT_HD bool bft_gh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }
