@@ -6,7 +6,7 @@ set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-final}; mkdir -p "$OUT"
 strip() { grep -v "amdgpu.ids" ; }
 python3 bench.py --steps 20 --warmup 5 2> "$OUT/bench.err" | strip > "$OUT/bench.json"
-( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/bench_trace" -o t -- python3 "$ROOT/bench.py" --steps 12 --warmup 3 --no-cpu-baseline --no-pcie > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err" )
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/bench_trace" -o t -- python3 "$ROOT/bench.py" --steps 12 --warmup 3 --no-pcie > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err" )
 python3 profiles/summarize_rocpd.py "$(find "$OUT/bench_trace" -name '*.db' | head -1)" > "$OUT/bench_kernel_stats.txt" 2>&1
 rm -rf "$OUT/bench_trace"
 bash tools/pmc_collect.sh cfg2 100000000 3 > "$OUT/pmc_cfg2.log" 2>&1; cp gpurun_out/pmc/cfg2/pmc_traffic.json "$OUT/pmc_k_query_config2.json"
