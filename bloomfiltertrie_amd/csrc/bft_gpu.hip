@@ -810,6 +810,62 @@ static int host_colorsets(bft_gpu* h) {
     return 0;
 }
 
+// One-word keys, sorted, with their genome ids (GT wide): flags on the fly, one 64-bit scan, scatter into the pair store, the
+// distinct-k-mer table and the segment offsets (bft_kernels_build.h).
+template <class GT>
+static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npk, DevBuf& npg, uint64_t& nk,
+                     uint64_t& np) {
+    DevBuf tmp, pos;
+    CK(pos.alloc(total * 8));
+    const BftPairFlags2<GT> pf{sk, sg};
+    auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
+    size_t tb2 = 0;
+    HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+    CK(tmp.alloc(tb2));
+    HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+    uint64_t last_pos = 0, last_k[2] = {0, 0};
+    GT last_g[2] = {0, 0};
+    HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(&last_k[1], sk + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(&last_g[1], sg + total - 1, sizeof(GT), hipMemcpyDeviceToHost, h->stream));
+    if (total > 1) {
+        HIPCK(hipMemcpyAsync(&last_k[0], sk + total - 2, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(&last_g[0], sg + total - 2, sizeof(GT), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCK(hipStreamSynchronize(h->stream));
+    const bool last_head = total == 1 || last_k[1] != last_k[0], last_keep = last_head || last_g[1] != last_g[0];
+    nk = (last_pos >> 32) + (last_head ? 1 : 0);
+    np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
+    CK(tk.alloc(nk * 8));
+    CK(seg_off.alloc((nk + 1) * 4));
+    CK(npk.alloc(np * 8));
+    CK(npg.alloc(np * 4));
+    hipLaunchKernelGGL(k_scatter_2<GT>, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, sk, sg, total, pos.as<uint64_t>(), npk.as<uint64_t>(),
+                       npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+    const uint32_t np32 = (uint32_t)np;
+    HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+// Stable sort of ordered one-word keys with their ids narrowed to GT (values through a transform iterator over the log), then dedupe_w1.
+template <class GT>
+static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npk, DevBuf& npg,
+                                 uint64_t& nk, uint64_t& np) {
+    DevBuf sk, sg, tmp;
+    CK(sk.alloc(total * 8));
+    CK(sg.alloc(total * sizeof(GT)));
+    const BftNarrowIds<GT> nar{src_g};
+    auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
+    size_t tb = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
+    CK(tmp.alloc(tb));
+    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
+    HIPCK(hipGetLastError());
+    tmp.release();
+    return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npk, npg, nk, np);
+}
+
 extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
@@ -880,6 +936,13 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
             HIPCK(hipGetLastError());
             HIPCK(hipStreamSynchronize(h->stream));
+        } else if (W == 1 && h->log_g_sorted && h->max_gid_seen < 65536 && !h->opt_no_composite) {
+            // 2n + 3'. ordered one-word keys whose composite does not fit (k = 31 with more than a few genomes): key + value sort with the
+            // ids narrowed to one or two bytes (the values are a third of the sort's traffic at four)
+            if (h->max_gid_seen < 256) CK(sort_dedupe_w1_narrow<uint8_t>(h, src_k, src_g, total, tk, seg_off, npk, npg, nk, np));
+            else CK(sort_dedupe_w1_narrow<uint16_t>(h, src_k, src_g, total, tk, seg_off, npk, npg, nk, np));
+            ck.release();
+            cg.release();
         } else {
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
@@ -890,37 +953,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         // (the insertion log stays until the new image is committed below: a failed build loses nothing)
         if (W == 1) {
             // 3'. one-word keys: flags on the fly, one 64-bit scan (as on the composite path)
-            DevBuf tmp, pos;
-            CK(pos.alloc(total * 8));
-            const BftPairFlags2 pf{sk.as<uint64_t>(), sg.as<uint32_t>()};
-            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
-            size_t tb2 = 0;
-            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-            CK(tmp.alloc(tb2));
-            HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-            uint64_t last_pos = 0, last_k[2] = {0, 0};
-            uint32_t last_g[2] = {0, 0};
-            HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCK(hipMemcpyAsync(&last_k[1], sk.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCK(hipMemcpyAsync(&last_g[1], sg.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
-            if (total > 1) {
-                HIPCK(hipMemcpyAsync(&last_k[0], sk.as<uint64_t>() + total - 2, 8, hipMemcpyDeviceToHost, h->stream));
-                HIPCK(hipMemcpyAsync(&last_g[0], sg.as<uint32_t>() + total - 2, 4, hipMemcpyDeviceToHost, h->stream));
-            }
-            HIPCK(hipStreamSynchronize(h->stream));
-            const bool last_head = total == 1 || last_k[1] != last_k[0], last_keep = last_head || last_g[1] != last_g[0];
-            nk = (last_pos >> 32) + (last_head ? 1 : 0);
-            np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
-            CK(tk.alloc(nk * 8));
-            CK(seg_off.alloc((nk + 1) * 4));
-            CK(npk.alloc(np * 8));
-            CK(npg.alloc(np * 4));
-            hipLaunchKernelGGL(k_scatter_2, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, sk.as<uint64_t>(), sg.as<uint32_t>(), total, pos.as<uint64_t>(),
-                               npk.as<uint64_t>(), npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
-            const uint32_t np32 = (uint32_t)np;
-            HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
-            HIPCK(hipGetLastError());
-            HIPCK(hipStreamSynchronize(h->stream));
+            CK(dedupe_w1<uint32_t>(h, sk.as<uint64_t>(), sg.as<uint32_t>(), total, tk, seg_off, npk, npg, nk, np));
         } else {
         // 3. flags, scans, compaction
         DevBuf head, keep, posK, posP, tmp;

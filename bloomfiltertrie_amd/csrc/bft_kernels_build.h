@@ -77,25 +77,33 @@ __global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_
     }
 }
 
-// The same on-the-fly flags for sorted one-word keys with their genome ids in a second array (the general sort's output).
+// The same on-the-fly flags for sorted one-word keys with their genome ids in a second array (the general sort's output).  GT: the
+// width the ids were sorted at (uint8_t / uint16_t when every id fits: the values are a third of the sort's traffic at 4 bytes).
+template <class GT>
+struct BftNarrowIds {  // value "iterator" of that sort: genome id i of the log, narrowed
+    const uint32_t* g;
+    __host__ __device__ GT operator()(uint32_t i) const { return (GT)g[i]; }
+};
+template <class GT>
 struct BftPairFlags2 {
     const uint64_t* k;
-    const uint32_t* g;
+    const GT* g;
     __host__ __device__ uint64_t operator()(uint32_t i) const {
         const uint64_t head = i == 0 || k[i] != k[i - 1], keep = head || g[i] != g[i - 1];
         return (head << 32) | keep;
     }
 };
-__global__ void k_scatter_2(const uint64_t* __restrict__ k, const uint32_t* __restrict__ g, uint64_t n, const uint64_t* __restrict__ pos,
+template <class GT>
+__global__ void k_scatter_2(const uint64_t* __restrict__ k, const GT* __restrict__ g, uint64_t n, const uint64_t* __restrict__ pos,
                             uint64_t* __restrict__ pk, uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t a = k[i], ps = pos[i];
-        const uint32_t ga = g[i];
+        const GT ga = g[i];
         const bool head = i == 0 || a != k[i - 1], keep = head || ga != g[i - 1];
         if (keep) {
             const uint32_t p = (uint32_t)ps;
             pk[p] = a;
-            pg[p] = ga;
+            pg[p] = (uint32_t)ga;
         }
         if (head) {
             const uint32_t q = (uint32_t)(ps >> 32);

@@ -195,7 +195,7 @@ def test_flat_form_matches_host_restatement(hostlib, flat_min):
         hostlib.bft_hosttest_free(h)
 
 
-@pytest.mark.parametrize("k,ngen", [(27, 3), (27, 130), (31, 2), (31, 4), (18, 40)])
+@pytest.mark.parametrize("k,ngen", [(27, 3), (27, 130), (31, 2), (31, 4), (31, 300), (18, 40)])
 def test_composite_sort_builds_the_same_image(k, ngen):
     """One-word keys with ascending genome ids are sorted as (T << bits | genome) composites when that fits 63 bits
     ("build_composite" 1, the default) and by the general key + value sort otherwise: every array of the image, the colour sets
