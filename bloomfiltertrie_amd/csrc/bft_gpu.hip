@@ -242,6 +242,7 @@ struct bft_gpu {
     // last work the *_dev entry points put on a caller's stream: image arrays are not released or rewritten before it is done
     hipEvent_t ext_ev = nullptr;
     bool ext_pending = false;
+    hipStream_t ext_stream = nullptr;  // the stream ext_ev was last recorded on
     uint32_t root_ncc = 0;
     uint64_t idx_sizes[9] = {0};
     int opt_wgs_per_cu = 0;   // k_query residency: 1 / 2 workgroups of 1024 threads per CU, 3 = two of 768, 0 = measured when the image is bound (tune_residency)
@@ -285,8 +286,11 @@ struct DeviceScope {
 static int note_foreign_stream(bft_gpu* h, hipStream_t s) {
     if (s == h->stream) return 0;
     if (!h->ext_ev) HIPCK(hipEventCreateWithFlags(&h->ext_ev, hipEventDisableTiming));
+    // one event: a caller that alternates between streams has the earlier stream's work drained here, before the event moves on
+    if (h->ext_pending && h->ext_stream != s) HIPCK(hipEventSynchronize(h->ext_ev));
     HIPCK(hipEventRecord(h->ext_ev, s));
     h->ext_pending = true;
+    h->ext_stream = s;
     return 0;
 }
 // Before image arrays are released, rewritten or re-derived: the queries the caller still has in flight must have drained.

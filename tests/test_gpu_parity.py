@@ -599,3 +599,37 @@ def test_hashed_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_
         ob, oc, _ = o2.query_branching(q[:20000])
         assert (bb == ob).all() and (bc == oc).all()
     t.close()
+
+
+def test_queries_on_two_caller_streams_around_a_rebuild():
+    """*_dev calls on two different caller streams, nothing synchronised by the caller, then an insertion + rebuild (which releases the
+    image arrays the queries read) and set_option calls that re-derive tables: every bitmap still equals ground truth."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(400000, 31), k))
+    half = len(km) // 2
+    t = BFT(k)
+    t.insert_kmers(np.ascontiguousarray(km[:half]), 0)
+    t.build()
+    dev = torch.device("cuda", 0)
+    q = np.ascontiguousarray(np.concatenate([km, S.snp_mutants(km[::4], k, 9)]))
+    dq = torch.from_numpy(q).to(dev)
+    n = len(q)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = [torch.zeros(((n + 63) // 64) * 8, dtype=torch.uint8, device=dev) for _ in range(6)]
+    torch.cuda.synchronize()
+    for i in range(4):
+        t.query_presence_dev(dq.data_ptr(), n, outs[i].data_ptr(), (s1 if i % 2 == 0 else s2).cuda_stream)
+    t.insert_kmers(np.ascontiguousarray(km[half:]), 1)  # the next query rebuilds
+    t.query_presence_dev(dq.data_ptr(), n, outs[4].data_ptr(), s2.cuda_stream)
+    t.set_option("node_hash", 0)
+    t.set_option("root_direct", 1)
+    t.query_presence_dev(dq.data_ptr(), n, outs[5].data_ptr(), s1.cuda_stream)
+    torch.cuda.synchronize()
+    first = S.member(q, S.distinct(km[:half]))
+    both = S.member(q, km)
+    for i in range(4):
+        assert (S.from_bits(outs[i].cpu().numpy(), n).astype(bool) == first).all(), i
+    for i in (4, 5):
+        assert (S.from_bits(outs[i].cpu().numpy(), n).astype(bool) == both).all(), i
