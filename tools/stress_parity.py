@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end check against ground truth kept in Python dictionaries: random k, genome counts, insertion orders (ascending /
+shuffled ids, duplicate batches, incremental rebuilds), then presence, colour sets, colour rows (host and device calls), sequence
+queries (host and device calls) -- across the build paths (composite / narrow-id / general sort) and the derived tables.
+usage: stress_parity.py [rounds] [seed]"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from bloomfiltertrie_amd import BFT, synth as S, _lib as L  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+for r in range(rounds):
+    rng = np.random.default_rng(seed0 * 1000 + r)
+    k = int(rng.choice([13, 18, 21, 27, 27, 31, 31, 36, 45, 63]))
+    ngen = int(rng.choice([1, 2, 4, 5, 9, 40, 130, 300]))
+    glen = int(rng.integers(3000, 30000))
+    deep = min(int(rng.integers(0, 3)), max(0, k // 9 - 1))
+    if deep:
+        base = S.low_entropy_kmers(glen, k, 12, seed=r + 7, levels=deep)
+        s = None
+    else:
+        g = S.random_genome(glen, 100 + r)
+        s = "".join("ACGT"[c] for c in g)
+        base = S.distinct(S.kmers_of(g, k))
+    nb = len(base)
+    member = rng.random((ngen, nb)) < rng.uniform(0.05, 0.9)
+    member[int(rng.integers(0, ngen)), :] |= rng.random(nb) < 0.5
+    order = np.arange(ngen)
+    shuffled = bool(rng.random() < 0.3)
+    if shuffled:
+        rng.shuffle(order)
+    t = BFT(k)
+    if rng.random() < 0.3:
+        t.set_option("group_hash", 0)
+    if rng.random() < 0.3:
+        t.set_option("build_composite", 0)
+    cut = int(rng.integers(0, ngen + 1))
+    for j, gi in enumerate(order):
+        if j == cut:
+            t.build()  # incremental: the sorted store is merged with the log of the rest
+        rows_g = np.ascontiguousarray(base[member[gi]])
+        if len(rows_g):
+            t.insert_kmers(rows_g, int(gi))
+            if rng.random() < 0.2:
+                t.insert_kmers(np.ascontiguousarray(rows_g[::3]), int(gi))  # duplicates
+    present_any = member.any(axis=0)
+    q = np.concatenate([base, S.snp_mutants(base[::3], k, r + 1)])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    pos = {key: i for i, key in enumerate(S.row_keys(base).tolist())}
+    idx = np.array([pos.get(key, -1) for key in S.row_keys(q).tolist()])
+    exp_pres = (idx >= 0) & present_any[np.maximum(idx, 0)]
+    bits, off, ids = t.query_colors(q)
+    pres = S.from_bits(bits, len(q)).astype(bool)
+    assert (pres == exp_pres).all(), ("presence", r, k, ngen)
+    for i in rng.integers(0, len(q), 300):
+        exp = np.flatnonzero(member[:, idx[i]]).tolist() if exp_pres[i] else []
+        assert ids[int(off[i]):int(off[i + 1])].tolist() == exp, ("colours", r, k, ngen, i)
+    exp_rows = np.zeros((len(q), ngen), dtype=np.uint8)
+    exp_rows[exp_pres] = member[:, idx[exp_pres]].T
+    b2, rows = t.query_color_rows(q)
+    assert (np.unpackbits(rows, axis=1, bitorder="little")[:, :ngen] == exp_rows).all(), ("rows host", r, k, ngen)
+    dq = torch.from_numpy(q).to(dev)
+    dbits = torch.zeros(((len(q) + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+    drows = torch.zeros((len(q), (ngen + 7) // 8), dtype=torch.uint8, device=dev)
+    dscr = torch.zeros(len(q), dtype=torch.int32, device=dev)
+    L.check(t._lib.bft_gpu_query_color_rows_dev(t._h, dq.data_ptr(), len(q), dbits.data_ptr(), drows.data_ptr(), dscr.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert (np.unpackbits(drows.cpu().numpy(), axis=1, bitorder="little")[:, :ngen] == exp_rows).all(), ("rows dev", r, k, ngen)
+    assert (S.from_bits(dbits.cpu().numpy(), len(q)).astype(bool) == exp_pres).all()
+    assert (S.from_bits(t.query_presence(q), len(q)).astype(bool) == exp_pres).all()  # (after the colour-set launch: rows mode is back)
+    b3, rws, sets = t.query_rows(q)
+    ek, ecs = t.extract()
+    assert (ek[rws[exp_pres]] == q[exp_pres]).all() and (ecs[rws[exp_pres]] == sets[exp_pres]).all(), ("rows", r, k, ngen)
+    if s is not None:
+        reads, spans = [], []
+        for _ in range(40):
+            a = int(rng.integers(0, glen - 200))
+            n = int(rng.integers(max(1, k - 2), 200))
+            reads.append(s[a:a + n])
+            spans.append((a, max(0, n - k + 1)))
+        thr = float(rng.choice([0.2, 0.75, 1.0]))
+        got = t.query_sequences(reads, thr)
+        kpos = np.array([pos[key] for key in S.row_keys(S.kmers_of(g, k)).tolist()])  # position in the genome -> row of base
+        for (a, m), gl in zip(spans, got):
+            cnt = member[:, kpos[a:a + m]].sum(axis=1) if m else np.zeros(ngen, dtype=int)
+            assert gl == np.flatnonzero((cnt >= math.ceil(m * thr)) & (cnt > 0)).tolist(), ("sequences", r, k, ngen)
+        enc = [x.encode() for x in reads]
+        offs = np.zeros(len(enc) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(e) for e in enc])
+        d_blob = torch.from_numpy(np.frombuffer(b"".join(enc), dtype=np.uint8).copy()).to(dev)
+        d_off = torch.from_numpy(offs).to(dev)
+        d_r = torch.zeros((len(enc), (ngen + 7) // 8), dtype=torch.uint8, device=dev)
+        t.query_sequences_dev(d_blob.data_ptr(), d_off.data_ptr(), len(enc), int(offs[-1]), thr, d_r.data_ptr(), False, st)
+        torch.cuda.synchronize()
+        unp = np.unpackbits(d_r.cpu().numpy(), axis=1, bitorder="little")[:, :ngen]
+        assert [np.flatnonzero(x).tolist() for x in unp] == got, ("sequences dev", r, k, ngen)
+    info = t.info()
+    assert info["kmers"] == int(present_any.sum())
+    print(f"round {r}: k={k} genomes={ngen} kmers={info['kmers']} deep={deep} shuffled={shuffled} cut={cut} ok", flush=True)
+    t.close()
+print("stress OK")
