@@ -26,6 +26,7 @@ SIGNATURES = {
     "bft_gpu_genome_name": (C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_uint32]),
     "bft_gpu_insert_kmers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
     "bft_gpu_insert_kmers_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
+    "bft_gpu_insert_kmers_dev_async": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P]),
     "bft_gpu_build": (C.c_int, [_P]),
     "bft_gpu_query_presence": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "bft_gpu_query_presence_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),

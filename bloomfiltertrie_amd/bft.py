@@ -121,6 +121,10 @@ class BFT:
     def insert_kmers_dev(self, d_ptr, n, id_genome):
         _lib.check(self._lib.bft_gpu_insert_kmers_dev(self._h, d_ptr, n, id_genome))
 
+    def insert_kmers_dev_async(self, d_ptr, n, id_genome, stream):
+        """insert_kmers_dev, stream-ordered on the caller's HIP stream (raw handle; None / 0 = the null stream): returns at once."""
+        _lib.check(self._lib.bft_gpu_insert_kmers_dev_async(self._h, d_ptr, n, id_genome, stream))
+
     def insert_kmers_new_genome(self, kmers_ascii, genome_name):
         """insert_kmers_new_genome(nb_kmers, kmers, genome_name, bft) (include/bft.h:72)."""
         gid = self.add_genome(genome_name)

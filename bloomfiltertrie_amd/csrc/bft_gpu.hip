@@ -439,35 +439,44 @@ static int log_reserve(bft_gpu* h, uint64_t need) {
 }
 
 template <int W>
-static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid) {
+static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid, hipStream_t s) {
     const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
-    hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), 0, h->stream, d_packed, n, h->B,
+    hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), 0, s, d_packed, n, h->B,
                        h->k, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
     HIPCK(hipGetLastError());
     return 0;
 }
 
-extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome) {
+// insertKmers on a device-resident batch.  !ordered: on the handle's stream, synchronised before returning (the caller may
+// reuse d_kmers at once).  ordered: stream-ordered on the caller's stream s (NULL = the null stream): nothing waits; the build waits for s.
+static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome, hipStream_t s, bool ordered) {
     if (!h || (!d_kmers && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (id_genome >= BFT_MAX_GENOME_ID) return fail(BFT_GPU_E_ARG, "id_genome out of range (must be below 2^24)");
     if (n == 0) return BFT_GPU_OK;
     ENTER(h);
     if (h->log_n + n + h->n_pairs >= 0x7FFFFFFFull) return fail(BFT_GPU_E_LIMIT, "more than 2^31-1 (k-mer, genome) pairs");
+    if (h->log_n + n > h->log_cap) CK(wait_foreign_stream(h));  // the log is about to move: batches still being packed into it finish first
     CK(log_reserve(h, h->log_n + n));
+    const hipStream_t run = ordered ? s : h->stream;
     const uint8_t* p = (const uint8_t*)d_kmers;
     switch (h->W) {
-    case 1: CK(launch_pack<1>(h, p, n, id_genome)); break;
-    case 2: CK(launch_pack<2>(h, p, n, id_genome)); break;
-    case 3: CK(launch_pack<3>(h, p, n, id_genome)); break;
-    default: CK(launch_pack<4>(h, p, n, id_genome)); break;
+    case 1: CK(launch_pack<1>(h, p, n, id_genome, run)); break;
+    case 2: CK(launch_pack<2>(h, p, n, id_genome, run)); break;
+    case 3: CK(launch_pack<3>(h, p, n, id_genome, run)); break;
+    default: CK(launch_pack<4>(h, p, n, id_genome, run)); break;
     }
-    HIPCK(hipStreamSynchronize(h->stream));
+    if (ordered) CK(note_foreign_stream(h, s));
+    else HIPCK(hipStreamSynchronize(h->stream));
     if ((h->log_n > 0 && id_genome < h->log_last_gid) || (h->store_any && id_genome < h->store_max_gid)) h->log_g_sorted = false;
     h->log_last_gid = id_genome;
     h->log_n += n;
     h->max_gid_seen = std::max(h->max_gid_seen, id_genome);
     h->any_insert = true;
     return BFT_GPU_OK;
+}
+extern "C" int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome) { return insert_dev(h, d_kmers, n, id_genome, nullptr, false); }
+extern "C" int bft_gpu_insert_kmers_dev_async(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_genome, void* hip_stream) {
+    return insert_dev(h, d_kmers, n, id_genome, (hipStream_t)hip_stream, true);
 }
 
 extern "C" int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint32_t id_genome) {
@@ -874,6 +883,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
     if (h->built && h->log_n == 0) return BFT_GPU_OK;
+    CK(wait_foreign_stream(h));  // batches still being packed into the log on a caller's stream (bft_gpu_insert_kmers_dev_async)
     const int W = h->W;
     const uint64_t total = h->n_pairs + h->log_n;
     double t0 = now_ms();
@@ -1390,7 +1400,7 @@ static int tune_residency(bft_gpu* h) {
             continue;
         h->tuned_wgs = wgs;
         h->im.probe_big = probe == 8;
-        for (int rep = 0; rep < 3 && rc == 0; rep++) {  // the first repetition warms the caches, the faster of the next two counts
+        for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second counts (large batches measure again: launch_query)
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
             if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");

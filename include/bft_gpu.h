@@ -66,6 +66,11 @@ int bft_gpu_genome_name(bft_gpu* h, uint32_t id_genome, char* out, uint32_t cap)
  * `kmers` is a HOST pointer; the _dev variant takes a DEVICE pointer to the same layout. */
 int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint32_t id_genome);
 int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, uint32_t id_genome);
+/* The same, stream-ordered on the caller's stream (NULL = the null stream): the batch is converted by a kernel enqueued on hip_stream and the
+ * call returns at once -- d_kmers follows stream semantics (it may be reused by later work on hip_stream, not before);
+ * bft_gpu_build (or the first query) waits for hip_stream.  A series of insertions costs its kernels, not a host
+ * round trip per call. */
+int bft_gpu_insert_kmers_dev_async(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, uint32_t id_genome, void* hip_stream);
 
 /* Bulk construction of the device image from everything inserted so far: GPU radix sort +
  * de-duplication of (k-mer, genome) pairs, colour-set interning, container assembly.

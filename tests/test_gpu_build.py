@@ -226,6 +226,51 @@ def test_composite_sort_builds_the_same_image(k, ngen):
     assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
 
 
+def test_stream_ordered_inserts_build_the_same_image():
+    """bft_gpu_insert_kmers_dev_async: batches converted on the caller's stream without a host round trip per call (their buffers
+    released to the caching allocator right away, the log growing by doubling in between) give the image of the synchronised calls."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k, ngen = 27, 24
+    dev = torch.device("cuda", 0)
+    base = S.distinct(S.kmers_of(S.random_genome(120000, 17), k))
+    rng = np.random.default_rng(4)
+    parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.4]) for _ in range(ngen)]
+    imgs = []
+    for mode in ("sync", "async"):
+        t = BFT(k)
+        side = torch.cuda.Stream(device=dev)
+        for g, part in enumerate(parts):
+            if mode == "sync":
+                d = torch.from_numpy(part).to(dev)
+                torch.cuda.synchronize()
+                t.insert_kmers_dev(d.data_ptr(), len(part), g)
+            else:
+                with torch.cuda.stream(side):
+                    d = torch.from_numpy(part).to(dev, non_blocking=False)
+                    t.insert_kmers_dev_async(d.data_ptr(), len(part), g, side.cuda_stream)
+                    d.record_stream(side)
+                    del d
+                    junk = torch.randint(0, 255, (len(part) * 7,), dtype=torch.uint8, device=dev)  # reuses the freed block, stream-ordered
+                    del junk
+        t.build()
+        ek, ecs = t.extract()
+        imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs))
+        t.close()
+    for name in ARRAYS:
+        assert (imgs[0][0][name] == imgs[1][0][name]).all(), name
+    assert (imgs[0][1] == imgs[1][1]).all() and (imgs[0][2] == imgs[1][2]).all()
+    # the null stream is a stream too (torch's default): same image again
+    t = BFT(k)
+    for g, part in enumerate(parts):
+        d = torch.from_numpy(part).to(dev)
+        t.insert_kmers_dev_async(d.data_ptr(), len(part), g, None)
+        del d
+    t.build()
+    for name in ARRAYS:
+        assert (imgs[0][0][name] == t.debug_array(name)).all(), name
+
+
 def test_failed_build_leaves_the_previous_image_and_the_pending_insertions_intact():
     """bft_gpu_build is all-or-nothing: a failure after sorting, colour interning and assembly -- injected right
     before the commit point -- must leave the old image answering as before and the pending k-mers in the log; the next
