@@ -123,6 +123,7 @@ def build_index(bft, pan, k, on_insert=None):
     """insertKmers genome by genome (ids ascending, device-resident batches), then the bulk build.  Returns the list of
     sorted distinct key tables, one per genome (the ground truth of presence and of colour sets) and the number of
     k-mer windows handed to the library."""
+    import torch
     keys = []
     n_in = 0
     for gid in range(pan.n):
@@ -130,7 +131,8 @@ def build_index(bft, pan, k, on_insert=None):
         if on_insert is not None:
             on_insert(gid, packed)
         else:
-            bft.insert_kmers_dev(packed.data_ptr(), packed.shape[0], gid)
+            # stream-ordered on torch's current stream: `packed` may go back to the caching allocator right away
+            bft.insert_kmers_dev_async(packed.data_ptr(), packed.shape[0], gid, torch.cuda.current_stream().cuda_stream)
         n_in += packed.shape[0]
         keys.append(unique_keys(keys_of(packed)))
         del packed
