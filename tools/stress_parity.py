@@ -43,12 +43,18 @@ for r in range(rounds):
     if rng.random() < 0.3:
         t.set_option("build_composite", 0)
     cut = int(rng.integers(0, ngen + 1))
+    use_async = bool(rng.random() < 0.4)
     for j, gi in enumerate(order):
         if j == cut:
             t.build()  # incremental: the sorted store is merged with the log of the rest
         rows_g = np.ascontiguousarray(base[member[gi]])
         if len(rows_g):
-            t.insert_kmers(rows_g, int(gi))
+            if use_async:  # stream-ordered device insert: the tensor goes back to the allocator at once
+                d_rows_g = torch.from_numpy(rows_g).to(dev)
+                t.insert_kmers_dev_async(d_rows_g.data_ptr(), len(rows_g), int(gi), st)
+                del d_rows_g
+            else:
+                t.insert_kmers(rows_g, int(gi))
             if rng.random() < 0.2:
                 t.insert_kmers(np.ascontiguousarray(rows_g[::3]), int(gi))  # duplicates
     present_any = member.any(axis=0)
@@ -104,6 +110,6 @@ for r in range(rounds):
         assert [np.flatnonzero(x).tolist() for x in unp] == got, ("sequences dev", r, k, ngen)
     info = t.info()
     assert info["kmers"] == int(present_any.sum())
-    print(f"round {r}: k={k} genomes={ngen} kmers={info['kmers']} deep={deep} shuffled={shuffled} cut={cut} ok", flush=True)
+    print(f"round {r}: k={k} genomes={ngen} kmers={info['kmers']} deep={deep} shuffled={shuffled} cut={cut} async={use_async} ok", flush=True)
     t.close()
 print("stress OK")
