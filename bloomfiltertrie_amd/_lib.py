@@ -42,6 +42,7 @@ SIGNATURES = {
     "bft_gpu_debug_get_array": (C.c_int, [_P, C.c_char_p, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bft_gpu_query_color_rows_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
     "bft_gpu_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
+    "bft_gpu_footprint": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "bft_gpu_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "bft_gpu_build_time": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
     "bft_gpu_extract": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -239,9 +239,18 @@ class BFT:
     def build_time(self):
         out = (C.c_double * 20)()
         _lib.check(self._lib.bft_gpu_build_time(self._h, out, 20))
-        return dict(zip(["gpu_sort_dedupe_ms", "color_intern_ms", "assemble_ms", "bookkeeping_ms", "derive_and_tune_ms",
-                         "query_wgs_per_cu", "tune_1wg_ms", "tune_2wg_ms", "query_probe_rows", "query_bucket_bits", "bucket_tune_plain_ms",
-                         "bucket_tune_bucketed_ms", "hashed_groups", "unhashed_groups", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms"], list(out)))
+        return dict(zip(["gpu_sort_dedupe_ms", "color_intern_ms", "assemble_ms", "bookkeeping_ms", "derive_ms",
+                         "query_wgs_per_cu", "tune_1wg_ms", "tune_2wg_ms", "query_probe_rows", "kmer_hash_lines", "kmer_hash_fill_ms",
+                         "_r11", "_r12", "_r13", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms"], list(out)))
+
+    FOOTPRINT_FIELDS = ["kmer_table", "colorset_per_kmer", "colorset_dictionary", "containers", "flat_ccs", "root_tables", "node_prefix_hash", "kmer_hash",
+                        "dictionary_bitmaps", "hash_table", "pair_store", "insertion_log"]
+
+    def footprint(self):
+        """Bytes in HBM per part of the handle (bft_gpu_footprint; src/printMemory.c:255 reports the reference's by container kind)."""
+        out = (C.c_uint64 * 12)()
+        _lib.check(self._lib.bft_gpu_footprint(self._h, out, 12))
+        return dict(zip(self.FOOTPRINT_FIELDS, [int(x) for x in out]))
 
     def debug_array(self, name, dtype=np.uint8):
         n = C.c_uint64()

@@ -326,103 +326,6 @@ __global__ void k_entries(const uint64_t* __restrict__ skey, const uint32_t* __r
     }
 }
 
-// Hashed form of the suffix groups of one depth (BFT_GH_*).  k_gh_flags marks the prefixes that own a group of BFT_GH_MIN..
-// BFT_GH_MAX rows, k_gh_list compacts them, k_group_hash builds them, one per 32-lane half of a wavefront: the rows are loaded
-// coalesced (32 at a time), then placed one after the other -- lane l looks at slot l % 4 of the (l / 4)-th bucket of the row's
-// probe sequence, a ballot finds the first free one -- which is exactly the order of bft_gh_build_group (the host restatement:
-// arrays bit-identical).  stats[1] += groups left unhashed.
-__global__ void k_gh_flags(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ pref_cnt,
-                           const uint32_t* __restrict__ pend, uint32_t P, uint32_t* __restrict__ flag) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x)
-        flag[q] = ((uint32_t)(skey[q] & 0x1FFFFu) != 0 && !pend[q] && bft_gh_group(pref_cnt[sp[q]])) ? 1u : 0u;  // UC prefixes and child nodes own no group
-}
-__global__ void k_gh_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ sp,
-                          const uint32_t* __restrict__ pref_row, const uint32_t* __restrict__ pref_cnt, uint32_t P, uint2* __restrict__ list) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x)
-        if (flag[q]) list[pos[q]] = make_uint2(pref_row[sp[q]], pref_cnt[sp[q]]);
-}
-#define GH_WAVES 4  // wavefronts per workgroup; every wavefront builds TWO groups at a time, one per 32-lane half
-template <int W>
-__global__ __launch_bounds__(64 * GH_WAVES) void k_group_hash(const uint64_t* __restrict__ tk, const uint2* __restrict__ list, uint32_t n_groups,
-                                                              uint64_t* __restrict__ tkh, uint8_t* __restrict__ tkrank, unsigned long long* __restrict__ stats) {
-    // Where a row goes depends only on which slots are taken, not on what they hold: the group's state is an occupancy bitmap
-    // (512 slots = 16 dwords, in LDS) and the rows go straight to their slot in HBM (the arrays arrive filled with BFT_GH_EMPTY / 0).
-    // A probe sequence is at most 8 buckets x 4 slots = 32 lanes, so a wavefront carries two groups.  (The version that staged
-    // the whole region in LDS -- 4.5 KB per group -- held 35 groups per CU and one per wavefront: 4.4 ms on config 3.)
-    __shared__ uint32_t s_occ[GH_WAVES][2][16];
-    __shared__ uint16_t s_slot[GH_WAVES][64];  // slot (inside the region) each row of the current 32-row chunk went to
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, half = lane >> 5, hl = lane & 31u;
-    uint32_t* occ = s_occ[wave][half];
-    const uint32_t n_pairs = (n_groups + 1u) / 2u;
-    for (uint32_t gp = blockIdx.x * GH_WAVES + wave; gp < n_pairs; gp += gridDim.x * GH_WAVES) {
-        const uint32_t g = 2u * gp + half;
-        const bool have = g < n_groups;
-        const uint64_t idx = have ? list[g].x : 0;
-        const uint32_t cnt = have ? list[g].y : 0;
-        uint64_t b0 = 0;
-        uint32_t nbk = 1;
-        if (have) bft_gh_region(idx, cnt, &b0, &nbk);
-        if (hl < 16) occ[hl] = 0;
-        // wavefront-uniform trip count, told so: a loop bound the compiler takes for divergent turns every v_readlane below into a
-        // waterfall loop (the first wavefront version of this kernel ran 6x slower for it)
-        const uint32_t cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)max(__shfl(cnt, 0), __shfl(cnt, 32)));
-        bool gave_up = false;
-        for (uint32_t base = 0; base < cmax; base += 32) {
-            uint64_t t[W];
-            uint32_t home = 0;
-            if (base + hl < cnt) {
-#pragma unroll
-                for (int w = 0; w < W; w++) t[w] = tk[(idx + base + hl) * W + w];
-                home = bft_gh_home<W>(t, nbk);
-            } else {
-#pragma unroll
-                for (int w = 0; w < W; w++) t[w] = 0;
-            }
-            const uint32_t m = min(32u, cmax - base);
-            for (uint32_t j = 0; j < m; j++) {  // j, m: scalar registers
-                // home bucket of row base + j of each half's group: lane j of the half (j is wavefront-uniform: two v_readlane + a select)
-                const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)home, (int)j), h1 = (uint32_t)__builtin_amdgcn_readlane((int)home, (int)(j + 32));
-                const uint32_t hj = half ? h1 : h0;
-                const bool row = base + j < cnt && !gave_up;
-                // lane hl: slot hl % 4 of the (hl / 4)-th bucket of the probe sequence (BFT_GH_MAXD + 1 = 8 buckets at most, fewer in a small region)
-                const uint32_t d = hl / BFT_GH_SLOTS;
-                uint32_t b = hj + d;
-                if (b >= nbk) b -= nbk;
-                const uint32_t bit = (b & 7u) * BFT_GH_SLOTS + hl % BFT_GH_SLOTS;
-                const bool is_free = row && d < nbk && !((occ[(b >> 3) & 15u] >> bit) & 1u);
-                const uint64_t fm64 = __ballot(is_free);
-                const uint32_t fm = half ? (uint32_t)(fm64 >> 32) : (uint32_t)fm64;
-                if (row && !fm) gave_up = true;  // no slot within the probe sequence: this half's group stays unhashed
-                if (row && fm && hl == (uint32_t)__builtin_ctz(fm)) {
-                    atomicOr(&occ[(b >> 3) & 15u], 1u << bit);
-                    s_slot[wave][half * 32u + j] = (uint16_t)(b * BFT_GH_SLOTS + hl % BFT_GH_SLOTS);  // told to the lane that holds row j
-                }
-            }
-            // every lane stores the row it loaded: two full store instructions per chunk instead of two one-lane stores per row
-            // (the vector memory pipeline takes a store instruction at a time whatever its lane count: 74 M of them were the kernel)
-            if (base + hl < cnt && !gave_up) {
-                const uint64_t slot = b0 * BFT_GH_SLOTS + s_slot[wave][lane];
-#pragma unroll
-                for (int w = 0; w < W; w++) tkh[slot * W + w] = t[w];
-                tkrank[slot] = (uint8_t)(base + hl);
-            }
-        }
-        if (have && gave_up) {  // the whole region says "unhashed": lookups fall back to the sorted table
-            const uint32_t nslots = nbk * BFT_GH_SLOTS;
-            for (uint32_t j = hl; j < nslots; j += 32) {
-                const uint64_t slot = b0 * BFT_GH_SLOTS + j;
-                tkh[slot * W] = BFT_GH_UNHASHED;
-#pragma unroll
-                for (int w = 1; w < W; w++) tkh[slot * W + w] = BFT_GH_EMPTY;
-                tkrank[slot] = 0;
-            }
-        }
-        // (the number of groups is the length of the list, counted on the host: one atomic per group on ONE address was most of
-        // this kernel's time -- 1.6 ms for the 2.6x10^5 groups of config 2, whatever their size)
-        if (have && hl == 0 && gave_up) atomicAdd(&stats[1], 1ull);
-    }
-}
-
 __global__ void k_ranks(const uint32_t* __restrict__ cc_f2, const uint32_t* __restrict__ cc_nwords, uint32_t C, uint64_t* __restrict__ f2w) {
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
         uint64_t* f2 = f2w + cc_f2[c];
@@ -504,19 +407,9 @@ struct Seg {  // per-depth output segments, concatenated at the end
 };
 
 template <int W>
-int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out, bool group_hash) {
+int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out) {
     const int L = k / 9, rb = 2 * (k - 9 * L);
     Scan scan(s);
-    DevBuf gh_stats;
-    uint64_t n_gh_groups_host = 0;
-    const bool gh = group_hash && W <= 2 && bft_gh_usable(k, W) && n > 0;
-    if (gh) {  // two slots per row, all free (BFT_GH_EMPTY = all ones)
-        CK(out.tkh.alloc(2 * n * W * 8 + 64));
-        CK(out.tkrank.alloc(2 * n + 64));
-        CK(gh_stats.alloc_zero(16, s));
-        HIPCK(hipMemsetAsync(out.tkh.p, 0xFF, out.tkh.bytes, s));
-        HIPCK(hipMemsetAsync(out.tkrank.p, 0, out.tkrank.bytes, s));
-    }
     std::vector<Seg> segs;
     DevBuf nd_lo, nd_hi;
     CK(nd_lo.alloc(4));
@@ -712,25 +605,6 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                nrank.as<uint32_t>(), last_level, rb, (uint32_t)(T_nodes + M), sg.f2w.as<uint64_t>(), sg.clus.as<uint64_t>(),
                                sg.child.as<uint64_t>(), next_lo.as<uint32_t>(), next_hi.as<uint32_t>());
             hipLaunchKernelGGL(k_ranks, G(C), cc_f2.as<uint32_t>(), cc_nwords.as<uint32_t>(), (uint32_t)C, sg.f2w.as<uint64_t>());
-            // suffix groups of this depth (not the one-row leaves of a k % 9 == 0 index) -> hashed form
-            if (gh && !(last_level && rb == 0)) {
-                DevBuf gflag, gpos, glist;
-                CK(gflag.alloc(P * 4));
-                CK(gpos.alloc(P * 4));
-                hipLaunchKernelGGL(k_gh_flags, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_cnt.as<uint32_t>(), pend.as<uint32_t>(), (uint32_t)P, gflag.as<uint32_t>());
-                uint64_t NG = 0;
-                CK(scan.run(gflag.as<uint32_t>(), gpos.as<uint32_t>(), P, &NG));
-                if (NG) {
-                    CK(glist.alloc(NG * sizeof(uint2)));
-                    hipLaunchKernelGGL(k_gh_list, G(P), gflag.as<uint32_t>(), gpos.as<uint32_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
-                                       (uint32_t)P, glist.as<uint2>());
-                    const dim3 ggrid((unsigned)std::min<uint64_t>(((NG + 1) / 2 + GH_WAVES - 1) / GH_WAVES, 256ull * 8));
-                    hipLaunchKernelGGL((k_group_hash<(W <= 2 ? W : 1)>), ggrid, dim3(64 * GH_WAVES), 0, s, tk, glist.as<uint2>(), (uint32_t)NG, out.tkh.as<uint64_t>(),
-                                       out.tkrank.as<uint8_t>(), gh_stats.as<unsigned long long>());
-                    HIPCK(hipStreamSynchronize(s));  // (the list lives until the kernel is done)
-                    n_gh_groups_host += NG;
-                }
-            }
         }
         if (UCR) hipLaunchKernelGGL(k_uc_rows, G(P), tk, W, skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_row.as<uint32_t>(), pref_cnt.as<uint32_t>(),
                                     ucpos.as<uint32_t>(), (uint32_t)P, 0u, sg.uck.as<uint64_t>(), sg.ucrow.as<uint32_t>());
@@ -790,13 +664,6 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CP(out.ucrow, g.ucrow, o_u * 4, g.n_uc * 4);
 #undef CP
         o_n += g.n_nodes; o_b += g.n_bf8; o_c += g.n_ccs; o_f += g.n_f2w; o_q += g.n_clus; o_e += g.n_child; o_u += g.n_uc;
-    }
-    if (gh) {
-        unsigned long long st[2] = {0, 0};
-        HIPCK(hipMemcpyAsync(st, gh_stats.p, 16, hipMemcpyDeviceToHost, s));
-        HIPCK(hipStreamSynchronize(s));
-        out.n_gh_groups = n_gh_groups_host;
-        out.n_gh_unhashed = st[1];
     }
     HIPCK(hipStreamSynchronize(s));
     out.n_nodes = T_nodes; out.n_ccs = T_ccs; out.n_f2w = T_f2w; out.n_clus = T_clus; out.n_child = T_child; out.n_bf8 = T_bf8; out.n_uc = T_uc;
@@ -1034,14 +901,14 @@ __global__ __launch_bounds__(ABLK) void k_cs_verify(const uint32_t* __restrict__
 
 }  // namespace
 
-int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out, bool group_hash) {
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
     if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be in [9, 126]");
     if (n >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 k-mers");
     switch (bft_words_for_k(k)) {
-    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out, group_hash);
-    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out, group_hash);
-    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out, group_hash);
-    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out, group_hash);
+    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out);
+    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out);
+    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out);
+    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out);
     }
 }
 

@@ -73,12 +73,10 @@ static inline int bft_grid_for(uint64_t nblk) {
 // GPU container assembly and colour interning (bft_assemble.hip)
 struct BftDeviceIndex {
     DevBuf nodes, bfT, ccs, f2w, clus, child, uck, ucrow;
-    DevBuf tkh, tkrank;  // hashed form of the suffix groups (BFT_GH_*), when asked for and k allows it
-    uint64_t n_gh_groups = 0, n_gh_unhashed = 0;
     uint64_t n_nodes = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_bf8 = 0, n_uc = 0;
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0, root_ncc = 0, root_uc = 0;
 };
-int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out, bool group_hash);
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out);
 // flat form of the CCs with >= flat_min prefixes (bft_image.h): extended headers, prefix bitmaps + ranks, entries
 struct BftCC;
 int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, const uint64_t* d_clus, const uint64_t* d_child, uint32_t flat_min,

@@ -1,7 +1,8 @@
 // bft_gpu.hip -- the C-ABI of include/bft_gpu.h: handle, device-memory cache, insertion log, bulk build, query entry points,
 // residency / probe tuning, .bft files, image replication.  One translation unit with its device code:
 //   bft_kernels_query.h  k_pack_to_tform (packed 2-bit k-mers -> T-form words: the per-level rev[]/rotation work of
-//                        src/presenceNode.c:1327-1371 done once per k-mer), k_query / k_query8 (batched isKmerPresent,
+//                        src/presenceNode.c:1327-1371 done once per k-mer), k_query_kh / k_branching_kh (the same queries through the
+//                        k-mer hash: one cache line per k-mer), k_query / k_query8 / k_query6 (batched isKmerPresent as a container walk,
 //                        src/presenceNode.c:1823-1921: one lane per k-mer, coalesced dword loads of the batch, hash table + root
 //                        Bloom block + root CC headers staged in LDS, 64 presence bits per wavefront via __ballot),
 //                        k_branching / k_branching8 (src/branchingNode.c)
@@ -51,7 +52,6 @@ static double now_ms() {
 
 // device code, by topic
 #include "bft_kernels_query.h"
-#include "bft_kernels_bucket.h"
 #include "bft_kernels_seq.h"
 #include "bft_kernels_build.h"
 #include "bft_kernels_color.h"
@@ -211,9 +211,11 @@ struct bft_gpu {
     DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
     bool opt_node_hash = true;    // "node_hash"
     uint64_t nph_inserted = 0, nph_dropped = 0;
-    DevBuf d_tkh, d_tkrank;       // hashed form of the suffix groups (BFT_GH_*), built with the containers when "group_hash" is on
-    uint64_t n_tkh_bytes = 0, n_tkrank_bytes = 0, n_gh_groups = 0, n_gh_unhashed = 0;
-    bool opt_group_hash = true;   // "group_hash": build (next build) and use the hashed form
+    DevBuf d_kh;                  // derived: k-mer hash (BFT_KH_*, k_kh_insert), optional
+    uint64_t kh_lines = 0;
+    bool opt_kmer_hash = true;    // "kmer_hash"
+    uint32_t opt_kh_load = 50;    // "kmer_hash_load": per cent of the table's slots in use
+    double kh_ms = 0;             // GPU time of the last fill
     int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
                                   // measured faster on this image (tune_residency)
     bool rstart_ok = false;       // d_rstart holds the range table of the current image
@@ -222,9 +224,7 @@ struct bft_gpu {
     uint64_t n_f18 = 0, n_fent = 0;
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
-    DevBuf d_tcolh;
     bool opt_no_composite = false;  // test hook ("build_composite" 0): the general sort + flag-array path also for ordered one-word keys
-    bool tcolh_tried = false;
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
@@ -240,27 +240,21 @@ struct bft_gpu {
     uint64_t kernel_launches = 0;
     bool timing = false;
     // last work the *_dev entry points put on a caller's stream: image arrays are not released or rewritten before it is done
-    hipEvent_t ext_ev = nullptr;
-    bool ext_pending = false;
-    hipStream_t ext_stream = nullptr;  // the stream ext_ev was last recorded on
+    struct ExtEv { hipStream_t stream; hipEvent_t ev; bool pending; };
+    std::vector<ExtEv> ext;  // one event per caller stream seen (a double-buffered caller alternates between two: neither call blocks the host)
     uint32_t root_ncc = 0;
     uint64_t idx_sizes[9] = {0};
-    int opt_wgs_per_cu = 0;   // k_query residency: 1 / 2 workgroups of 1024 threads per CU, 3 = two of 768, 0 = measured when the image is bound (tune_residency)
-    int tuned_wgs = 0;        // result of that measurement (0 = none yet)
-    int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big), 0 = measured with the residency
+    // The container walk (k_query*): how it sits on a CU and how it probes suffix groups.  0 = by rule from the shape of the index
+    // (default_launch_shape), or -- after bft_gpu_set_option("tune", 1) -- as measured on the image (tune_residency).
+    int opt_wgs_per_cu = 0;   // 1 / 2 workgroups of 1024 threads per CU, 3 = two of 768
+    int tuned_wgs = 0;
+    int opt_probe = 0;        // suffix-group probe: 4 or 8 rows per block (BftImage::probe_big)
     int tuned_probe = 0;
     double tune_ms[3] = {0, 0, 0};  // best time of the tuning batch per residency 1 / 2 / 3
     int opt_grid_mult = 1;    // grid = resident workgroups x this
-    // prefix-bucketed batches (bft_kernels_bucket.h): scratch grown on demand, reused across calls
-    int opt_bucket_bits = -1;   // "query_bucket_bits": -1 = measured on the first large batch, 0 = off, 4..10 = on with that many bits
-    int tuned_bucket_bits = -1; // result of that measurement (-1 = none yet)
-    double bucket_tune_ms[2] = {0, 0};  // plain / bucketed time of the tuning batch
-    DevBuf bk_trec, bk_pos, bk_hist, bk_off, bk_pbits, bk_prow, bk_plan, bk_tmp;
     DevBuf sq_codes, sq_bad, sq_npos, sq_poff, sq_tmp, sq_cs, sq_tile;  // scratch of the sequence queries (grown, never shrunk)
     hipStream_t sq_stream = nullptr;
     bool sq_used = false;
-    hipStream_t bk_stream = nullptr;  // the stream that last used the scratch
-    bool bk_used = false;
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
 };
 
@@ -283,22 +277,34 @@ struct DeviceScope {
     CK(set_device(h))
 
 // A *_dev entry point launched on a caller's stream: remember where that work ends.
+#define BFT_MAX_EXT_STREAMS 8
 static int note_foreign_stream(bft_gpu* h, hipStream_t s) {
     if (s == h->stream) return 0;
-    if (!h->ext_ev) HIPCK(hipEventCreateWithFlags(&h->ext_ev, hipEventDisableTiming));
-    // one event: a caller that alternates between streams has the earlier stream's work drained here, before the event moves on
-    if (h->ext_pending && h->ext_stream != s) HIPCK(hipEventSynchronize(h->ext_ev));
-    HIPCK(hipEventRecord(h->ext_ev, s));
-    h->ext_pending = true;
-    h->ext_stream = s;
+    bft_gpu::ExtEv* slot = nullptr;
+    for (auto& e : h->ext)
+        if (e.stream == s) slot = &e;
+    if (!slot && h->ext.size() < BFT_MAX_EXT_STREAMS) {
+        hipEvent_t ev = nullptr;
+        HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->ext.push_back({s, ev, false});
+        slot = &h->ext.back();
+    }
+    if (!slot) {  // more caller streams than slots: the oldest slot's work is drained and the slot moves on
+        slot = &h->ext[0];
+        if (slot->pending) HIPCK(hipEventSynchronize(slot->ev));
+        slot->stream = s;
+    }
+    HIPCK(hipEventRecord(slot->ev, s));
+    slot->pending = true;
     return 0;
 }
 // Before image arrays are released, rewritten or re-derived: the queries the caller still has in flight must have drained.
 static int wait_foreign_stream(bft_gpu* h) {
-    if (h->ext_pending) {
-        HIPCK(hipEventSynchronize(h->ext_ev));
-        h->ext_pending = false;
-    }
+    for (auto& e : h->ext)
+        if (e.pending) {
+            HIPCK(hipEventSynchronize(e.ev));
+            e.pending = false;
+        }
     return 0;
 }
 
@@ -391,7 +397,8 @@ extern "C" void bft_gpu_free(bft_gpu* h) {
     (void)wait_foreign_stream(h);
     for (hipEvent_t e : h->free_ev) (void)hipEventDestroy(e);
     h->free_ev.clear();
-    if (h->ext_ev) (void)hipEventDestroy(h->ext_ev);
+    for (auto& e : h->ext) (void)hipEventDestroy(e.ev);
+    h->ext.clear();
     const hipStream_t s = h->stream;
     if (s) (void)hipStreamSynchronize(s);
     delete h;                      // its buffers go to the cache under this stream's tag ...
@@ -422,6 +429,9 @@ static int log_reserve(bft_gpu* h, uint64_t need) {
     if (need <= h->log_cap) return 0;
     uint64_t ncap = std::max<uint64_t>(need, h->log_cap * 2);
     ncap = std::max<uint64_t>(ncap, 1 << 16);
+    // The log is about to move: batches still being packed into it on a caller's stream (bft_gpu_insert_kmers_dev_async) finish
+    // first -- the copy below would miss their rows and the old block would go back to the cache with writes in flight.
+    CK(wait_foreign_stream(h));
     DevBuf nk, ng;
     CK(nk.alloc(ncap * h->W * 8));
     CK(ng.alloc(ncap * 4));
@@ -430,8 +440,10 @@ static int log_reserve(bft_gpu* h, uint64_t need) {
             HIPCK(hipMemcpyAsync(nk.as<uint64_t>() + (uint64_t)w * ncap, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
                                  h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCK(hipMemcpyAsync(ng.p, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream));
     }
+    // (also without a copy: a fresh block may come from the cache with work of this handle's stream still queued on it, and the
+    // next writer may be a caller's stream, which is not ordered behind ours)
+    HIPCK(hipStreamSynchronize(h->stream));
     h->log_k.swap(nk);
     h->log_g.swap(ng);
     h->log_cap = ncap;
@@ -455,7 +467,6 @@ static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_g
     if (n == 0) return BFT_GPU_OK;
     ENTER(h);
     if (h->log_n + n + h->n_pairs >= 0x7FFFFFFFull) return fail(BFT_GPU_E_LIMIT, "more than 2^31-1 (k-mer, genome) pairs");
-    if (h->log_n + n > h->log_cap) CK(wait_foreign_stream(h));  // the log is about to move: batches still being packed into it finish first
     CK(log_reserve(h, h->log_n + n));
     const hipStream_t run = ordered ? s : h->stream;
     const uint8_t* p = (const uint8_t*)d_kmers;
@@ -585,11 +596,10 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_nph.bytes + h->n_tkh_bytes + h->n_tkrank_bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_nph.bytes + h->d_kh.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
-static int ensure_tcolh(bft_gpu* h);
 
 // Points h->im at the device arrays of the handle (cannot fail).
 static void point_image(bft_gpu* h, uint32_t nb_genomes) {
@@ -607,8 +617,8 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.clus = h->d_clus.as<uint64_t>();
     im.child = h->d_child.as<uint64_t>();
     im.tk = h->d_tk.as<uint64_t>();
-    im.tkh = (h->opt_group_hash && h->n_tkh_bytes) ? h->d_tkh.as<uint64_t>() : nullptr;
-    im.tkrank = (h->opt_group_hash && h->n_tkh_bytes) ? h->d_tkrank.as<uint8_t>() : nullptr;
+    im.kh = nullptr;    // (derive_kmer_hash)
+    im.kh_lines = 0;
     im.tcol = h->d_tcol.as<uint32_t>();
     im.uck = h->d_uck.as<uint64_t>();
     im.ucrow = h->d_ucrow.as<uint32_t>();
@@ -625,13 +635,9 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     h->has_cs_bm = false;  // the bitmap form of the colour-set dictionary is derived by the first colour-row query (ensure_cs_bitmaps)
     h->cs_bm_tried = false;
     h->d_cs_bm.release();
-    im.tcolh = nullptr;  // colour set per hashed slot: derived by the first sequence / colour-row query (ensure_tcolh)
     im.emit_cs = 0;
-    h->tcolh_tried = false;
-    h->d_tcolh.release();
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
-    h->tuned_bucket_bits = -1;  // measured again on the first large batch of the new image
     h->im.probe_big = h->opt_probe == 8;
 }
 
@@ -754,6 +760,55 @@ static void derive_node_hash(bft_gpu* h) {
     h->im.nph_no_uc = st[2] == 0 ? 1u : 0u;
 }
 
+// Derives the k-mer hash of the image h->im points at (BFT_KH_*).  An accelerator only: without it every query walks the containers.
+static void derive_kmer_hash(bft_gpu* h) {
+    h->im.kh = nullptr;
+    h->im.kh_lines = 0;
+    h->kh_lines = 0;
+    h->kh_ms = 0;
+    if (!h->opt_kmer_hash || !bft_kh_usable(h->k, h->W) || h->n_kmers == 0) {
+        h->d_kh.release();
+        return;
+    }
+    const uint64_t lines = bft_kh_lines_for(h->n_kmers, h->W, h->opt_kh_load);
+    const size_t bytes = lines * BFT_KH_LINE_WORDS * 8;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = h->d_kh.alloc(bytes) == 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess &&
+              hipMemsetAsync(h->d_kh.p, 0xFF, bytes, h->stream) == hipSuccess;
+    if (ok) {
+        const dim3 grid(grid_for((h->n_kmers + 255) / 256)), block(256);
+        if (h->W == 1) hipLaunchKernelGGL(k_kh_insert<1>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_kh.as<uint64_t>(), lines);
+        else hipLaunchKernelGGL(k_kh_insert<2>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_kh.as<uint64_t>(), lines);
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+        float ms = 0;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) h->kh_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (!ok) {
+        (void)hipGetLastError();
+        h->d_kh.release();
+        return;
+    }
+    h->kh_lines = lines;
+    h->im.kh = h->d_kh.as<uint64_t>();
+    h->im.kh_lines = lines;
+}
+
+// Launch shape of the container walk when nothing was measured ("tune") or fixed by the caller: two 768-thread workgroups per CU (the
+// arrangement that was best or within a few per cent of it on every index measured), 8-row probes once suffix groups
+// hold dozens of rows, and the root range table unless most root prefixes are child Nodes (their lookups pay it for nothing).
+static void default_launch_shape(bft_gpu* h) {
+    h->tuned_wgs = 3;
+    const uint64_t prefixes = std::max<uint64_t>(1, h->info[6]);
+    h->tuned_probe = h->n_kmers / prefixes >= 48 ? 8 : 4;
+    h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+    if (h->opt_root_direct == 3 && h->rstart_ok) {
+        h->tuned_rstart = h->info[5] * 4 < (1u << 18) ? 1 : 0;
+        h->im.rstart = h->tuned_rstart ? h->d_rstart.as<uint32_t>() : nullptr;
+    }
+}
+
 // Derives the table for the image h->im points at (after point_image).  An accelerator only: on any failure the walk simply
 // keeps the container path (im.rdir == NULL).
 static void derive_root_direct(bft_gpu* h) {
@@ -808,7 +863,8 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     point_image(h, nb_genomes);
     derive_root_direct(h);
     derive_node_hash(h);
-    if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
+    derive_kmer_hash(h);
+    default_launch_shape(h);
     return 0;
 }
 
@@ -1019,7 +1075,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     // 5. containers, level by level, on the GPU
     if (!tk.p) CK(tk.alloc(8));
     BftDeviceIndex idx;
-    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx, h->opt_group_hash));
+    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx));
     double t3 = now_ms();
     DevBuf n_ccx, n_f18buf, n_fentbuf;
     uint64_t n_f18 = 0, n_fent = 0;
@@ -1048,12 +1104,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->log_k.release();
     h->log_g.release();
     h->log_cap = 0;
-    h->d_tkh.swap(idx.tkh);
-    h->d_tkrank.swap(idx.tkrank);
-    h->n_tkh_bytes = h->d_tkh.p ? h->d_tkh.bytes : 0;
-    h->n_tkrank_bytes = h->d_tkrank.p ? h->d_tkrank.bytes : 0;
-    h->n_gh_groups = idx.n_gh_groups;
-    h->n_gh_unhashed = idx.n_gh_unhashed;
     h->d_nodes.swap(idx.nodes);
     h->d_bfT.swap(idx.bfT);
     h->d_ccs.swap(idx.ccs);
@@ -1102,9 +1152,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->built = true;
     derive_root_direct(h);
     derive_node_hash(h);
+    derive_kmer_hash(h);
+    default_launch_shape(h);
     I[12] = image_bytes(h);
-    // launch tuning on the committed image (timing runs only: a failure here leaves a complete, queryable index)
-    if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0) CK(tune_residency(h));
     h->build_ms[4] = now_ms() - t3;
     return BFT_GPU_OK;
 }
@@ -1156,7 +1206,6 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
 
 template <int W, bool STAGED>
 static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
-    if (W <= 2 && h->im.tkh != nullptr) return launch_query_k<W <= 2 ? W : 1, STAGED, 3>(h, d_kmers, n, d_bits64, d_rows, s, rec);  // hashed groups: no block probes
     if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
     return launch_query_k<W, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
@@ -1167,7 +1216,7 @@ static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s, rec) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
-static int launch_query_plain(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
+static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
     hipEvent_t e0, e1;
@@ -1182,155 +1231,27 @@ static int launch_query_plain(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, ui
     return 0;
 }
 
-// ---- prefix-bucketed batches (bft_kernels_bucket.h) ------------------------------------------------------------------------
-#define BK_MIN_N (1ull << 22)       // smaller batches keep the direct kernel: the passes would cost more than they save
-#define BK_MAX_CHUNK (1ull << 28)   // queries per pass (bounds the scratch: (8W + 8) bytes per query)
-#define BK_DEFAULT_BITS 8
-#define BK_PROBE 2
-
-template <int W, bool STAGED>
-static int launch_bk_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec, int bits) {
-    constexpr uint64_t TILE = BkTile<W>::value;
-    const uint32_t nb = 1u << bits;
-    const uint64_t ntiles64 = (n + TILE - 1) / TILE;
-    const uint32_t ntiles = (uint32_t)ntiles64;
-    const uint64_t padded = n + 64ull * nb;
-    const uint64_t nh = (uint64_t)nb * ntiles;
-    // scratch (grown, never shrunk)
-    if (h->bk_used && h->bk_stream != s) HIPCK(hipStreamSynchronize(h->bk_stream));  // one scratch: calls on different streams take turns
-    const size_t tb = BK_MAX_BUCKETS * 4;  // per-bucket totals
-    auto need = [&](DevBuf& b, size_t bytes) -> int {
-        if (b.bytes >= bytes) return 0;
-        if (h->bk_used) HIPCK(hipStreamSynchronize(s));  // the block being replaced may still be read by the previous call
-        return b.alloc(bytes + bytes / 8);
-    };
-    CK(need(h->bk_trec, padded * W * 8));
-    CK(need(h->bk_pos, ntiles64 * TILE * 2));  // lrank: u16 per query
-    CK(need(h->bk_hist, nh * 4));
-    CK(need(h->bk_off, nh * 4));
-    CK(need(h->bk_pbits, (padded / 64 + 1) * 8));
-    if (d_rows) CK(need(h->bk_prow, padded * 4));
-    CK(need(h->bk_plan, sizeof(BkPlan)));
-    CK(need(h->bk_tmp, tb));
-    h->bk_used = true;
-    h->bk_stream = s;
-    const int wgs = h->opt_wgs_per_cu == 1 ? 1 : 2;  // the walk: two workgroups per CU (64-VGPR build) unless "query_wgs_per_cu" says one
-    const dim3 pgrid((unsigned)std::min<uint64_t>(ntiles64, 256ull * 2)), blk(BK_BLOCK);
-    hipLaunchKernelGGL(k_bucket_hist<W>, pgrid, blk, 0, s, d_kmers, n, rec, bits, ntiles, h->bk_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_bucket_rowsum, dim3(nb), blk, 0, s, h->bk_hist.as<uint32_t>(), ntiles, h->bk_tmp.as<uint32_t>());
-    hipLaunchKernelGGL(k_bucket_plan, dim3(1), blk, 0, s, h->bk_tmp.as<uint32_t>(), bits, h->bk_plan.as<BkPlan>());
-    hipLaunchKernelGGL(k_bucket_rowscan, dim3(nb), blk, 0, s, h->bk_hist.as<uint32_t>(), ntiles, h->bk_plan.as<BkPlan>(), h->bk_off.as<uint32_t>());
-    hipLaunchKernelGGL(k_bucket_scatter<W>, pgrid, blk, 0, s, d_kmers, n, rec, h->k, bits, ntiles, h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
-                       h->bk_trec.as<uint64_t>(), h->bk_pos.as<uint16_t>());
-    HIPCK(hipGetLastError());
-    // the walk, XCD by XCD over the plan: two workgroups per CU (L2-resident slices gain from 8 waves per SIMD)
-    // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
-    size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
-    static std::atomic<uint64_t> attr_devs{0};
-    const uint64_t dev_bit = 1ull << (h->device & 63);
-    if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, BK_PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        HIPCK(hipFuncSetAttribute((const void*)k_query_bk8<W, STAGED, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        HIPCK(hipFuncSetAttribute((const void*)k_query_bk<W, STAGED, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-        attr_devs.fetch_or(dev_bit, std::memory_order_release);
-    }
-    const dim3 qgrid((unsigned)std::max<uint64_t>(8, std::min<uint64_t>((n + BK_BLOCK - 1) / BK_BLOCK, 256ull * wgs)));
-    uint32_t* prow = d_rows ? h->bk_prow.as<uint32_t>() : nullptr;
-    // suffix groups by one-load probes (bft_group_probe, PROBE 2): the bucket's slice of the table sits in the L2, where a probe
-    // costs per load instruction, not per line missed
-    const dim3 wblk(BK_WALK_BLOCK);
-    if (W <= 2 && h->im.tkh != nullptr && wgs == 1)
-        hipLaunchKernelGGL((k_query_bk<W, STAGED, 3>), qgrid, blk, std::max<size_t>(lds, 84u << 10), s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(),
-                           h->bk_pbits.as<uint64_t>(), prow);
-    else if (W <= 2 && h->im.tkh != nullptr)
-        hipLaunchKernelGGL((k_query_bk8<W, STAGED, 3>), qgrid, wblk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
-    else
-        hipLaunchKernelGGL((k_query_bk8<W, STAGED, BK_PROBE>), qgrid, wblk, lds, s, h->im, h->bk_trec.as<uint64_t>(), h->bk_plan.as<BkPlan>(), h->bk_pbits.as<uint64_t>(), prow);
-    if (d_rows)
-        hipLaunchKernelGGL((k_unpermute<(int)TILE, true>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
-                           bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);
-    else
-        hipLaunchKernelGGL((k_unpermute<(int)TILE, false>), pgrid, blk, 0, s, h->bk_pos.as<uint16_t>(), h->bk_hist.as<uint32_t>(), h->bk_off.as<uint32_t>(), h->bk_plan.as<BkPlan>(),
-                           bits, ntiles, h->bk_pbits.as<uint64_t>(), prow, n, d_bits64, d_rows);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-static int launch_query_bucketed(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec, int bits) {
-    const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
+// Presence (and, with im.emit_cs, the colour set of every found k-mer into d_out32) through the k-mer hash.
+static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s, int rec) {
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    for (uint64_t a = 0; a < n; a += BK_MAX_CHUNK) {  // BK_MAX_CHUNK is a multiple of 64: chunks are word aligned in the bitmap
-        const uint64_t m = std::min<uint64_t>(BK_MAX_CHUNK, n - a);
-        const uint8_t* q = d_kmers + a * (uint64_t)rec;
-        uint64_t* ob = d_bits64 + a / 64;
-        uint32_t* orow = d_rows ? d_rows + a : nullptr;
-#define BK(WW) (staged ? launch_bk_k<WW, true>(h, q, m, ob, orow, s, rec, bits) : launch_bk_k<WW, false>(h, q, m, ob, orow, s, rec, bits))
-        switch (h->W) {
-        case 1: CK(BK(1)); break;
-        case 2: CK(BK(2)); break;
-        case 3: CK(BK(3)); break;
-        default: CK(BK(4)); break;
-        }
-#undef BK
-    }
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8 * h->opt_grid_mult))), block(BFT_KH_BLOCK);
+    if (h->W == 1) hipLaunchKernelGGL(k_query_kh<1>, grid, block, 0, s, h->im, d_kmers, n, rec, d_bits64, d_out32);
+    else hipLaunchKernelGGL(k_query_kh<2>, grid, block, 0, s, h->im, d_kmers, n, rec, d_bits64, d_out32);
+    HIPCK(hipGetLastError());
     CK(timing_end(h, s, e0, e1));
     return 0;
 }
 
-// Which path a batch takes.  Small batches: the direct kernel.  Large ones: bucketed when "query_bucket_bits" says so, or
-// -- by default -- when it measured faster on the first large batch of this image (both paths run twice on that batch, which
-// makes that one call synchronise; same answers either way).  Whether bucketing pays depends on the index (a table that fits
-// the L2 gains nothing) and on the batch, so it is measured rather than guessed, like the residency -- and the residency itself
-// is measured again on that batch when it is automatic (the three arrangements of k_query: the build-time choice comes from a
-// 2^22-query synthetic batch, the real one separates arrangements 5-10 % apart).
+// Which kernel a batch takes: the k-mer hash answers presence and colour sets (one cache line per k-mer); rows -- positions in the
+// sorted table, what the reference keeps in resultPresence -- come from the container walk, as does everything on an image
+// without the table ("kmer_hash" 0, k >= 64, 2k % 64 == 0).  Same answers either way (tests/test_gpu_parity.py).
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
-    if (h->opt_bucket_bits > 0) return launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, h->opt_bucket_bits);  // forced: any batch size
-    if (n < BK_MIN_N || h->opt_bucket_bits == 0) return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
-    if (h->tuned_bucket_bits < 0) {
-        if (n < (1ull << 24)) return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);  // too small to judge: decide on a bigger batch
-        const bool timing = h->timing;
-        h->timing = false;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        int rc = 0;
-        if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
-        // modes 0..2: the direct kernel under residency 1 / 2 / 3 (only when the residency is automatic: the build-time choice was
-        // made on a 2^22-query batch, which resolves differences below ~10 % poorly -- this is the real batch); mode 3: bucketed
-        float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-        const int res0 = query_residency(h);
-        const bool auto_res = h->opt_wgs_per_cu == 0;
-        for (int rep = 0; rep < 2 && rc == 0; rep++)
-            for (int mode = 0; mode < 4 && rc == 0; mode++) {
-                if (mode < 3 && !auto_res && mode + 1 != res0) continue;
-                if (mode < 3) h->tuned_wgs = mode + 1;
-                if (hipEventRecord(ev[0], s) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
-                if (rc == 0) rc = mode == 3 ? launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, BK_DEFAULT_BITS) : launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
-                if (rc == 0 && (hipEventRecord(ev[1], s) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "query failed while tuning");
-                float ms = 0;
-                if (rc == 0 && hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
-                if (rc == 0 && ms < best[mode]) best[mode] = ms;
-            }
-        for (hipEvent_t e : ev)
-            if (e) (void)hipEventDestroy(e);
-        h->timing = timing;
-        h->tuned_wgs = res0;
-        CK(rc);
-        int rbest = res0 - 1;
-        for (int r = 0; r < 3; r++)
-            if (best[r] < best[rbest]) rbest = r;
-        if (auto_res) {
-            h->tuned_wgs = rbest + 1;
-            for (int r = 0; r < 3; r++) h->tune_ms[r] = best[r] < 1e29f ? best[r] : 0;
-        }
-        h->bucket_tune_ms[0] = best[rbest];
-        h->bucket_tune_ms[1] = best[3];
-        h->tuned_bucket_bits = best[3] < 0.95f * best[rbest] ? BK_DEFAULT_BITS : 0;
-        return 0;  // the caller's buffers hold the answers of the last run
-    }
-    if (h->tuned_bucket_bits > 0) return launch_query_bucketed(h, d_kmers, n, d_bits64, d_rows, s, rec, h->tuned_bucket_bits);
-    return launch_query_plain(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (h->im.kh != nullptr && (d_rows == nullptr || h->im.emit_cs)) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    return launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
 // Synthetic batch for tune_residency: k-mers of the index itself (pseudo-random rows of tk), every other one with a
@@ -1362,7 +1283,8 @@ __global__ void k_tune_queries(const uint64_t* __restrict__ tk, uint64_t n_kmers
     }
 }
 
-// One or two resident workgroups per CU for k_query on THIS image: time both on a batch drawn from the index.
+// bft_gpu_set_option("tune", 1): the launch shape of the container walk measured on THIS image, on a batch drawn from the index
+// (synchronises; never called implicitly -- a build or a query only ever applies default_launch_shape).
 static int tune_residency(bft_gpu* h) {
     if (h->n_kmers < (1u << 16)) {  // small (L2-resident) indexes: always two workgroups, 4-row probes
         h->tuned_wgs = 2;
@@ -1389,20 +1311,17 @@ static int tune_residency(bft_gpu* h) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventCreate failed");
-    // (residency 1 / 2 / 3) x (probe block 4 / 8 rows); options fixed by the caller are not varied, and an image with the hashed
-    // groups has no block probes to choose between (W <= 2: the PROBE 3 kernels)
-    const bool no_probe_choice = (h->W <= 2 && h->im.tkh != nullptr) || h->W > BFT_PROBE_MAX_W;
+    // (residency 1 / 2 / 3) x (probe block 4 / 8 rows); options fixed by the caller are not varied
     float best[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int cfg = 0; cfg < 6 && rc == 0; cfg++) {
         const int wgs = 1 + cfg % 3, probe = cfg >= 3 ? 8 : 4;
-        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (no_probe_choice && !h->opt_probe && probe == 8) ||
-            (h->W > BFT_PROBE_MAX_W && probe == 8))
+        if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W > BFT_PROBE_MAX_W && probe == 8))
             continue;
         h->tuned_wgs = wgs;
         h->im.probe_big = probe == 8;
         for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second counts (large batches measure again: launch_query)
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
-            if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
+            if (rc == 0) rc = launch_query_walk(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
             if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
             float ms = 0;
             if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
@@ -1432,7 +1351,7 @@ static int tune_residency(bft_gpu* h) {
             h->im.rstart = mode ? h->d_rstart.as<uint32_t>() : nullptr;
             for (int rep = 0; rep < 3 && rc == 0; rep++) {
                 if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
-                if (rc == 0) rc = launch_query_plain(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
+                if (rc == 0) rc = launch_query_walk(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
                 if (rc == 0 && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(BFT_GPU_E_HIP, "k_query failed while tuning");
                 float ms = 0;
                 if (rc == 0 && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventElapsedTime failed");
@@ -1488,11 +1407,19 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
+    if (h->im.kh != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
+        const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
+        const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8))), block(BFT_KH_BLOCK);
+        if (h->W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+        else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
+        HIPCK(hipGetLastError());
+        CK(timing_end(h, s, e0, e1));
+        return 0;
+    }
 #define BR(WW, PP) (staged ? launch_branching_k<WW, true, PP>(h, d_kmers, n, d_bits64, d_counts, s) : launch_branching_k<WW, false, PP>(h, d_kmers, n, d_bits64, d_counts, s))
-    const bool hashed = h->im.tkh != nullptr;  // images with the hashed groups: kernels without the block-probe code (W <= 2)
     switch (h->W) {
-    case 1: CK(hashed ? BR(1, 3) : BR(1, 0)); break;
-    case 2: CK(hashed ? BR(2, 3) : BR(2, 0)); break;
+    case 1: CK(BR(1, 0)); break;
+    case 2: CK(BR(2, 0)); break;
     case 3: CK(BR(3, 0)); break;
     default: CK(BR(4, 0)); break;
     }
@@ -1711,13 +1638,11 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
-    // with the bitmap dictionary the walk writes colour sets straight away (bft_hit_out): no rank gather, no row -> colour set pass
+    // with the bitmap dictionary the query kernel writes colour sets straight away (the k-mer hash holds them; bft_hit_out in the
+    // walk): no row -> colour set pass
     CK(ensure_cs_bitmaps(h));
     const bool direct = h->has_cs_bm;
-    if (direct) {
-        CK(ensure_tcolh(h));
-        h->im.emit_cs = 1;
-    }
+    if (direct) h->im.emit_cs = 1;
     const int rc = launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s);
     h->im.emit_cs = 0;
     CK(rc);
@@ -1752,36 +1677,6 @@ extern "C" int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64
 // info / timing / extraction
 // ------------------------------------------------------------------------------------------------
 // query_sequence (src/bft.c:1241-1351) for a batch of ASCII sequences
-// Colour set per slot of the hashed groups (BftImage::tcolh): with it a found k-mer's colour set is ONE gather behind the bucket
-// (slot -> colour set) instead of two (slot -> rank -> row -> colour set).  Derived on the first sequence query of an image by
-// looking every stored k-mer up in the image itself; 8 bytes per k-mer, not part of the packed image (a replica derives its own).
-template <int W>
-__global__ void k_tcolh_fill(BftImage im, uint64_t n, uint32_t* __restrict__ tcolh) {
-    const BftNode root = im.nodes[0];
-    const BftRootGlobal acc(im);
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t t[W];
-        bft_load_row<W>(im.tk + i * W, t);
-        const BftHit h = bft_walk<W, BftRootGlobal, 3>(im, acc, root, t);
-        if (h.present && h.gh_slot >= 0) tcolh[h.gh_slot] = im.tcol[i];
-    }
-}
-static int ensure_tcolh(bft_gpu* h) {
-    if (h->tcolh_tried) return 0;
-    h->tcolh_tried = true;
-    if (!h->im.tkh || h->W > 2 || h->n_kmers == 0) return 0;
-    CK(wait_foreign_stream(h));
-    CK(h->d_tcolh.alloc(2 * h->n_kmers * 4));
-    HIPCK(hipMemsetAsync(h->d_tcolh.p, 0xFF, 2 * h->n_kmers * 4, h->stream));
-    const dim3 grid(grid_for((h->n_kmers + 255) / 256)), block(256);
-    if (h->W == 1) hipLaunchKernelGGL(k_tcolh_fill<1>, grid, block, 0, h->stream, h->im, h->n_kmers, h->d_tcolh.as<uint32_t>());
-    else hipLaunchKernelGGL(k_tcolh_fill<2>, grid, block, 0, h->stream, h->im, h->n_kmers, h->d_tcolh.as<uint32_t>());
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(h->stream));  // the sequence kernels may run on a caller's stream
-    h->im.tcolh = h->d_tcolh.as<uint32_t>();
-    return 0;
-}
-
 // Sequence queries on device-resident input.  Scratch (codes, plan, colour set per position) belongs to the handle and only grows; calls on
 // different streams take turns on it.  Nothing here waits for the GPU: the positions of a chunk are counted on the device
 // (k_seq_plan + scan) and the kernels read the total from there.
@@ -1810,9 +1705,13 @@ static int launch_seq_walk_k(bft_gpu* h, uint32_t ns, int canonical, const uint6
 template <int W>
 static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    constexpr int W12 = W <= 2 ? W : 1;
-    if (W <= 2 && h->im.tkh != nullptr)
-        return staged ? launch_seq_walk_k<W12, true, 3>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W12, false, 3>(h, ns, canonical, d_soff, s);
+    if (W <= 2 && h->im.kh != nullptr) {
+        constexpr int W12 = W <= 2 ? W : 1;
+        hipLaunchKernelGGL(k_seq_kh<W12>, dim3(256 * 8), dim3(256), 0, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(),
+                           h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     return staged ? launch_seq_walk_k<W, true, 0>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W, false, 0>(h, ns, canonical, d_soff, s);
 }
 
@@ -1820,7 +1719,6 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
                                 int canonical, uint8_t* d_rows, hipStream_t s) {
     const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
     if (rowbytes == 0 || n_seqs == 0) return 0;
-    CK(ensure_tcolh(h));
     if (h->sq_used && h->sq_stream != s) HIPCK(hipStreamSynchronize(h->sq_stream));
     auto need = [&](DevBuf& b, size_t bytes) -> int {
         if (b.bytes >= bytes) return 0;
@@ -1988,8 +1886,8 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
 // image replication (one contiguous device blob: header, then 256-byte aligned sections)
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint64_t BLOB_MAGIC = 0x3130555047544642ull;  // "BFTGPU01"
-constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 17;
+constexpr uint64_t BLOB_MAGIC = 0x3230555047544642ull;  // "BFTGPU02"
+constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 15;
 enum { H_MAGIC, H_TOTAL, H_K, H_R1, H_R2, H_NKMERS, H_NPAIRS, H_NSETS, H_NIDS, H_ROOTNCC, H_MAXGID, H_ANYINS, H_NBGEN, H_NNAMES,
        H_STOREMAX, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
 
@@ -2008,9 +1906,9 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     for (const std::string& g : h->genomes) { p.names += g; p.names.push_back('\0'); }
     const uint64_t sz[BLOB_SECTIONS] = {h->idx_sizes[0], h->idx_sizes[1], h->idx_sizes[2], h->idx_sizes[3], h->idx_sizes[4], h->idx_sizes[5], h->idx_sizes[6],
                                         h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * 4,
-                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size(), h->n_tkh_bytes, h->n_tkrank_bytes};
+                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size()};
     const void* src[BLOB_SECTIONS] = {h->d_nodes.p, h->d_bfT.p, h->d_ccs.p, h->d_f2w.p, h->d_clus.p, h->d_child.p, h->d_uck.p, h->d_ucrow.p,
-                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr, h->d_tkh.p, h->d_tkrank.p};
+                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr};
     uint64_t o = BLOB_HDR_WORDS * 8;
     for (int i = 0; i < BLOB_SECTIONS; i++) {
         p.off[i] = o;
@@ -2080,10 +1978,10 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
     CK(bft_gpu_create_seeded((int)H[H_K], device, (int)H[H_R1], (int)H[H_R2], &h));
     const uint8_t* d = (const uint8_t*)d_blob;
     DevBuf* dst[BLOB_SECTIONS] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow,
-                                  &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g, nullptr, &h->d_tkh, &h->d_tkrank};
+                                  &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g, nullptr};
     int rc = 0;
     for (int i = 0; i < BLOB_SECTIONS && rc == 0; i++) {
-        if (i == 14 || ((i == 15 || i == 16) && H[H_SEC + i] == 0)) continue;  // names: below; no hashed form in the blob
+        if (i == 14) continue;  // names: below
         rc = dst[i]->alloc(H[H_SEC + i]);
         if (rc == 0 && H[H_SEC + i] &&
             hipMemcpyAsync(dst[i]->p, d + off[i], H[H_SEC + i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
@@ -2106,8 +2004,6 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
         for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
         h->cs_on_host = false;
-        h->n_tkh_bytes = H[H_SEC + 15];
-        h->n_tkrank_bytes = H[H_SEC + 16];
         rc = bind_image(h, (uint32_t)H[H_NBGEN]);
     }
     if (rc != 0) {
@@ -2126,12 +2022,10 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
     CK(ensure_built(h));
-    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "tkh", "tkrank"};
+    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol"};
     const DevBuf* bufs[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
-                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_tkh, &h->d_tkrank};
-    // (the hashed form: the 2 n W words / 2 n bytes that are defined, without the allocation slack)
-    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8,
-                                 h->n_tkh_bytes ? 2 * h->n_kmers * (uint64_t)h->W * 8 : 0, h->n_tkh_bytes ? 2 * h->n_kmers : 0};
+                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol};
+    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8, h->kh_lines * BFT_KH_LINE_WORDS * 8, h->n_kmers * 4};
     for (int i = 0; i < 14; i++)
         if (std::string(name) == names[i]) {
             const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
@@ -2171,17 +2065,19 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             derive_node_hash(h);
             h->info[12] = image_bytes(h);
-            if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0 || h->opt_root_direct == 3) CK(tune_residency(h));
         }
-    } else if (nm == "group_hash") {  // 1 (default): suffix groups through their hashed form; 0: through the sorted table only.  Takes
-        h->opt_group_hash = value != 0;  // effect at once when the image has the form (it is built with the containers when the option is on)
+    } else if (nm == "kmer_hash" || nm == "kmer_hash_load") {  // the k-mer hash: on / off, and its occupancy in per cent
+        if (nm == "kmer_hash_load") {
+            if (value < 10 || value > 80) return fail(BFT_GPU_E_ARG, "kmer_hash_load must be in [10, 80] (per cent)");
+            h->opt_kh_load = (uint32_t)value;
+        } else
+            h->opt_kmer_hash = value != 0;
         if (h->built) {
             ENTER(h);
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
-            const bool on = h->opt_group_hash && h->n_tkh_bytes;
-            h->im.tkh = on ? h->d_tkh.as<uint64_t>() : nullptr;
-            h->im.tkrank = on ? h->d_tkrank.as<uint8_t>() : nullptr;
+            derive_kmer_hash(h);
+            h->info[12] = image_bytes(h);
         }
     } else if (nm == "root_direct") {  // 2 (default): root level through the derived range + direct tables; 1: direct table only; 0: containers
         if (value < 0 || value > 3) return fail(BFT_GPU_E_ARG, "root_direct must be 0, 1, 2 or 3");
@@ -2191,12 +2087,16 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
             derive_root_direct(h);
+            default_launch_shape(h);
             h->info[12] = image_bytes(h);
-            if (h->opt_wgs_per_cu == 0 || h->opt_probe == 0 || h->opt_root_direct == 3) CK(tune_residency(h));  // the launch shape was measured with the other tables
         }
-    } else if (nm == "query_bucket_bits") {
-        if (value != -1 && value != 0 && (value < 4 || value > 10)) return fail(BFT_GPU_E_ARG, "query_bucket_bits must be -1 (automatic), 0 (off) or 4..10");
-        h->opt_bucket_bits = (int)value;
+    } else if (nm == "tune") {  // measure the launch shape of the container walk on the current image (synchronises)
+        if (value != 0 && h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            CK(tune_residency(h));
+        }
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;
@@ -2229,6 +2129,16 @@ extern "C" int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out) {
     return BFT_GPU_OK;
 }
 
+extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
+    if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
+    const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
+                            h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
+                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes, h->d_nph.bytes, h->d_kh.bytes, h->d_cs_bm.bytes,
+                            h->d_hashmod.bytes, h->pair_k.bytes + h->pair_g.bytes, h->log_k.bytes + h->log_g.bytes};
+    for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
@@ -2246,8 +2156,7 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
     const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
-                          h->im.probe_big ? 8.0 : 4.0, (double)(h->opt_bucket_bits >= 0 ? h->opt_bucket_bits : h->tuned_bucket_bits), h->bucket_tune_ms[0],
-                          h->bucket_tune_ms[1], (double)h->n_gh_groups, (double)h->n_gh_unhashed,
+                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, 0.0, 0.0, 0.0,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
                           (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
     for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];

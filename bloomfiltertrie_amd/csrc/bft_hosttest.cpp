@@ -18,12 +18,11 @@ struct HostTrie {
     std::vector<uint32_t> hashmod;
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
-    std::vector<uint64_t> rdir, nph;
+    std::vector<uint64_t> rdir, nph, kh;
     std::vector<uint32_t> rstart;
     uint64_t rstart_plain = 0;
     BftHostIndex idx;
     BftImage im;
-    bool probe2 = false;
 };
 
 template <int W>
@@ -93,20 +92,74 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
     memset(bits, 0, (nq + 7) / 8);
     for (uint64_t i = 0; i < nq; i++) {
         const BftRootGlobal root(t->im);
-        BftHit h = t->probe2 ? bft_walk<W, BftRootGlobal, 2>(t->im, root, t->im.nodes[0], &tq[i * W])   // one-load probes (bucketed kernel)
-                             : bft_walk<W, BftRootGlobal, -1>(t->im, root, t->im.nodes[0], &tq[i * W]);
+        const BftHit h = bft_walk<W, BftRootGlobal, -1>(t->im, root, t->im.nodes[0], &tq[i * W]);
         if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
-        if (rows) rows[i] = h.present ? (uint32_t)bft_hit_row(t->im, h) : 0xFFFFFFFFu;
+        if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
     }
     return cnt;
 }
 
-// hashed form of the suffix groups (BFT_GH_*): built by bft_build_index with the function the GPU kernel uses; on / off
-extern "C" void bft_hosttest_group_hash(void* hv, int on) {
+// k-mer hash (BFT_KH_*): sequential fill with the value = the row of the k-mer (the GPU stores the colour set there), then the same
+// lookup the kernels run.  load_pct: occupancy in per cent (the product's "kmer_hash_load"); 0 = drop the table.
+// Returns the number of lines, 0 when k does not allow the table.
+extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     HostTrie* t = (HostTrie*)hv;
-    const bool have = on && !t->idx.tkh.empty();
-    t->im.tkh = have ? t->idx.tkh.data() : nullptr;
-    t->im.tkrank = have ? t->idx.tkrank.data() : nullptr;
+    t->im.kh = nullptr;
+    t->im.kh_lines = 0;
+    t->kh.clear();
+    const uint64_t n = t->tk.size() / t->W;
+    if (!load_pct || !bft_kh_usable(t->k, t->W) || n == 0) return 0;
+    const uint64_t lines = bft_kh_lines_for(n, t->W, load_pct);
+    t->kh.assign(lines * BFT_KH_LINE_WORDS, BFT_KH_EMPTY);
+    for (uint64_t i = 0; i < n; i++) {
+        if (t->W == 1) bft_kh_insert_seq<1>(t->kh.data(), lines, &t->tk[i], (uint32_t)i);
+        else bft_kh_insert_seq<2>(t->kh.data(), lines, &t->tk[i * 2], (uint32_t)i);
+    }
+    t->im.kh = t->kh.data();
+    t->im.kh_lines = lines;
+    return lines;
+}
+template <int W>
+static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
+    std::vector<uint64_t> tq;
+    to_tform<W>(q, nq, t->B, t->k, tq);
+    uint64_t cnt = 0;
+    memset(bits, 0, (nq + 7) / 8);
+    for (uint64_t i = 0; i < nq; i++) {
+        uint32_t v = 0xFFFFFFFFu;
+        const bool hit = bft_kh_lookup<W>(t->im.kh, t->im.kh_lines, &tq[i * W], &v);
+        if (hit) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
+        if (vals) vals[i] = hit ? v : 0xFFFFFFFFu;
+    }
+    return cnt;
+}
+extern "C" int64_t bft_hosttest_query_kh(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
+    HostTrie* t = (HostTrie*)hv;
+    if (!t->im.kh) return -1;
+    return (int64_t)(t->W == 1 ? query_kh<1>(t, q, nq, bits, vals) : query_kh<2>(t, q, nq, bits, vals));
+}
+// mean lines read per lookup of the stored k-mers themselves, and the longest run (diagnostics of the table's occupancy)
+extern "C" double bft_hosttest_kh_probe_stats(void* hv, uint64_t* longest) {
+    HostTrie* t = (HostTrie*)hv;
+    if (!t->im.kh) return 0.0;
+    const uint64_t n = t->tk.size() / t->W, lines = t->im.kh_lines;
+    uint64_t total = 0, worst = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t* key = &t->tk[i * t->W];
+        uint64_t ln = t->W == 1 ? bft_kh_home<1>(key, lines) : bft_kh_home<2>(key, lines), steps = 1;
+        const uint32_t S = BFT_KH_SLOTS(t->W);
+        for (;; steps++) {
+            const uint64_t* line = t->kh.data() + ln * BFT_KH_LINE_WORDS;
+            bool hit = false;
+            for (uint32_t s = 0; s < S; s++) hit = hit || memcmp(line + s * t->W, key, t->W * 8) == 0;
+            if (hit) break;
+            ln = ln + 1 == lines ? 0 : ln + 1;
+        }
+        total += steps;
+        worst = std::max(worst, steps);
+    }
+    if (longest) *longest = worst;
+    return n ? (double)total / (double)n : 0.0;
 }
 
 // node prefix hash (BFT_NPH_*): the enumeration of k_nph_fill, sequential; on / off.  tiny != 0 sizes the table far too small so
@@ -181,9 +234,8 @@ extern "C" void bft_hosttest_root_direct(void* hv, int on) {
 extern "C" uint64_t bft_hosttest_root_plain(void* hv) { return ((HostTrie*)hv)->rstart_plain; }
 
 // suffix-group probe mode of the walk (BftImage::probe_big): same answers either way
-extern "C" void bft_hosttest_set_probe(void* hv, int big) {  // 0: 4-row blocks, 1: 8-row blocks, 2: one-load probes
+extern "C" void bft_hosttest_set_probe(void* hv, int big) {  // 0: 4-row blocks, 1: 8-row blocks
     ((HostTrie*)hv)->im.probe_big = big == 1 ? 1u : 0u;
-    ((HostTrie*)hv)->probe2 = big == 2;
 }
 
 extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* rows) {
@@ -196,14 +248,13 @@ extern "C" uint64_t bft_hosttest_query(void* hv, const uint8_t* q, uint64_t nq, 
     }
 }
 
-// out[10]=groups in the hashed form [11]=of which left unhashed
 // out[0]=k-mers [1]=nodes [2]=CCs [3]=UC rows [4]=child nodes [5]=prefixes [6]=CCs s=4 [7]=max CCs/node [8]=root CCs [9]=root UC rows
 extern "C" void bft_hosttest_stats(void* hv, uint64_t* out) {
     HostTrie* t = (HostTrie*)hv;
     out[0] = t->tk.size() / t->W; out[1] = t->idx.nodes.size(); out[2] = t->idx.ccs.size(); out[3] = t->idx.ucrow.size();
     out[4] = t->idx.n_child_nodes; out[5] = t->idx.n_prefixes; out[6] = t->idx.n_ccs_s4; out[7] = t->idx.max_ccs_per_node;
     out[8] = t->idx.nodes[0].ncc; out[9] = t->idx.nodes[0].uc_n;
-    out[10] = t->idx.n_gh_groups; out[11] = t->idx.n_gh_unhashed;
+    out[10] = 0; out[11] = 0;
 }
 
 // T-form round trip: packed -> T -> packed
@@ -252,8 +303,7 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     else if (nm == "uck") { p = t->idx.uck.data(); n = t->idx.uck.size() * 8; }
     else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }
     else if (nm == "tk") { p = t->tk.data(); n = t->tk.size() * 8; }
-    else if (nm == "tkh") { p = t->idx.tkh.data(); n = t->idx.tkh.empty() ? 0 : 2 * (t->tk.size() / t->W) * (uint64_t)t->W * 8; }  // without the slack words
-    else if (nm == "tkrank") { p = t->idx.tkrank.data(); n = t->idx.tkrank.empty() ? 0 : 2 * (t->tk.size() / t->W); }
+    else if (nm == "kh") { p = t->kh.data(); n = t->kh.size() * 8; }
     else return -1;
     if (nbytes) *nbytes = n;
     if (out) { if (cap < n) return -6; memcpy(out, p, n); }

@@ -102,21 +102,20 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 #define BFT_RDIR_VALID (1ull << 63)
 #define BFT_CLUS_LEN_SHIFT 32
 
-// Hashed form of the suffix groups (derived, optional; W <= 2 and 2k % 64 != 0).  The reference finds a suffix in its group
-// by binary search + memcmp (src/UC.c:81-124, src/presenceNode.c:1874-1915): log2(n) dependent cache lines; the sorted table
-// with interpolated block probes needs ~1.3 (26-row groups) to ~2 (170-row groups).  Here every group of BFT_GH_MIN..BFT_GH_MAX
-// rows [idx, idx+cnt) ALSO owns the slots [2 idx, 2 (idx+cnt)) of `tkh`: 32-byte buckets of four slots (one-word rows; 64
-// bytes for two-word rows), row -> bucket by a hash of its T-form, placed in the first of its home bucket and the next
-// BFT_GH_MAXD buckets (cyclically inside the group's region) with a free slot, in row order -- deterministic.  A lookup reads
-// the home bucket: found, or a free slot there => decided in ONE line; a full bucket without the row => next bucket.  A group
-// whose rows do not fit that rule is left unhashed: its whole region holds BFT_GH_UNHASHED and the lookup falls back to the
-// sorted table, which stays the authoritative copy (extraction, .bft files, branching scans use it).  Same answers always.
-#define BFT_GH_MIN 8u
-#define BFT_GH_MAX 255u
-#define BFT_GH_SLOTS 4u
-#define BFT_GH_MAXD 7u
-#define BFT_GH_EMPTY (~0ull)
-#define BFT_GH_UNHASHED (~0ull - 1ull)
+// k-mer hash (derived when the image is bound, optional; W <= 2 and 2k % 64 != 0): EVERY stored k-mer, whatever container of the trie
+// holds it, in one open-addressed table of 64-byte lines keyed by its T-form.  A line = BFT_KH_SLOTS(W) keys (W words each) followed by
+// as many 32-bit values (the k-mer's colour-set id) -- five slots for one-word keys, three for two-word keys.  A k-mer lives in the
+// first line at or after its home line (cyclically) that had a free slot when it was inserted, so a lookup reads lines from the home
+// line on until it meets the key (present; its colour set sits in the same line) or a line with a free slot (absent): ONE cache
+// line beyond the L2 per query at the default load (two slots per k-mer: 1.03-1.07 lines on average), where the container walk
+// of src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe even in its fastest form here.  On MI355X a
+// kernel of random gathers is bound by the number of lines it misses on (tools/microbench/gather.hip: ~55 G lines/s beyond the L2,
+// whether the lane reads 8 or 128 bytes of the line), so lines per query is the whole cost.  The table never changes an answer:
+// it holds exactly the k-mers of the sorted table `tk` (which stays the authoritative copy: rows, extraction, .bft files) and the
+// walk is used whenever the table is absent (k >= 64, 2k % 64 == 0, "kmer_hash" 0, allocation failure) or rows are asked for.
+#define BFT_KH_LINE_WORDS 8u
+#define BFT_KH_EMPTY (~0ull)
+#define BFT_KH_SLOTS(W) ((W) == 1 ? 5u : 3u)
 
 // Node prefix hash (derived when the image is bound, optional): the prefix entries of every node BELOW the root in one hash table
 // keyed by (node id, rotated prefix) -- 64-byte buckets of four {key, entry} pairs, sized for <= 1 key per bucket on average.  On a
@@ -152,10 +151,9 @@ struct BftImage {
     const uint64_t* clus;
     const uint64_t* child;
     const uint64_t* tk;       // [n_kmers * W] sorted T-form table
-    const uint64_t* tkh;      // [2 * n_kmers * W] hashed form of the suffix groups (BFT_GH_*, below), or NULL
-    const uint8_t* tkrank;    // [2 * n_kmers] row of a hashed slot, relative to its group's first row
+    const uint64_t* kh;       // [kh_lines * 8] k-mer hash (BFT_KH_*, above), or NULL
+    uint64_t kh_lines;
     const uint32_t* tcol;     // [n_kmers] colour-set id per row
-    const uint32_t* tcolh;    // [2 * n_kmers] colour-set id per slot of the hashed groups (derived on demand: sequence queries), or NULL
     uint32_t emit_cs;         // per launch: the query kernels write the colour set of a found k-mer where they otherwise write its row
     const uint64_t* uck;      // [n_uc_rows * W] node-UC rows (T-form)
     const uint32_t* ucrow;    // [n_uc_rows] row of that k-mer in tk

@@ -29,10 +29,6 @@ struct BloomBits {
 template <int W>
 bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex& o) {
     const int L = k / 9, rb = 2 * (k - 9 * L);
-    if (bft_gh_usable(k, W)) {  // hashed form of the suffix groups: two slots per row, all free
-        o.tkh.assign(2 * n * W + 8, BFT_GH_EMPTY);
-        o.tkrank.assign(2 * n + 8, 0);
-    }
     std::vector<NodeRange> cur{{0, n}};
     uint32_t node_base = 0;  // global id of cur[0]
     for (int d = 0; d < L && !cur.empty(); d++) {
@@ -198,11 +194,6 @@ bool run(const uint64_t* tk, uint64_t n, int k, const uint32_t* hm, BftHostIndex
                             ent |= (uint64_t)(node_base + M + next.size());
                             next.push_back(NodeRange{pref_row[p], pref_row[p] + cnt});
                             o.n_child_nodes++;
-                        }
-                        const bool is_group = d == L - 1 ? rb != 0 : cnt <= BFT_NB_KMERS_PER_UC;
-                        if (is_group && !o.tkh.empty() && bft_gh_group((uint32_t)cnt)) {
-                            o.n_gh_groups++;
-                            if (!bft_gh_build_group<W>(tk, o.tkh.data(), o.tkrank.data(), pref_row[p], (uint32_t)cnt)) o.n_gh_unhashed++;
                         }
                         if (len == 1) o.clus[clus_slot] = ent;
                         else o.child.push_back(ent);

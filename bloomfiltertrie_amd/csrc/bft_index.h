@@ -28,10 +28,6 @@ struct BftHostIndex {
     // derived by bft_flatten_index: extended CC headers and the flat form of the CCs with >= flat_min prefixes
     std::vector<BftCCX> ccx;
     std::vector<uint64_t> f18, fent;
-    // hashed form of the suffix groups (BFT_GH_*, bft_image.h): empty when k does not allow it
-    std::vector<uint64_t> tkh;
-    std::vector<uint8_t> tkrank;
-    uint64_t n_gh_groups = 0, n_gh_unhashed = 0;
     std::string error;
     // shape counters (printMemory.c-style)
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0;

@@ -144,7 +144,7 @@ __global__ void k_seq_tiles(const uint64_t* __restrict__ pos_off, uint32_t n_seq
 
 // k_seq_walk8 / k_seq_walk6: one lane per k-mer position of the chunk, persistent grid like k_query (same LDS staging).
 // A wavefront holds 64 consecutive positions: sequence of its first position from k_seq_tiles, then each lane steps forward;
-// window from the code stream; bft_walk; slot / row -> colour set (one gather); the colour set of the position (0xFFFFFFFF: no
+// window from the code stream; bft_walk; row -> colour set (one gather); the colour set of the position (0xFFFFFFFF: no
 // k-mer there, or absent) goes to csout[p] -- 4 bytes per position, the only per-position array of the path.
 // (Counting inside this kernel was tried: the counter lines and the range table are pushed out of the L2 by the walk's gathers,
 // 2.4 L2 misses per position instead of ~1.9, 6.0 ms instead of 4.2 per 10^6 reads of 150 nt.)
@@ -204,6 +204,30 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
     BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
     const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical, uint32_t* __restrict__ csout) {
     seq_walk_body<W, BFT_BLOCK6, STAGED, PROBE>(im, codes, bad, seq_off, pos_off, tile_seq, n_seqs, canonical, csout);
+}
+
+// The same through the k-mer hash (BFT_KH_*): the colour set of a position sits in the cache line that says the k-mer is stored --
+// one line per position, nothing staged.
+template <int W>
+__global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
+                                                const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
+                                                uint32_t* __restrict__ csout) {
+    const uint64_t P = pos_off[n_seqs];
+    const uint64_t nblk = (P + 255) / 256;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t p = blk * 256 + threadIdx.x;
+        if (p >= P) continue;
+        uint32_t lo = tile_seq[p >> 6];
+        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
+        uint32_t cs = 0xFFFFFFFFu;
+        uint64_t x[W], t[W];
+        if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
+            bft_tform_from_x<W>(x, im.k, t);
+            uint32_t val;
+            if (bft_kh_lookup<W>(im.kh, im.kh_lines, t, &val)) cs = val;
+        }
+        csout[p] = cs;
+    }
 }
 
 // Per-(sequence, genome) counters and the threshold, one WAVEFRONT per sequence, counters in LDS: no counter matrix in HBM, no

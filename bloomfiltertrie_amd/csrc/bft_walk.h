@@ -11,9 +11,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BFT_HD __host__ __device__ __forceinline__
-// (Tried: the rare paths -- sorted-table searches behind the hashed groups, node UC -- as real calls, __attribute__((noinline)).
-// The calling convention cost more scratch than the inlined arrays: 84-150 spilled VGPRs instead of 0-30.  PROBE 3 below removes
-// the block-probe code from the kernels that have the hashed groups instead.)
+// (Tried: the rare paths -- node UC, galloping searches -- as real calls, __attribute__((noinline)).  The calling convention cost
+// more scratch than the inlined arrays: 84-150 spilled VGPRs instead of 0-30.)
 #define BFT_HD_RARE __host__ __device__ __forceinline__
 #else
 #define BFT_HD inline
@@ -296,107 +295,85 @@ struct BftRootGlobal {
 
 struct BftHit {
     int present;
-    uint64_t row;      // row of the k-mer in tk (valid when present and gh_slot < 0)
-    int64_t gh_slot;   // >= 0: found in slot gh_slot of the hashed groups; its row is `row` (the group's first row) + tkrank[gh_slot]
+    uint64_t row;      // row of the k-mer in tk (valid when present)
 };
-// the row of a found k-mer (one more byte load when it was found through the hashed form: only callers that return rows pay it)
-BFT_HD uint64_t bft_hit_row(const BftImage& im, const BftHit& h) { return h.gh_slot >= 0 ? h.row + im.tkrank[h.gh_slot] : h.row; }
-// what a query kernel writes for a found k-mer: its row, or -- im.emit_cs, the colour-row and sequence paths -- its colour set, which for
-// a hit in the hashed groups is ONE gather (slot -> colour set) instead of three (slot -> rank, row -> colour set in a later pass)
-BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) {
-    if (im.emit_cs) return (h.gh_slot >= 0 && im.tcolh) ? im.tcolh[h.gh_slot] : im.tcol[bft_hit_row(im, h)];
-    return (uint32_t)bft_hit_row(im, h);
-}
+// what a query kernel writes for a found k-mer: its row, or -- im.emit_cs, the colour-row and sequence paths -- its colour set
+BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) { return im.emit_cs ? im.tcol[h.row] : (uint32_t)h.row; }
 
-// ---- hashed form of the suffix groups (bft_image.h, BFT_GH_*) ----
-BFT_HD bool bft_gh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }
-BFT_HD bool bft_gh_group(uint32_t cnt) { return cnt >= BFT_GH_MIN && cnt <= BFT_GH_MAX; }
+// ---- k-mer hash (bft_image.h, BFT_KH_*) ----
+BFT_HD bool bft_kh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }  // (the empty marker needs a key word that cannot be all ones)
 template <int W>
-BFT_HD uint32_t bft_gh_home(const uint64_t* t, uint32_t nbk) {
+BFT_HD uint64_t bft_kh_home(const uint64_t* t, uint64_t n_lines) {
     uint64_t h = t[0];
 #pragma unroll
     for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + t[w];
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;  // 64-bit finalizer (murmur3)
-    return (uint32_t)(((h >> 32) * (uint64_t)nbk) >> 32);
-}
-BFT_HD void bft_gh_region(uint64_t idx, uint32_t cnt, uint64_t* b0, uint32_t* nbk) {
-    *b0 = (idx + 1) >> 1;                        // first 4-slot bucket inside the slots [2 idx, 2 (idx + cnt))
-    *nbk = (uint32_t)(((idx + cnt) >> 1) - *b0);  // >= 3 for cnt >= BFT_GH_MIN
-}
-// Builds the hashed form of one group (rows in order: deterministic); tkh must hold BFT_GH_EMPTY in every word of the region.
-// Returns false when a row found no slot within BFT_GH_MAXD buckets of its home: the region is then marked unhashed.
-template <int W>
-BFT_HD bool bft_gh_build_group(const uint64_t* tk, uint64_t* tkh, uint8_t* tkrank, uint64_t idx, uint32_t cnt) {
-    uint64_t b0;
-    uint32_t nbk;
-    bft_gh_region(idx, cnt, &b0, &nbk);
-    for (uint32_t i = 0; i < cnt; i++) {
-        uint64_t t[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) t[w] = tk[(idx + i) * W + w];
-        uint32_t b = bft_gh_home<W>(t, nbk);
-        bool placed = false;
-        for (uint32_t d = 0; d <= BFT_GH_MAXD && d < nbk && !placed; d++) {
-            for (uint32_t s = 0; s < BFT_GH_SLOTS && !placed; s++) {
-                const uint64_t slot = (b0 + b) * BFT_GH_SLOTS + s;
-                if (tkh[slot * W] == BFT_GH_EMPTY) {
-#pragma unroll
-                    for (int w = 0; w < W; w++) tkh[slot * W + w] = t[w];
-                    tkrank[slot] = (uint8_t)i;
-                    placed = true;
-                }
-            }
-            b = b + 1 == nbk ? 0 : b + 1;
-        }
-        if (!placed) {
-            for (uint64_t slot = b0 * BFT_GH_SLOTS; slot < (b0 + nbk) * BFT_GH_SLOTS; slot++) {
-                tkh[slot * W] = BFT_GH_UNHASHED;
-#pragma unroll
-                for (int w = 1; w < W; w++) tkh[slot * W + w] = BFT_GH_EMPTY;
-                tkrank[slot] = 0;
-            }
-            return false;
-        }
-    }
-    return true;
-}
-// Lookup.  Returns true when the hashed form decided (hit filled when found), false when the group is unhashed.
-template <int W>
-BFT_HD bool bft_gh_lookup(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, BftHit& hit) {
-    uint64_t b0;
-    uint32_t nbk;
-    bft_gh_region(idx, cnt, &b0, &nbk);
-    uint32_t b = bft_gh_home<W>(t, nbk);
-    for (uint32_t d = 0; d <= BFT_GH_MAXD; d++) {  // (the first bucket decides ~85 % of the lookups: not unrolled)
-        const uint64_t s0 = (b0 + b) * BFT_GH_SLOTS;
-        uint64_t v[BFT_GH_SLOTS][W];
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (W == 1) {
-#pragma unroll
-            // 16-byte loads of one 32-byte aligned bucket.  (Non-temporal loads here, meant to keep the range table in the L2, were
-            // measured: config 2 2.33 -> 3.63 ms, config 4 3.70 -> 4.55 ms per launch -- they also bypass the Infinity Cache.)
-            for (uint32_t s = 0; s < BFT_GH_SLOTS; s += 2) {
-                const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(im.tkh + s0 + s);
-                v[s][0] = q.x;
-                v[s + 1][0] = q.y;
-            }
-        } else
+    return __umul64hi(h, n_lines);
+#else
+    return (uint64_t)(((unsigned __int128)h * n_lines) >> 64);
 #endif
-        {
+}
+// lines of the table of an index of n k-mers at `load_pct` per cent occupancy (default 50: two slots per k-mer)
+BFT_HD uint64_t bft_kh_lines_for(uint64_t n, int W, uint32_t load_pct) {
+    const uint64_t per_line = (uint64_t)BFT_KH_SLOTS(W) * load_pct;  // k-mers per line x 100
+    const uint64_t lines = (n * 100ull + per_line - 1) / per_line;
+    return lines < 4 ? 4 : lines + 1;
+}
+// One line into registers: the keys with 16-byte loads (the line is 64-byte aligned), nothing else -- the value is read only on a hit.
+template <int W>
+BFT_HD void bft_kh_load_keys(const uint64_t* line, uint64_t (*key)[W]) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (W == 1) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(line), b = *reinterpret_cast<const ulonglong2*>(line + 2);
+        key[0][0] = a.x; key[1][0] = a.y; key[2][0] = b.x; key[3][0] = b.y; key[4][0] = line[4];
+        return;
+    }
+#endif
 #pragma unroll
-            for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) bft_load_row<W>(im.tkh + (s0 + s) * W, v[s]);
-        }
+    for (uint32_t s = 0; s < S; s++) bft_load_row<W>(line + s * W, key[s]);
+}
+// Lookup: true when t is stored; *val = its value (the colour-set id).  Lines from the home line on: the key, or a free slot, ends it.
+template <int W>
+BFT_HD bool bft_kh_lookup(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t* val) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+    uint64_t ln = bft_kh_home<W>(t, n_lines);
+    for (;;) {
+        const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
+        uint64_t key[S][W];
+        bft_kh_load_keys<W>(line, key);
+        int at = -1;
         bool free_slot = false;
 #pragma unroll
-        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) {
-            if (v[s][0] == BFT_GH_UNHASHED) return false;
-            if (bft_cmp<W>(v[s], t) == 0) { hit.present = 1; hit.row = idx; hit.gh_slot = (int64_t)(s0 + s); return true; }
-            free_slot = free_slot || v[s][0] == BFT_GH_EMPTY;
+        for (uint32_t s = 0; s < S; s++) {
+            if (bft_cmp<W>(key[s], t) == 0) at = (int)s;
+            free_slot = free_slot || key[s][0] == BFT_KH_EMPTY;
         }
-        if (free_slot || d + 1 >= nbk) return true;  // the row would sit here or earlier: absent
-        b = b + 1 == nbk ? 0 : b + 1;
+        if (at >= 0) {
+            *val = reinterpret_cast<const uint32_t*>(line + S * W)[at];
+            return true;
+        }
+        if (free_slot) return false;  // t would have been put here
+        ln = ln + 1 == n_lines ? 0 : ln + 1;
     }
-    return true;
+}
+// Sequential insertion (the host restatement; the GPU kernel k_kh_insert claims slots with atomicCAS instead -- which slot of which
+// line a key lands in may then differ, what a lookup returns cannot).  The table must hold BFT_KH_EMPTY in every key word.
+template <int W>
+BFT_HD void bft_kh_insert_seq(uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t val) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+    uint64_t ln = bft_kh_home<W>(t, n_lines);
+    for (;;) {
+        uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
+        for (uint32_t s = 0; s < S; s++)
+            if (line[s * W] == BFT_KH_EMPTY) {
+                for (int w = 0; w < W; w++) line[s * W + w] = t[w];
+                reinterpret_cast<uint32_t*>(line + S * W)[s] = val;
+                return;
+            }
+        ln = ln + 1 == n_lines ? 0 : ln + 1;
+    }
 }
 
 // The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
@@ -608,15 +585,13 @@ BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, const uint64_t* 
 
 // d = the level that owns the group (its rows differ only in the key bits below that level)
 // PROBE: 0 / 1 fixes the mode at compile time (k_query: the 4-row code needs fewer registers than the 8-row one), -1 reads
-// im.probe_big.  PROBE 2 = ONE 16-byte load per probe (two one-word rows, or one two-word row) with a re-interpolated guess:
-// the mode of the bucketed kernel, whose table slice sits in the L2 -- there a probe costs per load instruction, not per
-// cache line missed, so wide blocks lose (measured: 8-row blocks 5.4 ms) and interpolation converges in 2-3 loads.
+// im.probe_big.
 template <int W, int PROBE>
 BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
     uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
     int dir = 0;
     const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
-    constexpr int NS = 4, NB = PROBE == 2 ? (W == 1 ? 2 : 1) : (W == 1 ? 8 : 4);  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
+    constexpr int NS = 4, NB = W == 1 ? 8 : 4;  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
 #pragma unroll
     for (int step = 0; step < BFT_PROBE_STEPS; step++) {
         if (big ? bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit) : bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit)) return;
@@ -642,20 +617,6 @@ BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt,
 // prefixes, then block probes (groups of >= BFT_WINDOW_PROBE rows of one or two words) or a galloping search.
 template <int W, int PROBE>
 BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit) {
-    if (W <= 2 && im.tkh != nullptr && bft_gh_group(cnt) && bft_gh_lookup<W>(im, idx, cnt, t, hit)) return;
-    if (PROBE == 3) {
-        // kernels launched on an image WITH the hashed groups: what is left for the sorted table are groups of fewer than 8 rows
-        // (<= 3 steps), the 0.02 % unhashed groups and remainder groups beyond 255 rows -- a plain binary search, and none of the
-        // block-probe code (its row arrays cost the 64-VGPR kernels their registers: 28-30 spilled VGPRs on two-word rows)
-        const uint64_t* rows = im.tk + idx * W;
-        const uint32_t z = bft_rows_lower_bound<W>(rows, cnt, t);
-        if (z < cnt) {
-            uint64_t q[W];
-            bft_load_row<W>(rows + (size_t)z * W, q);
-            if (bft_cmp<W>(q, t) == 0) { hit.present = 1; hit.row = idx + z; }
-        }
-        return;
-    }
     const uint64_t next36 = bft_next36<W>(t, im.k, d);
     const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
@@ -681,7 +642,6 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
     BftHit hit;
     hit.present = 0;
     hit.row = 0;
-    hit.gh_slot = -1;
     uint32_t node = 0;
     const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
     for (int d = d0; d < L; d++) {
@@ -776,60 +736,6 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         return hit;
     }
     return hit;
-}
-
-// Four k-mers at once through the derived tables (branching: the four successors / predecessors of a k-mer): root range table
-// -> hashed suffix group, with the loads of all four issued before any is used -- four independent two-load chains in flight
-// instead of four walks one after the other.  Decides a candidate only when its root prefix is plain and its group hashed (or
-// empty) and the home bucket settles it; returns a 4-bit mask of the decided candidates and sets bit v of *present for those
-// found.  The caller walks the others (bft_walk gives the same answer for any candidate, decided here or not).
-template <int W>
-BFT_HD uint32_t bft_fast4(const BftImage& im, const uint64_t (*t)[W], uint32_t* present) {
-    *present = 0;
-    // one-word rows only: sixteen two-word slots in flight do not fit the 64 VGPRs of the 8-waves-per-SIMD kernels (measured: spills)
-    if (W > 1 || im.rstart == nullptr || im.tkh == nullptr || im.L < 2) return 0u;
-    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-    uint32_t a[4], cnt[4], decided = 0;
-    uint64_t s0[4];
-    bool go[4];
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        const uint32_t r = bft_digit<W>(t[v], im.k, 0);
-        const Pair pr = *reinterpret_cast<const Pair*>(im.rstart + r);
-        a[v] = pr.a;
-        cnt[v] = (pr.b & ~BFT_RSTART_SPECIAL) - (pr.a & ~BFT_RSTART_SPECIAL);
-    }
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        const bool plain = !(a[v] & BFT_RSTART_SPECIAL);
-        if (plain && cnt[v] == 0) decided |= 1u << v;  // no k-mer under that root prefix
-        go[v] = plain && bft_gh_group(cnt[v]);
-        uint64_t b0 = 0;
-        uint32_t nbk = 1;
-        if (go[v]) bft_gh_region(a[v], cnt[v], &b0, &nbk);
-        s0[v] = go[v] ? (b0 + bft_gh_home<W>(t[v], nbk)) * BFT_GH_SLOTS : 0;
-    }
-    uint64_t sl[4][BFT_GH_SLOTS][W];
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-#pragma unroll
-        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) bft_load_row<W>(im.tkh + (s0[v] + s) * W, sl[v][s]);  // (slot 0.. of the table when !go: harmless)
-    }
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        if (!go[v]) continue;
-        bool hit = false, free_slot = false, unhashed = false;
-#pragma unroll
-        for (uint32_t s = 0; s < BFT_GH_SLOTS; s++) {
-            unhashed = unhashed || sl[v][s][0] == BFT_GH_UNHASHED;
-            hit = hit || bft_cmp<W>(sl[v][s], t[v]) == 0;
-            free_slot = free_slot || sl[v][s][0] == BFT_GH_EMPTY;
-        }
-        if (unhashed) continue;
-        if (hit) { *present |= 1u << v; decided |= 1u << v; }
-        else if (free_slot) decided |= 1u << v;  // the row would sit in this bucket: absent
-    }
-    return decided;
 }
 
 // How many of the four rows t | v << vo (v = 0..3; t has those two bits clear) the suffix group [idx, idx+cnt) holds.  The
@@ -969,7 +875,6 @@ BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& r
                 BftHit hit;
                 hit.present = 0;
                 hit.row = 0;
-                hit.gh_slot = -1;
                 tt[W - 1] = t[W - 1] | (v << vo);
                 bft_uc_search<W>(im, nd, tt, hit);
                 count += hit.present;
@@ -987,7 +892,6 @@ BFT_HD int bft_walk_last4(const BftImage& im, const Root& root, const BftNode& r
             BftHit hit;
             hit.present = 0;
             hit.row = 0;
-            hit.gh_slot = -1;
             tt[W - 1] = t[W - 1] | (v << vo);
             bft_group_search<W, 0>(im, idx, cnt, tt, d, hit);
             count += hit.present;

@@ -140,26 +140,37 @@ int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_km
  * [8]=max CCs per node, [9]=(k-mer,genome) pairs, [10]=distinct colour sets, [11]=genomes,
  * [12]=image bytes in HBM, [13]=root CCs, [14]=root UC rows, [15]=pending (unbuilt) pairs. */
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
+/* Bytes resident in HBM per part of the handle (the walk of src/printMemory.c:255 reports the reference's bytes per container kind):
+ * out[0]=sorted k-mer table tk, [1]=colour-set id per k-mer, [2]=colour-set dictionary, [3]=containers (nodes, Bloom blocks, CC headers, filter2
+ * words, cluster table, prefix entries, node UCs), [4]=flat form of the big CCs, [5]=root tables, [6]=node prefix hash, [7]=k-mer hash,
+ * [8]=bitmap form of the dictionary (derived by the first colour-row query), [9]=hash table (hash_v % 1504), [10]=sorted (k-mer, genome) pair store kept
+ * for later insertions (not counted in out[12] of bft_gpu_info), [11]=pending insertion log. */
+int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
 
-/* Tuning knobs: "query_wgs_per_cu" (how k_query sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per SIMD
- * with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each -- the two-word rows of k = 36..63 fit that budget and not the one
- * of 2; 0 = measured on the index when it is built and once more on the first batch of 2^24 queries or more, see "query_bucket_bits"), "query_probe" (rows per probe of the suffix-group search: 4 = adjacent
- * 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = measured like the residency), "query_grid_mult"
- * (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into one
- * hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "group_hash" (1, default: suffix groups of 8..255 rows also get a hashed form -- 32-byte
- * buckets, one cache line per lookup -- built with the containers and used by every query; 0: sorted table only), "root_direct" (the root level goes through tables derived from the containers:
- * 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain suffix groups, backed by the 2 MiB table; 3, default = 1 or 2,
- * whichever measured faster on the image; 0 = the containers), "query_bucket_bits" (large batches -- 2^22 queries and more -- are partitioned by the top bits of their rotated
- * root prefix so that every XCD walks its own slices of the index out of its L2: -1 = measured on the first batch of 2^24 queries or more of an image,
- * which makes that one call synchronise; 0 = never; 4..10 = always, with that many bits; answers are identical either way), "build_composite" (1, default: one-word keys whose genome ids arrive ascending and fit the key's spare low bits are sorted as one 8-byte composite
- * array; 0: the general key + value sort -- same image either way, a test hook), "reserve_pairs" (room in the insertion log for this many
- * pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it), "timing" (0/1: record HIP events around query kernels;
- * off until this option or the first bft_gpu_kernel_time call turns it on), "flat_min" (CCs with at
- * least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none). */
+/* Options.
+ * "kmer_hash" (1, default): besides the containers, every stored k-mer also sits in one open-addressed table of 64-byte lines keyed by its
+ *   T-form, value = its colour-set id; presence, colour, sequence and branching queries then cost ONE cache line per k-mer instead of a
+ *   container walk (src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe).  k <= 63 with 2k % 64 != 0; the table is
+ *   derived when an image is built, loaded or unpacked; rows (bft_gpu_query_rows) always come from the walk.  0: every query walks the containers.
+ * "kmer_hash_load" (50): occupancy of that table in per cent, 10..80 (50 = two slots per k-mer: 1.03-1.07 lines read per lookup).
+ * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
+ *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
+ *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
+ *   "query_grid_mult" (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into
+ *   one hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "root_direct" (the root level
+ *   goes through tables derived from the containers: 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain
+ *   suffix groups, backed by the 2 MiB table; 3, default = 2 unless most root prefixes are child Nodes; 0 = the containers), "flat_min" (CCs with at
+ *   least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none), "tune" (1: measure residency, probe
+ *   mode and root tables of the walk on the current image with a batch drawn from the index -- the only call that times anything; it synchronises;
+ *   nothing is ever tuned implicitly by a build or a query).
+ * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending and fit the key's spare low bits are sorted as one 8-byte composite
+ *   array; 0: the general key + value sort -- same image either way, a test hook), "reserve_pairs" (room in the insertion log for this many
+ *   pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it).
+ * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
 /* Test hook: raw device->host copy of one array of the image ("nodes", "bfT", "ccs", "f2w", "clus",
- * "child", "uck", "ucrow", "tk", and the derived "ccx", "f18", "fent", "tkh", "tkrank"); out may be NULL to query the size. */
+ * "child", "uck", "ucrow", "tk", "tcol", and the derived "ccx", "f18", "fent", "kh"); out may be NULL to query the size. */
 int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t cap_bytes, uint64_t* nbytes);
 
 /* HIP-event timing of the query kernels launched through this handle since the last reset:
@@ -167,12 +178,11 @@ int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t ca
  * first call of this function turns it on, so call it once (reset = 1) before the region to be timed. */
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
- * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, colour-set bitmaps) + k_query residency tuning, ms[5]=resident
- * k_query workgroups per CU in use, ms[6..7]=time of the tuning batch with 1 / 2 workgroups per CU (0 when not tuned), ms[8]=rows per suffix-group probe in use (4 or 8),
- * ms[9]=prefix-bucket bits in use for large batches (0 = direct kernel, -1 = not measured yet), ms[10..11]=time of the first large batch without / with bucketing,
- * ms[12]=suffix groups that own a hashed form, ms[13]=of which left unhashed (searched in the sorted table), ms[14]=root tables in use (0 / 1 / 2, see "root_direct"),
- * ms[15..16]=time of the tuning batch with the direct table alone / with the range table, ms[17]=keys in the node prefix hash, ms[18]=keys it dropped (full bucket:
- * those lookups take the container path), ms[19]=time of the tuning batch with residency 3 (ms[5] reports 1, 2 or 3). */
+ * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, root tables, node prefix
+ * hash, k-mer hash), ms[5]=resident k_query workgroups per CU in use (1, 2 or 3), ms[6..7]=time of the "tune" batch with 1 / 2 workgroups per CU (0 when not
+ * tuned), ms[8]=rows per suffix-group probe in use (4 or 8), ms[9]=lines of the k-mer hash (0 = none), ms[10]=GPU time of its fill, ms[11..13]=0,
+ * ms[14]=root tables in use (0 / 1 / 2, see "root_direct"), ms[15..16]="tune": time with the direct table alone / with the range table, ms[17]=keys in the
+ * node prefix hash, ms[18]=keys it dropped (full bucket: those lookups take the container path), ms[19]="tune": time with residency 3. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,

@@ -72,7 +72,12 @@ def hostlib(built):
     lib.bft_hosttest_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_set_probe.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_root_direct.argtypes = [C.c_void_p, C.c_int]
-    lib.bft_hosttest_group_hash.argtypes = [C.c_void_p, C.c_int]
+    lib.bft_hosttest_kmer_hash.restype = C.c_uint64
+    lib.bft_hosttest_kmer_hash.argtypes = [C.c_void_p, C.c_uint32]
+    lib.bft_hosttest_query_kh.restype = C.c_int64
+    lib.bft_hosttest_query_kh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_kh_probe_stats.restype = C.c_double
+    lib.bft_hosttest_kh_probe_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_node_hash.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.bft_hosttest_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_roundtrip.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
@@ -136,33 +141,37 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     bits8, rows8 = np.zeros_like(bits), np.zeros_like(rows)
     hostlib.bft_hosttest_set_probe(h, 1)  # 8-row blocks + re-interpolated guesses: a tuning mode, same answers
     hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
-    hostlib.bft_hosttest_set_probe(h, 2)  # one 16-byte load per probe, re-interpolated: the bucketed kernel's mode
-    bits2, rows2 = np.zeros_like(bits), np.zeros_like(rows)
-    hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits2.ctypes.data, rows2.ctypes.data)
     hostlib.bft_hosttest_set_probe(h, 0)
-    assert (bits8 == bits).all() and (rows8 == rows).all() and (bits2 == bits).all() and (rows2 == rows).all()
+    assert (bits8 == bits).all() and (rows8 == rows).all()
     for rd in (1, 2):  # root level through the derived direct table (1) and through range + direct tables (2): same answers, same rows
         hostlib.bft_hosttest_root_direct(h, rd)
         hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         hostlib.bft_hosttest_root_direct(h, 0)
         assert (bits8 == bits).all() and (rows8 == rows).all()
-    for rd in (0, 1, 2):  # suffix groups through their hashed form (with and without the root direct table): same answers, same rows
-        hostlib.bft_hosttest_group_hash(h, 1)
-        hostlib.bft_hosttest_root_direct(h, rd)
-        hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
-        hostlib.bft_hosttest_group_hash(h, 0)
-        hostlib.bft_hosttest_root_direct(h, 0)
-        assert (bits8 == bits).all() and (rows8 == rows).all()
+    # the k-mer hash (BFT_KH_*; the host fill stores the row as the value): the lookup the kernels run gives the walk's answers at
+    # the default occupancy, at a sparse one and at 80 % (long runs of full lines)
+    W = (2 * k + 63) // 64
+    for load in (50, 10, 80):
+        lines = hostlib.bft_hosttest_kmer_hash(h, load)
+        if W > 2 or (2 * k) % 64 == 0 or len(km) == 0:
+            assert lines == 0 and hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data) == -1
+            continue
+        n_st = len(S.distinct(km))
+        assert lines >= -(-n_st * 100 // ((5 if W == 1 else 3) * load))
+        got = hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+        assert got == int(S.from_bits(bits, len(q)).sum()) and (bits8 == bits).all() and (rows8 == rows).all(), load
+        worst = C.c_uint64()
+        mean = hostlib.bft_hosttest_kh_probe_stats(h, C.byref(worst))
+        assert 1.0 <= mean < (1.2 if load <= 50 else 2.5), (load, mean, worst.value)
+    hostlib.bft_hosttest_kmer_hash(h, 0)
     o = oracle_mod.OracleBFT(k)
     o.insert_kmers(km, 0)
     assert (bits == o.query_presence(q)).all()
     assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
     for tiny in (0, 1):  # levels below the root through the node prefix hash (full-size table; 8-bucket table: nearly every bucket full)
         hostlib.bft_hosttest_node_hash(h, 1, tiny)
-        hostlib.bft_hosttest_group_hash(h, tiny)
         hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         hostlib.bft_hosttest_node_hash(h, 0, 0)
-        hostlib.bft_hosttest_group_hash(h, 0)
         assert (bits8 == bits).all() and (rows8 == rows).all()
     st = np.zeros(12, np.uint64)
     hostlib.bft_hosttest_stats(h, st.ctypes.data)

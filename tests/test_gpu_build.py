@@ -11,7 +11,7 @@ from bloomfiltertrie_amd import BFT, _lib, synth as S
 
 pytestmark = pytest.mark.gpu
 
-ARRAYS = ["tk", "nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "ccx", "f18", "fent", "tkh", "tkrank"]
+ARRAYS = ["tk", "nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "ccx", "f18", "fent"]
 
 
 @pytest.fixture(scope="module")

@@ -445,20 +445,24 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0, 3.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
-    # (node prefix hash, residency, grid multiplier, probe rows, root direct table, prefix-bucket bits, hashed suffix groups)
-    for blk, wgs, mult, probe, rdir, bkb, gh in [(1, 0, 1, 0, 1, 0, 1), (0, 1, 1, 4, 0, 0, 0), (1, 2, 1, 8, 2, 8, 1), (1, 3, 1, 4, 0, 6, 0), (0, 1, 3, 8, 3, 0, 0),
-                                                 (1, 2, 1, 0, 0, 10, 1), (0, 3, 2, 8, 1, 4, 1), (1, 3, 1, 0, 3, 0, 1)]:
-        t.set_option("group_hash", gh)
+    # (node prefix hash, residency, grid multiplier, probe rows, root tables, k-mer hash on/off, its occupancy, measured launch shape)
+    for blk, wgs, mult, probe, rdir, kh, load, tune in [(1, 0, 1, 0, 1, 1, 50, 0), (0, 1, 1, 4, 0, 0, 50, 0), (1, 2, 1, 8, 2, 1, 80, 0), (1, 3, 1, 4, 0, 0, 50, 1),
+                                                        (0, 1, 3, 8, 3, 1, 10, 0), (1, 2, 1, 0, 0, 0, 50, 0), (0, 3, 2, 8, 1, 1, 65, 1), (1, 3, 1, 0, 3, 0, 50, 0)]:
+        t.set_option("kmer_hash_load", load)
+        t.set_option("kmer_hash", kh)
         t.set_option("node_hash", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)
         t.set_option("query_probe", probe)
         t.set_option("root_direct", rdir)
-        t.set_option("query_bucket_bits", bkb)
+        t.set_option("tune", tune)
+        assert (t.build_time()["kmer_hash_lines"] > 0) == bool(kh)
         bits, off, ids = t.query_colors(q)
-        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, bkb, gh)
+        assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, kh, load)
+        assert (t.query_presence(q) == obits).all()
         bb, bc = t.query_branching(q[:20000], with_counts=True)
-        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult, probe, rdir, bkb, gh)
+        assert (bb == ob).all() and (bc == oc).all(), (blk, wgs, mult, probe, rdir, kh, load)
+        assert (t.query_branching(q[:20000]) == ob).all()
     with pytest.raises(Exception):
         t.set_option("query_block", 1024)  # (a round-1 knob: gone)
     with pytest.raises(Exception):
@@ -466,15 +470,17 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     with pytest.raises(Exception):
         t.set_option("query_probe", 16)
     with pytest.raises(Exception):
-        t.set_option("query_bucket_bits", 11)
+        t.set_option("query_bucket_bits", 8)  # (round 2's prefix-bucketed batches: gone)
+    with pytest.raises(Exception):
+        t.set_option("kmer_hash_load", 95)
 
 
-@pytest.mark.parametrize("k,levels", [(27, 0), (27, 2), (31, 0), (36, 0), (63, 2), (72, 0), (126, 0)])
-def test_bucketed_batches_answer_like_the_direct_kernel(oracle_mod, k, levels):
-    """Prefix-bucketed batches (bft_kernels_bucket.h: partition by the top bits of the rotated root prefix, per-XCD sweep,
-    un-permutation) give bit-identical presence bitmaps, rows and colour rows to the direct kernel, for every bucket width,
-    ragged batch sizes (not a multiple of 64 / of the tile), all-absent and all-one-bucket batches; and both agree with
-    the oracle where it exists (k % 9 == 0)."""
+@pytest.mark.parametrize("k,levels", [(27, 0), (27, 2), (31, 0), (32, 0), (36, 0), (63, 2), (72, 0), (126, 0)])
+def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
+    """The k-mer hash (BFT_KH_*: every stored k-mer in one table of 64-byte lines) gives bit-identical presence bitmaps, colour sets
+    and colour rows to the container walk -- ragged batch sizes (not a multiple of 64), all-absent batches, k-mers that share their
+    first 8 nucleotides, every occupancy; where k does not allow the table (k >= 64, k = 32) the option changes nothing; and both
+    agree with ground truth and with the oracle where it exists (k % 9 == 0)."""
     from bloomfiltertrie_amd import BFT
     anc = S.random_genome(150000, 3 + k)
     gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 50 + g), k)) for g in range(3)]
@@ -484,79 +490,102 @@ def test_bucketed_batches_answer_like_the_direct_kernel(oracle_mod, k, levels):
     for g, km in enumerate(gk):
         t.insert_kmers(km, g)
     t.build()
+    usable = k <= 63 and (2 * k) % 64 != 0
+    assert (t.build_time()["kmer_hash_lines"] > 0) == usable and (t.footprint()["kmer_hash"] > 0) == usable
     allk = S.distinct(np.concatenate(gk))
     rng = np.random.default_rng(k)
     base = np.concatenate([allk, S.snp_mutants(allk, k, 1), S.pack_codes(rng.integers(0, 4, (5000, k), dtype=np.uint8))])
-    one_bucket = base[(base[:, 0] == base[0, 0]) & (base[:, 1] == base[0, 1])]  # same first 8 nucleotides: one bucket at any width
-    for n, src in ((300_007, base), (64, base), (1, base), (8192, base), (8193, base), (len(one_bucket), one_bucket)):
+    one_prefix = base[(base[:, 0] == base[0, 0]) & (base[:, 1] == base[0, 1])]  # same first 8 nucleotides
+    absent = base[~S.member(base, allk).astype(bool)]
+    for n, src in ((300_007, base), (64, base), (1, base), (8192, base), (8193, base), (len(one_prefix), one_prefix), (5001, absent)):
         q = np.ascontiguousarray(src[rng.integers(0, len(src), n)])
-        t.set_option("query_bucket_bits", 0)
-        ref_bits, ref_rows, ref_sets = t.query_rows(q) if n > 4096 else (t.query_presence(q), None, None)
+        t.set_option("kmer_hash", 0)
+        ref_bits, ref_rows, ref_sets = t.query_rows(q)
+        ref_b3, ref_crows = t.query_color_rows(q)
         truth = S.member(q, allk)
-        assert (S.from_bits(ref_bits, n).astype(bool) == truth).all()
-        for bits in (4, 8, 10):
-            t.set_option("query_bucket_bits", bits)
-            t.set_option("root_direct", 1 if bits != 4 else 0)
-            t.set_option("group_hash", 1 if bits != 10 else 0)
-            if n > 4096:  # (batches of <= 4096 host k-mers go through the pinned small-batch path: presence only below)
-                b2, r2, s2 = t.query_rows(q)
-                assert (b2 == ref_bits).all() and (r2 == ref_rows).all() and (s2 == ref_sets).all(), (k, n, bits)
-                b3, crows = t.query_color_rows(q)
-                unp = np.unpackbits(crows, axis=1, bitorder="little")[:, :3].astype(bool)
-                assert (b3 == ref_bits).all() and (unp.any(axis=1) == truth).all()
-            else:
-                assert (t.query_presence(q) == ref_bits).all(), (k, n, bits)
+        assert (S.from_bits(ref_bits, n).astype(bool) == truth).all() and (ref_b3 == ref_bits).all()
+        for load in (50, 80, 20):
+            t.set_option("kmer_hash_load", load)
+            t.set_option("kmer_hash", 1)
+            assert (t.query_presence(q) == ref_bits).all(), (k, n, load)
+            b2, r2, s2 = t.query_rows(q)
+            assert (b2 == ref_bits).all() and (r2 == ref_rows).all() and (s2 == ref_sets).all(), (k, n, load)
+            b3, crows = t.query_color_rows(q)
+            assert (b3 == ref_bits).all() and (crows == ref_crows).all(), (k, n, load)
+            b4, off4, ids4 = t.query_colors(q[:20000])
+            sizes = np.diff(off4)
+            assert (b4 == ref_bits[: (min(n, 20000) + 7) // 8]).all()
+            assert ((sizes > 0) == truth[:20000].astype(bool)).all()
     if k % 9 == 0:
         o = oracle_mod.OracleBFT(k)
         for g, km in enumerate(gk):
             o.insert_kmers(np.ascontiguousarray(km), g)
         q = np.ascontiguousarray(base[rng.integers(0, len(base), 50_000)])
-        t.set_option("query_bucket_bits", 8)
         bits, off, ids = t.query_colors(q)
         obits, ooff, oids = o.query_colors(q)
         assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all()
+        bb, bc = t.query_branching(q[:20000], with_counts=True)
+        ob, oc, _ = o.query_branching(q[:20000])
+        assert (bb == ob).all() and (bc == oc).all()
     t.close()
 
 
-def test_bucketed_path_is_chosen_by_measurement_and_keeps_answers():
-    """The automatic mode measures both paths on the first batch of >= 2^24 queries and keeps the faster; answers before,
-    during and after that measurement are the same."""
-    import torch
-    from bloomfiltertrie_amd import BFT, workloads as W
-    k = 27
-    dev = torch.device("cuda", 0)
-    pan = W.PanGenome(8, 1_000_000, 0.01, 5, dev)
+def _kh_home(key_words, n_lines):
+    """bft_kh_home restated with Python integers (tests only)."""
+    M = (1 << 64) - 1
+    h = key_words[0]
+    for w in key_words[1:]:
+        h = (((h ^ (h >> 29)) * 0x9E3779B97F4A7C15) + w) & M
+    h ^= h >> 33
+    h = (h * 0xFF51AFD7ED558CCD) & M
+    h ^= h >> 33
+    h = (h * 0xC4CEB9FE1A85EC53) & M
+    h ^= h >> 33
+    return (h * n_lines) >> 64
+
+
+@pytest.mark.parametrize("k", [27, 31, 45, 63])
+def test_kmer_hash_table_invariants(k):
+    """The table the GPU fills (slots claimed with atomicCAS, so the layout is not deterministic) holds every stored k-mer exactly once with
+    its colour set as the value, nothing else, and every k-mer sits in the first line from its home line on that is not full of other
+    keys -- the property the lookup's early exit relies on."""
+    from bloomfiltertrie_amd import BFT
+    W, S_ = (2 * k + 63) // 64, 5 if k <= 31 else 3
+    anc = S.random_genome(200000, k)
     t = BFT(k)
-    keys, _ = W.build_index(t, pan, k)
-    allk = W.union_of(keys)
-    g = torch.Generator(device=dev)
-    g.manual_seed(3)
-    nq = (1 << 24) + 12345
-    dq, qk = W.presence_batch(allk, k, nq, g)
-    dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    assert t.build_time()["query_bucket_bits"] == -1
-    t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)  # tunes
-    torch.cuda.synchronize()
-    truth = W.member(allk, qk)
-    assert bool((W.bits_to_bool(dbits, nq) == truth).all())
-    bt = t.build_time()
-    assert bt["query_bucket_bits"] in (0, 8) and bt["bucket_tune_plain_ms"] > 0 and bt["bucket_tune_bucketed_ms"] > 0
-    first = dbits.clone()
-    for mode in (0, 8, -1):
-        t.set_option("query_bucket_bits", mode)
-        dbits.zero_()
-        t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
-        torch.cuda.synchronize()
-        assert torch.equal(first, dbits)
+    for g in range(3):
+        t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k)), g)
+    t.set_option("kmer_hash_load", 70)
+    t.build()
+    kh = t.debug_array("kh", np.uint64).reshape(-1, 8)
+    tk = t.debug_array("tk", np.uint64).reshape(-1, W)
+    tcol = t.debug_array("tcol", np.uint32)
+    n_lines = int(t.build_time()["kmer_hash_lines"])
+    assert kh.shape[0] == n_lines
+    keys = kh[:, : S_ * W].reshape(n_lines, S_, W)
+    vals = kh[:, S_ * W:].copy().view(np.uint32).reshape(n_lines, -1)[:, :S_]
+    used = keys[:, :, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert int(used.sum()) == len(tk)
+    stored = keys[used]                                     # [n, W]
+    order = np.lexsort(tuple(stored[:, w] for w in range(W - 1, -1, -1)))
+    assert (stored[order] == tk).all()                      # exactly the sorted table's k-mers, each once
+    assert (vals[used][order] == tcol).all()                # value = colour set of that row
+    full = used.all(axis=1)
+    line_of = np.nonzero(used)[0][order]                    # line of tk row i
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, len(tk), 3000):
+        ln = _kh_home([int(x) for x in tk[i]], n_lines)
+        while ln != line_of[i]:
+            assert full[ln], (i, ln)
+            ln = (ln + 1) % n_lines
     t.close()
 
 
 @pytest.mark.parametrize("k,per_prefix", [(18, 20), (27, 12), (27, 120), (36, 30), (63, 200), (31, 40)])
-def test_hashed_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_prefix):
-    """Suffix groups of 8..255 rows through their hashed form (BFT_GH_*) and the root level through the derived range /
+def test_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_prefix):
+    """Suffix groups of a dozen to 200 rows (block probes of the sorted table) and the root level through the derived range /
     direct tables: presence, rows and colour sets equal the oracle's (k % 9 == 0) and ground truth, with each accelerator on
-    and off; the hashed form really is in use (groups counted) and 'unhashed' groups (fallback to the sorted table) answer too."""
+    and off, with and without the k-mer hash in front."""
     from bloomfiltertrie_amd import BFT
     n_pref = 1500
     km = S.low_entropy_kmers(n_pref * per_prefix, k, n_pref, seed=k + per_prefix, levels=1)
@@ -568,14 +597,12 @@ def test_hashed_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_
         t.insert_kmers(np.ascontiguousarray(part), g)
         t.insert_kmers(np.ascontiguousarray(part[::7]), (g + 1) % 3)
     t.build()
-    bt = t.build_time()
-    assert bt["hashed_groups"] > n_pref // 2 and bt["unhashed_groups"] <= bt["hashed_groups"]
     q = np.concatenate([km, S.snp_mutants(km, k, 3), S.snp_mutants(km[::2], k, 4), S.pack_codes(rng.integers(0, 4, (20000, k), dtype=np.uint8))])
     q = np.ascontiguousarray(q[rng.permutation(len(q))])
     truth = S.member(q, km)
     ref = None
     for gh, rd in ((1, 2), (0, 2), (1, 1), (1, 0), (0, 0)):
-        t.set_option("group_hash", gh)
+        t.set_option("kmer_hash", gh)
         t.set_option("root_direct", rd)
         bits, rows, sets = t.query_rows(q)
         assert (S.from_bits(bits, len(q)).astype(bool) == truth).all(), (gh, rd)
@@ -585,7 +612,7 @@ def test_hashed_suffix_groups_and_root_tables_against_oracle(oracle_mod, k, per_
             assert (stored[rows[truth]] == q[truth]).all() and (cs[rows[truth]] == sets[truth]).all()
         else:
             assert (bits == ref[0]).all() and (rows == ref[1]).all() and (sets == ref[2]).all(), (gh, rd)
-    t.set_option("group_hash", 1)
+    t.set_option("kmer_hash", 1)
     t.set_option("root_direct", 2)
     if o:
         o2 = oracle_mod.OracleBFT(k)

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--genomes", type=int, default=100)
     ap.add_argument("--queries", type=int, default=125_000_000)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--bucket-bits", type=int, default=0, help="experiment: stable-sort the batch by the top bits of its rotated root prefix (n2, n3, ...) first")
+    ap.add_argument("--opt", action="append", default=[], help="name=value handed to bft_gpu_set_option after the build (e.g. kmer_hash=0)")
     ap.add_argument("--k", type=int, default=27, help="27 = the reference-compatible stand-in; 31 = the k the north star names (extension, ground truth only)")
     args = ap.parse_args()
     import torch
@@ -40,6 +40,9 @@ def main():
         keys.append(torch.unique(keys_of(packed)))
         del packed
     t.build()
+    for o in args.opt:
+        name, v = o.split("=")
+        t.set_option(name, int(v))
     info = t.info()
     allk = torch.unique(torch.cat(keys))
     del keys
@@ -52,12 +55,6 @@ def main():
     delta = torch.randint(1, 4, (nq,), generator=g, device=dev)
     nt = (qk >> (2 * pos)) & 3
     qk = torch.where(mut, (qk & ~(torch.full_like(qk, 3) << (2 * pos))) | (((nt + delta) & 3) << (2 * pos)), qk)
-    if args.bucket_bits:
-        key = torch.zeros_like(qk)
-        for j in range(1, 1 + (args.bucket_bits + 1) // 2):
-            key = (key << 2) | ((qk >> (2 * j)) & 3)
-        qk = qk[torch.sort(key, stable=True).indices]
-        del key
     dq = qk.view(torch.uint8).reshape(-1, 8)[:, :(2 * k + 7) // 8].contiguous()
     dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -73,9 +70,10 @@ def main():
         t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
     torch.cuda.synchronize()
     ms, n = t.kernel_time(reset=True)
-    print(json.dumps({"bucket_bits": args.bucket_bits, "workload": f"k={k}, {args.genomes}-genome BFT, {nq} queries (50% present / 50% SNP mutants)", "ms": round(ms / n, 3),
+    print(json.dumps({"options": args.opt, "workload": f"k={k}, {args.genomes}-genome BFT, {nq} queries (50% present / 50% SNP mutants)", "ms": round(ms / n, 3),
                       "G_kmers_per_s": round(nq / (ms / n) / 1e6, 2), "parity_all_queries": ok, "present_fraction": round(float(truth.float().mean()), 4), "tuned": t.build_time(),
-                      "trie": {x: info[x] for x in ("kmers", "pairs", "colorsets", "nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")}}))
+                      "trie": {x: info[x] for x in ("kmers", "pairs", "colorsets", "nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
+                      "footprint": t.footprint()}))
 
 
 if __name__ == "__main__":

@@ -29,7 +29,6 @@ dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
 rowbytes = (G + 7) // 8
 drows = torch.zeros((nqc, rowbytes), dtype=torch.uint8, device=dev)
 dscr = torch.zeros(nqc, dtype=torch.int32, device=dev)
-t.set_option("query_bucket_bits", 0)
 for _ in range(reps):
     L.check(t._lib.bft_gpu_query_branching_dev(t._h, dq.data_ptr(), nq, dbits.data_ptr(), None, stream))
 for _ in range(reps):

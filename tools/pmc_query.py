@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc passes of tools/pmc_collect.sh: build the config-2 / config-4 index (workloads.py), then
 `reps` launches of the presence kernel on the resident batch.  Options after the workload name: name=value pairs handed to
-bft_gpu_set_option (e.g. group_hash=0 root_direct=0 query_bucket_bits=8).
+bft_gpu_set_option (e.g. kmer_hash=0 root_direct=0).
 "sweepK" = the index of tools/bench_k_sweep.py at k = K (e.g. sweep63: two-word rows).
 usage: pmc_query.py <cfg2|cfg4|cfg4k31|sweepK> <queries> <reps> [option=value ...]"""
 import os
@@ -25,9 +25,6 @@ if wl.startswith("sweep"):
     anc = S.random_genome(2_000_000, 1234)
     gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]
     t = BFT(k)
-    for name, v in opts:
-        if name in ("group_hash",):
-            t.set_option(name, int(v))
     for g, km in enumerate(gk):
         t.insert_kmers(km, g)
     t.build()
@@ -39,9 +36,6 @@ else:
     genomes = 10 if wl.startswith("cfg2") else 100
     pan = W.PanGenome(genomes, 2_000_000, 0.01, 4242, dev)
     t = BFT(k)
-    for name, v in opts:
-        if name in ("group_hash",):  # build-time options
-            t.set_option(name, int(v))
     keys, _ = W.build_index(t, pan, k)
     allk = W.union_of(keys)
     del keys
@@ -52,8 +46,6 @@ else:
     dq, qk = W.presence_batch(allk, k, nq, g)
 dbits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
-if "query_bucket_bits" not in dict(opts):
-    t.set_option("query_bucket_bits", 0)  # counters of the direct kernel unless asked otherwise (no tuning launches in the trace)
 for _ in range(reps):
     t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
 torch.cuda.synchronize()

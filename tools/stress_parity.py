@@ -39,7 +39,7 @@ for r in range(rounds):
         rng.shuffle(order)
     t = BFT(k)
     if rng.random() < 0.3:
-        t.set_option("group_hash", 0)
+        t.set_option("kmer_hash", 0)
     if rng.random() < 0.3:
         t.set_option("build_composite", 0)
     cut = int(rng.integers(0, ngen + 1))
