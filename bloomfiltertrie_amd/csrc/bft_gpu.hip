@@ -31,6 +31,7 @@
 #include "bft_hash.h"
 #include "bft_image.h"
 #include "bft_index.h"
+#include "bft_kh.h"
 #include "bft_walk.h"
 
 #define BFT_BLOCK 256
@@ -216,6 +217,7 @@ struct bft_gpu {
     bool opt_kmer_hash = true;    // "kmer_hash"
     uint32_t opt_kh_load = 50;    // "kmer_hash_load": per cent of the table's slots in use
     double kh_ms = 0;             // GPU time of the last fill
+    int opt_kh_ilp = 1;           // "kmer_hash_ilp": k-mers per lane and pass of k_query_kh (1, 2 or 4)
     int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
                                   // measured faster on this image (tune_residency)
     bool rstart_ok = false;       // d_rstart holds the range table of the current image
@@ -776,10 +778,8 @@ static void derive_kmer_hash(bft_gpu* h) {
     bool ok = h->d_kh.alloc(bytes) == 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess &&
               hipMemsetAsync(h->d_kh.p, 0xFF, bytes, h->stream) == hipSuccess;
     if (ok) {
-        const dim3 grid(grid_for((h->n_kmers + 255) / 256)), block(256);
-        if (h->W == 1) hipLaunchKernelGGL(k_kh_insert<1>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_kh.as<uint64_t>(), lines);
-        else hipLaunchKernelGGL(k_kh_insert<2>, grid, block, 0, h->stream, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_kh.as<uint64_t>(), lines);
-        ok = hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+        ok = bft_kh_fill(h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->W, h->d_kh.as<uint64_t>(), lines, h->stream) == 0 &&
+             hipEventRecord(e1, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
         float ms = 0;
         if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) h->kh_ms = ms;
     }
@@ -1235,10 +1235,7 @@ static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uin
 static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s, int rec) {
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8 * h->opt_grid_mult))), block(BFT_KH_BLOCK);
-    if (h->W == 1) hipLaunchKernelGGL(k_query_kh<1>, grid, block, 0, s, h->im, d_kmers, n, rec, d_bits64, d_out32);
-    else hipLaunchKernelGGL(k_query_kh<2>, grid, block, 0, s, h->im, d_kmers, n, rec, d_bits64, d_out32);
+    CK(bft_kh_query(h->im, h->opt_kh_ilp, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, s));
     HIPCK(hipGetLastError());
     CK(timing_end(h, s, e0, e1));
     return 0;
@@ -1408,11 +1405,7 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
     if (h->im.kh != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
-        const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-        const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8))), block(BFT_KH_BLOCK);
-        if (h->W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
-        else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, h->im, d_kmers, n, h->B, d_bits64, d_counts);
-        HIPCK(hipGetLastError());
+        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, s));
         CK(timing_end(h, s, e0, e1));
         return 0;
     }
@@ -1706,11 +1699,8 @@ template <int W>
 static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     if (W <= 2 && h->im.kh != nullptr) {
-        constexpr int W12 = W <= 2 ? W : 1;
-        hipLaunchKernelGGL(k_seq_kh<W12>, dim3(256 * 8), dim3(256), 0, s, h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(),
-                           h->sq_tile.as<uint32_t>(), ns, canonical, h->sq_cs.as<uint32_t>());
-        HIPCK(hipGetLastError());
-        return 0;
+        return bft_kh_seq(h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical,
+                          h->sq_cs.as<uint32_t>(), s);
     }
     return staged ? launch_seq_walk_k<W, true, 0>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W, false, 0>(h, ns, canonical, d_soff, s);
 }
@@ -2090,6 +2080,9 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
         }
+    } else if (nm == "kmer_hash_ilp") {
+        if (value != 1 && value != 2 && value != 4) return fail(BFT_GPU_E_ARG, "kmer_hash_ilp must be 1, 2 or 4");
+        h->opt_kh_ilp = (int)value;
     } else if (nm == "tune") {  // measure the launch shape of the container walk on the current image (synchronises)
         if (value != 0 && h->built) {
             ENTER(h);

@@ -1,5 +1,5 @@
-// bft_kernels_query.h -- batch loads of packed k-mers, T-form conversion into the insert log; k_query_kh / k_branching_kh (presence, colour set and
-// branching through the k-mer hash: one cache line per k-mer); k_query / k_query8 / k_query6 and k_branching* (the container walk)
+// bft_kernels_query.h -- T-form conversion into the insert log; k_query / k_query8 / k_query6 and k_branching* (presence and branching as a container walk;
+// the same queries through the k-mer hash: bft_kh.hip)
 // Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
 // the host code there).
 #pragma once
@@ -7,42 +7,7 @@
 // device helpers
 // ------------------------------------------------------------------------------------------------
 
-// Packed k-mer i -> X words, straight from global memory: the 64 lanes of a wavefront read one
-// contiguous 64*B-byte span with aligned dword loads (each lane the <= 2W+1 dwords that cover its
-// B bytes), then funnel-shift.  The last k-mers of a buffer whose window would cross the end of the
-// buffer take a byte path.
-template <int W>
-__device__ __forceinline__ void load_x(const uint8_t* __restrict__ packed, uint64_t i, int B, uint64_t end_aligned, uint64_t* x) {
-    constexpr int NDW = 2 * W + 1;
-    const uint64_t addr = (uint64_t)packed + i * (uint64_t)B;
-    const uint64_t a = addr & ~3ull;
-    const uint32_t mis = (uint32_t)(addr & 3ull), sh = mis * 8;
-    const uint32_t need = (mis + (uint32_t)B + 3u) >> 2;
-    uint32_t dw[NDW];
-    if (a + 4ull * need <= end_aligned) {
-        const uint32_t* p = (const uint32_t*)a;
-#pragma unroll
-        for (int j = 0; j < NDW; j++) dw[j] = ((uint32_t)j < need) ? p[j] : 0u;
-    } else {
-#pragma unroll
-        for (int j = 0; j < NDW; j++) dw[j] = 0;
-        const uint8_t* q = (const uint8_t*)addr;
-        for (int b = 0; b < B; b++) {
-            const uint32_t pos = mis + (uint32_t)b, v = (uint32_t)q[b] << (8 * (pos & 3));
-#pragma unroll
-            for (int j = 0; j < NDW; j++)
-                if ((pos >> 2) == (uint32_t)j) dw[j] |= v;
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < W; w++) {
-        const uint64_t lo = (uint64_t)dw[2 * w] | ((uint64_t)dw[2 * w + 1] << 32);
-        const uint64_t hi = dw[2 * w + 2];
-        x[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-    }
-    const int rem = B - 8 * (W - 1);
-    if (rem < 8) x[W - 1] &= (1ull << (8 * rem)) - 1ull;
-}
+#include "bft_kernels_load.h"
 
 template <int W>
 __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
@@ -320,139 +285,3 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
     branching_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, counts);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same queries through the k-mer hash (bft_image.h, BFT_KH_*): no staging, no walk -- T-form, home line, compare.
-// ------------------------------------------------------------------------------------------------
-#define BFT_KH_BLOCK 256
-// Batched isKmerPresent (src/presenceNode.c:1823-1921; loop of src/file_io.c:726-768): bit i = k-mer i is stored; out32 (optional):
-// its colour-set id (what get_annotation locates, src/bft.c:363-387), 0xFFFFFFFF when absent.  One lane per k-mer, 64 presence bits
-// per wavefront through __ballot, persistent grid.
-template <int W>
-__global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                          uint32_t* __restrict__ out32) {
-    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
-        bool present = false;
-        uint32_t val = 0xFFFFFFFFu;
-        if (i < n) {
-            uint64_t x[W], t[W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            bft_tform_from_x<W>(x, im.k, t);
-            present = bft_kh_lookup<W>(im.kh, im.kh_lines, t, &val);
-        }
-        const uint64_t mask = __ballot(present);
-        const uint64_t q0 = i & ~63ull;
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-        if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
-    }
-}
-
-// How many of four candidate k-mers are stored: the four home lines are loaded before any is looked at -- four independent
-// misses in flight instead of four dependent walks (src/presenceNode.c:15-1211 shares one descent between the four; here there
-// is no descent to share).  A candidate whose home line is full without holding it continues line by line (a few per cent).
-template <int W>
-__device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*cand)[W]) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
-    uint64_t ln[4], key[4][S][W];
-#pragma unroll
-    for (int v = 0; v < 4; v++) ln[v] = bft_kh_home<W>(cand[v], im.kh_lines);
-#pragma unroll
-    for (int v = 0; v < 4; v++) bft_kh_load_keys<W>(im.kh + ln[v] * BFT_KH_LINE_WORDS, key[v]);
-    int count = 0;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        bool hit = false, free_slot = false;
-#pragma unroll
-        for (uint32_t s = 0; s < S; s++) {
-            hit = hit || bft_cmp<W>(key[v][s], cand[v]) == 0;
-            free_slot = free_slot || key[v][s][0] == BFT_KH_EMPTY;
-        }
-        if (!hit && !free_slot) {  // full line without the key: the general lookup walks on from the home line
-            uint32_t val;
-            hit = bft_kh_lookup<W>(im.kh, im.kh_lines, cand[v], &val);
-        }
-        count += hit;
-    }
-    return count;
-}
-
-// Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998), see branching_body.
-template <int W>
-__global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                              uint8_t* __restrict__ counts) {
-    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-    const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
-        int branching = 0;
-        if (i < n) {
-            uint64_t x[W], y[W], t[W], cand[4][W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            // successors: drop the first nucleotide, the last one is the wildcard (bits vo.. of the T-form's last word)
-#pragma unroll
-            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
-            bft_tform_from_x<W>(y, k, t);
-            const int vo = rb ? 0 : 2;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-#pragma unroll
-                for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == W - 1 ? (uint64_t)v << vo : 0ull);
-            }
-            const int cr = kh_count4<W>(im, cand);
-            int cl = 0;
-            if (counts || cr < 2) {
-                // predecessors: shift in a wildcard first nucleotide (bits 0..1 of the first digit), drop the last one
-#pragma unroll
-                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
-                const int top = 2 * k - 64 * (W - 1);
-                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
-                bft_tform_from_x<W>(y, k, t);
-                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-#pragma unroll
-                    for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == ow ? (uint64_t)v << osh : 0ull);
-                }
-                cl = kh_count4<W>(im, cand);
-            }
-            branching = cr > 1 || cl > 1;
-            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
-        }
-        const uint64_t mask = __ballot(branching);
-        const uint64_t q0 = i & ~63ull;
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-    }
-}
-
-// Fills the table: one thread per stored k-mer claims the first free slot at or after its home line with a compare-and-swap on the
-// slot's first key word (a key word is never all ones: bft_kh_usable), then writes the rest of the key and the value.  Nothing
-// reads the table before the kernel is done.
-template <int W>
-__global__ __launch_bounds__(256) void k_kh_insert(const uint64_t* __restrict__ tk, const uint32_t* __restrict__ tcol, uint64_t n, uint64_t* __restrict__ kh,
-                                                   uint64_t n_lines) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t t[W];
-        bft_load_row<W>(tk + i * W, t);
-        const uint32_t val = tcol[i];
-        uint64_t ln = bft_kh_home<W>(t, n_lines);
-        bool placed = false;
-        while (!placed) {
-            uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
-            for (uint32_t s = 0; s < S && !placed; s++) {
-                unsigned long long* slot = (unsigned long long*)(line + s * W);
-                if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BFT_KH_EMPTY) continue;
-                if (atomicCAS(slot, (unsigned long long)BFT_KH_EMPTY, (unsigned long long)t[0]) == BFT_KH_EMPTY) {
-#pragma unroll
-                    for (int w = 1; w < W; w++) line[s * W + w] = t[w];
-                    reinterpret_cast<uint32_t*>(line + S * W)[s] = val;
-                    placed = true;
-                }
-            }
-            ln = ln + 1 == n_lines ? 0 : ln + 1;
-        }
-    }
-}

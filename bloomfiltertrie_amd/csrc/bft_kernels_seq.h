@@ -52,11 +52,7 @@ __global__ void k_seq_encode(const char* __restrict__ seqs, uint64_t n_chars, ui
     }
 }
 
-// reverse the 32 two-bit fields of a word
-__device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
-    x = __brevll(x);
-    return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
-}
+#include "bft_kernels_seqwin.h"
 
 // ---- plan (positions per sequence) -> window + walk + colour set -> counters ------------------------------------------------
 // k_seq_plan: k-mer positions of every sequence of a chunk, on the device (the device-resident entry point never sees the offsets
@@ -67,62 +63,6 @@ __global__ void k_seq_plan(const uint64_t* __restrict__ seq_off, uint64_t n_seqs
         const uint64_t len = seq_off[s + 1] - seq_off[s];
         npos[s] = len >= (uint64_t)k ? len - (uint64_t)k + 1 : 0;
     }
-}
-
-// The window of one k-mer position: 2k bits of the code stream at a bit offset (W+1 word loads + funnel shifts, O(1) instead of a
-// scan over k characters) -> packed words x[W]; false when one of its k "bad" bits is set (windows with a character outside ACGTU
-// are skipped by the reference, src/bft.c:1298).  canonical: the reverse complement = complement, reverse the 2-bit fields of the
-// 2k-bit string; strcmp(kmer, revcomp) >= 0 -> the reverse complement is searched (src/bft.c:1290-1296) = comparison of the
-// lowest differing field.  c0 = index of the window's first character in the blob.
-template <int W>
-__device__ __forceinline__ bool seq_window(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, uint64_t c0, int k, int canonical, uint64_t* x) {
-    const uint64_t w0 = c0 >> 5;
-    const uint32_t sh = (uint32_t)(c0 & 31u) * 2u;
-    uint64_t cw[W + 1], xf[W];
-#pragma unroll
-    for (int q = 0; q <= W; q++) cw[q] = codes[w0 + q];  // the code array has W+1 words of slack
-#pragma unroll
-    for (int q = 0; q < W; q++) xf[q] = sh ? (cw[q] >> sh) | (cw[q + 1] << (64u - sh)) : cw[q];
-    const int top = 2 * k - 64 * (W - 1);  // bits used in the last word
-    if (top < 64) xf[W - 1] &= (1ull << top) - 1ull;
-    bool ok = true;
-    {
-        const uint32_t bs = (uint32_t)(c0 & 31u);
-        int left = k;
-        uint32_t first = bad[w0] >> bs;
-        if (left < 32 - (int)bs) first &= (1u << left) - 1u;
-        ok = first == 0;
-        left -= 32 - (int)bs;
-        for (uint64_t j = w0 + 1; left > 0; j++, left -= 32) {
-            uint32_t m = bad[j];
-            if (left < 32) m &= (1u << left) - 1u;
-            ok = ok && m == 0;
-        }
-    }
-    bool use_rc = false;
-    uint64_t xr[W];
-    if (canonical) {
-        uint64_t rv[W + 1];
-#pragma unroll
-        for (int q = 0; q < W; q++) rv[q] = rev2_64(~xf[W - 1 - q]);
-        rv[W] = 0;
-        const uint32_t dn = (uint32_t)(64 * W - 2 * k);  // < 64
-#pragma unroll
-        for (int q = 0; q < W; q++) xr[q] = dn ? (rv[q] >> dn) | (rv[q + 1] << (64u - dn)) : rv[q];
-        if (top < 64) xr[W - 1] &= (1ull << top) - 1ull;
-        use_rc = true;
-#pragma unroll
-        for (int q = W - 1; q >= 0; q--) {  // the lowest differing field decides: word 0 last
-            const uint64_t df = xf[q] ^ xr[q];
-            if (df) {
-                const int fs = __builtin_ctzll(df) & ~1;
-                use_rc = ((xf[q] >> fs) & 3ull) > ((xr[q] >> fs) & 3ull);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < W; q++) x[q] = (canonical && use_rc) ? xr[q] : xf[q];
-    return ok;
 }
 
 // k_seq_tiles: the sequence of the first position of every 64-position tile (last s with pos_off[s] <= 64 t), one binary search
@@ -204,30 +144,6 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
     BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off, const uint64_t* __restrict__ pos_off,
     const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical, uint32_t* __restrict__ csout) {
     seq_walk_body<W, BFT_BLOCK6, STAGED, PROBE>(im, codes, bad, seq_off, pos_off, tile_seq, n_seqs, canonical, csout);
-}
-
-// The same through the k-mer hash (BFT_KH_*): the colour set of a position sits in the cache line that says the k-mer is stored --
-// one line per position, nothing staged.
-template <int W>
-__global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
-                                                const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
-                                                uint32_t* __restrict__ csout) {
-    const uint64_t P = pos_off[n_seqs];
-    const uint64_t nblk = (P + 255) / 256;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t p = blk * 256 + threadIdx.x;
-        if (p >= P) continue;
-        uint32_t lo = tile_seq[p >> 6];
-        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
-        uint32_t cs = 0xFFFFFFFFu;
-        uint64_t x[W], t[W];
-        if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
-            bft_tform_from_x<W>(x, im.k, t);
-            uint32_t val;
-            if (bft_kh_lookup<W>(im.kh, im.kh_lines, t, &val)) cs = val;
-        }
-        csout[p] = cs;
-    }
 }
 
 // Per-(sequence, genome) counters and the threshold, one WAVEFRONT per sequence, counters in LDS: no counter matrix in HBM, no

@@ -1,0 +1,237 @@
+// bft_kh.hip -- the queries of include/bft_gpu.h through the k-mer hash (bft_image.h, BFT_KH_*): fill, presence / colour set, branching,
+// sequence positions.  Its own translation unit: these kernels stage nothing and walk nothing -- T-form, home line, compare.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "bft_dev.h"
+#include "bft_image.h"
+#include "bft_kh.h"
+#include "bft_walk.h"
+#include "bft_kernels_load.h"
+#include "bft_kernels_seqwin.h"
+
+// Batched isKmerPresent (src/presenceNode.c:1823-1921; loop of src/file_io.c:726-768): bit i = k-mer i is stored; out32 (optional):
+// its colour-set id (what get_annotation locates, src/bft.c:363-387), 0xFFFFFFFF when absent.  One lane per k-mer, 64 presence bits
+// per wavefront through __ballot, persistent grid.
+// Q: k-mers per lane and pass -- their home lines are loaded before any is looked at, so a lane keeps Q misses in flight and a
+// wavefront that waits for the few lanes whose home line was full (a second, dependent line) still has work outstanding.
+template <int W, int Q>
+__global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                          uint32_t* __restrict__ out32) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t per_pass = (uint64_t)BFT_KH_BLOCK * Q, npass = (n + per_pass - 1) / per_pass;
+    for (uint64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
+        uint64_t t[Q][W], ln[Q], key[Q][S][W];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const uint64_t i = ps * per_pass + (uint64_t)q * BFT_KH_BLOCK + threadIdx.x;
+            uint64_t x[W];
+            load_x<W>(packed, i < n ? i : n - 1, B, end_aligned, x);
+            bft_tform_from_x<W>(x, im.k, t[q]);
+            ln[q] = bft_kh_home<W>(t[q], im.kh_lines);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) bft_kh_load_keys<W>(im.kh + ln[q] * BFT_KH_LINE_WORDS, key[q]);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const uint64_t i = ps * per_pass + (uint64_t)q * BFT_KH_BLOCK + threadIdx.x;
+            int at = -1;
+            bool free_slot = false;
+#pragma unroll
+            for (uint32_t s = 0; s < S; s++) {
+                if (bft_cmp<W>(key[q][s], t[q]) == 0) at = (int)s;
+                free_slot = free_slot || key[q][s][0] == BFT_KH_EMPTY;
+            }
+            bool present = at >= 0;
+            uint32_t val = 0xFFFFFFFFu;
+            if (present) {
+                if (out32) val = reinterpret_cast<const uint32_t*>(im.kh + ln[q] * BFT_KH_LINE_WORDS + S * W)[at];
+            } else if (!free_slot)  // full line without the key: the general lookup walks on from the home line
+                present = bft_kh_lookup<W>(im.kh, im.kh_lines, t[q], &val);
+            present = present && i < n;
+            const uint64_t mask = __ballot(present);
+            const uint64_t q0 = i & ~63ull;
+            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+            if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
+        }
+    }
+}
+
+// How many of four candidate k-mers are stored: the four home lines are loaded before any is looked at -- four independent
+// misses in flight instead of four dependent walks (src/presenceNode.c:15-1211 shares one descent between the four; here there
+// is no descent to share).  A candidate whose home line is full without holding it continues line by line (a few per cent).
+template <int W>
+__device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*cand)[W]) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+    uint64_t ln[4], key[4][S][W];
+#pragma unroll
+    for (int v = 0; v < 4; v++) ln[v] = bft_kh_home<W>(cand[v], im.kh_lines);
+#pragma unroll
+    for (int v = 0; v < 4; v++) bft_kh_load_keys<W>(im.kh + ln[v] * BFT_KH_LINE_WORDS, key[v]);
+    int count = 0;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        bool hit = false, free_slot = false;
+#pragma unroll
+        for (uint32_t s = 0; s < S; s++) {
+            hit = hit || bft_cmp<W>(key[v][s], cand[v]) == 0;
+            free_slot = free_slot || key[v][s][0] == BFT_KH_EMPTY;
+        }
+        if (!hit && !free_slot) {  // full line without the key: the general lookup walks on from the home line
+            uint32_t val;
+            hit = bft_kh_lookup<W>(im.kh, im.kh_lines, cand[v], &val);
+        }
+        count += hit;
+    }
+    return count;
+}
+
+// Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998), see branching_body.
+template <int W>
+__global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                              uint8_t* __restrict__ counts) {
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
+    const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
+        int branching = 0;
+        if (i < n) {
+            uint64_t x[W], y[W], t[W], cand[4][W];
+            load_x<W>(packed, i, B, end_aligned, x);
+            // successors: drop the first nucleotide, the last one is the wildcard (bits vo.. of the T-form's last word)
+#pragma unroll
+            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
+            bft_tform_from_x<W>(y, k, t);
+            const int vo = rb ? 0 : 2;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+#pragma unroll
+                for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == W - 1 ? (uint64_t)v << vo : 0ull);
+            }
+            const int cr = kh_count4<W>(im, cand);
+            int cl = 0;
+            if (counts || cr < 2) {
+                // predecessors: shift in a wildcard first nucleotide (bits 0..1 of the first digit), drop the last one
+#pragma unroll
+                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
+                const int top = 2 * k - 64 * (W - 1);
+                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
+                bft_tform_from_x<W>(y, k, t);
+                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == ow ? (uint64_t)v << osh : 0ull);
+                }
+                cl = kh_count4<W>(im, cand);
+            }
+            branching = cr > 1 || cl > 1;
+            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
+        }
+        const uint64_t mask = __ballot(branching);
+        const uint64_t q0 = i & ~63ull;
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+    }
+}
+
+// Fills the table: one thread per stored k-mer claims the first free slot at or after its home line with a compare-and-swap on the
+// slot's first key word (a key word is never all ones: bft_kh_usable), then writes the rest of the key and the value.  Nothing
+// reads the table before the kernel is done.
+template <int W>
+__global__ __launch_bounds__(256) void k_kh_insert(const uint64_t* __restrict__ tk, const uint32_t* __restrict__ tcol, uint64_t n, uint64_t* __restrict__ kh,
+                                                   uint64_t n_lines) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t t[W];
+        bft_load_row<W>(tk + i * W, t);
+        const uint32_t val = tcol[i];
+        uint64_t ln = bft_kh_home<W>(t, n_lines);
+        bool placed = false;
+        while (!placed) {
+            uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
+            for (uint32_t s = 0; s < S && !placed; s++) {
+                unsigned long long* slot = (unsigned long long*)(line + s * W);
+                if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BFT_KH_EMPTY) continue;
+                if (atomicCAS(slot, (unsigned long long)BFT_KH_EMPTY, (unsigned long long)t[0]) == BFT_KH_EMPTY) {
+#pragma unroll
+                    for (int w = 1; w < W; w++) line[s * W + w] = t[w];
+                    reinterpret_cast<uint32_t*>(line + S * W)[s] = val;
+                    placed = true;
+                }
+            }
+            ln = ln + 1 == n_lines ? 0 : ln + 1;
+        }
+    }
+}
+
+// The same through the k-mer hash (BFT_KH_*): the colour set of a position sits in the cache line that says the k-mer is stored --
+// one line per position, nothing staged.
+template <int W>
+__global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
+                                                const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
+                                                uint32_t* __restrict__ csout) {
+    const uint64_t P = pos_off[n_seqs];
+    const uint64_t nblk = (P + 255) / 256;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t p = blk * 256 + threadIdx.x;
+        if (p >= P) continue;
+        uint32_t lo = tile_seq[p >> 6];
+        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
+        uint32_t cs = 0xFFFFFFFFu;
+        uint64_t x[W], t[W];
+        if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
+            bft_tform_from_x<W>(x, im.k, t);
+            uint32_t val;
+            if (bft_kh_lookup<W>(im.kh, im.kh_lines, t, &val)) cs = val;
+        }
+        csout[p] = cs;
+    }
+}
+
+
+// ---- launchers (called from bft_gpu.hip) ------------------------------------------------------------------------------------
+static unsigned kh_grid(uint64_t n, uint64_t per_block, int mult) {
+    const uint64_t nblk = (n + per_block - 1) / per_block;
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8 * (uint64_t)std::max(1, mult)));
+}
+
+int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W, uint64_t* d_kh, uint64_t n_lines, hipStream_t s) {
+    const dim3 grid(kh_grid(n, 256, 1)), block(256);
+    if (W == 1) hipLaunchKernelGGL(k_kh_insert<1>, grid, block, 0, s, d_tk, d_tcol, n, d_kh, n_lines);
+    else hipLaunchKernelGGL(k_kh_insert<2>, grid, block, 0, s, d_tk, d_tcol, n, d_kh, n_lines);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int bft_kh_query(const BftImage& im, int ilp, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s) {
+    const int Q = ilp == 4 ? 4 : (ilp == 2 ? 2 : 1);
+    const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * Q, grid_mult)), block(BFT_KH_BLOCK);
+#define KH(WW)                                                                                                     \
+    if (Q == 1) hipLaunchKernelGGL((k_query_kh<WW, 1>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);      \
+    else if (Q == 2) hipLaunchKernelGGL((k_query_kh<WW, 2>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32); \
+    else hipLaunchKernelGGL((k_query_kh<WW, 4>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32)
+    if (im.W == 1) { KH(1); } else { KH(2); }
+#undef KH
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
+    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 1)), block(BFT_KH_BLOCK);
+    if (im.W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
+    else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
+               uint32_t n_seqs, int canonical, uint32_t* d_csout, hipStream_t s) {
+    const dim3 grid(256 * 8), block(256);
+    if (im.W == 1) hipLaunchKernelGGL(k_seq_kh<1>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout);
+    else hipLaunchKernelGGL(k_seq_kh<2>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout);
+    HIPCK(hipGetLastError());
+    return 0;
+}

@@ -442,6 +442,7 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     q = np.concatenate([km[::5], S.snp_mutants(km[::9], k, 2)])
     obits, ooff, oids = o.query_colors(q)
     ob, oc, _ = o.query_branching(q[:20000])
+    t.build()
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0, 3.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
@@ -456,6 +457,7 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
         t.set_option("query_probe", probe)
         t.set_option("root_direct", rdir)
         t.set_option("tune", tune)
+        t.set_option("kmer_hash_ilp", (1, 2, 4)[(blk + wgs + mult) % 3])
         assert (t.build_time()["kmer_hash_lines"] > 0) == bool(kh)
         bits, off, ids = t.query_colors(q)
         assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, kh, load)
