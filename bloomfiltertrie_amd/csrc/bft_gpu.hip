@@ -217,7 +217,6 @@ struct bft_gpu {
     bool opt_kmer_hash = true;    // "kmer_hash"
     uint32_t opt_kh_load = 50;    // "kmer_hash_load": per cent of the table's slots in use
     double kh_ms = 0;             // GPU time of the last fill
-    int opt_kh_ilp = 1;           // "kmer_hash_ilp": k-mers per lane and pass of k_query_kh (1, 2 or 4)
     int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
                                   // measured faster on this image (tune_residency)
     bool rstart_ok = false;       // d_rstart holds the range table of the current image
@@ -1235,7 +1234,7 @@ static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uin
 static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s, int rec) {
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    CK(bft_kh_query(h->im, h->opt_kh_ilp, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, s));
+    CK(bft_kh_query(h->im, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, s));
     HIPCK(hipGetLastError());
     CK(timing_end(h, s, e0, e1));
     return 0;
@@ -2080,9 +2079,6 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
         }
-    } else if (nm == "kmer_hash_ilp") {
-        if (value != 1 && value != 2 && value != 4) return fail(BFT_GPU_E_ARG, "kmer_hash_ilp must be 1, 2 or 4");
-        h->opt_kh_ilp = (int)value;
     } else if (nm == "tune") {  // measure the launch shape of the container walk on the current image (synchronises)
         if (value != 0 && h->built) {
             ENTER(h);

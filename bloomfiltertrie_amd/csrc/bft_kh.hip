@@ -14,48 +14,27 @@
 // Batched isKmerPresent (src/presenceNode.c:1823-1921; loop of src/file_io.c:726-768): bit i = k-mer i is stored; out32 (optional):
 // its colour-set id (what get_annotation locates, src/bft.c:363-387), 0xFFFFFFFF when absent.  One lane per k-mer, 64 presence bits
 // per wavefront through __ballot, persistent grid.
-// Q: k-mers per lane and pass -- their home lines are loaded before any is looked at, so a lane keeps Q misses in flight and a
-// wavefront that waits for the few lanes whose home line was full (a second, dependent line) still has work outstanding.
-template <int W, int Q>
+// (Two or four k-mers per lane and pass, their home lines loaded together, were measured on the 100-genome index: 41.5 / 37.5 G k-mers/s
+// against 44.6 with one -- the fabric's request rate is the limit, not the number of requests a lane keeps in flight; tools/probe_kh.py.)
+template <int W>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                           uint32_t* __restrict__ out32) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t per_pass = (uint64_t)BFT_KH_BLOCK * Q, npass = (n + per_pass - 1) / per_pass;
-    for (uint64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
-        uint64_t t[Q][W], ln[Q], key[Q][S][W];
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const uint64_t i = ps * per_pass + (uint64_t)q * BFT_KH_BLOCK + threadIdx.x;
-            uint64_t x[W];
-            load_x<W>(packed, i < n ? i : n - 1, B, end_aligned, x);
-            bft_tform_from_x<W>(x, im.k, t[q]);
-            ln[q] = bft_kh_home<W>(t[q], im.kh_lines);
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
+        bool present = false;
+        uint32_t val = 0xFFFFFFFFu;
+        if (i < n) {
+            uint64_t x[W], t[W];
+            load_x<W>(packed, i, B, end_aligned, x);
+            bft_tform_from_x<W>(x, im.k, t);
+            present = bft_kh_lookup<W>(im.kh, im.kh_lines, t, &val);
         }
-#pragma unroll
-        for (int q = 0; q < Q; q++) bft_kh_load_keys<W>(im.kh + ln[q] * BFT_KH_LINE_WORDS, key[q]);
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const uint64_t i = ps * per_pass + (uint64_t)q * BFT_KH_BLOCK + threadIdx.x;
-            int at = -1;
-            bool free_slot = false;
-#pragma unroll
-            for (uint32_t s = 0; s < S; s++) {
-                if (bft_cmp<W>(key[q][s], t[q]) == 0) at = (int)s;
-                free_slot = free_slot || key[q][s][0] == BFT_KH_EMPTY;
-            }
-            bool present = at >= 0;
-            uint32_t val = 0xFFFFFFFFu;
-            if (present) {
-                if (out32) val = reinterpret_cast<const uint32_t*>(im.kh + ln[q] * BFT_KH_LINE_WORDS + S * W)[at];
-            } else if (!free_slot)  // full line without the key: the general lookup walks on from the home line
-                present = bft_kh_lookup<W>(im.kh, im.kh_lines, t[q], &val);
-            present = present && i < n;
-            const uint64_t mask = __ballot(present);
-            const uint64_t q0 = i & ~63ull;
-            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-            if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
-        }
+        const uint64_t mask = __ballot(present);
+        const uint64_t q0 = i & ~63ull;
+        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
     }
 }
 
@@ -206,21 +185,17 @@ int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W,
     return 0;
 }
 
-int bft_kh_query(const BftImage& im, int ilp, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s) {
-    const int Q = ilp == 4 ? 4 : (ilp == 2 ? 2 : 1);
-    const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * Q, grid_mult)), block(BFT_KH_BLOCK);
-#define KH(WW)                                                                                                     \
-    if (Q == 1) hipLaunchKernelGGL((k_query_kh<WW, 1>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);      \
-    else if (Q == 2) hipLaunchKernelGGL((k_query_kh<WW, 2>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32); \
-    else hipLaunchKernelGGL((k_query_kh<WW, 4>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32)
-    if (im.W == 1) { KH(1); } else { KH(2); }
-#undef KH
+int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s) {
+    // (grid: four times the resident workgroups -- 44.6 -> 47.2 G k-mers/s on the 100-genome index: the tail of a persistent grid is shorter)
+    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4 * grid_mult)), block(BFT_KH_BLOCK);
+    if (im.W == 1) hipLaunchKernelGGL(k_query_kh<1>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);
+    else hipLaunchKernelGGL(k_query_kh<2>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);
     HIPCK(hipGetLastError());
     return 0;
 }
 
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
-    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 1)), block(BFT_KH_BLOCK);
+    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4)), block(BFT_KH_BLOCK);
     if (im.W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
     else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
     HIPCK(hipGetLastError());

@@ -99,6 +99,22 @@ def snp_mutate_packed(q, k, frac, gen):
     return q
 
 
+def make_queries_on_device(union_kmers, k, n, seed, device):
+    """Packed host k-mers [m, B] (any k) -> n device-resident queries: 50 % sampled as they are, 50 % single-SNP mutants (the
+    config-2 batch of SURVEY.md 8d), built on the GPU in chunks."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    U = torch.from_numpy(union_kmers).to(device)
+    out = torch.empty((n, U.shape[1]), dtype=torch.uint8, device=device)
+    chunk = 1 << 24
+    for a in range(0, n, chunk):
+        m = min(chunk, n - a)
+        idx = torch.randint(0, U.shape[0], (m,), generator=g, device=device)
+        out[a:a + m] = snp_mutate_packed(U[idx], k, 0.5, g)
+    return out
+
+
 class PanGenome:
     """n_genomes variants (snp_rate i.i.d. SNPs) of one random ancestor of genome_len nt, generated on `device` from `seed`.
     genome(g) regenerates genome g deterministically (codes uint8 [genome_len])."""

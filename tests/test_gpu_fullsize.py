@@ -23,7 +23,7 @@ def _keys_t(packed_t):
 def test_config2_full_batch_properties():
     import torch
     from bloomfiltertrie_amd import BFT
-    from bench import make_queries_on_device
+    from bloomfiltertrie_amd.workloads import make_queries_on_device
     k, nq = 27, 100_000_000
     anc = S.random_genome(2_000_000, 1234)
     gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]

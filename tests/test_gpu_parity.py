@@ -457,7 +457,6 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
         t.set_option("query_probe", probe)
         t.set_option("root_direct", rdir)
         t.set_option("tune", tune)
-        t.set_option("kmer_hash_ilp", (1, 2, 4)[(blk + wgs + mult) % 3])
         assert (t.build_time()["kmer_hash_lines"] > 0) == bool(kh)
         bits, off, ids = t.query_colors(q)
         assert (bits == obits).all() and (off == ooff).all() and (ids == oids).all(), (blk, wgs, mult, probe, rdir, kh, load)

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     from bloomfiltertrie_amd import BFT, synth as S
-    from bench import make_queries_on_device
+    from bloomfiltertrie_amd.workloads import make_queries_on_device
     dev = torch.device("cuda", 0)
     nq = 100_000_000
     out = []

@@ -58,7 +58,7 @@ def main():
     import torch
     from bloomfiltertrie_amd import BFT, synth as S
     sys.path.insert(0, ROOT)
-    from bench import make_queries_on_device
+    from bloomfiltertrie_amd.workloads import make_queries_on_device
     dev = torch.device("cuda", 0)
     for wl in args.workloads.split(","):
         k, gk = workload(wl)

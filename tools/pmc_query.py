@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 if wl.startswith("sweep"):
     import numpy as np  # noqa: E402
     from bloomfiltertrie_amd import synth as S  # noqa: E402
-    from bench import make_queries_on_device  # noqa: E402
+    from bloomfiltertrie_amd.workloads import make_queries_on_device  # noqa: E402
     k = int(wl[5:])
     anc = S.random_genome(2_000_000, 1234)
     gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from bloomfiltertrie_amd import BFT, synth as S  # noqa: E402
-from bench import make_queries_on_device  # noqa: E402
+from bloomfiltertrie_amd.workloads import make_queries_on_device  # noqa: E402
 from tools.perf_probe import workload  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"

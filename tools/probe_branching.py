@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from bloomfiltertrie_amd import BFT, synth as S  # noqa: E402
-from bench import make_queries_on_device  # noqa: E402
+from bloomfiltertrie_amd.workloads import make_queries_on_device  # noqa: E402
 from tools.perf_probe import workload  # noqa: E402
 
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000

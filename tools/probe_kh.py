@@ -40,10 +40,9 @@ def run(reps=5):
 
 for load in (50, 40, 65):
     t.set_option("kmer_hash_load", load)
-    for ilp in (1, 2, 4):
-        t.set_option("kmer_hash_ilp", ilp)
-        for mult in (1, 2, 4):
+    for mult in (1, 2, 4, 16):
+        if True:
             t.set_option("query_grid_mult", mult)
             ms, ok = run()
-            print(json.dumps({"k": k, "load": load, "ilp": ilp, "grid_mult": mult, "ms": round(ms, 3), "G_kmers_per_s": round(nq / ms / 1e6, 2), "ok": ok,
+            print(json.dumps({"k": k, "load": load, "grid_x": 4 * mult, "ms": round(ms, 3), "G_kmers_per_s": round(nq / ms / 1e6, 2), "ok": ok,
                               "kh_bytes": t.footprint()["kmer_hash"]}), flush=True)
