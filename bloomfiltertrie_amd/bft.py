@@ -189,6 +189,11 @@ class BFT:
         _lib.check(self._lib.bft_gpu_query_color_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
         return bits, rows
 
+    def query_color_rows_dev(self, d_kmers_ptr, n, d_bits_ptr, d_rows_ptr, d_scratch_u32_ptr, stream=None):
+        """Device-resident colour rows (bft_gpu_query_color_rows_dev): n x CEIL(nb_genomes/8) bytes at d_rows_ptr, no synchronisation."""
+        _lib.check(self._lib.bft_gpu_query_color_rows_dev(self._h, C.c_void_p(d_kmers_ptr), n, C.c_void_p(d_bits_ptr), C.c_void_p(d_rows_ptr),
+                                                          C.c_void_p(d_scratch_u32_ptr), C.c_void_p(stream or 0)))
+
     def query_branching(self, kmers, with_counts=False):
         """-query_branching (src/file_io.c:897-1020): bit per k-mer, optionally (successors << 4) | predecessors."""
         kmers = self._chk(kmers)

@@ -83,3 +83,20 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
                     hipStream_t s, DevBuf& ccx, DevBuf& f18, DevBuf& fent, uint64_t& n_f18, uint64_t& n_fent);
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
                           DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids);
+
+// Merging a sorted run of newly inserted k-mers into the built index (bft_merge.hip).  A "run" = sorted distinct T-form k-mers, a
+// colour-set id per k-mer and the dictionary those ids refer to -- what the index itself is made of.
+struct BftRun {
+    const uint64_t* tk;
+    const uint32_t* tcol;
+    uint64_t n;
+    const uint32_t* cs_off;
+    const uint32_t* cs_ids;
+    uint64_t n_sets;
+};
+struct BftRunOut {
+    DevBuf tk, tcol, cs_off, cs_ids;
+    uint64_t n = 0, n_sets = 0, n_ids = 0;
+};
+int bft_merge_runs(int W, const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out);
+int bft_count_pairs(const uint32_t* d_tcol, uint64_t n, const uint32_t* d_cs_off, hipStream_t s, uint64_t* total);

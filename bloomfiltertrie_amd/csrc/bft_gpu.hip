@@ -186,9 +186,9 @@ struct bft_gpu {
     std::vector<std::string> genomes;
     uint32_t max_gid_seen = 0;
     bool any_insert = false;
-    bool log_g_sorted = true;   // the log's genome ids are non-decreasing and >= every id of the pair store
-    uint32_t log_last_gid = 0, store_max_gid = 0;
-    bool store_any = false;
+    bool log_g_sorted = true;   // the log's genome ids are non-decreasing
+    uint32_t log_last_gid = 0;
+    uint64_t opt_flush_pairs = 1ull << 30;  // "flush_pairs": the log is merged into the index before it holds this many pairs
 
     // Small host batches (the per-k-mer calls of <bft/bft.h>, 4096-byte file chunks): a pinned, device-mapped staging
     // block the kernels read and write directly -- one launch + one stream wait instead of two staged copies around it.
@@ -199,9 +199,7 @@ struct bft_gpu {
     DevBuf log_k, log_g;
     uint64_t log_n = 0, log_cap = 0;
 
-    // canonical store: sorted unique (T, genome) pairs, SoA
-    DevBuf pair_k, pair_g;
-    uint64_t n_pairs = 0;
+    uint64_t n_pairs = 0;  // distinct (k-mer, genome) pairs the index holds = sum of the sizes of its k-mers' colour sets
 
     // image
     bool built = false;
@@ -467,7 +465,14 @@ static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_g
     if (id_genome >= BFT_MAX_GENOME_ID) return fail(BFT_GPU_E_ARG, "id_genome out of range (must be below 2^24)");
     if (n == 0) return BFT_GPU_OK;
     ENTER(h);
-    if (h->log_n + n + h->n_pairs >= 0x7FFFFFFFull) return fail(BFT_GPU_E_LIMIT, "more than 2^31-1 (k-mer, genome) pairs");
+    // No bound on the pairs an index holds (the reference has none, src/insertNode.c:18-36): a batch beyond what one sort takes is
+    // inserted in pieces, and the log is merged into the index before it reaches "flush_pairs".
+    if (n > h->opt_flush_pairs) {
+        const uint64_t half = n / 2;
+        CK(insert_dev(h, d_kmers, half, id_genome, s, ordered));
+        return insert_dev(h, (const uint8_t*)d_kmers + half * (uint64_t)h->B, n - half, id_genome, s, ordered);
+    }
+    if (h->log_n && h->log_n + n > h->opt_flush_pairs) CK(bft_gpu_build(h));
     CK(log_reserve(h, h->log_n + n));
     const hipStream_t run = ordered ? s : h->stream;
     const uint8_t* p = (const uint8_t*)d_kmers;
@@ -479,7 +484,7 @@ static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_g
     }
     if (ordered) CK(note_foreign_stream(h, s));
     else HIPCK(hipStreamSynchronize(h->stream));
-    if ((h->log_n > 0 && id_genome < h->log_last_gid) || (h->store_any && id_genome < h->store_max_gid)) h->log_g_sorted = false;
+    if (h->log_n > 0 && id_genome < h->log_last_gid) h->log_g_sorted = false;
     h->log_last_gid = id_genome;
     h->log_n += n;
     h->max_gid_seen = std::max(h->max_gid_seen, id_genome);
@@ -940,33 +945,17 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     if (h->built && h->log_n == 0) return BFT_GPU_OK;
     CK(wait_foreign_stream(h));  // batches still being packed into the log on a caller's stream (bft_gpu_insert_kmers_dev_async)
     const int W = h->W;
-    const uint64_t total = h->n_pairs + h->log_n;
+    const uint64_t total = h->log_n;  // the run: what was inserted since the last build
     double t0 = now_ms();
 
     DevBuf tk, seg_off, npk, npg;
     uint64_t nk = 0, np = 0;
     if (total > 0) {
-        // 1. the pairs to sort: the log alone on a first build, else the sorted store followed by the log
+        // 1. the pairs to sort: the insertion log
         DevBuf ck, cg, sk, sg;
         const uint64_t* src_k = h->log_k.as<uint64_t>();
         const uint32_t* src_g = h->log_g.as<uint32_t>();
-        uint64_t src_stride = h->log_cap;
-        if (h->n_pairs) {
-            CK(ck.alloc(total * W * 8));
-            CK(cg.alloc(total * 4));
-            for (int w = 0; w < W; w++) {
-                HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total, h->pair_k.as<uint64_t>() + (uint64_t)w * h->n_pairs, h->n_pairs * 8,
-                                     hipMemcpyDeviceToDevice, h->stream));
-                if (h->log_n)
-                    HIPCK(hipMemcpyAsync(ck.as<uint64_t>() + (uint64_t)w * total + h->n_pairs, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
-                                         h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
-            }
-            HIPCK(hipMemcpyAsync(cg.p, h->pair_g.p, h->n_pairs * 4, hipMemcpyDeviceToDevice, h->stream));
-            if (h->log_n) HIPCK(hipMemcpyAsync(cg.as<uint32_t>() + h->n_pairs, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
-            src_k = ck.as<uint64_t>();
-            src_g = cg.as<uint32_t>();
-            src_stride = total;
-        }
+        const uint64_t src_stride = h->log_cap;
         const int gb = bits_for(h->max_gid_seen);
         // (composites of up to 63 bits: rocPRIM's radix sort mis-sorts the bit range [2, 64) -- found by test_any_k_against_ground_truth[31-0])
         if (W == 1 && h->log_g_sorted && 2 * h->k + gb <= 63 && !h->opt_no_composite) {
@@ -1069,6 +1058,26 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
+    seg_off.release();
+    npk.release();
+    npg.release();
+    // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
+    uint64_t total_pairs = np;
+    if (h->built && h->n_kmers > 0 && nk > 0) {
+        const BftRun old_run{h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_cs_off.as<uint32_t>(), h->d_cs_ids.as<uint32_t>(), h->n_sets};
+        const BftRun new_run{tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, n_cs_off.as<uint32_t>(), n_cs_ids.as<uint32_t>(), n_sets};
+        BftRunOut mo;
+        CK(bft_merge_runs(W, old_run, new_run, h->stream, mo));
+        tk.swap(mo.tk);
+        n_tcol.swap(mo.tcol);
+        n_cs_off.swap(mo.cs_off);
+        n_cs_ids.swap(mo.cs_ids);
+        nk = mo.n;
+        n_sets = mo.n_sets;
+        n_ids = mo.n_ids;
+        CK(bft_count_pairs(n_tcol.as<uint32_t>(), nk, n_cs_off.as<uint32_t>(), h->stream, &total_pairs));
+    }
+    np = total_pairs;
     double t2 = now_ms();
 
     // 5. containers, level by level, on the GPU
@@ -1112,13 +1121,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->d_uck.swap(idx.uck);
     h->d_ucrow.swap(idx.ucrow);
     h->d_tk.swap(tk);
-    h->pair_k.swap(npk);
-    h->pair_g.swap(npg);
     h->n_pairs = np;
     h->log_n = 0;
     h->log_g_sorted = true;
-    h->store_any = np > 0;
-    h->store_max_gid = h->max_gid_seen;
     h->n_kmers = nk;
     h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
     h->idx_sizes[3] = idx.n_f2w * 8; h->idx_sizes[4] = idx.n_clus * 8; h->idx_sizes[5] = idx.n_child * 8;
@@ -1875,8 +1880,8 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
 // image replication (one contiguous device blob: header, then 256-byte aligned sections)
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint64_t BLOB_MAGIC = 0x3230555047544642ull;  // "BFTGPU02"
-constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 15;
+constexpr uint64_t BLOB_MAGIC = 0x3330555047544642ull;  // "BFTGPU03"
+constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 13;
 enum { H_MAGIC, H_TOTAL, H_K, H_R1, H_R2, H_NKMERS, H_NPAIRS, H_NSETS, H_NIDS, H_ROOTNCC, H_MAXGID, H_ANYINS, H_NBGEN, H_NNAMES,
        H_STOREMAX, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
 
@@ -1895,9 +1900,9 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     for (const std::string& g : h->genomes) { p.names += g; p.names.push_back('\0'); }
     const uint64_t sz[BLOB_SECTIONS] = {h->idx_sizes[0], h->idx_sizes[1], h->idx_sizes[2], h->idx_sizes[3], h->idx_sizes[4], h->idx_sizes[5], h->idx_sizes[6],
                                         h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * 4,
-                                        h->n_pairs * (uint64_t)h->W * 8, h->n_pairs * 4, p.names.size()};
+                                        p.names.size()};
     const void* src[BLOB_SECTIONS] = {h->d_nodes.p, h->d_bfT.p, h->d_ccs.p, h->d_f2w.p, h->d_clus.p, h->d_child.p, h->d_uck.p, h->d_ucrow.p,
-                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, h->pair_k.p, h->pair_g.p, nullptr};
+                                      h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, nullptr};
     uint64_t o = BLOB_HDR_WORDS * 8;
     for (int i = 0; i < BLOB_SECTIONS; i++) {
         p.off[i] = o;
@@ -1908,7 +1913,7 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     uint64_t* H = p.hdr;
     H[H_MAGIC] = BLOB_MAGIC; H[H_TOTAL] = o; H[H_K] = h->k; H[H_R1] = h->r1; H[H_R2] = h->r2; H[H_NKMERS] = h->n_kmers; H[H_NPAIRS] = h->n_pairs;
     H[H_NSETS] = h->n_sets; H[H_NIDS] = h->n_ids; H[H_ROOTNCC] = h->root_ncc; H[H_MAXGID] = h->max_gid_seen; H[H_ANYINS] = h->any_insert;
-    H[H_NBGEN] = h->im.nb_genomes; H[H_NNAMES] = h->genomes.size(); H[H_STOREMAX] = h->store_max_gid; H[H_STOREANY] = h->store_any;
+    H[H_NBGEN] = h->im.nb_genomes; H[H_NNAMES] = h->genomes.size();
     for (int i = 0; i < 16; i++) H[H_INFO + i] = h->info[i];
     for (int i = 0; i < 9; i++) H[H_IDX + i] = h->idx_sizes[i];
 }
@@ -1937,8 +1942,8 @@ extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* 
     for (int i = 0; i < BLOB_SECTIONS; i++) {
         const uint64_t n = p.hdr[H_SEC + i];
         if (!n) continue;
-        if (i != 14) HIPCK(hipMemcpyAsync(d + p.off[i], p.src[i], n, hipMemcpyDeviceToDevice, s));
-        else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));  // section 14: the genome names (host)
+        if (i != 12) HIPCK(hipMemcpyAsync(d + p.off[i], p.src[i], n, hipMemcpyDeviceToDevice, s));
+        else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));  // section 12: the genome names (host)
     }
     HIPCK(hipStreamSynchronize(s));  // the header and the names are host temporaries
     return BFT_GPU_OK;
@@ -1967,17 +1972,17 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
     CK(bft_gpu_create_seeded((int)H[H_K], device, (int)H[H_R1], (int)H[H_R2], &h));
     const uint8_t* d = (const uint8_t*)d_blob;
     DevBuf* dst[BLOB_SECTIONS] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow,
-                                  &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, &h->pair_k, &h->pair_g, nullptr};
+                                  &h->d_tk, &h->d_tcol, &h->d_cs_off, &h->d_cs_ids, nullptr};
     int rc = 0;
     for (int i = 0; i < BLOB_SECTIONS && rc == 0; i++) {
-        if (i == 14) continue;  // names: below
+        if (i == 12) continue;  // names: below
         rc = dst[i]->alloc(H[H_SEC + i]);
         if (rc == 0 && H[H_SEC + i] &&
             hipMemcpyAsync(dst[i]->p, d + off[i], H[H_SEC + i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
             rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
     }
-    std::string names(H[H_SEC + 14], '\0');
-    if (rc == 0 && !names.empty() && hipMemcpyAsync(&names[0], d + off[14], names.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+    std::string names(H[H_SEC + 12], '\0');
+    if (rc == 0 && !names.empty() && hipMemcpyAsync(&names[0], d + off[12], names.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
         rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
     if (rc == 0 && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "image blob copy failed");
     if (rc == 0) {
@@ -1989,7 +1994,6 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         }
         h->n_kmers = H[H_NKMERS]; h->n_pairs = H[H_NPAIRS]; h->n_sets = H[H_NSETS]; h->n_ids = H[H_NIDS];
         h->root_ncc = (uint32_t)H[H_ROOTNCC]; h->max_gid_seen = (uint32_t)H[H_MAXGID]; h->any_insert = H[H_ANYINS] != 0;
-        h->store_max_gid = (uint32_t)H[H_STOREMAX]; h->store_any = H[H_STOREANY] != 0;
         for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
         for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
         h->cs_on_host = false;
@@ -2039,9 +2043,12 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "reserve_pairs") {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
         // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)
-        if (value < 0 || value >= 0x7FFFFFFFll) return fail(BFT_GPU_E_ARG, "reserve_pairs must be in [0, 2^31-1)");
+        if (value < 0 || (uint64_t)value > h->opt_flush_pairs) return fail(BFT_GPU_E_ARG, "reserve_pairs must be in [0, flush_pairs]");
         ENTER(h);
         CK(log_reserve(h, (uint64_t)value));
+    } else if (nm == "flush_pairs") {  // the insertion log is merged into the index before it holds this many pairs (default 2^30; a test hook below that)
+        if (value < 1024 || value > (1ll << 30)) return fail(BFT_GPU_E_ARG, "flush_pairs must be in [1024, 2^30]");
+        h->opt_flush_pairs = (uint64_t)value;
     } else if (nm == "query_probe") {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;
@@ -2123,7 +2130,7 @@ extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
     const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
                             h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
                             h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes, h->d_nph.bytes, h->d_kh.bytes, h->d_cs_bm.bytes,
-                            h->d_hashmod.bytes, h->pair_k.bytes + h->pair_g.bytes, h->log_k.bytes + h->log_g.bytes};
+                            h->d_hashmod.bytes, 0ull, h->log_k.bytes + h->log_g.bytes};
     for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
     return BFT_GPU_OK;
 }

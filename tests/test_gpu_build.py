@@ -317,17 +317,55 @@ def test_rejects_out_of_range_genome_ids():
     assert t.info()["pending_pairs"] == len(km)
 
 
-def test_pair_limit_is_reported_not_overrun():
-    """< 2^31 (k-mer, genome) pairs per handle (DESIGN.md limits): the call that would cross it fails with BFT_GPU_E_LIMIT before
-    it allocates or touches anything, and the handle stays usable."""
-    import torch
-    from bloomfiltertrie_amd._lib import BFTError
-    t = BFT(27)
-    small = torch.zeros((1024, 7), dtype=torch.uint8, device="cuda")
-    with pytest.raises(BFTError, match="2\\^31"):
-        t.insert_kmers_dev(small.data_ptr(), (1 << 31) - 1, 0)   # (never dereferenced: the limit check comes first)
-    with pytest.raises(BFTError, match="reserve_pairs"):
-        t.set_option("reserve_pairs", 1 << 31)
-    km = S.distinct(S.kmers_of(S.random_genome(5000, 1), 27))
-    t.insert_kmers(km, 0)
-    assert (S.from_bits(t.query_presence(km), len(km))).all()
+def _colour_map(t):
+    """{packed k-mer bytes: tuple of genome ids} of everything the handle stores"""
+    km, cs = t.extract()
+    sets = {c: tuple(t.colorset(c)) for c in np.unique(cs).tolist()}
+    return {km[i].tobytes(): sets[int(cs[i])] for i in range(len(km))}, len(sets)
+
+
+@pytest.mark.parametrize("k,flush", [(27, 4096), (27, 60000), (31, 20000), (45, 30000), (18, 5000)])
+def test_insertions_merge_into_the_index_without_a_pair_bound(k, flush):
+    """The index is its own store: a build sorts only what was inserted since the last one and merges that run into the index
+    (bft_merge.hip).  With the flush threshold lowered ("flush_pairs": the log is merged before it holds that many pairs; 2^30 in
+    production -- the reference inserts without bound, src/insertNode.c:18-36) dozens of merges happen during one series of insert
+    calls: genome ids out of order, genomes inserted twice, a batch larger than the threshold (inserted in pieces).  The result --
+    k-mers, colour set of every k-mer, the number of distinct colour sets and of (k-mer, genome) pairs, presence answers -- equals
+    that of ONE build over everything, and ground truth."""
+    rng = np.random.default_rng(k + flush)
+    anc = S.random_genome(60000, k)
+    genomes = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 10 + g), k)) for g in range(9)]
+    order = [3, 0, 1, 2, 2, 5, 4, 8, 7, 6, 0]  # out of order, 2 and 0 twice
+    whole, merged = BFT(k), BFT(k)
+    merged.set_option("flush_pairs", flush)
+    truth = {}
+    for g in order:
+        km = genomes[g]
+        whole.insert_kmers(km, g)
+        for part in np.array_split(km, 3):  # several insert calls per genome; some cross the threshold, one (flush 4096) exceeds it
+            merged.insert_kmers(np.ascontiguousarray(part), g)
+        for row in km:
+            truth.setdefault(row.tobytes(), set()).add(g)
+    whole.build()
+    merged.build()
+    mw, nsw = _colour_map(whole)
+    mm, nsm = _colour_map(merged)
+    assert mw == mm and nsw == nsm
+    assert {kk: tuple(sorted(v)) for kk, v in truth.items()} == mm
+    iw, im_ = whole.info(), merged.info()
+    for f in ("kmers", "pairs", "colorsets", "nodes", "ccs", "prefixes", "child_nodes"):
+        assert iw[f] == im_[f], f
+    assert im_["pairs"] == sum(len(v) for v in truth.values()) and im_["pending_pairs"] == 0
+    assert merged.footprint()["pair_store"] == 0
+    allk = S.distinct(np.concatenate(genomes))
+    q = np.concatenate([allk, S.snp_mutants(allk[::3], k, 4), S.pack_codes(rng.integers(0, 4, (3000, k), dtype=np.uint8))])
+    assert (merged.query_presence(q) == whole.query_presence(q)).all()
+    assert (S.from_bits(merged.query_presence(q), len(q)) == S.member(q, allk)).all()
+    for arr in ARRAYS:  # the containers are a function of the k-mer set alone: bit-identical however the k-mers arrived
+        assert (merged.debug_array(arr) == whole.debug_array(arr)).all(), arr
+    with pytest.raises(Exception):
+        merged.set_option("flush_pairs", 10)
+    whole.close()
+    merged.close()
+
+

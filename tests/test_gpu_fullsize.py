@@ -144,3 +144,62 @@ def test_host_entry_points_across_their_chunk_boundaries():
     bb = t.query_branching(q)
     bb2 = t.query_branching(q[: (1 << 26)])
     assert (bb[: (1 << 23)] == bb2).all()
+
+
+def test_more_than_2_31_pairs_on_one_gpu():
+    """No bound on the (k-mer, genome) pairs of an index (the reference has none, src/insertNode.c:18-36; rounds 1-2 stopped at 2^31 - 1):
+    1100 genomes of 2 Mbp = 2.2x10^9 pairs, 5x10^8 distinct k-mers, through the ordinary insert calls -- the log is merged into the
+    index every 2^30 pairs (bft_merge.hip).  Checked: the pair and k-mer counts against torch's own sort of every key, presence and the
+    source genome's colour bit on samples of three genomes, absence / presence of mutants against the sorted keys."""
+    import torch
+    from bloomfiltertrie_amd import BFT, workloads as W
+    k, G, glen = 27, 1100, 2_000_000
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    pan = W.PanGenome(G, glen, 0.01, 77, dev)
+    t = BFT(k)
+    keys, n_pairs = [], 0
+    for g in range(G):
+        packed = W.pack_windows(pan.genome(g), k)
+        t.insert_kmers_dev_async(packed.data_ptr(), packed.shape[0], g, stream)
+        kg = W.unique_keys(W.keys_of(packed))
+        n_pairs += int(kg.numel())
+        keys.append(kg)
+        del packed
+    t.build()
+    info = t.info()
+    assert n_pairs > (1 << 31) and info["pairs"] == n_pairs and info["pending_pairs"] == 0 and info["genomes"] == G
+    allk = torch.sort(torch.cat(keys)).values
+    del keys
+    distinct = int((allk[1:] != allk[:-1]).sum().item()) + 1
+    assert info["kmers"] == distinct
+    rowbytes = (G + 7) // 8
+    for g in (0, 537, G - 1):
+        packed = W.pack_windows(pan.genome(g), k)[::53].contiguous()
+        n = packed.shape[0]
+        bits = torch.zeros(((n + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+        rows = torch.zeros((n, rowbytes), dtype=torch.uint8, device=dev)
+        scratch = torch.zeros(n, dtype=torch.int32, device=dev)
+        t.query_color_rows_dev(packed.data_ptr(), n, bits.data_ptr(), rows.data_ptr(), scratch.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert bool(W.bits_to_bool(bits, n).all())
+        assert bool(((rows[:, g // 8] >> (g % 8)) & 1).bool().all())
+        # colour-set sizes are plausible: an unmutated window is shared by most genomes, and no set is empty
+        sizes = torch.zeros(n, dtype=torch.int32, device=dev)
+        for b in range(rowbytes):
+            col = rows[:, b].int()
+            for j in range(8):
+                sizes += (col >> j) & 1
+        assert int(sizes.min()) >= 1 and int(sizes.max()) > G // 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    nq = 20_000_000
+    idx = torch.randint(0, allk.numel(), (nq,), generator=gen, device=dev)
+    qk = W.snp_mutate_keys(allk[idx], k, 0.5, gen)
+    dq = W.packed_of(qk, k)
+    bits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+    t.query_presence_dev(dq.data_ptr(), nq, bits.data_ptr(), stream)
+    torch.cuda.synchronize()
+    p = torch.searchsorted(allk, qk).clamp(max=allk.numel() - 1)
+    assert bool((W.bits_to_bool(bits, nq) == (allk[p] == qk)).all())
+    t.close()
