@@ -224,6 +224,8 @@ struct bft_gpu {
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
     bool opt_no_composite = false;  // test hook ("build_composite" 0): the general sort + flag-array path also for ordered one-word keys
+    int opt_msd = 1;                // "build_msd": root-prefix buckets + bucket sorts for 2^20 pairs and more (1), always (2: test hook), never (0)
+    uint32_t msd_max_bucket = 0;    // largest root-prefix bucket of the last build's sort (0: not bucketed)
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
@@ -911,10 +913,9 @@ static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t tota
     np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
     CK(tk.alloc(nk * 8));
     CK(seg_off.alloc((nk + 1) * 4));
-    CK(npk.alloc(np * 8));
     CK(npg.alloc(np * 4));
-    hipLaunchKernelGGL(k_scatter_2<GT>, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, sk, sg, total, pos.as<uint64_t>(), npk.as<uint64_t>(),
-                       npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+    hipLaunchKernelGGL(k_scatter_2<GT>, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, sk, sg, total, pos.as<uint64_t>(), npg.as<uint32_t>(),
+                       tk.as<uint64_t>(), seg_off.as<uint32_t>());
     const uint32_t np32 = (uint32_t)np;
     HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(hipGetLastError());
@@ -965,14 +966,46 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             CK(pos.alloc(total * 8));
             const BftCompose comp{src_k, src_g, (uint32_t)gb};
             auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), comp);
-            size_t tb = 0, tb2 = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            size_t tb = 0, tb2 = 0, tb3 = 0;
+            // MSD first: a stable sort on the top 18 bits of T (the rotated root prefix: 2^18 buckets of ~10^3 composites on a
+            // pan-genome index), then every bucket on its own on the remaining bits -- the bucket sorts run out of LDS, one read and
+            // one write of the array instead of the four or five full passes those bits cost a device-wide LSD sort (7 passes over
+            // 2x10^8 composites: 7.6 ms; this way 3 + 1).  Skewed inputs (a bucket beyond 2^16 composites) keep the one-sort path.
+            const unsigned top = (unsigned)std::min(18, 2 * h->k), rest = (unsigned)(2 * h->k) - top;
+            const bool msd = h->opt_msd && rest > 0 && (total >= (1u << 20) || h->opt_msd == 2);
+            DevBuf cs2, boff;
+            if (msd) {
+                CK(cs2.alloc(total * 8));
+                CK(boff.alloc(((1u << top) + 1) * 4));
+                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs2.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                HIPCK(rocprim::segmented_radix_sort_keys(nullptr, tb3, cs2.as<uint64_t>(), cs.as<uint64_t>(), (uint32_t)total, 1u << top, boff.as<uint32_t>(),
+                                                         boff.as<uint32_t>() + 1, (unsigned)gb, (unsigned)gb + rest, h->stream));
+            } else
+                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
             const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
             auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
             HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-            CK(tmp.alloc(std::max(tb, tb2)));
-            tb = tb2 = tmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            CK(tmp.alloc(std::max(std::max(tb, tb2), tb3)));
+            tb = tb2 = tb3 = tmp.bytes;
+            bool sorted = false;
+            if (msd) {
+                HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs2.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                DevBuf maxb;
+                CK(maxb.alloc_zero(4, h->stream));
+                hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs2.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
+                                   boff.as<uint32_t>(), maxb.as<uint32_t>());
+                uint32_t mx = 0;
+                HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
+                HIPCK(hipStreamSynchronize(h->stream));
+                if (mx <= (1u << 16)) {
+                    HIPCK(rocprim::segmented_radix_sort_keys(tmp.p, tb3, cs2.as<uint64_t>(), cs.as<uint64_t>(), (uint32_t)total, 1u << top, boff.as<uint32_t>(),
+                                                             boff.as<uint32_t>() + 1, (unsigned)gb, (unsigned)gb + rest, h->stream));
+                    sorted = true;
+                }
+                h->msd_max_bucket = mx;
+            }
+            if (!sorted) HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            cs2.release();
             ck.release();
             cg.release();
             HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
@@ -986,10 +1019,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             np = (last_pos & 0xFFFFFFFFull) + (last_keep ? 1 : 0);
             CK(tk.alloc(nk * 8));
             CK(seg_off.alloc((nk + 1) * 4));
-            CK(npk.alloc(np * 8));
             CK(npg.alloc(np * 4));
             hipLaunchKernelGGL(k_scatter_c, dim3(grid_for((total + 255) / 256)), dim3(256), 0, h->stream, cs.as<uint64_t>(), (uint32_t)gb, total, pos.as<uint64_t>(),
-                               npk.as<uint64_t>(), npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+                               npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
             const uint32_t np32 = (uint32_t)np;
             HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
             HIPCK(hipGetLastError());
@@ -1036,11 +1068,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         np = (uint64_t)lastP[0] + lastP[1];
         CK(tk.alloc(nk * W * 8));
         CK(seg_off.alloc((nk + 1) * 4));
-        CK(npk.alloc(np * W * 8));
         CK(npg.alloc(np * 4));
         hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, W, sg.as<uint32_t>(), total,
-                           head.as<uint32_t>(), keep.as<uint32_t>(), posK.as<uint32_t>(), posP.as<uint32_t>(), npk.as<uint64_t>(), np,
-                           npg.as<uint32_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>());
+                           head.as<uint32_t>(), keep.as<uint32_t>(), posK.as<uint32_t>(), posP.as<uint32_t>(), npg.as<uint32_t>(), tk.as<uint64_t>(),
+                           seg_off.as<uint32_t>());
         const uint32_t np32 = (uint32_t)np;
         HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipGetLastError());
@@ -1059,7 +1090,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
     seg_off.release();
-    npk.release();
     npg.release();
     // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
     uint64_t total_pairs = np;
@@ -2040,6 +2070,9 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "build_composite") {
         if (value != 0 && value != 1) return fail(BFT_GPU_E_ARG, "build_composite must be 0 or 1");
         h->opt_no_composite = value == 0;
+    } else if (nm == "build_msd") {
+        if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "build_msd must be 0, 1 or 2");
+        h->opt_msd = (int)value;
     } else if (nm == "reserve_pairs") {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
         // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)
@@ -2152,7 +2185,7 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
     const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
-                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, 0.0, 0.0, 0.0,
+                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, 0.0, 0.0,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
                           (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
     for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];

@@ -24,14 +24,9 @@ __global__ void k_flags(const uint64_t* __restrict__ keys, uint64_t stride, int 
 
 __global__ void k_scatter(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
                           const uint32_t* __restrict__ head, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ posK,
-                          const uint32_t* __restrict__ posP, uint64_t* __restrict__ pk, uint64_t pstride, uint32_t* __restrict__ pg,
-                          uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+                          const uint32_t* __restrict__ posP, uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (keep[i]) {
-            const uint32_t p = posP[i];
-            for (int w = 0; w < W; w++) pk[(uint64_t)w * pstride + p] = keys[(uint64_t)w * stride + i];
-            pg[p] = g[i];
-        }
+        if (keep[i]) pg[posP[i]] = g[i];
         if (head[i]) {
             const uint32_t q = posK[i];
             for (int w = 0; w < W; w++) tk[(uint64_t)q * W + w] = keys[(uint64_t)w * stride + i];
@@ -59,16 +54,32 @@ struct BftPairFlags {  // input of the scan: (first pair of its k-mer) << 32 | (
         return (head << 32) | keep;
     }
 };
-__global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_t n, const uint64_t* __restrict__ pos, uint64_t* __restrict__ pk,
-                            uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+// root-prefix buckets of the composites sorted on their top bits: off[r] = first composite whose prefix is >= r (r = 0..nb), and the
+// size of the largest bucket
+__global__ void k_msd_bounds(const uint64_t* __restrict__ c, uint64_t n, uint32_t shift, uint32_t nb, uint32_t* __restrict__ off, uint32_t* __restrict__ max_bucket) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nb) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((c[mid] >> shift) < (uint64_t)r) lo = mid + 1; else hi = mid;
+    }
+    off[r] = (uint32_t)lo;
+    if (r < nb) {  // this bucket's end = the next one's start: found by the same search
+        uint64_t lo2 = lo, hi2 = n;
+        while (lo2 < hi2) {
+            const uint64_t mid = (lo2 + hi2) >> 1;
+            if ((c[mid] >> shift) < (uint64_t)r + 1) lo2 = mid + 1; else hi2 = mid;
+        }
+        atomicMax(max_bucket, (uint32_t)(lo2 - lo));
+    }
+}
+__global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_t n, const uint64_t* __restrict__ pos, uint32_t* __restrict__ pg,
+                            uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
     const uint64_t gmask = (1ull << gb) - 1ull;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t a = c[i], b = i ? c[i - 1] : ~a, ps = pos[i];
-        if (a != b) {
-            const uint32_t p = (uint32_t)ps;
-            pk[p] = a >> gb;
-            pg[p] = (uint32_t)(a & gmask);
-        }
+        if (a != b) pg[(uint32_t)ps] = (uint32_t)(a & gmask);
         if ((a >> gb) != (b >> gb)) {
             const uint32_t q = (uint32_t)(ps >> 32);
             tk[q] = a >> gb;
@@ -95,16 +106,12 @@ struct BftPairFlags2 {
 };
 template <class GT>
 __global__ void k_scatter_2(const uint64_t* __restrict__ k, const GT* __restrict__ g, uint64_t n, const uint64_t* __restrict__ pos,
-                            uint64_t* __restrict__ pk, uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
+                            uint32_t* __restrict__ pg, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t a = k[i], ps = pos[i];
         const GT ga = g[i];
         const bool head = i == 0 || a != k[i - 1], keep = head || ga != g[i - 1];
-        if (keep) {
-            const uint32_t p = (uint32_t)ps;
-            pk[p] = a;
-            pg[p] = (uint32_t)ga;
-        }
+        if (keep) pg[(uint32_t)ps] = (uint32_t)ga;
         if (head) {
             const uint32_t q = (uint32_t)(ps >> 32);
             tk[q] = a;

@@ -13,10 +13,17 @@
  *      isKmerPresent (src/presenceNode.c:1284-1921) are restated byte for byte
  *      of the algorithm (byte-LUT popcounts, skip cells, memcmp row search).
  *
- * Documented deviation: on level_min==0 levels the reference hides the
- * cluster-start bits in bit 7 of suffix rows (src/presenceNode.c:1690-1812);
- * this restatement keeps an explicit extra_filter3 on every level, which
- * yields the same (position, cluster length) pair.
+ * level_min==0 levels (suffix length not 9 mod 36, not the root): the
+ * reference has no extra_filter3 there -- the cluster-start bit of a prefix
+ * hides in bit 7 of the last suffix byte of its first row, or in bit 0 of a
+ * child Node's UC_array.nb_children -- and findCluster walks children_type
+ * position by position from the SkipFilter3 cell (src/presenceNode.c:
+ * 1690-1812), handing running child / node counts on to presenceKmer
+ * (:1425-1448).  findCluster_lm0 below restates that walk and those counts;
+ * the frozen model keeps the flag bits in one bitvector per CC (they are
+ * moved into the rows when a .bft file is written, and back when one is
+ * read), so the walk reads the flag there and ACCOUNTS (counting mode) the
+ * byte the reference dereferences for it.
  *
  * PARITY: see the header -- primitives pinned, trie-level "parity unpinned"
  * against the reference binary (unbuildable here), checked against ground
@@ -968,6 +975,8 @@ static int count_children(const orc_cc *cc, int start, int end, int type) {
     return count;
 }
 
+static inline int level_min_of(const orc_bft *t, int i) { return i == t->k || i % 36 == 9; } /* src/CC.c:1906-1989 */
+
 /* findCluster, level_min==1 branch: src/presenceNode.c:1578-1688 */
 static void findCluster(const orc_cc *cc, int pos_filter2, int *pos_extra_filter3, int *hamming_weight_0) {
     int size_bf = cc->type >> 7;
@@ -1023,6 +1032,109 @@ MATCH:
     }
     *pos_extra_filter3 = pos_extra_tmp;
     *hamming_weight_0 = hw0;
+}
+
+/* findCluster, level_min==0 branch: src/presenceNode.c:1690-1812.  Same rank in filter2 / SkipFilter3 start as above, then the walk over
+ * children_type.  Out: the reference's cpt_node_return, pos_extra_filter3, hamming_weight_0 and res->{pos_children, count_children,
+ * count_nodes}. */
+static void findCluster_lm0(const orc_cc *cc, int pos_filter2, int *cpt_node_return, int *pos_extra_filter3, int *hamming_weight_0,
+                            int *r_pos_children, int *r_count_children, int *r_count_nodes) {
+    int size_bf = cc->type >> 7, type = (cc->type >> 6) & 1;
+    int s = (cc->type >> 1) & 0x1f, p = NB_CHAR_SUF_PREF * 2 - s;
+    int size_filter2 = size_bf + (1 << p) / 8;
+    int size_filter2_n_skip = size_filter2;
+    int skip_filter2 = (1 << p) / NB_UC_PER_SKP;
+    if (cc->nb_elem >= TRESH_SUF_PREF) size_filter2_n_skip += skip_filter2;
+    int nb_skp = CEIL((int)cc->nb_elem, NB_UC_PER_SKP);
+    int m = 0, hamming_weight = 0, k = size_bf + pos_filter2 / 8, cnt = 0;
+    int pos_extra_tmp = INT_MAX, hw0 = 0, posFilter2;
+    uint8_t word_tmp;
+#define LM0_FLAG(pos) ((cc->extra_filter3[(pos) >> 3] >> ((pos) & 7)) & 1)
+
+    if (cc->nb_elem >= TRESH_SUF_PREF) { /* SkipFilter2: :1619-1630 */
+        int skip_posfilter2 = (pos_filter2 / NB_UC_PER_SKP < skip_filter2 ? pos_filter2 / NB_UC_PER_SKP : skip_filter2) + size_filter2;
+        cnt = size_filter2;
+        while (cnt < skip_posfilter2) { hamming_weight += cc->BF_filter2[cnt]; cnt++; }
+        TOUCH(skip_posfilter2 - size_filter2);
+        cnt -= size_filter2;
+    }
+    hamming_weight += popcnt_8_par(cc->BF_filter2, size_bf + cnt * (NB_UC_PER_SKP / 8), k);
+    word_tmp = cc->BF_filter2[k];
+    for (k = 0; k <= pos_filter2 % 8; k++, word_tmp >>= 1) hamming_weight += word_tmp & 1;
+    posFilter2 = hamming_weight;
+    hamming_weight = 0;
+    while ((m < cc->nb_elem / NB_UC_PER_SKP) && ((hamming_weight += cc->BF_filter2[size_filter2_n_skip + m]) < posFilter2)) m++; /* :1648-1651 */
+    TOUCH(m + 1);
+    if (hamming_weight >= posFilter2) hamming_weight -= cc->BF_filter2[size_filter2_n_skip + m];
+
+    /* :1700-1712 -- k is a multiple of 128, i.e. a bucket start: count_Nodes_Children over [nb_elem_in_pv, k) is empty */
+    k = m * NB_UC_PER_SKP;
+    int pos_children = k / NB_UC_PER_SKP, nb_elem_in_pv = pos_children * NB_UC_PER_SKP;
+    int cpt_pv = 0, cpt_node = 0, end, it;
+    if (nb_elem_in_pv > cc->nb_elem - nb_elem_in_pv) cpt_node += cc->nb_Node_children - count_nodes(cc, nb_elem_in_pv, cc->nb_elem, type);
+    else cpt_node += count_nodes(cc, 0, nb_elem_in_pv, type);
+    const int cpt_node_return_tmp = cpt_node;
+    nb_elem_in_pv = 0;
+    it = k - pos_children * NB_UC_PER_SKP;
+    while (pos_children < nb_skp) { /* :1714-1752 */
+        end = pos_children == nb_skp - 1 ? cc->nb_elem - pos_children * NB_UC_PER_SKP : NB_UC_PER_SKP;
+        while (it < end) {
+            TOUCH(1); /* getNbElts: one children_type byte */
+            if ((nb_elem_in_pv = getNbElts(cc, k, type)) == 0) {
+                TOUCH(2); /* children_Node_container[cpt_node].UC_array.nb_children (uint16) */
+                hamming_weight += LM0_FLAG(k);
+                cpt_node++;
+            } else {
+                TOUCH(1); /* bit 7 of the last suffix byte of the group's first row */
+                hamming_weight += LM0_FLAG(k);
+                cpt_pv += nb_elem_in_pv;
+            }
+            if (hamming_weight == posFilter2) { pos_extra_tmp = k; goto MATCH2; }
+            k++;
+            it++;
+        }
+        it = 0;
+        cpt_pv = 0;
+        pos_children++;
+    }
+    if (pos_extra_tmp == INT_MAX) pos_extra_tmp = cc->nb_elem;
+MATCH2:
+    *r_pos_children = pos_children;
+    *r_count_children = cpt_pv - nb_elem_in_pv;
+    *r_count_nodes = cpt_node - (nb_elem_in_pv == 0);
+    if (pos_children < nb_skp) { /* cluster length: :1763-1810 */
+        it++;
+        k++;
+        end = pos_children == nb_skp - 1 ? cc->nb_elem - pos_children * NB_UC_PER_SKP : NB_UC_PER_SKP;
+        if (it >= end) { it = 0; cpt_pv = 0; pos_children++; }
+        while (pos_children < nb_skp) {
+            end = pos_children == nb_skp - 1 ? cc->nb_elem - pos_children * NB_UC_PER_SKP : NB_UC_PER_SKP;
+            while (it < end) {
+                TOUCH(1);
+                if ((nb_elem_in_pv = getNbElts(cc, k, type)) == 0) {
+                    TOUCH(2);
+                    if (LM0_FLAG(k)) goto OUT_LOOP;
+                    hw0 += 1;
+                    cpt_node++;
+                } else {
+                    TOUCH(1);
+                    if (LM0_FLAG(k)) goto OUT_LOOP;
+                    hw0 += 1;
+                    cpt_pv += nb_elem_in_pv;
+                }
+                k++;
+                it++;
+            }
+            it = 0;
+            cpt_pv = 0;
+            pos_children++;
+        }
+    }
+OUT_LOOP:
+    *cpt_node_return = cpt_node_return_tmp;
+    *pos_extra_filter3 = pos_extra_tmp;
+    *hamming_weight_0 = hw0;
+#undef LM0_FLAG
 }
 
 typedef struct {
@@ -1100,8 +1212,10 @@ static void is_kmer_present(const orc_bft *t, const uint8_t *kmer, orc_res *res)
             TOUCH(1);
             if ((cc->BF_filter2[size_bf + posFilter2 / 8] & (1u << (posFilter2 % 8))) == 0) return; /* :1548 */
 
-            int pos_extra, hw0;
-            findCluster(cc, posFilter2, &pos_extra, &hw0);
+            int pos_extra, hw0, cpt_node_tmp = -1, r_pos_children = 0, r_count_children = 0, r_count_nodes = 0;
+            const int lm = level_min_of(t, i);
+            if (lm) findCluster(cc, posFilter2, &pos_extra, &hw0);
+            else findCluster_lm0(cc, posFilter2, &cpt_node_tmp, &pos_extra, &hw0, &r_pos_children, &r_count_children, &r_count_nodes);
             if (pos_extra >= cc->nb_elem) return;
             int imin = pos_extra, imax = pos_extra + hw0, hit = 0;
             if (s == 8) { /* :1399-1410 */
@@ -1137,7 +1251,10 @@ static void is_kmer_present(const orc_bft *t, const uint8_t *kmer, orc_res *res)
                 const orc_uc *uc = &cc->children[bucket];
                 int psb = bucket * NB_UC_PER_SKP;
                 int nb_elem = cc->nb_elem - psb < NB_UC_PER_SKP ? cc->nb_elem - psb : NB_UC_PER_SKP;
-                if (imin - psb > psb + nb_elem - imin) psb = uc->nb_children - count_children(cc, imin, psb + nb_elem, type);
+                if (!lm && r_pos_children == bucket) { /* :1425-1430: the walk of findCluster already counted up to the cluster start */
+                    if (imin - pos_extra > psb + nb_elem - imin) psb = uc->nb_children - count_children(cc, imin, psb + nb_elem, type);
+                    else psb = r_count_children + count_children(cc, pos_extra, imin, type);
+                } else if (imin - psb > psb + nb_elem - imin) psb = uc->nb_children - count_children(cc, imin, psb + nb_elem, type);
                 else psb = count_children(cc, psb, imin, type);
                 /* isKmerPresent :1874-1915 */
                 int nb_elt = getNbElts(cc, imin, type);
@@ -1159,9 +1276,10 @@ static void is_kmer_present(const orc_bft *t, const uint8_t *kmer, orc_res *res)
                 }
                 return;
             }
-            /* child Node: :1443-1448 (cpt_node_tmp == -1) */
+            /* child Node: :1443-1448 */
             int idx;
-            if (imin < cc->nb_elem - imin) idx = count_nodes(cc, 0, imin, type);
+            if (cpt_node_tmp != -1) idx = r_count_nodes + count_nodes(cc, pos_extra, imin + 1, type) - 1;
+            else if (imin < cc->nb_elem - imin) idx = count_nodes(cc, 0, imin, type);
             else idx = cc->nb_Node_children - count_nodes(cc, imin, cc->nb_elem, type);
             node = cc->children_nodes[idx];
             i -= NB_CHAR_SUF_PREF;
@@ -1359,7 +1477,6 @@ long orc_extract(orc_bft *t, uint8_t *kmers_out, uint32_t *cs_out) {
 /* .bft writer / reader (src/write_to_disk.c)                         */
 /* ------------------------------------------------------------------ */
 
-static inline int level_min_of(const orc_bft *t, int i) { return i == t->k || i % 36 == 9; } /* src/CC.c:1906-1989 */
 
 static void wr(FILE *f, const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) { fprintf(stderr, "oracle: write error\n"); exit(1); } }
 static void wr_u16(FILE *f, uint16_t v) { wr(f, &v, 2); }

@@ -198,16 +198,18 @@ def test_flat_form_matches_host_restatement(hostlib, flat_min):
 @pytest.mark.parametrize("k,ngen", [(27, 3), (27, 130), (31, 2), (31, 4), (31, 300), (18, 40)])
 def test_composite_sort_builds_the_same_image(k, ngen):
     """One-word keys with ascending genome ids are sorted as (T << bits | genome) composites when that fits 63 bits
-    ("build_composite" 1, the default) and by the general key + value sort otherwise: every array of the image, the colour sets
-    and the extraction are identical -- including an incremental rebuild and duplicate (k-mer, genome) pairs."""
+    ("build_composite" 1, the default) -- root-prefix buckets first, then every bucket on its own ("build_msd" 2 forces that at this
+    small size; 0 = one device-wide sort) -- and by the general key + value sort otherwise: every array of the image, the colour
+    sets and the extraction are identical -- including an incremental build and duplicate (k-mer, genome) pairs."""
     from bloomfiltertrie_amd import BFT
     base = S.distinct(S.kmers_of(S.random_genome(30000, 5 + k), k))
     rng = np.random.default_rng(k + ngen)
     parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.3]) for _ in range(ngen)]
     imgs = []
-    for comp in (1, 0):
+    for comp, msd in ((1, 2), (0, 0), (1, 0)):
         t = BFT(k)
         t.set_option("build_composite", comp)
+        t.set_option("build_msd", msd)
         half = ngen // 2
         for g in range(half):
             t.insert_kmers(parts[g], g)
@@ -220,10 +222,11 @@ def test_composite_sort_builds_the_same_image(k, ngen):
         ek, ecs = t.extract()
         imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs, [t.colorset(c) for c in sorted(set(ecs.tolist()))[:200]]))
         t.close()
-    a, b = imgs
-    for name in ARRAYS:
-        assert (a[0][name] == b[0][name]).all(), name
-    assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
+    a = imgs[0]
+    for b in imgs[1:]:
+        for name in ARRAYS:
+            assert (a[0][name] == b[0][name]).all(), name
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
 
 
 def test_stream_ordered_inserts_build_the_same_image():

@@ -61,6 +61,34 @@ def test_deep_tries(oracle_mod, k, levels):
     _check_presence(t, km, k)
 
 
+@pytest.mark.parametrize("k,levels", [(27, 2), (36, 3), (63, 3)])
+def test_level_min_0_cluster_walk(oracle_mod, k, levels):
+    """Levels whose suffix length is not 9 mod 36 have no extra_filter3 in the reference: findCluster walks children_type from the
+    SkipFilter3 cell and hands its running child / node counts to presenceKmer (src/presenceNode.c:1690-1812, :1425-1448), restated
+    as findCluster_lm0.  A trie with many prefixes per cluster and child Nodes on such levels answers exactly (ground truth), its
+    colours come from the rows those counts locate, and the counting mode sees the walk (more bytes per query than levels alone)."""
+    rng = np.random.default_rng(k)
+    km = S.low_entropy_kmers(150000, k, 6, seed=3 + k, levels=levels)   # few root prefixes: big nodes below the root
+    halves = np.array_split(km[rng.permutation(len(km))], 2)
+    o = oracle_mod.OracleBFT(k)
+    c = oracle_mod.OracleBFT(k, count=True)
+    for g, part in enumerate(halves):
+        o.insert_kmers(np.ascontiguousarray(part), g)
+        c.insert_kmers(np.ascontiguousarray(part), g)
+    st = o.stats()
+    assert st["child_nodes"] > 0 and st["ccs"] > st["root_ccs"]
+    q = np.concatenate([km, S.snp_mutants(km, k, 2), S.snp_mutants(km[::2], k, 5)])
+    bits, off, ids = o.query_colors(q)
+    truth = S.member(q, km)
+    assert (S.from_bits(bits, len(q)) == truth).all()
+    which = {row.tobytes(): g for g, part in enumerate(halves) for row in part}
+    sizes = np.diff(off)
+    for i in np.flatnonzero(truth)[:: max(1, int(truth.sum()) // 4000)]:
+        assert sizes[i] == 1 and ids[off[i]] == which[q[i].tobytes()]
+    cbits, cnt = c.query_presence_count(q)
+    assert (cbits == bits).all() and cnt["levels"] > len(q) and cnt["bytes"] > 40 * len(q)
+
+
 def test_group_exactly_255_then_256(oracle_mod):
     k = 18
     rng = np.random.default_rng(3)
