@@ -42,26 +42,37 @@ int put_id(uint8_t* out, uint32_t id, uint8_t start_flag, uint8_t cont_flag) {
 // larger (:638-650) -- EXCEPT that on a tie with the mode the annotation is already in, it stays in that mode (:652-653).  The
 // result therefore depends on the order the ids arrived in; they arrive in ascending order (a k-mer meets genome ids in
 // increasing order), so the sorted id list IS the history and the rule is replayed over it, one id at a time, with the sizes of
-// :621-633 (mode 1: a new range costs two ids, extending the last one swaps its end).  disabled_flags (:622) is never set by the
-// reference and is not modelled; nor is the one-byte over-estimate of a run's end at id 4095 / 262143 while in bitmap mode
-// (:515-523), which needs > 4096 genomes in mode 0 to matter.  E.g. {6,7}: 6 enters in mode 2 (1 byte < 2 bytes of bitmap), at 7
-// all three modes cost 2 bytes and the annotation STAYS in mode 2 (a fresh decision would pick the bitmap).
+// :621-633 (mode 1: a new range costs two ids, extending the last one swaps its end).  While the annotation is a bitmap the reference
+// does not know its id list: it re-derives the two list sizes by scanning the bits (:476-535), and prices the END of a run with the
+// byte count of the id one past it (:515-523) -- one byte too many when the run ends at 63, 4095, 262143 or 16777215 (the ids after
+// which an id takes one more byte).  That estimate, not the exact size, is what the bitmap is compared with, so it is replayed too
+// (`over`); an annotation that leaves the bitmap on such an estimate is given the estimated size (a trailing zero byte, which
+// the decoders stop at).  disabled_flags (:622) is never set anywhere in the reference (grep: only tested), so there is nothing to
+// replay.  E.g. {6,7}: 6 enters in mode 2 (1 byte < 2 bytes of bitmap), at 7 all three modes cost 2 bytes and the annotation STAYS
+// in mode 2 (a fresh decision would pick the bitmap).
 void annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) {
     out.clear();
     if (n == 0) { out.push_back(0); return; }
     size_t s0 = 0, s1 = 0, s2 = 0, sz = 0;
     int mode = -1;
+    uint32_t pend = 0;  // runs of the set so far that end at an id of the form 64^j - 1 (bit j-1): over-priced while in bitmap mode
     for (uint32_t a = 0; a < n; a++) {
         const size_t b = (size_t)nb_bytes_id(ids[a]);
         s0 = (3 + (size_t)ids[a] + 7) / 8;
         s2 += b;
         if (a > 0 && ids[a] == ids[a - 1] + 1) s1 = s1 + b - (size_t)nb_bytes_id(ids[a - 1]);
         else s1 += 2 * b;
+        const size_t s1e = s1 + (mode == 0 ? (size_t)__builtin_popcount(pend) : 0);  // the reference's estimate of the ranges size
         int m;
-        if (s2 <= s1) { m = 2; sz = s2; } else { m = 1; sz = s1; }
+        if (s2 <= s1e) { m = 2; sz = s2; } else { m = 1; sz = s1e; }
         if (sz >= s0) { m = 0; sz = s0; }
-        if (mode >= 0 && m != mode && (mode == 0 ? s0 : (mode == 1 ? s1 : s2)) == sz) m = mode;  // tie: the current mode stays
+        if (mode >= 0 && m != mode && (mode == 0 ? s0 : (mode == 1 ? s1e : s2)) == sz) m = mode;  // tie: the current mode stays
         mode = m;
+        for (int j = 1; j <= 4; j++) {
+            const uint32_t edge = (1u << (6 * j)) - 1u;
+            if (ids[a] == edge) pend |= 1u << (j - 1);
+            if (ids[a] == edge + 1 && a > 0 && ids[a - 1] == edge) pend &= ~(1u << (j - 1));
+        }
     }
     out.assign(sz, 0);
     if (mode == 0) {

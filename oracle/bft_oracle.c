@@ -224,21 +224,30 @@ static void annot_sizes(const uint32_t *ids, int n, int *sz0, int *sz1, int *sz2
  * more than 4096 genomes in bitmap mode to show. */
 static int annot_best(const uint32_t *ids, int n, int *mode) {
     int s1 = 0, s2 = 0, cur = -1, cur_sz = 1;
+    /* While in bitmap mode the reference re-derives the list sizes from the bits and prices the end of a run with the byte count of
+     * the id one past it (src/annotation.c:515-523): +1 for every run ending at 63, 4095, 262143, 16777215 (`over`). */
+    int over63 = 0, over4095 = 0, over262143 = 0, over16m = 0;
     for (int a = 0; a < n; a++) {
         const int b = orc_nb_bytes_id(ids[a]);
         const int s0 = CEIL(3 + (int)ids[a], 8);
         s2 += b;
         if (a > 0 && ids[a] == ids[a - 1] + 1) s1 += b - orc_nb_bytes_id(ids[a - 1]);
         else s1 += 2 * b;
+        const int s1e = s1 + (cur == 0 ? over63 + over4095 + over262143 + over16m : 0);
         int m, sz;
-        if (s2 <= s1) { m = 2; sz = s2; } else { m = 1; sz = s1; }
+        if (s2 <= s1e) { m = 2; sz = s2; } else { m = 1; sz = s1e; }
         if (sz >= s0) { m = 0; sz = s0; }
         if (cur >= 0 && m != cur) {
-            const int same = cur == 0 ? s0 : (cur == 1 ? s1 : s2);
+            const int same = cur == 0 ? s0 : (cur == 1 ? s1e : s2);
             if (same == sz) m = cur;
         }
         cur = m;
         cur_sz = sz;
+        const int ext = a > 0 && ids[a] == ids[a - 1] + 1;
+        if (ids[a] == 63u) over63 = 1; else if (ids[a] == 64u && ext) over63 = 0;
+        if (ids[a] == 4095u) over4095 = 1; else if (ids[a] == 4096u && ext) over4095 = 0;
+        if (ids[a] == 262143u) over262143 = 1; else if (ids[a] == 262144u && ext) over262143 = 0;
+        if (ids[a] == 16777215u) over16m = 1; else if (ids[a] == 16777216u && ext) over16m = 0;
     }
     if (n == 0) { int s0; annot_sizes(ids, n, &s0, &s1, &s2); cur = 0; cur_sz = s0; }
     *mode = cur;

@@ -149,3 +149,141 @@ def test_annotation_mode_follows_the_insertion_history(oracle_mod):
         buf = np.zeros(16 + 4 * len(ids) + int(ids.max()) // 8, np.uint8)
         n = lib.bft_hosttest_annot_encode(ids.ctypes.data, len(ids), buf.ctypes.data, len(buf))
         assert n == len(enc) and buf[:n].tobytes() == enc
+
+
+def _ref_mode_history(ids):
+    """compute_best_mode (src/annotation.c:416-656) replayed over ascending ids, written straight from the reference: while the
+    annotation is a bitmap the two list sizes are re-derived by SCANNING ITS BITS (:476-535, with pow2_imin / tmp / tmp2 exactly
+    as there), otherwise from the stored ids (:540-615).  Returns (mode, size) after the last insertion.  Independent of both encoders."""
+    def nb(v):
+        return (max(1, int(v).bit_length()) + 5) // 6
+
+    def round_up(v):
+        v -= 1
+        for sh in (1, 2, 4, 8, 16):
+            v |= v >> sh
+        return v + 1
+
+    def nb_bis(pos, pow2):
+        return -(-(pow2.bit_length() - 1 + (1 if pow2 == pos else 0)) // 6)
+
+    mode, size, have = None, 0, []
+    for v in ids:
+        tot1 = tot2 = 0
+        tmp = tmp2 = 1
+        last = None
+        if mode == 0:
+            bits = set(x + 2 for x in have)
+            nbits = size * 8
+            lim = nbits if nbits - 2 < 64 else 66
+            run = False
+            for i in range(2, lim):
+                if i in bits:
+                    last = i - 2
+                    tot2 += 1
+                    tot1 += 0 if run else 1
+                    run = True
+                else:
+                    tot1 += 1 if run else 0
+                    run = False
+            if nbits - 2 < 64:
+                tot1 += 1 if run else 0
+            else:
+                pow2 = 0
+                for i in range(66, nbits):
+                    if i in bits:
+                        last = i - 2
+                        if last >= pow2:
+                            pow2 = round_up(last)
+                            tmp = tmp2 = nb_bis(last, pow2)
+                        tot2 += tmp
+                        tot1 += 0 if run else tmp
+                        run = True
+                    else:
+                        if run:
+                            if i - 2 >= pow2:
+                                pow2 = round_up(i - 2)
+                                tmp2 = nb_bis(i - 2, pow2)
+                            tot1 += tmp2
+                        run = False
+                if run:
+                    tot1 += 1 if last < 0x40 else tmp
+        elif mode in (1, 2):
+            sizes = [nb(x) for x in have]
+            last = have[-1]
+            tot2 = sum(sizes)
+            tot1 = sizes[0]
+            for i in range(1, len(have)):
+                if have[i] != have[i - 1] + 1:
+                    tot1 += sizes[i - 1] + sizes[i]
+            tot1 += sizes[-1]
+        new0, new1, new2 = -(-(3 + v) // 8), tot1, tot2
+        if last is None or v != last:
+            if last is None or v != last + 1:
+                new1 += 2 * nb(v)
+            elif mode == 0:
+                new1 += nb(v) - tmp
+            else:
+                new1 += nb(v) - nb(have[-1])
+            new2 += nb(v)
+        if new2 <= new1:
+            m, sz = 2, new2
+        else:
+            m, sz = 1, new1
+        if sz >= new0:
+            m, sz = 0, new0
+        if mode is not None and (new0, new1, new2)[mode] == sz and m != mode:
+            m = mode
+        mode, size = m, sz
+        have.append(v)
+    return mode, size
+
+
+def test_annotation_run_end_estimate_in_bitmap_mode(oracle_mod):
+    """a15, the run-end estimate (src/annotation.c:515-523): while an annotation is a bitmap, the reference prices the end of a run
+    with the byte count of the id one past it -- one byte too many for a run that ends at 63 (or 4095, 262143).  Derived by hand:
+      ids = 0..9, 20..29, 40..45, 50..55, 60..63: five runs of one-byte ids cost ranges 10 bytes, the list 36, the bitmap CEIL(66/8) = 9:
+      a bitmap.  Inserting 110 (a new run of a two-byte id: + 4): ranges cost 14 exactly, the bitmap CEIL(113/8) = 15 -- an exact
+      comparison leaves the bitmap (14 < 15); the reference adds 1 for the run that ends at 63 (priced as id 64: 2 bytes), sees 15 >= 15
+      and KEEPS the bitmap: 15 bytes, bits id + 2.
+    The same set with the last run ending at 62 instead has no such run: ranges 14 < 15 win.  Both encoders must agree with these and,
+    on random sets around the byte-count edges 63/64 and 4095/4096, with the replay of the reference's own scan (_ref_mode_history)."""
+    import ctypes as C
+    import os
+    from bloomfiltertrie_amd import _lib
+    lib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
+    lib.bft_hosttest_annot_encode.restype = C.c_int
+    lib.bft_hosttest_annot_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+
+    def product(ids):
+        a = np.array(ids, dtype=np.uint32)
+        buf = np.zeros(64 + 4 * len(a) + int(a.max()) // 8, np.uint8)
+        n = lib.bft_hosttest_annot_encode(a.ctypes.data, len(a), buf.ctypes.data, len(buf))
+        return buf[:n].tobytes()
+
+    runs63 = list(range(0, 10)) + list(range(20, 30)) + list(range(40, 46)) + list(range(50, 56)) + list(range(60, 64))
+    ids = runs63 + [110]
+    bitmap = bytearray(15)
+    for g in ids:
+        bitmap[(g + 2) // 8] |= 1 << ((g + 2) % 8)
+    assert _ref_mode_history(ids) == (0, 15)
+    assert oracle_mod.annot_encode(ids) == bytes(bitmap) and product(ids) == bytes(bitmap)
+    ids62 = [g for g in runs63 if g != 63] + [110]   # the last run ends at 62: nothing is over-priced, ranges (14 bytes) win
+    assert _ref_mode_history(ids62) == (1, 14)
+    enc = oracle_mod.annot_encode(ids62)
+    assert len(enc) == 14 and enc[0] & 3 == 1 and product(ids62) == enc and oracle_mod.annot_decode(enc) == ids62
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        edge = (63, 4095)[trial % 2]
+        parts = []
+        for _ in range(int(rng.integers(2, 8))):   # a few runs below the edge, often one that ends on it or crosses it
+            a0 = int(rng.integers(0, edge - 20))
+            parts.append(np.arange(a0, a0 + int(rng.integers(1, 12))))
+        end = edge + int(rng.integers(-1, 3))
+        parts.append(np.arange(end - int(rng.integers(0, 6)), end + 1))
+        parts.append(rng.integers(edge + 2, edge + 200, int(rng.integers(0, 4))))
+        idl = np.unique(np.concatenate(parts)).astype(np.uint32).tolist()
+        mode, size = _ref_mode_history(idl)
+        enc = oracle_mod.annot_encode(idl)
+        assert (enc[0] & 3, len(enc)) == (mode, size), (idl, mode, size)
+        assert product(idl) == enc and oracle_mod.annot_decode(enc) == idl
