@@ -100,3 +100,9 @@ struct BftRunOut {
 };
 int bft_merge_runs(int W, const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out);
 int bft_count_pairs(const uint32_t* d_tcol, uint64_t n, const uint32_t* d_cs_off, hipStream_t s, uint64_t* total);
+
+// The build's front end behind the root-prefix split (bft_front.hip): bucket-wise sort of the composites c = T << gb | genome on the
+// bits [gb, split_bit) and the de-duplicated outputs: sorted distinct k-mers, offsets of their genome-id lists, the genome ids.
+uint32_t bft_front_bucket_capacity(void);
+int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
+                      DevBuf& pg, uint64_t& nk, uint64_t& np);

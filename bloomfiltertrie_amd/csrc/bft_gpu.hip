@@ -966,48 +966,43 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             CK(pos.alloc(total * 8));
             const BftCompose comp{src_k, src_g, (uint32_t)gb};
             auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), comp);
-            size_t tb = 0, tb2 = 0, tb3 = 0;
+            size_t tb = 0, tb2 = 0;
             // MSD first: a stable sort on the top 18 bits of T (the rotated root prefix: 2^18 buckets of ~10^3 composites on a
-            // pan-genome index), then every bucket on its own on the remaining bits -- the bucket sorts run out of LDS, one read and
-            // one write of the array instead of the four or five full passes those bits cost a device-wide LSD sort (7 passes over
-            // 2x10^8 composites: 7.6 ms; this way 3 + 1).  Skewed inputs (a bucket beyond 2^16 composites) keep the one-sort path.
+            // pan-genome index), then every bucket on its own on the remaining bits, in LDS, with the duplicates flagged and counted
+            // on the way (bft_front.hip) -- one read and one write of the array instead of the four or five full passes those
+            // bits cost a device-wide LSD sort, and no flag scan over the pairs.  Skewed inputs (a bucket beyond what one workgroup
+            // sorts) keep the one-sort path.
             const unsigned top = (unsigned)std::min(18, 2 * h->k), rest = (unsigned)(2 * h->k) - top;
-            const bool msd = h->opt_msd && rest > 0 && (total >= (1u << 20) || h->opt_msd == 2);
-            DevBuf cs2, boff;
+            const bool msd = h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2);
+            bool done = false;
+            h->msd_max_bucket = 0;
             if (msd) {
-                CK(cs2.alloc(total * 8));
+                DevBuf boff, maxb;
                 CK(boff.alloc(((1u << top) + 1) * 4));
-                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs2.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
-                HIPCK(rocprim::segmented_radix_sort_keys(nullptr, tb3, cs2.as<uint64_t>(), cs.as<uint64_t>(), (uint32_t)total, 1u << top, boff.as<uint32_t>(),
-                                                         boff.as<uint32_t>() + 1, (unsigned)gb, (unsigned)gb + rest, h->stream));
-            } else
-                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
-            const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
-            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
-            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-            CK(tmp.alloc(std::max(std::max(tb, tb2), tb3)));
-            tb = tb2 = tb3 = tmp.bytes;
-            bool sorted = false;
-            if (msd) {
-                HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs2.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
-                DevBuf maxb;
                 CK(maxb.alloc_zero(4, h->stream));
-                hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs2.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
+                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                CK(tmp.alloc(tb));
+                HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
                 uint32_t mx = 0;
                 HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
                 HIPCK(hipStreamSynchronize(h->stream));
-                if (mx <= (1u << 16)) {
-                    HIPCK(rocprim::segmented_radix_sort_keys(tmp.p, tb3, cs2.as<uint64_t>(), cs.as<uint64_t>(), (uint32_t)total, 1u << top, boff.as<uint32_t>(),
-                                                             boff.as<uint32_t>() + 1, (unsigned)gb, (unsigned)gb + rest, h->stream));
-                    sorted = true;
-                }
                 h->msd_max_bucket = mx;
+                if (mx <= bft_front_bucket_capacity()) {
+                    pos.release();
+                    CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np));
+                    done = true;
+                }
             }
-            if (!sorted) HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
-            cs2.release();
-            ck.release();
-            cg.release();
+            if (!done) {
+            HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
+            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
+            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            if (std::max(tb, tb2) > tmp.bytes) CK(tmp.alloc(std::max(tb, tb2)));
+            tb = tb2 = tmp.bytes;
+            HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
             HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
             uint64_t last_pos = 0, last_c[2] = {0, 0};
             HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1026,6 +1021,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
             HIPCK(hipGetLastError());
             HIPCK(hipStreamSynchronize(h->stream));
+            }
+            ck.release();
+            cg.release();
         } else if (W == 1 && h->log_g_sorted && h->max_gid_seen < 65536 && !h->opt_no_composite) {
             // 2n + 3'. ordered one-word keys whose composite does not fit (k = 31 with more than a few genomes): key + value sort with the
             // ids narrowed to one or two bytes (the values are a third of the sort's traffic at four)
