@@ -207,6 +207,7 @@ def main():
 
     with BFT(k, device=local_rank) as warm:  # loads the code objects and the library sort kernels once (not part of any figure)
         wk = S.distinct(S.kmers_of(S.random_genome(120000, 5), k))
+        warm.set_option("build_msd", 2)
         warm.insert_kmers(wk, 0)
         warm.build()
         warm.query_presence(wk[:1000])
