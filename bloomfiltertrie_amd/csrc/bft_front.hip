@@ -23,7 +23,8 @@
 #define FB_WAVES (FB_BLOCK / 64)
 #define FB_EMAX 16                      // composites per thread
 #define FB_CAP (FB_BLOCK * FB_EMAX)     // largest bucket sorted in LDS (4096 composites = 32 KB)
-#define FB_DBITS 9                      // digit width: 36 remaining bits = four passes (8-bit digits: five -- 4.7 ms instead of 3.9 on config 3)
+#define FB_DBITS 8                      // digit width (9-bit digits, four passes instead of five over 36 bits, were slower: 5.9 ms against 4.7 on
+                                        // config 3 -- 40 KB of LDS per workgroup leaves three per CU, and the counters' upkeep grows with the digits)
 #define FB_DIGITS (1 << FB_DBITS)
 
 namespace {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round's leaders read what this round's leaders wrote
             }
             __syncthreads();
-            {   // digits 2 tid, 2 tid + 1: counts of the four wavefronts -> start of (digit, wavefront) in the bucket
+            {   // digit(s) of this thread: counts of the four wavefronts -> start of (digit, wavefront) in the bucket
                 constexpr int DPT = FB_DIGITS / FB_BLOCK;  // digits per thread
                 uint32_t cw[DPT][FB_WAVES], tot = 0;
 #pragma unroll
