@@ -52,6 +52,13 @@ SIGNATURES = {
     "bft_gpu_image_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "bft_gpu_image_pack": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "bft_gpu_image_unpack": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(_P)]),
+    "bft_gpu_group_shard": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bft_gpu_group_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "bft_gpu_group_free": (None, [_P]),
+    "bft_gpu_group_size": (C.c_int, [_P]),
+    "bft_gpu_group_query_presence": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "bft_gpu_group_query_color_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    "bft_gpu_group_query_branching": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
 }
 
 

@@ -288,6 +288,63 @@ class BFT:
         return out[:n.value].tobytes()
 
 
+class BFTGroup:
+    """One built index replicated on several GPUs of this process; host batches are sharded over them (bft_gpu_group_*)."""
+
+    def __init__(self, bft, devices):
+        self._lib = _lib.load()
+        self._bft = bft
+        arr = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        _lib.check(self._lib.bft_gpu_group_create(bft._h, bft.device, arr, len(devices), C.byref(g)))
+        self._g = g
+        self.nb = bft.nb
+
+    def size(self):
+        return self._lib.bft_gpu_group_size(self._g)
+
+    def close(self):
+        if self._g:
+            self._lib.bft_gpu_group_free(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query_presence(self, kmers):
+        kmers = self._bft._chk(kmers)
+        bits = np.zeros((len(kmers) + 7) // 8, dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_group_query_presence(self._g, kmers.ctypes.data, len(kmers), bits.ctypes.data))
+        return bits
+
+    def query_color_rows(self, kmers):
+        kmers = self._bft._chk(kmers)
+        n = len(kmers)
+        rowbytes = (self._bft.info()["genomes"] + 7) // 8
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        rows = np.zeros((n, rowbytes), dtype=np.uint8)
+        _lib.check(self._lib.bft_gpu_group_query_color_rows(self._g, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
+        return bits, rows
+
+    def query_branching(self, kmers, with_counts=False):
+        kmers = self._bft._chk(kmers)
+        n = len(kmers)
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        counts = np.zeros(n, dtype=np.uint8) if with_counts else None
+        _lib.check(self._lib.bft_gpu_group_query_branching(self._g, kmers.ctypes.data, n, bits.ctypes.data, counts.ctypes.data if with_counts else None))
+        return (bits, counts) if with_counts else bits
+
+
+def shard(n, parts, i):
+    """bft_gpu_group_shard: the contiguous 64-aligned slice [begin, end) of an n-query batch for part i of `parts`"""
+    a, b = C.c_uint64(), C.c_uint64()
+    _lib.check(_lib.load().bft_gpu_group_shard(n, parts, i, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def create_cdbg(k, device=0):
     """create_cdbg(k, treshold_compression) (include/bft.h:62)."""
     return BFT(k, device)

@@ -86,12 +86,34 @@ static batch read_kmer_file(const char* path, int k, int binary) {
     return b;
 }
 
+/* BFT_GPU_DEVICES="0,1,2,...": the -query_kmers / -query_branching batches are sharded over these GPUs of the node, the index replicated
+ * on each (bft_gpu_group_*; the reference's loops, src/file_io.c:651-895 and :897-1020, have one BFT_Root).  Unset: the one GPU of `h`. */
+static bft_gpu_group* group_from_env(bft_gpu* h) {
+    const char* e = getenv("BFT_GPU_DEVICES");
+    if (!e || !*e) return NULL;
+    int devs[64], n = 0;
+    for (const char* p = e; *p && n < 64;) {
+        devs[n++] = atoi(p);
+        while (*p && *p != ',') p++;
+        if (*p == ',') p++;
+    }
+    if (n < 2 && !(n == 1 && devs[0] != 0)) return NULL;
+    bft_gpu_group* g = NULL;
+    ck(bft_gpu_group_create(h, 0, devs, n, &g));
+    return g;
+}
+
 static void query_kmers(bft_gpu* h, const char* path, int k, int binary, uint32_t nb_genomes, char** names) {
     batch b = read_kmer_file(path, k, binary);
     const uint32_t rowbytes = (nb_genomes + 7) / 8;
     uint8_t* present = calloc((b.n_lines + 7) / 8 + 1, 1);
     uint8_t* rows = calloc(b.n_lines ? b.n_lines : 1, rowbytes ? rowbytes : 1);
-    ck(bft_gpu_query_color_rows(h, b.kmers, b.n_lines, present, rows)); /* invalid lines are all-zero k-mers: masked below */
+    bft_gpu_group* grp = group_from_env(h);
+    if (grp) {
+        ck(bft_gpu_group_query_color_rows(grp, b.kmers, b.n_lines, present, rows));
+        bft_gpu_group_free(grp);
+    } else
+        ck(bft_gpu_query_color_rows(h, b.kmers, b.n_lines, present, rows)); /* invalid lines are all-zero k-mers: masked below */
     char* tmp = strdup(path);
     char* base = basename(tmp);
     char* outname = malloc(strlen(base) + 5);
@@ -129,7 +151,12 @@ static void query_branching(bft_gpu* h, const char* path, int k, int binary) {
         if (b.valid[i]) { if (m != i) memmove(b.kmers + m * nb, b.kmers + i * nb, (size_t)nb); m++; }
     uint8_t* bits = calloc((m + 7) / 8 + 1, 1);
     printf("\nQuerying BFT for branching k-mers in %s\n\n", path);
-    ck(bft_gpu_query_branching(h, b.kmers, m, bits, NULL));
+    bft_gpu_group* grp = group_from_env(h);
+    if (grp) {
+        ck(bft_gpu_group_query_branching(grp, b.kmers, m, bits, NULL));
+        bft_gpu_group_free(grp);
+    } else
+        ck(bft_gpu_query_branching(h, b.kmers, m, bits, NULL));
     int count = 0;
     for (uint64_t i = 0; i < m; i++) count += (bits[i >> 3] >> (i & 7)) & 1;
     printf("\nNb branching k-mers = %d\n", count);

@@ -114,7 +114,6 @@ __device__ __forceinline__ void seq_walk_body(const BftImage& im, const uint64_t
     __syncthreads();
     const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
     const uint64_t P = pos_off[n_seqs];
-    const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nblk = (P + BLOCK - 1) / BLOCK;
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
         const uint64_t p = blk * BLOCK + threadIdx.x;

@@ -216,6 +216,23 @@ int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes);
 int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* hip_stream);
 int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int device, bft_gpu** out);
 
+/* One index on several GPUs of ONE process (the loops of src/file_io.c:651-895 and :897-1020 can only ever use one
+ * BFT_Root).  bft_gpu_group_create: `src` (a handle on GPU src_device; built if need be) is replicated into the HBM of every device of
+ * devices[0..n_devices) -- image blob packed on the source GPU, one peer copy per replica, unpacked there; the first slot naming
+ * src_device is served by src itself, further slots (the same device may appear twice) get copies.  The group owns its replicas, not src.
+ * The *_query_* calls cut a host batch into contiguous slices whose starts are multiples of 64 k-mers (bft_gpu_group_shard gives slice i
+ * of `parts`: the same rule bloomfiltertrie_amd/dist.py applies across processes), run the single-GPU entry point on every slice from
+ * one host thread per device, and return when all have answered into the caller's buffers -- same layouts as the single-GPU calls.
+ * Insertion stays single-GPU: insert into src, then create the group again. */
+typedef struct bft_gpu_group bft_gpu_group;
+int bft_gpu_group_shard(uint64_t n, int parts, int i, uint64_t* begin, uint64_t* end);
+int bft_gpu_group_create(bft_gpu* src, int src_device, const int* devices, int n_devices, bft_gpu_group** out);
+void bft_gpu_group_free(bft_gpu_group* g);
+int bft_gpu_group_size(bft_gpu_group* g);
+int bft_gpu_group_query_presence(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits);
+int bft_gpu_group_query_color_rows(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits, uint8_t* rows);
+int bft_gpu_group_query_branching(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* branching_bits, uint8_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,3 +251,23 @@ def test_host_index_dense_remainder_groups(hostlib):
         hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits.ctypes.data, None)
         assert (S.from_bits(bits, len(q)) == S.member(q, km)).all()
         hostlib.bft_hosttest_free(h)
+
+
+def test_group_shard_rule_through_the_c_symbol(built):
+    """bft_gpu_group_shard (no GPU involved): slices are contiguous, cover [0, n), start on multiples of 64 k-mers (whole bytes of the
+    presence bitmap) and are the ones dist.shard_bounds gives the ranks of a torch.distributed group."""
+    from bloomfiltertrie_amd import bft as B
+    from bloomfiltertrie_amd.dist import shard_bounds
+    for n in (0, 1, 63, 64, 65, 1000, 12345, 10 ** 9, 10 ** 9 + 7):
+        for parts in (1, 2, 3, 8):
+            cover = 0
+            for i in range(parts):
+                a, b = B.shard(n, parts, i)
+                assert a == cover and a <= b <= n and (a % 64 == 0 or a == n)
+                assert (a, b) == shard_bounds(n, parts, i)[:2]
+                cover = b
+            assert cover == n
+    with pytest.raises(Exception):
+        B.shard(10, 0, 0)
+    with pytest.raises(Exception):
+        B.shard(10, 2, 2)

@@ -661,3 +661,35 @@ def test_queries_on_two_caller_streams_around_a_rebuild():
         assert (S.from_bits(outs[i].cpu().numpy(), n).astype(bool) == first).all(), i
     for i in (4, 5):
         assert (S.from_bits(outs[i].cpu().numpy(), n).astype(bool) == both).all(), i
+
+
+@pytest.mark.parametrize("k,devices", [(27, [0]), (27, [0, 0]), (63, [0, 0, 0]), (31, [0, 0])])
+def test_device_group_answers_like_one_handle(k, devices):
+    """bft_gpu_group_*: the index replicated per device slot (the blob packed, copied, unpacked; the same device may serve several slots,
+    which is how a one-GPU box exercises replication and sharding), a host batch cut into 64-aligned slices, one host thread per slot:
+    presence, colour rows and branching equal the single handle's, for ragged sizes around the slice boundaries."""
+    from bloomfiltertrie_amd import BFT, BFTGroup
+    anc = S.random_genome(120000, k)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 30 + g), k)) for g in range(5)]
+    t = BFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+    grp = BFTGroup(t, devices)
+    assert grp.size() == len(devices)
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(k)
+    base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])
+    for n in (1, 63, 64, 65, 129, 100_003, 400_000):
+        q = np.ascontiguousarray(base[rng.integers(0, len(base), n)])
+        assert (grp.query_presence(q) == t.query_presence(q)).all(), n
+        gb, grows = grp.query_color_rows(q)
+        tb, trows = t.query_color_rows(q)
+        assert (gb == tb).all() and (grows == trows).all(), n
+        b1, c1 = grp.query_branching(q[:50_000], with_counts=True)
+        b2, c2 = t.query_branching(q[:50_000], with_counts=True)
+        assert (b1 == b2).all() and (c1 == c2).all(), n
+    assert (S.from_bits(grp.query_presence(base), len(base)) == S.member(base, allk)).all()
+    grp.close()
+    with pytest.raises(Exception):
+        BFTGroup(t, [99])
+    t.close()
