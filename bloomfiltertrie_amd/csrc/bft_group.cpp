@@ -56,8 +56,12 @@ static int replicate(bft_gpu* src, int src_dev, int dst_dev, bft_gpu** out) {
 extern "C" int bft_gpu_group_create(bft_gpu* src, int src_device, const int* devices, int n_devices, bft_gpu_group** out) {
     if (!src || !devices || n_devices <= 0 || !out) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     *out = nullptr;
-    int prev = -1;
+    int prev = -1, ndev = 0;
     (void)hipGetDevice(&prev);
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= ndev) return bft_fail(BFT_GPU_E_ARG, "bad device index in the group");
+    if (src_device < 0 || src_device >= ndev) return bft_fail(BFT_GPU_E_ARG, "bad source device index");
     uint64_t info[16] = {0};
     CK(bft_gpu_build(src));
     CK(bft_gpu_info(src, info, 16));
@@ -80,6 +84,7 @@ extern "C" int bft_gpu_group_create(bft_gpu* src, int src_device, const int* dev
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (rc != 0) {
+        (void)hipGetLastError();  // (a failed runtime call leaves its error behind: the next launch check must not find it)
         const std::string keep = bft_gpu_last_error();
         for (size_t i = 0; i < g->members.size(); i++)
             if (g->owned[i]) bft_gpu_free(g->members[i]);
