@@ -57,6 +57,13 @@ def test_build_load_query_csv(oracle_mod, tmp_path):
     assert f"Nb k-mers present = {int(pres.sum())}" in out.stdout
     _, _, nbr = o.query_branching(q)
     assert f"Nb branching k-mers = {nbr}" in out.stdout
+    # the same command with the batches sharded over a device group (BFT_GPU_DEVICES; two slots on the one GPU of this box): same bytes
+    os.rename(tmp_path / "queries.csv", tmp_path / "queries_one.csv")
+    out2 = subprocess.run([CLI, "load", "out.bft", "-query_kmers", "kmers", "qlist.txt", "-query_branching", "kmers", "qlist.txt"],
+                          capture_output=True, text=True, env=dict(os.environ, BFT_GPU_DEVICES="0,0"))
+    assert out2.returncode == 0, out2.stderr
+    assert (tmp_path / "queries.csv").read_bytes() == (tmp_path / "queries_one.csv").read_bytes()
+    assert f"Nb k-mers present = {int(pres.sum())}" in out2.stdout and f"Nb branching k-mers = {nbr}" in out2.stdout
 
 
 def test_kmers_comp_input_and_bad_k(tmp_path):
