@@ -208,7 +208,7 @@ struct bft_gpu {
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
     DevBuf d_rdir, d_rstart;      // derived: root direct table (BFT_RDIR_*, k_root_direct) and root range table (BFT_RSTART_*), optional
     DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
-    bool opt_node_hash = true;    // "node_hash"
+    int opt_node_hash = 1;        // "node_hash": 1 = derived when the image has no k-mer hash (the walk then answers every query), 2 = always, 0 = never
     uint64_t nph_inserted = 0, nph_dropped = 0;
     DevBuf d_kh;                  // derived: k-mer hash (BFT_KH_*, k_kh_insert), optional
     uint64_t kh_lines = 0;
@@ -729,7 +729,7 @@ static void derive_node_hash(bft_gpu* h) {
     h->im.nph_no_uc = 0;
     h->nph_inserted = h->nph_dropped = 0;
     const uint64_t n_nodes = h->idx_sizes[0] / sizeof(BftNode);
-    if (!h->opt_node_hash || n_nodes <= 1 || h->info[6] == 0) {
+    if (!h->opt_node_hash || (h->opt_node_hash == 1 && h->im.kh != nullptr) || n_nodes <= 1 || h->info[6] == 0) {
         h->d_nph.release();
         return;
     }
@@ -868,8 +868,8 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     h->n_fent = n_fent;
     point_image(h, nb_genomes);
     derive_root_direct(h);
-    derive_node_hash(h);
     derive_kmer_hash(h);
+    derive_node_hash(h);
     default_launch_shape(h);
     return 0;
 }
@@ -1183,8 +1183,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[3] = 0;
     h->built = true;
     derive_root_direct(h);
-    derive_node_hash(h);
     derive_kmer_hash(h);
+    derive_node_hash(h);
     default_launch_shape(h);
     I[12] = image_bytes(h);
     h->build_ms[4] = now_ms() - t3;
@@ -2085,7 +2085,8 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         h->opt_probe = (int)value;
         h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
     } else if (nm == "node_hash") {  // 1 (default): levels below the root through the node prefix hash; 0: through the containers
-        h->opt_node_hash = value != 0;
+        if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "node_hash must be 0, 1 or 2");
+        h->opt_node_hash = (int)value;
         if (h->built) {
             ENTER(h);
             CK(wait_foreign_stream(h));
@@ -2104,6 +2105,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
             derive_kmer_hash(h);
+            derive_node_hash(h);  // (by default the node prefix hash exists exactly when the k-mer hash does not)
             h->info[12] = image_bytes(h);
         }
     } else if (nm == "root_direct") {  // 2 (default): root level through the derived range + direct tables; 1: direct table only; 0: containers

@@ -156,8 +156,9 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
- *   "query_grid_mult" (grid = resident workgroups x value), "node_hash" (1, default: the prefix entries of the nodes below the root also go into
- *   one hash table keyed by (node, prefix) -- one cache line per level of a deep trie instead of four; 0: containers only), "root_direct" (the root level
+ *   "query_grid_mult" (grid = resident workgroups x value), "node_hash" (the prefix entries of the nodes below the root also go into one hash table keyed
+ *   by (node, prefix) -- one cache line per level of a deep trie instead of four: 1, default = when the image has no k-mer hash, i.e. when the walk answers
+ *   every query; 2 = always; 0 = never), "root_direct" (the root level
  *   goes through tables derived from the containers: 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain
  *   suffix groups, backed by the 2 MiB table; 3, default = 2 unless most root prefixes are child Nodes; 0 = the containers), "flat_min" (CCs with at
  *   least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none), "tune" (1: measure residency, probe

@@ -1672,12 +1672,52 @@ static uint16_t rd_u16(rd_ctx *c) { uint16_t v = 0; rd(c, &v, 2); return v; }
 static uint32_t rd_u32(rd_ctx *c) { uint32_t v = 0; rd(c, &v, 4); return v; }
 static int32_t rd_i32(rd_ctx *c) { int32_t v = 0; rd(c, &v, 4); return v; }
 
-static uint32_t cs_from_annot(orc_bft *t, const uint8_t *annot, int size) {
+/* Loader only: annotation bytes -> colour set of the model.  The same few 10^6 byte strings label the 10^7..10^8 rows of a pan-genome
+ * file, so the decode + cs_add walk runs once per distinct string (exact: a hit compares the bytes). */
+typedef struct { uint64_t h; uint32_t cs; int len; uint8_t *bytes; } annot_memo;
+static annot_memo *g_memo = NULL;
+static size_t g_memo_cap = 0, g_memo_n = 0;
+static void memo_clear(void) {
+    for (size_t i = 0; i < g_memo_cap; i++) free(g_memo[i].bytes);
+    free(g_memo);
+    g_memo = NULL;
+    g_memo_cap = g_memo_n = 0;
+}
+static uint32_t cs_from_annot_slow(orc_bft *t, const uint8_t *annot, int size) {
     uint32_t ids[4096];
     int n = decode_any(annot, size, ids, 4096);
     uint32_t cs = 0;
     for (int a = 0; a < n && a < 4096; a++) cs = cs_add(t, cs, ids[a]);
     return cs;
+}
+static uint32_t cs_from_annot(orc_bft *t, const uint8_t *annot, int size) {
+    while (size > 1 && annot[size - 1] == 0) size--; /* rows are padded to the UC's width with zero bytes */
+    if (g_memo_n * 2 >= g_memo_cap) {
+        const size_t ncap = g_memo_cap ? g_memo_cap * 2 : (1u << 16);
+        annot_memo *nm = xcalloc(ncap, sizeof(annot_memo));
+        for (size_t i = 0; i < g_memo_cap; i++)
+            if (g_memo[i].bytes) {
+                size_t j = (size_t)g_memo[i].h & (ncap - 1);
+                while (nm[j].bytes) j = (j + 1) & (ncap - 1);
+                nm[j] = g_memo[i];
+            }
+        free(g_memo);
+        g_memo = nm;
+        g_memo_cap = ncap;
+    }
+    const uint64_t h = orc_xxh64(annot, (size_t)size, 0x5bd1e995u);
+    size_t j = (size_t)h & (g_memo_cap - 1);
+    while (g_memo[j].bytes) {
+        if (g_memo[j].h == h && g_memo[j].len == size && memcmp(g_memo[j].bytes, annot, (size_t)size) == 0) return g_memo[j].cs;
+        j = (j + 1) & (g_memo_cap - 1);
+    }
+    g_memo[j].h = h;
+    g_memo[j].len = size;
+    g_memo[j].bytes = xmalloc((size_t)size + 1);
+    memcpy(g_memo[j].bytes, annot, (size_t)size);
+    g_memo[j].cs = cs_from_annot_slow(t, annot, size);
+    g_memo_n++;
+    return g_memo[j].cs;
 }
 
 /* read_UC uncompressed branch (src/write_to_disk.c:383-531): returns rows (nbs + size_annot each).  Rows that own an
@@ -1852,6 +1892,7 @@ orc_bft *orc_load_bft(const char *path) {
         for (int q = 0; q < 7; q++) (void)rd_i32(&c);
     if (!c.err) load_node(&c, t, &t->root, k, NULL);
     fclose(c.f);
+    memo_clear();
     for (int e = 0; e < lcs; e++) free(celems[e].bytes);
     free(celems);
     g_comp = NULL;

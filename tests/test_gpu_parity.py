@@ -447,7 +447,7 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     assert tuned in (1.0, 2.0, 3.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
     # (node prefix hash, residency, grid multiplier, probe rows, root tables, k-mer hash on/off, its occupancy, measured launch shape)
-    for blk, wgs, mult, probe, rdir, kh, load, tune in [(1, 0, 1, 0, 1, 1, 50, 0), (0, 1, 1, 4, 0, 0, 50, 0), (1, 2, 1, 8, 2, 1, 80, 0), (1, 3, 1, 4, 0, 0, 50, 1),
+    for blk, wgs, mult, probe, rdir, kh, load, tune in [(1, 0, 1, 0, 1, 1, 50, 0), (0, 1, 1, 4, 0, 0, 50, 0), (2, 2, 1, 8, 2, 1, 80, 0), (1, 3, 1, 4, 0, 0, 50, 1),
                                                         (0, 1, 3, 8, 3, 1, 10, 0), (1, 2, 1, 0, 0, 0, 50, 0), (0, 3, 2, 8, 1, 1, 65, 1), (1, 3, 1, 0, 3, 0, 50, 0)]:
         t.set_option("kmer_hash_load", load)
         t.set_option("kmer_hash", kh)
