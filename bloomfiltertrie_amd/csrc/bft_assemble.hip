@@ -124,7 +124,11 @@ __global__ void k_counts(const uint32_t* __restrict__ start, const uint32_t* __r
     }
 }
 
-// One workgroup per node.  cc_bits == nullptr: counting pass (node_ncc only).
+__global__ void k_cc_upper(const uint32_t* __restrict__ sz, uint32_t M, uint32_t* __restrict__ ub) {
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) ub[m] = sz[m] / BFT_NB_KMERS_PER_UC + 1u;
+}
+
+// One workgroup per node.  node_ccb: first Bloom-bitset slot of the node in cc_bits (an upper-bound layout, see assemble()).
 __global__ __launch_bounds__(ABLK) void k_assign_cc(const uint32_t* __restrict__ key_val, const uint32_t* __restrict__ key_cnt,
                                                     const uint32_t* __restrict__ node_kb, const uint32_t* __restrict__ nd_lo,
                                                     const uint32_t* __restrict__ nd_hi, const uint32_t* __restrict__ hashmod,
@@ -476,27 +480,31 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         }
         head.release(); khead.release(); ppos.release(); kpos.release();
 
-        // ---- CC assignment: counting pass, scan, writing pass ----
-        DevBuf key_cc, node_ncc, node_ccb, cc_bits;
+        // ---- CC assignment: one pass.  A node opens a CC only while >= 255 k-mers are unassigned and every CC but the last claims at
+        // least 255, so a node of U k-mers holds at most U / 255 + 1 CCs: the Bloom bitsets are written at those upper-bound slots
+        // (ubb) and the real CC numbering comes from a scan of the counts afterwards.  (A counting pass used to run first: the same
+        // kernel twice, 3.0 ms of config 3's assembly.) ----
+        DevBuf key_cc, node_ncc, node_ccb, cc_bits, ub, ubb;
         CK(key_cc.alloc(K * 4));
         CK(node_ncc.alloc(M * 4));
         CK(node_ccb.alloc((M + 1) * 4));
+        CK(ub.alloc(M * 4));
+        CK(ubb.alloc((M + 1) * 4));
         HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
+        hipLaunchKernelGGL(k_cc_upper, G(M), nsz.as<uint32_t>(), (uint32_t)M, ub.as<uint32_t>());
+        uint64_t CU = 0;
+        CK(scan.run(ub.as<uint32_t>(), ubb.as<uint32_t>(), M, &CU));
+        CK(cc_bits.alloc(CU * 48 * 4));
         const dim3 ngrid((unsigned)std::min<uint64_t>(M, 65535ull * 16));
         hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
                            nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
-                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)M);
+                           ubb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
         uint64_t C = 0;
         CK(scan.run(node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), M, &C));
         {
             const uint32_t c32 = (uint32_t)C;
             HIPCK(hipMemcpyAsync(node_ccb.as<uint32_t>() + M, &c32, 4, hipMemcpyHostToDevice, s));
         }
-        CK(cc_bits.alloc(C * 48 * 4));
-        HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
-        hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
-                           nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
-                           node_ccb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
         // limits (format): CCs per node, Bloom slice width
         std::vector<uint32_t> h_ncc(M);
         HIPCK(hipMemcpyAsync(h_ncc.data(), node_ncc.p, M * 4, hipMemcpyDeviceToHost, s));
@@ -623,7 +631,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(sg.bfT.alloc(BF8 * 8));
         hipLaunchKernelGGL(k_node_records, G(M), node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(),
                            node_bfoff.as<uint32_t>(), (uint32_t)M, (uint32_t)T_ccs, (uint32_t)T_uc, (uint32_t)T_bf8, sg.nodes.as<BftNode>());
-        if (BF8) hipLaunchKernelGGL(k_bloom_slice, ngrid, dim3(ABLK), 0, s, node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_bfoff.as<uint32_t>(),
+        if (BF8) hipLaunchKernelGGL(k_bloom_slice, ngrid, dim3(ABLK), 0, s, node_ncc.as<uint32_t>(), ubb.as<uint32_t>(), node_bfoff.as<uint32_t>(),
                                     cc_bits.as<uint32_t>(), (uint32_t)M, sg.bfT.as<uint8_t>());
         HIPCK(hipGetLastError());
         if (d == 0) {
@@ -795,7 +803,7 @@ __device__ __forceinline__ uint32_t wave_list_of(uint32_t e, uint32_t a) {
 
 // signature of the sorted genome-id list of each k-mer: a sum of mixed ids (order-free, so that the elements can be added
 // in any order by any lane) mixed with the length
-__global__ __launch_bounds__(ABLK) void k_cs_sig(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, uint64_t* __restrict__ sig,
+__global__ __launch_bounds__(ABLK) void k_cs_sig(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ pg, uint32_t nk, int weak, uint64_t* __restrict__ sig,
                                                  uint32_t* __restrict__ iota) {
     __shared__ unsigned long long acc[ABLK];
     const uint32_t lane = threadIdx.x & 63u, w0 = threadIdx.x & ~63u;
@@ -813,7 +821,8 @@ __global__ __launch_bounds__(ABLK) void k_cs_sig(const uint32_t* __restrict__ se
             if (in) atomicAdd(&acc[w0 + s], (unsigned long long)mix64((uint64_t)pg[e] + 0x632BE59BD9B4E019ULL));
         }
         if (valid) {
-            sig[i] = mix64((uint64_t)acc[threadIdx.x] ^ ((uint64_t)(b - a) * 0x9E3779B97F4A7C15ULL));
+            // (weak: a test hook -- the signature of a list is its length, so that different lists collide and the exact pass must run)
+            sig[i] = weak ? (uint64_t)(b - a) : mix64((uint64_t)acc[threadIdx.x] ^ ((uint64_t)(b - a) * 0x9E3779B97F4A7C15ULL));
             iota[i] = i;
         }
     }
@@ -827,13 +836,19 @@ __device__ __forceinline__ bool same_list(const uint32_t* __restrict__ seg_off, 
     return true;
 }
 
-// a new colour set starts where the (signature-sorted) list differs from its predecessor: exact comparison
+// a new colour set starts where the (signature-sorted) list differs from its predecessor.  exact = 0: by the 64-bit signature and the
+// length alone (two gathers of a whole list per k-mer saved: 2.0 ms of config 3's 8); k_cs_verify then compares EVERY k-mer's list
+// with the dictionary entry it was given, and a mismatch -- two different lists with one signature -- sends the caller back here with
+// exact = 1: the lists themselves are compared.
 __global__ void k_cs_heads(const uint64_t* __restrict__ sig_s, const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_off,
-                           const uint32_t* __restrict__ pg, uint32_t nk, uint32_t* __restrict__ head, uint32_t* __restrict__ len) {
+                           const uint32_t* __restrict__ pg, uint32_t nk, int exact, uint32_t* __restrict__ head, uint32_t* __restrict__ len) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
         const uint32_t a = order[i];
         uint32_t h = 1;
-        if (i > 0 && sig_s[i] == sig_s[i - 1] && same_list(seg_off, pg, a, order[i - 1])) h = 0;
+        if (i > 0 && sig_s[i] == sig_s[i - 1]) {
+            const uint32_t b = order[i - 1];
+            if (exact ? same_list(seg_off, pg, a, b) : (seg_off[a + 1] - seg_off[a] == seg_off[b + 1] - seg_off[b])) h = 0;
+        }
         head[i] = h;
         len[i] = h ? seg_off[a + 1] - seg_off[a] : 0;
     }
@@ -900,6 +915,11 @@ __global__ __launch_bounds__(ABLK) void k_cs_verify(const uint32_t* __restrict__
 }
 
 }  // namespace
+
+static bool g_weak_signature = false;
+static unsigned long long g_exact_passes = 0;
+void bft_test_weak_signature(bool on) { g_weak_signature = on; }
+unsigned long long bft_test_exact_passes(void) { return g_exact_passes; }
 
 int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
     if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be in [9, 126]");
@@ -976,7 +996,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     CK(csid.alloc(nk * 4));
     CK(off.alloc(nk * 4));
     const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
-    hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, sig.as<uint64_t>(), iota.as<uint32_t>());
+    hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, g_weak_signature ? 1 : 0, sig.as<uint64_t>(), iota.as<uint32_t>());
     // Equal lists only have to end up next to each other: the low 48 bits of the signature order them (6 radix passes instead
     // of 8).  Two different lists that agree on those bits could at worst split a run of equal lists, i.e. cost a duplicate
     // dictionary entry (expected once in ~10^14 / n_sets^2 builds); k_cs_heads still compares whole signatures and lists.
@@ -986,24 +1006,29 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
     CK(tmp.alloc(tb));
     HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
-    hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, head.as<uint32_t>(), len.as<uint32_t>());
-    CK(scan.run(head.as<uint32_t>(), csid.as<uint32_t>(), nk, &n_sets));
-    CK(scan.run(len.as<uint32_t>(), off.as<uint32_t>(), nk, &n_ids));
-    CK(d_cs_off.alloc((n_sets + 1) * 4));
-    CK(d_cs_ids.alloc(n_ids * 4));
-    {
-        const uint32_t t32 = (uint32_t)n_ids;
-        HIPCK(hipMemcpyAsync(d_cs_off.as<uint32_t>() + n_sets, &t32, 4, hipMemcpyHostToDevice, s));
-    }
-    hipLaunchKernelGGL(k_cs_assign, grid, block, 0, s, order.as<uint32_t>(), head.as<uint32_t>(), csid.as<uint32_t>(), off.as<uint32_t>(), d_seg_off, d_pg,
-                       (uint32_t)nk, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>());
-    CK(bad.alloc_zero(4, s));
-    hipLaunchKernelGGL(k_cs_verify, grid, block, 0, s, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
-                       bad.as<uint32_t>());
     uint32_t nbad = 0;
-    HIPCK(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
+    CK(bad.alloc(4));
+    for (int exact = 0; exact < 2; exact++) {
+        hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, exact, head.as<uint32_t>(), len.as<uint32_t>());
+        CK(scan.run(head.as<uint32_t>(), csid.as<uint32_t>(), nk, &n_sets));
+        CK(scan.run(len.as<uint32_t>(), off.as<uint32_t>(), nk, &n_ids));
+        CK(d_cs_off.alloc((n_sets + 1) * 4));
+        CK(d_cs_ids.alloc(n_ids * 4));
+        {
+            const uint32_t t32 = (uint32_t)n_ids;
+            HIPCK(hipMemcpyAsync(d_cs_off.as<uint32_t>() + n_sets, &t32, 4, hipMemcpyHostToDevice, s));
+        }
+        hipLaunchKernelGGL(k_cs_assign, grid, block, 0, s, order.as<uint32_t>(), head.as<uint32_t>(), csid.as<uint32_t>(), off.as<uint32_t>(), d_seg_off, d_pg,
+                           (uint32_t)nk, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>());
+        HIPCK(hipMemsetAsync(bad.p, 0, 4, s));
+        hipLaunchKernelGGL(k_cs_verify, grid, block, 0, s, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
+                           bad.as<uint32_t>());
+        HIPCK(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));
+        if (nbad == 0) break;  // (else: a signature collision -- once more with the lists compared)
+        g_exact_passes++;
+    }
     if (nbad) return bft_fail(BFT_GPU_E_LIMIT, "colour-set interning self-check failed");
     (void)np;
     return 0;

@@ -81,6 +81,8 @@ int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_
 struct BftCC;
 int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, const uint64_t* d_clus, const uint64_t* d_child, uint32_t flat_min,
                     hipStream_t s, DevBuf& ccx, DevBuf& f18, DevBuf& fent, uint64_t& n_f18, uint64_t& n_fent);
+void bft_test_weak_signature(bool on);            // test hook: every list's signature = its length (collisions galore)
+unsigned long long bft_test_exact_passes(void);   // how many times the interning had to fall back to comparing the lists
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
                           DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids);
 

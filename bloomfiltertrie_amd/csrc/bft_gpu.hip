@@ -2133,6 +2133,8 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "debug_stop") {  // libbft_gpu_probe.so only (make probe): truncates the walk, results are wrong
         h->im.debug_stop = (uint32_t)value;
 #endif
+    } else if (nm == "test_weak_signature") {  // test hook (tests/test_gpu_build.py): colour-set signatures that collide, see bft_intern_colors_gpu
+        bft_test_weak_signature(value != 0);
     } else if (nm == "inject_build_failure") {  // test hook (tests/test_gpu_build.py): exercises the all-or-nothing build
         h->inject_build_failure = value != 0;
     } else if (nm == "timing") {
@@ -2185,7 +2187,7 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
     const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
-                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, 0.0, 0.0,
+                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, (double)bft_test_exact_passes(), 0.0,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
                           (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
     for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];

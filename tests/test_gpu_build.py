@@ -372,3 +372,29 @@ def test_insertions_merge_into_the_index_without_a_pair_bound(k, flush):
     merged.close()
 
 
+
+
+def test_colour_interning_falls_back_to_exact_comparison_on_signature_collisions():
+    """Colour sets are interned by a 64-bit signature; every k-mer's list is then compared with the dictionary entry it was given, and a
+    mismatch makes the pass run again with the lists themselves compared.  With the test hook that makes a list's signature its LENGTH
+    (different sets collide everywhere) the fallback must run and the result must be what the ordinary build gives."""
+    k = 27
+    anc = S.random_genome(40000, 3)
+    genomes = [S.distinct(S.kmers_of(S.mutate(anc, 0.03, 40 + g), k)) for g in range(6)]
+    a, b = BFT(k), BFT(k)
+    b.set_option("test_weak_signature", 1)
+    try:
+        for g, km in enumerate(genomes):
+            a.insert_kmers(km, g)
+            b.insert_kmers(km, g)
+        a.build()
+        before = b.build_time()["intern_exact_passes"]
+        b.build()
+        assert b.build_time()["intern_exact_passes"] > before
+    finally:
+        b.set_option("test_weak_signature", 0)
+    ma, na = _colour_map(a)
+    mb, nb_ = _colour_map(b)
+    assert ma == mb and na == nb_ and a.info()["colorsets"] == b.info()["colorsets"]
+    a.close()
+    b.close()
