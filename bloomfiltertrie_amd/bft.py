@@ -74,7 +74,7 @@ class BFT:
         return int(n.value)
 
     def image_pack(self, d_blob_ptr, cap, stream=None):
-        """Copy the built index (containers, k-mer table, colour sets, pair store, genome names) into one
+        """Copy the built index (containers, k-mer table, colour sets, genome names) into one
         contiguous device buffer -- the payload of the broadcast that replicates the trie on the other GPUs."""
         _lib.check(self._lib.bft_gpu_image_pack(self._h, d_blob_ptr, cap, stream))
 

@@ -225,7 +225,7 @@ struct bft_gpu {
     bool has_cs_bm = false, cs_bm_tried = false;
     bool opt_no_composite = false;  // test hook ("build_composite" 0): the general sort + flag-array path also for ordered one-word keys
     int opt_msd = 1;                // "build_msd": root-prefix buckets + bucket sorts for 2^20 pairs and more (1), always (2: test hook), never (0)
-    uint32_t msd_max_bucket = 0;    // largest root-prefix bucket of the last build's sort (0: not bucketed)
+    uint32_t msd_max_bucket = 0;    // largest root-prefix bucket of the last build's sort (0: one device-wide sort)
     BftImage im;
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
@@ -885,10 +885,10 @@ static int host_colorsets(bft_gpu* h) {
     return 0;
 }
 
-// One-word keys, sorted, with their genome ids (GT wide): flags on the fly, one 64-bit scan, scatter into the pair store, the
+// One-word keys, sorted, with their genome ids (GT wide): flags on the fly, one 64-bit scan, scatter into the genome-id lists, the
 // distinct-k-mer table and the segment offsets (bft_kernels_build.h).
 template <class GT>
-static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npk, DevBuf& npg, uint64_t& nk,
+static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npg, uint64_t& nk,
                      uint64_t& np) {
     DevBuf tmp, pos;
     CK(pos.alloc(total * 8));
@@ -924,7 +924,7 @@ static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t tota
 }
 // Stable sort of ordered one-word keys with their ids narrowed to GT (values through a transform iterator over the log), then dedupe_w1.
 template <class GT>
-static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npk, DevBuf& npg,
+static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npg,
                                  uint64_t& nk, uint64_t& np) {
     DevBuf sk, sg, tmp;
     CK(sk.alloc(total * 8));
@@ -937,7 +937,7 @@ static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32
     HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
     HIPCK(hipGetLastError());
     tmp.release();
-    return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npk, npg, nk, np);
+    return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npg, nk, np);
 }
 
 extern "C" int bft_gpu_build(bft_gpu* h) {
@@ -949,7 +949,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     const uint64_t total = h->log_n;  // the run: what was inserted since the last build
     double t0 = now_ms();
 
-    DevBuf tk, seg_off, npk, npg;
+    DevBuf tk, seg_off, npg;
     uint64_t nk = 0, np = 0;
     if (total > 0) {
         // 1. the pairs to sort: the insertion log
@@ -1027,8 +1027,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         } else if (W == 1 && h->log_g_sorted && h->max_gid_seen < 65536 && !h->opt_no_composite) {
             // 2n + 3'. ordered one-word keys whose composite does not fit (k = 31 with more than a few genomes): key + value sort with the
             // ids narrowed to one or two bytes (the values are a third of the sort's traffic at four)
-            if (h->max_gid_seen < 256) CK(sort_dedupe_w1_narrow<uint8_t>(h, src_k, src_g, total, tk, seg_off, npk, npg, nk, np));
-            else CK(sort_dedupe_w1_narrow<uint16_t>(h, src_k, src_g, total, tk, seg_off, npk, npg, nk, np));
+            if (h->max_gid_seen < 256) CK(sort_dedupe_w1_narrow<uint8_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
+            else CK(sort_dedupe_w1_narrow<uint16_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
             ck.release();
             cg.release();
         } else {
@@ -1041,7 +1041,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         // (the insertion log stays until the new image is committed below: a failed build loses nothing)
         if (W == 1) {
             // 3'. one-word keys: flags on the fly, one 64-bit scan (as on the composite path)
-            CK(dedupe_w1<uint32_t>(h, sk.as<uint64_t>(), sg.as<uint32_t>(), total, tk, seg_off, npk, npg, nk, np));
+            CK(dedupe_w1<uint32_t>(h, sk.as<uint64_t>(), sg.as<uint32_t>(), total, tk, seg_off, npg, nk, np));
         } else {
         // 3. flags, scans, compaction
         DevBuf head, keep, posK, posP, tmp;

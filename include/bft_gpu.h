@@ -62,7 +62,9 @@ int bft_gpu_genome_name(bft_gpu* h, uint32_t id_genome, char* out, uint32_t cap)
 
 /* insertKmers(root, array_kmers, nb_kmers, id_genome, size_id_genome) (include/insertNode.h:26,
  * src/insertNode.c:18-36).  The batch is converted on the GPU and appended to a device-side log;
- * the trie image is (re)built in bulk by bft_gpu_build (or lazily by the first query).
+ * the log is merged into the index by bft_gpu_build (or lazily by the first query).  No bound on the number of (k-mer, genome)
+ * pairs an index holds (the reference has none): the log is merged on its own before it reaches 2^30 pairs ("flush_pairs"), a
+ * larger batch is taken in pieces.  Limits that remain: < 2^31 distinct k-mers, < 2^32 genome ids in the colour-set dictionary.
  * `kmers` is a HOST pointer; the _dev variant takes a DEVICE pointer to the same layout. */
 int bft_gpu_insert_kmers(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint32_t id_genome);
 int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, uint32_t id_genome);
@@ -72,10 +74,11 @@ int bft_gpu_insert_kmers_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers,
  * round trip per call. */
 int bft_gpu_insert_kmers_dev_async(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, uint32_t id_genome, void* hip_stream);
 
-/* Bulk construction of the device image from everything inserted so far: GPU radix sort +
- * de-duplication of (k-mer, genome) pairs, colour-set interning, container assembly.
- * Replaces the per-k-mer work of insertKmer_Node / insertSP_CC / transform2CC
- * (src/insertNode.c:38-423, src/CC.c:40-1474) with the invariants of SURVEY.md A.7. */
+/* Bulk construction: what was inserted since the last build is sorted and de-duplicated on the GPU (root-prefix buckets, bucket
+ * sorts in LDS), its colour sets interned, and that run is merged into the index (k-mers by position, colour sets by union: the index
+ * itself -- sorted k-mers, colour set per k-mer, dictionary -- is the only store); then the containers are assembled level by level.
+ * Replaces the per-k-mer work of insertKmer_Node / insertSP_CC / transform2CC / modify_annotations
+ * (src/insertNode.c:38-423, src/CC.c:40-1474, src/retrieveAnnotation.c:232-314) with the invariants of SURVEY.md A.7. */
 int bft_gpu_build(bft_gpu* h);
 
 /* The loop of src/file_io.c:726-768 over isKmerPresent (include/presenceNode.h:57,
@@ -143,8 +146,8 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Bytes resident in HBM per part of the handle (the walk of src/printMemory.c:255 reports the reference's bytes per container kind):
  * out[0]=sorted k-mer table tk, [1]=colour-set id per k-mer, [2]=colour-set dictionary, [3]=containers (nodes, Bloom blocks, CC headers, filter2
  * words, cluster table, prefix entries, node UCs), [4]=flat form of the big CCs, [5]=root tables, [6]=node prefix hash, [7]=k-mer hash,
- * [8]=bitmap form of the dictionary (derived by the first colour-row query), [9]=hash table (hash_v % 1504), [10]=sorted (k-mer, genome) pair store kept
- * for later insertions (not counted in out[12] of bft_gpu_info), [11]=pending insertion log. */
+ * [8]=bitmap form of the dictionary (derived by the first colour-row query), [9]=hash table (hash_v % 1504), [10]=0 (rounds 1-2 kept a sorted
+ * (k-mer, genome) pair store for later insertions; the index is its own store now), [11]=pending insertion log. */
 int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
 
 /* Options.
@@ -165,8 +168,10 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   mode and root tables of the walk on the current image with a batch drawn from the index -- the only call that times anything; it synchronises;
  *   nothing is ever tuned implicitly by a build or a query).
  * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending and fit the key's spare low bits are sorted as one 8-byte composite
- *   array; 0: the general key + value sort -- same image either way, a test hook), "reserve_pairs" (room in the insertion log for this many
- *   pending (k-mer, genome) pairs, so that a series of insert calls never re-allocates it).
+ *   array; 0: the general key + value sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
+ *   device-wide sort; 2: buckets at any size -- same image, test hooks), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
+ *   pairs, so that a series of insert calls never re-allocates it), "flush_pairs" (the log is merged into the index before it holds this many pairs:
+ *   2^30 by default, 1024..2^30).
  * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
