@@ -79,6 +79,8 @@ size_t pool_max_bytes() {
     return v;
 }
 constexpr size_t POOL_MAX_BLOCKS = 256;
+double g_malloc_ms = 0;          // time spent in hipMalloc by this process (diagnostic: bft_gpu_build_time)
+uint64_t g_malloc_calls = 0;
 thread_local int t_pool_device = -1;
 thread_local hipStream_t t_pool_stream = nullptr;
 
@@ -127,7 +129,10 @@ int bft_pool_alloc(void** p, size_t n, size_t* cap) {
         *cap = take.cap;
         return 0;
     }
+    const double t_m0 = now_ms();
     hipError_t e = hipMalloc(p, n);
+    g_malloc_ms += now_ms() - t_m0;
+    g_malloc_calls++;
     if (e != hipSuccess) {
         // out of memory with blocks parked in the cache: give them back and retry once
         std::vector<PoolBlock> all;
@@ -2187,7 +2192,7 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
     const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
-                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, (double)bft_test_exact_passes(), 0.0,
+                          h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, (double)bft_test_exact_passes(), g_malloc_ms,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
                           (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
     for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
             uint64_t x[W], t[W];
             load_x<W>(packed, i, B, end_aligned, x);
             bft_tform_from_x<W>(x, im.k, t);
-            present = bft_kh_lookup<W>(im.kh, im.kh_lines, t, out32 ? &val : nullptr);
+            uint64_t at = 0;
+            present = bft_kh_find<W>(im.kh, im.kh_lines, t, at);
+            if (present && out32) val = reinterpret_cast<const uint32_t*>(im.kh)[at];
         }
         const uint64_t mask = __ballot(present);
         const uint64_t q0 = i & ~63ull;
@@ -59,7 +61,8 @@ __device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*ca
             free_slot = free_slot || key[v][s][0] == BFT_KH_EMPTY;
         }
         if (!hit && !free_slot) {  // full line without the key: the general lookup walks on from the home line
-            hit = bft_kh_lookup<W>(im.kh, im.kh_lines, cand[v], nullptr);
+            uint64_t at = 0;
+            hit = bft_kh_find<W>(im.kh, im.kh_lines, cand[v], at);
         }
         count += hit;
     }

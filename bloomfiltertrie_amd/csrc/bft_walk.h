@@ -334,11 +334,11 @@ BFT_HD void bft_kh_load_keys(const uint64_t* line, uint64_t (*key)[W]) {
 #pragma unroll
     for (uint32_t s = 0; s < S; s++) bft_load_row<W>(line + s * W, key[s]);
 }
-// Lookup: true when t is stored; *val (when asked for: val != NULL) = its value, the colour-set id -- a second load into the same
-// line, issued only then (a presence query that fetched it anyway made 1.71 L2 requests per k-mer instead of 1.25).  Lines from the
-// home line on: the key, or a free slot, ends it.
+// Lookup: true when t is stored; value_at = where its value (the colour-set id) sits, as an index into the table seen as u32 words --
+// the caller reads it only if it wants it (a second load into the same line; a presence query that fetched it anyway made 1.71 L2
+// requests per k-mer instead of 1.25).  Lines from the home line on: the key, or a free slot, ends it.
 template <int W>
-BFT_HD bool bft_kh_lookup(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t* val) {
+BFT_HD bool bft_kh_find(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint64_t& value_at) {
     constexpr uint32_t S = BFT_KH_SLOTS(W);
     uint64_t ln = bft_kh_home<W>(t, n_lines);
     for (;;) {
@@ -353,12 +353,19 @@ BFT_HD bool bft_kh_lookup(const uint64_t* kh, uint64_t n_lines, const uint64_t* 
             free_slot = free_slot || key[s][0] == BFT_KH_EMPTY;
         }
         if (at >= 0) {
-            if (val) *val = reinterpret_cast<const uint32_t*>(line + S * W)[at];
+            value_at = (ln * BFT_KH_LINE_WORDS + S * W) * 2 + (uint64_t)at;
             return true;
         }
         if (free_slot) return false;  // t would have been put here
         ln = ln + 1 == n_lines ? 0 : ln + 1;
     }
+}
+template <int W>
+BFT_HD bool bft_kh_lookup(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t* val) {
+    uint64_t at = 0;
+    if (!bft_kh_find<W>(kh, n_lines, t, at)) return false;
+    *val = reinterpret_cast<const uint32_t*>(kh)[at];
+    return true;
 }
 // Sequential insertion (the host restatement; the GPU kernel k_kh_insert claims slots with atomicCAS instead -- which slot of which
 // line a key lands in may then differ, what a lookup returns cannot).  The table must hold BFT_KH_EMPTY in every key word.

@@ -186,7 +186,8 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
  * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, root tables, node prefix
  * hash, k-mer hash), ms[5]=resident k_query workgroups per CU in use (1, 2 or 3), ms[6..7]=time of the "tune" batch with 1 / 2 workgroups per CU (0 when not
- * tuned), ms[8]=rows per suffix-group probe in use (4 or 8), ms[9]=lines of the k-mer hash (0 = none), ms[10]=GPU time of its fill, ms[11..13]=0,
+ * tuned), ms[8]=rows per suffix-group probe in use (4 or 8), ms[9]=lines of the k-mer hash (0 = none), ms[10]=GPU time of its fill, ms[11]=largest root-prefix bucket of the last sort (0: one device-wide sort),
+ * ms[12]=times the colour-set interning had to compare lists (signature collisions), ms[13]=ms this process has spent in hipMalloc so far,
  * ms[14]=root tables in use (0 / 1 / 2, see "root_direct"), ms[15..16]="tune": time with the direct table alone / with the range table, ms[17]=keys in the
  * node prefix hash, ms[18]=keys it dropped (full bucket: those lookups take the container path), ms[19]="tune": time with residency 3. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);

@@ -271,3 +271,25 @@ def test_group_shard_rule_through_the_c_symbol(built):
         B.shard(10, 0, 0)
     with pytest.raises(Exception):
         B.shard(10, 2, 2)
+
+
+def test_hot_kernels_use_no_scratch(built):
+    """Register budget of the kernels the headline runs on, read from the code objects of the built library (no GPU needed): the k-mer hash
+    kernels must not touch scratch memory or spill vector registers.  (Round 3 lost 10 % of the headline for a while to a local whose
+    address was taken: 4 bytes of scratch written per query, 534 MB per launch -- tools/kernel_resources.py shows it at once.)"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), "_kh"], capture_output=True, text=True).stdout
+    rows = [l.split(None, 7) for l in out.splitlines()[1:] if l.strip()]
+    seen = set()
+    for vgpr, sgpr, vspill, sspill, scratch, lds, maxwg, name in rows:
+        m = re.match(r"void (k_query_kh|k_seq_kh|k_branching_kh|k_kh_insert)<(\d)", name)
+        if not m:
+            continue
+        seen.add(m.group(1))
+        assert int(vspill) == 0 and int(scratch) == 0, name
+        if m.group(1) == "k_query_kh":
+            assert int(vgpr) <= 32, name   # 8 wavefronts per SIMD with room to spare
+    assert seen == {"k_query_kh", "k_seq_kh", "k_branching_kh", "k_kh_insert"}
