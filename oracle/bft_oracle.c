@@ -1686,9 +1686,11 @@ static void memo_clear(void) {
 static uint32_t cs_from_annot_slow(orc_bft *t, const uint8_t *annot, int size) {
     uint32_t ids[4096];
     int n = decode_any(annot, size, ids, 4096);
-    uint32_t cs = 0;
-    for (int a = 0; a < n && a < 4096; a++) cs = cs_add(t, cs, ids[a]);
-    return cs;
+    if (n > 4096) n = 4096;
+    if (n == 0) return 0;
+    /* the whole list at once (a chain of cs_add would create -- and copy -- every prefix of it: quadratic, 20 s of a 50 s load of the
+     * 100-genome index); the byte memo above makes equal annotations share the set */
+    return cs_new(t, ids, n, 0, 0);
 }
 static uint32_t cs_from_annot(orc_bft *t, const uint8_t *annot, int size) {
     while (size > 1 && annot[size - 1] == 0) size--; /* rows are padded to the UC's width with zero bytes */
