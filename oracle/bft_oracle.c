@@ -376,6 +376,7 @@ struct orc_bft {
     long *cs_off; long cs_n, cs_cap; /* cs_off[c]..cs_off[c+1] */
     /* memo (cs, gid) -> cs' open addressing */
     uint64_t *memo_key; uint32_t *memo_val; long memo_cap, memo_n;
+    int *szmemo; long szmemo_n; /* annotation size per colour set (cs_size) */
 };
 
 static comp_elem *g_comp = NULL; /* only used while a file is being loaded (single-threaded test infrastructure) */
@@ -594,7 +595,7 @@ void orc_free(orc_bft *t) {
     free_node(&t->root, t->k);
     for (int e = 0; e < t->ncelems; e++) free(t->celems[e].bytes);
     free(t->celems); free(t->cs_pos);
-    free(t->hash_v); free(t->hmod); free(t->cs_ids); free(t->cs_off); free(t->memo_key); free(t->memo_val);
+    free(t->hash_v); free(t->hmod); free(t->cs_ids); free(t->cs_off); free(t->memo_key); free(t->memo_val); free(t->szmemo);
     free(t);
 }
 
@@ -835,11 +836,21 @@ static int cs_encode(orc_bft *t, uint32_t cs, uint8_t *out, int cap) {
     if (t->comp_on && b > a) { uint8_t tmp[8]; int n = put_comp_index(t->cs_pos[cs], tmp); if (n > cap) return -1; memcpy(out, tmp, (size_t)n); return n; }
     return orc_annot_encode(t->cs_ids + a, (int)(b - a), out, cap);
 }
+/* size of the annotation of colour set cs; the replay of compute_best_mode is O(ids) and freeze() asks once per row: remembered per set
+ * (sets are immutable once created) */
 static int cs_size(orc_bft *t, uint32_t cs) {
     long a = t->cs_off[cs], b = t->cs_off[cs + 1];
     int mode;
     if (t->comp_on && b > a) { uint8_t tmp[8]; return put_comp_index(t->cs_pos[cs], tmp); }
-    return b > a ? annot_best(t->cs_ids + a, (int)(b - a), &mode) : 1;
+    if (b <= a) return 1;
+    if ((long)cs >= t->szmemo_n) {
+        const long ncap = t->cs_n + 1024;
+        t->szmemo = xrealloc(t->szmemo, (size_t)ncap * sizeof(int));
+        for (long i = t->szmemo_n; i < ncap; i++) t->szmemo[i] = -1;
+        t->szmemo_n = ncap;
+    }
+    if (t->szmemo[cs] < 0) t->szmemo[cs] = annot_best(t->cs_ids + a, (int)(b - a), &mode);
+    return t->szmemo[cs];
 }
 
 static void freeze_uc_rows(orc_bft *t, orc_uc *uc, const uint8_t *rows, int n, int nbs) {
