@@ -801,6 +801,7 @@ static void derive_kmer_hash(bft_gpu* h) {
         h->d_kh.release();
         return;
     }
+    if (getenv("BFT_GPU_VERBOSE")) fprintf(stderr, "[bft_gpu] k-mer hash: %llu lines at %p (%zu bytes in a block of %zu)\n", (unsigned long long)lines, h->d_kh.p, bytes, h->d_kh.cap);
     h->kh_lines = lines;
     h->im.kh = h->d_kh.as<uint64_t>();
     h->im.kh_lines = lines;
