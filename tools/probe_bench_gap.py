@@ -45,6 +45,16 @@ for label in ("first", "second"):
     torch.cuda.synchronize()
     ms, n = t.kernel_time(reset=True)
     res[label] = round(ms / n, 4)
+# drift: the same launches over ~1.5 s
+series = []
+for _ in range(25):
+    t.kernel_time(reset=True)
+    for _ in range(20):
+        t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ms, n = t.kernel_time(reset=True)
+    series.append(round(ms / n, 3))
+res["series_20_launches_each"] = series
 # the table re-derived into a fresh allocation
 t.set_option("kmer_hash", 0)
 t.set_option("kmer_hash", 1)
