@@ -812,7 +812,8 @@ static void derive_kmer_hash(bft_gpu* h) {
 // hold dozens of rows, and the root range table unless most root prefixes are child Nodes (their lookups pay it for nothing).
 static void default_launch_shape(bft_gpu* h) {
     h->tuned_wgs = 3;
-    const uint64_t prefixes = std::max<uint64_t>(1, h->info[6]);
+    // (rows per ROOT prefix: the groups most queries end in hang off the root; deeper levels add prefixes, not rows)
+    const uint64_t prefixes = std::max<uint64_t>(1, std::min<uint64_t>(h->info[6], 1ull << 18));
     h->tuned_probe = h->n_kmers / prefixes >= 48 ? 8 : 4;
     h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
     if (h->opt_root_direct == 3 && h->rstart_ok) {
