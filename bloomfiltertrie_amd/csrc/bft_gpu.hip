@@ -782,7 +782,13 @@ struct KhFill {
     DevBuf buf;
     uint64_t lines = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s2 = nullptr;
     bool started = false;
+    ~KhFill() {  // (a build that fails half-way: the fill must be over before its buffer goes back to the cache)
+        if (started && s2) (void)hipStreamSynchronize(s2);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
 };
 static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, KhFill& f) {
     if (!h->opt_kmer_hash || !bft_kh_usable(h->k, h->W) || nk == 0) return;
@@ -794,10 +800,12 @@ static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, u
               hipMemsetAsync(f.buf.p, 0xFF, bytes, h->stream2) == hipSuccess &&
               bft_kh_fill(d_tk, d_tcol, nk, h->W, f.buf.as<uint64_t>(), f.lines, h->stream2) == 0 && hipEventRecord(f.e1, h->stream2) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(h->stream2); f.buf.release(); return; }
+    f.s2 = h->stream2;
     f.started = true;
 }
 static bool kh_finish(bft_gpu* h, KhFill& f, double* ms) {
     bool ok = f.started && hipStreamSynchronize(h->stream2) == hipSuccess;
+    f.started = false;
     float t = 0;
     if (ok && hipEventElapsedTime(&t, f.e0, f.e1) == hipSuccess && ms) *ms = t;
     if (f.e0) (void)hipEventDestroy(f.e0);
