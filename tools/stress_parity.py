@@ -42,6 +42,12 @@ for r in range(rounds):
         t.set_option("kmer_hash", 0)
     if rng.random() < 0.3:
         t.set_option("build_composite", 0)
+    if rng.random() < 0.5:
+        t.set_option("build_msd", int(rng.choice([0, 2])))          # one device-wide sort / root-prefix buckets at any size
+    if rng.random() < 0.5:
+        t.set_option("flush_pairs", int(rng.choice([1024, 5000, 40000])))  # the log is merged into the index many times on the way
+    if rng.random() < 0.3:
+        t.set_option("kmer_hash_load", int(rng.choice([20, 65, 80])))
     cut = int(rng.integers(0, ngen + 1))
     use_async = bool(rng.random() < 0.4)
     for j, gi in enumerate(order):
