@@ -236,6 +236,7 @@ struct bft_gpu {
     std::vector<uint32_t> hashmod;
     std::vector<uint32_t> cs_off, cs_ids;  // host copy of the colour-set dictionary, fetched on first use (host_colorsets)
     uint64_t n_sets = 0, n_ids = 0;
+    uint32_t cs_w = 4;  // bytes per genome id of the resident dictionary d_cs_ids (1 / 2 / 4: narrow_ids)
     bool cs_on_host = false;
     uint64_t info[16] = {0};
     double build_ms[5] = {0, 0, 0, 0, 0};
@@ -638,7 +639,8 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.uck = h->d_uck.as<uint64_t>();
     im.ucrow = h->d_ucrow.as<uint32_t>();
     im.cs_off = h->d_cs_off.as<uint32_t>();
-    im.cs_ids = h->d_cs_ids.as<uint32_t>();
+    im.cs_ids = h->d_cs_ids.p;
+    im.cs_w = h->cs_w;
     im.ccx = h->d_ccx.as<BftCCX>();
     im.f18 = h->d_f18.as<uint64_t>();
     im.fent = h->d_fent.as<uint64_t>();
@@ -923,13 +925,58 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     return 0;
 }
 
+// The genome ids of the dictionary stay resident in the narrowest width that holds every id (a pan-genome of 100 genomes: one byte
+// instead of four -- 484 MB -> 121 MB on config 3, 8 of the image's 49 bytes per k-mer); the build and the merge work on 32-bit ids.
+template <class T>
+__global__ void k_narrow_ids(const uint32_t* __restrict__ in, uint64_t n, T* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (T)in[i];
+}
+template <class T>
+__global__ void k_widen_ids(const T* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)in[i];
+}
+static uint32_t id_width(uint32_t max_gid) { return max_gid < 256u ? 1u : (max_gid < 65536u ? 2u : 4u); }
+// ids32 (n u32) -> out in width w; w == 4: the buffers are swapped
+static int narrow_ids(DevBuf& ids32, uint64_t n, uint32_t w, hipStream_t s, DevBuf& out) {
+    if (w == 4) { out.swap(ids32); return 0; }
+    CK(out.alloc(n * w));
+    const dim3 grid(grid_for((n + 255) / 256)), block(256);
+    if (n) {
+        if (w == 1) hipLaunchKernelGGL(k_narrow_ids<uint8_t>, grid, block, 0, s, ids32.as<uint32_t>(), n, out.as<uint8_t>());
+        else hipLaunchKernelGGL(k_narrow_ids<uint16_t>, grid, block, 0, s, ids32.as<uint32_t>(), n, out.as<uint16_t>());
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+// the resident dictionary as u32 (a transient of the merge); w == 4: `src` itself
+static int widen_ids(const DevBuf& src, uint64_t n, uint32_t w, hipStream_t s, DevBuf& tmp, const uint32_t** out) {
+    if (w == 4) { *out = src.as<uint32_t>(); return 0; }
+    CK(tmp.alloc(n * 4));
+    const dim3 grid(grid_for((n + 255) / 256)), block(256);
+    if (n) {
+        if (w == 1) hipLaunchKernelGGL(k_widen_ids<uint8_t>, grid, block, 0, s, src.as<uint8_t>(), n, tmp.as<uint32_t>());
+        else hipLaunchKernelGGL(k_widen_ids<uint16_t>, grid, block, 0, s, src.as<uint16_t>(), n, tmp.as<uint32_t>());
+        HIPCK(hipGetLastError());
+    }
+    *out = tmp.as<uint32_t>();
+    return 0;
+}
+
 // The colour-set dictionary lives in HBM; only bft_gpu_colorset and bft_gpu_write_bft need it on the host.
 static int host_colorsets(bft_gpu* h) {
     if (h->cs_on_host) return 0;
     h->cs_off.assign(h->n_sets + 1, 0);
     h->cs_ids.assign(h->n_ids, 0);
     HIPCK(hipMemcpy(h->cs_off.data(), h->d_cs_off.p, (h->n_sets + 1) * 4, hipMemcpyDeviceToHost));
-    if (h->n_ids) HIPCK(hipMemcpy(h->cs_ids.data(), h->d_cs_ids.p, h->n_ids * 4, hipMemcpyDeviceToHost));
+    if (h->n_ids) {
+        if (h->cs_w == 4) HIPCK(hipMemcpy(h->cs_ids.data(), h->d_cs_ids.p, h->n_ids * 4, hipMemcpyDeviceToHost));
+        else {
+            std::vector<uint8_t> raw(h->n_ids * h->cs_w);
+            HIPCK(hipMemcpy(raw.data(), h->d_cs_ids.p, raw.size(), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < h->n_ids; i++) h->cs_ids[i] = h->cs_w == 1 ? raw[i] : ((const uint16_t*)raw.data())[i];
+        }
+    }
     h->cs_on_host = true;
     return 0;
 }
@@ -1141,7 +1188,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
     uint64_t total_pairs = np;
     if (h->built && h->n_kmers > 0 && nk > 0) {
-        const BftRun old_run{h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_cs_off.as<uint32_t>(), h->d_cs_ids.as<uint32_t>(), h->n_sets};
+        DevBuf wide;
+        const uint32_t* old_ids = nullptr;
+        CK(widen_ids(h->d_cs_ids, h->n_ids, h->cs_w, h->stream, wide, &old_ids));
+        const BftRun old_run{h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->d_cs_off.as<uint32_t>(), old_ids, h->n_sets};
         const BftRun new_run{tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, n_cs_off.as<uint32_t>(), n_cs_ids.as<uint32_t>(), n_sets};
         BftRunOut mo;
         CK(bft_merge_runs(W, old_run, new_run, h->stream, mo));
@@ -1168,6 +1218,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     uint64_t n_f18 = 0, n_fent = 0;
     CK(bft_flatten_gpu(idx.ccs.as<BftCC>(), idx.n_ccs, idx.f2w.as<uint64_t>(), idx.clus.as<uint64_t>(), idx.child.as<uint64_t>(), h->opt_flat_min, h->stream,
                        n_ccx, n_f18buf, n_fentbuf, n_f18, n_fent));
+    const uint32_t new_cs_w = id_width(h->max_gid_seen);
+    DevBuf n_cs_ids_w;
+    CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
     CK(wait_foreign_stream(h));  // queries a caller still has in flight on its own stream read the arrays released below
     double kh_ms = 0;
     const bool kh_ok = kh_finish(h, khf, &kh_ms);
@@ -1179,7 +1232,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     // ---- commit: nothing above touched the handle; from here on nothing can fail before the image is whole ----
     h->d_tcol.swap(n_tcol);
     h->d_cs_off.swap(n_cs_off);
-    h->d_cs_ids.swap(n_cs_ids);
+    h->d_cs_ids.swap(n_cs_ids_w);
+    h->cs_w = new_cs_w;
     h->n_sets = n_sets;
     h->n_ids = n_ids;
     h->cs_on_host = false;
@@ -1651,7 +1705,7 @@ extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n
         if (!overflow && ids && total + cnt <= ids_cap) {
             if (cnt) {
                 CK(dids.alloc(cnt * 4));
-                hipLaunchKernelGGL(k_color_fill, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids,
+                hipLaunchKernelGGL(k_color_fill, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, h->im.cs_w,
                                    doff.as<uint64_t>(), m, dids.as<uint32_t>());
                 HIPCK(hipMemcpyAsync(ids + total, dids.p, cnt * 4, hipMemcpyDeviceToHost, h->stream));
                 HIPCK(hipStreamSynchronize(h->stream));
@@ -1675,7 +1729,7 @@ static int ensure_cs_bitmaps(bft_gpu* h) {
     if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
         const uint64_t stride = (rowbytes + 3) & ~3ull;  // dword-aligned dictionary rows (k_color_rows_bm)
         CK(h->d_cs_bm.alloc_zero(nsets * stride, h->stream));
-        hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, h->im.cs_off, h->im.cs_ids, nsets, (uint32_t)stride,
+        hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, h->im.cs_off, h->im.cs_ids, h->im.cs_w, nsets, (uint32_t)stride,
                            h->d_cs_bm.as<uint8_t>());
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));  // the row kernel may run on a caller's stream
@@ -1712,7 +1766,7 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
                                div_l, d_out);
     }
     else
-        hipLaunchKernelGGL(k_color_rows, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, h->im.cs_off, h->im.cs_ids, n, rowbytes, d_out);
+        hipLaunchKernelGGL(k_color_rows, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_rowidx, h->im.tcol, h->im.cs_off, h->im.cs_ids, h->im.cs_w, n, rowbytes, d_out);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1846,7 +1900,7 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
         }
         const uint32_t win = std::min<uint32_t>(SEQ_TALLY_G, (G + 63u) & ~63u);  // counters per wavefront: all genomes up to 2048
         hipLaunchKernelGGL(k_seq_tally, dim3((unsigned)std::min<uint64_t>((ns + SEQ_TALLY_WAVES - 1) / SEQ_TALLY_WAVES, 256ull * 16)), dim3(64 * SEQ_TALLY_WAVES),
-                           (size_t)SEQ_TALLY_WAVES * win * 4, s, h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, G, rowbytes,
+                           (size_t)SEQ_TALLY_WAVES * win * 4, s, h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, h->im.cs_w, G, rowbytes,
                            threshold, win, d_rows + a * rowbytes);
         HIPCK(hipGetLastError());
     }
@@ -1971,10 +2025,10 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
 // image replication (one contiguous device blob: header, then 256-byte aligned sections)
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint64_t BLOB_MAGIC = 0x3330555047544642ull;  // "BFTGPU03"
+constexpr uint64_t BLOB_MAGIC = 0x3430555047544642ull;  // "BFTGPU04"
 constexpr int BLOB_HDR_WORDS = 64, BLOB_SECTIONS = 13;
 enum { H_MAGIC, H_TOTAL, H_K, H_R1, H_R2, H_NKMERS, H_NPAIRS, H_NSETS, H_NIDS, H_ROOTNCC, H_MAXGID, H_ANYINS, H_NBGEN, H_NNAMES,
-       H_STOREMAX, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
+       H_CSW, H_STOREANY, H_INFO = 16, H_IDX = 32, H_SEC = 41 };
 
 struct BlobPlan {
     uint64_t hdr[BLOB_HDR_WORDS];
@@ -1990,7 +2044,7 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     p.names.clear();
     for (const std::string& g : h->genomes) { p.names += g; p.names.push_back('\0'); }
     const uint64_t sz[BLOB_SECTIONS] = {h->idx_sizes[0], h->idx_sizes[1], h->idx_sizes[2], h->idx_sizes[3], h->idx_sizes[4], h->idx_sizes[5], h->idx_sizes[6],
-                                        h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * 4,
+                                        h->idx_sizes[7], h->idx_sizes[8], h->n_kmers * 4, (h->n_sets + 1) * 4, h->n_ids * (uint64_t)h->cs_w,
                                         p.names.size()};
     const void* src[BLOB_SECTIONS] = {h->d_nodes.p, h->d_bfT.p, h->d_ccs.p, h->d_f2w.p, h->d_clus.p, h->d_child.p, h->d_uck.p, h->d_ucrow.p,
                                       h->d_tk.p, h->d_tcol.p, h->d_cs_off.p, h->d_cs_ids.p, nullptr};
@@ -2004,7 +2058,7 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
     uint64_t* H = p.hdr;
     H[H_MAGIC] = BLOB_MAGIC; H[H_TOTAL] = o; H[H_K] = h->k; H[H_R1] = h->r1; H[H_R2] = h->r2; H[H_NKMERS] = h->n_kmers; H[H_NPAIRS] = h->n_pairs;
     H[H_NSETS] = h->n_sets; H[H_NIDS] = h->n_ids; H[H_ROOTNCC] = h->root_ncc; H[H_MAXGID] = h->max_gid_seen; H[H_ANYINS] = h->any_insert;
-    H[H_NBGEN] = h->im.nb_genomes; H[H_NNAMES] = h->genomes.size();
+    H[H_NBGEN] = h->im.nb_genomes; H[H_NNAMES] = h->genomes.size(); H[H_CSW] = h->cs_w;  // (word 14: bytes per dictionary id)
     for (int i = 0; i < 16; i++) H[H_INFO + i] = h->info[i];
     for (int i = 0; i < 9; i++) H[H_IDX + i] = h->idx_sizes[i];
 }
@@ -2085,6 +2139,8 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         }
         h->n_kmers = H[H_NKMERS]; h->n_pairs = H[H_NPAIRS]; h->n_sets = H[H_NSETS]; h->n_ids = H[H_NIDS];
         h->root_ncc = (uint32_t)H[H_ROOTNCC]; h->max_gid_seen = (uint32_t)H[H_MAXGID]; h->any_insert = H[H_ANYINS] != 0;
+        h->cs_w = (uint32_t)H[H_CSW];
+        if (h->cs_w != 1 && h->cs_w != 2 && h->cs_w != 4) rc = fail(BFT_GPU_E_IO, "image blob: bad dictionary id width");
         for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
         for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
         h->cs_on_host = false;

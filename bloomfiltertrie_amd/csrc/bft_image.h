@@ -158,5 +158,6 @@ struct BftImage {
     const uint64_t* uck;      // [n_uc_rows * W] node-UC rows (T-form)
     const uint32_t* ucrow;    // [n_uc_rows] row of that k-mer in tk
     const uint32_t* cs_off;   // [n_cs + 1] colour-set dictionary (sorted genome ids)
-    const uint32_t* cs_ids;
+    const void* cs_ids;       // genome ids of all sets, cs_w bytes each (1 up to 256 genomes, 2 up to 65536, else 4): bft_cs_id()
+    uint32_t cs_w;
 };

@@ -16,25 +16,28 @@ __global__ void k_color_counts(const uint32_t* __restrict__ rows, const uint32_t
 }
 
 __global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
-                             const uint32_t* __restrict__ cs_ids, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* __restrict__ ids) {
+                             const void* __restrict__ cs_ids, uint32_t cs_w, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* __restrict__ ids) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = rows[i];
         if (r == BFT_ABSENT_ROW) continue;
         const uint32_t cs = tcol[r];
         const uint32_t a = cs_off[cs], b = cs_off[cs + 1];
         uint64_t o = offsets[i];
-        for (uint32_t q = a; q < b; q++) ids[o++] = cs_ids[q];
+        for (uint32_t q = a; q < b; q++) ids[o++] = bft_cs_id_at(cs_ids, cs_w, q);
     }
 }
 
 // colour-set dictionary as bitmaps, built once per image: one row per set, CEIL(G/8) bytes padded to a multiple of 4
 // (`stride`) so that the row kernel reads it with aligned dword loads
-__global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint64_t n_sets, uint32_t stride,
+__global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const void* __restrict__ cs_ids, uint32_t cs_w, uint64_t n_sets, uint32_t stride,
                              uint8_t* __restrict__ bm) {
     // one thread per set (a wavefront-cooperative fill with atomic ORs on the row dwords measured 2x slower)
     for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_sets; c += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t* o = bm + c * stride;
-        for (uint32_t q = cs_off[c]; q < cs_off[c + 1]; q++) o[cs_ids[q] >> 3] |= (uint8_t)(1u << (cs_ids[q] & 7));
+        for (uint32_t q = cs_off[c]; q < cs_off[c + 1]; q++) {
+            const uint32_t g = bft_cs_id_at(cs_ids, cs_w, q);
+            o[g >> 3] |= (uint8_t)(1u << (g & 7));
+        }
     }
 }
 
@@ -242,7 +245,7 @@ __global__ void k_row_colorsets(const uint32_t* rows, const uint32_t* __restrict
 }
 
 __global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
-                             const uint32_t* __restrict__ cs_ids, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
+                             const void* __restrict__ cs_ids, uint32_t cs_w, uint64_t n, uint32_t rowbytes, uint8_t* __restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t* o = out + i * rowbytes;
         for (uint32_t b = 0; b < rowbytes; b++) o[b] = 0;
@@ -250,7 +253,7 @@ __global__ void k_color_rows(const uint32_t* __restrict__ rows, const uint32_t* 
         if (r == BFT_ABSENT_ROW) continue;
         const uint32_t cs = tcol[r];
         for (uint32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) {
-            const uint32_t gid = cs_ids[q];
+            const uint32_t gid = bft_cs_id_at(cs_ids, cs_w, q);
             o[gid >> 3] |= (uint8_t)(1u << (gid & 7));
         }
     }

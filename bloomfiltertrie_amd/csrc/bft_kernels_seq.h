@@ -156,7 +156,7 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
 #define SEQ_TALLY_G 2048u
 #define SEQ_TALLY_WAVES 4
 __global__ __launch_bounds__(64 * SEQ_TALLY_WAVES) void k_seq_tally(const uint32_t* __restrict__ csin, const uint64_t* __restrict__ pos_off, uint32_t n_seqs,
-                                                                   const uint32_t* __restrict__ cs_off, const uint32_t* __restrict__ cs_ids, uint32_t G,
+                                                                   const uint32_t* __restrict__ cs_off, const void* __restrict__ cs_ids, uint32_t cs_w, uint32_t G,
                                                                    uint32_t rowbytes, double threshold, uint32_t win, uint8_t* __restrict__ out) {
     extern __shared__ uint32_t s_cnt[];  // [SEQ_TALLY_WAVES][win]: win = the genome window, sized by the host (few genomes: more workgroups per CU)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * SEQ_TALLY_WAVES) void k_seq_tally(const uint32
                     for (uint32_t q = cs_off[cs]; q < q1; q += 8) {  // eight ids per step, loaded together
                         uint32_t id[8];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) id[j] = cs_ids[min(q + (uint32_t)j, q1 - 1u)];
+                        for (int j = 0; j < 8; j++) id[j] = bft_cs_id_at(cs_ids, cs_w, min(q + (uint32_t)j, q1 - 1u));
 #pragma unroll
                         for (int j = 0; j < 8; j++)
                             if (q + (uint32_t)j < q1 && id[j] - win0 < wn) atomicAdd(&cnt[id[j] - win0], len);

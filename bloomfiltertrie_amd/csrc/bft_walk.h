@@ -300,6 +300,13 @@ struct BftHit {
 // what a query kernel writes for a found k-mer: its row, or -- im.emit_cs, the colour-row and sequence paths -- its colour set
 BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) { return im.emit_cs ? im.tcol[h.row] : (uint32_t)h.row; }
 
+// genome id q of the colour-set dictionary (stored in the narrowest width that holds every id of the index)
+BFT_HD uint32_t bft_cs_id_at(const void* cs_ids, uint32_t cs_w, uint64_t q) {
+    if (cs_w == 1) return reinterpret_cast<const uint8_t*>(cs_ids)[q];
+    if (cs_w == 2) return reinterpret_cast<const uint16_t*>(cs_ids)[q];
+    return reinterpret_cast<const uint32_t*>(cs_ids)[q];
+}
+
 // ---- k-mer hash (bft_image.h, BFT_KH_*) ----
 BFT_HD bool bft_kh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }  // (the empty marker needs a key word that cannot be all ones)
 template <int W>

@@ -398,3 +398,49 @@ def test_colour_interning_falls_back_to_exact_comparison_on_signature_collisions
     assert ma == mb and na == nb_ and a.info()["colorsets"] == b.info()["colorsets"]
     a.close()
     b.close()
+
+
+def test_dictionary_id_width_follows_the_largest_genome_id():
+    """The genome ids of the colour-set dictionary are resident in 1, 2 or 4 bytes, whichever holds the largest id inserted so far;
+    merges widen them on the way.  Colour ids, colour rows, the per-read tallies and a packed copy answer the same through every
+    width, and ground truth."""
+    import torch
+    k = 27
+    anc = S.random_genome(30000, 3)
+    gids = [0, 1, 2, 255, 256, 4000, 65535, 65536, 70001]
+    genomes = {g: S.distinct(S.kmers_of(S.mutate(anc, 0.02, 50 + i), k)) for i, g in enumerate(gids)}
+    t = BFT(k)
+    truth = {}
+    widths = []
+    for g in gids:
+        t.insert_kmers(genomes[g], g)
+        for row in genomes[g]:
+            truth.setdefault(row.tobytes(), []).append(g)
+        t.build()
+        fp, info = t.footprint(), t.info()
+        n_ids = sum(len(t.colorset(c)) for c in range(info["colorsets"]))
+        widths.append((fp["colorset_dictionary"] - 4 * (info["colorsets"] + 1)) // max(n_ids, 1))
+        q = genomes[g][::7]
+        bits, off, ids = t.query_colors(q)
+        assert S.from_bits(bits, len(q)).all()
+        for i in range(0, len(q), 41):
+            assert ids[int(off[i]):int(off[i + 1])].tolist() == truth[q[i].tobytes()]
+    assert widths == [1, 1, 1, 1, 2, 2, 2, 4, 4]
+    q = np.concatenate([genomes[g][::29] for g in gids])[:600]
+    bits, rows = t.query_color_rows(q)
+    for i in range(0, len(q), 13):
+        assert np.flatnonzero(np.unpackbits(rows[i], bitorder="little")).tolist() == truth[q[i].tobytes()]
+    reads = [bytes(S._ASCII[S.mutate(anc, 0.02, 50 + i)[100:400]]).decode() for i in (0, 4, 8)]
+    got = t.query_sequences(reads, 0.9)
+    assert [gids[0] in got[0], gids[4] in got[1], gids[8] in got[2]] == [True, True, True]
+    n = t.image_size()
+    blob = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    t.image_pack(blob.data_ptr(), n)
+    b = BFT.from_image(blob.data_ptr(), n, device=0)
+    assert b.footprint()["colorset_dictionary"] == t.footprint()["colorset_dictionary"]
+    assert b.query_sequences(reads, 0.9) == got
+    assert (b.query_color_rows(q)[1] == rows).all()
+    mt, _ = _colour_map(t)
+    assert mt == {kk: tuple(v) for kk, v in truth.items()}
+    t.close()
+    b.close()
