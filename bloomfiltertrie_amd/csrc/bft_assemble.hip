@@ -411,7 +411,7 @@ struct Seg {  // per-depth output segments, concatenated at the end
 };
 
 template <int W>
-int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out) {
+int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hipStream_t s, BftDeviceIndex& out, const BftAssembleHook* hook) {
     const int L = k / 9, rb = 2 * (k - 9 * L);
     Scan scan(s);
     std::vector<Seg> segs;
@@ -479,6 +479,9 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             hipLaunchKernelGGL(k_counts, G(K), key_row.as<uint32_t>(), key_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)K, key_cnt.as<uint32_t>());
         }
         head.release(); khead.release(); ppos.release(); kpos.release();
+        // (the two passes over the whole table are enqueued: what follows is a chain of small kernels and counts read back, which
+        // leaves most of the GPU to whatever the caller starts beside it now)
+        if (d == 0 && hook && hook->after_table_passes) hook->after_table_passes(hook->ctx, s);
 
         // ---- CC assignment: one pass.  A node opens a CC only while >= 255 k-mers are unassigned and every CC but the last claims at
         // least 255, so a node of U k-mers holds at most U / 255 + 1 CCs: the Bloom bitsets are written at those upper-bound slots
@@ -921,14 +924,14 @@ static unsigned long long g_exact_passes = 0;
 void bft_test_weak_signature(bool on) { g_weak_signature = on; }
 unsigned long long bft_test_exact_passes(void) { return g_exact_passes; }
 
-int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out) {
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out, const BftAssembleHook* hook) {
     if (!bft_valid_k(k)) return bft_fail(BFT_GPU_E_ARG, "k must be in [9, 126]");
     if (n >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 k-mers");
     switch (bft_words_for_k(k)) {
-    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out);
-    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out);
-    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out);
-    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out);
+    case 1: return assemble<1>(d_tk, n, k, d_hashmod, s, out, hook);
+    case 2: return assemble<2>(d_tk, n, k, d_hashmod, s, out, hook);
+    case 3: return assemble<3>(d_tk, n, k, d_hashmod, s, out, hook);
+    default: return assemble<4>(d_tk, n, k, d_hashmod, s, out, hook);
     }
 }
 

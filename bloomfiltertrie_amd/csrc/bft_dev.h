@@ -76,7 +76,14 @@ struct BftDeviceIndex {
     uint64_t n_nodes = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_bf8 = 0, n_uc = 0;
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0, root_ncc = 0, root_uc = 0;
 };
-int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out);
+void bft_trace_mark(const char* what);  // BFT_GPU_TRACE_BUILD=1 (nullptr: start of a build)
+// after_table_passes: called once, when the first level's passes over the whole sorted table are enqueued on `s`
+struct BftAssembleHook {
+    void (*after_table_passes)(void* ctx, hipStream_t s);
+    void* ctx;
+};
+int bft_assemble_gpu(const uint64_t* d_tk, uint64_t n, int k, const uint32_t* d_hashmod, hipStream_t s, BftDeviceIndex& out,
+                     const BftAssembleHook* hook = nullptr);
 // flat form of the CCs with >= flat_min prefixes (bft_image.h): extended headers, prefix bitmaps + ranks, entries
 struct BftCC;
 int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, const uint64_t* d_clus, const uint64_t* d_child, uint32_t flat_min,

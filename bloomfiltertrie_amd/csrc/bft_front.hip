@@ -26,6 +26,9 @@
 #define FB_DBITS 8                      // digit width (9-bit digits, four passes instead of five over 36 bits, were slower: 5.9 ms against 4.7 on
                                         // config 3 -- 40 KB of LDS per workgroup leaves three per CU, and the counters' upkeep grows with the digits)
 #define FB_DIGITS (1 << FB_DBITS)
+// (Also tried: the top 24 remaining bits first -- three passes instead of five --, every pass only for a bucket whose k-mers then fail
+// an order check.  On a pan-genome 85 % of the buckets fail it: the SNP variants of a k-mer share all but one base, one variant in
+// three differs from its neighbour only below those bits.  Dropped.)
 
 namespace {
 
@@ -226,6 +229,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     nk = total >> 32;
     np = total & 0xFFFFFFFFull;
     (void)n;
+    bft_trace_mark("bucket sort done (sync)");
     CK(tk.alloc(nk * 8));
     CK(seg_off.alloc((nk + 1) * 4));
     CK(pg.alloc(np * 4));

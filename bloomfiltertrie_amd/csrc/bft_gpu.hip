@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bft_gpu.h"
@@ -49,6 +50,16 @@ static int fail(int code, const std::string& msg) { return bft_fail(code, msg); 
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// BFT_GPU_TRACE_BUILD=1: host-side timeline of bft_gpu_build on stderr (where the host waits, allocates, reads counts back)
+static bool g_trace = getenv("BFT_GPU_TRACE_BUILD") != nullptr;
+static double g_trace_t0 = 0, g_trace_last = 0;
+void bft_trace_mark(const char* what) {
+    if (!g_trace) return;
+    const double t = now_ms();
+    if (!what) { g_trace_t0 = g_trace_last = t; return; }
+    fprintf(stderr, "[bft_gpu build] %8.3f ms (+%.3f) %s\n", t - g_trace_t0, t - g_trace_last, what);
+    g_trace_last = t;
 }
 
 // device code, by topic
@@ -131,8 +142,11 @@ int bft_pool_alloc(void** p, size_t n, size_t* cap) {
     }
     const double t_m0 = now_ms();
     hipError_t e = hipMalloc(p, n);
-    g_malloc_ms += now_ms() - t_m0;
-    g_malloc_calls++;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_malloc_ms += now_ms() - t_m0;
+        g_malloc_calls++;
+    }
     if (e != hipSuccess) {
         // out of memory with blocks parked in the cache: give them back and retry once
         std::vector<PoolBlock> all;
@@ -778,27 +792,58 @@ static void derive_node_hash(bft_gpu* h) {
 }
 
 // The fill of the k-mer hash for a table (tk, tcol) that is complete on the device, started on the handle's second stream: the build
-// assembles the containers on `stream` meanwhile (the fill is bound by L2 misses and atomics, the assembly by streams of the sorted
-// table and LDS work: 3.1 ms hidden behind 3.5).  kh_finish waits for it.  Any failure just leaves the image without the table.
+// assembles the containers on `stream` meanwhile.  The fill is bound by L2 misses and atomics and starves a streaming kernel beside
+// it (k_prefix_flags over the whole table: 0.2 ms alone, 2.8 ms beside the fill), so it starts behind the assembly's two passes over
+// the table (`after`: an event of the assembly stream) and overlaps the chain of small kernels and read-back counts that follows.
+// kh_finish waits for it.  Any failure just leaves the image without the table.
 struct KhFill {
     DevBuf buf;
     uint64_t lines = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, ew = nullptr;
     hipStream_t s2 = nullptr;
-    bool started = false;
+    bool started = false, prepared = false;
+    std::thread prep;  // kh_prepare_async
     ~KhFill() {  // (a build that fails half-way: the fill must be over before its buffer goes back to the cache)
+        if (prep.joinable()) prep.join();
         if (started && s2) (void)hipStreamSynchronize(s2);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        if (ew) (void)hipEventDestroy(ew);
     }
 };
-static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, KhFill& f) {
+// the host side of the fill that needs no table yet: the second stream, the table's memory, the events (a millisecond of driver
+// calls for a gigabyte table that is not in the cache)
+static void kh_prepare(bft_gpu* h, uint64_t nk, KhFill& f) {
+    f.prepared = false;
     if (!h->opt_kmer_hash || !bft_kh_usable(h->k, h->W) || nk == 0) return;
-    if (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); return; }
+    if (!h->stream2) {
+        int lo = 0, hi = 0;  // (numerically larger = lower priority)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); return; }
+    }
     f.lines = bft_kh_lines_for(nk, h->W, h->opt_kh_load);
+    if (f.buf.alloc(f.lines * BFT_KH_LINE_WORDS * 8) != 0) return;
+    f.prepared = (f.e0 || hipEventCreate(&f.e0) == hipSuccess) && (f.e1 || hipEventCreate(&f.e1) == hipSuccess) &&
+                 (f.ew || hipEventCreateWithFlags(&f.ew, hipEventDisableTiming) == hipSuccess);
+    if (!f.prepared) { (void)hipGetLastError(); f.buf.release(); }
+}
+// ... on a thread of its own while the build's stream is busy with the colour sets
+static void kh_prepare_async(bft_gpu* h, uint64_t nk, KhFill& f) {
+    KhFill* fp = &f;
+    f.prep = std::thread([h, nk, fp] {
+        if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
+        bft_pool_set_stream(h->device, h->stream);
+        kh_prepare(h, nk, *fp);
+    });
+}
+static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, KhFill& f, hipStream_t after = nullptr) {
+    if (f.prep.joinable()) f.prep.join();
+    if (!f.prepared || f.lines != bft_kh_lines_for(nk, h->W, h->opt_kh_load)) kh_prepare(h, nk, f);
+    if (!f.prepared) return;
     const size_t bytes = f.lines * BFT_KH_LINE_WORDS * 8;
-    if (f.buf.alloc(bytes) != 0) return;
-    bool ok = hipEventCreate(&f.e0) == hipSuccess && hipEventCreate(&f.e1) == hipSuccess && hipEventRecord(f.e0, h->stream2) == hipSuccess &&
+    bool ok = true;
+    if (after) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(h->stream2, f.ew, 0) == hipSuccess;
+    ok = ok && hipEventRecord(f.e0, h->stream2) == hipSuccess &&
               hipMemsetAsync(f.buf.p, 0xFF, bytes, h->stream2) == hipSuccess &&
               bft_kh_fill(d_tk, d_tcol, nk, h->W, f.buf.as<uint64_t>(), f.lines, h->stream2) == 0 && hipEventRecord(f.e1, h->stream2) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(h->stream2); f.buf.release(); return; }
@@ -1044,6 +1089,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     const int W = h->W;
     const uint64_t total = h->log_n;  // the run: what was inserted since the last build
     double t0 = now_ms();
+    bft_trace_mark(nullptr);
 
     DevBuf tk, seg_off, npg;
     uint64_t nk = 0, np = 0;
@@ -1076,15 +1122,21 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 DevBuf boff, maxb;
                 CK(boff.alloc(((1u << top) + 1) * 4));
                 CK(maxb.alloc_zero(4, h->stream));
-                HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                // (9-bit digits: the 18 bits in two onesweep passes instead of the three that rocPRIM's 8-bit default takes -- 2.76 ms
+                // against 3.79 on 2 x 10^8 keys, tools/microbench/msd_sort.hip)
+                using Msd9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
+                                                                                            rocprim::block_radix_rank_algorithm::match>>;
+                HIPCK(rocprim::radix_sort_keys<Msd9>(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
                 CK(tmp.alloc(tb));
-                HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                HIPCK(rocprim::radix_sort_keys<Msd9>(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
                 uint32_t mx = 0;
                 HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
                 HIPCK(hipStreamSynchronize(h->stream));
                 h->msd_max_bucket = mx;
+                bft_trace_mark("root-prefix split done (sync)");
                 if (mx <= bft_front_bucket_capacity()) {
                     pos.release();
                     CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np));
@@ -1173,6 +1225,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         }
         }
     }
+    bft_trace_mark("sort + dedupe done");
     double t1 = now_ms();
 
     // 4. colour sets: signature sort + exact run detection + verification, all on the GPU
@@ -1182,7 +1235,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(npg.alloc(4));
     }
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
+    KhFill khf;  // the k-mer hash, filled beside the container assembly
+    if (!(h->built && h->n_kmers > 0) && nk > 0) kh_prepare_async(h, nk, khf);  // (a merge changes the number of k-mers: kh_start prepares)
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
+    bft_trace_mark("colour sets interned");
     seg_off.release();
     npg.release();
     // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
@@ -1205,25 +1261,33 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(bft_count_pairs(n_tcol.as<uint32_t>(), nk, n_cs_off.as<uint32_t>(), h->stream, &total_pairs));
     }
     np = total_pairs;
-    KhFill khf;  // (from here on tk and n_tcol are final: the k-mer hash is filled beside the container assembly)
-    if (tk.p) kh_start(h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, khf);
+    struct KhStart {  // (from here on tk and n_tcol are final)
+        bft_gpu* h; const uint64_t* tk; const uint32_t* tcol; uint64_t nk; KhFill* f;
+        static void run(void* c, hipStream_t s) { KhStart* k = (KhStart*)c; kh_start(k->h, k->tk, k->tcol, k->nk, *k->f, s); }
+    } khs{h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, &khf};
+    const BftAssembleHook hook{tk.p ? &KhStart::run : nullptr, &khs};
+    bft_trace_mark("merge / bookkeeping");
     double t2 = now_ms();
 
     // 5. containers, level by level, on the GPU
     if (!tk.p) CK(tk.alloc(8));
     BftDeviceIndex idx;
-    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx));
+    CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx, &hook));
+    bft_trace_mark("containers assembled");
     double t3 = now_ms();
     DevBuf n_ccx, n_f18buf, n_fentbuf;
     uint64_t n_f18 = 0, n_fent = 0;
     CK(bft_flatten_gpu(idx.ccs.as<BftCC>(), idx.n_ccs, idx.f2w.as<uint64_t>(), idx.clus.as<uint64_t>(), idx.child.as<uint64_t>(), h->opt_flat_min, h->stream,
                        n_ccx, n_f18buf, n_fentbuf, n_f18, n_fent));
+    bft_trace_mark("flat forms");
     const uint32_t new_cs_w = id_width(h->max_gid_seen);
     DevBuf n_cs_ids_w;
     CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
     CK(wait_foreign_stream(h));  // queries a caller still has in flight on its own stream read the arrays released below
+    bft_trace_mark("ids narrowed, foreign stream waited");
     double kh_ms = 0;
     const bool kh_ok = kh_finish(h, khf, &kh_ms);
+    bft_trace_mark("k-mer hash fill waited");
     if (h->inject_build_failure) {
         h->inject_build_failure = false;
         return fail(BFT_GPU_E_LIMIT, "injected build failure (test hook)");
@@ -1289,6 +1353,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[2] = t3 - t2;
     h->build_ms[3] = 0;
     h->built = true;
+    bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
     if (kh_ok) {  // filled during the assembly
         h->d_kh.swap(khf.buf);
@@ -1301,9 +1366,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         h->kh_lines = 0;
         h->kh_ms = 0;
     }
+    bft_trace_mark("root tables");
     derive_node_hash(h);
     default_launch_shape(h);
     I[12] = image_bytes(h);
+    bft_trace_mark("launch shape; done");
     h->build_ms[4] = now_ms() - t3;
     return BFT_GPU_OK;
 }

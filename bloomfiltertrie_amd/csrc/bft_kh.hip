@@ -182,7 +182,9 @@ static unsigned kh_grid(uint64_t n, uint64_t per_block, int mult) {
 }
 
 int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W, uint64_t* d_kh, uint64_t n_lines, hipStream_t s) {
-    const dim3 grid(kh_grid(n, 256, 1)), block(256);
+    // (one key per thread, not a persistent grid: the fill runs beside the container assembly on a low-priority stream, and a
+    // workgroup that ends gives its CU slots to the assembly's next small kernel)
+    const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 0x7FFFFFFFull)), block(256);
     if (W == 1) hipLaunchKernelGGL(k_kh_insert<1>, grid, block, 0, s, d_tk, d_tcol, n, d_kh, n_lines);
     else hipLaunchKernelGGL(k_kh_insert<2>, grid, block, 0, s, d_tk, d_tcol, n, d_kh, n_lines);
     HIPCK(hipGetLastError());
