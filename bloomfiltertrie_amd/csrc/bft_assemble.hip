@@ -16,6 +16,7 @@
 // The arrays are bit-identical to the host restatement bft_index.cpp (tests/test_gpu_build.py).
 #include <hipcub/hipcub.hpp>
 
+#include <mutex>
 #include <vector>
 
 #include "bft_dev.h"
@@ -30,25 +31,85 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
+// Counts the host needs (array sizes, format limits) come back through a pinned block that kernels write: the scans and checks
+// of a stage are enqueued together and share ONE stream synchronisation (a total fetched by hipMemcpyAsync into pageable memory is
+// two staged copies and a synchronisation of its own: ~60 us each, sixteen per trie level).
+constexpr int PIN_SLOTS = 32;
+struct PinBlock {
+    uint64_t* p = nullptr;
+    PinBlock() {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (!cache().empty()) { p = cache().back(); cache().pop_back(); }
+        }
+        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+    }
+    ~PinBlock() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu());
+        cache().push_back(p);  // (a handful of 256-byte blocks per process, kept)
+    }
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<uint64_t*>& cache() { static std::vector<uint64_t*> c; return c; }
+};
+
+__global__ void k_scan_total(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, uint64_t* __restrict__ slot, int tail) {
+    const uint64_t t = (uint64_t)in[n - 1] + out[n - 1];
+    *slot = t;
+    if (tail) out[n] = (uint32_t)t;  // (the offsets array has n + 1 entries)
+}
+__global__ void k_set32(uint32_t* __restrict__ p, uint32_t v) { *p = v; }
+__global__ void k_publish(const uint32_t* __restrict__ v, int n, uint64_t* __restrict__ slots) {
+    if ((int)threadIdx.x < n) slots[threadIdx.x] = v[threadIdx.x];
+}
+
 struct Scan {
     DevBuf tmp;
     hipStream_t s;
+    PinBlock pin;
     explicit Scan(hipStream_t st) : s(st) {}
-    // out = exclusive sum of in (u32), returns total in *total
-    int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {
-        if (n == 0) { if (total) *total = 0; return 0; }
+    // out = exclusive sum of in (u32); the total lands in slot `slot` of the pinned block once the stream gets there
+    // tail: out[n] = total as well
+    int enqueue(const uint32_t* in, uint32_t* out, uint64_t n, int slot, bool tail = false) {
+        if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (scan totals)");
+        if (n == 0) {  // (the slot is not in flight: wait() precedes every reuse)
+            pin.p[slot] = 0;
+            if (tail) hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, out, 0u);
+            return 0;
+        }
         size_t tb = 0;
         HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
         if (tb > tmp.bytes) CK(tmp.alloc(tb));
         tb = tmp.bytes;
         HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
-        if (total) {
-            uint32_t a = 0, b = 0;
-            HIPCK(hipMemcpyAsync(&a, in + n - 1, 4, hipMemcpyDeviceToHost, s));
-            HIPCK(hipMemcpyAsync(&b, out + n - 1, 4, hipMemcpyDeviceToHost, s));
-            HIPCK(hipStreamSynchronize(s));
-            *total = (uint64_t)a + b;
+        hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, in, out, n, pin.p + slot, tail ? 1 : 0);
+        return 0;
+    }
+    // n <= PIN_SLOTS device words -> slots [slot, slot + n)
+    int publish(const uint32_t* d_vals, int n, int slot) {
+        if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (scan totals)");
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(PIN_SLOTS), 0, s, d_vals, n, pin.p + slot);
+        return 0;
+    }
+    int wait() {
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));
+        return 0;
+    }
+    uint64_t get(int slot) const { return pin.p[slot]; }
+    int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {
+        if (!total) {
+            if (n == 0) return 0;
+            size_t tb = 0;
+            HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
+            if (tb > tmp.bytes) CK(tmp.alloc(tb));
+            tb = tmp.bytes;
+            HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
+            return 0;
         }
+        CK(enqueue(in, out, n, 0));
+        CK(wait());
+        *total = get(0);
         return 0;
     }
 };
@@ -121,6 +182,34 @@ __global__ void k_counts(const uint32_t* __restrict__ start, const uint32_t* __r
         const uint32_t m = node[i];
         const uint32_t end = (i + 1 < n && node[i + 1] == m) ? start[i + 1] : nd_hi[m];
         cnt[i] = end - start[i];
+    }
+}
+
+// format limits and counters, reduced on the device (one atomic per wavefront)
+__global__ void k_ncc_limits(const uint32_t* __restrict__ node_ncc, uint32_t M, uint32_t* __restrict__ lim) {
+    uint32_t mx = 0;
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) mx = max(mx, node_ncc[m]);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o));
+    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&lim[0], mx);
+    if (blockIdx.x == 0 && threadIdx.x == 0) lim[1] = node_ncc[0];
+}
+__global__ void k_nb_limits(const uint32_t* __restrict__ cc_nb, uint32_t C, uint32_t* __restrict__ lim) {
+    uint32_t mx = 0, sum = 0, big = 0;  // (the prefixes of one depth are fewer than 2^32: they index u32 arrays)
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const uint32_t v = cc_nb[c];
+        mx = max(mx, v);
+        sum += v;
+        big += v >= BFT_TRESH_SUF_PREF;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_down(mx, o));
+        sum += __shfl_down(sum, o);
+        big += __shfl_down(big, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (mx) atomicMax(&lim[0], mx);
+        if (sum) atomicAdd(&lim[1], sum);
+        if (big) atomicAdd(&lim[2], big);
     }
 }
 
@@ -434,12 +523,9 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(nsz.alloc(M * 4));
         CK(node_off.alloc((M + 1) * 4));
         hipLaunchKernelGGL(k_sizes, G(M), nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), nsz.as<uint32_t>(), (uint32_t)M);
-        uint64_t A = 0;
-        CK(scan.run(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, &A));
-        {
-            const uint32_t a32 = (uint32_t)A;
-            HIPCK(hipMemcpyAsync(node_off.as<uint32_t>() + M, &a32, 4, hipMemcpyHostToDevice, s));
-        }
+        CK(scan.enqueue(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, 0, true));
+        CK(scan.wait());
+        const uint64_t A = scan.get(0);
         // ---- prefixes and keys ----
         DevBuf head, khead, ppos, kpos;
         CK(head.alloc(A * 4));
@@ -450,8 +536,11 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         if (A) {
             hipLaunchKernelGGL(k_prefix_flags<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
                                head.as<uint32_t>(), khead.as<uint32_t>());
-            CK(scan.run(head.as<uint32_t>(), ppos.as<uint32_t>(), A, &P));
-            CK(scan.run(khead.as<uint32_t>(), kpos.as<uint32_t>(), A, &K));
+            CK(scan.enqueue(head.as<uint32_t>(), ppos.as<uint32_t>(), A, 0));
+            CK(scan.enqueue(khead.as<uint32_t>(), kpos.as<uint32_t>(), A, 1));
+            CK(scan.wait());
+            P = scan.get(0);
+            K = scan.get(1);
         }
         DevBuf pref_r, pref_row, pref_node, pref_key, pref_cnt, key_val, key_row, key_node, key_cnt, node_kb;
         CK(pref_r.alloc(P * 4));
@@ -467,8 +556,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         {
             // nodes of an empty trie (n == 0) have no keys: node_kb = 0
             HIPCK(hipMemsetAsync(node_kb.p, 0, (M + 1) * 4, s));
-            const uint32_t k32 = (uint32_t)K;
-            HIPCK(hipMemcpyAsync(node_kb.as<uint32_t>() + M, &k32, 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, node_kb.as<uint32_t>() + M, (uint32_t)K);
         }
         if (A) {
             hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
@@ -495,28 +583,23 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(ubb.alloc((M + 1) * 4));
         HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
         hipLaunchKernelGGL(k_cc_upper, G(M), nsz.as<uint32_t>(), (uint32_t)M, ub.as<uint32_t>());
-        uint64_t CU = 0;
-        CK(scan.run(ub.as<uint32_t>(), ubb.as<uint32_t>(), M, &CU));
-        CK(cc_bits.alloc(CU * 48 * 4));
+        CK(scan.run(ub.as<uint32_t>(), ubb.as<uint32_t>(), M, nullptr));
+        CK(cc_bits.alloc((A / BFT_NB_KMERS_PER_UC + M) * 48 * 4));  // (the sum of the upper bounds is at most that: no count to wait for)
         const dim3 ngrid((unsigned)std::min<uint64_t>(M, 65535ull * 16));
         hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
                            nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
                            ubb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
-        uint64_t C = 0;
-        CK(scan.run(node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), M, &C));
-        {
-            const uint32_t c32 = (uint32_t)C;
-            HIPCK(hipMemcpyAsync(node_ccb.as<uint32_t>() + M, &c32, 4, hipMemcpyHostToDevice, s));
-        }
         // limits (format): CCs per node, Bloom slice width
-        std::vector<uint32_t> h_ncc(M);
-        HIPCK(hipMemcpyAsync(h_ncc.data(), node_ncc.p, M * 4, hipMemcpyDeviceToHost, s));
-        HIPCK(hipStreamSynchronize(s));
-        for (uint64_t m = 0; m < M; m++) {
-            if (h_ncc[m] > 2040) return bft_fail(BFT_GPU_E_LIMIT, "node with too many CCs for bf_wb");
-            out.max_ccs_per_node = std::max<uint64_t>(out.max_ccs_per_node, h_ncc[m]);
-        }
-        if (d == 0) out.root_ncc = h_ncc[0];
+        DevBuf lim;  // [0] largest number of CCs in a node, [1] that of node 0, [2] largest CC, [3] prefixes, [4] CCs with >= BFT_TRESH_SUF_PREF, [5] UC rows of node 0
+        CK(lim.alloc_zero(8 * 4, s));
+        hipLaunchKernelGGL(k_ncc_limits, G(M), node_ncc.as<uint32_t>(), (uint32_t)M, lim.as<uint32_t>());
+        CK(scan.enqueue(node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), M, 0, true));
+        CK(scan.publish(lim.as<uint32_t>(), 2, 1));
+        CK(scan.wait());
+        const uint64_t C = scan.get(0);
+        if (scan.get(1) > 2040) return bft_fail(BFT_GPU_E_LIMIT, "node with too many CCs for bf_wb");
+        out.max_ccs_per_node = std::max<uint64_t>(out.max_ccs_per_node, scan.get(1));
+        if (d == 0) out.root_ncc = scan.get(2);
 
         // ---- prefixes grouped by (node, cc) ----
         DevBuf skey, skey_s, iota, sp;
@@ -534,8 +617,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             DevBuf tmp;
             CK(tmp.alloc(tb));
             HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
-            HIPCK(hipStreamSynchronize(s));
-        }
+        }  // (no synchronisation: what is released here is only handed out again in the order of this stream, bft_pool_alloc)
         skey.release(); iota.release();
 
         // ---- CC runs, clusters ----
@@ -550,20 +632,12 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(cc_f2.alloc(C * 4));
         if (P) hipLaunchKernelGGL(k_runs, G(P), skey_s.as<uint64_t>(), (uint32_t)P, node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_qe.as<uint32_t>(),
                                   uc_qb.as<uint32_t>(), uc_qe.as<uint32_t>());
-        uint64_t F2 = 0;
         if (C) {
             hipLaunchKernelGGL(k_cc_meta, G(C), cc_qb.as<uint32_t>(), cc_qe.as<uint32_t>(), (uint32_t)C, cc_nb.as<uint32_t>(), cc_s.as<uint32_t>(),
                                cc_nwords.as<uint32_t>());
-            CK(scan.run(cc_nwords.as<uint32_t>(), cc_f2.as<uint32_t>(), C, &F2));
-            std::vector<uint32_t> h_nb(C);
-            HIPCK(hipMemcpyAsync(h_nb.data(), cc_nb.p, C * 4, hipMemcpyDeviceToHost, s));
-            HIPCK(hipStreamSynchronize(s));
-            for (uint64_t c = 0; c < C; c++) {
-                if (h_nb[c] > 65535) return bft_fail(BFT_GPU_E_LIMIT, "CC with more than 65535 prefixes (nb_elem is uint16, include/CC.h:36)");
-                out.n_prefixes += h_nb[c];
-                if (h_nb[c] >= BFT_TRESH_SUF_PREF) out.n_ccs_s4++;
-            }
+            hipLaunchKernelGGL(k_nb_limits, G(C), cc_nb.as<uint32_t>(), (uint32_t)C, lim.as<uint32_t>() + 2);
         }
+        CK(scan.enqueue(cc_nwords.as<uint32_t>(), cc_f2.as<uint32_t>(), C, 0));  // (read with the cluster counts below)
         DevBuf chead, pend, ucn, cidx, nrank, ucpos;
         CK(chead.alloc(P * 4));
         CK(pend.alloc(P * 4));
@@ -571,15 +645,20 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(cidx.alloc(P * 4));
         CK(nrank.alloc(P * 4));
         CK(ucpos.alloc(P * 4));
-        uint64_t Q = 0, Mnext = 0, UCR = 0;
         if (P) {
             hipLaunchKernelGGL(k_cluster_flags, G(P), skey_s.as<uint64_t>(), sp.as<uint32_t>(), pref_r.as<uint32_t>(), pref_cnt.as<uint32_t>(), (uint32_t)P,
                                node_ccb.as<uint32_t>(), cc_qb.as<uint32_t>(), cc_s.as<uint32_t>(), last_level, chead.as<uint32_t>(), pend.as<uint32_t>(),
                                ucn.as<uint32_t>());
-            CK(scan.run(chead.as<uint32_t>(), cidx.as<uint32_t>(), P, &Q));
-            CK(scan.run(pend.as<uint32_t>(), nrank.as<uint32_t>(), P, &Mnext));
-            CK(scan.run(ucn.as<uint32_t>(), ucpos.as<uint32_t>(), P, &UCR));
         }
+        CK(scan.enqueue(chead.as<uint32_t>(), cidx.as<uint32_t>(), P, 1));
+        CK(scan.enqueue(pend.as<uint32_t>(), nrank.as<uint32_t>(), P, 2));
+        CK(scan.enqueue(ucn.as<uint32_t>(), ucpos.as<uint32_t>(), P, 3));
+        CK(scan.publish(lim.as<uint32_t>() + 2, 3, 4));
+        CK(scan.wait());
+        const uint64_t F2 = scan.get(0), Q = scan.get(1), Mnext = scan.get(2), UCR = scan.get(3);
+        if (scan.get(4) > 65535) return bft_fail(BFT_GPU_E_LIMIT, "CC with more than 65535 prefixes (nb_elem is uint16, include/CC.h:36)");
+        out.n_prefixes += scan.get(5);
+        out.n_ccs_s4 += scan.get(6);
         DevBuf clus_q, clus_len, multi, cpos;
         CK(clus_q.alloc(Q * 4));
         CK(clus_len.alloc(Q * 4));
@@ -627,9 +706,12 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(node_bfoff.alloc(M * 4));
         hipLaunchKernelGGL(k_node_meta, G(M), node_ncc.as<uint32_t>(), uc_qb.as<uint32_t>(), uc_qe.as<uint32_t>(), ucpos.as<uint32_t>(), ucn.as<uint32_t>(),
                            (uint32_t)M, node_ucn.as<uint32_t>(), node_bf8.as<uint32_t>());
-        uint64_t BF8 = 0, ucchk = 0;
-        CK(scan.run(node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(), M, &ucchk));
-        CK(scan.run(node_bf8.as<uint32_t>(), node_bfoff.as<uint32_t>(), M, &BF8));
+        CK(scan.run(node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(), M, nullptr));
+        CK(scan.enqueue(node_bf8.as<uint32_t>(), node_bfoff.as<uint32_t>(), M, 0));
+        if (d == 0) CK(scan.publish(node_ucn.as<uint32_t>(), 1, 1));
+        CK(scan.wait());
+        const uint64_t BF8 = scan.get(0);
+        if (d == 0) out.root_uc = scan.get(1);
         if (T_bf8 + BF8 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "Bloom block offset overflow");
         CK(sg.bfT.alloc(BF8 * 8));
         hipLaunchKernelGGL(k_node_records, G(M), node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(),
@@ -637,13 +719,6 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         if (BF8) hipLaunchKernelGGL(k_bloom_slice, ngrid, dim3(ABLK), 0, s, node_ncc.as<uint32_t>(), ubb.as<uint32_t>(), node_bfoff.as<uint32_t>(),
                                     cc_bits.as<uint32_t>(), (uint32_t)M, sg.bfT.as<uint8_t>());
         HIPCK(hipGetLastError());
-        if (d == 0) {
-            uint32_t ru = 0;
-            HIPCK(hipMemcpyAsync(&ru, node_ucn.p, 4, hipMemcpyDeviceToHost, s));
-            HIPCK(hipStreamSynchronize(s));
-            out.root_uc = ru;
-        }
-        HIPCK(hipStreamSynchronize(s));
         sg.n_nodes = M; sg.n_bf8 = BF8; sg.n_ccs = C; sg.n_f2w = F2; sg.n_clus = Q; sg.n_child = E; sg.n_uc = UCR;
         T_nodes += M; T_ccs += C; T_f2w += F2; T_clus += Q; T_child += E; T_bf8 += BF8; T_uc += UCR;
         out.n_child_nodes += Mnext;

@@ -80,12 +80,17 @@ struct PoolBlock {
 std::mutex g_pool_mu;
 std::vector<PoolBlock> g_pool;
 size_t g_pool_bytes = 0;
-// cached, unused memory kept at most (per process): 8 GiB unless BFT_GPU_POOL_MAX_MB says otherwise (0 = no cache);
-// torch's allocator cannot see these blocks, so the cap bounds what the library withholds from it
+// cached, unused memory kept at most (per process): an eighth of the device's memory (36 GB of an MI355X's 288: the transients of a
+// 2 x 10^8-pair build are ~12 GB, and a hipFree of a gigabyte block costs a device synchronisation and ~0.2 ms), 8 GiB at least,
+// unless BFT_GPU_POOL_MAX_MB says otherwise (0 = no cache); torch's allocator cannot see these blocks, so the cap bounds what the
+// library withholds from it
 size_t pool_max_bytes() {
     static const size_t v = [] {
         const char* e = getenv("BFT_GPU_POOL_MAX_MB");
-        return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)8 << 30;
+        if (e) return (size_t)strtoull(e, nullptr, 10) << 20;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
+        return std::max<size_t>((size_t)8 << 30, tot / 8);
     }();
     return v;
 }
