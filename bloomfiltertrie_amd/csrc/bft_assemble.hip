@@ -526,6 +526,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(scan.enqueue(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, 0, true));
         CK(scan.wait());
         const uint64_t A = scan.get(0);
+        bft_trace_mark("  level: active rows");
         // ---- prefixes and keys ----
         DevBuf head, khead, ppos, kpos;
         CK(head.alloc(A * 4));
@@ -542,6 +543,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             P = scan.get(0);
             K = scan.get(1);
         }
+        bft_trace_mark("  level: prefix flags + scans");
         DevBuf pref_r, pref_row, pref_node, pref_key, pref_cnt, key_val, key_row, key_node, key_cnt, node_kb;
         CK(pref_r.alloc(P * 4));
         CK(pref_row.alloc(P * 4));
@@ -567,9 +569,6 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             hipLaunchKernelGGL(k_counts, G(K), key_row.as<uint32_t>(), key_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)K, key_cnt.as<uint32_t>());
         }
         head.release(); khead.release(); ppos.release(); kpos.release();
-        // (the two passes over the whole table are enqueued: what follows is a chain of small kernels and counts read back, which
-        // leaves most of the GPU to whatever the caller starts beside it now)
-        if (d == 0 && hook && hook->after_table_passes) hook->after_table_passes(hook->ctx, s);
 
         // ---- CC assignment: one pass.  A node opens a CC only while >= 255 k-mers are unassigned and every CC but the last claims at
         // least 255, so a node of U k-mers holds at most U / 255 + 1 CCs: the Bloom bitsets are written at those upper-bound slots
@@ -600,6 +599,11 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         if (scan.get(1) > 2040) return bft_fail(BFT_GPU_E_LIMIT, "node with too many CCs for bf_wb");
         out.max_ccs_per_node = std::max<uint64_t>(out.max_ccs_per_node, scan.get(1));
         if (d == 0) out.root_ncc = scan.get(2);
+        bft_trace_mark("  level: scatter, CC assignment");
+        // (the passes over the whole table and the root's CC assignment -- ONE workgroup claiming CC after CC, bound by latency: 0.8 ms
+        // alone, 3.5 ms beside a kernel that saturates the memory system -- are done: what follows is a chain of small kernels and
+        // counts read back, which leaves most of the GPU to whatever the caller starts beside it now)
+        if (d == 0 && hook && hook->after_table_passes) hook->after_table_passes(hook->ctx, s);
 
         // ---- prefixes grouped by (node, cc) ----
         DevBuf skey, skey_s, iota, sp;
@@ -659,6 +663,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         if (scan.get(4) > 65535) return bft_fail(BFT_GPU_E_LIMIT, "CC with more than 65535 prefixes (nb_elem is uint16, include/CC.h:36)");
         out.n_prefixes += scan.get(5);
         out.n_ccs_s4 += scan.get(6);
+        bft_trace_mark("  level: sort by (node, CC), runs, cluster flags");
         DevBuf clus_q, clus_len, multi, cpos;
         CK(clus_q.alloc(Q * 4));
         CK(clus_len.alloc(Q * 4));
@@ -671,6 +676,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                clus_len.as<uint32_t>(), multi.as<uint32_t>());
             CK(scan.run(multi.as<uint32_t>(), cpos.as<uint32_t>(), Q, &E));
         }
+        bft_trace_mark("  level: clusters");
         if (T_f2w + F2 > 0xFFFFFFFFull || T_clus + Q > 0xFFFFFFFFull || T_child + E > 0xFFFFFFFFull || T_uc + UCR > 0xFFFFFFFFull)
             return bft_fail(BFT_GPU_E_LIMIT, "index array offset overflow (u32)");
 
@@ -712,6 +718,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(scan.wait());
         const uint64_t BF8 = scan.get(0);
         if (d == 0) out.root_uc = scan.get(1);
+        bft_trace_mark("  level: entries, node records");
         if (T_bf8 + BF8 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "Bloom block offset overflow");
         CK(sg.bfT.alloc(BF8 * 8));
         hipLaunchKernelGGL(k_node_records, G(M), node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(),
@@ -992,6 +999,129 @@ __global__ __launch_bounds__(ABLK) void k_cs_verify(const uint32_t* __restrict__
     }
 }
 
+// ---- interning by a hash of the signatures ----
+// The lists of a pan-genome repeat massively (config 3: 4.5 x 10^7 k-mers, 1.6 x 10^6 distinct lists, and nine k-mers in ten carry one
+// of the 100 one-genome lists): every k-mer looks its signature up in an open-addressed table -- the popular lists are L2 hits --,
+// the few distinct signatures are sorted (that order numbers the sets, whichever thread inserted first), and the first k-mer to claim
+// a slot lends the dictionary its list.  Sorting every k-mer's signature instead (6 radix passes over 4.5 x 10^7 pairs, then gathers
+// in that order) was 3.5 ms of config 3's 6.5.
+struct CsSlot {
+    unsigned long long sig;  // 0: free
+    uint32_t rep;            // a k-mer with this signature
+    uint32_t id;             // number of the set
+};
+__device__ __forceinline__ unsigned long long cs_key(uint64_t sig) { return sig ? sig : 0x9E3779B97F4A7C15ULL; }
+
+// (Nine lookups in ten ask for one of a hundred slots: as device-scope atomic loads those queue up at the few memory channels that
+// own them -- 13 ms.  Each workgroup therefore remembers, in LDS, the slot where a signature was last found; a remembered slot is
+// confirmed by an ordinary cached load of its signature, which is immutable once claimed -- a stale view can only show the slot free
+// and sends the lookup down the atomic path.)
+#define CS_CACHE 2048u
+__global__ __launch_bounds__(ABLK) void k_cs_hash_insert(const uint64_t* __restrict__ sig, uint32_t nk, CsSlot* __restrict__ tab, uint32_t mask,
+                                                         uint32_t* __restrict__ slot_of,
+                                                         uint32_t* __restrict__ counters) {  // [0] slots claimed, [1] lookups that gave up (table too full)
+    __shared__ uint32_t cache[CS_CACHE];
+    __shared__ uint32_t s_new, s_fail;  // (one global atomic per workgroup at the end: 10^6 atomics on ONE address take 10 ns each)
+    for (uint32_t j = threadIdx.x; j < CS_CACHE; j += blockDim.x) cache[j] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) { s_new = 0; s_fail = 0; }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = cs_key(sig[i]);
+        const uint32_t ch = (uint32_t)(key >> 40) & (CS_CACHE - 1u);
+        const uint32_t cand = cache[ch];
+        if (cand != 0xFFFFFFFFu && tab[cand].sig == key) {
+            slot_of[i] = cand;
+            continue;
+        }
+        uint32_t pos = (uint32_t)key & mask;
+        uint32_t found = 0xFFFFFFFFu;
+        for (int probe = 0; probe < 256; probe++) {
+            unsigned long long cur = __hip_atomic_load(&tab[pos].sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                cur = atomicCAS(&tab[pos].sig, 0ull, key);
+                if (cur == 0ull) {
+                    tab[pos].rep = i;
+                    atomicAdd(&s_new, 1u);
+                    cur = key;
+                }
+            }
+            if (cur == key) { found = pos; break; }
+            pos = (pos + 1u) & mask;
+        }
+        if (found == 0xFFFFFFFFu) atomicAdd(&s_fail, 1u);
+        else cache[ch] = found;
+        slot_of[i] = found;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_new) atomicAdd(&counters[0], s_new);
+        if (s_fail) atomicAdd(&counters[1], s_fail);
+    }
+}
+
+// the claimed slots, in any order: every workgroup counts its share of the table, reserves that many places with one atomic, writes
+__global__ __launch_bounds__(ABLK) void k_cs_hash_compact(const CsSlot* __restrict__ tab, uint32_t n_slots, uint64_t* __restrict__ keys, uint32_t* __restrict__ slots,
+                                                          uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t per = (n_slots + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * per, p1 = min(n_slots, p0 + per);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) mine += tab[p].sig != 0ull;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base = s_cnt ? atomicAdd(cnt, s_cnt) : 0u; s_cnt = 0; }
+    __syncthreads();
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const unsigned long long v = tab[p].sig;
+        if (v != 0ull) {
+            const uint32_t j = s_base + atomicAdd(&s_cnt, 1u);
+            keys[j] = v;
+            slots[j] = p;
+        }
+    }
+}
+
+// r-th signature in order: the set's number, its representative and the length of its list
+__global__ void k_cs_hash_ids(const uint32_t* __restrict__ slots_s, uint32_t n_sets, CsSlot* __restrict__ tab, const uint32_t* __restrict__ seg_off,
+                              uint32_t* __restrict__ rep, uint32_t* __restrict__ len) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_sets; r += gridDim.x * blockDim.x) {
+        CsSlot* sl = tab + slots_s[r];
+        sl->id = r;
+        const uint32_t a = sl->rep;
+        rep[r] = a;
+        len[r] = seg_off[a + 1] - seg_off[a];
+    }
+}
+
+// dictionary entries: the lanes of a wavefront copy each representative's list together, 64 ids at a time
+__global__ __launch_bounds__(ABLK) void k_cs_hash_copy(const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cs_off, uint32_t n_sets, const uint32_t* __restrict__ seg_off,
+                                                       const uint32_t* __restrict__ pg, uint32_t* __restrict__ cs_ids) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nblk = (n_sets + ABLK - 1) / ABLK;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint32_t r = blk * ABLK + threadIdx.x;
+        uint32_t src = 0, len = 0, dst = 0;
+        if (r < n_sets) {
+            src = seg_off[rep[r]];
+            dst = cs_off[r];
+            len = cs_off[r + 1] - dst;
+        }
+        uint64_t todo = __ballot(len != 0);
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t s0 = __shfl(src, t), l0 = __shfl(len, t), d0 = __shfl(dst, t);
+            for (uint32_t j = lane; j < l0; j += 64) cs_ids[d0 + j] = pg[s0 + j];
+        }
+    }
+}
+
+__global__ void k_cs_hash_tcol(const uint32_t* __restrict__ slot_of, const CsSlot* __restrict__ tab, uint32_t nk, uint32_t* __restrict__ tcol) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) tcol[i] = tab[slot_of[i]].id;
+}
+
 }  // namespace
 
 static bool g_weak_signature = false;
@@ -1047,11 +1177,11 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
     return 0;
 }
 
-// Interning of the colour sets (sorted genome-id list of each distinct k-mer, CSR seg_off/pg) into a dictionary:
-// signature -> radix sort -> run heads by EXACT list comparison with the predecessor -> ids; then a verification
-// pass over every k-mer.  Two different sets can never share an id (the comparison is exact); two equal sets get
-// the same id whenever they are adjacent after the sort, which only a 64-bit signature collision can prevent
-// (that would cost a duplicate dictionary entry, never a wrong answer).
+// Interning of the colour sets (sorted genome-id list of each distinct k-mer, CSR seg_off/pg) into a dictionary: a 64-bit signature
+// per list, equal signatures found through a hash table (k_cs_hash_*), sets numbered in the order of their signatures, then a
+// verification pass that compares EVERY k-mer's list with the dictionary entry it was given.  A mismatch -- two different lists with
+// one signature -- sends the build through the sorted path, where runs of equal lists are found by comparing the lists themselves.
+// Two different sets can therefore never share an id, and two equal sets always do.
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
                           DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids) {
     n_sets = 0;
@@ -1064,17 +1194,77 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
         return 0;
     }
     Scan scan(s);
-    DevBuf sig, sig_s, iota, order, head, len, csid, off, tmp, bad;
+    DevBuf sig, iota, bad;
     CK(sig.alloc(nk * 8));
-    CK(sig_s.alloc(nk * 8));
     CK(iota.alloc(nk * 4));
+    CK(bad.alloc(4));
+    uint32_t nbad = 0;
+    const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
+    hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, g_weak_signature ? 1 : 0, sig.as<uint64_t>(), iota.as<uint32_t>());
+
+    // ---- by a hash of the signatures (kernels above).  The table starts at nk / 8 slots (a pan-genome has far fewer distinct lists than
+    // k-mers) and is retried at 2 nk when more than half of it fills: then every list may be distinct. ----
+    bool done = false;
+    {
+        DevBuf tab, slot_of, cnt, keys, keys_s, slots, slots_s, rep, len, tmp;
+        CK(slot_of.alloc(nk * 4));
+        CK(cnt.alloc(3 * 4));
+        uint64_t n_slots = 1ull << 16;
+        while (n_slots < nk / 8) n_slots <<= 1;
+        for (int attempt = 0; attempt < 2 && !done; attempt++) {
+            if (attempt) {
+                while (n_slots < 2 * nk) n_slots <<= 1;
+            }
+            CK(tab.alloc_zero(n_slots * sizeof(CsSlot), s));
+            HIPCK(hipMemsetAsync(cnt.p, 0, 12, s));
+            hipLaunchKernelGGL(k_cs_hash_insert, grid, block, 0, s, sig.as<uint64_t>(), (uint32_t)nk, tab.as<CsSlot>(), (uint32_t)(n_slots - 1), slot_of.as<uint32_t>(),
+                               cnt.as<uint32_t>());
+            CK(scan.publish(cnt.as<uint32_t>(), 2, 0));
+            CK(scan.wait());
+            if (scan.get(1) == 0 && scan.get(0) * 2 <= n_slots) done = true;
+            else if (n_slots >= 2 * nk) break;  // (cannot happen: at most nk signatures in 2 nk slots)
+        }
+        if (done) {
+            n_sets = scan.get(0);
+            CK(keys.alloc(n_sets * 8));
+            CK(keys_s.alloc(n_sets * 8));
+            CK(slots.alloc(n_sets * 4));
+            CK(slots_s.alloc(n_sets * 4));
+            CK(rep.alloc(n_sets * 4));
+            CK(len.alloc(n_sets * 4));
+            const dim3 tgrid(bft_grid_for((n_slots + ABLK - 1) / ABLK)), sgrid(bft_grid_for((n_sets + ABLK - 1) / ABLK));
+            hipLaunchKernelGGL(k_cs_hash_compact, tgrid, block, 0, s, tab.as<CsSlot>(), (uint32_t)n_slots, keys.as<uint64_t>(), slots.as<uint32_t>(), cnt.as<uint32_t>() + 2);
+            size_t tb = 0;
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
+            CK(tmp.alloc(tb));
+            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
+            hipLaunchKernelGGL(k_cs_hash_ids, sgrid, block, 0, s, slots_s.as<uint32_t>(), (uint32_t)n_sets, tab.as<CsSlot>(), d_seg_off, rep.as<uint32_t>(), len.as<uint32_t>());
+            CK(d_cs_off.alloc((n_sets + 1) * 4));
+            CK(scan.enqueue(len.as<uint32_t>(), d_cs_off.as<uint32_t>(), n_sets, 0, true));
+            hipLaunchKernelGGL(k_cs_hash_tcol, grid, block, 0, s, slot_of.as<uint32_t>(), tab.as<CsSlot>(), (uint32_t)nk, d_tcol.as<uint32_t>());
+            CK(scan.wait());
+            n_ids = scan.get(0);
+            CK(d_cs_ids.alloc(n_ids * 4));
+            hipLaunchKernelGGL(k_cs_hash_copy, sgrid, block, 0, s, rep.as<uint32_t>(), d_cs_off.as<uint32_t>(), (uint32_t)n_sets, d_seg_off, d_pg, d_cs_ids.as<uint32_t>());
+            HIPCK(hipMemsetAsync(bad.p, 0, 4, s));
+            hipLaunchKernelGGL(k_cs_verify, grid, block, 0, s, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
+                               bad.as<uint32_t>());
+            CK(scan.publish(bad.as<uint32_t>(), 1, 1));
+            CK(scan.wait());
+            nbad = (uint32_t)scan.get(1);
+            done = nbad == 0;  // (else: two different lists with one signature -- the sorted path below compares the lists)
+        }
+    }
+    if (done) return 0;
+
+    // ---- by a sort of every k-mer's signature: equal lists next to each other, runs found by comparison ----
+    DevBuf sig_s, order, head, len, csid, off, tmp;
+    CK(sig_s.alloc(nk * 8));
     CK(order.alloc(nk * 4));
     CK(head.alloc(nk * 4));
     CK(len.alloc(nk * 4));
     CK(csid.alloc(nk * 4));
     CK(off.alloc(nk * 4));
-    const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
-    hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, g_weak_signature ? 1 : 0, sig.as<uint64_t>(), iota.as<uint32_t>());
     // Equal lists only have to end up next to each other: the low 48 bits of the signature order them (6 radix passes instead
     // of 8).  Two different lists that agree on those bits could at worst split a run of equal lists, i.e. cost a duplicate
     // dictionary entry (expected once in ~10^14 / n_sets^2 builds); k_cs_heads still compares whole signatures and lists.
@@ -1084,9 +1274,8 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
     CK(tmp.alloc(tb));
     HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
-    uint32_t nbad = 0;
-    CK(bad.alloc(4));
-    for (int exact = 0; exact < 2; exact++) {
+    for (int exact = 1; exact < 2; exact++) {
+        g_exact_passes++;
         hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, exact, head.as<uint32_t>(), len.as<uint32_t>());
         CK(scan.run(head.as<uint32_t>(), csid.as<uint32_t>(), nk, &n_sets));
         CK(scan.run(len.as<uint32_t>(), off.as<uint32_t>(), nk, &n_ids));
@@ -1104,8 +1293,6 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
         HIPCK(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, s));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(s));
-        if (nbad == 0) break;  // (else: a signature collision -- once more with the lists compared)
-        g_exact_passes++;
     }
     if (nbad) return bft_fail(BFT_GPU_E_LIMIT, "colour-set interning self-check failed");
     (void)np;

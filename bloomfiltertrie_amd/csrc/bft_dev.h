@@ -77,7 +77,7 @@ struct BftDeviceIndex {
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0, root_ncc = 0, root_uc = 0;
 };
 void bft_trace_mark(const char* what);  // BFT_GPU_TRACE_BUILD=1 (nullptr: start of a build)
-// after_table_passes: called once, when the first level's passes over the whole sorted table are enqueued on `s`
+// after_table_passes: called once, when the first level's passes over the whole sorted table and its CC assignment are done on `s`
 struct BftAssembleHook {
     void (*after_table_passes)(void* ctx, hipStream_t s);
     void* ctx;

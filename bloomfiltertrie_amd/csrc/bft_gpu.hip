@@ -797,10 +797,10 @@ static void derive_node_hash(bft_gpu* h) {
 }
 
 // The fill of the k-mer hash for a table (tk, tcol) that is complete on the device, started on the handle's second stream: the build
-// assembles the containers on `stream` meanwhile.  The fill is bound by L2 misses and atomics and starves a streaming kernel beside
-// it (k_prefix_flags over the whole table: 0.2 ms alone, 2.8 ms beside the fill), so it starts behind the assembly's two passes over
-// the table (`after`: an event of the assembly stream) and overlaps the chain of small kernels and read-back counts that follows.
-// kh_finish waits for it.  Any failure just leaves the image without the table.
+// assembles the containers on `stream` meanwhile.  The fill is bound by L2 misses and atomics and starves what runs beside it of
+// memory bandwidth and latency (k_prefix_flags over the whole table: 0.2 ms alone, 2.8 ms beside the fill; the root's single-workgroup
+// k_assign_cc: 0.8 -> 3.5 ms), so it starts behind those (`after`: an event of the assembly stream) and overlaps the chain of small
+// kernels and read-back counts that follows.  kh_finish waits for it.  Any failure just leaves the image without the table.
 struct KhFill {
     DevBuf buf;
     uint64_t lines = 0;
