@@ -444,3 +444,25 @@ def test_dictionary_id_width_follows_the_largest_genome_id():
     assert mt == {kk: tuple(v) for kk, v in truth.items()}
     t.close()
     b.close()
+
+
+def test_interning_when_nearly_every_colour_set_is_distinct():
+    """The interning's hash table starts small (a pan-genome has few distinct lists) and is retried at twice the number of k-mers when
+    it fills beyond half: 60 000 k-mers with random subsets of 40 genomes carry ~60 000 distinct sets, more than half of the first
+    table.  Sets, their number and every k-mer's set equal ground truth."""
+    k = 27
+    base = S.distinct(S.kmers_of(S.random_genome(60000 + k - 1, 77), k))
+    rng = np.random.default_rng(5)
+    member = rng.random((40, len(base))) < 0.5
+    member[0, ~member.any(axis=0)] = True  # every k-mer is in some genome
+    t = BFT(k)
+    before = t.build_time()["intern_exact_passes"]
+    for g in range(40):
+        t.insert_kmers(np.ascontiguousarray(base[member[g]]), g)
+    t.build()
+    assert t.build_time()["intern_exact_passes"] == before  # (the retry is not the exact fallback)
+    truth = {base[i].tobytes(): tuple(np.flatnonzero(member[:, i]).tolist()) for i in range(len(base))}
+    got, nsets = _colour_map(t)
+    assert got == truth
+    assert nsets == len(set(truth.values())) == t.info()["colorsets"] and nsets > 40000
+    t.close()
