@@ -43,8 +43,17 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbit
     return m;
 }
 
+// vals != nullptr: c holds whole T-form k-mers grouped by their top bits and vals the genome id of each (vw bytes wide); the composite
+// (T's bits below the split) << lo_bit | genome is formed here -- the top bits are the bucket's number, so a k-mer of up to 64 - lo_bit
+// bits below the split fits whatever the number of genomes (k = 31: 44 bits and up to 2^20 genomes) -- and goes back into c.
+__device__ __forceinline__ uint64_t load_id(const void* vals, uint32_t vw, uint64_t i) {
+    if (vw == 1) return reinterpret_cast<const uint8_t*>(vals)[i];
+    if (vw == 2) return reinterpret_cast<const uint16_t*>(vals)[i];
+    return reinterpret_cast<const uint32_t*>(vals)[i];
+}
+
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
-                                                          uint64_t* __restrict__ counts) {
+                                                          uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw) {
     __shared__ uint64_t keys[FB_CAP];
     __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];
     __shared__ uint32_t wtot[FB_WAVES];
@@ -63,7 +72,11 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
 #pragma unroll
         for (uint32_t r = 0; r < FB_EMAX; r++) {
             const uint32_t idx = wbase + r * 64u + lane;
-            key[r] = (r < E && idx < n) ? c[a0 + idx] : ~0ull;
+            key[r] = ~0ull;
+            if (r < E && idx < n) {
+                key[r] = c[a0 + idx];
+                if (vals) key[r] = ((key[r] & ((1ull << (hi_bit - lo_bit)) - 1ull)) << lo_bit) | load_id(vals, vw, (uint64_t)a0 + idx);
+            }
         }
         for (uint32_t bit = lo_bit; bit < hi_bit; bit += FB_DBITS) {
             const int nbits = (int)min((uint32_t)FB_DBITS, hi_bit - bit);
@@ -168,7 +181,8 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
 // first genome id, and the genome ids (c & gmask) of its distinct pairs.
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t gb,
                                                           const uint64_t* __restrict__ bases, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off,
-                                                          uint32_t* __restrict__ pg) {
+                                                          uint32_t* __restrict__ pg, int kv, uint32_t rest) {  // kv: the composites lack the bucket's
+                                                                                                             // bits (k_bucket_sort, vals); rest: T bits below the split
     __shared__ uint32_t w_nk[FB_WAVES], w_np[FB_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gmask = (1ull << gb) - 1ull, lt_mask = (1ull << lane) - 1ull;
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
             if (keep) pg[prank] = (uint32_t)(a & gmask);
             if (head) {
                 const uint32_t q = kb + (uint32_t)__builtin_popcountll(hm & lt_mask);
-                tk[q] = a >> gb;
+                tk[q] = kv ? (((uint64_t)b << rest) | (a >> gb)) : (a >> gb);
                 seg_off[q] = prank;  // (a head is always kept: its pair is the k-mer's first)
             }
             kbase += tk_all;
@@ -212,13 +226,13 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
 uint32_t bft_front_bucket_capacity(void) { return FB_CAP; }
 
 int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
-                      DevBuf& pg, uint64_t& nk, uint64_t& np) {
+                      DevBuf& pg, uint64_t& nk, uint64_t& np, const void* d_vals, uint32_t vw) {
     DevBuf counts, bases, tmp;
     CK(counts.alloc(((uint64_t)nb + 1) * 8));
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
     const dim3 grid(std::min<uint32_t>(nb, 256u * 16u)), block(FB_BLOCK);
-    hipLaunchKernelGGL(k_bucket_sort, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>());
+    hipLaunchKernelGGL(k_bucket_sort, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw);
     size_t tb = 0;
     HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
     CK(tmp.alloc(tb));
@@ -233,7 +247,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     CK(tk.alloc(nk * 8));
     CK(seg_off.alloc((nk + 1) * 4));
     CK(pg.alloc(np * 4));
-    hipLaunchKernelGGL(k_bucket_emit, grid, block, 0, s, d_c, d_boff, nb, gb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(), pg.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_emit, grid, block, 0, s, d_c, d_boff, nb, gb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(), pg.as<uint32_t>(), d_vals ? 1 : 0, split_bit - gb);
     const uint32_t np32 = (uint32_t)np;
     HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, s));
     HIPCK(hipGetLastError());

@@ -1086,6 +1086,43 @@ static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32
     return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npg, nk, np);
 }
 
+// The same front end for ordered one-word keys whose composite does not fit 63 bits (k = 31 beyond a couple of genomes, k = 27 beyond
+// 512): a stable key + value sort on the 18 root-prefix bits -- the ids travel beside the keys, narrowed to VT --, then the buckets
+// (bft_front.hip), where the bits a bucket's k-mers share make room for the id.  done = false: a bucket is too large, nothing was built.
+using Msd9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
+                                                                            rocprim::block_radix_rank_algorithm::match>>;
+template <class VT>
+static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, int gb, DevBuf& tk, DevBuf& seg_off, DevBuf& npg,
+                           uint64_t& nk, uint64_t& np, bool& done) {
+    done = false;
+    const unsigned top = (unsigned)std::min(18, 2 * h->k), rest = (unsigned)(2 * h->k) - top;
+    DevBuf sk, sv, tmp, boff, maxb;
+    CK(sk.alloc(total * 8));
+    CK(sv.alloc(total * sizeof(VT)));
+    CK(boff.alloc(((1u << top) + 1) * 4));
+    CK(maxb.alloc_zero(4, h->stream));
+    const BftNarrowIds<VT> nar{src_g};
+    auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
+    size_t tb = 0;
+    HIPCK(rocprim::radix_sort_pairs<Msd9>(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
+    CK(tmp.alloc(tb));
+    HIPCK(rocprim::radix_sort_pairs<Msd9>(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
+    hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(),
+                       maxb.as<uint32_t>());
+    uint32_t mx = 0;
+    HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    tmp.release();
+    h->msd_max_bucket = mx;
+    bft_trace_mark("root-prefix split done (sync)");
+    if (mx > bft_front_bucket_capacity()) return 0;
+    CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, sv.p,
+                         (uint32_t)sizeof(VT)));
+    done = true;
+    return 0;
+}
+
 extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
@@ -1129,9 +1166,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 CK(maxb.alloc_zero(4, h->stream));
                 // (9-bit digits: the 18 bits in two onesweep passes instead of the three that rocPRIM's 8-bit default takes -- 2.76 ms
                 // against 3.79 on 2 x 10^8 keys, tools/microbench/msd_sort.hip)
-                using Msd9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
-                                                                                            rocprim::block_radix_rank_algorithm::match>>;
                 HIPCK(rocprim::radix_sort_keys<Msd9>(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
                 CK(tmp.alloc(tb));
                 HIPCK(rocprim::radix_sort_keys<Msd9>(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
@@ -1177,11 +1211,23 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             }
             ck.release();
             cg.release();
-        } else if (W == 1 && h->log_g_sorted && h->max_gid_seen < 65536 && !h->opt_no_composite) {
-            // 2n + 3'. ordered one-word keys whose composite does not fit (k = 31 with more than a few genomes): key + value sort with the
-            // ids narrowed to one or two bytes (the values are a third of the sort's traffic at four)
-            if (h->max_gid_seen < 256) CK(sort_dedupe_w1_narrow<uint8_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
-            else CK(sort_dedupe_w1_narrow<uint16_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
+        } else if (W == 1 && h->log_g_sorted && !h->opt_no_composite && (h->max_gid_seen < 65536 || (2 * h->k - std::min(18, 2 * h->k)) + gb <= 64)) {
+            // 2s. ordered one-word keys whose composite does not fit (k = 31 with more than a few genomes): the root-prefix split with
+            // the ids beside the keys, then the buckets -- where the composite does fit, the bucket's number being implied
+            bool done = false;
+            h->msd_max_bucket = 0;
+            if (h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2) && (2 * h->k - std::min(18, 2 * h->k)) + gb <= 64) {
+                if (h->max_gid_seen < 256) CK(split_dedupe_w1<uint8_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
+                else if (h->max_gid_seen < 65536) CK(split_dedupe_w1<uint16_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
+                else CK(split_dedupe_w1<uint32_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
+            }
+            // 2n + 3'. ... or one key + value sort over every bit with the ids narrowed to one or two bytes (the values are a third of
+            // the sort's traffic at four), flags on the fly, one scan
+            if (!done) {
+                if (h->max_gid_seen < 256) CK(sort_dedupe_w1_narrow<uint8_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
+                else if (h->max_gid_seen < 65536) CK(sort_dedupe_w1_narrow<uint16_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
+                else CK(sort_dedupe_w1_narrow<uint32_t>(h, src_k, src_g, total, tk, seg_off, npg, nk, np));
+            }
             ck.release();
             cg.release();
         } else {
