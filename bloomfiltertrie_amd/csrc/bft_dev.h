@@ -113,6 +113,8 @@ int bft_count_pairs(const uint32_t* d_tcol, uint64_t n, const uint32_t* d_cs_off
 // The build's front end behind the root-prefix split (bft_front.hip): bucket-wise sort of the composites c = T << gb | genome on the
 // bits [gb, split_bit) and the de-duplicated outputs: sorted distinct k-mers, offsets of their genome-id lists, the genome ids.
 uint32_t bft_front_bucket_capacity(void);
+void bft_test_front_rank_mode(int mode);   // test hook: k_bucket_sort's mode (0 atomics + check, 1 ballots only, 2 the check always fails)
 // d_vals (vw bytes per id): d_c holds whole T-form k-mers grouped by the bits from split_bit - gb up, the ids beside them
 int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
-                      DevBuf& pg, uint64_t& nk, uint64_t& np, const void* d_vals = nullptr, uint32_t vw = 0);
+                      DevBuf& pg, uint64_t& nk, uint64_t& np, uint32_t max_bucket, uint32_t* n_redone, const void* d_vals = nullptr, uint32_t vw = 0);
+// (max_bucket: the largest of the buckets; *n_redone: buckets whose order check failed and that were sorted again)

@@ -52,46 +52,35 @@ __device__ __forceinline__ uint64_t load_id(const void* vals, uint32_t vw, uint6
     return reinterpret_cast<const uint32_t*>(vals)[i];
 }
 
-__global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
-                                                          uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw) {
-    __shared__ uint64_t keys[FB_CAP];
-    __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];
-    __shared__ uint32_t wtot[FB_WAVES];
-    __shared__ uint32_t s_nk, s_np;
+// LSD radix passes over the bits [lo_bit, hi_bit) of the bucket's composites: keys in registers (wavefront w owns the slots
+// [w E 64, (w + 1) E 64) of the bucket: order = (wave, round, lane)), per-wavefront digit counters, one exchange through `keys` per
+// pass; on return key[] and keys[] hold the same arrangement.
+//   BALLOT   the lanes that hold the same digit find each other with eight __ballot's, one of them bumps the counter for all: a
+//            lane's rank among its peers is its position among them -- stable by construction.
+//   !BALLOT  every lane bumps the counter itself with one LDS atomic that returns its rank.  The LDS unit serves the lanes of one
+//            instruction that hit one address in lane order on this hardware, but nothing documents that: the caller checks the
+//            final order and repeats the bucket with BALLOT when it is off (never seen; counted in *n_redone).
+template <bool BALLOT, int EMAX>
+__device__ __forceinline__ void radix_passes(uint64_t (&key)[EMAX], uint64_t* keys, uint32_t (*cnt)[FB_DIGITS], uint32_t* wtot, uint32_t n, uint32_t E, uint32_t lo_bit,
+                                             uint32_t hi_bit) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
-        if (n == 0 || n > FB_CAP) {  // (buckets beyond the capacity are excluded by the caller: the whole build then takes the one-sort path)
-            if (tid == 0) counts[b] = 0;
-            continue;
-        }
-        const uint32_t E = (n + FB_BLOCK - 1) / FB_BLOCK;       // rounds; wavefront w owns [w E 64, (w + 1) E 64): order = (wave, round, lane)
-        const uint32_t wbase = wave * E * 64u;
-        uint64_t key[FB_EMAX];
+    const uint32_t wbase = wave * E * 64u;
+    for (uint32_t bit = lo_bit; bit < hi_bit; bit += FB_DBITS) {
+        const int nbits = (int)min((uint32_t)FB_DBITS, hi_bit - bit);
+        const uint32_t mask = (1u << nbits) - 1u;
 #pragma unroll
-        for (uint32_t r = 0; r < FB_EMAX; r++) {
+        for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[wave][lane * (FB_DIGITS / 64) + j] = 0;  // the wavefront's own counters (LDS operations of one wavefront are in order)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t rank[EMAX];
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            rank[r] = 0;
+            if (r >= E) continue;  // (uniform)
             const uint32_t idx = wbase + r * 64u + lane;
-            key[r] = ~0ull;
-            if (r < E && idx < n) {
-                key[r] = c[a0 + idx];
-                if (vals) key[r] = ((key[r] & ((1ull << (hi_bit - lo_bit)) - 1ull)) << lo_bit) | load_id(vals, vw, (uint64_t)a0 + idx);
-            }
-        }
-        for (uint32_t bit = lo_bit; bit < hi_bit; bit += FB_DBITS) {
-            const int nbits = (int)min((uint32_t)FB_DBITS, hi_bit - bit);
-            const uint32_t mask = (1u << nbits) - 1u;
-#pragma unroll
-            for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[wave][lane * (FB_DIGITS / 64) + j] = 0;  // the wavefront's own counters (LDS operations of one wavefront are in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            uint32_t rank[FB_EMAX];
-#pragma unroll
-            for (uint32_t r = 0; r < FB_EMAX; r++) {
-                rank[r] = 0;
-                if (r >= E) continue;  // (uniform)
-                const uint32_t idx = wbase + r * 64u + lane;
-                const bool valid = idx < n;
-                const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
+            const bool valid = idx < n;
+            const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
+            if (BALLOT) {
                 const uint64_t peers = match_digit(d, valid, nbits);
                 if (valid) {
                     const int leader = __builtin_ctzll(peers);
@@ -103,56 +92,118 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
                     base = __shfl(base, leader);
                     rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round's leaders read what this round's leaders wrote
+            } else if (valid) {
+                rank[r] = atomicAdd(&cnt[wave][d], 1u);
             }
-            __syncthreads();
-            {   // digit(s) of this thread: counts of the four wavefronts -> start of (digit, wavefront) in the bucket
-                constexpr int DPT = FB_DIGITS / FB_BLOCK;  // digits per thread
-                uint32_t cw[DPT][FB_WAVES], tot = 0;
-#pragma unroll
-                for (int j = 0; j < DPT; j++) {
-#pragma unroll
-                    for (int w = 0; w < FB_WAVES; w++) { cw[j][w] = cnt[w][tid * DPT + j]; tot += cw[j][w]; }
-                }
-                uint32_t inc = tot;  // inclusive scan over the threads' totals: shuffles inside a wavefront, four partial sums across
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(inc, o);
-                    if ((int)lane >= o) inc += v;
-                }
-                if (lane == 63) wtot[wave] = inc;
-                __syncthreads();
-                uint32_t before = 0;
-#pragma unroll
-                for (int w = 0; w < FB_WAVES; w++)
-                    if (w < (int)wave) before += wtot[w];
-                uint32_t start = before + inc - tot;
-#pragma unroll
-                for (int j = 0; j < DPT; j++) {
-#pragma unroll
-                    for (int w = 0; w < FB_WAVES; w++) { cnt[w][tid * DPT + j] = start; start += cw[j][w]; }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t r = 0; r < FB_EMAX; r++) {
-                if (r >= E) continue;
-                const uint32_t idx = wbase + r * 64u + lane;
-                if (idx < n) keys[cnt[wave][(uint32_t)(key[r] >> bit) & mask] + rank[r]] = key[r];
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t r = 0; r < FB_EMAX; r++) {
-                const uint32_t idx = wbase + r * 64u + lane;
-                if (r < E && idx < n) key[r] = keys[idx];
-            }
-            // (no barrier here: the next pass writes `keys` only after two more barriers, and zeroes only its own counters)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round reads what this round wrote
         }
+        __syncthreads();
+        {   // digit(s) of this thread: counts of the four wavefronts -> start of (digit, wavefront) in the bucket
+            constexpr int DPT = FB_DIGITS / FB_BLOCK;  // digits per thread
+            uint32_t cw[DPT][FB_WAVES], tot = 0;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+#pragma unroll
+                for (int w = 0; w < FB_WAVES; w++) { cw[j][w] = cnt[w][tid * DPT + j]; tot += cw[j][w]; }
+            }
+            uint32_t inc = tot;  // inclusive scan over the threads' totals: shuffles inside a wavefront, four partial sums across
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(inc, o);
+                if ((int)lane >= o) inc += v;
+            }
+            if (lane == 63) wtot[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++)
+                if (w < (int)wave) before += wtot[w];
+            uint32_t start = before + inc - tot;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+#pragma unroll
+                for (int w = 0; w < FB_WAVES; w++) { cnt[w][tid * DPT + j] = start; start += cw[j][w]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            if (r >= E) continue;
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (idx < n) keys[cnt[wave][(uint32_t)(key[r] >> bit) & mask] + rank[r]] = key[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (r < E && idx < n) key[r] = keys[idx];
+        }
+        // (no barrier here: the next pass writes `keys` only after two more barriers, and zeroes only its own counters)
+    }
+}
+
+template <int EMAX>
+__device__ __forceinline__ void load_bucket(uint64_t (&key)[EMAX], const uint64_t* __restrict__ c, const void* __restrict__ vals, uint32_t vw, uint32_t a0, uint32_t n,
+                                            uint32_t E, uint32_t lo_bit, uint32_t hi_bit) {
+    const uint32_t lane = threadIdx.x & 63u, wbase = (threadIdx.x >> 6) * E * 64u;
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+        const uint32_t idx = wbase + r * 64u + lane;
+        key[r] = ~0ull;
+        if (r < E && idx < n) {
+            key[r] = c[a0 + idx];
+            if (vals) key[r] = ((key[r] & ((1ull << (hi_bit - lo_bit)) - 1ull)) << lo_bit) | load_id(vals, vw, (uint64_t)a0 + idx);
+        }
+    }
+}
+
+// mode: 0 = ranks from LDS atomics, checked, BALLOT on failure; 1 = BALLOT only; 2 = test hook: the check always fails
+// EMAX: composites per thread, i.e. buckets of up to 256 EMAX composites (the host picks the smallest that holds the largest bucket:
+// the kernel is bound by the latency of its LDS round trips and barriers, and both the registers and the LDS of a workgroup -- hence
+// the workgroups a CU holds -- go with EMAX: 4 per CU at 16, 7 at 9)
+template <int EMAX>
+__global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : 4)) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
+                                                          uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw, int mode, uint32_t* __restrict__ n_redone,
+                                                          uint32_t min_n) {  // buckets of up to min_n composites are k_bucket_sort_wave's
+    __shared__ uint64_t keys[FB_BLOCK * EMAX];
+    __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];
+    __shared__ uint32_t wtot[FB_WAVES];
+    __shared__ uint32_t s_nk, s_np;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
+        if (n <= min_n && min_n) continue;
+        if (n == 0 || n > (uint32_t)(FB_BLOCK * EMAX)) {  // (buckets beyond the capacity are excluded by the caller: the whole build then takes the one-sort path)
+            if (tid == 0) counts[b] = 0;
+            continue;
+        }
+        const uint32_t E = (n + FB_BLOCK - 1) / FB_BLOCK;       // rounds
+        const uint32_t wbase = wave * E * 64u;
+        uint64_t key[EMAX];
+        load_bucket<EMAX>(key, c, vals, vw, a0, n, E, lo_bit, hi_bit);
+        bool sorted = false;
+        if (mode != 1 && lo_bit < hi_bit) {
+            radix_passes<false, EMAX>(key, keys, cnt, wtot, n, E, lo_bit, hi_bit);
+            // In order over EVERY bit?  (The ids below lo_bit are not sorted on: equal k-mers must have kept their insertion order, i.e.
+            // ascending ids, which only a stable sort does.)
+            int off = mode == 2;
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                if (r < E && idx < n && idx) off |= keys[idx - 1] > key[r];
+            }
+            sorted = __syncthreads_or(off) == 0;
+            if (!sorted) {
+                if (tid == 0) atomicAdd(n_redone, 1u);
+                load_bucket<EMAX>(key, c, vals, vw, a0, n, E, lo_bit, hi_bit);  // (the insertion order again)
+            }
+        }
+        if (!sorted) radix_passes<true, EMAX>(key, keys, cnt, wtot, n, E, lo_bit, hi_bit);
         // duplicates against the left neighbour (the first composite of a bucket starts a k-mer: buckets differ in their top bits)
         if (tid == 0) { s_nk = 0; s_np = 0; }
         if (lo_bit >= hi_bit) {  // nothing was sorted (the split covered every T bit): the keys are only in registers yet
 #pragma unroll
-            for (uint32_t r = 0; r < FB_EMAX; r++) {
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
                 const uint32_t idx = wbase + r * 64u + lane;
                 if (r < E && idx < n) keys[idx] = key[r];
             }
@@ -160,7 +211,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
         __syncthreads();
         uint32_t nk = 0, np = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < FB_EMAX; r++) {
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
             const uint32_t idx = wbase + r * 64u + lane;
             if (r < E && idx < n) {
                 const uint64_t prev = idx ? keys[idx - 1] : ~key[r];
@@ -174,6 +225,137 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_sort(uint64_t* __restrict__
         __syncthreads();
         if (tid == 0) counts[b] = ((uint64_t)s_nk << 32) | s_np;
         __syncthreads();
+    }
+}
+
+
+// The same for the small buckets, ONE WAVEFRONT per bucket (up to 64 EW composites): no barrier anywhere -- the LDS operations of a
+// wavefront are in order --, four independent buckets per workgroup.  The workgroup version above spends most of a pass waiting at
+// its four barriers (1300 cycles per bucket and pass on a CU where the arithmetic is 200); a pan-genome bucket is ~760 composites.
+template <int EW>
+__global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wave(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
+                                                               uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw, int mode,
+                                                               uint32_t* __restrict__ n_redone) {
+    __shared__ uint64_t keys_all[FB_WAVES][64 * EW];
+    __shared__ uint32_t cnt_all[FB_WAVES][FB_DIGITS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t* keys = keys_all[wave];
+    uint32_t* cnt = cnt_all[wave];
+    for (uint32_t b = blockIdx.x * FB_WAVES + wave; b < nb; b += gridDim.x * FB_WAVES) {
+        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
+        if (n > 64u * EW) continue;  // (k_bucket_sort's)
+        if (n == 0) {
+            if (lane == 0) counts[b] = 0;
+            continue;
+        }
+        const uint32_t E = (n + 63u) / 64u;  // rounds: slot (round r, lane l) = composite r 64 + l of the bucket
+        uint64_t key[EW];
+        bool sorted = false;
+        for (int attempt = (mode == 1 ? 1 : 0); attempt < 2 && !sorted; attempt++) {  // 0: ranks from LDS atomics, checked; 1: from ballots (see radix_passes)
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                const uint32_t idx = r * 64u + lane;
+                key[r] = ~0ull;
+                if (r < E && idx < n) {
+                    key[r] = c[a0 + idx];
+                    if (vals) key[r] = ((key[r] & ((1ull << (hi_bit - lo_bit)) - 1ull)) << lo_bit) | load_id(vals, vw, (uint64_t)a0 + idx);
+                }
+            }
+            for (uint32_t bit = lo_bit; bit < hi_bit; bit += FB_DBITS) {
+                const int nbits = (int)min((uint32_t)FB_DBITS, hi_bit - bit);
+                const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+                for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[lane * (FB_DIGITS / 64) + j] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t rank[EW];
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    rank[r] = 0;
+                    if (r >= E) continue;  // (uniform)
+                    const bool valid = r * 64u + lane < n;
+                    const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
+                    if (attempt == 0) {
+                        if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
+                    } else {
+                        const uint64_t peers = match_digit(d, valid, nbits);
+                        if (valid) {
+                            const int leader = __builtin_ctzll(peers);
+                            uint32_t base = 0;
+                            if ((int)lane == leader) {
+                                base = cnt[d];
+                                cnt[d] = base + (uint32_t)__builtin_popcountll(peers);
+                            }
+                            base = __shfl(base, leader);
+                            rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                {   // the lane's digits: counts -> starts
+                    constexpr int DPL = FB_DIGITS / 64;
+                    uint32_t cw[DPL], tot = 0;
+#pragma unroll
+                    for (int j = 0; j < DPL; j++) { cw[j] = cnt[lane * DPL + j]; tot += cw[j]; }
+                    uint32_t inc = tot;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t v = __shfl_up(inc, o);
+                        if ((int)lane >= o) inc += v;
+                    }
+                    uint32_t start = inc - tot;
+#pragma unroll
+                    for (int j = 0; j < DPL; j++) { cnt[lane * DPL + j] = start; start += cw[j]; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    if (r >= E) continue;
+                    if (r * 64u + lane < n) keys[cnt[(uint32_t)(key[r] >> bit) & mask] + rank[r]] = key[r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    const uint32_t idx = r * 64u + lane;
+                    if (r < E && idx < n) key[r] = keys[idx];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            if (lo_bit >= hi_bit) {  // nothing to sort: the keys are only in registers yet
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    const uint32_t idx = r * 64u + lane;
+                    if (r < E && idx < n) keys[idx] = key[r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            sorted = true;
+            if (attempt == 0 && lo_bit < hi_bit) {  // in order over EVERY bit (see k_bucket_sort)?
+                int off = mode == 2;
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    const uint32_t idx = r * 64u + lane;
+                    if (r < E && idx < n && idx) off |= keys[idx - 1] > key[r];
+                }
+                sorted = __ballot(off != 0) == 0ull;
+                if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        uint32_t nk = 0, np = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+            const uint32_t idx = r * 64u + lane;
+            if (r < E && idx < n) {
+                const uint64_t prev = idx ? keys[idx - 1] : ~key[r];
+                nk += (key[r] >> lo_bit) != (prev >> lo_bit);
+                np += key[r] != prev;
+                c[a0 + idx] = key[r];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { nk += __shfl_down(nk, o); np += __shfl_down(np, o); }
+        if (lane == 0) counts[b] = ((uint64_t)nk << 32) | np;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next bucket overwrites keys)
     }
 }
 
@@ -224,22 +406,40 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
 }  // namespace
 
 uint32_t bft_front_bucket_capacity(void) { return FB_CAP; }
+static int g_rank_mode = 0;                 // k_bucket_sort's mode ("test_front_rank_mode")
+void bft_test_front_rank_mode(int mode) { g_rank_mode = mode; }
 
 int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
-                      DevBuf& pg, uint64_t& nk, uint64_t& np, const void* d_vals, uint32_t vw) {
+                      DevBuf& pg, uint64_t& nk, uint64_t& np, uint32_t max_bucket, uint32_t* n_redone, const void* d_vals, uint32_t vw) {
     DevBuf counts, bases, tmp;
     CK(counts.alloc(((uint64_t)nb + 1) * 8));
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
     const dim3 grid(std::min<uint32_t>(nb, 256u * 16u)), block(FB_BLOCK);
-    hipLaunchKernelGGL(k_bucket_sort, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw);
+    DevBuf redone;
+    CK(redone.alloc_zero(4, s));
+// the small buckets a wavefront each, the others a workgroup each
+    const uint32_t wave_cap = max_bucket <= 512u ? 512u : 1024u;
+    const dim3 wgrid(std::min<uint32_t>((nb + FB_WAVES - 1) / FB_WAVES, 256u * 16u));
+    if (wave_cap == 512u) hipLaunchKernelGGL(k_bucket_sort_wave<8>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
+    else hipLaunchKernelGGL(k_bucket_sort_wave<16>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
+#define FB_LAUNCH(E) hipLaunchKernelGGL(k_bucket_sort<E>, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), wave_cap)
+    if (max_bucket <= wave_cap) {}
+    else if (max_bucket <= 256u * 6u) FB_LAUNCH(6);
+    else if (max_bucket <= 256u * 9u) FB_LAUNCH(9);
+    else if (max_bucket <= 256u * 12u) FB_LAUNCH(12);
+    else FB_LAUNCH(16);
+#undef FB_LAUNCH
     size_t tb = 0;
     HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
     CK(tmp.alloc(tb));
     HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
     uint64_t total = 0;
     HIPCK(hipMemcpyAsync(&total, bases.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s));
+    uint32_t nr = 0;
+    HIPCK(hipMemcpyAsync(&nr, redone.p, 4, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
+    if (n_redone) *n_redone = nr;
     nk = total >> 32;
     np = total & 0xFFFFFFFFull;
     (void)n;

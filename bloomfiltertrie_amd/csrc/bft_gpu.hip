@@ -249,6 +249,7 @@ struct bft_gpu {
     uint32_t opt_flat_min = BFT_TRESH_SUF_PREF;  // CCs with at least this many prefixes get the flat form ("flat_min")
     bool has_cs_bm = false, cs_bm_tried = false;
     bool opt_no_composite = false;  // test hook ("build_composite" 0): the general sort + flag-array path also for ordered one-word keys
+    uint32_t front_redone = 0;      // root-prefix buckets of the last build whose order check failed (bft_front.hip)
     int opt_msd = 1;                // "build_msd": root-prefix buckets + bucket sorts for 2^20 pairs and more (1), always (2: test hook), never (0)
     uint32_t msd_max_bucket = 0;    // largest root-prefix bucket of the last build's sort (0: one device-wide sort)
     BftImage im;
@@ -1117,7 +1118,7 @@ static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* sr
     h->msd_max_bucket = mx;
     bft_trace_mark("root-prefix split done (sync)");
     if (mx > bft_front_bucket_capacity()) return 0;
-    CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, sv.p,
+    CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, mx, &h->front_redone, sv.p,
                          (uint32_t)sizeof(VT)));
     done = true;
     return 0;
@@ -1135,6 +1136,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
 
     DevBuf tk, seg_off, npg;
     uint64_t nk = 0, np = 0;
+    h->front_redone = 0;
+    h->msd_max_bucket = 0;
     if (total > 0) {
         // 1. the pairs to sort: the insertion log
         DevBuf ck, cg, sk, sg;
@@ -1178,7 +1181,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 bft_trace_mark("root-prefix split done (sync)");
                 if (mx <= bft_front_bucket_capacity()) {
                     pos.release();
-                    CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np));
+                    CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, mx, &h->front_redone));
                     done = true;
                 }
             }
@@ -1402,7 +1405,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[0] = t1 - t0;
     h->build_ms[1] = t2 - t1;
     h->build_ms[2] = t3 - t2;
-    h->build_ms[3] = 0;
+    h->build_ms[3] = (double)h->front_redone;
     h->built = true;
     bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
@@ -2370,6 +2373,9 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "debug_stop") {  // libbft_gpu_probe.so only (make probe): truncates the walk, results are wrong
         h->im.debug_stop = (uint32_t)value;
 #endif
+    } else if (nm == "test_front_rank_mode") {  // test hook (tests/test_gpu_build.py): how the root-prefix buckets rank their digits, see k_bucket_sort
+        if (value > 2) return fail(BFT_GPU_E_ARG, "test_front_rank_mode must be 0, 1 or 2");
+        bft_test_front_rank_mode((int)value);
     } else if (nm == "test_weak_signature") {  // test hook (tests/test_gpu_build.py): colour-set signatures that collide, see bft_intern_colors_gpu
         bft_test_weak_signature(value != 0);
     } else if (nm == "inject_build_failure") {  // test hook (tests/test_gpu_build.py): exercises the all-or-nothing build

@@ -184,7 +184,7 @@ int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, uint64_t ca
  * first call of this function turns it on, so call it once (reset = 1) before the region to be timed. */
 int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
 /* Same for the GPU part and the host part of bft_gpu_build (last call): ms[0]=sort+dedupe (GPU),
- * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=bookkeeping, ms[4]=derived arrays (flat CC form, root tables, node prefix
+ * ms[1]=colour-set interning (GPU), ms[2]=container assembly (GPU), ms[3]=root-prefix buckets of the last sort whose order check failed and that were sorted a second time (expected 0: see k_bucket_sort), ms[4]=derived arrays (flat CC form, root tables, node prefix
  * hash, k-mer hash), ms[5]=resident k_query workgroups per CU in use (1, 2 or 3), ms[6..7]=time of the "tune" batch with 1 / 2 workgroups per CU (0 when not
  * tuned), ms[8]=rows per suffix-group probe in use (4 or 8), ms[9]=lines of the k-mer hash (0 = none), ms[10]=GPU time of its fill, ms[11]=largest root-prefix bucket of the last sort (0: one device-wide sort),
  * ms[12]=times the colour-set interning had to compare lists (signature collisions), ms[13]=ms this process has spent in hipMalloc so far,

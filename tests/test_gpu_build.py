@@ -466,3 +466,47 @@ def test_interning_when_nearly_every_colour_set_is_distinct():
     assert got == truth
     assert nsets == len(set(truth.values())) == t.info()["colorsets"] and nsets > 40000
     t.close()
+
+
+@pytest.mark.parametrize("k,gids", [(27, [0, 1, 2, 3, 4]), (27, [0, 1]), (31, [0, 1, 2, 3, 4]), (31, [3, 7]), (31, [0, 300, 301, 70000]), (27, [5, 600, 601, 602, 603]), (20, [0, 1, 2]),
+                                    (9, [0, 1, 2])])
+def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
+    """A root-prefix bucket ranks its digits with one LDS atomic per key, checks the final order over every bit -- k-mers ascending,
+    the ids of a k-mer in insertion order -- and is sorted again with ballot ranks (stable by construction) when the check fails
+    (bft_front.hip: a wavefront per bucket up to 1024 composites, a workgroup per larger one).  "test_front_rank_mode": 0 as shipped,
+    1 ballots only, 2 the check always fails (every bucket is sorted twice).  Image, extraction and colour sets are those of the
+    device-wide sort in every mode -- composites that fit 63 bits and those that only fit inside a bucket (k = 31; ids of one, two
+    and four bytes) --; as shipped no bucket fails the check."""
+    n_pref = 40
+    base = S.low_entropy_kmers(30000, k, n_pref, 11 + k) if k >= 18 else S.distinct(S.pack_codes(np.random.default_rng(k).integers(0, 4, (30000, k), dtype=np.uint8)))
+    rng = np.random.default_rng(k + len(gids))
+    parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.5]) for _ in gids]  # ~375 k-mers per genome and bucket
+    imgs, redone = [], []
+    try:
+        for msd, mode in ((0, 0), (2, 0), (2, 1), (2, 2)):
+            t = BFT(k)
+            t.set_option("build_msd", msd)
+            t.set_option("test_front_rank_mode", mode)
+            for i, (g, p) in enumerate(zip(gids, parts)):
+                t.insert_kmers(p, g)
+                if i == 1:
+                    t.insert_kmers(p[::3], g)  # duplicate pairs
+            t.build()
+            bt = t.build_time()
+            redone.append(int(bt["sort_redone_buckets"]))
+            assert (bt["sort_max_bucket"] > 0) == (msd == 2)
+            assert bt["sort_max_bucket"] <= 4096
+            ek, ecs = t.extract()
+            imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs, [list(t.colorset(c)) for c in sorted(set(ecs.tolist()))[:100]]))
+            t.close()
+    finally:
+        w = BFT(k)
+        w.set_option("test_front_rank_mode", 0)
+        w.close()
+    a = imgs[0]
+    for b in imgs[1:]:
+        for name in ARRAYS:
+            assert (a[0][name] == b[0][name]).all(), name
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
+    assert redone[0] == 0 and redone[1] == 0 and redone[2] == 0, redone
+    assert redone[3] >= n_pref if k > 9 else redone[3] == 0, redone  # (k = 9: the split covers every bit, nothing is sorted in a bucket)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--sample", type=int, default=2_000_000)
     ap.add_argument("--reserve", action="store_true", help="reserve the insertion log for the total up front instead of letting it grow by doubling")
     ap.add_argument("--sync-inserts", action="store_true", help="bft_gpu_insert_kmers_dev (synchronised per call) instead of the stream-ordered bft_gpu_insert_kmers_dev_async")
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to bft_gpu_set_option before the inserts (repeatable)")
     args = ap.parse_args()
     import torch
     from bloomfiltertrie_amd import BFT
@@ -61,6 +62,9 @@ def main():
         warm.query_presence(w[:1000].cpu().numpy())
         del w
     t = BFT(args.k)
+    for o in args.opt:
+        name, val = o.split("=")
+        t.set_option(name, int(val))
     t_ins = 0.0
     if args.reserve:  # the total is known up front (genomes x windows), as with the count line of a kmers_comp file
         t0 = time.perf_counter()
