@@ -133,11 +133,16 @@ __global__ __launch_bounds__(256) void k_kh_insert(const uint64_t* __restrict__ 
         bool placed = false;
         while (!placed) {
             uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
-            // (slot by slot: reading the first key word of all the line's slots up front -- five agent-scope loads in flight instead of
-            // ~2.5 dependent ones -- was measured slower, 4.3 ms against 3.2 on config 3: the loads are L2 transactions of their own)
-            for (uint32_t s = 0; s < S && !placed; s++) {
+            // An ordinary, cached look at the slots' first key words picks the candidates: a stale view can only show a taken slot as
+            // free, never the reverse, and the compare-and-swap decides.  (Agent-scope atomic loads slot by slot -- each an L2
+            // transaction of its own -- made the fill 2.9 ms on config 3; all five at once, 4.3 ms.)
+            uint64_t view[S];
+#pragma unroll
+            for (uint32_t s = 0; s < S; s++) view[s] = line[s * W];
+#pragma unroll
+            for (uint32_t s = 0; s < S; s++) {
+                if (placed || view[s] != BFT_KH_EMPTY) continue;
                 unsigned long long* slot = (unsigned long long*)(line + s * W);
-                if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BFT_KH_EMPTY) continue;
                 if (atomicCAS(slot, (unsigned long long)BFT_KH_EMPTY, (unsigned long long)t[0]) == BFT_KH_EMPTY) {
 #pragma unroll
                     for (int w = 1; w < W; w++) line[s * W + w] = t[w];
