@@ -6,15 +6,20 @@
 // keeps every container sorted (insertSP_CC src/CC.c:714-1474, insertKmer_UC src/UC.c:13-79) and appends the genome id to the k-mer's
 // annotation when the k-mer is already there (modify_annotations, src/retrieveAnnotation.c:232-314).
 //
-//   k_bucket_sort   one workgroup per bucket: the bucket's composites are sorted on the remaining T bits by a stable LSD radix sort
-//                   that never leaves the CU -- keys in registers, 8-bit digits, ranks from wavefront ballots (the lanes that hold
-//                   the same digit find each other with eight __ballot's; one of them bumps the wavefront's own LDS counter for all),
-//                   a 256-digit scan, one exchange through LDS per pass --, then duplicates are flagged against the left neighbour
-//                   and the bucket goes back in place together with its counts (distinct k-mers, distinct pairs).
+//   k_bucket_sort_wave   one WAVEFRONT per bucket of up to 1024 composites (a pan-genome bucket holds ~760): a stable LSD radix sort on
+//                   the remaining T bits that never leaves the CU and never meets a barrier -- keys in registers, 9-bit digits, the
+//                   rank of a key = what one LDS atomic on the wavefront's digit counter returns, a 512-digit scan by shuffles, one
+//                   exchange through LDS per pass --, then duplicates are flagged against the left neighbour and the bucket goes back
+//                   in place together with its counts (distinct k-mers, distinct pairs).  The atomic ranks are stable only if the LDS
+//                   serves the lanes of an instruction in lane order -- it does, undocumented --: the final order is checked over
+//                   every bit, and a bucket that fails is sorted again with ranks from wavefront ballots (stable by construction).
+//   k_bucket_sort   the same with one workgroup per bucket, for the larger ones (up to 4096 composites; variants by keys per thread)
 //   k_bucket_emit   after one scan of the 2^18 count pairs: every bucket writes its k-mers, their offsets and the genome ids at
 //                   its place in the outputs.
+// Composites that do not fit 63 bits (k = 31; k = 27 beyond 512 genomes) arrive as whole k-mers with the ids beside them: the bits a
+// bucket's k-mers share are dropped inside the bucket, which makes room for the id.
 // One read and one write of the array for all the remaining bits, where a device-wide LSD sort spends a pass per 8 bits
-// (rocPRIM: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms).
+// (rocPRIM: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms; these kernels: 3.0 ms).
 #include <hipcub/hipcub.hpp>
 
 #include "bft_dev.h"
@@ -23,8 +28,9 @@
 #define FB_WAVES (FB_BLOCK / 64)
 #define FB_EMAX 16                      // composites per thread
 #define FB_CAP (FB_BLOCK * FB_EMAX)     // largest bucket sorted in LDS (4096 composites = 32 KB)
-#define FB_DBITS 8                      // digit width (9-bit digits, four passes instead of five over 36 bits, were slower: 5.9 ms against 4.7 on
-                                        // config 3 -- 40 KB of LDS per workgroup leaves three per CU, and the counters' upkeep grows with the digits)
+#define FB_DBITS 9                      // digit width: four passes over the 36 bits a k = 27 bucket sorts on, five over k = 31's 44 (8-bit digits: five
+                                        // and six; 3.7 -> 3.0 ms and 4.3 -> 3.8 ms on config 3 -- the ranks come from LDS atomics, whose cost does
+                                        // not grow with the digit as the ballots' does; wider digits cost LDS, i.e. workgroups per CU)
 #define FB_DIGITS (1 << FB_DBITS)
 // (Also tried: the top 24 remaining bits first -- three passes instead of five --, every pass only for a bucket whose k-mers then fail
 // an order check.  On a pan-genome 85 % of the buckets fail it: the SNP variants of a k-mer share all but one base, one variant in
@@ -162,7 +168,7 @@ __device__ __forceinline__ void load_bucket(uint64_t (&key)[EMAX], const uint64_
 // the kernel is bound by the latency of its LDS round trips and barriers, and both the registers and the LDS of a workgroup -- hence
 // the workgroups a CU holds -- go with EMAX: 4 per CU at 16, 7 at 9)
 template <int EMAX>
-__global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : 4)) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
+__global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : EMAX <= 12 ? 4 : 3)) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
                                                           uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw, int mode, uint32_t* __restrict__ n_redone,
                                                           uint32_t min_n) {  // buckets of up to min_n composites are k_bucket_sort_wave's
     __shared__ uint64_t keys[FB_BLOCK * EMAX];
