@@ -24,6 +24,12 @@ python3 tools/bench_k_sweep.py 2>&1 | strip > "$OUT/k_sweep.jsonl"
 python3 tools/bench_insert.py --reserve 2>&1 | strip | tail -n 1 > "$OUT/insert_config3.json"
 python3 tools/bench_insert.py --reserve --k 31 2>&1 | strip | tail -n 1 > "$OUT/insert_config3_k31.json"
 bash tools/profile_build_trace.sh "${1:-final}/build_config3" --reserve > /dev/null 2>&1
+# one build as a timeline: kernels with start offsets and idle gaps (tools/build_timeline.py), and the host's own marks (BFT_GPU_TRACE_BUILD)
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/build_tl" -- python3 "$ROOT/tools/bench_insert.py" --reserve --sample 100000 > /dev/null 2>&1 )
+python3 tools/build_timeline.py "$OUT/build_tl" > "$OUT/build_config3_timeline.txt" 2>&1
+rm -rf "$OUT/build_tl"
+BFT_GPU_TRACE_BUILD=1 python3 tools/bench_insert.py --reserve --sample 100000 2>&1 >/dev/null | grep "bft_gpu build" | tail -n 26 > "$OUT/build_config3_host_marks.txt"
+BFT_GPU_TRACE_BUILD=1 python3 tools/bench_insert.py --reserve --k 31 --sample 100000 2>&1 >/dev/null | grep "bft_gpu build" | tail -n 26 > "$OUT/build_config3_k31_host_marks.txt"
 python3 tools/bench_sequences.py 2>&1 | strip | grep "^{" > "$OUT/sequences.json"
 python3 tools/bench_color_rows.py 2>&1 | strip | grep "^{" > "$OUT/color_rows.jsonl"
 ls -la "$OUT"
