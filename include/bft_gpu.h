@@ -144,7 +144,7 @@ int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_km
  * [12]=image bytes in HBM, [13]=root CCs, [14]=root UC rows, [15]=pending (unbuilt) pairs. */
 int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 /* Bytes resident in HBM per part of the handle (the walk of src/printMemory.c:255 reports the reference's bytes per container kind):
- * out[0]=sorted k-mer table tk, [1]=colour-set id per k-mer, [2]=colour-set dictionary, [3]=containers (nodes, Bloom blocks, CC headers, filter2
+ * out[0]=sorted k-mer table tk, [1]=colour-set id per k-mer, [2]=colour-set dictionary (offsets + genome ids in 1, 2 or 4 bytes, by the largest id inserted), [3]=containers (nodes, Bloom blocks, CC headers, filter2
  * words, cluster table, prefix entries, node UCs), [4]=flat form of the big CCs, [5]=root tables, [6]=node prefix hash, [7]=k-mer hash,
  * [8]=bitmap form of the dictionary (derived by the first colour-row query), [9]=hash table (hash_v % 1504), [10]=0 (rounds 1-2 kept a sorted
  * (k-mer, genome) pair store for later insertions; the index is its own store now), [11]=pending insertion log. */
@@ -167,9 +167,11 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none), "tune" (1: measure residency, probe
  *   mode and root tables of the walk on the current image with a batch drawn from the index -- the only call that times anything; it synchronises;
  *   nothing is ever tuned implicitly by a build or a query).
- * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending and fit the key's spare low bits are sorted as one 8-byte composite
- *   array; 0: the general key + value sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
- *   device-wide sort; 2: buckets at any size -- same image, test hooks), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
+ * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending take the root-prefix front end -- as 8-byte composites
+ *   k-mer << bits | genome where that fits 63 bits, as (k-mer, id) pairs whose composite is formed inside a bucket otherwise; 0: the general key + value
+ *   sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
+ *   device-wide sort; 2: buckets at any size -- same image, test hooks), "test_front_rank_mode" (process-wide test hook: how a bucket ranks its digits:
+ *   0, default = LDS atomics + order check + ballot fallback, 1 = ballots only, 2 = the check always fails), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
  *   pairs, so that a series of insert calls never re-allocates it), "flush_pairs" (the log is merged into the index before it holds this many pairs:
  *   2^30 by default, 1024..2^30).
  * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on). */
