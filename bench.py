@@ -333,6 +333,19 @@ def main():
                                 "image_bytes_per_kmer": round(img / info["kmers"], 2), "file_bytes_per_kmer": round(fb / info["kmers"], 2),
                                 "parts": fp, "write_bft_s": round(t_w, 2),
                                 "note": "image = every array a query may touch (the index is its own store: no (k-mer, genome) pair list is kept)"}
+            # "compact_table": the sorted table and the colour set per k-mer leave HBM (the k-mer hash holds both); the same launches, timed
+            try:
+                bft.set_option("compact_table", 1)
+                cimg = bft.info()["image_bytes"]
+                bits_c = torch.zeros_like(dbits)
+                c_ms = timed_launches(bft, dq.data_ptr(), nq, bits_c.data_ptr(), stream, 5)
+                same = bool(torch.equal(bits_c, dbits))
+                del bits_c
+                out["footprint"]["compact_table"] = {"image_bytes": cimg, "image_over_file": round(cimg / fb, 2), "image_bytes_per_kmer": round(cimg / info["kmers"], 2),
+                                                     "M_kmers_per_s": round(nq / c_ms / 1e3, 1), "same_bits": same,
+                                                     "note": "bft_gpu_set_option(compact_table, 1): rows, extraction, merges, .bft files and the container walk bring the table back first"}
+            finally:
+                bft.set_option("compact_table", 0)
         except Exception as e:
             out["footprint"] = {"error": repr(e), "parts": fp}
 

@@ -237,6 +237,8 @@ struct bft_gpu {
     DevBuf d_kh;                  // derived: k-mer hash (BFT_KH_*, k_kh_insert), optional
     uint64_t kh_lines = 0;
     bool opt_kmer_hash = true;    // "kmer_hash"
+    bool opt_compact = false;     // "compact_table": the sorted table and the colour set per k-mer are dropped once the k-mer hash holds them (ensure_table)
+    bool table_dropped = false;   // d_tk / d_tcol are not resident: the k-mer hash is the only copy
     uint32_t opt_kh_load = 50;    // "kmer_hash_load": per cent of the table's slots in use
     double kh_ms = 0;             // GPU time of the last fill
     hipStream_t stream2 = nullptr; // bft_gpu_build fills the k-mer hash here while the containers are assembled on `stream`
@@ -902,6 +904,49 @@ static void derive_kmer_hash(bft_gpu* h) {
     h->im.kh_lines = lines;
 }
 
+// "compact_table": the k-mer hash holds every (k-mer, colour set) of the index, so the sorted table tk and tcol -- 12 of the image's
+// 41 bytes per k-mer on the 100-genome index -- need not stay resident for presence, colour, branching and sequence queries.  They are
+// dropped after a build and come back (a dump of the table's slots + one radix sort: milliseconds) when something asks for rows, an
+// extraction, a merge, a .bft file, a packed image or the container walk.  One-word keys only (k <= 31).
+static bool compact_possible(const bft_gpu* h) { return h->W == 1 && h->im.kh != nullptr && h->n_kmers > 0; }
+static void drop_table(bft_gpu* h) {
+    if (!h->opt_compact || h->table_dropped || !compact_possible(h)) return;
+    h->d_tk.release();
+    h->d_tcol.release();
+    h->table_dropped = true;
+    h->im.tk = nullptr;
+    h->im.tcol = nullptr;
+    h->info[12] = image_bytes(h);
+}
+static int ensure_table(bft_gpu* h) {
+    if (!h->table_dropped) return 0;
+    CK(wait_foreign_stream(h));
+    const uint64_t n = h->n_kmers;
+    DevBuf keys, vals, cnt, tmp, tk, tcol;
+    CK(keys.alloc(n * 8));
+    CK(vals.alloc(n * 4));
+    CK(tk.alloc(n * 8));
+    CK(tcol.alloc(n * 4));
+    CK(cnt.alloc_zero(8, h->stream));
+    CK(bft_kh_dump1(h->d_kh.as<uint64_t>(), h->kh_lines, keys.as<uint64_t>(), vals.as<uint32_t>(), cnt.as<unsigned long long>(), h->stream));
+    unsigned long long got = 0;
+    HIPCK(hipMemcpyAsync(&got, cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (got != n) return fail(BFT_GPU_E_HIP, "k-mer hash does not hold the index (compact_table)");
+    size_t tb = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+    CK(tmp.alloc(tb));
+    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->d_tk.swap(tk);
+    h->d_tcol.swap(tcol);
+    h->table_dropped = false;
+    h->im.tk = h->d_tk.as<uint64_t>();
+    h->im.tcol = h->d_tcol.as<uint32_t>();
+    h->info[12] = image_bytes(h);
+    return 0;
+}
+
 // Launch shape of the container walk when nothing was measured ("tune") or fixed by the caller: two 768-thread workgroups per CU (the
 // arrangement that was best or within a few per cent of it on every index measured), 8-row probes once suffix groups
 // hold dozens of rows, and the root range table unless most root prefixes are child Nodes (their lookups pay it for nothing).
@@ -1129,6 +1174,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     ENTER(h);
     if (h->built && h->log_n == 0) return BFT_GPU_OK;
     CK(wait_foreign_stream(h));  // batches still being packed into the log on a caller's stream (bft_gpu_insert_kmers_dev_async)
+    if (h->built) CK(ensure_table(h));  // ("compact_table": the merge reads the index's sorted table)
     const int W = h->W;
     const uint64_t total = h->log_n;  // the run: what was inserted since the last build
     double t0 = now_ms();
@@ -1424,13 +1470,18 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     derive_node_hash(h);
     default_launch_shape(h);
     I[12] = image_bytes(h);
+    h->table_dropped = false;
+    drop_table(h);  // ("compact_table")
     bft_trace_mark("launch shape; done");
     h->build_ms[4] = now_ms() - t3;
     return BFT_GPU_OK;
 }
 
-static int ensure_built(bft_gpu* h) {
-    if (!h->built || h->log_n) return bft_gpu_build(h);
+static int ensure_table(bft_gpu* h);
+// need_table = false: the caller is answered by the k-mer hash alone ("compact_table": the sorted table may be away)
+static int ensure_built(bft_gpu* h, bool need_table = true) {
+    if (!h->built || h->log_n) CK(bft_gpu_build(h));
+    if (need_table) CK(ensure_table(h));
     return 0;
 }
 
@@ -1518,6 +1569,7 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
     if (h->im.kh != nullptr && (d_rows == nullptr || h->im.emit_cs)) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    CK(ensure_table(h));
     return launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
@@ -1694,7 +1746,7 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
 extern "C" int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_branching_bits, void* d_counts, void* hip_stream) {
     if (!h || ((!d_kmers || !d_branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     CK(launch_branching(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_branching_bits, (uint8_t*)d_counts, s));
     return note_foreign_stream(h, s);
@@ -1703,7 +1755,7 @@ extern "C" int bft_gpu_query_branching_dev(bft_gpu* h, const void* d_kmers, uint
 extern "C" int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* branching_bits, uint8_t* counts) {
     if (!h || ((!kmers || !branching_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     const uint64_t chunk = 1ull << 26;
     const uint64_t mc = std::min(n, chunk);
     DevBuf dk, db, dc;
@@ -1724,7 +1776,7 @@ extern "C" int bft_gpu_query_branching(bft_gpu* h, const uint8_t* kmers, uint64_
 extern "C" int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* hip_stream) {
     if (!h || ((!d_kmers || !d_present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     CK(launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, nullptr, s));
     return note_foreign_stream(h, s);
@@ -1769,7 +1821,7 @@ static int query_small(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* pr
 extern "C" int bft_gpu_query_presence(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits) {
     if (!h || ((!kmers || !present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     if (n && n <= BFT_PIN_MAX_N) return query_small(h, kmers, n, present_bits, nullptr, nullptr);
     const uint64_t chunk = 1ull << 26;  // multiple of 64: chunks are byte aligned in the bitmap
     DevBuf dk, db;
@@ -1897,7 +1949,7 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
                                             void* hip_stream) {
     if (!h || ((!d_kmers || !d_present_bits || !d_rows || !d_scratch_rows_u32) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const uint32_t rowbytes = (h->im.nb_genomes + 7) / 8;
     if (n == 0 || rowbytes == 0) return BFT_GPU_OK;
@@ -1905,6 +1957,7 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
     // walk): no row -> colour set pass
     CK(ensure_cs_bitmaps(h));
     const bool direct = h->has_cs_bm;
+    if (!direct) CK(ensure_table(h));
     if (direct) h->im.emit_cs = 1;
     const int rc = launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s);
     h->im.emit_cs = 0;
@@ -2033,7 +2086,7 @@ extern "C" int bft_gpu_query_sequences_dev(bft_gpu* h, const void* d_seqs, const
     if (!h || ((!d_seqs || !d_seq_off || !d_rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (!(threshold > 0) || threshold > 1) return fail(BFT_GPU_E_ARG, "the threshold must be in (0, 1] (reference src/bft.c:1246-1247)");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     CK(query_sequences_core(h, (const char*)d_seqs, (const uint64_t*)d_seq_off, n_seqs, total_chars, threshold, canonical, (uint8_t*)d_rows, s));
     return note_foreign_stream(h, s);
@@ -2044,7 +2097,7 @@ extern "C" int bft_gpu_query_sequences(bft_gpu* h, const char* seqs, const uint6
     if (!h || ((!seqs || !seq_off || !rows) && n_seqs)) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (!(threshold > 0) || threshold > 1) return fail(BFT_GPU_E_ARG, "the threshold must be in (0, 1] (reference src/bft.c:1246-1247)");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));  // (the k-mer hash answers; the walk fetches the table itself)
     const uint32_t G = h->im.nb_genomes, rowbytes = (G + 7) / 8;
     if (rowbytes == 0 || n_seqs == 0) return BFT_GPU_OK;
     // host buffers: the blob and its offsets (rebased to the first sequence) go up in pieces of at most 2^30 characters
@@ -2188,7 +2241,7 @@ void plan_blob(bft_gpu* h, BlobPlan& p) {
 extern "C" int bft_gpu_image_size(bft_gpu* h, uint64_t* nbytes) {
     if (!h || !nbytes) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));
     BlobPlan p;
     plan_blob(h, p);
     *nbytes = p.hdr[H_TOTAL];
@@ -2344,9 +2397,20 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             ENTER(h);
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
+            CK(ensure_table(h));
             derive_kmer_hash(h);
             derive_node_hash(h);  // (by default the node prefix hash exists exactly when the k-mer hash does not)
             h->info[12] = image_bytes(h);
+            drop_table(h);
+        }
+    } else if (nm == "compact_table") {  // 1: the sorted k-mer table and the colour set per k-mer do not stay resident beside the k-mer hash (ensure_table)
+        h->opt_compact = value != 0;
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            if (h->opt_compact) drop_table(h);
+            else CK(ensure_table(h));
         }
     } else if (nm == "root_direct") {  // 2 (default): root level through the derived range + direct tables; 1: direct table only; 0: containers
         if (value < 0 || value > 3) return fail(BFT_GPU_E_ARG, "root_direct must be 0, 1, 2 or 3");
@@ -2364,6 +2428,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             ENTER(h);
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
+            CK(ensure_table(h));
             CK(tune_residency(h));
         }
     } else if (nm == "query_grid_mult") {
@@ -2484,7 +2549,7 @@ extern "C" int bft_gpu_extract(bft_gpu* h, uint8_t* kmers_out, uint32_t* colorse
 extern "C" int bft_gpu_colorset(bft_gpu* h, uint32_t cs, uint32_t* ids, uint32_t cap, uint32_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));
     CK(host_colorsets(h));
     if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
     const uint32_t a = h->cs_off[cs], b = h->cs_off[cs + 1];
@@ -2529,7 +2594,7 @@ extern "C" int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t n, 
 extern "C" int bft_gpu_colorset_annot(bft_gpu* h, uint32_t cs, uint8_t* annot, uint32_t cap, uint32_t* n_out) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));
     CK(host_colorsets(h));
     if ((uint64_t)cs + 1 >= h->cs_off.size()) return fail(BFT_GPU_E_ARG, "unknown colour set");
     const uint32_t a = h->cs_off[cs], b = h->cs_off[cs + 1];

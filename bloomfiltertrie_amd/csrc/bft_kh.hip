@@ -186,6 +186,48 @@ static unsigned kh_grid(uint64_t n, uint64_t per_block, int mult) {
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8 * (uint64_t)std::max(1, mult)));
 }
 
+// Every (key, value) the table holds, in any order: each workgroup counts the occupied slots of its share of the lines, reserves that
+// many places with one atomic, writes.  (One-word keys: the "compact_table" option rebuilds the sorted table from this.)
+__global__ __launch_bounds__(256) void k_kh_dump1(const uint64_t* __restrict__ kh, uint64_t n_lines, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                  unsigned long long* __restrict__ cnt) {
+    constexpr uint32_t S = BFT_KH_SLOTS(1);
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_base;
+    const uint64_t per = (n_lines + gridDim.x - 1) / gridDim.x, l0 = blockIdx.x * per, l1 = min(n_lines, l0 + per);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint64_t ln = l0 + threadIdx.x; ln < l1; ln += blockDim.x) {
+        const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
+#pragma unroll
+        for (uint32_t sl = 0; sl < S; sl++) mine += line[sl] != BFT_KH_EMPTY;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base = s_cnt ? atomicAdd(cnt, (unsigned long long)s_cnt) : 0ull; s_cnt = 0; }
+    __syncthreads();
+    for (uint64_t ln = l0 + threadIdx.x; ln < l1; ln += blockDim.x) {
+        const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
+        const uint32_t* v = reinterpret_cast<const uint32_t*>(line + S);
+#pragma unroll
+        for (uint32_t sl = 0; sl < S; sl++) {
+            const uint64_t key = line[sl];
+            if (key != BFT_KH_EMPTY) {
+                const uint64_t j = s_base + atomicAdd(&s_cnt, 1u);
+                keys[j] = key;
+                vals[j] = v[sl];
+            }
+        }
+    }
+}
+
+int bft_kh_dump1(const uint64_t* d_kh, uint64_t n_lines, uint64_t* d_keys, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_kh_dump1, dim3(256 * 8), dim3(256), 0, s, d_kh, n_lines, d_keys, d_vals, d_cnt);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W, uint64_t* d_kh, uint64_t n_lines, hipStream_t s) {
     // (one key per thread, not a persistent grid: the fill runs beside the container assembly on a low-priority stream, and a
     // workgroup that ends gives its CU slots to the assembly's next small kernel)

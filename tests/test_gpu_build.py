@@ -510,3 +510,90 @@ def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
         assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
     assert redone[0] == 0 and redone[1] == 0 and redone[2] == 0, redone
     assert redone[3] >= n_pref if k > 9 else redone[3] == 0, redone  # (k = 9: the split covers every bit, nothing is sorted in a bucket)
+
+
+@pytest.mark.parametrize("k", [27, 31, 18])
+def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
+    """"compact_table": once the k-mer hash holds every (k-mer, colour set) the sorted table and the colour set per k-mer leave HBM;
+    presence, colour-row, branching and sequence queries go on as before; rows, extraction, a .bft file, a packed image and a merge of
+    new insertions bring the table back first.  Everything equals what a handle without the option gives."""
+    import torch
+    anc = S.random_genome(50000, k)
+    genomes = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 20 + g), k)) for g in range(6)]
+    a, b = BFT(k), BFT(k)
+    b.set_option("compact_table", 1)
+    for t in (a, b):
+        for g in range(4):
+            t.add_genome(f"g{g}.fa")
+            t.insert_kmers(genomes[g], g)
+        t.build()
+    fa, fb = a.footprint(), b.footprint()
+    assert fb["kmer_table"] == 0 and fb["colorset_per_kmer"] == 0 and fa["kmer_table"] > 0
+    assert b.info()["image_bytes"] < a.info()["image_bytes"] - 12 * a.info()["kmers"] + 1024
+    allk = S.distinct(np.concatenate(genomes[:4]))
+    q = np.concatenate([allk[::3], S.snp_mutants(allk[::7], k, 4)])
+    assert (a.query_presence(q) == b.query_presence(q)).all()
+
+    def rows_dev(t):  # the device-resident colour rows (the host call goes through row numbers)
+        dq = torch.from_numpy(q).to("cuda:0")
+        bits = torch.zeros(((len(q) + 63) // 64) * 8, dtype=torch.uint8, device="cuda:0")
+        rows = torch.zeros((len(q), (t.info()["genomes"] + 7) // 8), dtype=torch.uint8, device="cuda:0")
+        scratch = torch.zeros(len(q), dtype=torch.int32, device="cuda:0")
+        t.query_color_rows_dev(dq.data_ptr(), len(q), bits.data_ptr(), rows.data_ptr(), scratch.data_ptr())
+        torch.cuda.synchronize()
+        return bits.cpu().numpy(), rows.cpu().numpy()
+
+    (ba, wa), (bb, wb) = rows_dev(a), rows_dev(b)
+    assert (ba == bb).all() and (wa == wb).all()
+    assert (a.query_branching(q[:4000]) == b.query_branching(q[:4000])).all()
+    reads = [bytes(S._ASCII[S.mutate(anc, 0.02, 20 + g)[500:700]]).decode() for g in range(4)]
+    assert a.query_sequences(reads, 0.9) == b.query_sequences(reads, 0.9)
+    assert b.footprint()["kmer_table"] == 0  # still away: none of those needed it
+    # rows / colour ids / extraction bring it back
+    ra, rb = a.query_color_rows(q), b.query_color_rows(q)
+    assert (ra[0] == rb[0]).all() and (ra[1] == rb[1]).all() and (ra[1] == wa).all()
+    b.set_option("compact_table", 1)
+    ca, cb = a.query_colors(q[:3000]), b.query_colors(q[:3000])
+    assert all((x == y).all() for x, y in zip(ca, cb))
+    ka, sa = a.extract()
+    kb, sb = b.extract()
+    assert (ka == kb).all() and (sa == sb).all()
+    assert b.footprint()["kmer_table"] == fa["kmer_table"]
+    for name in ARRAYS:
+        assert (a.debug_array(name) == b.debug_array(name)).all(), name
+    b.set_option("compact_table", 1)  # away again
+    assert b.footprint()["kmer_table"] == 0
+    if k % 9 == 0:  # (the .bft format's k)
+        a.write_bft(str(tmp_path / "a.bft"))
+        b.write_bft(str(tmp_path / "b.bft"))
+        assert open(tmp_path / "a.bft", "rb").read() == open(tmp_path / "b.bft", "rb").read()
+        assert b.footprint()["kmer_table"] > 0
+        b.set_option("compact_table", 1)
+    n = b.image_size()
+    blob = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    b.image_pack(blob.data_ptr(), n)
+    c = BFT.from_image(blob.data_ptr(), n, device=0)
+    assert (c.query_presence(q) == a.query_presence(q)).all() and (c.extract()[0] == ka).all()
+    c.close()
+    # a merge of new insertions
+    b.set_option("compact_table", 1)
+    for t in (a, b):
+        for g in (4, 5):
+            t.add_genome(f"g{g}.fa")
+            t.insert_kmers(genomes[g], g)
+        t.build()
+    assert b.footprint()["kmer_table"] == 0
+    q2 = np.concatenate([genomes[5][::2], q[:5000]])
+    assert (a.query_presence(q2) == b.query_presence(q2)).all()
+    ra, rb = a.query_color_rows(q2), b.query_color_rows(q2)
+    assert (ra[1] == rb[1]).all()
+    ma, na = _colour_map(a)
+    mb, nb_ = _colour_map(b)
+    assert ma == mb and na == nb_
+    # the k-mer hash switched off: the walk needs the table
+    b.set_option("compact_table", 1)
+    b.set_option("kmer_hash", 0)
+    assert b.footprint()["kmer_table"] > 0
+    assert (a.query_presence(q2) == b.query_presence(q2)).all()
+    a.close()
+    b.close()

@@ -48,6 +48,8 @@ for r in range(rounds):
         t.set_option("flush_pairs", int(rng.choice([1024, 5000, 40000])))  # the log is merged into the index many times on the way
     if rng.random() < 0.3:
         t.set_option("kmer_hash_load", int(rng.choice([20, 65, 80])))
+    if rng.random() < 0.4:
+        t.set_option("compact_table", 1)                                   # the sorted table leaves HBM whenever the k-mer hash can stand in for it
     cut = int(rng.integers(0, ngen + 1))
     use_async = bool(rng.random() < 0.4)
     for j, gi in enumerate(order):
