@@ -907,8 +907,12 @@ static void derive_kmer_hash(bft_gpu* h) {
 // "compact_table": the k-mer hash holds every (k-mer, colour set) of the index, so the sorted table tk and tcol -- 12 of the image's
 // 41 bytes per k-mer on the 100-genome index -- need not stay resident for presence, colour, branching and sequence queries.  They are
 // dropped after a build and come back (a dump of the table's slots + one radix sort: milliseconds) when something asks for rows, an
-// extraction, a merge, a .bft file, a packed image or the container walk.  One-word keys only (k <= 31).
-static bool compact_possible(const bft_gpu* h) { return h->W == 1 && h->im.kh != nullptr && h->n_kmers > 0; }
+// extraction, a merge, a .bft file, a packed image or the container walk.
+__global__ void k_rows_from_words(const uint64_t* __restrict__ words, uint64_t n, int W, uint64_t* __restrict__ rows) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        for (int w = 0; w < W; w++) rows[i * W + w] = words[(uint64_t)w * n + i];
+}
+static bool compact_possible(const bft_gpu* h) { return h->W <= 2 && h->im.kh != nullptr && h->n_kmers > 0; }
 static void drop_table(bft_gpu* h) {
     if (!h->opt_compact || h->table_dropped || !compact_possible(h)) return;
     h->d_tk.release();
@@ -922,21 +926,30 @@ static int ensure_table(bft_gpu* h) {
     if (!h->table_dropped) return 0;
     CK(wait_foreign_stream(h));
     const uint64_t n = h->n_kmers;
+    const int W = h->W;
     DevBuf keys, vals, cnt, tmp, tk, tcol;
-    CK(keys.alloc(n * 8));
+    CK(keys.alloc(n * W * 8));
     CK(vals.alloc(n * 4));
-    CK(tk.alloc(n * 8));
+    CK(tk.alloc(n * W * 8));
     CK(tcol.alloc(n * 4));
     CK(cnt.alloc_zero(8, h->stream));
-    CK(bft_kh_dump1(h->d_kh.as<uint64_t>(), h->kh_lines, keys.as<uint64_t>(), vals.as<uint32_t>(), cnt.as<unsigned long long>(), h->stream));
+    CK(bft_kh_dump(h->d_kh.as<uint64_t>(), h->kh_lines, W, keys.as<uint64_t>(), n, vals.as<uint32_t>(), cnt.as<unsigned long long>(), h->stream));
     unsigned long long got = 0;
     HIPCK(hipMemcpyAsync(&got, cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     if (got != n) return fail(BFT_GPU_E_HIP, "k-mer hash does not hold the index (compact_table)");
-    size_t tb = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
-    CK(tmp.alloc(tb));
-    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+    if (W == 1) {
+        size_t tb = 0;
+        HIPCK(rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+        CK(tmp.alloc(tb));
+        HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+    } else {  // two-word keys: the build's permutation sort (words apart, as the dump wrote them), then rows of two words
+        DevBuf sorted;
+        CK(sorted.alloc(n * W * 8));
+        CK(sort_pairs(h, keys.as<uint64_t>(), n, vals.as<uint32_t>(), n, sorted.as<uint64_t>(), n, tcol.as<uint32_t>(), true));
+        hipLaunchKernelGGL(k_rows_from_words, dim3(grid_for((n + 255) / 256)), dim3(256), 0, h->stream, sorted.as<uint64_t>(), n, W, tk.as<uint64_t>());
+        HIPCK(hipGetLastError());
+    }
     HIPCK(hipStreamSynchronize(h->stream));
     h->d_tk.swap(tk);
     h->d_tcol.swap(tcol);

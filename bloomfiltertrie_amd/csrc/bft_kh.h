@@ -7,8 +7,8 @@
 
 #define BFT_KH_BLOCK 256
 // fills the table (d_kh: n_lines x 64 bytes, every byte 0xFF) with the n rows of the sorted table and their colour sets
-// one-word keys: every (key, value) of the table, unordered; *d_cnt (zeroed by the caller) = how many
-int bft_kh_dump1(const uint64_t* d_kh, uint64_t n_lines, uint64_t* d_keys, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
+// every (key, value) of the table, unordered, word w of key j at d_keys[w * stride + j]; *d_cnt (zeroed by the caller) = how many
+int bft_kh_dump(const uint64_t* d_kh, uint64_t n_lines, int W, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
 int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W, uint64_t* d_kh, uint64_t n_lines, hipStream_t s);
 // presence bits (+ colour-set id per k-mer when d_out32 != NULL) of n packed k-mers of `rec` bytes each
 int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s);

@@ -187,10 +187,12 @@ static unsigned kh_grid(uint64_t n, uint64_t per_block, int mult) {
 }
 
 // Every (key, value) the table holds, in any order: each workgroup counts the occupied slots of its share of the lines, reserves that
-// many places with one atomic, writes.  (One-word keys: the "compact_table" option rebuilds the sorted table from this.)
-__global__ __launch_bounds__(256) void k_kh_dump1(const uint64_t* __restrict__ kh, uint64_t n_lines, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                  unsigned long long* __restrict__ cnt) {
-    constexpr uint32_t S = BFT_KH_SLOTS(1);
+// many places with one atomic, writes (word w of the j-th key at keys[w * stride + j]).  The "compact_table" option rebuilds the sorted
+// table from this.
+template <int W>
+__global__ __launch_bounds__(256) void k_kh_dump(const uint64_t* __restrict__ kh, uint64_t n_lines, uint64_t* __restrict__ keys, uint64_t stride, uint32_t* __restrict__ vals,
+                                                 unsigned long long* __restrict__ cnt) {
+    constexpr uint32_t S = BFT_KH_SLOTS(W);
     __shared__ uint32_t s_cnt;
     __shared__ unsigned long long s_base;
     const uint64_t per = (n_lines + gridDim.x - 1) / gridDim.x, l0 = blockIdx.x * per, l1 = min(n_lines, l0 + per);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void k_kh_dump1(const uint64_t* __restrict__ k
     for (uint64_t ln = l0 + threadIdx.x; ln < l1; ln += blockDim.x) {
         const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
 #pragma unroll
-        for (uint32_t sl = 0; sl < S; sl++) mine += line[sl] != BFT_KH_EMPTY;
+        for (uint32_t sl = 0; sl < S; sl++) mine += line[sl * W] != BFT_KH_EMPTY;
     }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -209,21 +211,22 @@ __global__ __launch_bounds__(256) void k_kh_dump1(const uint64_t* __restrict__ k
     __syncthreads();
     for (uint64_t ln = l0 + threadIdx.x; ln < l1; ln += blockDim.x) {
         const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
-        const uint32_t* v = reinterpret_cast<const uint32_t*>(line + S);
+        const uint32_t* v = reinterpret_cast<const uint32_t*>(line + S * W);
 #pragma unroll
         for (uint32_t sl = 0; sl < S; sl++) {
-            const uint64_t key = line[sl];
-            if (key != BFT_KH_EMPTY) {
+            if (line[sl * W] != BFT_KH_EMPTY) {
                 const uint64_t j = s_base + atomicAdd(&s_cnt, 1u);
-                keys[j] = key;
+#pragma unroll
+                for (int w = 0; w < W; w++) keys[(uint64_t)w * stride + j] = line[sl * W + w];
                 vals[j] = v[sl];
             }
         }
     }
 }
 
-int bft_kh_dump1(const uint64_t* d_kh, uint64_t n_lines, uint64_t* d_keys, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_kh_dump1, dim3(256 * 8), dim3(256), 0, s, d_kh, n_lines, d_keys, d_vals, d_cnt);
+int bft_kh_dump(const uint64_t* d_kh, uint64_t n_lines, int W, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s) {
+    if (W == 1) hipLaunchKernelGGL(k_kh_dump<1>, dim3(256 * 8), dim3(256), 0, s, d_kh, n_lines, d_keys, stride, d_vals, d_cnt);
+    else hipLaunchKernelGGL(k_kh_dump<2>, dim3(256 * 8), dim3(256), 0, s, d_kh, n_lines, d_keys, stride, d_vals, d_cnt);
     HIPCK(hipGetLastError());
     return 0;
 }

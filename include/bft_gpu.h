@@ -170,7 +170,7 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  * Footprint: "compact_table" (0, default; 1: the sorted k-mer table and the colour set per k-mer -- 12 bytes per k-mer -- do not stay resident once the
  *   k-mer hash holds every (k-mer, colour set): presence, colour-row, branching and sequence queries never need them; rows, extraction, a merge
  *   of new insertions, .bft files, packed images, the container walk and "tune" bring them back first -- a dump of the table + one sort, milliseconds --
- *   and they stay until the next build or until the option is set again.  One-word keys (k <= 31) with a k-mer hash only; otherwise no effect).
+ *   and they stay until the next build or until the option is set again.  No effect on a handle without a k-mer hash (k >= 64, 2k % 64 == 0, "kmer_hash" 0)).
  * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending take the root-prefix front end -- as 8-byte composites
  *   k-mer << bits | genome where that fits 63 bits, as (k-mer, id) pairs whose composite is formed inside a bucket otherwise; 0: the general key + value
  *   sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one

@@ -512,7 +512,7 @@ def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
     assert redone[3] >= n_pref if k > 9 else redone[3] == 0, redone  # (k = 9: the split covers every bit, nothing is sorted in a bucket)
 
 
-@pytest.mark.parametrize("k", [27, 31, 18])
+@pytest.mark.parametrize("k", [27, 31, 18, 45, 63])
 def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
     """"compact_table": once the k-mer hash holds every (k-mer, colour set) the sorted table and the colour set per k-mer leave HBM;
     presence, colour-row, branching and sequence queries go on as before; rows, extraction, a .bft file, a packed image and a merge of
