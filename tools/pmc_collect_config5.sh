@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -- python3 "$ROOT/tools/pmc_config5.py" $REPS > "$OUT/stats.log" 2>&1
 python3 "$ROOT/profiles/summarize_rocpd.py" "$(find "$OUT/stats" -name '*.db' | head -1)" > "$OUT/kernel_stats.txt"
 i=0
-for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/tools/pmc_config5.py" $REPS > "$OUT/pass$i.log" 2>&1
 done
