@@ -42,12 +42,12 @@ struct PinBlock {
             std::lock_guard<std::mutex> lk(mu());
             if (!cache().empty()) { p = cache().back(); cache().pop_back(); }
         }
-        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
     }
     ~PinBlock() {
         if (!p) return;
         std::lock_guard<std::mutex> lk(mu());
-        cache().push_back(p);  // (a handful of 256-byte blocks per process, kept)
+        cache().push_back(p);  // (a handful of 256-byte blocks per process, kept; portable: any device of the process may write them)
     }
     static std::mutex& mu() { static std::mutex m; return m; }
     static std::vector<uint64_t*>& cache() { static std::vector<uint64_t*> c; return c; }
