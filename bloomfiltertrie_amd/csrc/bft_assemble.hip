@@ -1012,45 +1012,63 @@ struct CsSlot {
 };
 __device__ __forceinline__ unsigned long long cs_key(uint64_t sig) { return sig ? sig : 0x9E3779B97F4A7C15ULL; }
 
-// (Nine lookups in ten ask for one of a hundred slots: as device-scope atomic loads those queue up at the few memory channels that
-// own them -- 13 ms.  Each workgroup therefore remembers, in LDS, the slot where a signature was last found; a remembered slot is
-// confirmed by an ordinary cached load of its signature, which is immutable once claimed -- a stale view can only show the slot free
-// and sends the lookup down the atomic path.)
+// (Nine lookups in ten ask for one of a hundred slots: as device-scope atomics those queue up at the few memory channels that own
+// them -- 13 ms; a run of ONE genome asks 2 x 10^6 times for one slot.  Each workgroup therefore remembers, in LDS, the slot where a
+// signature was last found; a remembered slot is confirmed by an ordinary cached load of its signature, which is immutable once
+// claimed -- a stale view can only show the slot free and sends the lookup down the atomic path.  And only ONE thread of the workgroup
+// at a time takes the atomic path for an entry of that memory (an LDS lock per entry): the others with the same signature find the
+// slot remembered when they look again.)
 #define CS_CACHE 2048u
 __global__ __launch_bounds__(ABLK) void k_cs_hash_insert(const uint64_t* __restrict__ sig, uint32_t nk, CsSlot* __restrict__ tab, uint32_t mask,
                                                          uint32_t* __restrict__ slot_of,
                                                          uint32_t* __restrict__ counters) {  // [0] slots claimed, [1] lookups that gave up (table too full)
     __shared__ uint32_t cache[CS_CACHE];
+    __shared__ uint32_t lock[CS_CACHE];
     __shared__ uint32_t s_new, s_fail;  // (one global atomic per workgroup at the end: 10^6 atomics on ONE address take 10 ns each)
-    for (uint32_t j = threadIdx.x; j < CS_CACHE; j += blockDim.x) cache[j] = 0xFFFFFFFFu;
+    for (uint32_t j = threadIdx.x; j < CS_CACHE; j += blockDim.x) { cache[j] = 0xFFFFFFFFu; lock[j] = 0; }
     if (threadIdx.x == 0) { s_new = 0; s_fail = 0; }
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
-        const unsigned long long key = cs_key(sig[i]);
+    const uint32_t nblk = (nk + ABLK - 1) / ABLK;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint32_t i = blk * ABLK + threadIdx.x;
+        bool done = i >= nk;
+        const unsigned long long key = done ? 0ull : cs_key(sig[i]);
         const uint32_t ch = (uint32_t)(key >> 40) & (CS_CACHE - 1u);
-        const uint32_t cand = cache[ch];
-        if (cand != 0xFFFFFFFFu && tab[cand].sig == key) {
-            slot_of[i] = cand;
-            continue;
-        }
-        uint32_t pos = (uint32_t)key & mask;
         uint32_t found = 0xFFFFFFFFu;
-        for (int probe = 0; probe < 256; probe++) {
-            unsigned long long cur = __hip_atomic_load(&tab[pos].sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == 0ull) {
-                cur = atomicCAS(&tab[pos].sig, 0ull, key);
-                if (cur == 0ull) {
-                    tab[pos].rep = i;
-                    atomicAdd(&s_new, 1u);
-                    cur = key;
+        // (every lane of the wavefront stays in the loop until all are done: a lane that holds a lock finishes its lookup inside the
+        // iteration, so the lanes waiting for it -- of this wavefront or another -- see the slot the next time round)
+        for (int round = 0; round < 4096 && __any(!done); round++) {
+            if (!done) {
+                const uint32_t cand = cache[ch];
+                if (cand != 0xFFFFFFFFu && tab[cand].sig == key) {
+                    found = cand;
+                    done = true;
+                } else if (atomicCAS(&lock[ch], 0u, 1u) == 0u) {
+                    uint32_t pos = (uint32_t)key & mask;
+                    for (int probe = 0; probe < 64; probe++) {  // (beyond that the table is too full: the caller retries with a larger one)
+                        unsigned long long cur = __hip_atomic_load(&tab[pos].sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cur == 0ull) {
+                            cur = atomicCAS(&tab[pos].sig, 0ull, key);
+                            if (cur == 0ull) {
+                                tab[pos].rep = i;
+                                atomicAdd(&s_new, 1u);
+                                cur = key;
+                            }
+                        }
+                        if (cur == key) { found = pos; break; }
+                        pos = (pos + 1u) & mask;
+                    }
+                    if (found != 0xFFFFFFFFu) cache[ch] = found;
+                    __threadfence_block();
+                    atomicExch(&lock[ch], 0u);
+                    done = true;
                 }
             }
-            if (cur == key) { found = pos; break; }
-            pos = (pos + 1u) & mask;
         }
-        if (found == 0xFFFFFFFFu) atomicAdd(&s_fail, 1u);
-        else cache[ch] = found;
-        slot_of[i] = found;
+        if (i < nk) {
+            if (found == 0xFFFFFFFFu) atomicAdd(&s_fail, 1u);
+            slot_of[i] = found;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1183,7 +1201,7 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
 // one signature -- sends the build through the sorted path, where runs of equal lists are found by comparing the lists themselves.
 // Two different sets can therefore never share an id, and two equal sets always do.
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
-                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids) {
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint) {
     n_sets = 0;
     n_ids = 0;
     CK(d_tcol.alloc(nk * 4));
@@ -1210,7 +1228,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
         CK(slot_of.alloc(nk * 4));
         CK(cnt.alloc(3 * 4));
         uint64_t n_slots = 1ull << 16;
-        while (n_slots < nk / 8) n_slots <<= 1;
+        while (n_slots < nk / 8 || n_slots < 3 * distinct_hint) n_slots <<= 1;  // (distinct_hint: lists the caller knows to differ -- a merge's old sets)
         for (int attempt = 0; attempt < 2 && !done; attempt++) {
             if (attempt) {
                 while (n_slots < 2 * nk) n_slots <<= 1;

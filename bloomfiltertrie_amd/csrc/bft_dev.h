@@ -76,6 +76,7 @@ struct BftDeviceIndex {
     uint64_t n_nodes = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_bf8 = 0, n_uc = 0;
     uint64_t n_child_nodes = 0, n_prefixes = 0, n_ccs_s4 = 0, max_ccs_per_node = 0, root_ncc = 0, root_uc = 0;
 };
+bool bft_trace_on(void);
 void bft_trace_mark(const char* what);  // BFT_GPU_TRACE_BUILD=1 (nullptr: start of a build)
 // after_table_passes: called once, when the first level's passes over the whole sorted table and its CC assignment are done on `s`
 struct BftAssembleHook {
@@ -91,7 +92,7 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
 void bft_test_weak_signature(bool on);            // test hook: every list's signature = its length (collisions galore)
 unsigned long long bft_test_exact_passes(void);   // how many times the interning had to fall back to comparing the lists
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
-                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids);
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint = 0);
 
 // Merging a sorted run of newly inserted k-mers into the built index (bft_merge.hip).  A "run" = sorted distinct T-form k-mers, a
 // colour-set id per k-mer and the dictionary those ids refer to -- what the index itself is made of.

@@ -54,6 +54,7 @@ static double now_ms() {
 // BFT_GPU_TRACE_BUILD=1: host-side timeline of bft_gpu_build on stderr (where the host waits, allocates, reads counts back)
 static bool g_trace = getenv("BFT_GPU_TRACE_BUILD") != nullptr;
 static double g_trace_t0 = 0, g_trace_last = 0;
+bool bft_trace_on(void) { return g_trace; }
 void bft_trace_mark(const char* what) {
     if (!g_trace) return;
     const double t = now_ms();
@@ -97,6 +98,8 @@ size_t pool_max_bytes() {
 constexpr size_t POOL_MAX_BLOCKS = 256;
 double g_malloc_ms = 0;          // time spent in hipMalloc by this process (diagnostic: bft_gpu_build_time)
 uint64_t g_malloc_calls = 0;
+double g_free_ms = 0;            // ... and in hipFree
+uint64_t g_free_calls = 0;
 thread_local int t_pool_device = -1;
 thread_local hipStream_t t_pool_stream = nullptr;
 
@@ -181,7 +184,13 @@ void bft_pool_release(void* p, size_t cap) {
         } else
             keep = false;
     }
-    if (!keep) (void)hipFree(p);
+    if (!keep) {
+        const double t0 = now_ms();
+        (void)hipFree(p);
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_free_ms += now_ms() - t0;
+        g_free_calls++;
+    }
 }
 
 void bft_pool_drop_stream(hipStream_t s) {
@@ -1486,6 +1495,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->table_dropped = false;
     drop_table(h);  // ("compact_table")
     bft_trace_mark("launch shape; done");
+    if (bft_trace_on()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        fprintf(stderr, "[bft_gpu build] cache of released blocks: %zu blocks, %.1f MB; this process so far: %llu hipMalloc (%.2f ms), %llu hipFree on release (%.2f ms)\n", g_pool.size(),
+                g_pool_bytes / 1048576.0, (unsigned long long)g_malloc_calls, g_malloc_ms, (unsigned long long)g_free_calls, g_free_ms);
+    }
     h->build_ms[4] = now_ms() - t3;
     return BFT_GPU_OK;
 }

@@ -20,6 +20,8 @@
 #include "bft_walk.h"
 
 #define MBLK 256
+// (tracing only: the stream is drained so that the mark shows the GPU time of the stage before it)
+#define TRACE_STAGE(s, what) do { if (bft_trace_on()) { (void)hipStreamSynchronize(s); bft_trace_mark(what); } } while (0)
 #define NONE32 0xFFFFFFFFu
 
 namespace {
@@ -134,20 +136,79 @@ __global__ void k_u_len_old(const uint32_t* __restrict__ used, const uint32_t* _
     for (uint64_t a = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; a < n_sets_a; a += (uint64_t)gridDim.x * blockDim.x)
         if (used[a]) len[uidx[a]] = cs_off_a[a + 1] - cs_off_a[a];
 }
-// fill != nullptr: second pass, writes the union at off[u]; else the lengths
-__global__ void k_u_pairs(const uint64_t* __restrict__ key_s, const uint32_t* __restrict__ head, const uint32_t* __restrict__ hidx, uint64_t n_b, uint32_t n_used,
-                          const uint32_t* __restrict__ cs_off_a, const uint32_t* __restrict__ cs_ids_a, const uint32_t* __restrict__ cs_off_b,
-                          const uint32_t* __restrict__ cs_ids_b, uint32_t* __restrict__ len, const uint32_t* __restrict__ off, uint32_t* __restrict__ fill) {
-    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n_b; q += (uint64_t)gridDim.x * blockDim.x) {
-        if (!head[q]) continue;
-        const uint64_t key = key_s[q];
-        const uint32_t a1 = (uint32_t)(key >> 32), b = (uint32_t)key, u = n_used + hidx[q];
-        const uint32_t* x = a1 ? cs_ids_a + cs_off_a[a1 - 1] : nullptr;
-        const uint32_t nx = a1 ? cs_off_a[a1] - cs_off_a[a1 - 1] : 0u;
-        const uint32_t* y = cs_ids_b + cs_off_b[b];
-        const uint32_t ny = cs_off_b[b + 1] - cs_off_b[b];
-        if (fill) union_len(x, nx, y, ny, fill + off[u]);
-        else len[u] = union_len(x, nx, y, ny, nullptr);
+// Union of two sorted id lists by the 64 lanes of a wavefront, the shorter one (`small`, at most 64 ids: a run is a few genomes) held one
+// id per lane: every small id finds its place in `big` by binary search (and whether it is there already), every big id the number of
+// NEW small ids below it by a search over the lanes.  out == nullptr: only the length.  Reads and writes of `big` are coalesced.
+__device__ __forceinline__ uint32_t wave_union(const uint32_t* __restrict__ big, uint32_t n_big, const uint32_t* __restrict__ small, uint32_t n_small,
+                                               uint32_t* __restrict__ out, uint32_t lane) {
+    const bool has = lane < n_small;
+    const uint32_t sv = has ? small[lane] : 0xFFFFFFFFu;
+    uint32_t lb = 0;
+    bool there = false;
+    if (has) {
+        uint32_t lo = 0, hi = n_big;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (big[mid] < sv) lo = mid + 1; else hi = mid;
+        }
+        lb = lo;
+        there = lo < n_big && big[lo] == sv;
+    }
+    const uint64_t fresh = __ballot(has && !there);
+    if (!out) return n_big + (uint32_t)__builtin_popcountll(fresh);
+    if (has && !there) out[lb + (uint32_t)__builtin_popcountll(fresh & ((1ull << lane) - 1ull))] = sv;
+    for (uint32_t j0 = 0; j0 < n_big; j0 += 64) {  // (every lane takes part in every shuffle)
+        const uint32_t j = j0 + lane;
+        const uint32_t v = j < n_big ? big[j] : 0u;
+        uint32_t lo = 0, hi = n_small;  // small ids below v
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const uint32_t mid = min((lo + hi) >> 1, 63u);
+            const uint32_t sm = __shfl(sv, mid);
+            if (lo < hi) { if (sm < v) lo = mid + 1; else hi = mid; }
+        }
+        if (j < n_big) out[j + (uint32_t)__builtin_popcountll(lo >= 64 ? fresh : (fresh & ((1ull << lo) - 1ull)))] = v;
+    }
+    return n_big + (uint32_t)__builtin_popcountll(fresh);
+}
+
+// fill != nullptr: second pass, writes the union at off[u]; else the lengths.  One pair at a time per wavefront when one of its lists
+// fits the lanes; a pair of two long lists is merged by its own lane.
+__global__ __launch_bounds__(MBLK) void k_u_pairs(const uint64_t* __restrict__ key_s, const uint32_t* __restrict__ head, const uint32_t* __restrict__ hidx, uint64_t n_b,
+                                                  uint32_t n_used, const uint32_t* __restrict__ cs_off_a, const uint32_t* __restrict__ cs_ids_a,
+                                                  const uint32_t* __restrict__ cs_off_b, const uint32_t* __restrict__ cs_ids_b, uint32_t* __restrict__ len,
+                                                  const uint32_t* __restrict__ off, uint32_t* __restrict__ fill) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nblk = (n_b + MBLK - 1) / MBLK;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // whole wavefronts stay in the loop together
+        const uint64_t q = blk * MBLK + threadIdx.x;
+        uint32_t xs = 0, nx = 0, ys = 0, ny = 0, u = 0;
+        bool hd = false;
+        if (q < n_b && head[q]) {
+            hd = true;
+            const uint64_t key = key_s[q];
+            const uint32_t a1 = (uint32_t)(key >> 32), b = (uint32_t)key;
+            u = n_used + hidx[q];
+            if (a1) { xs = cs_off_a[a1 - 1]; nx = cs_off_a[a1] - xs; }
+            ys = cs_off_b[b];
+            ny = cs_off_b[b + 1] - ys;
+        }
+        const bool coop = hd && (nx <= 64u || ny <= 64u);
+        if (hd && !coop) {  // two long lists
+            if (fill) union_len(cs_ids_a + xs, nx, cs_ids_b + ys, ny, fill + off[u]);
+            else len[u] = union_len(cs_ids_a + xs, nx, cs_ids_b + ys, ny, nullptr);
+        }
+        uint64_t todo = __ballot(coop);
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t xs0 = __shfl(xs, t), nx0 = __shfl(nx, t), ys0 = __shfl(ys, t), ny0 = __shfl(ny, t), u0 = __shfl(u, t);
+            const bool y_small = ny0 <= 64u;
+            const uint32_t* big = y_small ? cs_ids_a + xs0 : cs_ids_b + ys0;
+            const uint32_t* sml = y_small ? cs_ids_b + ys0 : cs_ids_a + xs0;
+            const uint32_t n = wave_union(big, y_small ? nx0 : ny0, sml, y_small ? ny0 : nx0, fill ? fill + off[u0] : nullptr, lane);
+            if (!fill && lane == 0) len[u0] = n;
+        }
     }
 }
 __global__ void k_u_fill_old(const uint32_t* __restrict__ used, const uint32_t* __restrict__ uidx, const uint32_t* __restrict__ cs_off_a,
@@ -203,11 +264,13 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
     CK(cnt.alloc_zero((n_a + 1) * 4, s));
     CK(qex.alloc((n_a + 1) * 4));
     hipLaunchKernelGGL(k_merge_search<W>, G(n_b), a.tk, n_a, b.tk, n_b, pos.as<uint32_t>(), ins.as<uint32_t>());
+    TRACE_STAGE(s, "  merge: search");
     uint64_t n_ins = 0, chk = 0;
     CK(scan.run(ins.as<uint32_t>(), pex.as<uint32_t>(), n_b, &n_ins));
     hipLaunchKernelGGL(k_merge_count, G(n_b), pos.as<uint32_t>(), ins.as<uint32_t>(), n_b, cnt.as<uint32_t>());
     CK(scan.run(cnt.as<uint32_t>(), qex.as<uint32_t>(), n_a + 1, &chk));
     if (chk != n_ins) return bft_fail(BFT_GPU_E_LIMIT, "merge self-check failed (insertion counts disagree)");
+    TRACE_STAGE(s, "  merge: counts + scans");
     const uint64_t n_o = n_a + n_ins;
     if (n_o >= 0x7FFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "more than 2^31-1 distinct k-mers");
     DevBuf pa, pb, orow;
@@ -217,11 +280,14 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
     CK(pb.alloc(n_o * 4));
     CK(orow.alloc(n_b * 4));
     HIPCK(hipMemsetAsync(pb.p, 0xFF, n_o * 4, s));
+    TRACE_STAGE(s, "  merge: outputs allocated");
     hipLaunchKernelGGL(k_merge_old<W>, G(n_a), a.tk, a.tcol, n_a, qex.as<uint32_t>(), cnt.as<uint32_t>(), out.tk.as<uint64_t>(), pa.as<uint32_t>());
     hipLaunchKernelGGL(k_merge_new<W>, G(n_b), b.tk, b.tcol, n_b, pos.as<uint32_t>(), ins.as<uint32_t>(), pex.as<uint32_t>(), qex.as<uint32_t>(), cnt.as<uint32_t>(),
                        out.tk.as<uint64_t>(), pa.as<uint32_t>(), pb.as<uint32_t>(), orow.as<uint32_t>());
     HIPCK(hipGetLastError());
+    TRACE_STAGE(s, "  merge: scatter of both sides");
     pos.release(); ins.release(); pex.release(); cnt.release(); qex.release();
+    bft_trace_mark("  merge: k-mers placed");
 
     // ---- colour sets: U = old sets still on a row of their own + the unique (old | none, run) combinations ----
     DevBuf used, uidx, key, key_s, iota, order, head, hidx, urow;
@@ -249,6 +315,7 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
         HIPCK(hipStreamSynchronize(s));
     }
     key.release(); iota.release();
+    bft_trace_mark("  merge: (old, run) pairs sorted");
     hipLaunchKernelGGL(k_pair_heads, G(n_b), key_s.as<uint64_t>(), n_b, head.as<uint32_t>());
     CK(scan.run(head.as<uint32_t>(), hidx.as<uint32_t>(), n_b, &n_comb));
     const uint64_t n_u = n_used + n_comb;
@@ -272,6 +339,7 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
         n_uids64 = v;
     }
     if (n_uids64 != n_uids) return bft_fail(BFT_GPU_E_LIMIT, "colour-set dictionary beyond 2^32 genome ids");
+    bft_trace_mark("  merge: union lengths");
     CK(uids.alloc(std::max<uint64_t>(1, n_uids) * 4));
     {
         const uint64_t nw = (a.n_sets + 3) / 4;
@@ -282,8 +350,10 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
                        (uint32_t*)nullptr, uoff.as<uint32_t>(), uids.as<uint32_t>());
     hipLaunchKernelGGL(k_pair_of_row, G(n_b), order.as<uint32_t>(), head.as<uint32_t>(), hidx.as<uint32_t>(), n_b, (uint32_t)n_used, urow.as<uint32_t>());
     HIPCK(hipGetLastError());
+    bft_trace_mark("  merge: union lists enqueued");
     DevBuf tcol_u;
-    CK(bft_intern_colors_gpu(uoff.as<uint32_t>(), uids.as<uint32_t>(), n_u, n_uids, s, tcol_u, out.cs_off, out.cs_ids, out.n_sets, out.n_ids));
+    CK(bft_intern_colors_gpu(uoff.as<uint32_t>(), uids.as<uint32_t>(), n_u, n_uids, s, tcol_u, out.cs_off, out.cs_ids, out.n_sets, out.n_ids, n_used));
+    bft_trace_mark("  merge: lists interned");
     hipLaunchKernelGGL(k_tcol_old, G(n_o), pa.as<uint32_t>(), pb.as<uint32_t>(), n_o, uidx.as<uint32_t>(), tcol_u.as<uint32_t>(), out.tcol.as<uint32_t>());
     hipLaunchKernelGGL(k_tcol_new, G(n_b), orow.as<uint32_t>(), urow.as<uint32_t>(), n_b, tcol_u.as<uint32_t>(), out.tcol.as<uint32_t>());
     HIPCK(hipGetLastError());

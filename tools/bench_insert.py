@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--sample", type=int, default=2_000_000)
     ap.add_argument("--reserve", action="store_true", help="reserve the insertion log for the total up front instead of letting it grow by doubling")
     ap.add_argument("--sync-inserts", action="store_true", help="bft_gpu_insert_kmers_dev (synchronised per call) instead of the stream-ordered bft_gpu_insert_kmers_dev_async")
+    ap.add_argument("--add-genome", action="store_true", help="after the build, insert one more genome and time the incremental build (a merge)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to bft_gpu_set_option before the inserts (repeatable)")
     args = ap.parse_args()
     import torch
@@ -58,6 +59,8 @@ def main():
         w = pack_windows(anc[:50000], args.k)  # bench.py does the same): not part of any figure
         warm.set_option("build_msd", 2)  # (the root-prefix bucket kernels too: they otherwise load on the first large build)
         warm.insert_kmers_dev(w.data_ptr(), w.shape[0], 0)
+        warm.build()
+        warm.insert_kmers_dev(w.data_ptr(), w.shape[0] // 2, 1)  # (and the merge kernels: a second build on the same handle)
         warm.build()
         warm.query_presence(w[:1000].cpu().numpy())
         del w
@@ -94,6 +97,25 @@ def main():
     t.build()
     t_build = time.perf_counter() - t0
     del batches
+    # one more genome onto the finished index (-add_genomes): its run is sorted and merged into the index, not everything re-sorted
+    add = None
+    if args.add_genome:
+        m = torch.rand(args.genome_len, generator=g, device=dev) < args.snp_rate
+        delta = torch.randint(1, 4, (args.genome_len,), generator=g, device=dev, dtype=torch.uint8)
+        extra = pack_windows(torch.where(m, (anc + delta) & 3, anc), args.k)
+        before = t.info()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t.insert_kmers_dev_async(extra.data_ptr(), extra.shape[0], args.genomes, stream)
+        t.build()
+        t_add = time.perf_counter() - t0
+        after = t.info()
+        ek = torch.unique(keys_of(extra))
+        per_genome_keys.append(ek)
+        add = {"pairs": int(extra.shape[0]), "ms": round(t_add * 1e3, 2), "new_kmers": after["kmers"] - before["kmers"], "new_colorsets": after["colorsets"] - before["colorsets"],
+               "build_breakdown_ms": {k_: round(v, 1) for k_, v in t.build_time().items() if k_.endswith("_ms") and v}}
+        args.genomes += 1
+        del extra
     info = t.info()
     # ---- properties ----
     allk = torch.unique(torch.cat(per_genome_keys))
@@ -121,6 +143,7 @@ def main():
         "value": round(npairs_in / (t_ins + t_build) / 1e6, 2), "unit": "M pairs/s",
         "build_breakdown_ms": {k_: round(v, 1) for k_, v in t.build_time().items()},
         "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
+        "add_one_genome": add,
         "parity": {"counts": bool(ok_counts), "presence_sample": ok_presence, "colors_sample": ok_colors, "sample": ns},
     }
     print(json.dumps(out))
