@@ -21,8 +21,8 @@ json.dump(out, open(os.path.join(sys.argv[1], "pmc_query.json"), "w"), indent=1)
 PY
 python3 tools/bench_config5.py 2>&1 | strip | tail -n 1 > "$OUT/config5.json"
 python3 tools/bench_k_sweep.py 2>&1 | strip > "$OUT/k_sweep.jsonl"
-python3 tools/bench_insert.py --reserve 2>&1 | strip | tail -n 1 > "$OUT/insert_config3.json"
-python3 tools/bench_insert.py --reserve --k 31 2>&1 | strip | tail -n 1 > "$OUT/insert_config3_k31.json"
+python3 tools/bench_insert.py --reserve --add-genome 2>&1 | strip | tail -n 1 > "$OUT/insert_config3.json"
+python3 tools/bench_insert.py --reserve --add-genome --k 31 2>&1 | strip | tail -n 1 > "$OUT/insert_config3_k31.json"
 bash tools/profile_build_trace.sh "${1:-final}/build_config3" --reserve > /dev/null 2>&1
 # one build as a timeline: kernels with start offsets and idle gaps (tools/build_timeline.py), and the host's own marks (BFT_GPU_TRACE_BUILD)
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/build_tl" -- python3 "$ROOT/tools/bench_insert.py" --reserve --sample 100000 > /dev/null 2>&1 )
