@@ -880,11 +880,14 @@ static void kh_prepare(bft_gpu* h, uint64_t nk, KhFill& f) {
 // ... on a thread of its own while the build's stream is busy with the colour sets
 static void kh_prepare_async(bft_gpu* h, uint64_t nk, KhFill& f) {
     KhFill* fp = &f;
-    f.prep = std::thread([h, nk, fp] {
-        if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
-        bft_pool_set_stream(h->device, h->stream);
-        kh_prepare(h, nk, *fp);
-    });
+    try {
+        f.prep = std::thread([h, nk, fp] {
+            if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
+            bft_pool_set_stream(h->device, h->stream);
+            kh_prepare(h, nk, *fp);
+        });
+    } catch (...) {  // (no thread to be had: kh_start prepares on the caller's)
+    }
 }
 static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, KhFill& f, hipStream_t after = nullptr) {
     if (f.prep.joinable()) f.prep.join();
