@@ -597,3 +597,34 @@ def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
     assert (a.query_presence(q2) == b.query_presence(q2)).all()
     a.close()
     b.close()
+
+
+def test_host_inserts_through_the_pinned_ring_keep_their_order_and_content():
+    """Host batches up to a megabyte are copied into a ring of eight pinned slots that the packing kernel reads asynchronously
+    (bft_gpu_insert_kmers); larger ones take the staged copy.  Forty small batches (the ring wraps five times), a large one in the
+    middle and the caller's buffer overwritten right after every call: k-mers, colour sets and answers equal ground truth."""
+    k = 27
+    rng = np.random.default_rng(11)
+    anc = S.random_genome(400000, 9)
+    big = S.distinct(S.kmers_of(anc, k))  # ~4x10^5 k-mers x 7 bytes: beyond a slot
+    assert big.nbytes > (1 << 20)
+    t = BFT(k)
+    truth = {}
+    scratch = np.zeros((30000, big.shape[1]), dtype=np.uint8)
+    for g in range(41):
+        if g == 20:
+            t.insert_kmers(big, g)
+            src = big
+        else:
+            src = np.ascontiguousarray(big[rng.choice(len(big), int(rng.integers(1, 30000)), replace=False)])
+            scratch[: len(src)] = src
+            t.insert_kmers(scratch[: len(src)], g)
+            scratch[:] = 0xFF  # the library must have taken its copy
+        for row in src:
+            truth.setdefault(row.tobytes(), []).append(g)
+    t.build()
+    got, _ = _colour_map(t)
+    assert got == {kk: tuple(v) for kk, v in truth.items()}
+    q = np.concatenate([big[::5], S.snp_mutants(big[::11], k, 2)])
+    assert (S.from_bits(t.query_presence(q), len(q)) == S.member(q, big)).all()
+    t.close()
