@@ -31,28 +31,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-// Counts the host needs (array sizes, format limits) come back through a pinned block that kernels write: the scans and checks
-// of a stage are enqueued together and share ONE stream synchronisation (a total fetched by hipMemcpyAsync into pageable memory is
-// two staged copies and a synchronisation of its own: ~60 us each, sixteen per trie level).
-constexpr int PIN_SLOTS = 32;
-struct PinBlock {
-    uint64_t* p = nullptr;
-    PinBlock() {
-        {
-            std::lock_guard<std::mutex> lk(mu());
-            if (!cache().empty()) { p = cache().back(); cache().pop_back(); }
-        }
-        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
-    }
-    ~PinBlock() {
-        if (!p) return;
-        std::lock_guard<std::mutex> lk(mu());
-        cache().push_back(p);  // (a handful of 256-byte blocks per process, kept; portable: any device of the process may write them)
-    }
-    static std::mutex& mu() { static std::mutex m; return m; }
-    static std::vector<uint64_t*>& cache() { static std::vector<uint64_t*> c; return c; }
-};
-
+// (PinBlock, bft_dev.h: counts the host needs come back through a pinned block that kernels write)
 __global__ void k_scan_total(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, uint64_t* __restrict__ slot, int tail) {
     const uint64_t t = (uint64_t)in[n - 1] + out[n - 1];
     *slot = t;

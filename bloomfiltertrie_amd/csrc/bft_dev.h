@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/bft_gpu.h"
 
@@ -65,6 +67,29 @@ struct DevBuf {
     }
 };
 
+// Counts the host needs (array sizes, format limits) come back through a pinned block that kernels write: the scans and checks
+// of a stage are enqueued together and share ONE stream synchronisation (a total fetched by hipMemcpyAsync into pageable memory is
+// two staged copies and a synchronisation of its own: ~60 us each, sixteen per trie level).
+constexpr int PIN_SLOTS = 32;
+struct PinBlock {
+    uint64_t* p = nullptr;
+    PinBlock() {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (!cache().empty()) { p = cache().back(); cache().pop_back(); }
+        }
+        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+    }
+    ~PinBlock() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu());
+        cache().push_back(p);  // (a handful of 256-byte blocks per process, kept; portable: any device of the process may write them)
+    }
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<uint64_t*>& cache() { static std::vector<uint64_t*> c; return c; }
+};
+
+
 static inline int bft_grid_for(uint64_t nblk) {
     const uint64_t cap = 256ull * 8ull;  // 256 CUs x 8 resident workgroups of 256 threads
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(nblk, cap));
@@ -117,5 +142,8 @@ uint32_t bft_front_bucket_capacity(void);
 void bft_test_front_rank_mode(int mode);   // test hook: k_bucket_sort's mode (0 atomics + check, 1 ballots only, 2 the check always fails)
 // d_vals (vw bytes per id): d_c holds whole T-form k-mers grouped by the bits from split_bit - gb up, the ids beside them
 int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
-                      DevBuf& pg, uint64_t& nk, uint64_t& np, uint32_t max_bucket, uint32_t* n_redone, const void* d_vals = nullptr, uint32_t vw = 0);
-// (max_bucket: the largest of the buckets; *n_redone: buckets whose order check failed and that were sorted again)
+                      DevBuf& pg, uint64_t& nk, uint64_t& np, const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone,
+                      const void* d_vals = nullptr, uint32_t vw = 0);
+// (d_max_bucket: the size of the largest bucket, on the device -- it reaches the host, *max_bucket, while the first sort kernel runs;
+// *done = false: that bucket is beyond bft_front_bucket_capacity() and nothing was produced (d_c may have been reordered inside its
+// buckets); *n_redone: buckets whose order check failed and that were sorted again)

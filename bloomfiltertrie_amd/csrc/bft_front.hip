@@ -365,15 +365,22 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
     }
 }
 
+// what the host waits for: slots[0] = *a (when given), slots[1] = *b
+__global__ void k_front_publish(const uint64_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t* __restrict__ slots) {
+    if (a) { slots[0] = *a; slots[1] = *b; }
+    else slots[0] = *b;
+}
+
 // bases[b] = exclusive scan of counts (k-mers << 32 | pairs).  Every bucket places its k-mers (T = c >> gb), the offset of each k-mer's
 // first genome id, and the genome ids (c & gmask) of its distinct pairs.
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t gb,
                                                           const uint64_t* __restrict__ bases, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off,
-                                                          uint32_t* __restrict__ pg, int kv, uint32_t rest) {  // kv: the composites lack the bucket's
-                                                                                                             // bits (k_bucket_sort, vals); rest: T bits below the split
+                                                          uint32_t* __restrict__ pg, int kv, uint32_t rest,  // kv: the composites lack the bucket's
+                                                          uint32_t nk, uint32_t np) {                        // bits (k_bucket_sort, vals); rest: T bits below the split
     __shared__ uint32_t w_nk[FB_WAVES], w_np[FB_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gmask = (1ull << gb) - 1ull, lt_mask = (1ull << lane) - 1ull;
+    if (blockIdx.x == 0 && tid == 0) seg_off[nk] = np;  // the offsets array has nk + 1 entries
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
         if (n == 0) continue;
@@ -416,7 +423,11 @@ static int g_rank_mode = 0;                 // k_bucket_sort's mode ("test_front
 void bft_test_front_rank_mode(int mode) { g_rank_mode = mode; }
 
 int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_t nb, uint32_t gb, uint32_t split_bit, hipStream_t s, DevBuf& tk, DevBuf& seg_off,
-                      DevBuf& pg, uint64_t& nk, uint64_t& np, uint32_t max_bucket, uint32_t* n_redone, const void* d_vals, uint32_t vw) {
+                      DevBuf& pg, uint64_t& nk, uint64_t& np, const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone,
+                      const void* d_vals, uint32_t vw) {
+    *done = false;
+    PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets sorted again
+    if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (front end counts)");
     DevBuf counts, bases, tmp;
     CK(counts.alloc(((uint64_t)nb + 1) * 8));
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
@@ -424,40 +435,52 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     const dim3 grid(std::min<uint32_t>(nb, 256u * 16u)), block(FB_BLOCK);
     DevBuf redone;
     CK(redone.alloc_zero(4, s));
+    // The size of the largest bucket decides which workgroup variant the larger buckets need, and whether the buckets fit at all; it
+    // travels to the host behind the split while the wavefront kernel -- whose own variant follows the MEAN bucket -- is already
+    // running (a synchronisation in front of it left the GPU idle for ~0.15 ms).
+    hipEvent_t ev;
+    HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
+    hipError_t e = hipEventRecord(ev, s);
     // the small buckets a wavefront each, the others a workgroup each (one after the other: on two streams the two kernels --
     // both latency-bound, different LDS footprints -- got in each other's way: 8.6 ms instead of 2.0 + 0.8)
-    const uint32_t wave_cap = max_bucket <= 512u ? 512u : 1024u;
+    const uint32_t wave_cap = n / std::max(nb, 1u) <= 192u ? 512u : 1024u;
     const dim3 wgrid(std::min<uint32_t>((nb + FB_WAVES - 1) / FB_WAVES, 256u * 16u));
     if (wave_cap == 512u) hipLaunchKernelGGL(k_bucket_sort_wave<8>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
     else hipLaunchKernelGGL(k_bucket_sort_wave<16>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
+    if (e == hipSuccess) e = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    HIPCK(e);
+    const uint32_t mx = (uint32_t)pin.p[0];
+    *max_bucket = mx;
+    bft_trace_mark("root-prefix split done (largest bucket known)");
+    if (mx > FB_CAP) return 0;
 #define FB_LAUNCH(E) hipLaunchKernelGGL(k_bucket_sort<E>, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), wave_cap)
-    if (max_bucket <= wave_cap) {}
-    else if (max_bucket <= 256u * 6u) FB_LAUNCH(6);
-    else if (max_bucket <= 256u * 9u) FB_LAUNCH(9);
-    else if (max_bucket <= 256u * 12u) FB_LAUNCH(12);
+    if (mx <= wave_cap) {}
+    else if (mx <= 256u * 6u) FB_LAUNCH(6);
+    else if (mx <= 256u * 9u) FB_LAUNCH(9);
+    else if (mx <= 256u * 12u) FB_LAUNCH(12);
     else FB_LAUNCH(16);
 #undef FB_LAUNCH
     size_t tb = 0;
     HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
     CK(tmp.alloc(tb));
     HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
-    uint64_t total = 0;
-    HIPCK(hipMemcpyAsync(&total, bases.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s));
-    uint32_t nr = 0;
-    HIPCK(hipMemcpyAsync(&nr, redone.p, 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
+    HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s));
-    if (n_redone) *n_redone = nr;
+    const uint64_t total = pin.p[1];
+    if (n_redone) *n_redone = (uint32_t)pin.p[2];
     nk = total >> 32;
     np = total & 0xFFFFFFFFull;
-    (void)n;
     bft_trace_mark("bucket sort done (sync)");
     CK(tk.alloc(nk * 8));
     CK(seg_off.alloc((nk + 1) * 4));
     CK(pg.alloc(np * 4));
-    hipLaunchKernelGGL(k_bucket_emit, grid, block, 0, s, d_c, d_boff, nb, gb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(), pg.as<uint32_t>(), d_vals ? 1 : 0, split_bit - gb);
-    const uint32_t np32 = (uint32_t)np;
-    HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, s));
+    // (seg_off[nk] = np is the kernel's too: nothing of this call is left on the host's side when it returns, the stream goes on)
+    hipLaunchKernelGGL(k_bucket_emit, grid, block, 0, s, d_c, d_boff, nb, gb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(), pg.as<uint32_t>(), d_vals ? 1 : 0, split_bit - gb,
+                       (uint32_t)nk, (uint32_t)np);
     HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
+    *done = true;
     return 0;
 }

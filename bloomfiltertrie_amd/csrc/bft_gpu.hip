@@ -1214,16 +1214,11 @@ static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* sr
     HIPCK(rocprim::radix_sort_pairs<Msd9>(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
     hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(),
                        maxb.as<uint32_t>());
-    uint32_t mx = 0;
-    HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
     tmp.release();
+    uint32_t mx = 0;
+    CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done,
+                         &h->front_redone, sv.p, (uint32_t)sizeof(VT)));
     h->msd_max_bucket = mx;
-    bft_trace_mark("root-prefix split done (sync)");
-    if (mx > bft_front_bucket_capacity()) return 0;
-    CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, mx, &h->front_redone, sv.p,
-                         (uint32_t)sizeof(VT)));
-    done = true;
     return 0;
 }
 
@@ -1279,15 +1274,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
                 uint32_t mx = 0;
-                HIPCK(hipMemcpyAsync(&mx, maxb.p, 4, hipMemcpyDeviceToHost, h->stream));
-                HIPCK(hipStreamSynchronize(h->stream));
+                CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx,
+                                     &done, &h->front_redone));
                 h->msd_max_bucket = mx;
-                bft_trace_mark("root-prefix split done (sync)");
-                if (mx <= bft_front_bucket_capacity()) {
-                    pos.release();
-                    CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, mx, &h->front_redone));
-                    done = true;
-                }
+                if (done) pos.release();
             }
             if (!done) {
             HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
