@@ -110,10 +110,11 @@ static int run_sharded(bft_gpu_group* g, uint64_t n, F f) {
     const int parts = (int)g->members.size();
     std::vector<int> rc(parts, 0);
     std::vector<std::string> msg(parts);
+    std::vector<uint64_t> lo(parts, 0), hi(parts, 0);
+    for (int i = 0; i < parts; i++) CK(bft_gpu_group_shard(n, parts, i, &lo[i], &hi[i]));  // (before any thread exists: an early return must not leave one unjoined)
     std::vector<std::thread> th;
     for (int i = 0; i < parts; i++) {
-        uint64_t a = 0, b = 0;
-        CK(bft_gpu_group_shard(n, parts, i, &a, &b));
+        const uint64_t a = lo[i], b = hi[i];
         if (b <= a) continue;
         th.emplace_back([&, i, a, b] {
             rc[i] = f(g->members[i], a, b - a);
