@@ -628,3 +628,33 @@ def test_host_inserts_through_the_pinned_ring_keep_their_order_and_content():
     q = np.concatenate([big[::5], S.snp_mutants(big[::11], k, 2)])
     assert (S.from_bits(t.query_presence(q), len(q)) == S.member(q, big)).all()
     t.close()
+
+
+@pytest.mark.parametrize("k,gids", [(27, list(range(12))), (31, list(range(12))), (31, [0, 400, 70000])])
+def test_a_bucket_beyond_the_capacity_falls_back_to_the_device_wide_sort(k, gids):
+    """The size of the largest root-prefix bucket reaches the host while the wavefront kernel is already sorting the smaller buckets in
+    place (bft_front_buckets); when that bucket is beyond what a workgroup sorts (4096 composites) nothing is produced and the build
+    takes the device-wide sort from the insertion log.  Three prefixes carry every k-mer here: image, extraction and colour sets equal
+    those of a handle that never tried the buckets, and the handle reports the bucket it met."""
+    base = S.low_entropy_kmers(9000, k, 3, 5 + k)  # ~3000 k-mers per prefix, times the genomes that hold them
+    rng = np.random.default_rng(k)
+    parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.6]) for _ in gids]
+    imgs = []
+    for msd in (0, 2):
+        t = BFT(k)
+        t.set_option("build_msd", msd)
+        for g, p in zip(gids, parts):
+            t.insert_kmers(p, g)
+        t.build()
+        bt = t.build_time()
+        if msd == 2:
+            assert bt["sort_max_bucket"] > 4096, bt["sort_max_bucket"]
+        ek, ecs = t.extract()
+        imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs, [list(t.colorset(c)) for c in sorted(set(ecs.tolist()))[:100]]))
+        q = np.concatenate([base[::3], S.snp_mutants(base[::7], k, 1)])
+        assert (S.from_bits(t.query_presence(q), len(q)) == S.member(q, np.concatenate(parts))).all()
+        t.close()
+    a, b = imgs
+    for name in ARRAYS:
+        assert (a[0][name] == b[0][name]).all(), name
+    assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
