@@ -52,6 +52,63 @@ def query_presence_sharded(bft, kmers, group=None):
     return gather_bitmaps(t, n, ws, rk, per, group).cpu().numpy()
 
 
+def gather_rows(local_rows, n, world_size, per, width, group=None):
+    """all_gather fixed-width per-query rows (`per` rows of `width` bytes from every rank) and trim to n rows."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(per * width, dtype=torch.uint8, device=local_rows.device)
+    buf[: local_rows.numel()] = local_rows.reshape(-1)
+    out = torch.empty(per * width * world_size, dtype=torch.uint8, device=local_rows.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out[: n * width].reshape(n, width)
+
+
+def query_color_rows_sharded(bft, kmers, nb_genomes, group=None):
+    """The colour-row query (-query_kmers with its CSV rows, src/file_io.c:726-768) sharded like query_presence_sharded: every rank
+    answers its slice -- presence bitmap and one CEIL(nb_genomes/8)-byte genome bitmap per k-mer --, both are gathered (fixed-width
+    rows concatenate like the bitmaps do: SURVEY.md 8e) and every rank returns (bits, rows[n, width])."""
+    import torch
+    import torch.distributed as dist
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    n, width = len(kmers), (int(nb_genomes) + 7) // 8
+    a, b, per = shard_bounds(n, ws, rk)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", bft.device)
+        local = torch.zeros(per // 8, dtype=torch.uint8, device=dev)
+        rows = torch.zeros(per * width, dtype=torch.uint8, device=dev)
+        if b > a:
+            dq = torch.from_numpy(np.ascontiguousarray(kmers[a:b])).pin_memory().to(dev, non_blocking=True)
+            scratch = torch.empty(b - a, dtype=torch.int32, device=dev)
+            bft.query_color_rows_dev(dq.data_ptr(), b - a, local.data_ptr(), rows.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        lb, lr = bft.query_color_rows(kmers[a:b]) if b > a else (np.zeros(0, np.uint8), np.zeros((0, width), np.uint8))
+        local, rows = torch.from_numpy(np.ascontiguousarray(lb)), torch.from_numpy(np.ascontiguousarray(lr).reshape(-1))
+    bits = gather_bitmaps(local, n, ws, rk, per, group)
+    return bits.cpu().numpy(), gather_rows(rows, n, ws, per, width, group).cpu().numpy()
+
+
+def query_branching_sharded(bft, kmers, group=None):
+    """-query_branching (src/file_io.c:897-1020) sharded the same way: (branching bitmap, (successors << 4 | predecessors) per k-mer)
+    on every rank."""
+    import torch
+    import torch.distributed as dist
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    n = len(kmers)
+    a, b, per = shard_bounds(n, ws, rk)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", bft.device)
+        local = torch.zeros(per // 8, dtype=torch.uint8, device=dev)
+        counts = torch.zeros(per, dtype=torch.uint8, device=dev)
+        if b > a:
+            dq = torch.from_numpy(np.ascontiguousarray(kmers[a:b])).pin_memory().to(dev, non_blocking=True)
+            bft.query_branching_dev(dq.data_ptr(), b - a, local.data_ptr(), counts.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        lb, lc = bft.query_branching(kmers[a:b], with_counts=True) if b > a else (np.zeros(0, np.uint8), np.zeros(0, np.uint8))
+        local, counts = torch.from_numpy(np.ascontiguousarray(lb)), torch.from_numpy(np.ascontiguousarray(lc))
+    bits = gather_bitmaps(local, n, ws, rk, per, group)
+    return bits.cpu().numpy(), gather_rows(counts, n, ws, per, 1, group).cpu().numpy().reshape(-1)
+
+
 class GatherPipeline:
     """The step / drain logic of bench.py's multi-GPU loop: every step answers this rank's resident shard into one of two
     result buffers and starts the all_gather of that buffer asynchronously (RCCL runs it on its own stream), so the

@@ -154,3 +154,80 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert d["rc"] == 0 and [x["RANK"] for x in d["recs"]] == ["0", "1", "2"] and {x["WORLD_SIZE"] for x in d["recs"]} == {"3"}
     assert {x["MASTER_ADDR"] for x in d["recs"]} == {"127.0.0.1"} and len({x["MASTER_PORT"] for x in d["recs"]}) == 1
     assert all(x["cmd"][0].endswith("bench.py") and "--gpus" in x["cmd"] for x in d["recs"])
+
+
+def _rows_worker(rank, world, port, k, genomes, q, ret):
+    """colour rows and branching through the sharded calls on gloo: the per-rank answers come from the oracle (the checker), the
+    slicing and the two gathers -- bitmaps and fixed-width rows -- are the product's."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from bloomfiltertrie_amd.dist import query_branching_sharded, query_color_rows_sharded
+
+    class FakeBFT:
+        device = 0
+
+        def __init__(self):
+            self.o = O.OracleBFT(k)
+            for g, km in enumerate(genomes):
+                self.o.insert_kmers(km, g)
+
+        def query_color_rows(self, kmers):
+            bits, off, ids = self.o.query_colors(np.ascontiguousarray(kmers))
+            rows = np.zeros((len(kmers), (len(genomes) + 7) // 8), np.uint8)
+            for i in range(len(kmers)):
+                for g in ids[int(off[i]):int(off[i + 1])]:
+                    rows[i, g >> 3] |= 1 << (g & 7)
+            return bits, rows
+
+        def query_branching(self, kmers, with_counts=False):
+            bits, counts, _ = self.o.query_branching(np.ascontiguousarray(kmers))
+            return (bits, counts) if with_counts else bits
+
+    f = FakeBFT()
+    bits, rows = query_color_rows_sharded(f, q, len(genomes))
+    bbits, counts = query_branching_sharded(f, q)
+    ret[rank] = (bits.tobytes(), rows.tobytes(), rows.shape, bbits.tobytes(), counts.tobytes())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [700, 4099])
+def test_sharded_colour_rows_and_branching_gloo_world2(oracle_mod, nq):
+    """colour and branching queries shard like presence queries -- contiguous 64-aligned slices, the fixed-width rows
+    gathered beside the bitmaps.  Both ranks end with the answers of the whole batch: genome bitmaps == the inserting genomes,
+    branching counts == the oracle's on the unsharded batch."""
+    import torch.multiprocessing as mp
+    k = 18
+    anc = S.random_genome(6000, 3)
+    genomes = [S.distinct(S.kmers_of(S.mutate(anc, 0.03, 40 + g), k)) for g in range(11)]
+    allk = S.distinct(np.concatenate(genomes))
+    rng = np.random.default_rng(1)
+    q = np.concatenate([allk[rng.choice(len(allk), nq // 2)], S.pack_codes(rng.integers(0, 4, (nq - nq // 2, k), dtype=np.uint8))])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, k, genomes, q, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    exp_rows = np.zeros((nq, 2), np.uint8)
+    for g, km in enumerate(genomes):
+        exp_rows[S.member(q, km), g >> 3] |= 1 << (g & 7)
+    o = oracle_mod.OracleBFT(k)
+    for g, km in enumerate(genomes):
+        o.insert_kmers(km, g)
+    ebits, ecounts, _ = o.query_branching(q)
+    for r in range(2):
+        bits, rows, shape, bbits, counts = ret[r]
+        assert shape == (nq, 2)
+        assert bits == S.to_bits(S.member(q, allk)).tobytes()
+        assert rows == exp_rows.tobytes()
+        assert bbits == ebits.tobytes() and counts == ecounts.tobytes()

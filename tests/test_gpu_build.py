@@ -160,6 +160,36 @@ def test_replicate_image_single_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_sharded_queries_single_rank_rccl():
+    """dist.query_presence_sharded / query_color_rows_sharded / query_branching_sharded over the nccl (= RCCL) backend with
+    world_size 1: the device-resident branch of each (pinned copy in, *_dev call, gathers out of HBM) equals the host entry points."""
+    import torch
+    import torch.distributed as dist
+    from bloomfiltertrie_amd.dist import query_branching_sharded, query_color_rows_sharded, query_presence_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29612")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        k = 27
+        anc = S.random_genome(30000, 2)
+        t = BFT(k)
+        for g in range(19):
+            t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.02, 70 + g), k)), g)
+        t.build()
+        ek, _ = t.extract()
+        q = np.ascontiguousarray(np.concatenate([ek[::3], S.snp_mutants(ek[::5], k, 3)])[:20001])
+        assert (query_presence_sharded(t, q) == t.query_presence(q)).all()
+        bits, rows = query_color_rows_sharded(t, q, t.info()["genomes"])
+        hb, hr = t.query_color_rows(q)
+        assert (bits == hb).all() and rows.shape == hr.shape and (rows == hr).all()
+        bb, counts = query_branching_sharded(t, q)
+        xb, xc = t.query_branching(q, with_counts=True)
+        assert (bb == xb).all() and (counts == xc).all()
+        t.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("flat_min", [1, 255, 3584, 65536])
 def test_flat_form_matches_host_restatement(hostlib, flat_min):
     """The derived arrays (extended CC headers, flat prefix bitmaps + ranks, flat entries) for any threshold are
