@@ -240,6 +240,7 @@ struct bft_gpu {
         for (int i = 0; i < RING_SLOTS; i++)
             if (ring_ev[i]) (void)hipEventDestroy(ring_ev[i]);
         if (ring) (void)hipHostFree(ring);
+        if (kh_ctr) (void)hipFree(kh_ctr);
     }
 
     // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
@@ -305,6 +306,16 @@ struct bft_gpu {
     int tuned_probe = 0;
     double tune_ms[3] = {0, 0, 0};  // best time of the tuning batch per residency 1 / 2 / 3
     int opt_grid_mult = 1;    // grid = resident workgroups x this
+    // The k-mer hash kernels claim their blocks of k-mers from a counter instead of splitting them by workgroup number (k_query_kh,
+    // bft_kh.hip): one counter pair per stream that launches them -- launches of one stream follow each other, so a pair has one user at
+    // a time, and the kernel leaves it zeroed.  Streams beyond the slots, and batches too small to matter, take the static split.
+    int opt_query_dynamic = 1;
+    uint32_t opt_query_chunk = 8;  // blocks of 256 k-mers per claim
+    static constexpr int KH_CTR_SLOTS = 32;
+    uint32_t* kh_ctr = nullptr;  // (its own hipMalloc, not a block of the cache: nothing that was released while still in flight may write here)
+    hipStream_t kh_ctr_stream[KH_CTR_SLOTS] = {};
+    int kh_ctr_used = 0;
+    bool kh_ctr_failed = false;
     DevBuf sq_codes, sq_bad, sq_npos, sq_poff, sq_tmp, sq_cs, sq_tile;  // scratch of the sequence queries (grown, never shrunk)
     hipStream_t sq_stream = nullptr;
     bool sq_used = false;
@@ -1605,11 +1616,38 @@ static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uin
     return 0;
 }
 
+// The claim counters of stream s (see struct bft_gpu), or NULL: the static split.
+static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n) {
+    // (below ~2 x 10^7 lines of work a launch is over before the XCDs drift apart, and a claim costs its ~12 ns on the one counter:
+    // 2^20 k-mers 28 us split statically, 57 us claimed; 2^24: 400 / 409; 1.25 x 10^8: 2.72-3.06 ms / 2.62)
+    static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
+    if (!h->opt_query_dynamic || env_off || n < ((uint64_t)1 << 25) || h->kh_ctr_failed) return nullptr;
+    if (!h->kh_ctr) {  // (once per handle; a blocking memset: no launch of any stream can meet a counter that is not zero yet)
+        if (hipMalloc((void**)&h->kh_ctr, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess || hipMemset(h->kh_ctr, 0, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->kh_ctr) (void)hipFree(h->kh_ctr);
+            h->kh_ctr = nullptr;
+            h->kh_ctr_failed = true;
+            return nullptr;
+        }
+    }
+    int slot = -1;
+    for (int i = 0; i < h->kh_ctr_used; i++)
+        if (h->kh_ctr_stream[i] == s) slot = i;
+    if (slot < 0) {
+        if (h->kh_ctr_used == bft_gpu::KH_CTR_SLOTS) return nullptr;
+        slot = h->kh_ctr_used++;
+        h->kh_ctr_stream[slot] = s;
+    }
+    return h->kh_ctr + 2 * slot;
+}
+
 // Presence (and, with im.emit_cs, the colour set of every found k-mer into d_out32) through the k-mer hash.
 static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s, int rec) {
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    CK(bft_kh_query(h->im, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, s));
+    CK(bft_kh_query(h->im, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, claim_counters(h, s, n), h->opt_query_chunk, s));
     HIPCK(hipGetLastError());
     CK(timing_end(h, s, e0, e1));
     return 0;
@@ -1780,7 +1818,7 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
     if (h->im.kh != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
-        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, s));
+        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8), std::max(1u, h->opt_query_chunk / 4u), s));
         CK(timing_end(h, s, e0, e1));
         return 0;
     }
@@ -2484,6 +2522,11 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             CK(ensure_table(h));
             CK(tune_residency(h));
         }
+    } else if (nm == "query_dynamic") {  // 0: the k-mer hash kernels split their batch by workgroup number (what they did before the claims)
+        h->opt_query_dynamic = value != 0;
+    } else if (nm == "query_chunk") {
+        if (value < 1 || value > 1024) return fail(BFT_GPU_E_ARG, "query_chunk must be in [1,1024]");
+        h->opt_query_chunk = (uint32_t)value;
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");
         h->opt_grid_mult = (int)value;

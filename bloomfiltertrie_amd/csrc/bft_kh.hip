@@ -16,13 +16,50 @@
 // per wavefront through __ballot, persistent grid.
 // (Two or four k-mers per lane and pass, their home lines loaded together, were measured on the 100-genome index: 41.5 / 37.5 G k-mers/s
 // against 44.6 with one -- the fabric's request rate is the limit, not the number of requests a lane keeps in flight; tools/probe_kh.py.)
-template <int W>
+// DYN: the blocks of 256 k-mers are not dealt out by workgroup number but claimed, `chunk` blocks at a time, from a counter in device
+// memory (ctr[0]; ctr[1] counts the workgroups that are done, the last one zeroes both for the next launch on the stream).  Workgroups
+// are bound to an XCD by their number -- every XCD gets an eighth of a static partition however fast it gets through it --, and how
+// fast depends on where the table lies: 2.70 / 2.77 / 3.03 ms for the same table, batch and kernel (same misses, same latency per
+// request, fewer requests in flight: XCDs idle at the end), 2.63 ms wherever it lies once the chunks are claimed.
+struct KhClaims {
+    uint32_t* ctr;
+    uint32_t chunk;
+    uint64_t nblk, blk, blk_end;
+    uint32_t* s_next;  // one word of LDS
+    // the first chunk of the workgroup; the next claim is sent off at once and travels while the chunk is answered
+    __device__ __forceinline__ void first() {
+        if (threadIdx.x == 0) *s_next = atomicAdd(&ctr[0], 1u);
+        take();
+    }
+    __device__ __forceinline__ void take() {
+        __syncthreads();
+        blk = (uint64_t)*s_next * chunk;
+        blk_end = min(nblk, blk + chunk);
+        __syncthreads();
+        if (threadIdx.x == 0 && blk < nblk) *s_next = atomicAdd(&ctr[0], 1u);
+    }
+    __device__ __forceinline__ void advance() {
+        if (++blk == blk_end) take();
+    }
+    // after the loop: every workgroup has made its last claim once the last one gets here
+    __device__ __forceinline__ void done() {
+        if (threadIdx.x == 0 && atomicAdd(&ctr[1], 1u) == gridDim.x - 1u) {
+            ctr[0] = 0u;
+            ctr[1] = 0u;
+        }
+    }
+};
+
+template <int W, bool DYN>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                          uint32_t* __restrict__ out32) {
+                                                          uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
+    __shared__ uint32_t s_next;
+    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, &s_next};
+    if (DYN) cl.first();
+    while (cl.blk < nblk) {
+        const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
         bool present = false;
         uint32_t val = 0xFFFFFFFFu;
         if (i < n) {
@@ -37,7 +74,10 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
         const uint64_t q0 = i & ~63ull;
         if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
         if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
+        if (DYN) cl.advance();
+        else cl.blk += gridDim.x;
     }
+    if (DYN) cl.done();
 }
 
 // How many of four candidate k-mers are stored: the four home lines are loaded before any is looked at -- four independent
@@ -70,14 +110,17 @@ __device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*ca
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998), see branching_body.
-template <int W>
+template <int W, bool DYN>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                              uint8_t* __restrict__ counts) {
+                                                              uint8_t* __restrict__ counts, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
     const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BFT_KH_BLOCK + threadIdx.x;
+    __shared__ uint32_t s_next;
+    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, &s_next};
+    if (DYN) cl.first();
+    for (; cl.blk < nblk; DYN ? cl.advance() : (void)(cl.blk += gridDim.x)) {
+        const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
         int branching = 0;
         if (i < n) {
             uint64_t x[W], y[W], t[W], cand[4][W];
@@ -116,6 +159,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
         const uint64_t q0 = i & ~63ull;
         if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
     }
+    if (DYN) cl.done();
 }
 
 // Fills the table: one thread per stored k-mer claims the first free slot at or after its home line with a compare-and-swap on the
@@ -241,19 +285,35 @@ int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W,
     return 0;
 }
 
-int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s) {
-    // (grid: four times the resident workgroups -- 44.6 -> 47.2 G k-mers/s on the 100-genome index: the tail of a persistent grid is shorter)
-    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4 * grid_mult)), block(BFT_KH_BLOCK);
-    if (im.W == 1) hipLaunchKernelGGL(k_query_kh<1>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);
-    else hipLaunchKernelGGL(k_query_kh<2>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32);
+// d_ctr != NULL: claimed chunks, and no more workgroups than are resident; else the static partition over four times as many (44.6 ->
+// 47.2 G k-mers/s on the 100-genome index when it was the only form: the tail of a persistent grid is shorter)
+int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
+                 hipStream_t s) {
+    const dim3 block(BFT_KH_BLOCK);
+    if (d_ctr) {
+        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * chunk, grid_mult));
+        if (im.W == 1) hipLaunchKernelGGL((k_query_kh<1, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
+        else hipLaunchKernelGGL((k_query_kh<2, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
+    } else {
+        const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4 * grid_mult));
+        if (im.W == 1) hipLaunchKernelGGL((k_query_kh<1, false>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, 1u);
+        else hipLaunchKernelGGL((k_query_kh<2, false>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, 1u);
+    }
     HIPCK(hipGetLastError());
     return 0;
 }
 
-int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, hipStream_t s) {
-    const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4)), block(BFT_KH_BLOCK);
-    if (im.W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
-    else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts);
+int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
+    const dim3 block(BFT_KH_BLOCK);
+    if (d_ctr) {
+        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * chunk, 1));
+        if (im.W == 1) hipLaunchKernelGGL((k_branching_kh<1, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
+        else hipLaunchKernelGGL((k_branching_kh<2, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
+    } else {
+        const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4));
+        if (im.W == 1) hipLaunchKernelGGL((k_branching_kh<1, false>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, 1u);
+        else hipLaunchKernelGGL((k_branching_kh<2, false>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, 1u);
+    }
     HIPCK(hipGetLastError());
     return 0;
 }
