@@ -102,6 +102,30 @@ def test_config4_per_gpu_share_full_size(torch_dev, k):
         t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
         torch.cuda.synchronize()
         assert torch.equal(first, dbits)
+    # The k-mer hash kernel claims its blocks of k-mers from a per-stream counter at this size ("query_dynamic", default): the static
+    # split gives the same bits; two streams at once -- a counter pair each -- and ragged sizes around the chunk of 2048 k-mers too;
+    # the counters are left zeroed, so the launches that follow are whole again.
+    t.set_option("query_dynamic", 0)
+    dbits.zero_()
+    t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(first, dbits)
+    t.set_option("query_dynamic", 1)
+    s2 = torch.cuda.Stream(device=dev)
+    n2 = (1 << 25) + 2049 + 77
+    other = torch.zeros(((n2 + 63) // 64) * 8, dtype=torch.uint8, device=dev)
+    for chunk in (8, 3):
+        t.set_option("query_chunk", chunk)
+        for _ in range(3):
+            dbits.zero_()
+            other.zero_()
+            torch.cuda.synchronize()
+            t.query_presence_dev(dq.data_ptr(), nq, dbits.data_ptr(), stream)
+            t.query_presence_dev(dq.data_ptr(), n2, other.data_ptr(), s2.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(first, dbits)
+            assert bool((W.bits_to_bool(other, n2) == truth[:n2]).all())
+    t.set_option("query_chunk", 8)
     ns = 3_000_001  # host entry point on a ragged slice
     hb = t.query_presence(dq[:ns].cpu().numpy())
     assert (np.unpackbits(hb, bitorder="little")[:ns].astype(bool) == got[:ns].cpu().numpy()).all()
