@@ -310,7 +310,8 @@ struct bft_gpu {
     // bft_kh.hip): one counter pair per stream that launches them -- launches of one stream follow each other, so a pair has one user at
     // a time, and the kernel leaves it zeroed.  Streams beyond the slots, and batches too small to matter, take the static split.
     int opt_query_dynamic = 1;
-    uint32_t opt_query_chunk = 8;  // blocks of 256 k-mers per claim
+    uint32_t opt_query_chunk = 4;  // largest claim, in blocks of 256 k-mers (4 = every claim: the smaller the window of the query stream the
+                                   // resident workgroups read at a time, the better -- 2.61 / 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64)
     static constexpr int KH_CTR_SLOTS = 32;
     uint32_t* kh_ctr = nullptr;  // (its own hipMalloc, not a block of the cache: nothing that was released while still in flight may write here)
     hipStream_t kh_ctr_stream[KH_CTR_SLOTS] = {};
@@ -1818,7 +1819,7 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
     if (h->im.kh != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
-        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8), std::max(1u, h->opt_query_chunk / 4u), s));
+        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8), h->opt_query_chunk, s));
         CK(timing_end(h, s, e0, e1));
         return 0;
     }
@@ -2525,7 +2526,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "query_dynamic") {  // 0: the k-mer hash kernels split their batch by workgroup number (what they did before the claims)
         h->opt_query_dynamic = value != 0;
     } else if (nm == "query_chunk") {
-        if (value < 1 || value > 1024) return fail(BFT_GPU_E_ARG, "query_chunk must be in [1,1024]");
+        if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_chunk must be in [1,64]");
         h->opt_query_chunk = (uint32_t)value;
     } else if (nm == "query_grid_mult") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_grid_mult must be in [1,64]");

@@ -16,30 +16,42 @@
 // per wavefront through __ballot, persistent grid.
 // (Two or four k-mers per lane and pass, their home lines loaded together, were measured on the 100-genome index: 41.5 / 37.5 G k-mers/s
 // against 44.6 with one -- the fabric's request rate is the limit, not the number of requests a lane keeps in flight; tools/probe_kh.py.)
-// DYN: the blocks of 256 k-mers are not dealt out by workgroup number but claimed, `chunk` blocks at a time, from a counter in device
+// DYN: the blocks of 256 k-mers are not dealt out by workgroup number but claimed, up to `chunk` blocks at a time, from a counter in device
 // memory (ctr[0]; ctr[1] counts the workgroups that are done, the last one zeroes both for the next launch on the stream).  Workgroups
 // are bound to an XCD by their number -- every XCD gets an eighth of a static partition however fast it gets through it --, and how
 // fast depends on where the table lies: 2.70 / 2.77 / 3.03 ms for the same table, batch and kernel (same misses, same latency per
 // request, fewer requests in flight: XCDs idle at the end), 2.63 ms wherever it lies once the chunks are claimed.
+// A claim takes remaining / (2 x workgroups) blocks, at most `chunk`, at least BFT_KH_MIN_CLAIM: the counter serves a claim every ~12 ns,
+// 2048 resident workgroups that answer a block in ~11 us saturate it below ~3 blocks per claim (a block per claim: 5.9 ms per launch, two:
+// 3.4, against 2.6-2.7) -- so never fewer than four.  More per claim did not pay either (the default `chunk` is four as well): what the
+// resident workgroups read of the query stream at a time should stay a narrow window.
+#define BFT_KH_MIN_CLAIM 4u
 struct KhClaims {
-    uint32_t* ctr;
+    uint32_t* ctr;     // ctr[0]: the next unclaimed block
     uint32_t chunk;
     uint64_t nblk, blk, blk_end;
-    uint32_t* s_next;  // one word of LDS
+    uint32_t* s_next;  // two words of LDS: first block and size of the claim in flight
+    uint64_t start;    // first block of the claim being answered
+    __device__ __forceinline__ void claim(uint64_t from) {
+        const uint64_t rem = nblk - min(nblk, from);
+        const uint32_t want = (uint32_t)max((uint64_t)min(chunk, BFT_KH_MIN_CLAIM), min((uint64_t)chunk, rem / (2ull * gridDim.x)));
+        s_next[1] = want;
+        s_next[0] = atomicAdd(&ctr[0], want);
+    }
     // the first chunk of the workgroup; the next claim is sent off at once and travels while the chunk is answered
     __device__ __forceinline__ void first() {
-        if (threadIdx.x == 0) *s_next = atomicAdd(&ctr[0], 1u);
+        if (threadIdx.x == 0) claim(0);
         take();
     }
     __device__ __forceinline__ void take() {
         __syncthreads();
-        blk = (uint64_t)*s_next * chunk;
-        blk_end = min(nblk, blk + chunk);
+        blk = start = s_next[0];
+        blk_end = min(nblk, blk + s_next[1]);
         __syncthreads();
-        if (threadIdx.x == 0 && blk < nblk) *s_next = atomicAdd(&ctr[0], 1u);
+        if (threadIdx.x == 0 && blk < nblk) claim(blk_end);
     }
     __device__ __forceinline__ void advance() {
-        if (++blk == blk_end) take();
+        if (++blk >= blk_end) take();
     }
     // after the loop: every workgroup has made its last claim once the last one gets here
     __device__ __forceinline__ void done() {
@@ -50,13 +62,20 @@ struct KhClaims {
     }
 };
 
+// The presence words of a claim (one per wavefront and block) are gathered in LDS and leave as ONE coalesced store of whole lines: a claim
+// of four blocks is exactly one 128-byte line of the bitmap.  Stored wavefront by wavefront, a line was written 8 bytes at a time over
+// ~40 us while the gathers turn the L2 over every ~10 us -- evicted in pieces --, and the launch time followed where the 15 MB bitmap lay
+// (2.60 / 2.82 ms on the same table and batch, fresh bitmaps flipping it inside a process: profiles/r03/probe_dynamic_inputs.jsonl).
+#define BFT_KH_MAX_CLAIM 64u
 template <int W, bool DYN>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                           uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
-    __shared__ uint32_t s_next;
-    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, &s_next};
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, nwords = (n + 63) / 64;
+    constexpr uint32_t WPB = BFT_KH_BLOCK / 64;  // presence words per block
+    __shared__ uint32_t s_next[2];
+    __shared__ uint64_t s_bits[DYN ? BFT_KH_MAX_CLAIM * WPB : 1];
+    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, s_next, 0};
     if (DYN) cl.first();
     while (cl.blk < nblk) {
         const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
@@ -71,11 +90,20 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
             if (present && out32) val = reinterpret_cast<const uint32_t*>(im.kh)[at];
         }
         const uint64_t mask = __ballot(present);
-        const uint64_t q0 = i & ~63ull;
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
         if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
-        if (DYN) cl.advance();
-        else cl.blk += gridDim.x;
+        if (!DYN) {
+            const uint64_t q0 = i & ~63ull;
+            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+            cl.blk += gridDim.x;
+        } else {
+            if ((threadIdx.x & 63u) == 0) s_bits[(cl.blk - cl.start) * WPB + (threadIdx.x >> 6)] = mask;
+            if (cl.blk + 1 >= cl.blk_end) {  // the claim is answered: its words leave together
+                __syncthreads();
+                const uint64_t w0 = cl.start * WPB, w1 = min(nwords, cl.blk_end * WPB);
+                if (w0 + threadIdx.x < w1) __builtin_nontemporal_store(s_bits[threadIdx.x], &bits64[w0 + threadIdx.x]);
+            }
+            cl.advance();  // (its barriers stand between these reads of s_bits and the next claim's writes)
+        }
     }
     if (DYN) cl.done();
 }
@@ -116,8 +144,8 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
     const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
-    __shared__ uint32_t s_next;
-    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, &s_next};
+    __shared__ uint32_t s_next[2];
+    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, s_next, 0};
     if (DYN) cl.first();
     for (; cl.blk < nblk; DYN ? cl.advance() : (void)(cl.blk += gridDim.x)) {
         const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
@@ -290,8 +318,9 @@ int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W,
 int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
                  hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
+    chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
     if (d_ctr) {
-        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * chunk, grid_mult));
+        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * 2, grid_mult));
         if (im.W == 1) hipLaunchKernelGGL((k_query_kh<1, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
         else hipLaunchKernelGGL((k_query_kh<2, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
     } else {
@@ -306,7 +335,7 @@ int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
     if (d_ctr) {
-        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * chunk, 1));
+        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * 2, 1));
         if (im.W == 1) hipLaunchKernelGGL((k_branching_kh<1, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
         else hipLaunchKernelGGL((k_branching_kh<2, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
     } else {

@@ -156,7 +156,7 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   container walk (src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe).  k <= 63 with 2k % 64 != 0; the table is
  *   derived when an image is built, loaded or unpacked; rows (bft_gpu_query_rows) always come from the walk.  0: every query walks the containers.
  * "kmer_hash_load" (50): occupancy of that table in per cent, 10..80 (50 = two slots per k-mer: 1.03-1.07 lines read per lookup).
- * "query_dynamic" (1, default): the k-mer hash kernels claim their blocks of k-mers, "query_chunk" (8) blocks of 256 at a time, from a counter
+ * "query_dynamic" (1, default): the k-mer hash kernels claim their blocks of k-mers, up to "query_chunk" (4) blocks of 256 at a time, from a counter
  *   (one per stream that launches them) instead of splitting the batch by workgroup number -- workgroups are bound to an XCD by their number, and a
  *   static split makes the launch as slow as the XCD that reaches the table slowest; batches below 2^25 k-mers keep the static split.  0: always static.
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per

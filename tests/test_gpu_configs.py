@@ -114,7 +114,7 @@ def test_config4_per_gpu_share_full_size(torch_dev, k):
     s2 = torch.cuda.Stream(device=dev)
     n2 = (1 << 25) + 2049 + 77
     other = torch.zeros(((n2 + 63) // 64) * 8, dtype=torch.uint8, device=dev)
-    for chunk in (8, 3):
+    for chunk in (4, 16, 3):
         t.set_option("query_chunk", chunk)
         for _ in range(3):
             dbits.zero_()
@@ -125,7 +125,7 @@ def test_config4_per_gpu_share_full_size(torch_dev, k):
             torch.cuda.synchronize()
             assert torch.equal(first, dbits)
             assert bool((W.bits_to_bool(other, n2) == truth[:n2]).all())
-    t.set_option("query_chunk", 8)
+    t.set_option("query_chunk", 4)
     ns = 3_000_001  # host entry point on a ragged slice
     hb = t.query_presence(dq[:ns].cpu().numpy())
     assert (np.unpackbits(hb, bitorder="little")[:ns].astype(bool) == got[:ns].cpu().numpy()).all()

@@ -46,7 +46,7 @@ for d in range(n_der):
         for ch in (1, 2, 4, 16, 32, 64):
             t.set_option("query_chunk", ch)
             rec[f"dynamic_chunk{ch}_ms"] = timed(1)
-        t.set_option("query_chunk", 8)
+        t.set_option("query_chunk", 4)
     print(json.dumps(rec), flush=True)
     t.set_option("kmer_hash", 0)
     held.append(torch.empty((97 + 61 * d) << 20, dtype=torch.uint8, device=dev))
