@@ -291,5 +291,5 @@ def test_hot_kernels_use_no_scratch(built):
         seen.add(m.group(1))
         assert int(vspill) == 0 and int(scratch) == 0, name
         if m.group(1) == "k_query_kh":
-            assert int(vgpr) <= 32, name   # 8 wavefronts per SIMD with room to spare
+            assert int(vgpr) <= 48, name   # 8 wavefronts per SIMD need <= 64; the two-word kernel with claimed chunks takes 35, the one-word one 16
     assert seen == {"k_query_kh", "k_seq_kh", "k_branching_kh", "k_kh_insert"}
