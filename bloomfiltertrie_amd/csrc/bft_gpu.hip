@@ -310,6 +310,7 @@ struct bft_gpu {
     // bft_kh.hip): one counter pair per stream that launches them -- launches of one stream follow each other, so a pair has one user at
     // a time, and the kernel leaves it zeroed.  Streams beyond the slots, and batches too small to matter, take the static split.
     int opt_query_dynamic = 1;
+    uint64_t opt_query_dynamic_min = (uint64_t)1 << 25;  // batches below this many k-mers (lines of work for the branching kernel) keep the static split
     uint32_t opt_query_chunk = 4;  // largest claim, in blocks of 256 k-mers (4 = every claim: the smaller the window of the query stream the
                                    // resident workgroups read at a time, the better -- 2.61 / 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64)
     static constexpr int KH_CTR_SLOTS = 32;
@@ -1622,7 +1623,7 @@ static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n) {
     // (below ~2 x 10^7 lines of work a launch is over before the XCDs drift apart, and a claim costs its ~12 ns on the one counter:
     // 2^20 k-mers 28 us split statically, 57 us claimed; 2^24: 400 / 409; 1.25 x 10^8: 2.72-3.06 ms / 2.62)
     static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
-    if (!h->opt_query_dynamic || env_off || n < ((uint64_t)1 << 25) || h->kh_ctr_failed) return nullptr;
+    if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || h->kh_ctr_failed) return nullptr;
     if (!h->kh_ctr) {  // (once per handle; a blocking memset: no launch of any stream can meet a counter that is not zero yet)
         if (hipMalloc((void**)&h->kh_ctr, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess || hipMemset(h->kh_ctr, 0, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) {
@@ -2525,6 +2526,8 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         }
     } else if (nm == "query_dynamic") {  // 0: the k-mer hash kernels split their batch by workgroup number (what they did before the claims)
         h->opt_query_dynamic = value != 0;
+    } else if (nm == "query_dynamic_min") {
+        h->opt_query_dynamic_min = value;
     } else if (nm == "query_chunk") {
         if (value < 1 || value > 64) return fail(BFT_GPU_E_ARG, "query_chunk must be in [1,64]");
         h->opt_query_chunk = (uint32_t)value;

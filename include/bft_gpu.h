@@ -158,7 +158,8 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  * "kmer_hash_load" (50): occupancy of that table in per cent, 10..80 (50 = two slots per k-mer: 1.03-1.07 lines read per lookup).
  * "query_dynamic" (1, default): the k-mer hash kernels claim their blocks of k-mers, up to "query_chunk" (4) blocks of 256 at a time, from a counter
  *   (one per stream that launches them) instead of splitting the batch by workgroup number -- workgroups are bound to an XCD by their number, and a
- *   static split makes the launch as slow as the XCD that reaches the table slowest; batches below 2^25 k-mers keep the static split.  0: always static.
+ *   static split makes the launch as slow as the XCD that reaches the table slowest; batches below "query_dynamic_min" (2^25) k-mers keep the static
+ *   split (the claims cost ~50 us per launch on their one counter: profiles/r03/probe_dynamic_sizes.jsonl).  0: always static.
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
