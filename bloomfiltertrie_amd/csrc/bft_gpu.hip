@@ -255,6 +255,9 @@ struct bft_gpu {
     DevBuf d_hashmod, d_nodes, d_bfT, d_ccs, d_f2w, d_clus, d_child, d_tk, d_tcol, d_uck, d_ucrow, d_cs_off, d_cs_ids, d_cs_bm;
     DevBuf d_ccx, d_f18, d_fent;  // derived: flat form of the big CCs (bft_flatten_gpu)
     DevBuf d_rdir, d_rstart;      // derived: root direct table (BFT_RDIR_*, k_root_direct) and root range table (BFT_RSTART_*), optional
+    DevBuf d_rq;                  // derived: root quartile table (BFT_RQ_*, k_root_quartiles), optional
+    int opt_root_quartiles = 1;   // "root_quartiles"
+    bool rq_ok = false;
     DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
     int opt_node_hash = 1;        // "node_hash": 1 = derived when the image has no k-mer hash (the walk then answers every query), 2 = always, 0 = never
     uint64_t nph_inserted = 0, nph_dropped = 0;
@@ -310,7 +313,8 @@ struct bft_gpu {
     // bft_kh.hip): one counter pair per stream that launches them -- launches of one stream follow each other, so a pair has one user at
     // a time, and the kernel leaves it zeroed.  Streams beyond the slots, and batches too small to matter, take the static split.
     int opt_query_dynamic = 1;
-    uint64_t opt_query_dynamic_min = (uint64_t)1 << 25;  // batches below this many k-mers (lines of work for the branching kernel) keep the static split
+    uint64_t opt_query_dynamic_min = (uint64_t)1 << 16;  // batches below this many k-mers (lines of work for the branching kernel) keep the static split
+    uint64_t claims_static_launches = 0;  // launches that wanted a counter pair and found every slot taken by other streams
     uint32_t opt_query_chunk = 4;  // largest claim, in blocks of 256 k-mers (4 = every claim: the smaller the window of the query stream the
                                    // resident workgroups read at a time, the better -- 2.61 / 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64)
     static constexpr int KH_CTR_SLOTS = 32;
@@ -325,6 +329,8 @@ struct bft_gpu {
 };
 
 static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
+// rows per probe block of the suffix-group search ("query_probe": 4 or 8) -> BftImage::probe_big
+static uint32_t probe_mode(int rows) { return rows == 8 ? 1u : 0u; }
 
 static int set_device(bft_gpu* h) {
     HIPCK(hipSetDevice(h->device));
@@ -689,10 +695,11 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_nph.bytes + h->d_kh.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
+static void ensure_claim_counters(bft_gpu* h);
 
 // Points h->im at the device arrays of the handle (cannot fail).
 static void point_image(bft_gpu* h, uint32_t nb_genomes) {
@@ -723,6 +730,7 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.fent = h->d_fent.as<uint64_t>();
     im.rdir = nullptr;  // derived after this call (derive_root_direct)
     im.rstart = nullptr;
+    im.rq = nullptr;
     im.nph = nullptr;   // (derive_node_hash)
     im.nph_mask = 0;
     im.nph_no_uc = 0;
@@ -732,7 +740,7 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.emit_cs = 0;
     h->tuned_wgs = 0;
     h->tuned_probe = 0;
-    h->im.probe_big = h->opt_probe == 8;
+    h->im.probe_big = probe_mode(h->opt_probe);
 }
 
 // Root direct table: one thread per 18-bit prefix evaluates the root level's Bloom probe + CC lookup on the bound image.
@@ -754,6 +762,15 @@ __global__ void k_root_ranges_check(const uint64_t* __restrict__ rdir, uint32_t*
     if (r >= (1u << 18)) return;
     const uint32_t a = rs[r];
     if (!(a & BFT_RSTART_SPECIAL) && !bft_root_range_ok(a, rs[r + 1], rdir[r])) rs[r] = a | BFT_RSTART_SPECIAL;  // (readers mask the flag)
+}
+
+// Root quartile table (BFT_RQ_*): one thread per root prefix; for a plain group three lower-bound searches on the top two of the
+// key bits that follow the root digit.
+template <int W>
+__global__ void k_root_quartiles(BftImage im, const uint32_t* __restrict__ rs, uint32_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << 18)) return;
+    out[r] = bft_root_quartile_entry<W>(im, rs[r], rs[r + 1]);
 }
 
 // Node prefix hash.  k_nph_ccnode: the node of every CC (one thread per node).  k_nph_fill: one WAVEFRONT per CC below the root,
@@ -1026,10 +1043,11 @@ static void default_launch_shape(bft_gpu* h) {
     // (rows per ROOT prefix: the groups most queries end in hang off the root; deeper levels add prefixes, not rows)
     const uint64_t prefixes = std::max<uint64_t>(1, std::min<uint64_t>(h->info[6], 1ull << 18));
     h->tuned_probe = h->n_kmers / prefixes >= 48 ? 8 : 4;
-    h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+    h->im.probe_big = probe_mode(h->opt_probe ? h->opt_probe : h->tuned_probe);
     if (h->opt_root_direct == 3 && h->rstart_ok) {
         h->tuned_rstart = h->info[5] * 4 < (1u << 18) ? 1 : 0;
         h->im.rstart = h->tuned_rstart ? h->d_rstart.as<uint32_t>() : nullptr;
+        h->im.rq = h->tuned_rstart && h->rq_ok ? h->d_rq.as<uint32_t>() : nullptr;
     }
 }
 
@@ -1038,7 +1056,9 @@ static void default_launch_shape(bft_gpu* h) {
 static void derive_root_direct(bft_gpu* h) {
     h->im.rdir = nullptr;
     h->im.rstart = nullptr;
+    h->im.rq = nullptr;
     h->rstart_ok = false;
+    h->rq_ok = false;
     h->tuned_rstart = -1;
     if (!h->opt_root_direct || h->root_ncc == 0 || h->n_kmers == 0) return;
     if (h->d_rdir.bytes < (8u << 18) && h->d_rdir.alloc(8u << 18) != 0) return;
@@ -1069,6 +1089,20 @@ static void derive_root_direct(bft_gpu* h) {
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
     h->rstart_ok = true;
     h->im.rstart = h->d_rstart.as<uint32_t>();  // (mode 3: tune_residency decides whether it stays)
+    h->rq_ok = false;
+    if (!h->opt_root_quartiles || h->L < 2) return;
+    if (h->d_rq.bytes < (4u << 18) && h->d_rq.alloc(4u << 18) != 0) return;
+    tmp.rstart = h->im.rstart;
+    const dim3 gq((1u << 18) / 256);
+    switch (h->W) {
+    case 1: hipLaunchKernelGGL(k_root_quartiles<1>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
+    case 2: hipLaunchKernelGGL(k_root_quartiles<2>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
+    case 3: hipLaunchKernelGGL(k_root_quartiles<3>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
+    default: hipLaunchKernelGGL(k_root_quartiles<4>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    h->rq_ok = true;
+    h->im.rq = h->d_rq.as<uint32_t>();
 }
 
 // (Re)derives the flat form of the handle's current containers, points the image at everything and tunes the launch.
@@ -1514,6 +1548,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->build_ms[2] = t3 - t2;
     h->build_ms[3] = (double)h->front_redone;
     h->built = true;
+    ensure_claim_counters(h);
     bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
     if (kh_ok) {  // filled during the assembly
@@ -1562,6 +1597,7 @@ static int query_residency(const bft_gpu* h) {
     return h->tuned_wgs ? h->tuned_wgs : 2;
 }
 
+static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n);
 template <int W, bool STAGED, int PROBE>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
@@ -1572,9 +1608,11 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     // hash table + the root area (the root's Bloom block and CC headers, or -- with the derived root tables -- k_query's queue of deferred lanes)
     size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
-    const uint64_t nblk = (n + block - 1) / block;
     const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
-    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, resident * h->opt_grid_mult)));
+    // chunks of 1024 k-mers per wavefront (query_body): the first by wavefront number, the others claimed from the stream's counter pair
+    const uint64_t n_chunks = (n + 1023) / 1024, wg_chunks = (n_chunks + block / 64 - 1) / (block / 64);
+    uint32_t* ctr = claim_counters(h, s, n);
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wg_chunks, resident * h->opt_grid_mult)));
     static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
     const uint64_t dev_bit = 1ull << (h->device & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
@@ -1584,9 +1622,9 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     // rec: bytes per input record (B, or 8W for the zero-padded word records of the sequence path); load_x reads that many
-    if (res == 1) hipLaunchKernelGGL((k_query<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
-    else if (res == 3) hipLaunchKernelGGL((k_query6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
-    else hipLaunchKernelGGL((k_query8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows);
+    if (res == 1) hipLaunchKernelGGL((k_query<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
+    else if (res == 3) hipLaunchKernelGGL((k_query6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
+    else hipLaunchKernelGGL((k_query8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1618,27 +1656,29 @@ static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uin
     return 0;
 }
 
-// The claim counters of stream s (see struct bft_gpu), or NULL: the static split.
-static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n) {
-    // (below ~2 x 10^7 lines of work a launch is over before the XCDs drift apart, and a claim costs its ~12 ns on the one counter:
-    // 2^20 k-mers 28 us split statically, 57 us claimed; 2^24: 400 / 409; 1.25 x 10^8: 2.72-3.06 ms / 2.62)
-    static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
-    if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || h->kh_ctr_failed) return nullptr;
-    if (!h->kh_ctr) {  // (once per handle; a blocking memset: no launch of any stream can meet a counter that is not zero yet)
-        if (hipMalloc((void**)&h->kh_ctr, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess || hipMemset(h->kh_ctr, 0, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess ||
-            hipDeviceSynchronize() != hipSuccess) {
-            (void)hipGetLastError();
-            if (h->kh_ctr) (void)hipFree(h->kh_ctr);
-            h->kh_ctr = nullptr;
-            h->kh_ctr_failed = true;
-            return nullptr;
-        }
+// The claim counters of the handle: allocated and zeroed once, when the first image is committed (bft_gpu_build, bft_gpu_image_unpack) --
+// never on the path of a query call.
+static void ensure_claim_counters(bft_gpu* h) {
+    if (h->kh_ctr || h->kh_ctr_failed) return;
+    if (hipMalloc((void**)&h->kh_ctr, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess || hipMemset(h->kh_ctr, 0, bft_gpu::KH_CTR_SLOTS * 8) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {  // (blocking: no launch of any stream can meet a counter that is not zero yet)
+        (void)hipGetLastError();
+        if (h->kh_ctr) (void)hipFree(h->kh_ctr);
+        h->kh_ctr = nullptr;
+        h->kh_ctr_failed = true;
     }
+}
+// The claim counters of stream s (see struct bft_gpu), or NULL: every round of blocks is dealt out by workgroup number.  A handle keeps a
+// pair for each of the first KH_CTR_SLOTS streams it is queried on; launches on a stream beyond them run static rounds and are counted
+// (bft_gpu_build_time, entry 20: nothing is silent).
+static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n) {
+    static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
+    if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || !h->kh_ctr) return nullptr;
     int slot = -1;
     for (int i = 0; i < h->kh_ctr_used; i++)
         if (h->kh_ctr_stream[i] == s) slot = i;
     if (slot < 0) {
-        if (h->kh_ctr_used == bft_gpu::KH_CTR_SLOTS) return nullptr;
+        if (h->kh_ctr_used == bft_gpu::KH_CTR_SLOTS) { h->claims_static_launches++; return nullptr; }
         slot = h->kh_ctr_used++;
         h->kh_ctr_stream[slot] = s;
     }
@@ -1701,7 +1741,7 @@ static int tune_residency(bft_gpu* h) {
     if (h->n_kmers < (1u << 16)) {  // small (L2-resident) indexes: always two workgroups, 4-row probes
         h->tuned_wgs = 2;
         h->tuned_probe = 4;
-        h->im.probe_big = h->opt_probe == 8;
+        h->im.probe_big = probe_mode(h->opt_probe);
         return 0;
     }
     const uint64_t m = 1ull << 22;
@@ -1730,7 +1770,7 @@ static int tune_residency(bft_gpu* h) {
         if ((h->opt_wgs_per_cu && h->opt_wgs_per_cu != wgs) || (h->opt_probe && h->opt_probe != probe) || (h->W > BFT_PROBE_MAX_W && probe == 8))
             continue;
         h->tuned_wgs = wgs;
-        h->im.probe_big = probe == 8;
+        h->im.probe_big = probe_mode(probe);
         for (int rep = 0; rep < 2 && rc == 0; rep++) {  // the first repetition warms the caches, the second counts (large batches measure again: launch_query)
             if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
             if (rc == 0) rc = launch_query_walk(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
@@ -1757,10 +1797,11 @@ static int tune_residency(bft_gpu* h) {
     // on how many there are, so both are timed with the residency / probe mode just chosen.
     if (rc == 0 && h->opt_root_direct == 3 && h->rstart_ok) {
         h->tuned_wgs = win_wgs;
-        h->im.probe_big = (h->opt_probe ? h->opt_probe : win_probe) == 8;
+        h->im.probe_big = probe_mode(h->opt_probe ? h->opt_probe : win_probe);
         float rs[2] = {1e30f, 1e30f};
         for (int mode = 0; mode < 2 && rc == 0; mode++) {
             h->im.rstart = mode ? h->d_rstart.as<uint32_t>() : nullptr;
+            h->im.rq = mode && h->rq_ok ? h->d_rq.as<uint32_t>() : nullptr;
             for (int rep = 0; rep < 3 && rc == 0; rep++) {
                 if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(BFT_GPU_E_HIP, "hipEventRecord failed");
                 if (rc == 0) rc = launch_query_walk(h, q.as<uint8_t>(), m, bits.as<uint64_t>(), nullptr, h->stream);
@@ -1774,18 +1815,19 @@ static int tune_residency(bft_gpu* h) {
         h->rstart_tune_ms[1] = rs[1];
         h->tuned_rstart = rs[1] < rs[0] ? 1 : 0;
         h->im.rstart = h->tuned_rstart ? h->d_rstart.as<uint32_t>() : nullptr;
+        h->im.rq = h->tuned_rstart && h->rq_ok ? h->d_rq.as<uint32_t>() : nullptr;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     h->timing = timing;
     h->im.debug_stop = dbg;
     h->tuned_wgs = 0;
-    h->im.probe_big = h->opt_probe == 8;
+    h->im.probe_big = probe_mode(h->opt_probe);
     CK(rc);
     for (int r = 0; r < 3; r++) h->tune_ms[r] = std::min(best[r], best[r + 3]) < 1e29f ? std::min(best[r], best[r + 3]) : 0;
     h->tuned_wgs = win_wgs;
     h->tuned_probe = win_probe;
-    h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+    h->im.probe_big = probe_mode(h->opt_probe ? h->opt_probe : h->tuned_probe);
     return 0;
 }
 
@@ -2116,7 +2158,7 @@ static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint6
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     if (W <= 2 && h->im.kh != nullptr) {
         return bft_kh_seq(h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical,
-                          h->sq_cs.as<uint32_t>(), s);
+                          h->sq_cs.as<uint32_t>(), claim_counters(h, s, h->opt_query_dynamic_min), h->opt_query_chunk, s);
     }
     return staged ? launch_seq_walk_k<W, true, 0>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W, false, 0>(h, ns, canonical, d_soff, s);
 }
@@ -2411,7 +2453,7 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
         for (int i = 0; i < 16; i++) h->info[i] = H[H_INFO + i];
         for (int i = 0; i < 9; i++) h->idx_sizes[i] = H[H_IDX + i];
         h->cs_on_host = false;
-        rc = bind_image(h, (uint32_t)H[H_NBGEN]);
+        if (rc == 0) rc = bind_image(h, (uint32_t)H[H_NBGEN]);
     }
     if (rc != 0) {
         const std::string keep = g_err;
@@ -2420,6 +2462,7 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
     }
     h->info[12] = image_bytes(h);
     h->built = true;
+    ensure_claim_counters(h);
     *out = h;
     return BFT_GPU_OK;
 }
@@ -2469,7 +2512,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "query_probe") {
         if (value != 0 && value != 4 && value != 8) return fail(BFT_GPU_E_ARG, "query_probe must be 0 (automatic), 4 or 8");
         h->opt_probe = (int)value;
-        h->im.probe_big = (h->opt_probe ? h->opt_probe : h->tuned_probe) == 8;
+        h->im.probe_big = probe_mode(h->opt_probe ? h->opt_probe : h->tuned_probe);
     } else if (nm == "node_hash") {  // 1 (default): levels below the root through the node prefix hash; 0: through the containers
         if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "node_hash must be 0, 1 or 2");
         h->opt_node_hash = (int)value;
@@ -2512,9 +2555,23 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             ENTER(h);
             CK(wait_foreign_stream(h));
             HIPCK(hipStreamSynchronize(h->stream));
+            CK(ensure_table(h));  // ("compact_table": k_root_ranges reads the sorted table)
             derive_root_direct(h);
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
+            drop_table(h);
+        }
+    } else if (nm == "root_quartiles") {  // 1 (default): plain root groups are searched quarter by quarter (BFT_RQ_*)
+        h->opt_root_quartiles = value != 0;
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            CK(ensure_table(h));
+            derive_root_direct(h);
+            default_launch_shape(h);
+            h->info[12] = image_bytes(h);
+            drop_table(h);
         }
     } else if (nm == "tune") {  // measure the launch shape of the container walk on the current image (synchronises)
         if (value != 0 && h->built) {
@@ -2552,8 +2609,12 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         h->opt_flat_min = (uint32_t)value;
         if (h->built) {  // re-derive the flat arrays of the current image
             ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            CK(ensure_table(h));  // ("compact_table": the derived tables are rebuilt from the sorted table)
             CK(bind_image(h, h->im.nb_genomes));
             h->info[12] = image_bytes(h);
+            drop_table(h);
         }
     } else
         return fail(BFT_GPU_E_ARG, "unknown option");
@@ -2572,7 +2633,7 @@ extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
     if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
                             h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
-                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes, h->d_nph.bytes, h->d_kh.bytes, h->d_cs_bm.bytes,
+                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes, h->d_cs_bm.bytes,
                             h->d_hashmod.bytes, 0ull, h->log_k.bytes + h->log_g.bytes};
     for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
     return BFT_GPU_OK;
@@ -2594,11 +2655,11 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[20] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+    const double v[21] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
                           h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, (double)bft_test_exact_passes(), g_malloc_ms,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
-                          (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2]};
-    for (int i = 0; i < n_out && i < 20; i++) ms[i] = v[i];
+                          (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2], (double)h->claims_static_launches};
+    for (int i = 0; i < n_out && i < 21; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

@@ -19,7 +19,7 @@ struct HostTrie {
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
     std::vector<uint64_t> rdir, nph, kh;
-    std::vector<uint32_t> rstart;
+    std::vector<uint32_t> rstart, rq;
     uint64_t rstart_plain = 0;
     BftHostIndex idx;
     BftImage im;
@@ -207,6 +207,7 @@ extern "C" void bft_hosttest_root_direct(void* hv, int on) {
     HostTrie* t = (HostTrie*)hv;
     t->im.rdir = nullptr;
     t->im.rstart = nullptr;
+    t->im.rq = nullptr;
     if (!on || t->idx.nodes.empty() || !t->idx.nodes[0].ncc) return;
     t->rdir.assign(1u << 18, 0);
     const BftRootGlobal root(t->im);
@@ -230,6 +231,17 @@ extern "C" void bft_hosttest_root_direct(void* hv, int on) {
     uint64_t plain = 0;
     for (uint32_t r = 0; r < (1u << 18); r++) plain += !(t->rstart[r] & BFT_RSTART_SPECIAL);
     t->rstart_plain = plain;
+    if (on < 3 || t->im.L < 2) return;  // 3: also the root quartile table (BFT_RQ_*), k_root_quartiles
+    t->rq.assign(1u << 18, 0);
+    for (uint32_t r = 0; r < (1u << 18); r++) {
+        switch (t->W) {
+        case 1: t->rq[r] = bft_root_quartile_entry<1>(t->im, t->rstart[r], t->rstart[r + 1]); break;
+        case 2: t->rq[r] = bft_root_quartile_entry<2>(t->im, t->rstart[r], t->rstart[r + 1]); break;
+        case 3: t->rq[r] = bft_root_quartile_entry<3>(t->im, t->rstart[r], t->rstart[r + 1]); break;
+        default: t->rq[r] = bft_root_quartile_entry<4>(t->im, t->rstart[r], t->rstart[r + 1]); break;
+        }
+    }
+    t->im.rq = t->rq.data();
 }
 extern "C" uint64_t bft_hosttest_root_plain(void* hv) { return ((HostTrie*)hv)->rstart_plain; }
 

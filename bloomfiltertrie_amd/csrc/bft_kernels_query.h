@@ -8,6 +8,7 @@
 // ------------------------------------------------------------------------------------------------
 
 #include "bft_kernels_load.h"
+#include "bft_claims.h"
 
 template <int W>
 __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
@@ -47,12 +48,23 @@ struct BftRootLds {
 #define BFT_LDS_HM_BYTES 65536u
 #define BFT_LDS_ROOT_MAX_CC 64u
 
+// The batch is dealt out WAVEFRONT by wavefront, in chunks of 1024 k-mers = 16 passes of 64 = the 16 presence words of one 128-byte line
+// of the bitmap: the first chunk of a wavefront by its number, the others claimed from ctr[0] (NULL: all by number; see bft_claims.h for
+// why batches are claimed at all).  A wavefront gathers the words of its chunk in its own 128 bytes of LDS and stores the line with one
+// instruction.  Nothing here makes the wavefronts of a workgroup wait for each other: a barrier per pass costs this latency-bound kernel
+// 10-30 %, and rounds of four blocks per WORKGROUP (three barriers per round, the scheme of k_query_kh) took 7.6 ms where this takes
+// (measured, profiles/r04/probe_walk.jsonl) -- a wavefront of the walk is as slow as its slowest lane, a workgroup would be as slow as its
+// slowest wavefront.
+#define BFT_WALK_PASSES 16u   // passes of 64 k-mers per chunk: one 128-byte line of presence bits
+
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
+                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t* l_hm = (uint32_t*)lds;
     uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    constexpr uint32_t WPW = BLOCK / 64;  // wavefronts per workgroup
+    __shared__ uint64_t s_bits[WPW][BFT_WALK_PASSES];
     const BftNode root = im.nodes[0];
     // the root's Bloom block and CC headers are only read when the root level goes through the containers: with the derived
     // root tables (im.rdir) that LDS space holds the queue of deferred lanes instead (below)
@@ -74,94 +86,110 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     __syncthreads();
     const BftRootLds<STAGED> acc{im, l_hm, l_bf, l_cc};
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BLOCK - 1) / BLOCK;
-    if (im.rstart == nullptr) {
-        // no range table: every lane walks its k-mer to the end
-        for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-            const uint64_t i = blk * BLOCK + threadIdx.x;
-            int present = 0;
-            uint32_t row = BFT_ABSENT_ROW;
-            if (i < n) {
-                uint64_t x[W], t[W];
-                load_x<W>(packed, i, B, end_aligned, x);
-                bft_tform_from_x<W>(x, im.k, t);
-                const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
-                present = h.present;
-                if (present && rows) row = bft_hit_out(im, h);
-            }
-            const uint64_t mask = __ballot(present);
-            const uint64_t q0 = i & ~63ull;  // first query of this wavefront
-            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-            if (rows && i < n) rows[i] = row;
-        }
-        return;
-    }
+    constexpr uint64_t CHUNK = 64ull * BFT_WALK_PASSES;
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK, nwords = (n + 63) / 64;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t n_waves = (uint64_t)gridDim.x * WPW;
+    if (n_waves >= n_chunks) ctr = nullptr;  // (the first round covers the batch: no counter involved)
+    uint64_t chunk = (uint64_t)blockIdx.x * WPW + wave;
+    uint32_t next_claim = 0;
+    volatile uint64_t* my_bits = s_bits[wave];
+    const bool with_queue = im.rstart != nullptr;
     // With the range table: every lane takes the short path (range table -> suffix group); a lane whose root prefix is "special"
     // (child Node, UC rows: the long container path) only parks its k-mer in its wavefront's queue in LDS, and the wavefront walks
     // the queue when it is full.  A wavefront is as slow as its slowest lane, and with ~5 % special prefixes (config 4) nearly
-    // every wavefront had one: parked, the long path is walked by (nearly) full wavefronts, once per ~20 passes.  No workgroup
-    // barrier is involved (measured: two barriers per pass cost this miss-bound kernel 10-30 %); a parked lane's answer is OR-ed
-    // into the word its own wavefront stored earlier (same wavefront, same address: in order).
+    // every wavefront had one: parked, the long path is walked by (nearly) full wavefronts, once per ~20 passes.  A parked lane's
+    // answer is OR-ed into its presence word: in the wavefront's LDS words while its chunk is still being gathered there, else in the
+    // bitmap itself (the line was stored earlier by this very wavefront: same wavefront, same address, in order).
     constexpr uint32_t QCAP = W == 1 ? 64u : (W == 2 ? 32u : 16u);   // entries per wavefront: 16 x QCAP x (8 W + 4) bytes <= the 14 KiB root area
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint64_t* q_t = (uint64_t*)l_bf + (size_t)wave * QCAP * W;                          // [QCAP * W] parked T-forms of this wavefront
     uint32_t* q_i = (uint32_t*)((uint64_t*)l_bf + (size_t)(BLOCK / 64) * QCAP * W) + (size_t)wave * QCAP;  // [QCAP] their query (offset from qbase)
     uint32_t qn = 0;          // entries parked (wavefront-uniform)
     uint64_t qbase = 0;       // queries are parked as 32-bit offsets from the first query of the pass the queue was last empty in
-    auto drain = [&]() {
+    auto answer_late = [&](uint64_t i, const BftHit& h, bool chunk_open) {
+        if (h.present) {
+            if (chunk_open && i / CHUNK == chunk) atomicOr((unsigned long long*)&s_bits[wave][(i >> 6) % BFT_WALK_PASSES], 1ull << (i & 63u));
+            else atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
+        }
+        if (rows) rows[i] = h.present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
+    };
+    auto drain = [&](bool chunk_open) {
         if (lane < qn) {
             uint64_t t[W];
 #pragma unroll
             for (int w = 0; w < W; w++) t[w] = q_t[(size_t)lane * W + w];
             const uint64_t i = qbase + q_i[lane];
             const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
-            if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
-            if (rows) rows[i] = h.present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
+            answer_late(i, h, chunk_open);
         }
         qn = 0;
     };
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t i = blk * BLOCK + threadIdx.x;
-        int present = 0;
-        bool parked = false;
-        uint64_t t[W];
-        if (i < n) {
-            uint64_t x[W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            bft_tform_from_x<W>(x, im.k, t);
-            const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 1>(im, acc, root, t);
-            if (h.present == BFT_HIT_DEFERRED) parked = true;
-            else {
-                present = h.present;
-                if (rows) rows[i] = present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
-            }
-        }
-        const uint64_t mask = __ballot(present);
-        const uint64_t q0 = i & ~63ull;  // first query of this wavefront
-        if (lane == 0 && q0 < n) bits64[q0 >> 6] = mask;
-        const uint64_t pm = __ballot(parked);
-        if (pm) {
-            const uint32_t np = (uint32_t)__popcll(pm);
-            if (qn == 0) qbase = q0;
-            if (qn + np > QCAP || q0 + 64 - qbase > 0xFFFFFFFFull) { drain(); qbase = q0; }
-            if (np > QCAP) {  // more special lanes than the queue holds (a deep trie: every prefix is a child Node): walk them here
-                if (parked) {
-                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
-                    if (h.present) atomicOr((unsigned long long*)&bits64[i >> 6], 1ull << (i & 63u));
-                    if (rows) rows[i] = h.present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
+    while (chunk < n_chunks) {
+        for (uint32_t pass = 0; pass < BFT_WALK_PASSES; pass++) {
+            const uint64_t q0 = chunk * CHUNK + (uint64_t)pass * 64;  // first query of this pass
+            if (q0 >= n) break;
+            const uint64_t i = q0 + lane;
+            int present = 0;
+            bool parked = false;
+            uint64_t t[W];
+            if (i < n) {
+                uint64_t x[W];
+                load_x<W>(packed, i, B, end_aligned, x);
+                bft_tform_from_x<W>(x, im.k, t);
+                if (with_queue) {
+                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 1>(im, acc, root, t);
+                    if (h.present == BFT_HIT_DEFERRED) parked = true;
+                    else {
+                        present = h.present;
+                        if (rows) rows[i] = present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
+                    }
+                } else {  // no range table: every lane walks its k-mer to the end
+                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE>(im, acc, root, t);
+                    present = h.present;
+                    if (rows) rows[i] = present ? bft_hit_out(im, h) : BFT_ABSENT_ROW;
                 }
-            } else {
-                if (parked) {
-                    const uint32_t qp = qn + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            }
+            const uint64_t mask = __ballot(present);
+            if (lane == 0) my_bits[pass] = mask;
+            // the claim for the next chunk travels while this one is answered (sent after the first pass: at the start of a launch
+            // every wavefront would ask at the same instant)
+            if (pass == 0 && ctr && lane == 0) next_claim = atomicAdd(&ctr[0], 1u);
+            const uint64_t pm = __ballot(parked);
+            if (pm) {
+                const uint32_t np = (uint32_t)__popcll(pm);
+                if (qn == 0) qbase = q0;
+                if (qn + np > QCAP || q0 + 64 - qbase > 0xFFFFFFFFull) { drain(true); qbase = q0; }
+                if (np > QCAP) {  // more special lanes than the queue holds (a deep trie: every prefix is a child Node): walk them here
+                    if (parked) {
+                        const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 2>(im, acc, root, t);
+                        answer_late(i, h, true);
+                    }
+                } else {
+                    if (parked) {
+                        const uint32_t qp = qn + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
 #pragma unroll
-                    for (int w = 0; w < W; w++) q_t[(size_t)qp * W + w] = t[w];
-                    q_i[qp] = (uint32_t)(i - qbase);
+                        for (int w = 0; w < W; w++) q_t[(size_t)qp * W + w] = t[w];
+                        q_i[qp] = (uint32_t)(i - qbase);
+                    }
+                    qn += np;
                 }
-                qn += np;
             }
         }
+        // the chunk's line of presence words: lanes 0..15, one store instruction
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint64_t wi = chunk * BFT_WALK_PASSES + lane;
+            if (lane < BFT_WALK_PASSES && wi < nwords) bits64[wi] = my_bits[lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        chunk = ctr ? n_waves + (uint64_t)__builtin_amdgcn_readfirstlane(next_claim) : chunk + n_waves;
     }
-    if (qn) drain();
+    if (qn) drain(false);
+    // ctr[1] counts the wavefronts that are done; the last one zeroes the pair for the next launch on the stream
+    if (ctr && lane == 0 && atomicAdd(&ctr[1], 1u) == (uint32_t)n_waves - 1u) {
+        ctr[0] = 0u;
+        ctr[1] = 0u;
+    }
 }
 
 // Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in
@@ -172,21 +200,23 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
 // from the image (-1; the other workgroup sizes): the 4-row code alone fits the 64 VGPRs of k_query8 without spilling.
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                 uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+                                                 uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                                                             uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
-    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+                                                                                             uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
+                                                                                             uint32_t* __restrict__ ctr) {
+    query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 // k_query6: the arrangement in between -- two 768-thread workgroups per CU, 6 wavefronts per SIMD with 84 VGPRs each.  The walk
 // of the two-word rows (k = 36..63) needs 73-81 VGPRs: k_query8 spills 20-40 of them, k_query runs 4 wavefronts per SIMD.
 #define BFT_BLOCK6 768
 template <int W, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                                                                 uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows) {
-    query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows);
+                                                                                                 uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
+                                                                                                 uint32_t* __restrict__ ctr) {
+    query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):

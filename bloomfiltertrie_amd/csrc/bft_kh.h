@@ -11,11 +11,11 @@
 int bft_kh_dump(const uint64_t* d_kh, uint64_t n_lines, int W, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
 int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W, uint64_t* d_kh, uint64_t n_lines, hipStream_t s);
 // presence bits (+ colour-set id per k-mer when d_out32 != NULL) of n packed k-mers of `rec` bytes each
-// d_ctr: NULL, or two zeroed 32-bit words that no other launch in flight uses -- the blocks of 256 k-mers are then claimed `chunk` at a
-// time instead of dealt out by workgroup number (k_query_kh), and the kernel leaves the words zeroed
+// d_ctr: NULL, or two zeroed 32-bit words that no other launch in flight uses -- the rounds of `chunk` blocks of 256 k-mers after the first
+// are then claimed instead of dealt out by workgroup number (bft_claims.h), and the kernel leaves the words zeroed
 int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
                  hipStream_t s);
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s);
 // colour set of every k-mer position of a chunk of sequences (the arrays of query_sequences_core)
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
-               uint32_t n_seqs, int canonical, uint32_t* d_csout, hipStream_t s);
+               uint32_t n_seqs, int canonical, uint32_t* d_csout, uint32_t* d_ctr, uint32_t chunk, hipStream_t s);

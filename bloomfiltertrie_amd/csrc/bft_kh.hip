@@ -7,6 +7,7 @@
 #include "bft_dev.h"
 #include "bft_image.h"
 #include "bft_kh.h"
+#include "bft_claims.h"
 #include "bft_walk.h"
 #include "bft_kernels_load.h"
 #include "bft_kernels_seqwin.h"
@@ -16,67 +17,25 @@
 // per wavefront through __ballot, persistent grid.
 // (Two or four k-mers per lane and pass, their home lines loaded together, were measured on the 100-genome index: 41.5 / 37.5 G k-mers/s
 // against 44.6 with one -- the fabric's request rate is the limit, not the number of requests a lane keeps in flight; tools/probe_kh.py.)
-// DYN: the blocks of 256 k-mers are not dealt out by workgroup number but claimed, up to `chunk` blocks at a time, from a counter in device
-// memory (ctr[0]; ctr[1] counts the workgroups that are done, the last one zeroes both for the next launch on the stream).  Workgroups
-// are bound to an XCD by their number -- every XCD gets an eighth of a static partition however fast it gets through it --, and how
-// fast depends on where the table lies: 2.70 / 2.77 / 3.03 ms for the same table, batch and kernel (same misses, same latency per
-// request, fewer requests in flight: XCDs idle at the end), 2.63 ms wherever it lies once the chunks are claimed.
-// A claim takes remaining / (2 x workgroups) blocks, at most `chunk`, at least BFT_KH_MIN_CLAIM: the counter serves a claim every ~12 ns,
-// 2048 resident workgroups that answer a block in ~11 us saturate it below ~3 blocks per claim (a block per claim: 5.9 ms per launch, two:
-// 3.4, against 2.6-2.7) -- so never fewer than four.  More per claim did not pay either (the default `chunk` is four as well): what the
-// resident workgroups read of the query stream at a time should stay a narrow window.
-#define BFT_KH_MIN_CLAIM 4u
-struct KhClaims {
-    uint32_t* ctr;     // ctr[0]: the next unclaimed block
-    uint32_t chunk;
-    uint64_t nblk, blk, blk_end;
-    uint32_t* s_next;  // two words of LDS: first block and size of the claim in flight
-    uint64_t start;    // first block of the claim being answered
-    __device__ __forceinline__ void claim(uint64_t from) {
-        const uint64_t rem = nblk - min(nblk, from);
-        const uint32_t want = (uint32_t)max((uint64_t)min(chunk, BFT_KH_MIN_CLAIM), min((uint64_t)chunk, rem / (2ull * gridDim.x)));
-        s_next[1] = want;
-        s_next[0] = atomicAdd(&ctr[0], want);
-    }
-    // the first chunk of the workgroup; the next claim is sent off at once and travels while the chunk is answered
-    __device__ __forceinline__ void first() {
-        if (threadIdx.x == 0) claim(0);
-        take();
-    }
-    __device__ __forceinline__ void take() {
-        __syncthreads();
-        blk = start = s_next[0];
-        blk_end = min(nblk, blk + s_next[1]);
-        __syncthreads();
-        if (threadIdx.x == 0 && blk < nblk) claim(blk_end);
-    }
-    __device__ __forceinline__ void advance() {
-        if (++blk >= blk_end) take();
-    }
-    // after the loop: every workgroup has made its last claim once the last one gets here
-    __device__ __forceinline__ void done() {
-        if (threadIdx.x == 0 && atomicAdd(&ctr[1], 1u) == gridDim.x - 1u) {
-            ctr[0] = 0u;
-            ctr[1] = 0u;
-        }
-    }
-};
-
-// The presence words of a claim (one per wavefront and block) are gathered in LDS and leave as ONE coalesced store of whole lines: a claim
+// The blocks of 256 k-mers are dealt out in rounds of `chunk` blocks: the first round by workgroup number, the others claimed from a counter
+// in device memory (bft_claims.h; ctr == NULL: every round by workgroup number).
+// The presence words of a round (one per wavefront and block) are gathered in LDS and leave as ONE coalesced store of whole lines: a round
 // of four blocks is exactly one 128-byte line of the bitmap.  Stored wavefront by wavefront, a line was written 8 bytes at a time over
 // ~40 us while the gathers turn the L2 over every ~10 us -- evicted in pieces --, and the launch time followed where the 15 MB bitmap lay
 // (2.60 / 2.82 ms on the same table and batch, fresh bitmaps flipping it inside a process: profiles/r03/probe_dynamic_inputs.jsonl).
+#define BFT_KH_MIN_CLAIM 4u
 #define BFT_KH_MAX_CLAIM 64u
-template <int W, bool DYN>
+typedef BftClaims<BFT_KH_MIN_CLAIM> KhClaims;
+template <int W>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                           uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, nwords = (n + 63) / 64;
     constexpr uint32_t WPB = BFT_KH_BLOCK / 64;  // presence words per block
     __shared__ uint32_t s_next[2];
-    __shared__ uint64_t s_bits[DYN ? BFT_KH_MAX_CLAIM * WPB : 1];
-    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, s_next, 0};
-    if (DYN) cl.first();
+    __shared__ uint64_t s_bits[BFT_KH_MAX_CLAIM * WPB];
+    KhClaims cl(ctr, chunk, nblk, s_next);
+    cl.first();
     while (cl.blk < nblk) {
         const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
         bool present = false;
@@ -91,21 +50,15 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
         }
         const uint64_t mask = __ballot(present);
         if (out32 && i < n) out32[i] = present ? val : 0xFFFFFFFFu;
-        if (!DYN) {
-            const uint64_t q0 = i & ~63ull;
-            if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
-            cl.blk += gridDim.x;
-        } else {
-            if ((threadIdx.x & 63u) == 0) s_bits[(cl.blk - cl.start) * WPB + (threadIdx.x >> 6)] = mask;
-            if (cl.blk + 1 >= cl.blk_end) {  // the claim is answered: its words leave together
-                __syncthreads();
-                const uint64_t w0 = cl.start * WPB, w1 = min(nwords, cl.blk_end * WPB);
-                if (w0 + threadIdx.x < w1) __builtin_nontemporal_store(s_bits[threadIdx.x], &bits64[w0 + threadIdx.x]);
-            }
-            cl.advance();  // (its barriers stand between these reads of s_bits and the next claim's writes)
+        if ((threadIdx.x & 63u) == 0) s_bits[(cl.blk - cl.start) * WPB + (threadIdx.x >> 6)] = mask;
+        if (cl.last_of_round()) {  // the round is answered: its words leave together
+            __syncthreads();
+            const uint64_t w0 = cl.start * WPB, w1 = min(nwords, cl.blk_end * WPB);
+            if (w0 + threadIdx.x < w1) __builtin_nontemporal_store(s_bits[threadIdx.x], &bits64[w0 + threadIdx.x]);
         }
+        cl.advance();  // (its barriers stand between these reads of s_bits and the next round's writes)
     }
-    if (DYN) cl.done();
+    cl.done();
 }
 
 // How many of four candidate k-mers are stored: the four home lines are loaded before any is looked at -- four independent
@@ -138,16 +91,20 @@ __device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*ca
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998), see branching_body.
-template <int W, bool DYN>
+// Rounds of blocks as in k_query_kh; the branching bits and the neighbour counts of a round leave LDS as whole lines.
+#define BFT_KH_BR_MAX_CLAIM 16u
+template <int W>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                               uint8_t* __restrict__ counts, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
-    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK;
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, nwords = (n + 63) / 64;
+    constexpr uint32_t WPB = BFT_KH_BLOCK / 64;
     const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
     __shared__ uint32_t s_next[2];
-    KhClaims cl{ctr, chunk, nblk, blockIdx.x, 0, s_next, 0};
-    if (DYN) cl.first();
-    for (; cl.blk < nblk; DYN ? cl.advance() : (void)(cl.blk += gridDim.x)) {
+    __shared__ uint64_t s_bits[BFT_KH_BR_MAX_CLAIM * WPB];
+    KhClaims cl(ctr, chunk, nblk, s_next);
+    cl.first();
+    while (cl.blk < nblk) {
         const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
         int branching = 0;
         if (i < n) {
@@ -164,7 +121,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
                 for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == W - 1 ? (uint64_t)v << vo : 0ull);
             }
             const int cr = kh_count4<W>(im, cand);
-            int cl = 0;
+            int cl_ = 0;
             if (counts || cr < 2) {
                 // predecessors: shift in a wildcard first nucleotide (bits 0..1 of the first digit), drop the last one
 #pragma unroll
@@ -178,16 +135,21 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
 #pragma unroll
                     for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == ow ? (uint64_t)v << osh : 0ull);
                 }
-                cl = kh_count4<W>(im, cand);
+                cl_ = kh_count4<W>(im, cand);
             }
-            branching = cr > 1 || cl > 1;
-            if (counts) counts[i] = (uint8_t)((cr << 4) | cl);
+            branching = cr > 1 || cl_ > 1;
+            if (counts) counts[i] = (uint8_t)((cr << 4) | cl_);  // (a wavefront's 64 bytes: one coalesced store)
         }
         const uint64_t mask = __ballot(branching);
-        const uint64_t q0 = i & ~63ull;
-        if ((threadIdx.x & 63u) == 0 && q0 < n) bits64[q0 >> 6] = mask;
+        if ((threadIdx.x & 63u) == 0) s_bits[(cl.blk - cl.start) * WPB + (threadIdx.x >> 6)] = mask;
+        if (cl.last_of_round()) {
+            __syncthreads();
+            const uint64_t w0 = cl.start * WPB, w1 = min(nwords, cl.blk_end * WPB);
+            if (w0 + threadIdx.x < w1) __builtin_nontemporal_store(s_bits[threadIdx.x], &bits64[w0 + threadIdx.x]);
+        }
+        cl.advance();
     }
-    if (DYN) cl.done();
+    cl.done();
 }
 
 // Fills the table: one thread per stored k-mer claims the first free slot at or after its home line with a compare-and-swap on the
@@ -232,11 +194,14 @@ __global__ __launch_bounds__(256) void k_kh_insert(const uint64_t* __restrict__ 
 template <int W>
 __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
                                                 const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
-                                                uint32_t* __restrict__ csout) {
+                                                uint32_t* __restrict__ csout, uint32_t* __restrict__ ctr, uint32_t chunk) {
     const uint64_t P = pos_off[n_seqs];
     const uint64_t nblk = (P + 255) / 256;
-    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const uint64_t p = blk * 256 + threadIdx.x;
+    __shared__ uint32_t s_next[2];
+    KhClaims cl(ctr, chunk, nblk, s_next);  // (the number of positions is only known on the device: the grid is the resident one, rounds beyond nblk are empty)
+    cl.first();
+    for (; cl.blk < nblk; cl.advance()) {
+        const uint64_t p = cl.blk * 256 + threadIdx.x;
         if (p >= P) continue;
         uint32_t lo = tile_seq[p >> 6];
         while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
@@ -249,15 +214,11 @@ __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __r
         }
         csout[p] = cs;
     }
+    cl.done();
 }
 
 
 // ---- launchers (called from bft_gpu.hip) ------------------------------------------------------------------------------------
-static unsigned kh_grid(uint64_t n, uint64_t per_block, int mult) {
-    const uint64_t nblk = (n + per_block - 1) / per_block;
-    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nblk, 256ull * 8 * (uint64_t)std::max(1, mult)));
-}
-
 // Every (key, value) the table holds, in any order: each workgroup counts the occupied slots of its share of the lines, reserves that
 // many places with one atomic, writes (word w of the j-th key at keys[w * stride + j]).  The "compact_table" option rebuilds the sorted
 // table from this.
@@ -313,45 +274,42 @@ int bft_kh_fill(const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t n, int W,
     return 0;
 }
 
-// d_ctr != NULL: claimed chunks, and no more workgroups than are resident; else the static partition over four times as many (44.6 ->
-// 47.2 G k-mers/s on the 100-genome index when it was the only form: the tail of a persistent grid is shorter)
+// Rounds of `chunk` blocks (bft_claims.h).  d_ctr != NULL: the rounds after the first are claimed, and no more workgroups than are resident
+// are launched; else every round is dealt out by workgroup number, over four times as many (44.6 -> 47.2 G k-mers/s on the 100-genome
+// index when that was the only form: the tail of a persistent grid is shorter).
+static dim3 kh_round_grid(uint64_t n, uint32_t chunk, int mult, bool claimed) {
+    const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, rounds = (nblk + chunk - 1) / chunk;
+    const uint64_t resident = 256ull * 8 * (uint64_t)std::max(1, mult) * (claimed ? 1ull : 4ull);
+    return dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(rounds, resident)));
+}
+
 int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
                  hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
     chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
-    if (d_ctr) {
-        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * 2, grid_mult));
-        if (im.W == 1) hipLaunchKernelGGL((k_query_kh<1, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
-        else hipLaunchKernelGGL((k_query_kh<2, true>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
-    } else {
-        const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4 * grid_mult));
-        if (im.W == 1) hipLaunchKernelGGL((k_query_kh<1, false>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, 1u);
-        else hipLaunchKernelGGL((k_query_kh<2, false>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, 1u);
-    }
+    const dim3 grid = kh_round_grid(n, chunk, grid_mult, d_ctr != nullptr);
+    if (im.W == 1) hipLaunchKernelGGL(k_query_kh<1>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
+    else hipLaunchKernelGGL(k_query_kh<2>, grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk);
     HIPCK(hipGetLastError());
     return 0;
 }
 
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
-    if (d_ctr) {
-        const dim3 grid(kh_grid(n, (uint64_t)BFT_KH_BLOCK * 2, 1));
-        if (im.W == 1) hipLaunchKernelGGL((k_branching_kh<1, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
-        else hipLaunchKernelGGL((k_branching_kh<2, true>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
-    } else {
-        const dim3 grid(kh_grid(n, BFT_KH_BLOCK, 4));
-        if (im.W == 1) hipLaunchKernelGGL((k_branching_kh<1, false>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, 1u);
-        else hipLaunchKernelGGL((k_branching_kh<2, false>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, 1u);
-    }
+    chunk = std::max(1u, std::min(chunk, BFT_KH_BR_MAX_CLAIM));
+    const dim3 grid = kh_round_grid(n, chunk, 1, d_ctr != nullptr);
+    if (im.W == 1) hipLaunchKernelGGL(k_branching_kh<1>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
+    else hipLaunchKernelGGL(k_branching_kh<2>, grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk);
     HIPCK(hipGetLastError());
     return 0;
 }
 
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
-               uint32_t n_seqs, int canonical, uint32_t* d_csout, hipStream_t s) {
+               uint32_t n_seqs, int canonical, uint32_t* d_csout, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
     const dim3 grid(256 * 8), block(256);
-    if (im.W == 1) hipLaunchKernelGGL(k_seq_kh<1>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout);
-    else hipLaunchKernelGGL(k_seq_kh<2>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout);
+    chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
+    if (im.W == 1) hipLaunchKernelGGL(k_seq_kh<1>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout, d_ctr, chunk);
+    else hipLaunchKernelGGL(k_seq_kh<2>, grid, block, 0, s, im, d_codes, d_bad, d_seq_off, d_pos_off, d_tile_seq, n_seqs, canonical, d_csout, d_ctr, chunk);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -523,6 +523,27 @@ BFT_HD bool bft_root_range_ok(uint32_t a, uint32_t b, uint64_t v) {
     return cnt == 0;
 }
 
+// rq[r] (BFT_RQ_*, bft_image.h) of a root group [a, b): offsets of the first rows whose next two key bits are >= 1, 2, 3; 0 for a
+// special, empty or oversized range (the walk never consults those).
+template <int W>
+BFT_HD uint32_t bft_root_quartile_entry(const BftImage& im, uint32_t a_raw, uint32_t b_raw) {
+    const uint32_t a = a_raw, b = b_raw & ~BFT_RSTART_SPECIAL;
+    if ((a & BFT_RSTART_SPECIAL) || b <= a || b - a > 255u) return 0u;
+    uint32_t q = 0;
+    for (uint32_t j = 1; j < 4; j++) {
+        uint32_t lo = a, hi = b;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            uint64_t row[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) row[w] = im.tk[(uint64_t)mid * W + w];
+            if ((uint32_t)(bft_next36<W>(row, im.k, 0) >> 34) < j) lo = mid + 1; else hi = mid;
+        }
+        q |= (lo - a) << (8 * (j - 1));
+    }
+    return q;
+}
+
 // Two adjacent one-word rows of the table, first one at an even index: one 16-byte load.  Device buffers carry 256 bytes
 // of slack (bft_pool_alloc), so a pair that straddles the end of the table is still readable; the host copy is clamped.
 BFT_HD void bft_load_pair(const BftImage& im, uint64_t gi, uint64_t* a, uint64_t* b) {
@@ -601,20 +622,26 @@ BFT_HD bool bft_probe_block(const BftImage& im, uint64_t guess, const uint64_t* 
 
 // d = the level that owns the group (its rows differ only in the key bits below that level)
 // PROBE: 0 / 1 fixes the mode at compile time (k_query: the 4-row code needs fewer registers than the 8-row one), -1 reads
-// im.probe_big.
+// im.probe_big.  qbits: the rows [idx, idx+cnt) share the top 36 - qbits of the 36 key bits that follow level d (36: a whole suffix
+// group; 34: one quarter of a root group, BFT_RQ_*), so positions are interpolated on the low qbits of them.
 template <int W, int PROBE>
-BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit) {
-    uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W];
+BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt, uint32_t g, const uint64_t* t, int d, BftHit& hit, int qbits) {
+    uint64_t lo2 = idx, hi2 = idx + cnt, guess = idx + g, edge[W] = {};
     int dir = 0;
-    const bool big = PROBE < 0 ? im.probe_big != 0 : PROBE != 0;
+    const int mode = PROBE < 0 ? (int)im.probe_big : PROBE;
     constexpr int NS = 4, NB = W == 1 ? 8 : 4;  // one-word rows: 32-byte / 64-byte blocks; two-word rows: 64 bytes in both modes (+4 % over 32)
+    // (128-byte blocks -- 16 one-word rows, one fabric request in tools/microbench/gather.hip -- were measured in round 4: 10.3 ms against
+    // 8.1 with 64-byte blocks on the config-4 share, profiles/r04/probe_walk.jsonl: the walk pays for the registers and the bytes)
 #pragma unroll
     for (int step = 0; step < BFT_PROBE_STEPS; step++) {
-        if (big ? bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit) : bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit)) return;
+        bool over;
+        if (mode == 1) over = bft_probe_block<W, NB>(im, guess, t, &lo2, &hi2, edge, &dir, hit);
+        else over = bft_probe_block<W, NS>(im, guess, t, &lo2, &hi2, edge, &dir, hit);
+        if (over) return;
         uint64_t dist = 0;
-        if (big) {  // rows between the edge row and t, by the group's mean density
+        if (mode != 0) {  // rows between the edge row and t, by the group's mean density
             const uint64_t a = bft_next36<W>(t, im.k, d), b = bft_next36<W>(edge, im.k, d);
-            dist = ((a > b ? a - b : b - a) * cnt) >> 36;
+            dist = ((a > b ? a - b : b - a) * cnt) >> qbits;
         }
         if (dir < 0) guess = hi2 - lo2 > dist + 1 ? hi2 - 1 - dist : lo2;
         else guess = hi2 - lo2 > dist ? lo2 + dist : hi2 - 1;
@@ -632,12 +659,12 @@ BFT_HD_RARE void bft_group_probe(const BftImage& im, uint64_t idx, uint32_t cnt,
 // Search of the suffix group [idx, idx+cnt) of level d for t (src/presenceNode.c:1874-1915): interpolate on the next two
 // prefixes, then block probes (groups of >= BFT_WINDOW_PROBE rows of one or two words) or a galloping search.
 template <int W, int PROBE>
-BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit) {
-    const uint64_t next36 = bft_next36<W>(t, im.k, d);
-    const uint32_t g = (uint32_t)((next36 * cnt) >> 36);
+BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, const uint64_t* t, int d, BftHit& hit, int qbits = 36) {
+    const uint64_t next = bft_next36<W>(t, im.k, d) & ((1ull << qbits) - 1ull);
+    const uint32_t g = (uint32_t)((next * cnt) >> qbits);
 #if defined(BFT_WINDOW_PROBE) && BFT_WINDOW_PROBE
     if (W <= BFT_PROBE_MAX_W && cnt >= BFT_WINDOW_PROBE) {
-        bft_group_probe<W, PROBE>(im, idx, cnt, g, t, d, hit);
+        bft_group_probe<W, PROBE>(im, idx, cnt, g, t, d, hit, qbits);
         return;
     }
 #endif
@@ -696,7 +723,15 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
                 if (!(a & BFT_RSTART_SPECIAL)) {
                     const uint32_t b = pr.b & ~BFT_RSTART_SPECIAL;
                     if (BFT_DBG_STOP(im) >= 1 && BFT_DBG_STOP(im) <= 4) { hit.present = (int)(b & 1); return hit; }
-                    if (b != a) bft_group_search<W, PROBE>(im, a, b - a, t, 0, hit);
+                    if (b == a) return hit;
+                    if (im.rq != nullptr) {
+                        // the quarter of the group the k-mer's next two key bits select (BFT_RQ_*): exact bounds, interpolated on its own
+                        const uint32_t q = im.rq[r], seg = (uint32_t)(bft_next36<W>(t, im.k, 0) >> 34);
+                        const uint32_t s0 = seg ? BFT_RQ_OFF(q, seg) : 0u, s1 = seg < 3 ? BFT_RQ_OFF(q, seg + 1) : b - a;
+                        if (s1 > s0) bft_group_search<W, PROBE>(im, a + s0, s1 - s0, t, 0, hit, 34);
+                        return hit;
+                    }
+                    bft_group_search<W, PROBE>(im, a, b - a, t, 0, hit);
                     return hit;
                 }
                 if (ROOTMODE == 1) { hit.present = BFT_HIT_DEFERRED; return hit; }

@@ -143,11 +143,15 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
     hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
     hostlib.bft_hosttest_set_probe(h, 0)
     assert (bits8 == bits).all() and (rows8 == rows).all()
-    for rd in (1, 2):  # root level through the derived direct table (1) and through range + direct tables (2): same answers, same rows
+    # root level through the derived direct table (1), through range + direct tables (2), and with the quartile table that steers the
+    # search of a plain group (3; in every probe mode): same answers, same rows
+    for rd, mode in ((1, 0), (2, 0), (3, 0), (3, 1)):
         hostlib.bft_hosttest_root_direct(h, rd)
+        hostlib.bft_hosttest_set_probe(h, mode)
         hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         hostlib.bft_hosttest_root_direct(h, 0)
-        assert (bits8 == bits).all() and (rows8 == rows).all()
+        hostlib.bft_hosttest_set_probe(h, 0)
+        assert (bits8 == bits).all() and (rows8 == rows).all(), (rd, mode)
     # the k-mer hash (BFT_KH_*; the host fill stores the row as the value): the lookup the kernels run gives the walk's answers at
     # the default occupancy, at a sparse one and at 80 % (long runs of full lines)
     W = (2 * k + 63) // 64
