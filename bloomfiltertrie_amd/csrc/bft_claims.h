@@ -66,6 +66,12 @@ struct BftClaims {
         if (ctr && threadIdx.x == 0 && blk == start) claim(blk_end);
         if (++blk >= blk_end) take();
     }
+    // the same for kernels that answer `nb` blocks of a round at a time
+    __device__ __forceinline__ void advance_by(uint32_t nb) {
+        if (ctr && threadIdx.x == 0 && blk == start) claim(blk_end);
+        blk += nb;
+        if (blk >= blk_end) take();
+    }
     // after the loop: every workgroup has made its last claim once the last one gets here
     __device__ __forceinline__ void done() {
         if (ctr && threadIdx.x == 0 && atomicAdd(&ctr[1], 1u) == gridDim.x - 1u) {

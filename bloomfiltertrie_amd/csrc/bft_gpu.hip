@@ -261,12 +261,14 @@ struct bft_gpu {
     DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
     int opt_node_hash = 1;        // "node_hash": 1 = derived when the image has no k-mer hash (the walk then answers every query), 2 = always, 0 = never
     uint64_t nph_inserted = 0, nph_dropped = 0;
-    DevBuf d_kh;                  // derived: k-mer hash (BFT_KH_*, k_kh_insert), optional
-    uint64_t kh_lines = 0;
+    DevBuf d_kh, d_kreg;          // derived: k-mer hash and its region table (BFT_KH_*, bft_kh_build), optional
+    uint64_t kh_lines = 0;        // lines in use
+    BftKhGeometry kh_geo = {0, 0, 0, 0, 0};
     bool opt_kmer_hash = true;    // "kmer_hash"
+    bool opt_walk_hash = false;   // "walk_hash": presence / colour queries through the container walk, which looks plain root groups up in the table's regions
     bool opt_compact = false;     // "compact_table": the sorted table and the colour set per k-mer are dropped once the k-mer hash holds them (ensure_table)
     bool table_dropped = false;   // d_tk / d_tcol are not resident: the k-mer hash is the only copy
-    uint32_t opt_kh_load = 50;    // "kmer_hash_load": per cent of the table's slots in use
+    uint32_t opt_kh_load = 60;    // "kmer_hash_load": per cent of the slots of a region's home lines in use
     double kh_ms = 0;             // GPU time of the last fill
     hipStream_t stream2 = nullptr; // bft_gpu_build fills the k-mer hash here while the containers are assembled on `stream`
     int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
@@ -695,7 +697,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes + h->d_kreg.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -718,7 +720,10 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.child = h->d_child.as<uint64_t>();
     im.tk = h->d_tk.as<uint64_t>();
     im.kh = nullptr;    // (derive_kmer_hash)
+    im.kreg = nullptr;
     im.kh_lines = 0;
+    im.kh_S = im.kh_f = im.kh_wb = im.kh_rb = im.kh_cb = 0;
+    im.walk_kh = 0;
     im.tcol = h->d_tcol.as<uint32_t>();
     im.uck = h->d_uck.as<uint64_t>();
     im.ucrow = h->d_ucrow.as<uint32_t>();
@@ -832,7 +837,7 @@ static void derive_node_hash(bft_gpu* h) {
     h->im.nph_no_uc = 0;
     h->nph_inserted = h->nph_dropped = 0;
     const uint64_t n_nodes = h->idx_sizes[0] / sizeof(BftNode);
-    if (!h->opt_node_hash || (h->opt_node_hash == 1 && h->im.kh != nullptr) || n_nodes <= 1 || h->info[6] == 0) {
+    if (!h->opt_node_hash || (h->opt_node_hash == 1 && h->im.kh != nullptr && !h->opt_walk_hash) || n_nodes <= 1 || h->info[6] == 0) {
         h->d_nph.release();
         return;
     }
@@ -871,19 +876,21 @@ static void derive_node_hash(bft_gpu* h) {
     h->im.nph_no_uc = st[2] == 0 ? 1u : 0u;
 }
 
-// The fill of the k-mer hash for a table (tk, tcol) that is complete on the device, started on the handle's second stream: the build
-// assembles the containers on `stream` meanwhile.  The fill is bound by L2 misses and atomics and starves what runs beside it of
-// memory bandwidth and latency (k_prefix_flags over the whole table: 0.2 ms alone, 2.8 ms beside the fill; the root's single-workgroup
-// k_assign_cc: 0.8 -> 3.5 ms), so it starts behind those (`after`: an event of the assembly stream) and overlaps the chain of small
-// kernels and read-back counts that follows.  kh_finish waits for it.  Any failure just leaves the image without the table.
+// The build of the k-mer hash for a table (tk, tcol) that is complete on the device, started on the handle's second stream: the build
+// assembles the containers on `stream` meanwhile.  The build sorts and gathers and starves what runs beside it of memory bandwidth and
+// latency (k_prefix_flags over the whole table: 0.2 ms alone, 2.8 ms beside it; the root's single-workgroup k_assign_cc: 0.8 -> 3.5 ms),
+// so it starts behind those (`after`: an event of the assembly stream) and overlaps the chain of small kernels and read-back counts that
+// follows.  kh_finish waits for it.  Any failure just leaves the image without the table.
 struct KhFill {
-    DevBuf buf;
-    uint64_t lines = 0;
+    DevBuf buf, kreg, status;
+    BftKhScratch scratch;
+    BftKhGeometry geo = {0, 0, 0, 0, 0};
+    uint64_t lines_cap = 0, lines_used = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, ew = nullptr;
     hipStream_t s2 = nullptr;
     bool started = false, prepared = false;
     std::thread prep;  // kh_prepare_async
-    ~KhFill() {  // (a build that fails half-way: the fill must be over before its buffer goes back to the cache)
+    ~KhFill() {  // (a build that fails half-way: the fill must be over before its buffers go back to the cache)
         if (prep.joinable()) prep.join();
         if (started && s2) (void)hipStreamSynchronize(s2);
         if (e0) (void)hipEventDestroy(e0);
@@ -891,92 +898,124 @@ struct KhFill {
         if (ew) (void)hipEventDestroy(ew);
     }
 };
-// the host side of the fill that needs no table yet: the second stream, the table's memory, the events (a millisecond of driver
-// calls for a gigabyte table that is not in the cache)
-static void kh_prepare(bft_gpu* h, uint64_t nk, KhFill& f) {
+static bool kh_wanted(const bft_gpu* h, uint64_t nk) { return h->opt_kmer_hash && nk > 0 && nk < (1ull << 31); }
+// the host side of the build that needs no table yet: the second stream, the table's memory, the events (a millisecond of driver
+// calls for a gigabyte table that is not in the cache).  n_values: the colour sets of the index, or -- before they are known -- a bound
+// (sets <= k-mers): fewer slots per line at worst, i.e. a table allocated larger than needed, never smaller.
+static void kh_prepare(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill& f) {
     f.prepared = false;
-    if (!h->opt_kmer_hash || !bft_kh_usable(h->k, h->W) || nk == 0) return;
+    if (!kh_wanted(h, nk)) return;
     if (!h->stream2) {
         int lo = 0, hi = 0;  // (numerically larger = lower priority)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
         if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); return; }
     }
-    f.lines = bft_kh_lines_for(nk, h->W, h->opt_kh_load);
-    if (f.buf.alloc(f.lines * BFT_KH_LINE_WORDS * 8) != 0) return;
+    f.geo = bft_kh_geometry(h->k, std::max<uint64_t>(1, n_values));
+    if (!bft_kh_has_kernels(h->W, f.geo.S)) return;
+    f.lines_cap = bft_kh_lines_bound(nk, f.geo.S, h->opt_kh_load);
+    if (f.lines_cap > BFT_KREG_LINE_MASK) return;
+    if (f.buf.alloc(f.lines_cap * BFT_KH_LINE_WORDS * 8) != 0 || f.kreg.alloc((BFT_KH_REGIONS + 2) * 4) != 0 || f.status.alloc(8) != 0) return;
     f.prepared = (f.e0 || hipEventCreate(&f.e0) == hipSuccess) && (f.e1 || hipEventCreate(&f.e1) == hipSuccess) &&
                  (f.ew || hipEventCreateWithFlags(&f.ew, hipEventDisableTiming) == hipSuccess);
     if (!f.prepared) { (void)hipGetLastError(); f.buf.release(); }
 }
 // ... on a thread of its own while the build's stream is busy with the colour sets
-static void kh_prepare_async(bft_gpu* h, uint64_t nk, KhFill& f) {
+static void kh_prepare_async(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill& f) {
     KhFill* fp = &f;
     try {
-        f.prep = std::thread([h, nk, fp] {
+        f.prep = std::thread([h, nk, n_values, fp] {
             if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
             bft_pool_set_stream(h->device, h->stream);
-            kh_prepare(h, nk, *fp);
+            kh_prepare(h, nk, n_values, *fp);
         });
     } catch (...) {  // (no thread to be had: kh_start prepares on the caller's)
     }
 }
-static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, KhFill& f, hipStream_t after = nullptr) {
+// run: the stream the build is enqueued on (the handle's second stream behind `after`, or the handle's own)
+static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, uint64_t n_sets, KhFill& f, hipStream_t after, hipStream_t run) {
     if (f.prep.joinable()) f.prep.join();
-    if (!f.prepared || f.lines != bft_kh_lines_for(nk, h->W, h->opt_kh_load)) kh_prepare(h, nk, f);
-    if (!f.prepared) return;
-    const size_t bytes = f.lines * BFT_KH_LINE_WORDS * 8;
+    const BftKhGeometry geo = bft_kh_geometry(h->k, std::max<uint64_t>(1, n_sets));
+    // (prepared with a bound on the colour sets: keep the block unless the real geometry needs a tenth less)
+    const uint64_t need = kh_wanted(h, nk) && bft_kh_has_kernels(h->W, geo.S) ? bft_kh_lines_bound(nk, geo.S, h->opt_kh_load) : 0;
+    if (!f.prepared || f.lines_cap < need || f.lines_cap > need + need / 10) kh_prepare(h, nk, n_sets, f);
+    if (!f.prepared || need == 0) return;
+    f.geo = geo;
+    if (!run) run = h->stream2;
     bool ok = true;
-    if (after) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(h->stream2, f.ew, 0) == hipSuccess;
-    ok = ok && hipEventRecord(f.e0, h->stream2) == hipSuccess &&
-              hipMemsetAsync(f.buf.p, 0xFF, bytes, h->stream2) == hipSuccess &&
-              bft_kh_fill(d_tk, d_tcol, nk, h->W, f.buf.as<uint64_t>(), f.lines, h->stream2) == 0 && hipEventRecord(f.e1, h->stream2) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(h->stream2); f.buf.release(); return; }
-    f.s2 = h->stream2;
-    f.started = true;
+    if (after && after != run) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(run, f.ew, 0) == hipSuccess;
+    ok = ok && hipEventRecord(f.e0, run) == hipSuccess &&
+         bft_kh_build(d_tk, d_tcol, nk, h->k, h->W, f.geo, h->opt_kh_load, f.buf.as<uint64_t>(), f.lines_cap, f.kreg.as<uint32_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 &&
+         hipEventRecord(f.e1, run) == hipSuccess;
+    f.s2 = run;
+    f.started = true;  // (whatever was enqueued is waited for before the buffers go anywhere)
+    if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(run); f.started = false; f.buf.release(); }
 }
 static bool kh_finish(bft_gpu* h, KhFill& f, double* ms) {
-    bool ok = f.started && hipStreamSynchronize(h->stream2) == hipSuccess;
+    bool ok = f.started && hipStreamSynchronize(f.s2) == hipSuccess;
     f.started = false;
     float t = 0;
     if (ok && hipEventElapsedTime(&t, f.e0, f.e1) == hipSuccess && ms) *ms = t;
     if (f.e0) (void)hipEventDestroy(f.e0);
     if (f.e1) (void)hipEventDestroy(f.e1);
     f.e0 = f.e1 = nullptr;
-    if (!ok) { (void)hipGetLastError(); f.buf.release(); }
+    uint32_t st[2] = {1, 0};
+    if (ok) ok = hipMemcpy(st, f.status.p, 8, hipMemcpyDeviceToHost) == hipSuccess && st[0] == 0;
+    for (DevBuf& b : f.scratch.b) b.release();
+    f.lines_used = st[1];
+    if (!ok) { (void)hipGetLastError(); f.buf.release(); f.kreg.release(); }
+    if (ok && getenv("BFT_GPU_VERBOSE"))
+        fprintf(stderr, "[bft_gpu] k-mer hash: %llu lines in use of %llu, %u slots (%u-bit header fields, %u-byte bodies: %u key + %u value bits), %.2f ms\n",
+                (unsigned long long)f.lines_used, (unsigned long long)f.lines_cap, f.geo.S, f.geo.f, f.geo.wb, f.geo.rb, f.geo.cb, t);
     return ok;
 }
-
-// Derives the k-mer hash of the image h->im points at (BFT_KH_*).  An accelerator only: without it every query walks the containers.
-static void derive_kmer_hash(bft_gpu* h) {
-    h->im.kh = nullptr;
-    h->im.kh_lines = 0;
+// the table of a finished build becomes the image's
+static void kh_adopt(bft_gpu* h, KhFill& f, double ms) {
+    h->d_kh.swap(f.buf);
+    h->d_kreg.swap(f.kreg);
+    h->kh_lines = f.lines_used;
+    h->kh_geo = f.geo;
+    h->kh_ms = ms;
+    h->im.kh = h->d_kh.as<uint64_t>();
+    h->im.kreg = h->d_kreg.as<uint32_t>();
+    h->im.kh_lines = f.lines_used;
+    h->im.kh_S = f.geo.S; h->im.kh_f = f.geo.f; h->im.kh_wb = f.geo.wb; h->im.kh_rb = f.geo.rb; h->im.kh_cb = f.geo.cb;
+}
+static void kh_drop(bft_gpu* h) {
+    h->d_kh.release();
+    h->d_kreg.release();
     h->kh_lines = 0;
     h->kh_ms = 0;
-    if (!h->opt_kmer_hash || !bft_kh_usable(h->k, h->W) || h->n_kmers == 0) {
-        h->d_kh.release();
-        return;
-    }
-    const uint64_t lines = bft_kh_lines_for(h->n_kmers, h->W, h->opt_kh_load);
-    const size_t bytes = lines * BFT_KH_LINE_WORDS * 8;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = h->d_kh.alloc(bytes) == 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess &&
-              hipMemsetAsync(h->d_kh.p, 0xFF, bytes, h->stream) == hipSuccess;
-    if (ok) {
-        ok = bft_kh_fill(h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->W, h->d_kh.as<uint64_t>(), lines, h->stream) == 0 &&
-             hipEventRecord(e1, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
-        float ms = 0;
-        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) h->kh_ms = ms;
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (!ok) {
-        (void)hipGetLastError();
-        h->d_kh.release();
-        return;
-    }
-    if (getenv("BFT_GPU_VERBOSE")) fprintf(stderr, "[bft_gpu] k-mer hash: %llu lines at %p (%zu bytes in a block of %zu)\n", (unsigned long long)lines, h->d_kh.p, bytes, h->d_kh.cap);
-    h->kh_lines = lines;
-    h->im.kh = h->d_kh.as<uint64_t>();
-    h->im.kh_lines = lines;
+    h->im.kh = nullptr;
+    h->im.kreg = nullptr;
+    h->im.kh_lines = 0;
+    h->im.walk_kh = 0;
+}
+
+// Derives the k-mer hash of the image h->im points at (BFT_KH_*), on the handle's own stream.  An accelerator only: without it every
+// query walks the containers.
+static void derive_kmer_hash(bft_gpu* h) {
+    kh_drop(h);
+    if (!kh_wanted(h, h->n_kmers)) return;
+    KhFill f;
+    kh_start(h, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->n_sets, f, nullptr, h->stream);
+    double ms = 0;
+    if (kh_finish(h, f, &ms)) kh_adopt(h, f, ms);
+}
+
+// The walk's view of the region table: bit 31 of kreg[r] = "r is not a plain suffix group of the root" (what bit 31 of rstart[r] says),
+// and whether the walk may use the table at all (it needs the range table's verdict on every prefix).
+__global__ void k_kreg_flags(const uint32_t* __restrict__ rstart, uint32_t* __restrict__ kreg) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= BFT_KH_REGIONS) return;
+    const uint32_t v = kreg[r] & ~BFT_KREG_SPECIAL;
+    kreg[r] = (rstart[r] & BFT_RSTART_SPECIAL) ? (v | BFT_KREG_SPECIAL) : v;
+}
+static void sync_kreg_flags(bft_gpu* h) {
+    h->im.walk_kh = 0;
+    if (!h->im.kh || !h->rstart_ok) return;
+    hipLaunchKernelGGL(k_kreg_flags, dim3(BFT_KH_REGIONS / 256), dim3(256), 0, h->stream, h->d_rstart.as<uint32_t>(), h->d_kreg.as<uint32_t>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    h->im.walk_kh = 1;
 }
 
 // "compact_table": the k-mer hash holds every (k-mer, colour set) of the index, so the sorted table tk and tcol -- 12 of the image's
@@ -987,7 +1026,7 @@ __global__ void k_rows_from_words(const uint64_t* __restrict__ words, uint64_t n
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         for (int w = 0; w < W; w++) rows[i * W + w] = words[(uint64_t)w * n + i];
 }
-static bool compact_possible(const bft_gpu* h) { return h->W <= 2 && h->im.kh != nullptr && h->n_kmers > 0; }
+static bool compact_possible(const bft_gpu* h) { return h->im.kh != nullptr && h->n_kmers > 0; }
 static void drop_table(bft_gpu* h) {
     if (!h->opt_compact || h->table_dropped || !compact_possible(h)) return;
     h->d_tk.release();
@@ -1008,7 +1047,7 @@ static int ensure_table(bft_gpu* h) {
     CK(tk.alloc(n * W * 8));
     CK(tcol.alloc(n * 4));
     CK(cnt.alloc_zero(8, h->stream));
-    CK(bft_kh_dump(h->d_kh.as<uint64_t>(), h->kh_lines, W, keys.as<uint64_t>(), n, vals.as<uint32_t>(), cnt.as<unsigned long long>(), h->stream));
+    CK(bft_kh_dump(h->im, keys.as<uint64_t>(), n, vals.as<uint32_t>(), cnt.as<unsigned long long>(), h->stream));
     unsigned long long got = 0;
     HIPCK(hipMemcpyAsync(&got, cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
@@ -1121,6 +1160,7 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     point_image(h, nb_genomes);
     derive_root_direct(h);
     derive_kmer_hash(h);
+    sync_kreg_flags(h);
     derive_node_hash(h);
     default_launch_shape(h);
     return 0;
@@ -1431,7 +1471,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
     KhFill khf;  // the k-mer hash, filled beside the container assembly
-    if (!(h->built && h->n_kmers > 0) && nk > 0) kh_prepare_async(h, nk, khf);  // (a merge changes the number of k-mers: kh_start prepares)
+    if (!(h->built && h->n_kmers > 0) && nk > 0) kh_prepare_async(h, nk, nk, khf);  // (a merge changes the number of k-mers: kh_start prepares)
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
     bft_trace_mark("colour sets interned");
     seg_off.release();
@@ -1456,10 +1496,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(bft_count_pairs(n_tcol.as<uint32_t>(), nk, n_cs_off.as<uint32_t>(), h->stream, &total_pairs));
     }
     np = total_pairs;
-    struct KhStart {  // (from here on tk and n_tcol are final)
-        bft_gpu* h; const uint64_t* tk; const uint32_t* tcol; uint64_t nk; KhFill* f;
-        static void run(void* c, hipStream_t s) { KhStart* k = (KhStart*)c; kh_start(k->h, k->tk, k->tcol, k->nk, *k->f, s); }
-    } khs{h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, &khf};
+    struct KhStart {  // (from here on tk, n_tcol and the number of colour sets are final)
+        bft_gpu* h; const uint64_t* tk; const uint32_t* tcol; uint64_t nk, n_sets; KhFill* f;
+        static void run(void* c, hipStream_t s) { KhStart* k = (KhStart*)c; kh_start(k->h, k->tk, k->tcol, k->nk, k->n_sets, *k->f, s, nullptr); }
+    } khs{h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, n_sets, &khf};
     const BftAssembleHook hook{tk.p ? &KhStart::run : nullptr, &khs};
     bft_trace_mark("merge / bookkeeping");
     double t2 = now_ms();
@@ -1551,17 +1591,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     ensure_claim_counters(h);
     bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
-    if (kh_ok) {  // filled during the assembly
-        h->d_kh.swap(khf.buf);
-        h->kh_lines = khf.lines;
-        h->kh_ms = kh_ms;
-        h->im.kh = h->d_kh.as<uint64_t>();
-        h->im.kh_lines = khf.lines;
-    } else {
-        h->d_kh.release();
-        h->kh_lines = 0;
-        h->kh_ms = 0;
-    }
+    if (kh_ok) kh_adopt(h, khf, kh_ms);  // built during the assembly
+    else kh_drop(h);
+    sync_kreg_flags(h);
     bft_trace_mark("root tables");
     derive_node_hash(h);
     default_launch_shape(h);
@@ -1701,9 +1733,15 @@ static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint6
 static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
-    if (h->im.kh != nullptr && (d_rows == nullptr || h->im.emit_cs)) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    const bool no_rows = d_rows == nullptr || h->im.emit_cs;  // presence or colour sets: what the k-mer hash holds
+    if (h->im.kh != nullptr && no_rows && !h->opt_walk_hash) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
     CK(ensure_table(h));
-    return launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    // the walk may look plain root groups up in their regions of the k-mer hash when no row is asked for
+    const uint32_t keep = h->im.walk_kh;
+    if (!no_rows || !h->opt_walk_hash) h->im.walk_kh = 0;
+    const int rc = launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    h->im.walk_kh = keep;
+    return rc;
 }
 
 // Synthetic batch for tune_residency: k-mers of the index itself (pseudo-random rows of tk), every other one with a
@@ -2156,7 +2194,7 @@ static int launch_seq_walk_k(bft_gpu* h, uint32_t ns, int canonical, const uint6
 template <int W>
 static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    if (W <= 2 && h->im.kh != nullptr) {
+    if (h->im.kh != nullptr) {
         return bft_kh_seq(h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical,
                           h->sq_cs.as<uint32_t>(), claim_counters(h, s, h->opt_query_dynamic_min), h->opt_query_chunk, s);
     }
@@ -2472,11 +2510,12 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
     CK(ensure_built(h));
-    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol"};
-    const DevBuf* bufs[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
-                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol};
-    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8, h->kh_lines * BFT_KH_LINE_WORDS * 8, h->n_kmers * 4};
-    for (int i = 0; i < 14; i++)
+    static const char* names[15] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol", "kreg"};
+    const DevBuf* bufs[15] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
+                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol, &h->d_kreg};
+    const uint64_t derived[6] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8, h->kh_lines * BFT_KH_LINE_WORDS * 8, h->n_kmers * 4,
+                                 h->im.kh ? (uint64_t)(BFT_KH_REGIONS + 1) * 4 : 0ull};
+    for (int i = 0; i < 15; i++)
         if (std::string(name) == names[i]) {
             const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
             if (nbytes) *nbytes = sz;
@@ -2523,7 +2562,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             derive_node_hash(h);
             h->info[12] = image_bytes(h);
         }
-    } else if (nm == "kmer_hash" || nm == "kmer_hash_load") {  // the k-mer hash: on / off, and its occupancy in per cent
+    } else if (nm == "kmer_hash" || nm == "kmer_hash_load") {  // the k-mer hash: on / off, and the occupancy of its home lines in per cent
         if (nm == "kmer_hash_load") {
             if (value < 10 || value > 80) return fail(BFT_GPU_E_ARG, "kmer_hash_load must be in [10, 80] (per cent)");
             h->opt_kh_load = (uint32_t)value;
@@ -2535,9 +2574,19 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));
             derive_kmer_hash(h);
-            derive_node_hash(h);  // (by default the node prefix hash exists exactly when the k-mer hash does not)
+            sync_kreg_flags(h);
+            derive_node_hash(h);  // (by default the node prefix hash exists exactly when the container walk answers queries)
             h->info[12] = image_bytes(h);
             drop_table(h);
+        }
+    } else if (nm == "walk_hash") {  // 1: presence / colour queries through the container walk, plain root groups looked up in their regions of the k-mer hash
+        h->opt_walk_hash = value != 0;
+        if (h->built) {
+            ENTER(h);
+            CK(wait_foreign_stream(h));
+            HIPCK(hipStreamSynchronize(h->stream));
+            derive_node_hash(h);
+            h->info[12] = image_bytes(h);
         }
     } else if (nm == "compact_table") {  // 1: the sorted k-mer table and the colour set per k-mer do not stay resident beside the k-mer hash (ensure_table)
         h->opt_compact = value != 0;
@@ -2557,6 +2606,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));  // ("compact_table": k_root_ranges reads the sorted table)
             derive_root_direct(h);
+            sync_kreg_flags(h);
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
             drop_table(h);
@@ -2569,6 +2619,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));
             derive_root_direct(h);
+            sync_kreg_flags(h);
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
             drop_table(h);
@@ -2633,7 +2684,7 @@ extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
     if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
                             h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
-                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes, h->d_cs_bm.bytes,
+                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes + h->d_kreg.bytes, h->d_cs_bm.bytes,
                             h->d_hashmod.bytes, 0ull, h->log_k.bytes + h->log_g.bytes};
     for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
     return BFT_GPU_OK;

@@ -12,13 +12,15 @@
 #include "bft_hash.h"
 #include "bft_index.h"
 #include "bft_walk.h"
+#include "bft_kh_host.h"
 
 struct HostTrie {
     int k, L, W, B;
     std::vector<uint32_t> hashmod;
     std::vector<uint64_t> tk;
     std::vector<uint32_t> tcol, cs_off, cs_ids;
-    std::vector<uint64_t> rdir, nph, kh;
+    std::vector<uint64_t> rdir, nph;
+    BftKhHostTable kh;
     std::vector<uint32_t> rstart, rq;
     uint64_t rstart_plain = 0;
     BftHostIndex idx;
@@ -94,30 +96,76 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
         const BftRootGlobal root(t->im);
         const BftHit h = bft_walk<W, BftRootGlobal, -1>(t->im, root, t->im.nodes[0], &tq[i * W]);
         if (h.present) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
-        if (rows) rows[i] = h.present ? (uint32_t)h.row : 0xFFFFFFFFu;
+        if (rows) rows[i] = h.present ? (h.from_kh ? h.cs : (uint32_t)h.row) : 0xFFFFFFFFu;  // (the host table's values are the rows)
     }
     return cnt;
 }
 
-// k-mer hash (BFT_KH_*): sequential fill with the value = the row of the k-mer (the GPU stores the colour set there), then the same
-// lookup the kernels run.  load_pct: occupancy in per cent (the product's "kmer_hash_load"); 0 = drop the table.
-// Returns the number of lines, 0 when k does not allow the table.
+// k-mer hash (BFT_KH_*): the sequential restatement of the canonical build (bft_kh_host.h) with the value = the row of the k-mer (the GPU
+// stores the colour set there), then the same lookup the kernels run.  load_pct: occupancy of the home lines in per cent (the product's
+// "kmer_hash_load"); 0 = drop the table.  Returns the number of lines in use.
 extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     HostTrie* t = (HostTrie*)hv;
     t->im.kh = nullptr;
+    t->im.kreg = nullptr;
     t->im.kh_lines = 0;
-    t->kh.clear();
+    t->kh = BftKhHostTable();
     const uint64_t n = t->tk.size() / t->W;
-    if (!load_pct || !bft_kh_usable(t->k, t->W) || n == 0) return 0;
-    const uint64_t lines = bft_kh_lines_for(n, t->W, load_pct);
-    t->kh.assign(lines * BFT_KH_LINE_WORDS, BFT_KH_EMPTY);
-    for (uint64_t i = 0; i < n; i++) {
-        if (t->W == 1) bft_kh_insert_seq<1>(t->kh.data(), lines, &t->tk[i], (uint32_t)i);
-        else bft_kh_insert_seq<2>(t->kh.data(), lines, &t->tk[i * 2], (uint32_t)i);
+    if (!load_pct || n == 0) return 0;
+    std::vector<uint32_t> rows(n);
+    for (uint64_t i = 0; i < n; i++) rows[i] = (uint32_t)i;
+    switch (t->W) {
+    case 1: bft_kh_build_host<1>(t->tk.data(), rows.data(), n, t->k, n, load_pct, t->kh); break;
+    case 2: bft_kh_build_host<2>(t->tk.data(), rows.data(), n, t->k, n, load_pct, t->kh); break;
+    case 3: bft_kh_build_host<3>(t->tk.data(), rows.data(), n, t->k, n, load_pct, t->kh); break;
+    default: bft_kh_build_host<4>(t->tk.data(), rows.data(), n, t->k, n, load_pct, t->kh); break;
     }
-    t->im.kh = t->kh.data();
-    t->im.kh_lines = lines;
-    return lines;
+    if (!t->kh.ok) return 0;
+    t->im.kh = t->kh.lines.data();
+    t->im.kreg = t->kh.kreg.data();
+    t->im.kh_lines = t->kh.lines.size() / BFT_KH_LINE_WORDS;
+    t->im.kh_S = t->kh.S; t->im.kh_f = t->kh.f; t->im.kh_wb = t->kh.wb; t->im.kh_rb = t->kh.rb; t->im.kh_cb = t->kh.cb;
+    return t->im.kh_lines;
+}
+// the walk looks plain root groups up in their regions of the table (BftImage::walk_kh; needs the table and the root range table):
+// returns 1 when switched on
+extern "C" int bft_hosttest_walk_kh(void* hv, int on) {
+    HostTrie* t = (HostTrie*)hv;
+    t->im.walk_kh = 0;
+    if (!on || !t->im.kh || !t->im.rstart) return 0;
+    for (uint32_t r = 0; r < BFT_KH_REGIONS; r++)
+        t->kh.kreg[r] = (t->kh.kreg[r] & ~BFT_KREG_SPECIAL) | ((t->rstart[r] & BFT_RSTART_SPECIAL) ? BFT_KREG_SPECIAL : 0u);
+    t->im.walk_kh = 1;
+    return 1;
+}
+// The sequential restatement on arrays handed in (tests compare the GPU-built table with it): tk = n sorted T-form rows, vals < n_values.
+// Returns the words of the table (8 per line); geo[0..4] as bft_hosttest_kh_geometry.  0 when the table cannot be built.
+extern "C" uint64_t bft_hosttest_kh_build(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, uint64_t n_values, uint32_t load_pct, uint64_t* lines_out,
+                                          uint64_t cap_words, uint32_t* kreg_out, uint32_t* geo) {
+    BftKhHostTable tab;
+    switch (bft_words_for_k(k)) {
+    case 1: bft_kh_build_host<1>(tk, vals, n, k, n_values, load_pct, tab); break;
+    case 2: bft_kh_build_host<2>(tk, vals, n, k, n_values, load_pct, tab); break;
+    case 3: bft_kh_build_host<3>(tk, vals, n, k, n_values, load_pct, tab); break;
+    default: bft_kh_build_host<4>(tk, vals, n, k, n_values, load_pct, tab); break;
+    }
+    if (geo) { geo[0] = tab.S; geo[1] = tab.f; geo[2] = tab.rb; geo[3] = tab.cb; geo[4] = tab.max_tail; geo[5] = tab.wb; }
+    if (!tab.ok || tab.lines.size() > cap_words) return 0;
+    memcpy(lines_out, tab.lines.data(), tab.lines.size() * 8);
+    memcpy(kreg_out, tab.kreg.data(), tab.kreg.size() * 4);
+    return tab.lines.size();
+}
+// geometry of the host table: out[0..5] = slots per line, bits of a header field, key bits, value bits, largest tail, bytes of a slot body
+extern "C" void bft_hosttest_kh_geometry(void* hv, uint32_t* out) {
+    HostTrie* t = (HostTrie*)hv;
+    out[0] = t->kh.S; out[1] = t->kh.f; out[2] = t->kh.rb; out[3] = t->kh.cb; out[4] = t->kh.max_tail; out[5] = t->kh.wb;
+}
+// raw copy of the host table (tests compare it with the GPU's: the layout is canonical)
+extern "C" uint64_t bft_hosttest_kh_arrays(void* hv, uint64_t* lines_out, uint64_t lines_cap_words, uint32_t* kreg_out) {
+    HostTrie* t = (HostTrie*)hv;
+    if (lines_out && lines_cap_words >= t->kh.lines.size()) memcpy(lines_out, t->kh.lines.data(), t->kh.lines.size() * 8);
+    if (kreg_out && !t->kh.kreg.empty()) memcpy(kreg_out, t->kh.kreg.data(), t->kh.kreg.size() * 4);
+    return t->kh.lines.size();
 }
 template <int W>
 static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
@@ -127,7 +175,7 @@ static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bi
     memset(bits, 0, (nq + 7) / 8);
     for (uint64_t i = 0; i < nq; i++) {
         uint32_t v = 0xFFFFFFFFu;
-        const bool hit = bft_kh_lookup<W>(t->im.kh, t->im.kh_lines, &tq[i * W], &v);
+        const bool hit = bft_kh_lookup<W, 0>(t->im, &tq[i * W], &v);
         if (hit) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
         if (vals) vals[i] = hit ? v : 0xFFFFFFFFu;
     }
@@ -136,30 +184,47 @@ static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bi
 extern "C" int64_t bft_hosttest_query_kh(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
     HostTrie* t = (HostTrie*)hv;
     if (!t->im.kh) return -1;
-    return (int64_t)(t->W == 1 ? query_kh<1>(t, q, nq, bits, vals) : query_kh<2>(t, q, nq, bits, vals));
+    switch (t->W) {
+    case 1: return (int64_t)query_kh<1>(t, q, nq, bits, vals);
+    case 2: return (int64_t)query_kh<2>(t, q, nq, bits, vals);
+    case 3: return (int64_t)query_kh<3>(t, q, nq, bits, vals);
+    default: return (int64_t)query_kh<4>(t, q, nq, bits, vals);
+    }
 }
 // mean lines read per lookup of the stored k-mers themselves, and the longest run (diagnostics of the table's occupancy)
-extern "C" double bft_hosttest_kh_probe_stats(void* hv, uint64_t* longest) {
-    HostTrie* t = (HostTrie*)hv;
-    if (!t->im.kh) return 0.0;
-    const uint64_t n = t->tk.size() / t->W, lines = t->im.kh_lines;
+template <int W>
+static double kh_probe_stats(HostTrie* t, uint64_t* longest) {
+    const uint64_t n = t->tk.size() / W;
     uint64_t total = 0, worst = 0;
     for (uint64_t i = 0; i < n; i++) {
-        const uint64_t* key = &t->tk[i * t->W];
-        uint64_t ln = t->W == 1 ? bft_kh_home<1>(key, lines) : bft_kh_home<2>(key, lines), steps = 1;
-        const uint32_t S = BFT_KH_SLOTS(t->W);
-        for (;; steps++) {
-            const uint64_t* line = t->kh.data() + ln * BFT_KH_LINE_WORDS;
-            bool hit = false;
-            for (uint32_t s = 0; s < S; s++) hit = hit || memcmp(line + s * t->W, key, t->W * 8) == 0;
-            if (hit) break;
-            ln = ln + 1 == lines ? 0 : ln + 1;
+        const uint64_t* key = &t->tk[i * W];
+        const BftKhRegion g = bft_kh_region(t->im.kreg, bft_digit<W>(key, t->k, 0));
+        uint64_t remle[W];
+        BftKhKey<W> kk;
+        bft_kh_rem<W>(key, t->k, remle);
+        bft_kh_key<W>(remle, t->im.kh_rb, t->im.kh_f, t->im.kh_cb, kk);
+        uint64_t ln = (uint64_t)g.first + bft_kh_home_of(bft_kh_hash<W>(remle), g.mh), steps = 1;
+        for (;; steps++, ln++) {
+            uint32_t v;
+            const uint64_t* line = t->im.kh + ln * BFT_KH_LINE_WORDS;
+            if (bft_kh_scan<W, 0>(t->im, line, line, kk, &v) > 0) break;
+            if (steps > g.lines) { steps = ~0ull >> 1; break; }  // (a stored k-mer the lookup cannot find: the caller's bound fails)
         }
         total += steps;
         worst = std::max(worst, steps);
     }
     if (longest) *longest = worst;
     return n ? (double)total / (double)n : 0.0;
+}
+extern "C" double bft_hosttest_kh_probe_stats(void* hv, uint64_t* longest) {
+    HostTrie* t = (HostTrie*)hv;
+    if (!t->im.kh) return 0.0;
+    switch (t->W) {
+    case 1: return kh_probe_stats<1>(t, longest);
+    case 2: return kh_probe_stats<2>(t, longest);
+    case 3: return kh_probe_stats<3>(t, longest);
+    default: return kh_probe_stats<4>(t, longest);
+    }
 }
 
 // node prefix hash (BFT_NPH_*): the enumeration of k_nph_fill, sequential; on / off.  tiny != 0 sizes the table far too small so
@@ -315,7 +380,8 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     else if (nm == "uck") { p = t->idx.uck.data(); n = t->idx.uck.size() * 8; }
     else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }
     else if (nm == "tk") { p = t->tk.data(); n = t->tk.size() * 8; }
-    else if (nm == "kh") { p = t->kh.data(); n = t->kh.size() * 8; }
+    else if (nm == "kh") { p = t->kh.lines.data(); n = t->kh.lines.size() * 8; }
+    else if (nm == "kreg") { p = t->kh.kreg.data(); n = t->kh.kreg.size() * 4; }
     else return -1;
     if (nbytes) *nbytes = n;
     if (out) { if (cap < n) return -6; memcpy(out, p, n); }

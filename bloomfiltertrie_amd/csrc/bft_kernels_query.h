@@ -94,7 +94,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     uint64_t chunk = (uint64_t)blockIdx.x * WPW + wave;
     uint32_t next_claim = 0;
     volatile uint64_t* my_bits = s_bits[wave];
-    const bool with_queue = im.rstart != nullptr;
+    const bool with_queue = im.rstart != nullptr || im.walk_kh;
     // With the range table: every lane takes the short path (range table -> suffix group); a lane whose root prefix is "special"
     // (child Node, UC rows: the long container path) only parks its k-mer in its wavefront's queue in LDS, and the wavefront walks
     // the queue when it is full.  A wavefront is as slow as its slowest lane, and with ~5 % special prefixes (config 4) nearly

@@ -295,10 +295,12 @@ struct BftRootGlobal {
 
 struct BftHit {
     int present;
-    uint64_t row;      // row of the k-mer in tk (valid when present)
+    uint64_t row;      // row of the k-mer in tk (valid when present and !from_kh)
+    uint32_t cs;       // its colour set, when it was found in the k-mer hash (from_kh; im.walk_kh: no row is known then)
+    int from_kh;
 };
 // what a query kernel writes for a found k-mer: its row, or -- im.emit_cs, the colour-row and sequence paths -- its colour set
-BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) { return im.emit_cs ? im.tcol[h.row] : (uint32_t)h.row; }
+BFT_HD uint32_t bft_hit_out(const BftImage& im, const BftHit& h) { return im.emit_cs ? (h.from_kh ? h.cs : im.tcol[h.row]) : (uint32_t)h.row; }
 
 // genome id q of the colour-set dictionary (stored in the narrowest width that holds every id of the index)
 BFT_HD uint32_t bft_cs_id_at(const void* cs_ids, uint32_t cs_w, uint64_t q) {
@@ -308,88 +310,256 @@ BFT_HD uint32_t bft_cs_id_at(const void* cs_ids, uint32_t cs_w, uint64_t q) {
 }
 
 // ---- k-mer hash (bft_image.h, BFT_KH_*) ----
-BFT_HD bool bft_kh_usable(int k, int W) { return W <= 2 && (2 * k) % 64 != 0; }  // (the empty marker needs a key word that cannot be all ones)
+// geometry of the table of an index: key bits, value bits -> slots per line, bits of a header field, bytes of a slot body
+BFT_HD uint32_t bft_kh_rb(int k) { return (uint32_t)(2 * k - 18); }
+BFT_HD uint32_t bft_kh_value_bits(uint64_t n_values) {  // values 0 .. n_values - 1 are stored as 1 .. n_values
+    uint32_t b = 1;
+    while (b < 32 && (n_values >> b)) b++;
+    return b;
+}
+BFT_HD uint32_t bft_kh_field_bits(uint32_t S, uint32_t rb) {
+    uint32_t f = 128u / S - 1u;
+    if (f > 32u) f = 32u;
+    return f < rb ? f : rb;
+}
+BFT_HD uint32_t bft_kh_body_bytes(uint32_t S) { return 48u / S; }
+BFT_HD uint32_t bft_kh_slots_for(uint32_t rb, uint32_t cb) {
+    for (uint32_t s = BFT_KH_MAX_SLOTS; s > 1; s--)
+        if (cb + rb - bft_kh_field_bits(s, rb) <= 8u * bft_kh_body_bytes(s)) return s;
+    return 1u;
+}
+// home lines of a region of n k-mers at `load_pct` per cent occupancy of the home lines
+BFT_HD uint32_t bft_kh_home_lines(uint64_t n, uint32_t S, uint32_t load_pct) {
+    if (n == 0) return 0u;
+    const uint64_t per = (uint64_t)S * load_pct;
+    const uint64_t m = (n * 100ull + per - 1) / per;
+    return (uint32_t)(m < 1 ? 1 : m);
+}
+// The bits of a T-form k-mer below its root prefix, as W little-endian words (word 0 least significant).
 template <int W>
-BFT_HD uint64_t bft_kh_home(const uint64_t* t, uint64_t n_lines) {
-    uint64_t h = t[0];
+BFT_HD void bft_kh_rem(const uint64_t* t, int k, uint64_t* remle) {
 #pragma unroll
-    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + t[w];
+    for (int i = 0; i < W; i++) remle[i] = t[W - 1 - i];
+    const int tb0 = 2 * k - 64 * (W - 1);  // bits of the T-form in its top word t[0]
+    if (tb0 > 18) remle[W - 1] &= (1ull << (tb0 - 18)) - 1ull;
+    else {
+        remle[W - 1] = 0;
+        if (W > 1 && tb0 < 18) remle[W > 1 ? W - 2 : 0] &= (1ull << (64 - (18 - tb0))) - 1ull;
+    }
+}
+template <int W>
+BFT_HD uint64_t bft_kh_hash(const uint64_t* remle) {
+    uint64_t h = remle[0];
+#pragma unroll
+    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + remle[w];
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;  // 64-bit finalizer (murmur3)
+    return h;
+}
+// the code (0..3) of the smallest allowed tail >= need, 4 when there is none
+BFT_HD uint32_t bft_kh_tail_code(uint64_t need) { return need <= 1 ? 0u : (need <= 2 ? 1u : (need <= 4 ? 2u : (need <= 32 ? 3u : 4u))); }
+BFT_HD uint32_t bft_kh_home_of(uint64_t hash, uint32_t mh) { return (uint32_t)(((hash >> 32) * (uint64_t)mh) >> 32); }
+// A k-mer as its slot sees it: `field` = the low f key bits (what the line's header holds), `body` = the other key bits at [cb, cb + rb - f)
+// of the slot's body, W words, with the value + 1 to be OR-ed into bits [0, cb); `bmask` = the mask of those key bits.
+template <int W>
+struct BftKhKey {
+    uint64_t field, body[W], bmask[W];
+};
+template <int W>
+BFT_HD void bft_kh_key(const uint64_t* remle, uint32_t rb, uint32_t f, uint32_t cb, BftKhKey<W>& key) {
+    key.field = f ? remle[0] & ((f < 64 ? 1ull << f : 0ull) - 1ull) : 0ull;
+    // hi = remle >> f (rb - f bits), then body = hi << cb
+    uint64_t hi[W], m[W];
+    const uint32_t hb = rb - f;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        hi[i] = f ? (remle[i] >> f) | (i + 1 < W ? remle[i + 1] << (64 - f) : 0ull) : remle[i];
+        const int lo = 64 * i;
+        m[i] = (int)hb >= lo + 64 ? ~0ull : ((int)hb > lo ? (1ull << (hb - lo)) - 1ull : 0ull);
+        hi[i] &= m[i];
+    }
+    key.body[0] = hi[0] << cb;
+    key.bmask[0] = m[0] << cb;
+#pragma unroll
+    for (int i = 1; i < W; i++) {
+        key.body[i] = (hi[i] << cb) | (hi[i - 1] >> (64 - cb));
+        key.bmask[i] = (m[i] << cb) | (m[i - 1] >> (64 - cb));
+    }
+}
+// 64 bits of a multiword little-endian bit string from bit `o` on (zeros beyond its NW words)
+template <int NW>
+BFT_HD uint64_t bft_kh_bits_at(const uint64_t* ln, uint32_t o) {
+    const uint32_t wi = o >> 6, sh = o & 63u;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {  // (selects, not a dynamic index: the words stay in registers)
+        if ((uint32_t)i == wi) lo = ln[i];
+        if ((uint32_t)i == wi + 1) hi = ln[i];
+    }
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+// The region of root prefix r: first line, lines, home lines.  (kreg[r] and kreg[r + 1] in ONE 8-byte load, 4-byte aligned.)
+struct BftKhRegion { uint32_t first, lines, mh, special; };
+BFT_HD BftKhRegion bft_kh_region(const uint32_t* kreg, uint32_t r) {
+    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+    const Pair pr = *reinterpret_cast<const Pair*>(kreg + r);
+    BftKhRegion g;
+    g.first = pr.a & BFT_KREG_LINE_MASK;
+    g.lines = (pr.b & BFT_KREG_LINE_MASK) - g.first;
+    g.mh = g.lines - BFT_KH_TAIL_OF((pr.a >> BFT_KREG_TAIL_SHIFT) & 3u);
+    g.special = pr.a & BFT_KREG_SPECIAL;
+    return g;
+}
+// the header of a line (two words): one 16-byte load
+BFT_HD void bft_kh_load_header(const uint64_t* line, uint64_t* hd) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(h, n_lines);
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(line);
+    hd[0] = v.x;
+    hd[1] = v.y;
 #else
-    return (uint64_t)(((unsigned __int128)h * n_lines) >> 64);
+    hd[0] = line[0];
+    hd[1] = line[1];
 #endif
 }
-// lines of the table of an index of n k-mers at `load_pct` per cent occupancy (default 50: two slots per k-mer)
-BFT_HD uint64_t bft_kh_lines_for(uint64_t n, int W, uint32_t load_pct) {
-    const uint64_t per_line = (uint64_t)BFT_KH_SLOTS(W) * load_pct;  // k-mers per line x 100
-    const uint64_t lines = (n * 100ull + per_line - 1) / per_line;
-    return lines < 4 ? 4 : lines + 1;
-}
-// One line into registers: the keys with 16-byte loads (the line is 64-byte aligned), nothing else -- the value is read only on a hit.
+// The body of slot s (W words, zero-extended): byte offset 16 + s wb of the line, wb bytes.  One load instruction per 16 bytes, at the
+// body's byte address; a load that would run past the line's end starts earlier and is shifted (the table's last line is followed by
+// the allocation's slack, but a load never leaves its own 64 bytes).
 template <int W>
-BFT_HD void bft_kh_load_keys(const uint64_t* line, uint64_t (*key)[W]) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
+BFT_HD void bft_kh_load_body(const uint64_t* line, uint32_t s, uint32_t wb, uint64_t* body) {
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(line) + 16u + s * wb;
+#pragma unroll
+    for (int i = 0; i < W; i++) body[i] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (W == 1) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(line), b = *reinterpret_cast<const ulonglong2*>(line + 2);
-        key[0][0] = a.x; key[1][0] = a.y; key[2][0] = b.x; key[3][0] = b.y; key[4][0] = line[4];
-        return;
+    struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
+    struct __attribute__((packed, aligned(1))) U16 { uint64_t a, b; };
+    if (W == 1) {  // wb <= 8: eight bytes that end no later than the line
+        const uint32_t off = 16u + s * wb, back = off + 8u > 64u ? off + 8u - 64u : 0u;
+        const uint64_t v = reinterpret_cast<const U8*>(p - back)->v;
+        body[0] = v >> (8u * back);
+    } else {
+        const uint32_t off = 16u + s * wb;
+#pragma unroll
+        for (int i = 0; i < W; i += 2) {
+            if (8u * (uint32_t)i >= wb) break;
+            const uint32_t at = off + 8u * (uint32_t)i, back = at + 16u > 64u ? at + 16u - 64u : 0u;  // back < 16
+            const U16 v = *reinterpret_cast<const U16*>(p + 8 * i - back);
+            const uint64_t a = back >= 8u ? v.b : v.a, b2 = back >= 8u ? 0ull : v.b;
+            const uint32_t sh = 8u * (back & 7u);
+            const uint64_t lo = sh ? (a >> sh) | (b2 << (64 - sh)) : a, hi = sh ? b2 >> sh : b2;
+            body[i] = lo;
+            if (i + 1 < W) body[i + 1] = hi;
+        }
     }
+#else
+    for (uint32_t b = 0; b < wb && b < 8u * W; b++) body[b >> 3] |= (uint64_t)p[b] << (8 * (b & 7));
 #endif
+    if (wb < 8u * W) {  // (bytes behind the body belong to the next slot)
 #pragma unroll
-    for (uint32_t s = 0; s < S; s++) bft_load_row<W>(line + s * W, key[s]);
-}
-// Lookup: true when t is stored; value_at = where its value (the colour-set id) sits, as an index into the table seen as u32 words --
-// the caller reads it only if it wants it (a second load into the same line; a presence query that fetched it anyway made 1.71 L2
-// requests per k-mer instead of 1.25).  Lines from the home line on: the key, or a free slot, ends it.
-template <int W>
-BFT_HD bool bft_kh_find(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint64_t& value_at) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
-    uint64_t ln = bft_kh_home<W>(t, n_lines);
-    for (;;) {
-        const uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
-        uint64_t key[S][W];
-        bft_kh_load_keys<W>(line, key);
-        int at = -1;
-        bool free_slot = false;
-#pragma unroll
-        for (uint32_t s = 0; s < S; s++) {
-            if (bft_cmp<W>(key[s], t) == 0) at = (int)s;
-            free_slot = free_slot || key[s][0] == BFT_KH_EMPTY;
+        for (int i = 0; i < W; i++) {
+            const uint32_t lo = 8u * (uint32_t)i;
+            if (wb <= lo) body[i] = 0;
+            else if (wb < lo + 8u) body[i] &= (1ull << (8u * (wb - lo))) - 1ull;
         }
-        if (at >= 0) {
-            value_at = (ln * BFT_KH_LINE_WORDS + S * W) * 2 + (uint64_t)at;
-            return true;
-        }
-        if (free_slot) return false;  // t would have been put here
-        ln = ln + 1 == n_lines ? 0 : ln + 1;
     }
 }
-template <int W>
-BFT_HD bool bft_kh_lookup(const uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t* val) {
-    uint64_t at = 0;
-    if (!bft_kh_find<W>(kh, n_lines, t, at)) return false;
-    *val = reinterpret_cast<const uint32_t*>(kh)[at];
-    return true;
-}
-// Sequential insertion (the host restatement; the GPU kernel k_kh_insert claims slots with atomicCAS instead -- which slot of which
-// line a key lands in may then differ, what a lookup returns cannot).  The table must hold BFT_KH_EMPTY in every key word.
-template <int W>
-BFT_HD void bft_kh_insert_seq(uint64_t* kh, uint64_t n_lines, const uint64_t* t, uint32_t val) {
-    constexpr uint32_t S = BFT_KH_SLOTS(W);
-    uint64_t ln = bft_kh_home<W>(t, n_lines);
-    for (;;) {
-        uint64_t* line = kh + ln * BFT_KH_LINE_WORDS;
-        for (uint32_t s = 0; s < S; s++)
-            if (line[s * W] == BFT_KH_EMPTY) {
-                for (int w = 0; w < W; w++) line[s * W + w] = t[w];
-                reinterpret_cast<uint32_t*>(line + S * W)[s] = val;
-                return;
-            }
-        ln = ln + 1 == n_lines ? 0 : ln + 1;
+// One line against one k-mer: 1 = found (*val = its value), 0 = not here and the line has a free slot (absent), -1 = not here, line full.
+// The header (16 bytes: S fields of f bits -- the low key bits of the slots --, the S occupancy bits on top) says which slots can hold the
+// k-mer at all; only those slots' bodies are read: an absent k-mer costs one load instruction, a stored one two.
+// SS > 0: the slots per line as a compile-time constant (the kernels of bft_kh.hip); SS == 0: read from the image (the walk, the host).
+template <int W, int SS>
+BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t* hd, const BftKhKey<W>& key, uint32_t* val) {
+    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh_S, f = im.kh_f, wb = im.kh_wb, cb = im.kh_cb;
+    const uint64_t fmask = f ? (f < 64 ? 1ull << f : 0ull) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
+    const uint32_t occ = (uint32_t)(hd[1] >> (64u - S));  // bit s: slot s is in use
+    uint32_t cand = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < (SS > 0 ? (uint32_t)SS : BFT_KH_MAX_SLOTS); s++) {
+        if (SS == 0 && s >= S) break;
+        const uint64_t fld = f ? bft_kh_bits_at<2>(hd, s * f) & fmask : 0ull;
+        cand |= (fld == key.field ? 1u : 0u) << s;
     }
+    cand &= occ;
+    while (cand) {  // (a second candidate: two slots whose k-mers share their low f key bits -- once in thousands of lines)
+        const uint32_t s = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        uint64_t body[W];
+        bft_kh_load_body<W>(line, s, wb, body);
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
+        if (same) { *val = (uint32_t)(body[0] & vmask) - 1u; return 1; }
+    }
+    return occ != (1u << S) - 1u ? 0 : -1;
+}
+// Lookup of a T-form k-mer whose region is known: true when stored, *val = its value (the colour-set id).
+template <int W, int SS>
+BFT_HD bool bft_kh_find_in(const BftImage& im, const BftKhRegion& g, const uint64_t* t, uint32_t* val) {
+    if (g.lines == 0) return false;
+    uint64_t remle[W];
+    BftKhKey<W> key;
+    bft_kh_rem<W>(t, im.k, remle);
+    bft_kh_key<W>(remle, im.kh_rb, im.kh_f, im.kh_cb, key);
+    uint64_t ln_i = (uint64_t)g.first + bft_kh_home_of(bft_kh_hash<W>(remle), g.mh);
+    const uint64_t end = (uint64_t)g.first + g.lines;
+    for (; ln_i < end; ln_i++) {  // (a well-formed table ends the search before `end`: the last line of a region has a free slot)
+        const uint64_t* line = im.kh + ln_i * BFT_KH_LINE_WORDS;
+        uint64_t hd[2];
+        bft_kh_load_header(line, hd);
+        const int res = bft_kh_scan<W, SS>(im, line, hd, key, val);
+        if (res > 0) return true;
+        if (res == 0) return false;
+    }
+    return false;
+}
+template <int W, int SS>
+BFT_HD bool bft_kh_lookup(const BftImage& im, const uint64_t* t, uint32_t* val) {
+    const BftKhRegion g = bft_kh_region(im.kreg, bft_digit<W>(t, im.k, 0));
+    return bft_kh_find_in<W, SS>(im, g, t, val);
+}
+// What a k-mer adds to slot s of its line: the 8 line words to OR in (header field, occupancy bit, body).
+template <int W>
+BFT_HD void bft_kh_slot_image(const uint64_t* t, int k, uint32_t S, uint32_t rb, uint32_t f, uint32_t wb, uint32_t cb, uint32_t s, uint32_t val, uint64_t* img) {
+    uint64_t remle[W];
+    BftKhKey<W> key;
+    bft_kh_rem<W>(t, k, remle);
+    bft_kh_key<W>(remle, rb, f, cb, key);
+    key.body[0] |= (uint64_t)val + 1ull;
+#pragma unroll
+    for (uint32_t i = 0; i < BFT_KH_LINE_WORDS; i++) img[i] = 0;
+    // header: field at bits [s f, (s + 1) f), occupancy at bit 128 - S + s
+    const uint32_t fo = s * f;
+    if (f) {
+        img[fo >> 6] |= key.field << (fo & 63u);
+        if ((fo & 63u) + f > 64u) img[(fo >> 6) + 1] |= key.field >> (64u - (fo & 63u));
+    }
+    img[1] |= 1ull << (64u - S + s);
+    // body at byte 16 + s wb
+    const uint32_t bo = 128u + 8u * s * wb;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const uint32_t o = bo + 64u * (uint32_t)i, wi = o >> 6, sh = o & 63u;
+        if (wi < BFT_KH_LINE_WORDS) img[wi] |= key.body[i] << sh;
+        if (sh && wi + 1 < BFT_KH_LINE_WORDS) img[wi + 1] |= key.body[i] >> (64u - sh);
+    }
+}
+// A used slot back to its k-mer: the T-form bits below the root prefix (W little-endian words) and the value.
+template <int W>
+BFT_HD void bft_kh_slot_decode(const BftImage& im, const uint64_t* line, const uint64_t* hd, uint32_t s, uint64_t* remle, uint32_t* val) {
+    const uint32_t f = im.kh_f, cb = im.kh_cb, hb = im.kh_rb - f;
+    uint64_t body[W];
+    bft_kh_load_body<W>(line, s, im.kh_wb, body);
+    *val = (uint32_t)(body[0] & ((1ull << cb) - 1ull)) - 1u;
+    const uint64_t fld = f ? bft_kh_bits_at<2>(hd, s * f) & ((f < 64 ? 1ull << f : 0ull) - 1ull) : 0ull;
+    // hi = (body >> cb) masked to hb bits; rem = hi << f | field
+    uint64_t hi[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        hi[i] = (body[i] >> cb) | (i + 1 < W ? body[i + 1] << (64 - cb) : 0ull);
+        const int lo = 64 * i;
+        hi[i] &= (int)hb >= lo + 64 ? ~0ull : ((int)hb > lo ? (1ull << (hb - lo)) - 1ull : 0ull);
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) remle[i] = f ? (hi[i] << f) | (i > 0 ? hi[i - 1] >> (64 - f) : 0ull) : hi[i];
+    remle[0] |= fld;
 }
 
 // The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
@@ -685,6 +855,8 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
     BftHit hit;
     hit.present = 0;
     hit.row = 0;
+    hit.cs = 0;
+    hit.from_kh = 0;
     uint32_t node = 0;
     const int L = im.L, rb = 2 * (im.k - 9 * im.L);  // rb: bits of the k % 9 remainder (0 for reference-compatible k)
     for (int d = d0; d < L; d++) {
@@ -714,7 +886,18 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         if (d == 0 && im.rdir != nullptr) {
             // Root level through the derived tables (bft_image.h).  Plain suffix groups: two adjacent words of the 1 MiB range
             // table give {first row, count}.
-            if (ROOTMODE != 2 && im.rstart != nullptr) {
+            if (ROOTMODE != 2 && im.walk_kh) {
+                // A plain suffix group of the root in its hashed form: the group's region of the k-mer hash (bft_image.h, BFT_KH_*) holds
+                // its suffixes with their colour sets -- one line instead of the probes of the sorted rows (src/UC.c:81-124 finds the
+                // suffix by binary search; same answer).  Special prefixes (child Node, UC rows) keep the containers.
+                const BftKhRegion g = bft_kh_region(im.kreg, r);
+                if (!g.special) {
+                    uint32_t cs = 0;
+                    if (bft_kh_find_in<W, 0>(im, g, t, &cs)) { hit.present = 1; hit.cs = cs; hit.from_kh = 1; }
+                    return hit;
+                }
+                if (ROOTMODE == 1) { hit.present = BFT_HIT_DEFERRED; return hit; }
+            } else if (ROOTMODE != 2 && im.rstart != nullptr) {
                 // rstart[r] and rstart[r + 1] in ONE 8-byte load (4-byte aligned: the hardware takes unaligned dwordx2 loads); a
                 // gather costs per load instruction, and loading the second word only after testing the first would add a round trip
                 struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };

@@ -76,6 +76,10 @@ def hostlib(built):
     lib.bft_hosttest_kmer_hash.argtypes = [C.c_void_p, C.c_uint32]
     lib.bft_hosttest_query_kh.restype = C.c_int64
     lib.bft_hosttest_query_kh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_kh_geometry.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bft_hosttest_walk_kh.argtypes = [C.c_void_p, C.c_int]
+    lib.bft_hosttest_kh_arrays.restype = C.c_uint64
+    lib.bft_hosttest_kh_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.bft_hosttest_kh_probe_stats.restype = C.c_double
     lib.bft_hosttest_kh_probe_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_node_hash.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -152,21 +156,33 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
         hostlib.bft_hosttest_root_direct(h, 0)
         hostlib.bft_hosttest_set_probe(h, 0)
         assert (bits8 == bits).all() and (rows8 == rows).all(), (rd, mode)
-    # the k-mer hash (BFT_KH_*; the host fill stores the row as the value): the lookup the kernels run gives the walk's answers at
-    # the default occupancy, at a sparse one and at 80 % (long runs of full lines)
-    W = (2 * k + 63) // 64
-    for load in (50, 10, 80):
+    # the k-mer hash (BFT_KH_*; the host build stores the row as the value): the lookup the kernels run gives the walk's answers at the
+    # default occupancy, at a sparse one and at 80 % (runs of full lines), for every k (1 to 10 slots per line)
+    for load in (60, 10, 80):
         lines = hostlib.bft_hosttest_kmer_hash(h, load)
-        if W > 2 or (2 * k) % 64 == 0 or len(km) == 0:
+        if len(km) == 0:
             assert lines == 0 and hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data) == -1
             continue
+        geo = np.zeros(6, np.uint32)
+        hostlib.bft_hosttest_kh_geometry(h, geo.ctypes.data)
+        S_, f_, rb_, cb_, tail_, wb_ = (int(x) for x in geo)
         n_st = len(S.distinct(km))
-        assert lines >= -(-n_st * 100 // ((5 if W == 1 else 3) * load))
+        fits = lambda s_: cb_ + rb_ - min(32, 128 // s_ - 1, rb_) <= 8 * (48 // s_)
+        assert rb_ == 2 * k - 18 and (1 << cb_) > n_st and f_ == min(32, 128 // S_ - 1, rb_) and wb_ == 48 // S_ and fits(S_) and (S_ == 10 or not fits(S_ + 1))
+        assert lines >= -(-n_st * 100 // (S_ * load)) and tail_ in (1, 2, 4, 32)
         got = hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         assert got == int(S.from_bits(bits, len(q)).sum()) and (bits8 == bits).all() and (rows8 == rows).all(), load
+        # ... and the container walk that looks plain root groups up in their regions of the table (the table's values are the rows here)
+        hostlib.bft_hosttest_root_direct(h, 2)
+        if hostlib.bft_hosttest_walk_kh(h, 1):
+            hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
+            assert (bits8 == bits).all() and (rows8 == rows).all(), load
+            hostlib.bft_hosttest_walk_kh(h, 0)
+        hostlib.bft_hosttest_root_direct(h, 0)
         worst = C.c_uint64()
         mean = hostlib.bft_hosttest_kh_probe_stats(h, C.byref(worst))
-        assert 1.0 <= mean < (1.2 if load <= 50 else 2.5), (load, mean, worst.value)
+        # (one slot per line at 80 %: the textbook (1 + 1 / (1 - a)) / 2 = 3 lines per successful lookup; eight slots at 60 %: 1.05)
+        assert 1.0 <= mean < ((1.25 if S_ >= 5 else 2.0) if load <= 60 else 3.6), (load, S_, mean, worst.value)
     hostlib.bft_hosttest_kmer_hash(h, 0)
     o = oracle_mod.OracleBFT(k)
     o.insert_kmers(km, 0)
@@ -289,7 +305,7 @@ def test_hot_kernels_use_no_scratch(built):
     rows = [l.split(None, 7) for l in out.splitlines()[1:] if l.strip()]
     seen = set()
     for vgpr, sgpr, vspill, sspill, scratch, lds, maxwg, name in rows:
-        m = re.match(r"void (k_query_kh|k_seq_kh|k_branching_kh|k_kh_insert)<(\d)", name)
+        m = re.match(r"void (k_query_kh|k_seq_kh|k_branching_kh|k_kh_write)<(\d)", name)
         if not m:
             continue
         seen.add(m.group(1))

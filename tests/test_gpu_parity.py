@@ -1,5 +1,7 @@
 """GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C-ABI, against the CPU
 oracle on the same seeded inputs, bit-exact (integer/bit work: no tolerance), plus ground truth set semantics."""
+import os
+
 import numpy as np
 import pytest
 
@@ -446,11 +448,17 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
     tuned = t.build_time()["query_wgs_per_cu"]
     assert tuned in (1.0, 2.0, 3.0)
     assert t.build_time()["query_probe_rows"] in (4.0, 8.0)
-    # (node prefix hash, residency, grid multiplier, probe rows, root tables, k-mer hash on/off, its occupancy, measured launch shape)
-    for blk, wgs, mult, probe, rdir, kh, load, tune in [(1, 0, 1, 0, 1, 1, 50, 0), (0, 1, 1, 4, 0, 0, 50, 0), (2, 2, 1, 8, 2, 1, 80, 0), (1, 3, 1, 4, 0, 0, 50, 1),
-                                                        (0, 1, 3, 8, 3, 1, 10, 0), (1, 2, 1, 0, 0, 0, 50, 0), (0, 3, 2, 8, 1, 1, 65, 1), (1, 3, 1, 0, 3, 0, 50, 0)]:
+    # (node prefix hash, residency, grid multiplier, probe rows, root tables, k-mer hash on/off, its occupancy, measured launch shape,
+    #  the walk through the hash's regions, root quartile table, claimed chunks)
+    for blk, wgs, mult, probe, rdir, kh, load, tune, wh, rq, dyn in [(1, 0, 1, 0, 1, 1, 50, 0, 0, 1, 1), (0, 1, 1, 4, 0, 0, 50, 0, 0, 0, 1), (2, 2, 1, 8, 2, 1, 80, 0, 1, 1, 0),
+                                                                    (1, 3, 1, 4, 0, 0, 50, 1, 1, 0, 1), (0, 1, 3, 8, 3, 1, 10, 0, 1, 1, 1), (1, 2, 1, 0, 0, 0, 50, 0, 0, 1, 0),
+                                                                    (0, 3, 2, 8, 1, 1, 65, 1, 0, 0, 1), (1, 3, 1, 0, 3, 0, 50, 0, 0, 1, 1), (1, 3, 1, 8, 2, 1, 60, 0, 1, 0, 1)]:
         t.set_option("kmer_hash_load", load)
         t.set_option("kmer_hash", kh)
+        t.set_option("walk_hash", wh)
+        t.set_option("root_quartiles", rq)
+        t.set_option("query_dynamic", dyn)
+        t.set_option("query_dynamic_min", 1024 if dyn else 1 << 16)
         t.set_option("node_hash", blk)
         t.set_option("query_wgs_per_cu", wgs)
         t.set_option("query_grid_mult", mult)
@@ -479,9 +487,10 @@ def test_launch_options_do_not_change_answers(oracle_mod, k, deep):
 @pytest.mark.parametrize("k,levels", [(27, 0), (27, 2), (31, 0), (32, 0), (36, 0), (63, 2), (72, 0), (126, 0)])
 def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
     """The k-mer hash (BFT_KH_*: every stored k-mer in one table of 64-byte lines) gives bit-identical presence bitmaps, colour sets
-    and colour rows to the container walk -- ragged batch sizes (not a multiple of 64), all-absent batches, k-mers that share their
-    first 8 nucleotides, every occupancy; where k does not allow the table (k >= 64, k = 32) the option changes nothing; and both
-    agree with ground truth and with the oracle where it exists (k % 9 == 0)."""
+    and colour rows to the container walk -- over the sorted table ("kmer_hash" 0) and with the plain root groups looked up in their regions
+    of the table ("walk_hash" 1) -- ragged batch sizes (not a multiple of 64), all-absent batches, k-mers that share their first 8
+    nucleotides, every occupancy, every key width (k = 27 ... 126: one to four words, 8 to 1 slots per line); and all of them agree with
+    ground truth and with the oracle where it exists (k % 9 == 0)."""
     from bloomfiltertrie_amd import BFT
     anc = S.random_genome(150000, 3 + k)
     gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 50 + g), k)) for g in range(3)]
@@ -491,8 +500,7 @@ def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
     for g, km in enumerate(gk):
         t.insert_kmers(km, g)
     t.build()
-    usable = k <= 63 and (2 * k) % 64 != 0
-    assert (t.build_time()["kmer_hash_lines"] > 0) == usable and (t.footprint()["kmer_hash"] > 0) == usable
+    assert t.build_time()["kmer_hash_lines"] > 0 and t.footprint()["kmer_hash"] > 0  # every k has the table
     allk = S.distinct(np.concatenate(gk))
     rng = np.random.default_rng(k)
     base = np.concatenate([allk, S.snp_mutants(allk, k, 1), S.pack_codes(rng.integers(0, 4, (5000, k), dtype=np.uint8))])
@@ -505,10 +513,15 @@ def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
         ref_b3, ref_crows = t.query_color_rows(q)
         truth = S.member(q, allk)
         assert (S.from_bits(ref_bits, n).astype(bool) == truth).all() and (ref_b3 == ref_bits).all()
-        for load in (50, 80, 20):
+        for load in (60, 80, 20):
             t.set_option("kmer_hash_load", load)
             t.set_option("kmer_hash", 1)
             assert (t.query_presence(q) == ref_bits).all(), (k, n, load)
+            t.set_option("walk_hash", 1)
+            assert (t.query_presence(q) == ref_bits).all(), (k, n, load, "walk_hash")
+            bw, crw = t.query_color_rows(q)
+            assert (bw == ref_bits).all() and (crw == ref_crows).all(), (k, n, load, "walk_hash")
+            t.set_option("walk_hash", 0)
             b2, r2, s2 = t.query_rows(q)
             assert (b2 == ref_bits).all() and (r2 == ref_rows).all() and (s2 == ref_sets).all(), (k, n, load)
             b3, crows = t.query_color_rows(q)
@@ -531,54 +544,41 @@ def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
     t.close()
 
 
-def _kh_home(key_words, n_lines):
-    """bft_kh_home restated with Python integers (tests only)."""
-    M = (1 << 64) - 1
-    h = key_words[0]
-    for w in key_words[1:]:
-        h = (((h ^ (h >> 29)) * 0x9E3779B97F4A7C15) + w) & M
-    h ^= h >> 33
-    h = (h * 0xFF51AFD7ED558CCD) & M
-    h ^= h >> 33
-    h = (h * 0xC4CEB9FE1A85EC53) & M
-    h ^= h >> 33
-    return (h * n_lines) >> 64
-
-
-@pytest.mark.parametrize("k", [27, 31, 45, 63])
+@pytest.mark.parametrize("k", [18, 27, 31, 32, 45, 63, 64, 90, 126])
 def test_kmer_hash_table_invariants(k):
-    """The table the GPU fills (slots claimed with atomicCAS, so the layout is not deterministic) holds every stored k-mer exactly once with
-    its colour set as the value, nothing else, and every k-mer sits in the first line from its home line on that is not full of other
-    keys -- the property the lookup's early exit relies on."""
-    from bloomfiltertrie_amd import BFT
-    W, S_ = (2 * k + 63) // 64, 5 if k <= 31 else 3
+    """The layout of the k-mer hash is canonical (bft_image.h): the table the GPU builds -- a device-wide sort by home line, a max-scan, a
+    pass of atomic ORs -- is, byte for byte, the table the sequential host restatement (bft_kh_host.h) builds from the same sorted k-mers
+    and colour sets: every stored k-mer exactly once with its colour set as the value, nothing else, every k-mer in the first line from its
+    home line on that was not full, and a free slot in the last line of every region -- the properties the lookup's early exit relies on."""
+    import ctypes as C
+    from bloomfiltertrie_amd import BFT, _lib
+    W = (2 * k + 63) // 64
     anc = S.random_genome(200000, k)
     t = BFT(k)
     for g in range(3):
-        t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k)), g)
+        km = S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k))
+        if g == 0:
+            km = np.concatenate([km, S.low_entropy_kmers(30000, k, 6, seed=k, levels=1)])  # regions of thousands of k-mers beside regions of one
+        t.insert_kmers(km, g)
     t.set_option("kmer_hash_load", 70)
     t.build()
-    kh = t.debug_array("kh", np.uint64).reshape(-1, 8)
+    kh = t.debug_array("kh", np.uint64)
+    kreg = t.debug_array("kreg", np.uint32)
     tk = t.debug_array("tk", np.uint64).reshape(-1, W)
     tcol = t.debug_array("tcol", np.uint32)
-    n_lines = int(t.build_time()["kmer_hash_lines"])
-    assert kh.shape[0] == n_lines
-    keys = kh[:, : S_ * W].reshape(n_lines, S_, W)
-    vals = kh[:, S_ * W:].copy().view(np.uint32).reshape(n_lines, -1)[:, :S_]
-    used = keys[:, :, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)
-    assert int(used.sum()) == len(tk)
-    stored = keys[used]                                     # [n, W]
-    order = np.lexsort(tuple(stored[:, w] for w in range(W - 1, -1, -1)))
-    assert (stored[order] == tk).all()                      # exactly the sorted table's k-mers, each once
-    assert (vals[used][order] == tcol).all()                # value = colour set of that row
-    full = used.all(axis=1)
-    line_of = np.nonzero(used)[0][order]                    # line of tk row i
-    rng = np.random.default_rng(1)
-    for i in rng.integers(0, len(tk), 3000):
-        ln = _kh_home([int(x) for x in tk[i]], n_lines)
-        while ln != line_of[i]:
-            assert full[ln], (i, ln)
-            ln = (ln + 1) % n_lines
+    n_sets = t.info()["colorsets"]
+    assert len(kreg) == (1 << 18) + 1 and len(kh) == int(t.build_time()["kmer_hash_lines"]) * 8 and int(kreg[-1] & 0x1FFFFFFF) * 8 == len(kh)
+    hostlib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
+    hostlib.bft_hosttest_kh_build.restype = C.c_uint64
+    hostlib.bft_hosttest_kh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lines = np.zeros(len(kh) + 1024, np.uint64)
+    hreg = np.zeros((1 << 18) + 1, np.uint32)
+    geo = np.zeros(6, np.uint32)
+    tkc, tcc = np.ascontiguousarray(tk), np.ascontiguousarray(tcol)
+    nw = hostlib.bft_hosttest_kh_build(tkc.ctypes.data, tcc.ctypes.data, len(tk), k, n_sets, 70, lines.ctypes.data, len(lines), hreg.ctypes.data, geo.ctypes.data)
+    assert nw == len(kh), (nw, len(kh))
+    assert ((kreg & 0x7FFFFFFF) == hreg).all()   # (bit 31: the walk's "special" flag, derived from the root range table)
+    assert (kh == lines[:nw]).all()
     t.close()
 
 

@@ -1,6 +1,11 @@
-cd /tmp && export TMPDIR=/tmp
+# counter passes of tools/pmc_live.py for a few option sets of the query path (config-4 share); results under gpurun_out/
 cd $GRAFT_REPO_ROOT
-python tools/pmc_live.py cfg4 125000000 gpurun_out/pmc_walk_q0.json kmer_hash=0 root_quartiles=0 > gpurun_out/pmc_walk_q0.log 2>&1
-python tools/pmc_live.py cfg4 125000000 gpurun_out/pmc_walk_q1.json kmer_hash=0 root_quartiles=1 > gpurun_out/pmc_walk_q1.log 2>&1
-python tools/pmc_live.py cfg4 125000000 gpurun_out/pmc_walk_q1_w1.json kmer_hash=0 root_quartiles=1 query_wgs_per_cu=1 > gpurun_out/pmc_walk_q1_w1.log 2>&1
-tail -c 1500 gpurun_out/pmc_walk_q0.log; echo; tail -c 1500 gpurun_out/pmc_walk_q1.log; echo; tail -c 1500 gpurun_out/pmc_walk_q1_w1.log
+for v in "$@"; do
+  name=$(echo "$v" | tr ' =' '__')
+  python tools/pmc_live.py cfg4 125000000 gpurun_out/pmc_${name}.json $v > gpurun_out/pmc_${name}.log 2>&1
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/pmc_${name}.json"))
+print("${v}", {k:d.get(k) for k in ("l2_misses_per_query","l2_requests_per_query","ea_read_requests_per_query","hbm_bytes_per_query","kernel_us_under_pmc_mean","error")})
+PY
+done

@@ -52,6 +52,9 @@ def timed(bits):
 
 
 if not variants:
+    variants = ["kmer_hash=1", "walk_hash=1", "kmer_hash=0", "kmer_hash_load=50", "kmer_hash_load=70", "kmer_hash_load=80", "compact_table=1", "walk_hash=1,query_wgs_per_cu=1",
+                "walk_hash=1,query_wgs_per_cu=2", "query_dynamic=0"]
+if False:
     variants = [
         "query_dynamic=0,root_quartiles=0,query_probe=8",
         "query_dynamic=1,root_quartiles=0,query_probe=8",
@@ -72,8 +75,8 @@ if not variants:
 kh_ms = timed(torch.zeros_like(ref))
 rows = [{"variant": "kmer_hash (default path)", "ms": round(kh_ms, 4), "G_kmers_per_s": round(nq / kh_ms / 1e6, 2), "truth_ok": truth_ok, "k": k, "genomes": genomes}]
 print(rows[-1], flush=True)
-t.set_option("kmer_hash", 0)
-defaults = {"query_dynamic": 1, "root_quartiles": 1, "query_probe": 0, "query_wgs_per_cu": 0, "query_grid_mult": 1, "root_direct": 3, "node_hash": 1}
+defaults = {"kmer_hash_load": 60, "kmer_hash": 1, "walk_hash": 0, "query_dynamic": 1, "root_quartiles": 1, "query_probe": 0, "query_wgs_per_cu": 0, "query_grid_mult": 1,
+            "root_direct": 3, "node_hash": 1, "compact_table": 0}
 for v in variants:
     opts = dict(defaults)
     opts.update({a.split("=")[0]: int(a.split("=")[1]) for a in v.split(",")})
@@ -81,7 +84,10 @@ for v in variants:
         t.set_option(name, val)
     bits = torch.zeros_like(ref)
     ms = timed(bits)
-    rows.append({"variant": v, "ms": round(ms, 4), "G_kmers_per_s": round(nq / ms / 1e6, 2), "same_bits": bool(torch.equal(bits, ref))})
+    fp = t.footprint()
+    rows.append({"variant": v, "ms": round(ms, 4), "G_kmers_per_s": round(nq / ms / 1e6, 2), "same_bits": bool(torch.equal(bits, ref)),
+                 "image_B_per_kmer": round(t.info()["image_bytes"] / t.info()["kmers"], 2), "kh_B_per_kmer": round(fp["kmer_hash"] / t.info()["kmers"], 2),
+                 "kh_lines": t.build_time()["kmer_hash_lines"]})
     print(rows[-1], flush=True)
     del bits
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
