@@ -261,9 +261,8 @@ struct bft_gpu {
     DevBuf d_nph;                 // derived: node prefix hash (BFT_NPH_*, k_nph_fill), optional
     int opt_node_hash = 1;        // "node_hash": 1 = derived when the image has no k-mer hash (the walk then answers every query), 2 = always, 0 = never
     uint64_t nph_inserted = 0, nph_dropped = 0;
-    DevBuf d_kh, d_kreg;          // derived: k-mer hash and its region table (BFT_KH_*, bft_kh_build), optional
-    uint64_t kh_lines = 0;        // lines in use
-    BftKhGeometry kh_geo = {0, 0, 0, 0, 0};
+    DevBuf d_kh, d_rspec;         // derived: k-mer hash (BFT_KH_*, bft_kh_build), optional; one "special" bit per root prefix for the walk (sync_walk_kh)
+    uint64_t kh_lines = 0;        // home lines
     bool opt_kmer_hash = true;    // "kmer_hash"
     bool opt_walk_hash = false;   // "walk_hash": presence / colour queries through the container walk, which looks plain root groups up in the table's regions
     bool opt_compact = false;     // "compact_table": the sorted table and the colour set per k-mer are dropped once the k-mer hash holds them (ensure_table)
@@ -697,7 +696,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes + h->d_kreg.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes + h->d_rspec.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -719,10 +718,9 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.clus = h->d_clus.as<uint64_t>();
     im.child = h->d_child.as<uint64_t>();
     im.tk = h->d_tk.as<uint64_t>();
-    im.kh = nullptr;    // (derive_kmer_hash)
-    im.kreg = nullptr;
-    im.kh_lines = 0;
-    im.kh_S = im.kh_f = im.kh_wb = im.kh_rb = im.kh_cb = 0;
+    im.kh_lines = nullptr;    // (derive_kmer_hash)
+    memset(&im.kh, 0, sizeof(im.kh));
+    im.rspec = nullptr;
     im.walk_kh = 0;
     im.tcol = h->d_tcol.as<uint32_t>();
     im.uck = h->d_uck.as<uint64_t>();
@@ -837,7 +835,7 @@ static void derive_node_hash(bft_gpu* h) {
     h->im.nph_no_uc = 0;
     h->nph_inserted = h->nph_dropped = 0;
     const uint64_t n_nodes = h->idx_sizes[0] / sizeof(BftNode);
-    if (!h->opt_node_hash || (h->opt_node_hash == 1 && h->im.kh != nullptr && !h->opt_walk_hash) || n_nodes <= 1 || h->info[6] == 0) {
+    if (!h->opt_node_hash || (h->opt_node_hash == 1 && h->im.kh_lines != nullptr && !h->opt_walk_hash) || n_nodes <= 1 || h->info[6] == 0) {
         h->d_nph.release();
         return;
     }
@@ -882,14 +880,16 @@ static void derive_node_hash(bft_gpu* h) {
 // so it starts behind those (`after`: an event of the assembly stream) and overlaps the chain of small kernels and read-back counts that
 // follows.  kh_finish waits for it.  Any failure just leaves the image without the table.
 struct KhFill {
-    DevBuf buf, kreg, status;
+    DevBuf buf, status;
     BftKhScratch scratch;
-    BftKhGeometry geo = {0, 0, 0, 0, 0};
+    BftKhGeo geo;
     uint64_t lines_cap = 0, lines_used = 0;
+    uint32_t db = BFT_KH_DBITS, retry_db = 0;  // displacement bits of this attempt; of the next one, when this one met a larger displacement
     hipEvent_t e0 = nullptr, e1 = nullptr, ew = nullptr;
     hipStream_t s2 = nullptr;
     bool started = false, prepared = false;
     std::thread prep;  // kh_prepare_async
+    KhFill() { memset(&geo, 0, sizeof(geo)); }
     ~KhFill() {  // (a build that fails half-way: the fill must be over before its buffers go back to the cache)
         if (prep.joinable()) prep.join();
         if (started && s2) (void)hipStreamSynchronize(s2);
@@ -899,6 +899,7 @@ struct KhFill {
     }
 };
 static bool kh_wanted(const bft_gpu* h, uint64_t nk) { return h->opt_kmer_hash && nk > 0 && nk < (1ull << 31); }
+static bool kh_geo_ok(const bft_gpu* h, const BftKhGeo& g) { return bft_kh_has_kernels(h->W, g.S) && g.nl + BFT_KH_TAIL_LINES < (1ull << 32); }
 // the host side of the build that needs no table yet: the second stream, the table's memory, the events (a millisecond of driver
 // calls for a gigabyte table that is not in the cache).  n_values: the colour sets of the index, or -- before they are known -- a bound
 // (sets <= k-mers): fewer slots per line at worst, i.e. a table allocated larger than needed, never smaller.
@@ -910,11 +911,10 @@ static void kh_prepare(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill& f) {
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
         if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); return; }
     }
-    f.geo = bft_kh_geometry(h->k, std::max<uint64_t>(1, n_values));
-    if (!bft_kh_has_kernels(h->W, f.geo.S)) return;
-    f.lines_cap = bft_kh_lines_bound(nk, f.geo.S, h->opt_kh_load);
-    if (f.lines_cap > BFT_KREG_LINE_MASK) return;
-    if (f.buf.alloc(f.lines_cap * BFT_KH_LINE_WORDS * 8) != 0 || f.kreg.alloc((BFT_KH_REGIONS + 2) * 4) != 0 || f.status.alloc(8) != 0) return;
+    f.geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_values), h->opt_kh_load, f.db);
+    if (!kh_geo_ok(h, f.geo)) return;
+    f.lines_cap = f.geo.nl + BFT_KH_TAIL_LINES;
+    if (f.buf.alloc(f.lines_cap * BFT_KH_LINE_WORDS * 8) != 0 || f.status.alloc(16) != 0) return;
     f.prepared = (f.e0 || hipEventCreate(&f.e0) == hipSuccess) && (f.e1 || hipEventCreate(&f.e1) == hipSuccess) &&
                  (f.ew || hipEventCreateWithFlags(&f.ew, hipEventDisableTiming) == hipSuccess);
     if (!f.prepared) { (void)hipGetLastError(); f.buf.release(); }
@@ -934,18 +934,19 @@ static void kh_prepare_async(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill&
 // run: the stream the build is enqueued on (the handle's second stream behind `after`, or the handle's own)
 static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, uint64_t n_sets, KhFill& f, hipStream_t after, hipStream_t run) {
     if (f.prep.joinable()) f.prep.join();
-    const BftKhGeometry geo = bft_kh_geometry(h->k, std::max<uint64_t>(1, n_sets));
+    if (!kh_wanted(h, nk)) return;
+    const BftKhGeo geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_sets), h->opt_kh_load, f.db);
+    if (!kh_geo_ok(h, geo)) return;
     // (prepared with a bound on the colour sets: keep the block unless the real geometry needs a tenth less)
-    const uint64_t need = kh_wanted(h, nk) && bft_kh_has_kernels(h->W, geo.S) ? bft_kh_lines_bound(nk, geo.S, h->opt_kh_load) : 0;
+    const uint64_t need = geo.nl + BFT_KH_TAIL_LINES;
     if (!f.prepared || f.lines_cap < need || f.lines_cap > need + need / 10) kh_prepare(h, nk, n_sets, f);
-    if (!f.prepared || need == 0) return;
+    if (!f.prepared) return;
     f.geo = geo;
     if (!run) run = h->stream2;
     bool ok = true;
     if (after && after != run) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(run, f.ew, 0) == hipSuccess;
     ok = ok && hipEventRecord(f.e0, run) == hipSuccess &&
-         bft_kh_build(d_tk, d_tcol, nk, h->k, h->W, f.geo, h->opt_kh_load, f.buf.as<uint64_t>(), f.lines_cap, f.kreg.as<uint32_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 &&
-         hipEventRecord(f.e1, run) == hipSuccess;
+         bft_kh_build(d_tk, d_tcol, nk, h->k, h->W, f.geo, f.buf.as<uint64_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 && hipEventRecord(f.e1, run) == hipSuccess;
     f.s2 = run;
     f.started = true;  // (whatever was enqueued is waited for before the buffers go anywhere)
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(run); f.started = false; f.buf.release(); }
@@ -958,63 +959,67 @@ static bool kh_finish(bft_gpu* h, KhFill& f, double* ms) {
     if (f.e0) (void)hipEventDestroy(f.e0);
     if (f.e1) (void)hipEventDestroy(f.e1);
     f.e0 = f.e1 = nullptr;
-    uint32_t st[2] = {1, 0};
-    if (ok) ok = hipMemcpy(st, f.status.p, 8, hipMemcpyDeviceToHost) == hipSuccess && st[0] == 0;
+    uint32_t st[4] = {2, 0, 0, 0};
+    if (ok) ok = hipMemcpy(st, f.status.p, 16, hipMemcpyDeviceToHost) == hipSuccess && st[0] == 0;
     for (DevBuf& b : f.scratch.b) b.release();
     f.lines_used = st[1];
-    if (!ok) { (void)hipGetLastError(); f.buf.release(); f.kreg.release(); }
-    if (ok && getenv("BFT_GPU_VERBOSE"))
-        fprintf(stderr, "[bft_gpu] k-mer hash: %llu lines in use of %llu, %u slots (%u-bit header fields, %u-byte bodies: %u key + %u value bits), %.2f ms\n",
-                (unsigned long long)f.lines_used, (unsigned long long)f.lines_cap, f.geo.S, f.geo.f, f.geo.wb, f.geo.rb, f.geo.cb, t);
+    f.geo.maxd = st[2];  // (a lookup looks no further than the table's largest displacement)
+    f.retry_db = st[0] == 1 && f.db == BFT_KH_DBITS ? bft_kh_retry_dbits(st[2]) : 0;  // a k-mer displaced beyond the slots' bits: once more with more
+    if (!ok) { (void)hipGetLastError(); f.buf.release(); }
+    if (getenv("BFT_GPU_VERBOSE"))
+        fprintf(stderr, "[bft_gpu] k-mer hash: %s, %llu home lines (2^%u x %u), %u slots (%u-bit header fields, %u-byte bodies: %u key bits (%u below the hashed %u, %u of q) + 3 + %u value bits), %.2f ms\n",
+                ok ? "built" : "NOT built", (unsigned long long)f.geo.nl, f.geo.hb - f.geo.t, f.geo.m, f.geo.S, f.geo.f, f.geo.wb, f.geo.kb, f.geo.restb, f.geo.hb, f.geo.qb, f.geo.cb, t);
     return ok;
 }
 // the table of a finished build becomes the image's
 static void kh_adopt(bft_gpu* h, KhFill& f, double ms) {
     h->d_kh.swap(f.buf);
-    h->d_kreg.swap(f.kreg);
-    h->kh_lines = f.lines_used;
-    h->kh_geo = f.geo;
+    h->kh_lines = f.geo.nl;
     h->kh_ms = ms;
-    h->im.kh = h->d_kh.as<uint64_t>();
-    h->im.kreg = h->d_kreg.as<uint32_t>();
-    h->im.kh_lines = f.lines_used;
-    h->im.kh_S = f.geo.S; h->im.kh_f = f.geo.f; h->im.kh_wb = f.geo.wb; h->im.kh_rb = f.geo.rb; h->im.kh_cb = f.geo.cb;
+    h->im.kh_lines = h->d_kh.as<uint64_t>();
+    h->im.kh = f.geo;
 }
 static void kh_drop(bft_gpu* h) {
     h->d_kh.release();
-    h->d_kreg.release();
     h->kh_lines = 0;
     h->kh_ms = 0;
-    h->im.kh = nullptr;
-    h->im.kreg = nullptr;
-    h->im.kh_lines = 0;
+    h->im.kh_lines = nullptr;
+    memset(&h->im.kh, 0, sizeof(h->im.kh));
     h->im.walk_kh = 0;
 }
 
 // Derives the k-mer hash of the image h->im points at (BFT_KH_*), on the handle's own stream.  An accelerator only: without it every
 // query walks the containers.
-static void derive_kmer_hash(bft_gpu* h) {
+static void derive_kmer_hash(bft_gpu* h, uint32_t db = BFT_KH_DBITS) {
     kh_drop(h);
     if (!kh_wanted(h, h->n_kmers)) return;
-    KhFill f;
-    kh_start(h, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->n_sets, f, nullptr, h->stream);
-    double ms = 0;
-    if (kh_finish(h, f, &ms)) kh_adopt(h, f, ms);
+    for (int attempt = 0; attempt < 2 && db; attempt++) {
+        KhFill f;
+        f.db = db;
+        kh_start(h, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->n_sets, f, nullptr, h->stream);
+        double ms = 0;
+        if (kh_finish(h, f, &ms)) { kh_adopt(h, f, ms); return; }
+        db = f.retry_db;
+    }
 }
 
-// The walk's view of the region table: bit 31 of kreg[r] = "r is not a plain suffix group of the root" (what bit 31 of rstart[r] says),
-// and whether the walk may use the table at all (it needs the range table's verdict on every prefix).
-__global__ void k_kreg_flags(const uint32_t* __restrict__ rstart, uint32_t* __restrict__ kreg) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= BFT_KH_REGIONS) return;
-    const uint32_t v = kreg[r] & ~BFT_KREG_SPECIAL;
-    kreg[r] = (rstart[r] & BFT_RSTART_SPECIAL) ? (v | BFT_KREG_SPECIAL) : v;
+// What the walk needs to look plain root groups up in the k-mer hash: one bit per root prefix, "not a plain suffix group of the root"
+// (bit 31 of rstart[r]: child Node, UC rows) -- those keep the containers.
+__global__ void k_rspec(const uint32_t* __restrict__ rstart, uint32_t* __restrict__ rspec) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (1u << 18) / 32) return;
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; b++) bits |= ((rstart[32 * w + b] & BFT_RSTART_SPECIAL) ? 1u : 0u) << b;
+    rspec[w] = bits;
 }
-static void sync_kreg_flags(bft_gpu* h) {
+static void sync_walk_kh(bft_gpu* h) {
     h->im.walk_kh = 0;
-    if (!h->im.kh || !h->rstart_ok) return;
-    hipLaunchKernelGGL(k_kreg_flags, dim3(BFT_KH_REGIONS / 256), dim3(256), 0, h->stream, h->d_rstart.as<uint32_t>(), h->d_kreg.as<uint32_t>());
+    h->im.rspec = nullptr;
+    if (!h->im.kh_lines || !h->rstart_ok) return;
+    if (h->d_rspec.bytes < (1u << 18) / 8 && h->d_rspec.alloc((1u << 18) / 8) != 0) return;
+    hipLaunchKernelGGL(k_rspec, dim3((1u << 18) / 32 / 256), dim3(256), 0, h->stream, h->d_rstart.as<uint32_t>(), h->d_rspec.as<uint32_t>());
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    h->im.rspec = h->d_rspec.as<uint32_t>();
     h->im.walk_kh = 1;
 }
 
@@ -1026,7 +1031,7 @@ __global__ void k_rows_from_words(const uint64_t* __restrict__ words, uint64_t n
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         for (int w = 0; w < W; w++) rows[i * W + w] = words[(uint64_t)w * n + i];
 }
-static bool compact_possible(const bft_gpu* h) { return h->im.kh != nullptr && h->n_kmers > 0; }
+static bool compact_possible(const bft_gpu* h) { return h->im.kh_lines != nullptr && h->n_kmers > 0; }
 static void drop_table(bft_gpu* h) {
     if (!h->opt_compact || h->table_dropped || !compact_possible(h)) return;
     h->d_tk.release();
@@ -1160,7 +1165,7 @@ static int bind_image(bft_gpu* h, uint32_t nb_genomes) {
     point_image(h, nb_genomes);
     derive_root_direct(h);
     derive_kmer_hash(h);
-    sync_kreg_flags(h);
+    sync_walk_kh(h);
     derive_node_hash(h);
     default_launch_shape(h);
     return 0;
@@ -1592,8 +1597,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
     if (kh_ok) kh_adopt(h, khf, kh_ms);  // built during the assembly
+    else if (khf.retry_db) derive_kmer_hash(h, khf.retry_db);  // (a k-mer displaced beyond three bits' worth of lines: once more, with more bits)
     else kh_drop(h);
-    sync_kreg_flags(h);
+    sync_walk_kh(h);
     bft_trace_mark("root tables");
     derive_node_hash(h);
     default_launch_shape(h);
@@ -1734,7 +1740,7 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
     const bool no_rows = d_rows == nullptr || h->im.emit_cs;  // presence or colour sets: what the k-mer hash holds
-    if (h->im.kh != nullptr && no_rows && !h->opt_walk_hash) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (h->im.kh_lines != nullptr && no_rows && !h->opt_walk_hash) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
     CK(ensure_table(h));
     // the walk may look plain root groups up in their regions of the k-mer hash when no row is asked for
     const uint32_t keep = h->im.walk_kh;
@@ -1899,7 +1905,7 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    if (h->im.kh != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
+    if (h->im.kh_lines != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
         CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8), h->opt_query_chunk, s));
         CK(timing_end(h, s, e0, e1));
         return 0;
@@ -2194,7 +2200,7 @@ static int launch_seq_walk_k(bft_gpu* h, uint32_t ns, int canonical, const uint6
 template <int W>
 static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint64_t* d_soff, hipStream_t s) {
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
-    if (h->im.kh != nullptr) {
+    if (h->im.kh_lines != nullptr) {
         return bft_kh_seq(h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical,
                           h->sq_cs.as<uint32_t>(), claim_counters(h, s, h->opt_query_dynamic_min), h->opt_query_chunk, s);
     }
@@ -2510,12 +2516,12 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
     CK(ensure_built(h));
-    static const char* names[15] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol", "kreg"};
-    const DevBuf* bufs[15] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
-                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol, &h->d_kreg};
-    const uint64_t derived[6] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8, h->kh_lines * BFT_KH_LINE_WORDS * 8, h->n_kmers * 4,
-                                 h->im.kh ? (uint64_t)(BFT_KH_REGIONS + 1) * 4 : 0ull};
-    for (int i = 0; i < 15; i++)
+    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol"};
+    const DevBuf* bufs[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
+                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol};
+    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8,
+                                 h->kh_lines ? (h->kh_lines + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS * 8 : 0ull, h->n_kmers * 4};
+    for (int i = 0; i < 14; i++)
         if (std::string(name) == names[i]) {
             const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
             if (nbytes) *nbytes = sz;
@@ -2574,7 +2580,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));
             derive_kmer_hash(h);
-            sync_kreg_flags(h);
+            sync_walk_kh(h);
             derive_node_hash(h);  // (by default the node prefix hash exists exactly when the container walk answers queries)
             h->info[12] = image_bytes(h);
             drop_table(h);
@@ -2606,7 +2612,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));  // ("compact_table": k_root_ranges reads the sorted table)
             derive_root_direct(h);
-            sync_kreg_flags(h);
+            sync_walk_kh(h);
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
             drop_table(h);
@@ -2619,7 +2625,7 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(ensure_table(h));
             derive_root_direct(h);
-            sync_kreg_flags(h);
+            sync_walk_kh(h);
             default_launch_shape(h);
             h->info[12] = image_bytes(h);
             drop_table(h);
@@ -2684,7 +2690,7 @@ extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
     if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
                             h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
-                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes + h->d_kreg.bytes, h->d_cs_bm.bytes,
+                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes + h->d_rspec.bytes, h->d_cs_bm.bytes,
                             h->d_hashmod.bytes, 0ull, h->log_k.bytes + h->log_g.bytes};
     for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
     return BFT_GPU_OK;

@@ -21,7 +21,7 @@ struct HostTrie {
     std::vector<uint32_t> tcol, cs_off, cs_ids;
     std::vector<uint64_t> rdir, nph;
     BftKhHostTable kh;
-    std::vector<uint32_t> rstart, rq;
+    std::vector<uint32_t> rstart, rq, rspec;
     uint64_t rstart_plain = 0;
     BftHostIndex idx;
     BftImage im;
@@ -103,12 +103,11 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
 
 // k-mer hash (BFT_KH_*): the sequential restatement of the canonical build (bft_kh_host.h) with the value = the row of the k-mer (the GPU
 // stores the colour set there), then the same lookup the kernels run.  load_pct: occupancy of the home lines in per cent (the product's
-// "kmer_hash_load"); 0 = drop the table.  Returns the number of lines in use.
+// "kmer_hash_load"); 0 = drop the table.  Returns the number of home lines.
 extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     HostTrie* t = (HostTrie*)hv;
-    t->im.kh = nullptr;
-    t->im.kreg = nullptr;
-    t->im.kh_lines = 0;
+    t->im.kh_lines = nullptr;
+    t->im.walk_kh = 0;
     t->kh = BftKhHostTable();
     const uint64_t n = t->tk.size() / t->W;
     if (!load_pct || n == 0) return 0;
@@ -121,27 +120,32 @@ extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     default: bft_kh_build_host<4>(t->tk.data(), rows.data(), n, t->k, n, load_pct, t->kh); break;
     }
     if (!t->kh.ok) return 0;
-    t->im.kh = t->kh.lines.data();
-    t->im.kreg = t->kh.kreg.data();
-    t->im.kh_lines = t->kh.lines.size() / BFT_KH_LINE_WORDS;
-    t->im.kh_S = t->kh.S; t->im.kh_f = t->kh.f; t->im.kh_wb = t->kh.wb; t->im.kh_rb = t->kh.rb; t->im.kh_cb = t->kh.cb;
-    return t->im.kh_lines;
+    t->im.kh_lines = t->kh.lines.data();
+    t->im.kh = t->kh.g;
+    return t->kh.g.nl;
 }
-// the walk looks plain root groups up in their regions of the table (BftImage::walk_kh; needs the table and the root range table):
-// returns 1 when switched on
+// the walk looks plain root groups up in the table (BftImage::walk_kh; needs the table and the root range table): returns 1 when on
 extern "C" int bft_hosttest_walk_kh(void* hv, int on) {
     HostTrie* t = (HostTrie*)hv;
     t->im.walk_kh = 0;
-    if (!on || !t->im.kh || !t->im.rstart) return 0;
-    for (uint32_t r = 0; r < BFT_KH_REGIONS; r++)
-        t->kh.kreg[r] = (t->kh.kreg[r] & ~BFT_KREG_SPECIAL) | ((t->rstart[r] & BFT_RSTART_SPECIAL) ? BFT_KREG_SPECIAL : 0u);
+    t->im.rspec = nullptr;
+    if (!on || !t->im.kh_lines || !t->im.rstart) return 0;
+    t->rspec.assign((1u << 18) / 32, 0u);
+    for (uint32_t r = 0; r < (1u << 18); r++)
+        if (t->rstart[r] & BFT_RSTART_SPECIAL) t->rspec[r >> 5] |= 1u << (r & 31u);
+    t->im.rspec = t->rspec.data();
     t->im.walk_kh = 1;
     return 1;
 }
+static void geo_out(const BftKhHostTable& tab, uint32_t* out) {
+    const BftKhGeo& g = tab.g;
+    out[0] = g.S; out[1] = g.f; out[2] = g.wb; out[3] = g.cb; out[4] = g.kb; out[5] = g.qb; out[6] = g.hb; out[7] = g.restb; out[8] = g.t; out[9] = g.m;
+    out[10] = (uint32_t)g.nl; out[11] = tab.max_d; out[12] = g.db;
+}
 // The sequential restatement on arrays handed in (tests compare the GPU-built table with it): tk = n sorted T-form rows, vals < n_values.
-// Returns the words of the table (8 per line); geo[0..4] as bft_hosttest_kh_geometry.  0 when the table cannot be built.
+// Returns the words of the table (8 per line); geo[0..11] as bft_hosttest_kh_geometry.  0 when the table cannot be built.
 extern "C" uint64_t bft_hosttest_kh_build(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, uint64_t n_values, uint32_t load_pct, uint64_t* lines_out,
-                                          uint64_t cap_words, uint32_t* kreg_out, uint32_t* geo) {
+                                          uint64_t cap_words, uint32_t* geo) {
     BftKhHostTable tab;
     switch (bft_words_for_k(k)) {
     case 1: bft_kh_build_host<1>(tk, vals, n, k, n_values, load_pct, tab); break;
@@ -149,24 +153,14 @@ extern "C" uint64_t bft_hosttest_kh_build(const uint64_t* tk, const uint32_t* va
     case 3: bft_kh_build_host<3>(tk, vals, n, k, n_values, load_pct, tab); break;
     default: bft_kh_build_host<4>(tk, vals, n, k, n_values, load_pct, tab); break;
     }
-    if (geo) { geo[0] = tab.S; geo[1] = tab.f; geo[2] = tab.rb; geo[3] = tab.cb; geo[4] = tab.max_tail; geo[5] = tab.wb; }
+    if (geo) geo_out(tab, geo);
     if (!tab.ok || tab.lines.size() > cap_words) return 0;
     memcpy(lines_out, tab.lines.data(), tab.lines.size() * 8);
-    memcpy(kreg_out, tab.kreg.data(), tab.kreg.size() * 4);
     return tab.lines.size();
 }
-// geometry of the host table: out[0..5] = slots per line, bits of a header field, key bits, value bits, largest tail, bytes of a slot body
-extern "C" void bft_hosttest_kh_geometry(void* hv, uint32_t* out) {
-    HostTrie* t = (HostTrie*)hv;
-    out[0] = t->kh.S; out[1] = t->kh.f; out[2] = t->kh.rb; out[3] = t->kh.cb; out[4] = t->kh.max_tail; out[5] = t->kh.wb;
-}
-// raw copy of the host table (tests compare it with the GPU's: the layout is canonical)
-extern "C" uint64_t bft_hosttest_kh_arrays(void* hv, uint64_t* lines_out, uint64_t lines_cap_words, uint32_t* kreg_out) {
-    HostTrie* t = (HostTrie*)hv;
-    if (lines_out && lines_cap_words >= t->kh.lines.size()) memcpy(lines_out, t->kh.lines.data(), t->kh.lines.size() * 8);
-    if (kreg_out && !t->kh.kreg.empty()) memcpy(kreg_out, t->kh.kreg.data(), t->kh.kreg.size() * 4);
-    return t->kh.lines.size();
-}
+// geometry of the host table: out[0..12] (12: displacement bits) = slots per line, field bits, body bytes, value bits, key bits, q bits, hashed bits, bits below,
+// t, m, home lines, largest displacement
+extern "C" void bft_hosttest_kh_geometry(void* hv, uint32_t* out) { geo_out(((HostTrie*)hv)->kh, out); }
 template <int W>
 static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
     std::vector<uint64_t> tq;
@@ -183,12 +177,44 @@ static uint64_t query_kh(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bi
 }
 extern "C" int64_t bft_hosttest_query_kh(void* hv, const uint8_t* q, uint64_t nq, uint8_t* bits, uint32_t* vals) {
     HostTrie* t = (HostTrie*)hv;
-    if (!t->im.kh) return -1;
+    if (!t->im.kh_lines) return -1;
     switch (t->W) {
     case 1: return (int64_t)query_kh<1>(t, q, nq, bits, vals);
     case 2: return (int64_t)query_kh<2>(t, q, nq, bits, vals);
     case 3: return (int64_t)query_kh<3>(t, q, nq, bits, vals);
     default: return (int64_t)query_kh<4>(t, q, nq, bits, vals);
+    }
+}
+// every slot of the host table decoded back (bft_kh_slot_decode, what "compact_table" rebuilds the sorted table from): 1 when the decoded
+// (k-mer, value) pairs are exactly the rows of the sorted table with their row numbers
+template <int W>
+static int kh_roundtrip(HostTrie* t) {
+    const uint64_t n = t->tk.size() / W, nl = t->kh.g.nl + BFT_KH_TAIL_LINES;
+    std::vector<uint8_t> seen(n, 0);
+    uint64_t cnt = 0;
+    for (uint64_t ln = 0; ln < nl; ln++) {
+        const uint64_t* line = t->im.kh_lines + ln * BFT_KH_LINE_WORDS;
+        const uint32_t occ = (uint32_t)(line[1] >> (64u - t->kh.g.S));
+        for (uint32_t s = 0; s < t->kh.g.S; s++) {
+            if (!((occ >> s) & 1u)) continue;
+            uint64_t key[W];
+            uint32_t v;
+            bft_kh_slot_decode<W>(t->im, line, line, ln, s, key, &v);
+            if (v >= n || seen[v] || memcmp(key, &t->tk[(uint64_t)v * W], W * 8) != 0) return 0;
+            seen[v] = 1;
+            cnt++;
+        }
+    }
+    return cnt == n;
+}
+extern "C" int bft_hosttest_kh_roundtrip(void* hv) {
+    HostTrie* t = (HostTrie*)hv;
+    if (!t->im.kh_lines) return -1;
+    switch (t->W) {
+    case 1: return kh_roundtrip<1>(t);
+    case 2: return kh_roundtrip<2>(t);
+    case 3: return kh_roundtrip<3>(t);
+    default: return kh_roundtrip<4>(t);
     }
 }
 // mean lines read per lookup of the stored k-mers themselves, and the longest run (diagnostics of the table's occupancy)
@@ -197,18 +223,14 @@ static double kh_probe_stats(HostTrie* t, uint64_t* longest) {
     const uint64_t n = t->tk.size() / W;
     uint64_t total = 0, worst = 0;
     for (uint64_t i = 0; i < n; i++) {
-        const uint64_t* key = &t->tk[i * W];
-        const BftKhRegion g = bft_kh_region(t->im.kreg, bft_digit<W>(key, t->k, 0));
-        uint64_t remle[W];
         BftKhKey<W> kk;
-        bft_kh_rem<W>(key, t->k, remle);
-        bft_kh_key<W>(remle, t->im.kh_rb, t->im.kh_f, t->im.kh_cb, kk);
-        uint64_t ln = (uint64_t)g.first + bft_kh_home_of(bft_kh_hash<W>(remle), g.mh), steps = 1;
-        for (;; steps++, ln++) {
+        bft_kh_key<W>(&t->tk[i * W], t->k, t->im.kh, kk);
+        uint64_t steps = 1;
+        for (uint32_t d = 0;; d++, steps++) {
             uint32_t v;
-            const uint64_t* line = t->im.kh + ln * BFT_KH_LINE_WORDS;
-            if (bft_kh_scan<W, 0>(t->im, line, line, kk, &v) > 0) break;
-            if (steps > g.lines) { steps = ~0ull >> 1; break; }  // (a stored k-mer the lookup cannot find: the caller's bound fails)
+            const uint64_t* line = t->im.kh_lines + (kk.home + d) * BFT_KH_LINE_WORDS;
+            if (bft_kh_scan<W, 0>(t->im, line, line, kk, d, &v) > 0) break;
+            if (d >= t->im.kh.maxd) { steps = ~0ull >> 1; break; }  // (a stored k-mer the lookup cannot find: the caller's bound fails)
         }
         total += steps;
         worst = std::max(worst, steps);
@@ -218,7 +240,7 @@ static double kh_probe_stats(HostTrie* t, uint64_t* longest) {
 }
 extern "C" double bft_hosttest_kh_probe_stats(void* hv, uint64_t* longest) {
     HostTrie* t = (HostTrie*)hv;
-    if (!t->im.kh) return 0.0;
+    if (!t->im.kh_lines) return 0.0;
     switch (t->W) {
     case 1: return kh_probe_stats<1>(t, longest);
     case 2: return kh_probe_stats<2>(t, longest);
@@ -381,7 +403,6 @@ extern "C" int bft_hosttest_get_array(void* hv, const char* name, void* out, uin
     else if (nm == "ucrow") { p = t->idx.ucrow.data(); n = t->idx.ucrow.size() * 4; }
     else if (nm == "tk") { p = t->tk.data(); n = t->tk.size() * 8; }
     else if (nm == "kh") { p = t->kh.lines.data(); n = t->kh.lines.size() * 8; }
-    else if (nm == "kreg") { p = t->kh.kreg.data(); n = t->kh.kreg.size() * 4; }
     else return -1;
     if (nbytes) *nbytes = n;
     if (out) { if (cap < n) return -6; memcpy(out, p, n); }

@@ -111,43 +111,46 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 #define BFT_CLUS_LEN_SHIFT 32
 
 // k-mer hash (derived when the image is built, loaded or unpacked; optional; any k): EVERY stored k-mer, whatever container of the trie
-// holds it, in one table of 64-byte lines that is laid out ROOT PREFIX BY ROOT PREFIX -- the hashed form of the suffix groups (and child
-// Nodes) that hang off the root.  The k-mers under root prefix r (the top 18 bits of the T-form: src/presenceNode.c:1327-1371) own the
-// lines [kreg[r], kreg[r + 1]) -- the REGION of r; kreg (2^18 + 1 words, 1 MiB: it stays in the L2) is the only other thing a lookup
-// reads.  Inside its region a k-mer is known by the bits below the root prefix alone (RB = 2k - 18 of them: the prefix is implied by
-// the region, which is what lets a line hold 8 k-mers of k = 27 where the table of round 3 held 5), hashed to one of the region's mh
-// home lines, stored in the first line from there on with a free slot; the region ends in `tail` lines no k-mer calls home, sized so
-// that the last line of a region always keeps a free slot: a lookup reads lines from the home line on until it meets the key (present;
-// its colour set sits in the same slot) or a line with a free slot (absent), and never leaves the region.  An empty region (kreg[r] ==
-// kreg[r + 1]) answers "absent" without reading a table line at all.
+// holds it, in one open-addressed table of 64-byte lines.  A k-mer lives in the first line at or after its HOME line that had a free slot
+// when the table was laid out; a lookup reads lines from the home line on until it meets the key (present; its colour set sits in the
+// same slot), a line with a free slot (absent), or has looked as far past home as any k-mer of the table is displaced (absent).  At the default occupancy of the
+// home lines (60 %) a lookup reads 1.05-1.1 lines: ONE cache line beyond the L2 per query, where the container walk of
+// src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe even in its fastest form here; on MI355X a kernel of
+// random gathers is bound by the lines it misses on (tools/microbench/gather.hip: ~55 G lines/s beyond the L2, whether the lane reads 8
+// or 128 bytes of the line), so lines per query is the whole cost.
+//   key     The home line is computed from the top hb = min(32, 2k) bits of the T-form, hi, XOR-ed with a hash of the other bits (rest):
+//           hi' = perm(hi ^ mix(rest)) -- perm a fixed bijection that scatters: a bijection of hi for every rest --, split as (a | c), c the low t bits:
+//           home = a m + floor(c m / 2^t)  (nl = 2^(hb - t) m home lines, m in [16, 32]: any table size within 6 %).
+//           The home line thus KNOWS most of hi', and the slot stores only what it does not: q = c - ceil(sub 2^t / m) (qb bits) under the
+//           rest bits -- 2k - 32 + qb key bits instead of 2k (k = 27, 100 genomes: 32 instead of 54; this quotienting is what lets a line
+//           hold 8 k-mers of k = 27 or 31 where the table of round 3 held 5).  A k-mer displaced d lines from home stores d (3 bits; a build that
+//           meets a larger displacement is redone with as many bits as it takes: one slot per line, k >= 97, takes 7 or 8).
 //   line    = header (16 bytes) + S slot bodies of wb = floor(48 / S) bytes, body s at byte 16 + s wb.  Header: S fields of
-//             f = min(32, floor(128 / S) - 1, RB) bits, field s at bits [s f, (s + 1) f) = the LOW f key bits of slot s; bits [128 - S, 128):
-//             slot s is in use.  Body: bits [0, CB) = colour-set id + 1 (CB = bits of the number of colour sets), bits [CB, CB + RB - f) =
-//             the other key bits.  S = the largest of 10..1 whose body holds CB + RB - f bits (k = 27, 100 genomes: 8 slots, 15-bit
-//             fields, 6-byte bodies; k = 31: 7 slots, 17-bit fields).  A lookup loads the HEADER (one 16-byte load), compares the S fields
-//             with the k-mer's low key bits, and reads the body (one more load) only of a slot that matches: an absent k-mer costs one load
-//             instruction on the line, a stored one two -- where loading the 64 bytes takes four.  That matters as much as the line
-//             count: the CU's address path spends ~64 cycles on every vector memory instruction of a wavefront whatever it loads, and the
-//             query kernels are bound by those cycles as much as by the lines they miss on.
-//   kreg[r] = first line of region r (bits 0..28) | tail code (bits 29..30: 1, 2, 4 or 32 lines) | BFT_KREG_SPECIAL (bit 31: r is not a plain suffix group
-//             of the root -- only the container walk looks at it); kreg[2^18] = lines in use
-//   home    = mulhi32(hash(bits below the root prefix) >> 32, mh),  mh = lines of the region - tail
-// The layout is CANONICAL: the k-mers of a region in (home line, T-form) order fill their lines by slot-level linear probing, so the
-// table is a function of the stored set and the occupancy alone (the GPU build -- one device-wide sort by home line, one max-scan, one
-// pass of atomic ORs -- and the sequential host restatement give the same bytes: tests/test_gpu_parity.py).  At the default occupancy of
-// the home lines (60 %) a lookup reads 1.05-1.1 lines; on MI355X a kernel of random gathers is bound by the lines it misses on
-// (tools/microbench/gather.hip: ~55 G lines/s beyond the L2), so lines per query is the whole cost.  The table never changes an answer:
-// it holds exactly the k-mers of the sorted table `tk` with their colour sets, `tk` can be rebuilt from it ("compact_table"), and the
-// container walk is used whenever the table is absent ("kmer_hash" 0, allocation failure, a region beyond 32 tail lines) or rows are asked for.
+//           f = min(32, floor(128 / S) - 1) bits, field s at bits [s f, (s + 1) f) = the LOW f bits of slot s's stored key; bits
+//           [128 - S, 128): slot s is in use.  Body: bits [0, CB) = colour-set id + 1 (CB = bits of the number of colour sets), [CB, CB + db)
+//           = d, above them the other key bits.  S = the largest of 10..1 whose body holds all that.  A lookup that loads the HEADER
+//           first (one 16-byte load) reads the body only of a slot whose field matches: an absent k-mer costs one load instruction on the
+//           line, a stored one two (bft_kh_scan: branching, sequences, the walk); the presence kernel fetches whole lines by quads of lanes
+//           (bft_kh.hip, k_query_kh).
+// The layout is CANONICAL: the k-mers in (home line, T-form) order fill the lines by slot-level linear probing, so the table is a function
+// of the stored set, the colour sets and the occupancy alone: the GPU build -- one device-wide sort by home line, one max-scan, one pass of
+// atomic ORs -- and the sequential host restatement give the same bytes (tests/test_gpu_parity.py).  The table never changes an answer: it
+// holds exactly the k-mers of the sorted table `tk` with their colour sets, `tk` can be rebuilt from it ("compact_table"), and the
+// container walk is used whenever the table is absent ("kmer_hash" 0, allocation failure, a k-mer displaced 256 lines or more)
+// or rows are asked for.
 #define BFT_KH_LINE_WORDS 8u
-#define BFT_KREG_LINE_MASK 0x1FFFFFFFu
-#define BFT_KREG_TAIL_SHIFT 29
-#define BFT_KREG_SPECIAL 0x80000000u
-#define BFT_KH_MAX_TAIL 32u
-// the tail lines of a region: kreg[r] holds 0..3 for 1, 2, 4 or 32 lines (the smallest of them that holds what spills past the last home line)
-#define BFT_KH_TAIL_OF(enc) (1u << ((0x5210u >> (4u * (enc))) & 15u))
-#define BFT_KH_REGIONS (1u << 18)
 #define BFT_KH_MAX_SLOTS 10u
+#define BFT_KH_DBITS 3u        // displacement bits of a slot: 3, or -- when a build meets a k-mer displaced further -- as many as that takes, up to
+#define BFT_KH_MAX_DBITS 8u
+#define BFT_KH_TAIL_LINES 256u // lines behind the home lines: what the last home lines spill into (the largest displacement + 1)
+struct BftKhGeo {
+    uint32_t S, f, wb, cb;     // slots per line, bits of a header field, bytes of a slot body, value bits
+    uint32_t db, maxd;         // displacement bits of a slot; the largest displacement in the table (a lookup looks no further)
+    uint32_t kb, qb;           // bits of a stored key (rest bits + qb), bits of q
+    uint32_t hb, restb;        // hashed high bits of the T-form, bits below them
+    uint32_t t, m, inv;        // home = a m + floor(c m / 2^t); inv = ceil(2^32 / m)
+    uint64_t nl;               // home lines
+};
 
 // Node prefix hash (derived when the image is bound, optional): the prefix entries of every node BELOW the root in one hash table
 // keyed by (node id, rotated prefix) -- 64-byte buckets of four {key, entry} pairs, sized for <= 1 key per bucket on average.  On a
@@ -184,12 +187,11 @@ struct BftImage {
     const uint64_t* clus;
     const uint64_t* child;
     const uint64_t* tk;       // [n_kmers * W] sorted T-form table
-    const uint64_t* kh;       // [kh_lines * 8] k-mer hash (BFT_KH_*, above), or NULL
-    const uint32_t* kreg;     // [2^18 + 1] its region table
-    uint64_t kh_lines;
-    uint32_t kh_S, kh_f, kh_wb, kh_rb, kh_cb;  // slots per line, bits of a header field, bytes of a slot body, key bits and value bits of a slot
-    uint32_t walk_kh;         // 1: the container walk looks a plain root suffix group up in its region of the k-mer hash (one line) instead
-                              // of searching its rows of the sorted table -- when the caller wants presence or colour sets, not rows
+    const uint64_t* kh_lines; // [(kh.nl + BFT_KH_TAIL_LINES) * 8] k-mer hash (BFT_KH_*, above), or NULL
+    BftKhGeo kh;
+    const uint32_t* rspec;    // [2^18 / 32] one bit per root prefix: not a plain suffix group of the root (bit 31 of rstart), or NULL
+    uint32_t walk_kh;         // 1: the container walk looks a plain root suffix group up in the k-mer hash (one line) instead of searching
+                              // its rows of the sorted table -- when the caller wants presence or colour sets, not rows
     const uint32_t* tcol;     // [n_kmers] colour-set id per row
     uint32_t emit_cs;         // per launch: the query kernels write the colour set of a found k-mer where they otherwise write its row
     const uint64_t* uck;      // [n_uc_rows * W] node-UC rows (T-form)

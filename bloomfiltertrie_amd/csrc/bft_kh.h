@@ -7,19 +7,13 @@
 #include "bft_image.h"
 
 #define BFT_KH_BLOCK 256
-struct BftKhGeometry { uint32_t S, f, wb, rb, cb; };  // slots per line, bits of a header field, bytes of a slot body, key bits, value bits
-// the geometry of the table of an index of k-mers of length k whose values are 0 .. n_values - 1
-BftKhGeometry bft_kh_geometry(int k, uint64_t n_values);
 bool bft_kh_has_kernels(int W, uint32_t S);
-// lines that hold the table of n k-mers for certain (what to allocate; the lines in use come back in d_status[1])
-uint64_t bft_kh_lines_bound(uint64_t n, uint32_t S, uint32_t load_pct);
-// Builds the table of the n rows of the sorted table d_tk (W words per row) with values d_vals on stream s: d_kh (lines_cap lines) and
-// d_kreg (2^18 + 1 words) are overwritten; d_status: two words, [0] != 0 afterwards = no table (a region that would need more than
-// BFT_KH_MAX_TAIL tail lines, more lines than lines_cap), [1] = lines in use.  Nothing is synchronised; the transients live in `sc`,
-// which the caller keeps until s has drained.
-struct BftKhScratch { DevBuf b[14]; };
-int bft_kh_build(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeometry& g, uint32_t load_pct, uint64_t* d_kh, uint64_t lines_cap,
-                 uint32_t* d_kreg, uint32_t* d_status, BftKhScratch& sc, hipStream_t s);
+// Builds the table (geometry g: bft_kh_geometry, bft_walk.h) of the n rows of the sorted table d_tk (W words per row) with values d_vals on
+// stream s: d_kh ((g.nl + BFT_KH_TAIL_LINES) lines) is overwritten; d_status: four words, [0] != 0 afterwards = no table (a k-mer displaced
+// further from its home line than g.db bits hold: redo with more), [1] = lines in use, [2] = the largest displacement.  Nothing is
+// synchronised; the transients live in `sc`, which the caller keeps until s has drained.
+struct BftKhScratch { DevBuf b[7]; };
+int bft_kh_build(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint32_t* d_status, BftKhScratch& sc, hipStream_t s);
 // every (k-mer, value) of the table, unordered, word w of k-mer j at d_keys[w * stride + j]; *d_cnt (zeroed by the caller) = how many
 int bft_kh_dump(const BftImage& im, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
 // presence bits (+ colour-set id per k-mer when d_out32 != NULL) of n packed k-mers of `rec` bytes each

@@ -9,68 +9,47 @@
 #include "bft_walk.h"
 
 struct BftKhHostTable {
-    uint32_t S = 0, f = 0, wb = 0, rb = 0, cb = 0;
-    std::vector<uint64_t> lines;   // 8 words per line
-    std::vector<uint32_t> kreg;    // 2^18 + 1
+    BftKhGeo g;
+    std::vector<uint64_t> lines;   // 8 words per line, g.nl + BFT_KH_TAIL_LINES lines
     bool ok = false;
-    uint32_t max_tail = 0;
+    uint32_t max_d = 0;
+    uint64_t lines_used = 0;
 };
 
-// tk: n sorted T-form rows of W words; vals[i] < n_values.  Rows of a region in (home line, row) order; slot p_i = max(home slot, p_(i-1) + 1);
-// lines of the region = max(home lines + 1, lines touched, + 1 when the last touched line is full).
+// tk: n sorted T-form rows of W words; vals[i] < n_values.  Rows in (home line, row) order; slot p_i = max(home slot, p_(i-1) + 1).
 template <int W>
 static void bft_kh_build_host(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, uint64_t n_values, uint32_t load_pct, BftKhHostTable& out) {
-    out.rb = bft_kh_rb(k);
-    out.cb = bft_kh_value_bits(n_values);
-    out.S = bft_kh_slots_for(out.rb, out.cb);
-    out.f = bft_kh_field_bits(out.S, out.rb);
-    out.wb = bft_kh_body_bytes(out.S);
-    out.kreg.assign(BFT_KH_REGIONS + 1, 0);
-    out.lines.clear();
-    out.ok = true;
-    out.max_tail = 0;
-    const uint32_t S = out.S;
-    uint64_t i = 0, line0 = 0;
-    std::vector<std::pair<uint32_t, uint64_t>> order;  // (home line, row)
-    for (uint32_t r = 0; r < BFT_KH_REGIONS; r++) {
-        uint64_t e = i;
-        while (e < n && bft_digit<W>(tk + e * W, k, 0) == r) e++;
-        const uint64_t nr = e - i;
-        uint32_t L = 0, tail = 0;
-        if (nr) {
-            const uint32_t mh = bft_kh_home_lines(nr, S, load_pct);
-            order.clear();
-            for (uint64_t x = i; x < e; x++) {
-                uint64_t remle[W];
-                bft_kh_rem<W>(tk + x * W, k, remle);
-                order.push_back({bft_kh_home_of(bft_kh_hash<W>(remle), mh), x});
-            }
-            std::stable_sort(order.begin(), order.end(), [](const std::pair<uint32_t, uint64_t>& a, const std::pair<uint32_t, uint64_t>& b) { return a.first < b.first; });
-            std::vector<uint64_t> pos(nr);
-            uint64_t p = 0;
-            for (uint64_t x = 0; x < nr; x++) {
-                const uint64_t home = (uint64_t)order[x].first * S;
-                p = x == 0 ? home : std::max(home, p + 1);
-                pos[x] = p;
-            }
-            uint64_t used = p / S + 1;
-            if (p % S == S - 1) used++;
-            const uint32_t code = bft_kh_tail_code(used > mh ? used - mh : 1);
-            if (code > 3u) out.ok = false;
-            tail = code & 3u;  // (the code; the lines: BFT_KH_TAIL_OF)
-            L = mh + BFT_KH_TAIL_OF(tail);
-            out.max_tail = std::max(out.max_tail, BFT_KH_TAIL_OF(tail));
-            out.lines.resize((line0 + L) * BFT_KH_LINE_WORDS, 0ull);
-            for (uint64_t x = 0; x < nr; x++) {
-                uint64_t img[BFT_KH_LINE_WORDS];
-                bft_kh_slot_image<W>(tk + order[x].second * W, k, S, out.rb, out.f, out.wb, out.cb, (uint32_t)(pos[x] % S), vals[order[x].second], img);
-                uint64_t* line = out.lines.data() + (line0 + pos[x] / S) * BFT_KH_LINE_WORDS;
-                for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++) line[q] |= img[q];
-            }
+    // first with the default displacement bits; a k-mer displaced further: once more with as many bits as that displacement takes (+ 1)
+    uint32_t db = BFT_KH_DBITS;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        out.g = bft_kh_geometry(k, n, n_values, load_pct, db);
+        const BftKhGeo& g = out.g;
+        out.lines.assign((g.nl + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS, 0ull);
+        out.ok = true;
+        out.max_d = 0;
+        out.lines_used = 0;
+        std::vector<std::pair<uint64_t, uint64_t>> order(n);  // (home line, row)
+        for (uint64_t i = 0; i < n; i++) {
+            BftKhKey<W> key;
+            bft_kh_key<W>(tk + i * W, k, g, key);
+            order[i] = {key.home, i};
         }
-        out.kreg[r] = (uint32_t)line0 | (tail << BFT_KREG_TAIL_SHIFT);
-        line0 += L;
-        i = e;
+        std::stable_sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first < b.first; });
+        uint64_t p = 0;
+        for (uint64_t x = 0; x < n; x++) {
+            const uint64_t home = order[x].first;
+            p = x == 0 ? home * g.S : std::max(home * g.S, p + 1);
+            const uint64_t ln = p / g.S, d = ln - home;
+            out.max_d = std::max<uint32_t>(out.max_d, (uint32_t)std::min<uint64_t>(d, 0xFFFFFFFFull));
+            if (d > g.maxd) { out.ok = false; continue; }
+            uint64_t img[BFT_KH_LINE_WORDS];
+            bft_kh_slot_image<W>(tk + order[x].second * W, k, g, (uint32_t)(p % g.S), (uint32_t)d, vals[order[x].second], img);
+            uint64_t* line = out.lines.data() + ln * BFT_KH_LINE_WORDS;
+            for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++) line[q] |= img[q];
+            out.lines_used = ln + 1;
+        }
+        if (out.ok) { out.g.maxd = out.max_d; return; }
+        db = bft_kh_retry_dbits(out.max_d);
+        if (db == 0) return;  // (256 lines or more: no table)
     }
-    out.kreg[BFT_KH_REGIONS] = (uint32_t)line0;
 }

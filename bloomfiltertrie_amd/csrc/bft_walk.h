@@ -310,79 +310,148 @@ BFT_HD uint32_t bft_cs_id_at(const void* cs_ids, uint32_t cs_w, uint64_t q) {
 }
 
 // ---- k-mer hash (bft_image.h, BFT_KH_*) ----
-// geometry of the table of an index: key bits, value bits -> slots per line, bits of a header field, bytes of a slot body
-BFT_HD uint32_t bft_kh_rb(int k) { return (uint32_t)(2 * k - 18); }
+// Geometry of the table of an index (BftKhGeo, bft_image.h): computed once per build on the host.
 BFT_HD uint32_t bft_kh_value_bits(uint64_t n_values) {  // values 0 .. n_values - 1 are stored as 1 .. n_values
     uint32_t b = 1;
     while (b < 32 && (n_values >> b)) b++;
     return b;
 }
-BFT_HD uint32_t bft_kh_field_bits(uint32_t S, uint32_t rb) {
+BFT_HD uint32_t bft_kh_field_bits(uint32_t S, uint32_t kb) {
     uint32_t f = 128u / S - 1u;
     if (f > 32u) f = 32u;
-    return f < rb ? f : rb;
+    return f < kb ? f : kb;
 }
 BFT_HD uint32_t bft_kh_body_bytes(uint32_t S) { return 48u / S; }
-BFT_HD uint32_t bft_kh_slots_for(uint32_t rb, uint32_t cb) {
-    for (uint32_t s = BFT_KH_MAX_SLOTS; s > 1; s--)
-        if (cb + rb - bft_kh_field_bits(s, rb) <= 8u * bft_kh_body_bytes(s)) return s;
-    return 1u;
+// displacement bits for the second attempt of a build whose first met a k-mer displaced `maxd` lines: what maxd takes, + 1; 0: give up
+BFT_HD uint32_t bft_kh_retry_dbits(uint32_t maxd) {
+    uint32_t b = 1;
+    while (b < 32 && (maxd >> b)) b++;
+    return b + 1 <= BFT_KH_MAX_DBITS ? b + 1 : (b <= BFT_KH_MAX_DBITS ? BFT_KH_MAX_DBITS : 0u);
 }
-// home lines of a region of n k-mers at `load_pct` per cent occupancy of the home lines
-BFT_HD uint32_t bft_kh_home_lines(uint64_t n, uint32_t S, uint32_t load_pct) {
-    if (n == 0) return 0u;
-    const uint64_t per = (uint64_t)S * load_pct;
-    const uint64_t m = (n * 100ull + per - 1) / per;
-    return (uint32_t)(m < 1 ? 1 : m);
-}
-// The bits of a T-form k-mer below its root prefix, as W little-endian words (word 0 least significant).
-template <int W>
-BFT_HD void bft_kh_rem(const uint64_t* t, int k, uint64_t* remle) {
-#pragma unroll
-    for (int i = 0; i < W; i++) remle[i] = t[W - 1 - i];
-    const int tb0 = 2 * k - 64 * (W - 1);  // bits of the T-form in its top word t[0]
-    if (tb0 > 18) remle[W - 1] &= (1ull << (tb0 - 18)) - 1ull;
-    else {
-        remle[W - 1] = 0;
-        if (W > 1 && tb0 < 18) remle[W > 1 ? W - 2 : 0] &= (1ull << (64 - (18 - tb0))) - 1ull;
+// n k-mers of length k, values below n_values, `load_pct` per cent of the home lines' slots in use
+BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t load_pct, uint32_t db = BFT_KH_DBITS) {
+    BftKhGeo g;
+    const uint32_t tb = (uint32_t)(2 * k);
+    g.hb = tb < 32u ? tb : 32u;
+    g.restb = tb - g.hb;
+    g.cb = bft_kh_value_bits(n_values);
+    g.db = db; g.maxd = (1u << db) - 1u;
+    g.S = 1; g.f = 0; g.wb = 48; g.kb = 0; g.qb = 0; g.t = 0; g.m = 1; g.inv = 0; g.nl = 1;
+    for (uint32_t S = BFT_KH_MAX_SLOTS; S >= 1; S--) {
+        // home lines wanted -> nl = 2^(hb - t) * m with m in [16, 32] (t <= 27: the magic division of bft_kh_place needs frac < 2^27)
+        const uint64_t per = (uint64_t)S * load_pct;
+        uint64_t want = (n * 100ull + per - 1) / per;
+        if (want < 1) want = 1;
+        uint32_t lg = 0;
+        while ((want >> (lg + 1)) != 0) lg++;  // floor(log2(want))
+        uint32_t abits = lg > 4 ? lg - 4 : 0;   // bits of the part `a` of the hashed high bits
+        if (abits > g.hb) abits = g.hb;
+        if (g.hb - abits > 27u) abits = g.hb - 27u;
+        const uint32_t t = g.hb - abits;
+        uint64_t m = (want + (1ull << abits) - 1) >> abits;
+        if (m < 2) m = 2;  // (m = 1 has no 32-bit magic number; a table is never smaller than 2^(hb - 27) * 2 lines)
+        // q < ceil(2^t / m): its bits
+        const uint64_t span = ((1ull << t) + m - 1) / m;
+        uint32_t qb = 0;
+        while (qb < 32 && ((span - 1) >> qb)) qb++;
+        const uint32_t kb = g.restb + qb, f = bft_kh_field_bits(S, kb), wb = bft_kh_body_bytes(S);
+        if (S == 1 || g.cb + db + kb - f <= 8u * wb) {
+            g.S = S; g.f = f; g.wb = wb; g.kb = kb; g.qb = qb; g.t = t; g.m = (uint32_t)m;
+            g.inv = (uint32_t)(((1ull << 32) + m - 1) / m);
+            g.nl = (uint64_t)m << abits;
+            break;
+        }
     }
+    return g;
+}
+// T-form k-mer -> its hashed high bits (hb of them) and the bits below, as W little-endian words
+template <int W>
+BFT_HD uint32_t bft_kh_split(const uint64_t* t, int k, uint32_t hb, uint64_t* restle) {
+#pragma unroll
+    for (int i = 0; i < W; i++) restle[i] = t[W - 1 - i];
+    const int tb0 = 2 * k - 64 * (W - 1);  // bits of the T-form in its top word t[0]
+    uint32_t hi;
+    if (tb0 >= (int)hb) {
+        hi = (uint32_t)(t[0] >> (tb0 - (int)hb));
+        restle[W - 1] = tb0 > (int)hb ? restle[W - 1] & ((1ull << (tb0 - (int)hb)) - 1ull) : 0ull;
+    } else {  // (W > 1: the hashed bits straddle the two top words)
+        const int below = (int)hb - tb0;  // bits taken from t[1]
+        hi = (uint32_t)((t[0] << below) | (t[W > 1 ? 1 : 0] >> (64 - below)));
+        restle[W - 1] = 0;
+        restle[W > 1 ? W - 2 : 0] &= (1ull << (64 - below)) - 1ull;
+    }
+    return hb < 32u ? hi & ((1u << hb) - 1u) : hi;
 }
 template <int W>
-BFT_HD uint64_t bft_kh_hash(const uint64_t* remle) {
-    uint64_t h = remle[0];
+BFT_HD uint32_t bft_kh_mix(const uint64_t* restle) {  // 32 well-mixed bits of the bits below
+    uint64_t h = restle[0] ^ 0x2545F4914F6CDD1Dull;
 #pragma unroll
-    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + remle[w];
+    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + restle[w];
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;  // 64-bit finalizer (murmur3)
-    return h;
+    return (uint32_t)(h >> 32);
 }
-// the code (0..3) of the smallest allowed tail >= need, 4 when there is none
-BFT_HD uint32_t bft_kh_tail_code(uint64_t need) { return need <= 1 ? 0u : (need <= 2 ? 1u : (need <= 4 ? 2u : (need <= 32 ? 3u : 4u))); }
-BFT_HD uint32_t bft_kh_home_of(uint64_t hash, uint32_t mh) { return (uint32_t)(((hash >> 32) * (uint64_t)mh) >> 32); }
-// A k-mer as its slot sees it: `field` = the low f key bits (what the line's header holds), `body` = the other key bits at [cb, cb + rb - f)
-// of the slot's body, W words, with the value + 1 to be OR-ed into bits [0, cb); `bmask` = the mask of those key bits.
+// A bijection of the hb-bit integers that scatters them (murmur3's 32-bit finalizer, cut down to hb bits: xor-shifts and odd multipliers
+// are invertible modulo 2^hb) and its inverse.  The hashed high bits of the T-form are the root prefix and the start of the next digit:
+// k-mers that share them (a deep trie) must not share their home lines.
+BFT_HD uint32_t bft_kh_perm(uint32_t x, uint32_t hb) {
+    const uint32_t M = hb < 32u ? (1u << hb) - 1u : 0xFFFFFFFFu, s1 = hb / 2u ? hb / 2u : 1u, s2 = (hb * 13u) / 32u ? (hb * 13u) / 32u : 1u;
+    x &= M;
+    x ^= x >> s1; x = (x * 0x85EBCA6Bu) & M;
+    x ^= x >> s2; x = (x * 0xC2B2AE35u) & M;
+    x ^= x >> s1;
+    return x;
+}
+BFT_HD uint32_t bft_kh_unshift(uint32_t y, uint32_t s) {  // x with y = x ^ (x >> s)
+    uint32_t x = y;
+    for (uint32_t k = s; k < 32u; k += s) x ^= y >> k;
+    return x;
+}
+BFT_HD uint32_t bft_kh_perm_inv(uint32_t x, uint32_t hb) {
+    const uint32_t M = hb < 32u ? (1u << hb) - 1u : 0xFFFFFFFFu, s1 = hb / 2u ? hb / 2u : 1u, s2 = (hb * 13u) / 32u ? (hb * 13u) / 32u : 1u;
+    x &= M;
+    x = bft_kh_unshift(x, s1); x = (x * 0x7ED1B41Du) & M;  // (0xC2B2AE35^-1 mod 2^32)
+    x = bft_kh_unshift(x, s2); x = (x * 0xA5CB9243u) & M;  // (0x85EBCA6B^-1 mod 2^32)
+    x = bft_kh_unshift(x, s1);
+    return x & M;
+}
+// A k-mer as the table sees it: its home line; `field` = the low f bits of its stored key (what a line's header holds); `body` = value
+// (to be OR-ed in) at [0, cb), displacement at [cb, cb + db) (to be OR-ed in), the other key bits above; `bmask` = displacement + key bits.
+// The stored key = the bits below the hashed ones, shifted up by qb, | q: the home line stands for the rest of the hashed bits.
+//   hi' = perm(hi ^ mix(rest))  (a bijection of hi for every rest)  = (a : hb - t bits | c : t bits)
+//   line = a m + sub,  sub = floor(c m / 2^t),  q = floor((c m mod 2^t) / m) = c - ceil(sub 2^t / m)
 template <int W>
 struct BftKhKey {
-    uint64_t field, body[W], bmask[W];
+    uint64_t home, field, body[W], bmask[W];
 };
 template <int W>
-BFT_HD void bft_kh_key(const uint64_t* remle, uint32_t rb, uint32_t f, uint32_t cb, BftKhKey<W>& key) {
-    key.field = f ? remle[0] & ((f < 64 ? 1ull << f : 0ull) - 1ull) : 0ull;
-    // hi = remle >> f (rb - f bits), then body = hi << cb
-    uint64_t hi[W], m[W];
-    const uint32_t hb = rb - f;
+BFT_HD void bft_kh_key(const uint64_t* t, int k, const BftKhGeo& g, BftKhKey<W>& key) {
+    uint64_t restle[W], kle[W];
+    const uint32_t hi = bft_kh_split<W>(t, k, g.hb, restle);
+    const uint32_t hp = bft_kh_perm(hi ^ bft_kh_mix<W>(restle), g.hb);
+    const uint64_t a = g.t < 32u ? (uint64_t)(hp >> g.t) : 0ull, c = g.t < 32u ? (uint64_t)(hp & ((1u << g.t) - 1u)) : (uint64_t)hp;
+    const uint64_t cm = c * g.m, sub = cm >> g.t, frac = cm & ((1ull << g.t) - 1ull);
+    const uint64_t q = (frac * g.inv) >> 32;  // = frac / m (frac < 2^27, m <= 32)
+    key.home = a * g.m + sub;
+    // stored key (kb bits) = rest << qb | q
+#pragma unroll
+    for (int i = 0; i < W; i++) kle[i] = g.qb ? (restle[i] << g.qb) | (i > 0 ? restle[i - 1] >> (64 - g.qb) : 0ull) : restle[i];
+    kle[0] |= q;
+    const uint32_t f = g.f, sh = g.cb + g.db, hbits = g.kb - f;
+    key.field = f ? kle[0] & ((1ull << f) - 1ull) : 0ull;
+    uint64_t hi_k[W], m[W];
 #pragma unroll
     for (int i = 0; i < W; i++) {
-        hi[i] = f ? (remle[i] >> f) | (i + 1 < W ? remle[i + 1] << (64 - f) : 0ull) : remle[i];
+        hi_k[i] = f ? (kle[i] >> f) | (i + 1 < W ? kle[i + 1] << (64 - f) : 0ull) : kle[i];
         const int lo = 64 * i;
-        m[i] = (int)hb >= lo + 64 ? ~0ull : ((int)hb > lo ? (1ull << (hb - lo)) - 1ull : 0ull);
-        hi[i] &= m[i];
+        m[i] = (int)hbits >= lo + 64 ? ~0ull : ((int)hbits > lo ? (1ull << (hbits - lo)) - 1ull : 0ull);
+        hi_k[i] &= m[i];
     }
-    key.body[0] = hi[0] << cb;
-    key.bmask[0] = m[0] << cb;
+    key.body[0] = hi_k[0] << sh;
+    key.bmask[0] = (m[0] << sh) | ((((uint64_t)1 << g.db) - 1ull) << g.cb);
 #pragma unroll
     for (int i = 1; i < W; i++) {
-        key.body[i] = (hi[i] << cb) | (hi[i - 1] >> (64 - cb));
-        key.bmask[i] = (m[i] << cb) | (m[i - 1] >> (64 - cb));
+        key.body[i] = (hi_k[i] << sh) | (hi_k[i - 1] >> (64 - sh));
+        key.bmask[i] = (m[i] << sh) | (m[i - 1] >> (64 - sh));
     }
 }
 // 64 bits of a multiword little-endian bit string from bit `o` on (zeros beyond its NW words)
@@ -397,18 +466,6 @@ BFT_HD uint64_t bft_kh_bits_at(const uint64_t* ln, uint32_t o) {
     }
     return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
-// The region of root prefix r: first line, lines, home lines.  (kreg[r] and kreg[r + 1] in ONE 8-byte load, 4-byte aligned.)
-struct BftKhRegion { uint32_t first, lines, mh, special; };
-BFT_HD BftKhRegion bft_kh_region(const uint32_t* kreg, uint32_t r) {
-    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-    const Pair pr = *reinterpret_cast<const Pair*>(kreg + r);
-    BftKhRegion g;
-    g.first = pr.a & BFT_KREG_LINE_MASK;
-    g.lines = (pr.b & BFT_KREG_LINE_MASK) - g.first;
-    g.mh = g.lines - BFT_KH_TAIL_OF((pr.a >> BFT_KREG_TAIL_SHIFT) & 3u);
-    g.special = pr.a & BFT_KREG_SPECIAL;
-    return g;
-}
 // the header of a line (two words): one 16-byte load
 BFT_HD void bft_kh_load_header(const uint64_t* line, uint64_t* hd) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -421,8 +478,7 @@ BFT_HD void bft_kh_load_header(const uint64_t* line, uint64_t* hd) {
 #endif
 }
 // The body of slot s (W words, zero-extended): byte offset 16 + s wb of the line, wb bytes.  One load instruction per 16 bytes, at the
-// body's byte address; a load that would run past the line's end starts earlier and is shifted (the table's last line is followed by
-// the allocation's slack, but a load never leaves its own 64 bytes).
+// body's byte address; a load that would run past the line's end starts earlier and is shifted (a load never leaves its own 64 bytes).
 template <int W>
 BFT_HD void bft_kh_load_body(const uint64_t* line, uint32_t s, uint32_t wb, uint64_t* body) {
     const uint8_t* p = reinterpret_cast<const uint8_t*>(line) + 16u + s * wb;
@@ -461,14 +517,14 @@ BFT_HD void bft_kh_load_body(const uint64_t* line, uint32_t s, uint32_t wb, uint
         }
     }
 }
-// One line against one k-mer: 1 = found (*val = its value), 0 = not here and the line has a free slot (absent), -1 = not here, line full.
-// The header (16 bytes: S fields of f bits -- the low key bits of the slots --, the S occupancy bits on top) says which slots can hold the
-// k-mer at all; only those slots' bodies are read: an absent k-mer costs one load instruction, a stored one two.
-// SS > 0: the slots per line as a compile-time constant (the kernels of bft_kh.hip); SS == 0: read from the image (the walk, the host).
+// One line, `d` lines past the k-mer's home line, against the k-mer: 1 = found (*val = its value), 0 = not here and the line has a free
+// slot (absent), -1 = not here, line full.  The header (16 bytes: S fields of f bits -- the low key bits of the slots --, the S occupancy
+// bits on top) says which slots can hold the k-mer at all; only those slots' bodies are read: an absent k-mer costs one load instruction,
+// a stored one two.  SS > 0: the slots per line as a compile-time constant (the kernels of bft_kh.hip); SS == 0: read from the image.
 template <int W, int SS>
-BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t* hd, const BftKhKey<W>& key, uint32_t* val) {
-    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh_S, f = im.kh_f, wb = im.kh_wb, cb = im.kh_cb;
-    const uint64_t fmask = f ? (f < 64 ? 1ull << f : 0ull) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
+BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t* hd, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
+    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh.S, f = im.kh.f, wb = im.kh.wb, cb = im.kh.cb;
+    const uint64_t fmask = f ? (1ull << f) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
     const uint32_t occ = (uint32_t)(hd[1] >> (64u - S));  // bit s: slot s is in use
     uint32_t cand = 0;
 #pragma unroll
@@ -478,62 +534,77 @@ BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t*
         cand |= (fld == key.field ? 1u : 0u) << s;
     }
     cand &= occ;
-    while (cand) {  // (a second candidate: two slots whose k-mers share their low f key bits -- once in thousands of lines)
+    while (cand) {  // (a second candidate: two slots whose keys share their low f bits -- once in thousands of lines)
         const uint32_t s = (uint32_t)__builtin_ctz(cand);
         cand &= cand - 1u;
         uint64_t body[W];
         bft_kh_load_body<W>(line, s, wb, body);
-        bool same = true;
+        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0;
 #pragma unroll
-        for (int i = 0; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
+        for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
         if (same) { *val = (uint32_t)(body[0] & vmask) - 1u; return 1; }
     }
     return occ != (1u << S) - 1u ? 0 : -1;
 }
-// Lookup of a T-form k-mer whose region is known: true when stored, *val = its value (the colour-set id).
+// The same against a line that is already in registers (8 words): every offset a compile-time constant.
 template <int W, int SS>
-BFT_HD bool bft_kh_find_in(const BftImage& im, const BftKhRegion& g, const uint64_t* t, uint32_t* val) {
-    if (g.lines == 0) return false;
-    uint64_t remle[W];
+BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
+    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S;
+    const uint32_t f = im.kh.f, cb = im.kh.cb;
+    const uint64_t fmask = f ? (1ull << f) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
+    const uint32_t occ = (uint32_t)(ln[1] >> (64u - S));
+    int found = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < S; s++) {
+        const uint64_t fld = f ? bft_kh_bits_at<2>(ln, s * f) & fmask : 0ull;
+        const uint64_t b0 = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb);
+        bool same = fld == key.field && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0;
+#pragma unroll
+        for (int i = 1; i < W; i++) {
+            if (8u * (uint32_t)i >= wb) break;
+            const uint64_t b = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb + 64u * (uint32_t)i);
+            same = same && ((b ^ key.body[i]) & key.bmask[i]) == 0;  // (bmask is zero beyond the body's bits)
+        }
+        if (same) {
+            *val = (uint32_t)(b0 & vmask) - 1u;
+            found = 1;
+        }
+    }
+    return found ? 1 : (occ != (1u << S) - 1u ? 0 : -1);
+}
+// Lookup of a T-form k-mer: true when stored, *val = its value (the colour-set id).  Lines from the home line on: the key, a line with a
+// free slot, or the table's largest displacement past home, ends it.
+template <int W, int SS>
+BFT_HD bool bft_kh_lookup(const BftImage& im, const uint64_t* t, uint32_t* val) {
     BftKhKey<W> key;
-    bft_kh_rem<W>(t, im.k, remle);
-    bft_kh_key<W>(remle, im.kh_rb, im.kh_f, im.kh_cb, key);
-    uint64_t ln_i = (uint64_t)g.first + bft_kh_home_of(bft_kh_hash<W>(remle), g.mh);
-    const uint64_t end = (uint64_t)g.first + g.lines;
-    for (; ln_i < end; ln_i++) {  // (a well-formed table ends the search before `end`: the last line of a region has a free slot)
-        const uint64_t* line = im.kh + ln_i * BFT_KH_LINE_WORDS;
+    bft_kh_key<W>(t, im.k, im.kh, key);
+    for (uint32_t d = 0; d <= im.kh.maxd; d++) {
+        const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
         uint64_t hd[2];
         bft_kh_load_header(line, hd);
-        const int res = bft_kh_scan<W, SS>(im, line, hd, key, val);
+        const int res = bft_kh_scan<W, SS>(im, line, hd, key, d, val);
         if (res > 0) return true;
         if (res == 0) return false;
     }
     return false;
 }
-template <int W, int SS>
-BFT_HD bool bft_kh_lookup(const BftImage& im, const uint64_t* t, uint32_t* val) {
-    const BftKhRegion g = bft_kh_region(im.kreg, bft_digit<W>(t, im.k, 0));
-    return bft_kh_find_in<W, SS>(im, g, t, val);
-}
-// What a k-mer adds to slot s of its line: the 8 line words to OR in (header field, occupancy bit, body).
+// What a k-mer stored d lines past its home line adds to slot s of that line: the 8 line words to OR in (header field, occupancy, body).
 template <int W>
-BFT_HD void bft_kh_slot_image(const uint64_t* t, int k, uint32_t S, uint32_t rb, uint32_t f, uint32_t wb, uint32_t cb, uint32_t s, uint32_t val, uint64_t* img) {
-    uint64_t remle[W];
+BFT_HD void bft_kh_slot_image(const uint64_t* t, int k, const BftKhGeo& g, uint32_t s, uint32_t d, uint32_t val, uint64_t* img) {
     BftKhKey<W> key;
-    bft_kh_rem<W>(t, k, remle);
-    bft_kh_key<W>(remle, rb, f, cb, key);
-    key.body[0] |= (uint64_t)val + 1ull;
+    bft_kh_key<W>(t, k, g, key);
+    key.body[0] |= ((uint64_t)val + 1ull) | ((uint64_t)d << g.cb);
 #pragma unroll
     for (uint32_t i = 0; i < BFT_KH_LINE_WORDS; i++) img[i] = 0;
     // header: field at bits [s f, (s + 1) f), occupancy at bit 128 - S + s
-    const uint32_t fo = s * f;
-    if (f) {
+    const uint32_t fo = s * g.f;
+    if (g.f) {
         img[fo >> 6] |= key.field << (fo & 63u);
-        if ((fo & 63u) + f > 64u) img[(fo >> 6) + 1] |= key.field >> (64u - (fo & 63u));
+        if ((fo & 63u) + g.f > 64u) img[(fo >> 6) + 1] |= key.field >> (64u - (fo & 63u));
     }
-    img[1] |= 1ull << (64u - S + s);
+    img[1] |= 1ull << (64u - g.S + s);
     // body at byte 16 + s wb
-    const uint32_t bo = 128u + 8u * s * wb;
+    const uint32_t bo = 128u + 8u * s * g.wb;
 #pragma unroll
     for (int i = 0; i < W; i++) {
         const uint32_t o = bo + 64u * (uint32_t)i, wi = o >> 6, sh = o & 63u;
@@ -541,25 +612,49 @@ BFT_HD void bft_kh_slot_image(const uint64_t* t, int k, uint32_t S, uint32_t rb,
         if (sh && wi + 1 < BFT_KH_LINE_WORDS) img[wi + 1] |= key.body[i] >> (64u - sh);
     }
 }
-// A used slot back to its k-mer: the T-form bits below the root prefix (W little-endian words) and the value.
+// A used slot of line `ln` back to its k-mer (T-form, W words, word 0 most significant) and its value.
 template <int W>
-BFT_HD void bft_kh_slot_decode(const BftImage& im, const uint64_t* line, const uint64_t* hd, uint32_t s, uint64_t* remle, uint32_t* val) {
-    const uint32_t f = im.kh_f, cb = im.kh_cb, hb = im.kh_rb - f;
-    uint64_t body[W];
-    bft_kh_load_body<W>(line, s, im.kh_wb, body);
+BFT_HD void bft_kh_slot_decode(const BftImage& im, const uint64_t* line, const uint64_t* hd, uint64_t ln, uint32_t s, uint64_t* t, uint32_t* val) {
+    const BftKhGeo& g = im.kh;
+    const uint32_t f = g.f, cb = g.cb, sh = cb + g.db, hbits = g.kb - f;
+    uint64_t body[W], kle[W], restle[W];
+    bft_kh_load_body<W>(line, s, g.wb, body);
     *val = (uint32_t)(body[0] & ((1ull << cb) - 1ull)) - 1u;
-    const uint64_t fld = f ? bft_kh_bits_at<2>(hd, s * f) & ((f < 64 ? 1ull << f : 0ull) - 1ull) : 0ull;
-    // hi = (body >> cb) masked to hb bits; rem = hi << f | field
-    uint64_t hi[W];
+    const uint32_t d = (uint32_t)(body[0] >> cb) & ((1u << g.db) - 1u);
+    const uint64_t fld = f ? bft_kh_bits_at<2>(hd, s * f) & ((1ull << f) - 1ull) : 0ull;
 #pragma unroll
     for (int i = 0; i < W; i++) {
-        hi[i] = (body[i] >> cb) | (i + 1 < W ? body[i + 1] << (64 - cb) : 0ull);
+        uint64_t x = (body[i] >> sh) | (i + 1 < W ? body[i + 1] << (64 - sh) : 0ull);
         const int lo = 64 * i;
-        hi[i] &= (int)hb >= lo + 64 ? ~0ull : ((int)hb > lo ? (1ull << (hb - lo)) - 1ull : 0ull);
+        x &= (int)hbits >= lo + 64 ? ~0ull : ((int)hbits > lo ? (1ull << (hbits - lo)) - 1ull : 0ull);
+        restle[i] = x;  // (key bits above the field, for now)
     }
 #pragma unroll
-    for (int i = 0; i < W; i++) remle[i] = f ? (hi[i] << f) | (i > 0 ? hi[i - 1] >> (64 - f) : 0ull) : hi[i];
-    remle[0] |= fld;
+    for (int i = 0; i < W; i++) kle[i] = f ? (restle[i] << f) | (i > 0 ? restle[i - 1] >> (64 - f) : 0ull) : restle[i];
+    kle[0] |= fld;
+    // stored key = rest << qb | q; home line = a m + sub -> c = ceil(sub 2^t / m) + q -> hi' -> hi
+    const uint64_t q = g.qb ? kle[0] & ((1ull << g.qb) - 1ull) : 0ull;
+#pragma unroll
+    for (int i = 0; i < W; i++) restle[i] = g.qb ? (kle[i] >> g.qb) | (i + 1 < W ? kle[i + 1] << (64 - g.qb) : 0ull) : kle[i];
+    const uint64_t home = ln - d, a = home / g.m, sub = home % g.m;
+    const uint64_t c = ((sub << g.t) + g.m - 1) / g.m + q;
+    const uint32_t hp = (uint32_t)((g.t < 32u ? a << g.t : 0ull) | c);
+    uint32_t hi = bft_kh_perm_inv(hp, g.hb) ^ bft_kh_mix<W>(restle);
+    if (g.hb < 32u) hi &= (1u << g.hb) - 1u;
+    // T = hi << restb | rest
+    uint64_t tl[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) tl[i] = restle[i];
+    {
+        const uint32_t o = g.restb, wi = o >> 6, s2 = o & 63u;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if ((uint32_t)i == wi) tl[i] |= (uint64_t)hi << s2;
+            if ((uint32_t)i == wi + 1 && s2 > 32u) tl[i] |= (uint64_t)hi >> (64u - s2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) t[i] = tl[W - 1 - i];
 }
 
 // The node's UC (src/presenceNode.c:1554-1573): exact search among its < 255 rows.
@@ -887,13 +982,12 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
             // Root level through the derived tables (bft_image.h).  Plain suffix groups: two adjacent words of the 1 MiB range
             // table give {first row, count}.
             if (ROOTMODE != 2 && im.walk_kh) {
-                // A plain suffix group of the root in its hashed form: the group's region of the k-mer hash (bft_image.h, BFT_KH_*) holds
-                // its suffixes with their colour sets -- one line instead of the probes of the sorted rows (src/UC.c:81-124 finds the
-                // suffix by binary search; same answer).  Special prefixes (child Node, UC rows) keep the containers.
-                const BftKhRegion g = bft_kh_region(im.kreg, r);
-                if (!g.special) {
+                // A plain suffix group of the root in its hashed form: the k-mer hash (bft_image.h, BFT_KH_*) holds the group's suffixes with
+                // their colour sets -- one line instead of the probes of the sorted rows (src/UC.c:81-124 finds the suffix by binary
+                // search; same answer).  Special prefixes (child Node, UC rows: one bit per prefix in rspec) keep the containers.
+                if (!((im.rspec[r >> 5] >> (r & 31u)) & 1u)) {
                     uint32_t cs = 0;
-                    if (bft_kh_find_in<W, 0>(im, g, t, &cs)) { hit.present = 1; hit.cs = cs; hit.from_kh = 1; }
+                    if (bft_kh_lookup<W, 0>(im, t, &cs)) { hit.present = 1; hit.cs = cs; hit.from_kh = 1; }
                     return hit;
                 }
                 if (ROOTMODE == 1) { hit.present = BFT_HIT_DEFERRED; return hit; }

@@ -78,8 +78,7 @@ def hostlib(built):
     lib.bft_hosttest_query_kh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.bft_hosttest_kh_geometry.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_walk_kh.argtypes = [C.c_void_p, C.c_int]
-    lib.bft_hosttest_kh_arrays.restype = C.c_uint64
-    lib.bft_hosttest_kh_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.bft_hosttest_kh_roundtrip.argtypes = [C.c_void_p]
     lib.bft_hosttest_kh_probe_stats.restype = C.c_double
     lib.bft_hosttest_kh_probe_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_node_hash.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -157,22 +156,25 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
         hostlib.bft_hosttest_set_probe(h, 0)
         assert (bits8 == bits).all() and (rows8 == rows).all(), (rd, mode)
     # the k-mer hash (BFT_KH_*; the host build stores the row as the value): the lookup the kernels run gives the walk's answers at the
-    # default occupancy, at a sparse one and at 80 % (runs of full lines), for every k (1 to 10 slots per line)
+    # default occupancy, at a sparse one and at 80 % (runs of full lines), for every k (1 to 10 slots per line); every slot decodes back to
+    # its k-mer (what "compact_table" rebuilds the sorted table from)
     for load in (60, 10, 80):
-        lines = hostlib.bft_hosttest_kmer_hash(h, load)
+        nl = hostlib.bft_hosttest_kmer_hash(h, load)
         if len(km) == 0:
-            assert lines == 0 and hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data) == -1
+            assert nl == 0 and hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data) == -1
             continue
-        geo = np.zeros(6, np.uint32)
+        geo = np.zeros(13, np.uint32)
         hostlib.bft_hosttest_kh_geometry(h, geo.ctypes.data)
-        S_, f_, rb_, cb_, tail_, wb_ = (int(x) for x in geo)
+        S_, f_, wb_, cb_, kb_, qb_, hb_, restb_, t_, m_, nl_, maxd_, db_ = (int(x) for x in geo)
         n_st = len(S.distinct(km))
-        fits = lambda s_: cb_ + rb_ - min(32, 128 // s_ - 1, rb_) <= 8 * (48 // s_)
-        assert rb_ == 2 * k - 18 and (1 << cb_) > n_st and f_ == min(32, 128 // S_ - 1, rb_) and wb_ == 48 // S_ and fits(S_) and (S_ == 10 or not fits(S_ + 1))
-        assert lines >= -(-n_st * 100 // (S_ * load)) and tail_ in (1, 2, 4, 32)
+        assert nl > 0  # (displacements beyond three bits' worth of lines -- one slot per line, 80 % -- take a second attempt with more bits)
+        assert hb_ == min(32, 2 * k) and restb_ == 2 * k - hb_ and (1 << cb_) > n_st and kb_ == restb_ + qb_ and f_ == min(32, 128 // S_ - 1, kb_)
+        assert wb_ == 48 // S_ and cb_ + db_ + kb_ - f_ <= 8 * wb_ and nl == nl_ == (m_ << (hb_ - t_)) and t_ <= 27 and 2 <= m_ <= 32
+        assert maxd_ < (1 << db_) and (db_ == 3 or S_ <= 4) and nl * S_ * load >= n_st * 100 and (1 << qb_) >= -(-(1 << t_) // m_)
         got = hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         assert got == int(S.from_bits(bits, len(q)).sum()) and (bits8 == bits).all() and (rows8 == rows).all(), load
-        # ... and the container walk that looks plain root groups up in their regions of the table (the table's values are the rows here)
+        assert hostlib.bft_hosttest_kh_roundtrip(h) == 1, load
+        # ... and the container walk that looks plain root groups up in the table (the table's values are the rows here)
         hostlib.bft_hosttest_root_direct(h, 2)
         if hostlib.bft_hosttest_walk_kh(h, 1):
             hostlib.bft_hosttest_query(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
