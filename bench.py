@@ -18,10 +18,13 @@ RCCL all_gather of the presence bitmaps.  Inputs are resident in HBM before the 
 `python bench.py --gpus N` without torchrun starts the N ranks itself (fresh child processes, before this process touches a GPU).
 
 roofline: `traffic` = HBM bytes per launch from hardware counters collected IN THIS RUN (tools/pmc_live.py: rocprofv3 --pmc passes in
-child processes after the timed region, so the counters describe the library that was timed), `achieved` = traffic / mean kernel
-time, `frac` = achieved / 8 TB/s.  Without a profiler the figures come from profiles/r03/pmc_query.json when its source hash matches
-the library's, else `frac` is null and `pmc_stale` true.  `gather` = L2 misses per second against the measured random-gather
-ceiling of the chip -- the limit that binds this kernel.
+child processes after the timed region -- same library, same workload generator and seed as the timed batch --: FETCH_SIZE + WRITE_SIZE as
+counted, `traffic_counted`, plus a calibrated correction for the coalesced query stream the fetch counter tallies at half, `stream_correction`),
+`achieved` = traffic / mean kernel time (HIP events on the launch stream), `frac` = achieved / 8 TB/s -- an estimate resting on that
+calibration, not a bound.  Without a profiler the figures come from profiles/r04/pmc_query.json when its source hash matches the library's,
+else `frac` is null and `pmc_stale` true.  `gather` = L2 misses per second against the measured random-gather ceiling of the chip -- the
+limit that binds this kernel.  The container walk ("walk_hash": plain root groups in hashed form, special prefixes
+through the containers) gets the same block of its own under `container_walk.roofline`.
 """
 import argparse
 import json
@@ -43,6 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (6.3 TB/s a
 # inside the 256 MiB Infinity Cache, 49 G/s on an 8 GiB one)
 GATHER_CEILING_G = 56.0
 GATHER_CEILING_SRC = "profiles/r03/microbench_gather.jsonl (indep4, 1 GiB table; dependent chains: 55.2)"
+PMC_FALLBACK = "r04/pmc_query.json"
 
 
 def parse():
@@ -136,12 +140,12 @@ def load_profile_json(name):
 
 
 def roofline_block(pmc, nq, avg_ms, launches, kernel, kmer_bytes, live):
-    """frac = HBM bytes per launch (hardware counters) / mean kernel time / 8 TB/s: at most 1 by construction.  design = the bytes the
+    """frac = HBM bytes per launch (hardware counters + the calibrated stream correction) / mean kernel time / 8 TB/s.  design = the bytes the
     layout needs per query (the packed k-mer, its answer bit, one 64-byte line of the k-mer hash); wasted = counter / design."""
     design = kmer_bytes + 0.125 + 64.0
     out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel,
            "avg_launch_ms": round(avg_ms, 4), "launches": int(launches), "design_bytes_per_query": round(design, 3),
-           "pmc": "live (tools/pmc_live.py, this run)" if live else "profiles/r03/pmc_query.json"}
+           "pmc": "live (tools/pmc_live.py, this run)" if live else "profiles/" + PMC_FALLBACK}
     if not pmc or "hbm_bytes_per_query" not in pmc:
         out["pmc_stale"] = True
         out["pmc"] = (pmc or {}).get("error", "no counter figures for this library")
@@ -150,9 +154,10 @@ def roofline_block(pmc, nq, avg_ms, launches, kernel, kmer_bytes, live):
     traffic = per_q * nq
     achieved = traffic / (avg_ms * 1e-3) / 1e9
     out.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": round(traffic),
-                "hbm_bytes_per_query": per_q, "wasted": round(per_q / design, 3),
-                "traffic_note": "FETCH_SIZE x 1024 (64 B tallied per L2->fabric read request: exact for whole-line gathers, profiles/r03/pmc_microbench.json) "
-                                "+ WRITE_SIZE x 1024 + half of the coalesced query stream (tallied at 1/2, MI355X_MICROARCH.md HBM)",
+                "traffic_counted": round(pmc.get("fetch_bytes_tallied", 0) + pmc.get("write_bytes", 0)), "stream_correction": round(pmc.get("stream_correction_bytes", 0)),
+                "hbm_bytes_per_query": per_q, "wasted": round(per_q / design, 3), "frac_is": "estimate (counters + calibrated stream correction), not a bound",
+                "traffic_note": "traffic = traffic_counted (FETCH_SIZE x 1024: 64 B tallied per L2->fabric read request, exact for whole-line gathers, profiles/r03/pmc_microbench.json; "
+                                "+ WRITE_SIZE x 1024) + stream_correction (half of the coalesced query stream, which the fetch counter tallies at 1/2: MI355X_MICROARCH.md HBM)",
                 "kernel_us_under_pmc": pmc.get("kernel_us_under_pmc_mean"), "lib_source_hash": pmc.get("lib_source_hash")})
     mpq = pmc.get("l2_misses_per_query")
     if mpq:
@@ -162,21 +167,21 @@ def roofline_block(pmc, nq, avg_ms, launches, kernel, kmer_bytes, live):
     return out
 
 
-def pmc_for(workload_key, nq, kmer_bytes, allow_live):
-    """counter figures for the query kernel on `workload_key` (tools/pmc_query.py name): live passes, else the committed file if it
-    was collected on this library's sources"""
+def pmc_for(workload_key, nq, kmer_bytes, allow_live, opts=(), stored_key=None):
+    """counter figures for the query kernel on `workload_key` (tools/pmc_query.py name) with the options `opts`: live passes, else the
+    committed file if it was collected on this library's sources"""
     from tools import pmc_live
     if allow_live:
-        res = pmc_live.collect(workload_key, nq, 3, "k_query", kmer_bytes=kmer_bytes)
+        res = pmc_live.collect(workload_key, nq, 3, "k_query", opts=opts, kmer_bytes=kmer_bytes)
         if "error" not in res and "hbm_bytes_per_query" in res:
             return res, True
         err = res.get("error")
     else:
         err = "live collection disabled"
-    stored = (load_profile_json("r03/pmc_query.json") or {}).get(workload_key)
+    stored = (load_profile_json(PMC_FALLBACK) or {}).get(stored_key or workload_key)
     if stored and stored.get("lib_source_hash") == pmc_live.source_hash() and stored.get("queries_per_launch") == nq:
         return stored, False
-    return {"error": f"{err}; profiles/r03/pmc_query.json is for other sources"}, False
+    return {"error": f"{err}; profiles/{PMC_FALLBACK} is for other sources"}, False
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -298,8 +303,9 @@ def main():
         "parity_ok": parity_ok,
         "answers_checked_per_gpu": nq,
         "present_fraction": round(n_present / nq, 4),
-        "build": {"insert_build_s": round(t_insert, 3), "M_pairs_per_s": round(n_pairs_in / max(t_insert, 1e-9) / 1e6, 1),
-                  "note": "100 stream-ordered insert calls + bft_gpu_build, torch's window packing and per-genome key tables included (tools/bench_insert.py times the library alone)",
+        "build": {"insert_build_s_incl_torch": round(t_insert, 3), "M_pairs_per_s_incl_torch_packing": round(n_pairs_in / max(t_insert, 1e-9) / 1e6, 1),
+                  "note": "NOT the library's build rate: 100 stream-ordered insert calls + bft_gpu_build TOGETHER WITH torch's window packing and per-genome key tables of this "
+                          "script (tools/bench_insert.py times the library alone: profiles/r04/insert_config3.json)",
                   **{k_: round(v, 2) for k_, v in build_times.items() if not k_.startswith("_")}},
     }
     avg_ms = kern_ms / max(1, launches)
@@ -333,19 +339,25 @@ def main():
                                 "image_bytes_per_kmer": round(img / info["kmers"], 2), "file_bytes_per_kmer": round(fb / info["kmers"], 2),
                                 "parts": fp, "write_bft_s": round(t_w, 2),
                                 "note": "image = every array a query may touch (the index is its own store: no (k-mer, genome) pair list is kept)"}
-            # "compact_table": the sorted table and the colour set per k-mer leave HBM (the k-mer hash holds both); the same launches, timed
+            # the image as queries leave it ("compact_table", the default: the sorted table and the colour set per k-mer are not resident --
+            # the k-mer hash holds both; write_bft just brought them back) against the image with the table kept; the same launches, timed
             try:
                 bft.set_option("compact_table", 1)
-                cimg = bft.info()["image_bytes"]
+                cimg, cfp = bft.info()["image_bytes"], bft.footprint()
                 bits_c = torch.zeros_like(dbits)
                 c_ms = timed_launches(bft, dq.data_ptr(), nq, bits_c.data_ptr(), stream, 5)
                 same = bool(torch.equal(bits_c, dbits))
                 del bits_c
-                out["footprint"]["compact_table"] = {"image_bytes": cimg, "image_over_file": round(cimg / fb, 2), "image_bytes_per_kmer": round(cimg / info["kmers"], 2),
-                                                     "M_kmers_per_s": round(nq / c_ms / 1e3, 1), "same_bits": same,
-                                                     "note": "bft_gpu_set_option(compact_table, 1): rows, extraction, merges, .bft files and the container walk bring the table back first"}
-            finally:
                 bft.set_option("compact_table", 0)
+                timg = bft.info()["image_bytes"]
+                out["footprint"].update({"image_bytes": cimg, "image_over_file": round(cimg / fb, 2), "image_bytes_per_kmer": round(cimg / info["kmers"], 2), "parts": cfp,
+                                         "M_kmers_per_s": round(nq / c_ms / 1e3, 1), "same_bits": same,
+                                         "kmer_hash_bytes_per_kmer": round(cfp["kmer_hash"] / info["kmers"], 2),
+                                         "with_sorted_table": {"image_bytes": timg, "image_over_file": round(timg / fb, 2), "image_bytes_per_kmer": round(timg / info["kmers"], 2),
+                                                               "note": "bft_gpu_set_option(compact_table, 0), or after rows / extraction / a merge / write_bft / the container walk "
+                                                                       "brought the table back (it then stays until the next build)"}})
+            finally:
+                bft.set_option("compact_table", 1)
         except Exception as e:
             out["footprint"] = {"error": repr(e), "parts": fp}
 
@@ -356,20 +368,35 @@ def main():
     if world == 1 and not args.no_cpu_baseline and bft_path and os.path.exists(bft_path):
         try:
             from oracle import oracle as O
-            cores = os.cpu_count() or 1
+            # the cores this process may run on: the affinity mask, cut by the cgroup's CPU quota when there is one
+            cores_os = os.cpu_count() or 1
+            cores_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores_os
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    quota = float(q) / float(per)
+            except Exception:
+                pass
+            cores = max(1, min(cores_aff, int(quota) if quota and quota >= 1 else cores_aff))
             t0 = time.time()
             orc = O.OracleBFT.load_bft(bft_path)
             orc.freeze()  # (the packed arrays of include/CC.h:34-67 the query loop runs on: built here, not inside the timed loop)
             t_load = time.time() - t0
             ns = args.cpu_sample or min(nq, 400_000 * cores)
             sample = np.ascontiguousarray(dq[:ns].cpu().numpy())
+            orc.query_presence(sample[: min(ns, 200_000 * cores)], threads=cores)  # (first touch of the trie's pages by the threads that will read them)
             t0 = time.time()
             obits = orc.query_presence(sample, threads=cores)
             t_q = time.time() - t0
-            n1 = min(ns, 2_000_000)
-            t0 = time.time()
-            orc.query_presence(sample[:n1], threads=1)
-            t_q1 = time.time() - t0
+            scaling = {}
+            for th in sorted({1, 8, 64, cores}):
+                if th > cores:
+                    continue
+                n_th = min(ns, 1_500_000 * th)
+                t0 = time.time()
+                orc.query_presence(sample[:n_th], threads=th)
+                scaling[str(th)] = round(n_th / (time.time() - t0) / 1e6, 3)
             orc.close()
             gpu_bits = dbits[: (ns + 7) // 8].cpu().numpy()
             tail = ns % 8
@@ -378,8 +405,10 @@ def main():
             out["cpu_baseline"] = {
                 "value": round(ns / t_q / 1e6, 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
                 "sample": f"first {ns} queries of the same batch; the oracle's isKmerPresent loop over {cores} threads on the trie the GPU built, read from the "
-                          f".bft file it wrote by the oracle's restatement of read_BFT_Root ({t_load:.1f} s); 1 thread: {n1 / t_q1 / 1e6:.3f} M k-mers/s",
-                "single_thread": round(n1 / t_q1 / 1e6, 3),
+                          f".bft file it wrote by the oracle's restatement of read_BFT_Root ({t_load:.1f} s)",
+                "cores_detail": {"os_cpu_count": cores_os, "sched_affinity": cores_aff, "cgroup_cpu_quota": quota, "threads_used": cores},
+                "M_kmers_per_s_by_threads": scaling, "single_thread": scaling.get("1"),
+                "note": "a reported baseline, not the target; the thread-scaling row says how far the host's memory system carries the loop",
             }
             if args.measure_ref_scan:  # the counting build of the oracle on the same file (another load): SURVEY 8d's S, live
                 cnt = O.OracleBFT.load_bft(bft_path, count=True)
@@ -411,17 +440,30 @@ def main():
         out["roofline"]["ref_scan_bytes_avoided"] = round(ref_scan / out["roofline"]["hbm_bytes_per_query"], 2)
 
     if secondary:
-        # ---- the same index through the container walk alone (no k-mer hash): presenceKmer / findCluster / suffix search as kernels ----
+        # ---- the same index through the container walk: presenceKmer's root level (root range / direct tables) -> a plain suffix group in
+        # its hashed form (one line of the k-mer hash), or -- child Node, root UC -- Bloom probe / node prefix hash -> filter2 rank -> cluster
+        # -> prefix entry -> suffix-group probes of the sorted rows (k_query6h); and with every suffix group searched in the sorted table ----
         try:
-            bft.set_option("kmer_hash", 0)
+            bft.set_option("walk_hash", 1)
             bits_w = torch.zeros_like(dbits)
             ms_w = timed_launches(bft, dq.data_ptr(), nq, bits_w.data_ptr(), stream, max(3, args.steps // 2))
             out["container_walk"] = {"value": round(nq / ms_w / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms_w, 4), "same_bits": bool(torch.equal(bits_w, dbits)),
-                                     "note": "bft_gpu_set_option(kmer_hash, 0): Bloom probe / root tables -> filter2 rank -> cluster -> prefix entry -> suffix-group probes of the sorted table (k_query6)"}
+                                     "note": "bft_gpu_set_option(walk_hash, 1): the container walk answers (k_query6h); plain suffix groups of the root are looked up in their "
+                                             "hashed form (the k-mer hash: one line), special prefixes (child Nodes, root UC) walk the containers and probe sorted rows"}
+            if std:
+                pmc_w, live_w = pmc_for("cfg4", nq, B, allow_live=not args.no_pmc, opts=("walk_hash=1",), stored_key="cfg4_walk_hash")
+                out["container_walk"]["roofline"] = roofline_block(pmc_w, nq, ms_w, max(3, args.steps // 2), "k_query6h", B, live_w)
+            bft.set_option("walk_hash", 0)
+            bft.set_option("kmer_hash", 0)
+            ms_s = timed_launches(bft, dq.data_ptr(), nq, bits_w.data_ptr(), stream, 3)
+            out["container_walk"]["sorted_table_only"] = {"value": round(nq / ms_s / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms_s, 4),
+                                                          "same_bits": bool(torch.equal(bits_w, dbits)),
+                                                          "note": "bft_gpu_set_option(kmer_hash, 0): no hashed form at all; every suffix group by block probes of the sorted table "
+                                                                  "from a guess interpolated inside its quarter (k_query6)"}
             bft.set_option("kmer_hash", 1)
             del bits_w
         except Exception as e:
-            out["container_walk"] = {"error": repr(e)}
+            out["container_walk"] = dict(out.get("container_walk") or {}, error=repr(e))
         bft.close()
         del dq, qk, allk
         torch.cuda.empty_cache()

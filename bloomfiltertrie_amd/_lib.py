@@ -59,6 +59,10 @@ SIGNATURES = {
     "bft_gpu_group_query_presence": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "bft_gpu_group_query_color_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_group_query_branching": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    "bft_gpu_group_member_device": (C.c_int, [_P, C.c_int]),
+    "bft_gpu_group_query_presence_dev": (C.c_int, [_P, _P, _P, _P, _P]),
+    "bft_gpu_group_query_color_rows_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "bft_gpu_group_query_branching_dev": (C.c_int, [_P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -337,6 +337,29 @@ class BFTGroup:
         _lib.check(self._lib.bft_gpu_group_query_branching(self._g, kmers.ctypes.data, n, bits.ctypes.data, counts.ctypes.data if with_counts else None))
         return (bits, counts) if with_counts else bits
 
+    # -- device-resident batches: one per slot, in the memory of that slot's GPU; only enqueues (bft_gpu_group_*_dev) --------------
+    def member_device(self, i):
+        return self._lib.bft_gpu_group_member_device(self._g, i)
+
+    @staticmethod
+    def _ptrs(vals):
+        return (C.c_void_p * len(vals))(*[C.c_void_p(v) if v else None for v in vals])
+
+    def query_presence_dev(self, d_kmers, n, d_bits, streams=None):
+        """d_kmers / d_bits / streams: device pointers (ints) per slot; n: k-mers per slot"""
+        ns = (C.c_uint64 * len(n))(*n)
+        _lib.check(self._lib.bft_gpu_group_query_presence_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(streams) if streams else None))
+
+    def query_color_rows_dev(self, d_kmers, n, d_bits, d_rows, d_scratch, streams=None):
+        ns = (C.c_uint64 * len(n))(*n)
+        _lib.check(self._lib.bft_gpu_group_query_color_rows_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(d_rows), self._ptrs(d_scratch),
+                                                                self._ptrs(streams) if streams else None))
+
+    def query_branching_dev(self, d_kmers, n, d_bits, d_counts=None, streams=None):
+        ns = (C.c_uint64 * len(n))(*n)
+        _lib.check(self._lib.bft_gpu_group_query_branching_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(d_counts) if d_counts else None,
+                                                               self._ptrs(streams) if streams else None))
+
 
 def shard(n, parts, i):
     """bft_gpu_group_shard: the contiguous 64-aligned slice [begin, end) of an n-query batch for part i of `parts`"""

@@ -265,9 +265,10 @@ struct bft_gpu {
     uint64_t kh_lines = 0;        // home lines
     bool opt_kmer_hash = true;    // "kmer_hash"
     bool opt_walk_hash = false;   // "walk_hash": presence / colour queries through the container walk, which looks plain root groups up in the table's regions
-    bool opt_compact = false;     // "compact_table": the sorted table and the colour set per k-mer are dropped once the k-mer hash holds them (ensure_table)
+    bool opt_compact = true;      // "compact_table" (default on): the sorted table and the colour set per k-mer are dropped once the k-mer hash holds them (ensure_table)
     bool table_dropped = false;   // d_tk / d_tcol are not resident: the k-mer hash is the only copy
-    uint32_t opt_kh_load = 60;    // "kmer_hash_load": per cent of the slots of a region's home lines in use
+    uint32_t opt_kh_load = 55;    // "kmer_hash_load": per cent of the slots of the home lines in use (55: 47.9 G k-mers/s at 15.0 B per k-mer on the config-4 share;
+                                  // 50: 48.4 / 16.6; 60: 45.7 / 13.5; 70: 39.3 / 11.7 -- profiles/r04/kh_forms.jsonl)
     double kh_ms = 0;             // GPU time of the last fill
     hipStream_t stream2 = nullptr; // bft_gpu_build fills the k-mer hash here while the containers are assembled on `stream`
     int opt_root_direct = 3;      // "root_direct": 0 = containers, 1 = direct table, 2 = direct table + range table, 3 = 1 or 2, whichever
@@ -1660,6 +1661,19 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     // rec: bytes per input record (B, or 8W for the zero-padded word records of the sequence path); load_x reads that many
+    if (h->im.walk_kh && PROBE == 0) {  // ("walk_hash": launch_query leaves im.walk_kh set only for this)
+        static std::atomic<uint64_t> attr_h{0};
+        if (!(attr_h.load(std::memory_order_acquire) & dev_bit)) {
+            HIPCK(hipFuncSetAttribute((const void*)k_query6h<W, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
+            attr_h.fetch_or(dev_bit, std::memory_order_release);
+        }
+        const uint64_t wgc = (n_chunks + BFT_BLOCK6 / 64 - 1) / (BFT_BLOCK6 / 64);
+        const dim3 gridh((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wgc, 512ull * h->opt_grid_mult)));
+        size_t ldsh = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
+        hipLaunchKernelGGL((k_query6h<W, STAGED>), gridh, dim3(BFT_BLOCK6), ldsh, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     if (res == 1) hipLaunchKernelGGL((k_query<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
     else if (res == 3) hipLaunchKernelGGL((k_query6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
     else hipLaunchKernelGGL((k_query8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
@@ -1669,7 +1683,7 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
 
 template <int W, bool STAGED>
 static int launch_query_ws(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
-    if (W <= BFT_PROBE_MAX_W && h->im.probe_big) return launch_query_k<W, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
+    if (W <= BFT_PROBE_MAX_W && h->im.probe_big && !h->im.walk_kh) return launch_query_k<W, STAGED, 1>(h, d_kmers, n, d_bits64, d_rows, s, rec);
     return launch_query_k<W, STAGED, 0>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
@@ -1679,17 +1693,23 @@ static int launch_query_w(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     return staged ? launch_query_ws<W, true>(h, d_kmers, n, d_bits64, d_rows, s, rec) : launch_query_ws<W, false>(h, d_kmers, n, d_bits64, d_rows, s, rec);
 }
 
-static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0) {
+// through_kh: plain root groups are looked up in the k-mer hash (k_query6h) -- the caller wants presence or colour sets, not rows
+static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec_bytes = 0, bool through_kh = false) {
     if (n == 0) return 0;
     const int rec = rec_bytes ? rec_bytes : h->B;
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
+    const uint32_t keep = h->im.walk_kh;
+    if (!through_kh) h->im.walk_kh = 0;
+    int rc = 0;
     switch (h->W) {
-    case 1: CK(launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
-    case 2: CK(launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
-    case 3: CK(launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
-    default: CK(launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s, rec)); break;
+    case 1: rc = launch_query_w<1>(h, d_kmers, n, d_bits64, d_rows, s, rec); break;
+    case 2: rc = launch_query_w<2>(h, d_kmers, n, d_bits64, d_rows, s, rec); break;
+    case 3: rc = launch_query_w<3>(h, d_kmers, n, d_bits64, d_rows, s, rec); break;
+    default: rc = launch_query_w<4>(h, d_kmers, n, d_bits64, d_rows, s, rec); break;
     }
+    h->im.walk_kh = keep;
+    CK(rc);
     CK(timing_end(h, s, e0, e1));
     return 0;
 }
@@ -1742,12 +1762,8 @@ static int launch_query(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t
     const bool no_rows = d_rows == nullptr || h->im.emit_cs;  // presence or colour sets: what the k-mer hash holds
     if (h->im.kh_lines != nullptr && no_rows && !h->opt_walk_hash) return launch_query_kh(h, d_kmers, n, d_bits64, d_rows, s, rec);
     CK(ensure_table(h));
-    // the walk may look plain root groups up in their regions of the k-mer hash when no row is asked for
-    const uint32_t keep = h->im.walk_kh;
-    if (!no_rows || !h->opt_walk_hash) h->im.walk_kh = 0;
-    const int rc = launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec);
-    h->im.walk_kh = keep;
-    return rc;
+    // the walk looks plain root groups up in the k-mer hash when no row is asked for ("walk_hash")
+    return launch_query_walk(h, d_kmers, n, d_bits64, d_rows, s, rec, no_rows && h->opt_walk_hash);
 }
 
 // Synthetic batch for tune_residency: k-mers of the index itself (pseudo-random rows of tk), every other one with a

@@ -19,6 +19,7 @@
 struct bft_gpu_group {
     std::vector<bft_gpu*> members;  // one handle per device slot
     std::vector<bool> owned;        // replicas made here (freed with the group); the source handle is the caller's
+    std::vector<int> devices;       // the device of every slot
     int k = 0, B = 0;
     uint32_t nb_genomes = 0;
 };
@@ -75,12 +76,13 @@ extern "C" int bft_gpu_group_create(bft_gpu* src, int src_device, const int* dev
         if (devices[i] == src_device && !src_used) {  // the source serves its own device (first slot that names it)
             g->members.push_back(src);
             g->owned.push_back(false);
+            g->devices.push_back(devices[i]);
             src_used = true;
             continue;
         }
         bft_gpu* r = nullptr;
         rc = replicate(src, src_device, devices[i], &r);
-        if (rc == 0) { g->members.push_back(r); g->owned.push_back(true); }
+        if (rc == 0) { g->members.push_back(r); g->owned.push_back(true); g->devices.push_back(devices[i]); }
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (rc != 0) {
@@ -104,6 +106,35 @@ extern "C" void bft_gpu_group_free(bft_gpu_group* g) {
 
 extern "C" int bft_gpu_group_size(bft_gpu_group* g) { return g ? (int)g->members.size() : 0; }
 
+extern "C" int bft_gpu_group_member_device(bft_gpu_group* g, int i) {
+    if (!g || i < 0 || i >= (int)g->members.size()) return -1;
+    return g->devices[(size_t)i];
+}
+
+// ---- device-resident batches: member i answers the batch that lies in ITS GPU's memory, on ITS stream.  Nothing here waits for a GPU and no
+// host thread is started: every member's call only enqueues (the single-GPU *_dev entry points are stream-ordered), so the members of the
+// group run side by side.  streams may be NULL (every member's own stream) and so may streams[i].
+extern "C" int bft_gpu_group_query_presence_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* hip_streams) {
+    if (!g || !d_kmers || !n || !d_present_bits) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    for (size_t i = 0; i < g->members.size(); i++)
+        if (n[i]) CK(bft_gpu_query_presence_dev(g->members[i], d_kmers[i], n[i], d_present_bits[i], hip_streams ? hip_streams[i] : nullptr));
+    return BFT_GPU_OK;
+}
+extern "C" int bft_gpu_group_query_color_rows_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* d_rows,
+                                                  void* const* d_scratch_rows_u32, void* const* hip_streams) {
+    if (!g || !d_kmers || !n || !d_present_bits || !d_rows || !d_scratch_rows_u32) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    for (size_t i = 0; i < g->members.size(); i++)
+        if (n[i]) CK(bft_gpu_query_color_rows_dev(g->members[i], d_kmers[i], n[i], d_present_bits[i], d_rows[i], d_scratch_rows_u32[i], hip_streams ? hip_streams[i] : nullptr));
+    return BFT_GPU_OK;
+}
+extern "C" int bft_gpu_group_query_branching_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_branching_bits, void* const* d_counts,
+                                                 void* const* hip_streams) {
+    if (!g || !d_kmers || !n || !d_branching_bits) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    for (size_t i = 0; i < g->members.size(); i++)
+        if (n[i]) CK(bft_gpu_query_branching_dev(g->members[i], d_kmers[i], n[i], d_branching_bits[i], d_counts ? d_counts[i] : nullptr, hip_streams ? hip_streams[i] : nullptr));
+    return BFT_GPU_OK;
+}
+
 // One host thread per member on its slice; the first failure (code and message) is reported on the calling thread.
 template <class F>
 static int run_sharded(bft_gpu_group* g, uint64_t n, F f) {
@@ -116,10 +147,15 @@ static int run_sharded(bft_gpu_group* g, uint64_t n, F f) {
     for (int i = 0; i < parts; i++) {
         const uint64_t a = lo[i], b = hi[i];
         if (b <= a) continue;
-        th.emplace_back([&, i, a, b] {
+        auto work = [&, i, a, b] {
             rc[i] = f(g->members[i], a, b - a);
             if (rc[i] != 0) msg[i] = bft_gpu_last_error();
-        });
+        };
+        try {
+            th.emplace_back(work);
+        } catch (...) {  // (no thread to be had: this slice is answered on the calling thread -- nothing may cross the extern "C" boundary)
+            work();
+        }
     }
     for (std::thread& t : th) t.join();
     for (int i = 0; i < parts; i++)
@@ -134,7 +170,7 @@ extern "C" int bft_gpu_group_query_presence(bft_gpu_group* g, const uint8_t* kme
 }
 
 extern "C" int bft_gpu_group_query_color_rows(bft_gpu_group* g, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint8_t* rows) {
-    if (!g || !rows || (!kmers && n)) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    if (!g || ((!rows || !kmers) && n)) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t B = (uint64_t)g->B, rowbytes = (g->nb_genomes + 7) / 8;
     return run_sharded(g, n, [&](bft_gpu* h, uint64_t a, uint64_t m) {
         return bft_gpu_query_color_rows(h, kmers + a * B, m, present_bits ? present_bits + a / 8 : nullptr, rows + a * rowbytes);

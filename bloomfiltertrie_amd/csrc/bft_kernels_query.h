@@ -57,7 +57,7 @@ struct BftRootLds {
 // slowest wavefront.
 #define BFT_WALK_PASSES 16u   // passes of 64 k-mers per chunk: one 128-byte line of presence bits
 
-template <int W, int BLOCK, bool STAGED, int PROBE>
+template <int W, int BLOCK, bool STAGED, int PROBE, bool WKH = false>
 __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                            uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -137,7 +137,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
                 load_x<W>(packed, i, B, end_aligned, x);
                 bft_tform_from_x<W>(x, im.k, t);
                 if (with_queue) {
-                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 1>(im, acc, root, t);
+                    const BftHit h = bft_walk<W, BftRootLds<STAGED>, PROBE, 1, WKH>(im, acc, root, t);
                     if (h.present == BFT_HIT_DEFERRED) parked = true;
                     else {
                         present = h.present;
@@ -217,6 +217,15 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
                                                                                                  uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
                                                                                                  uint32_t* __restrict__ ctr) {
     query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
+}
+
+// k_query6h: k_query6 with the lookup of plain root groups in the k-mer hash compiled in (4-row probes: only the few special prefixes
+// search sorted rows at all) -- the kernel of "walk_hash".
+template <int W, bool STAGED>
+__global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6h(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
+                                                                                                  uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
+                                                                                                  uint32_t* __restrict__ ctr) {
+    query_body<W, BFT_BLOCK6, STAGED, 0, true>(im, packed, n, B, bits64, rows, ctr);
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):

@@ -945,7 +945,15 @@ BFT_HD void bft_group_search(const BftImage& im, uint64_t idx, uint32_t cnt, con
 // again later with mode 2 (k_query queues those lanes and walks them together: a wavefront no longer pays the long
 // container path for its few special lanes); 2 = rdir entry for every prefix (skips the range table).
 #define BFT_HIT_DEFERRED 2
-template <int W, class Root, int PROBE = -1, int ROOTMODE = 0>
+// WKH: the lookup of plain root groups in the k-mer hash (im.walk_kh) is compiled in at all -- the host restatement, and the kernels
+// launched for "walk_hash" (k_query6h); everywhere else its registers would be dead weight (the 8-row probe kernels spilled 50-110 VGPRs
+// with it).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BFT_WKH_DEFAULT false
+#else
+#define BFT_WKH_DEFAULT true
+#endif
+template <int W, class Root, int PROBE = -1, int ROOTMODE = 0, bool WKH = BFT_WKH_DEFAULT>
 BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& start_node, const uint64_t* t, const int d0 = 0) {
     BftHit hit;
     hit.present = 0;
@@ -981,7 +989,7 @@ BFT_HD BftHit bft_walk(const BftImage& im, const Root& root, const BftNode& star
         if (d == 0 && im.rdir != nullptr) {
             // Root level through the derived tables (bft_image.h).  Plain suffix groups: two adjacent words of the 1 MiB range
             // table give {first row, count}.
-            if (ROOTMODE != 2 && im.walk_kh) {
+            if (WKH && ROOTMODE != 2 && im.walk_kh) {
                 // A plain suffix group of the root in its hashed form: the k-mer hash (bft_image.h, BFT_KH_*) holds the group's suffixes with
                 // their colour sets -- one line instead of the probes of the sorted rows (src/UC.c:81-124 finds the suffix by binary
                 // search; same answer).  Special prefixes (child Node, UC rows: one bit per prefix in rspec) keep the containers.

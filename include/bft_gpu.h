@@ -151,30 +151,36 @@ int bft_gpu_info(bft_gpu* h, uint64_t* out, int n_out);
 int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
 
 /* Options.
- * "kmer_hash" (1, default): besides the containers, every stored k-mer also sits in one open-addressed table of 64-byte lines keyed by its
- *   T-form, value = its colour-set id; presence, colour, sequence and branching queries then cost ONE cache line per k-mer instead of a
- *   container walk (src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe).  k <= 63 with 2k % 64 != 0; the table is
- *   derived when an image is built, loaded or unpacked; rows (bft_gpu_query_rows) always come from the walk.  0: every query walks the containers.
- * "kmer_hash_load" (50): occupancy of that table in per cent, 10..80 (50 = two slots per k-mer: 1.03-1.07 lines read per lookup).
- * "query_dynamic" (1, default): the k-mer hash kernels claim their blocks of k-mers, up to "query_chunk" (4) blocks of 256 at a time, from a counter
- *   (one per stream that launches them) instead of splitting the batch by workgroup number -- workgroups are bound to an XCD by their number, and a
- *   static split makes the launch as slow as the XCD that reaches the table slowest; batches below "query_dynamic_min" (2^25) k-mers keep the static
- *   split (the claims cost ~50 us per launch on their one counter: profiles/r03/probe_dynamic_sizes.jsonl).  0: always static.
+ * "kmer_hash" (1, default): besides the containers, every stored k-mer also sits in one open-addressed table of 64-byte lines (bft_image.h,
+ *   BFT_KH_*: home line from a scattering bijection of the T-form's top 32 bits, which the line then stands for -- a slot stores 2k - 32 + ~9
+ *   key bits and the colour-set id, 8 k-mers per line at k = 27 / 31 and 100 genomes); presence, colour, sequence and branching queries then cost
+ *   ONE cache line per k-mer instead of a container walk (src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe).  Any
+ *   k; derived when an image is built, loaded or unpacked; rows (bft_gpu_query_rows) always come from the walk.  0: no table, every query walks
+ *   the containers and searches the sorted table.
+ * "kmer_hash_load" (55): occupancy of the table's home lines in per cent, 10..80 (55: 1.06 lines read per lookup, 15 bytes per k-mer at k = 27).
+ * "walk_hash" (0, default; 1: presence / colour queries are answered by the container walk, k_query6h, whose root level looks PLAIN suffix groups up in
+ *   their hashed form -- the table above: one line -- and walks the containers for the rest: child Nodes, the root's UC).
+ * "query_dynamic" (1, default): the query kernels deal their blocks of k-mers out in rounds: the first by workgroup (wavefront) number, the others
+ *   claimed from a counter (one pair per stream that launches them, allocated when the first image is built) -- workgroups are bound to an XCD by
+ *   their number, and a static split makes the launch as slow as the XCD that reaches the table slowest; "query_chunk" (4) blocks of 256 per round
+ *   of the k-mer hash kernels; batches below "query_dynamic_min" (2^16) k-mers are split statically; a handle queried on more than 32 streams
+ *   runs the extra streams' launches static (counted: bft_gpu_build_time entry 20).  0: always static.
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
  *   "query_grid_mult" (grid = resident workgroups x value), "node_hash" (the prefix entries of the nodes below the root also go into one hash table keyed
  *   by (node, prefix) -- one cache line per level of a deep trie instead of four: 1, default = when the image has no k-mer hash, i.e. when the walk answers
- *   every query; 2 = always; 0 = never), "root_direct" (the root level
+ *   every query ("kmer_hash" 0, "walk_hash" 1); 2 = always; 0 = never), "root_quartiles" (1, default: a 1 MiB table of the quarter boundaries of every plain root
+ *   group: its sorted rows are searched from a guess interpolated inside the k-mer's quarter), "root_direct" (the root level
  *   goes through tables derived from the containers: 1 = a 2 MiB table with one entry per 18-bit prefix; 2 = a 1 MiB table of row ranges for the plain
  *   suffix groups, backed by the 2 MiB table; 3, default = 2 unless most root prefixes are child Nodes; 0 = the containers), "flat_min" (CCs with at
  *   least this many prefixes also get the two-load flat form; default 3584 = the CCs in s=4 mode; 65536 = none), "tune" (1: measure residency, probe
  *   mode and root tables of the walk on the current image with a batch drawn from the index -- the only call that times anything; it synchronises;
  *   nothing is ever tuned implicitly by a build or a query).
- * Footprint: "compact_table" (0, default; 1: the sorted k-mer table and the colour set per k-mer -- 12 bytes per k-mer -- do not stay resident once the
+ * Footprint: "compact_table" (1, default: the sorted k-mer table and the colour set per k-mer -- 12 bytes per k-mer -- do not stay resident once the
  *   k-mer hash holds every (k-mer, colour set): presence, colour-row, branching and sequence queries never need them; rows, extraction, a merge
  *   of new insertions, .bft files, packed images, the container walk and "tune" bring them back first -- a dump of the table + one sort, milliseconds --
- *   and they stay until the next build or until the option is set again.  No effect on a handle without a k-mer hash (k >= 64, 2k % 64 == 0, "kmer_hash" 0)).
+ *   and they stay until the next build or until the option is set again.  No effect on a handle without a k-mer hash ("kmer_hash" 0).  0: the table stays.)
  * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending take the root-prefix front end -- as 8-byte composites
  *   k-mer << bits | genome where that fits 63 bits, as (k-mer, id) pairs whose composite is formed inside a bucket otherwise; 0: the general key + value
  *   sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
@@ -218,9 +224,10 @@ int bft_gpu_query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint
  * (include/bft.h:97, src/bft.c:363-387): mode 0 (bitmap, genome g <-> bit g+2), 1 (ranges) or 2 (id list), chosen the way the
  * reference chooses it: compute_best_mode re-decides at every insertion of a genome id and keeps the current mode on a size tie
  * (src/annotation.c:621-653), so the bytes depend on the order the ids arrived in -- ascending -- and the rule is replayed over the
- * sorted id list (e.g. {6,7} stays the id list 1a 1e it started as, although a bitmap would be no longer).  Not modelled: the
- * never-set disabled_flags (:622) and the run-end size estimate in bitmap mode beyond 4096 genomes (:515-523).  The same bytes go
- * into the .bft files bft_gpu_write_bft writes.  annot may be NULL to query the size. */
+ * sorted id list (e.g. {6,7} stays the id list 1a 1e it started as, although a bitmap would be no longer), the run-end size estimate of the
+ * bitmap mode included (:515-523: the end of a run is priced with the byte count of the id one past it).  disabled_flags (:622) is never set
+ * anywhere in the reference: nothing to replay.  The same bytes go into the .bft files bft_gpu_write_bft writes.  annot may be NULL to
+ * query the size. */
 int bft_gpu_colorset_annot(bft_gpu* h, uint32_t colorset, uint8_t* annot, uint32_t cap, uint32_t* n_out);
 
 /* Replication of a built index on another GPU (the query path shards over GPUs with the trie image
@@ -249,6 +256,17 @@ int bft_gpu_group_size(bft_gpu_group* g);
 int bft_gpu_group_query_presence(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits);
 int bft_gpu_group_query_color_rows(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits, uint8_t* rows);
 int bft_gpu_group_query_branching(bft_gpu_group* g, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* branching_bits, uint8_t* counts);
+/* The same on DEVICE-RESIDENT batches: arrays of bft_gpu_group_size(g) entries, entry i = the batch of slot i -- d_kmers[i] (n[i] packed k-mers)
+ * and the outputs lie in the memory of GPU bft_gpu_group_member_device(g, i); hip_streams[i] (or NULL: the slot's own stream; hip_streams itself
+ * may be NULL) orders the work.  Like the single-GPU *_dev calls these only enqueue: no host thread, no synchronisation, the slots run side by
+ * side; the caller synchronises its streams (a caller that owns one shard per GPU -- the partition of bft_gpu_group_shard or any other -- keeps
+ * every buffer where it is produced and consumed: the resident rate of every GPU, not the host link's).  n[i] == 0 skips slot i. */
+int bft_gpu_group_member_device(bft_gpu_group* g, int i);
+int bft_gpu_group_query_presence_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* hip_streams);
+int bft_gpu_group_query_color_rows_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* d_rows,
+                                       void* const* d_scratch_rows_u32, void* const* hip_streams);
+int bft_gpu_group_query_branching_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_branching_bits, void* const* d_counts,
+                                      void* const* hip_streams);
 
 #ifdef __cplusplus
 }

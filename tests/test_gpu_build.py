@@ -551,6 +551,7 @@ def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
     anc = S.random_genome(50000, k)
     genomes = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 20 + g), k)) for g in range(6)]
     a, b = BFT(k), BFT(k)
+    a.set_option("compact_table", 0)  # (the option is on by default since round 4)
     b.set_option("compact_table", 1)
     for t in (a, b):
         for g in range(4):
@@ -625,6 +626,17 @@ def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
     b.set_option("kmer_hash", 0)
     assert b.footprint()["kmer_table"] > 0
     assert (a.query_presence(q2) == b.query_presence(q2)).all()
+    # options that re-derive tables FROM the sorted table while it is away bring it back themselves (round 3's advice: "flat_min" and
+    # "root_direct" read a NULL table and refilled the k-mer hash from it)
+    b.set_option("kmer_hash", 1)
+    b.set_option("compact_table", 1)
+    assert b.footprint()["kmer_table"] == 0
+    for name, v in (("flat_min", 2000), ("root_direct", 1), ("root_direct", 3), ("root_quartiles", 0), ("root_quartiles", 1), ("walk_hash", 1)):
+        b.set_option(name, v)
+        assert b.footprint()["kmer_table"] == 0 or name == "walk_hash", name
+        assert (a.query_presence(q2) == b.query_presence(q2)).all(), name
+    ra, rb = a.query_color_rows(q2), b.query_color_rows(q2)
+    assert (ra[0] == rb[0]).all() and (ra[1] == rb[1]).all()
     a.close()
     b.close()
 

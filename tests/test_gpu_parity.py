@@ -692,3 +692,55 @@ def test_device_group_answers_like_one_handle(k, devices):
     with pytest.raises(Exception):
         BFTGroup(t, [99])
     t.close()
+
+
+@pytest.mark.parametrize("k", [27, 63])
+def test_device_group_on_resident_batches(k):
+    """bft_gpu_group_*_dev: every slot answers the shard that lies in its GPU's memory on a stream of its own; nothing is synchronised by the
+    calls (the slots run side by side) -- presence, colour rows and branching of the shards equal the single handle's on the whole batch.
+    Three slots on the one device of this box: the shards of bft_gpu_group_shard."""
+    import torch
+    from bloomfiltertrie_amd import BFT, BFTGroup, shard
+    anc = S.random_genome(120000, k + 1)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 40 + g), k)) for g in range(9)]
+    t = BFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+    grp = BFTGroup(t, [0, 0, 0])
+    assert [grp.member_device(i) for i in range(3)] == [0, 0, 0] and grp.member_device(3) == -1
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(k)
+    base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])
+    n = 300_007
+    q = np.ascontiguousarray(base[rng.integers(0, len(base), n)])
+    ref_bits = t.query_presence(q)
+    ref_b2, ref_rows = t.query_color_rows(q)
+    ref_br, ref_cnt = t.query_branching(q, with_counts=True)
+    rowbytes = ref_rows.shape[1]
+    dev = torch.device("cuda", 0)
+    parts = [shard(n, 3, i) for i in range(3)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    dq = [torch.from_numpy(q[a:b]).to(dev) for a, b in parts]
+    ns = [b - a for a, b in parts]
+    bits = [torch.zeros(((m + 63) // 64) * 8, dtype=torch.uint8, device=dev) for m in ns]
+    rows = [torch.zeros((m, rowbytes), dtype=torch.uint8, device=dev) for m in ns]
+    scratch = [torch.zeros(m, dtype=torch.int32, device=dev) for m in ns]
+    brb = [torch.zeros(((m + 63) // 64) * 8, dtype=torch.uint8, device=dev) for m in ns]
+    cnt = [torch.zeros(m, dtype=torch.uint8, device=dev) for m in ns]
+    torch.cuda.synchronize()
+    sp = [s.cuda_stream for s in streams]
+    grp.query_presence_dev([x.data_ptr() for x in dq], ns, [x.data_ptr() for x in bits], sp)
+    torch.cuda.synchronize()
+    got = np.concatenate([x.cpu().numpy()[: (m + 7) // 8] for x, m in zip(bits, ns)])  # (shard starts are multiples of 64: byte ranges of the bitmap)
+    assert (got[: (n + 7) // 8] == ref_bits).all()
+    grp.query_color_rows_dev([x.data_ptr() for x in dq], ns, [x.data_ptr() for x in bits], [x.data_ptr() for x in rows], [x.data_ptr() for x in scratch], sp)
+    grp.query_branching_dev([x.data_ptr() for x in dq], ns, [x.data_ptr() for x in brb], [x.data_ptr() for x in cnt], sp)
+    torch.cuda.synchronize()
+    assert (np.concatenate([x.cpu().numpy() for x in rows]) == ref_rows).all()
+    assert (np.concatenate([x.cpu().numpy()[: (m + 7) // 8] for x, m in zip(brb, ns)])[: (n + 7) // 8] == ref_br).all()
+    assert (np.concatenate([x.cpu().numpy() for x in cnt]) == ref_cnt).all()
+    # a slot without work, the slots' own streams
+    grp.query_presence_dev([dq[0].data_ptr(), 0, dq[2].data_ptr()], [ns[0], 0, ns[2]], [bits[0].data_ptr(), 0, bits[2].data_ptr()], None)
+    torch.cuda.synchronize()
+    grp.close()
+    t.close()
