@@ -242,11 +242,12 @@ class BFT:
         return ms.value, n.value
 
     def build_time(self):
-        out = (C.c_double * 20)()
-        _lib.check(self._lib.bft_gpu_build_time(self._h, out, 20))
+        out = (C.c_double * 25)()
+        _lib.check(self._lib.bft_gpu_build_time(self._h, out, 25))
         return dict(zip(["gpu_sort_dedupe_ms", "color_intern_ms", "assemble_ms", "sort_redone_buckets", "derive_ms",
                          "query_wgs_per_cu", "tune_1wg_ms", "tune_2wg_ms", "query_probe_rows", "kmer_hash_lines", "kmer_hash_fill_ms",
-                         "sort_max_bucket", "intern_exact_passes", "process_hipmalloc_ms", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms"], list(out)))
+                         "sort_max_bucket", "intern_exact_passes", "process_hipmalloc_ms", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms",
+                         "claims_static_launches", "kmer_hash_slots", "kmer_hash_dbits", "kmer_hash_maxd", "kmer_hash_overflow"], list(out)))
 
     FOOTPRINT_FIELDS = ["kmer_table", "colorset_per_kmer", "colorset_dictionary", "containers", "flat_ccs", "root_tables", "node_prefix_hash", "kmer_hash",
                         "dictionary_bitmaps", "hash_table", "pair_store", "insertion_log"]

@@ -262,6 +262,8 @@ struct bft_gpu {
     int opt_node_hash = 1;        // "node_hash": 1 = derived when the image has no k-mer hash (the walk then answers every query), 2 = always, 0 = never
     uint64_t nph_inserted = 0, nph_dropped = 0;
     DevBuf d_kh, d_rspec;         // derived: k-mer hash (BFT_KH_*, bft_kh_build), optional; one "special" bit per root prefix for the walk (sync_walk_kh)
+    DevBuf d_kh_ovf_k, d_kh_ovf_v; // its overflow list (sorted k-mers, values)
+    uint32_t kh_ovf_n = 0;
     uint64_t kh_lines = 0;        // home lines
     bool opt_kmer_hash = true;    // "kmer_hash"
     bool opt_walk_hash = false;   // "walk_hash": presence / colour queries through the container walk, which looks plain root groups up in the table's regions
@@ -697,7 +699,7 @@ static int upload(DevBuf& d, const std::vector<T>& v) {
 static uint64_t image_bytes(const bft_gpu* h) {
     return h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_tk.bytes + h->d_tcol.bytes +
            h->d_uck.bytes + h->d_ucrow.bytes + h->d_cs_off.bytes + h->d_cs_ids.bytes + h->d_hashmod.bytes + h->d_cs_bm.bytes + h->d_ccx.bytes +
-           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes + h->d_rspec.bytes;
+           h->d_f18.bytes + h->d_fent.bytes + h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes + h->d_nph.bytes + h->d_kh.bytes + h->d_rspec.bytes + h->d_kh_ovf_k.bytes + h->d_kh_ovf_v.bytes;
 }
 
 static int tune_residency(bft_gpu* h);
@@ -721,6 +723,9 @@ static void point_image(bft_gpu* h, uint32_t nb_genomes) {
     im.tk = h->d_tk.as<uint64_t>();
     im.kh_lines = nullptr;    // (derive_kmer_hash)
     memset(&im.kh, 0, sizeof(im.kh));
+    im.kh_ovf = nullptr;
+    im.kh_ovf_val = nullptr;
+    im.kh_ovf_n = 0;
     im.rspec = nullptr;
     im.walk_kh = 0;
     im.tcol = h->d_tcol.as<uint32_t>();
@@ -881,11 +886,11 @@ static void derive_node_hash(bft_gpu* h) {
 // so it starts behind those (`after`: an event of the assembly stream) and overlaps the chain of small kernels and read-back counts that
 // follows.  kh_finish waits for it.  Any failure just leaves the image without the table.
 struct KhFill {
-    DevBuf buf, status;
+    DevBuf buf, status, ovf_k, ovf_v;
     BftKhScratch scratch;
     BftKhGeo geo;
     uint64_t lines_cap = 0, lines_used = 0;
-    uint32_t db = BFT_KH_DBITS, retry_db = 0;  // displacement bits of this attempt; of the next one, when this one met a larger displacement
+    uint32_t ovf_n = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, ew = nullptr;
     hipStream_t s2 = nullptr;
     bool started = false, prepared = false;
@@ -912,10 +917,12 @@ static void kh_prepare(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill& f) {
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
         if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); return; }
     }
-    f.geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_values), h->opt_kh_load, f.db);
+    f.geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_values), h->opt_kh_load);
     if (!kh_geo_ok(h, f.geo)) return;
     f.lines_cap = f.geo.nl + BFT_KH_TAIL_LINES;
-    if (f.buf.alloc(f.lines_cap * BFT_KH_LINE_WORDS * 8) != 0 || f.status.alloc(16) != 0) return;
+    if (f.buf.alloc(f.lines_cap * BFT_KH_LINE_WORDS * 8) != 0 || f.status.alloc(16) != 0 || f.ovf_k.alloc((size_t)BFT_KH_OVF_CAP * h->W * 8) != 0 ||
+        f.ovf_v.alloc((size_t)BFT_KH_OVF_CAP * 4) != 0)
+        return;
     f.prepared = (f.e0 || hipEventCreate(&f.e0) == hipSuccess) && (f.e1 || hipEventCreate(&f.e1) == hipSuccess) &&
                  (f.ew || hipEventCreateWithFlags(&f.ew, hipEventDisableTiming) == hipSuccess);
     if (!f.prepared) { (void)hipGetLastError(); f.buf.release(); }
@@ -936,7 +943,7 @@ static void kh_prepare_async(bft_gpu* h, uint64_t nk, uint64_t n_values, KhFill&
 static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, uint64_t nk, uint64_t n_sets, KhFill& f, hipStream_t after, hipStream_t run) {
     if (f.prep.joinable()) f.prep.join();
     if (!kh_wanted(h, nk)) return;
-    const BftKhGeo geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_sets), h->opt_kh_load, f.db);
+    const BftKhGeo geo = bft_kh_geometry(h->k, nk, std::max<uint64_t>(1, n_sets), h->opt_kh_load);
     if (!kh_geo_ok(h, geo)) return;
     // (prepared with a bound on the colour sets: keep the block unless the real geometry needs a tenth less)
     const uint64_t need = geo.nl + BFT_KH_TAIL_LINES;
@@ -946,8 +953,9 @@ static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, u
     if (!run) run = h->stream2;
     bool ok = true;
     if (after && after != run) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(run, f.ew, 0) == hipSuccess;
-    ok = ok && hipEventRecord(f.e0, run) == hipSuccess &&
-         bft_kh_build(d_tk, d_tcol, nk, h->k, h->W, f.geo, f.buf.as<uint64_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 && hipEventRecord(f.e1, run) == hipSuccess;
+    ok = ok && hipEventRecord(f.e0, run) == hipSuccess;
+    ok = ok && bft_kh_sort(d_tk, d_tcol, nk, h->k, h->W, f.geo, f.scratch, run) == 0 && bft_kh_lay(nk, h->k, h->W, f.geo, f.buf.as<uint64_t>(), f.ovf_k.as<uint64_t>(), f.ovf_v.as<uint32_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 &&
+         hipEventRecord(f.e1, run) == hipSuccess;
     f.s2 = run;
     f.started = true;  // (whatever was enqueued is waited for before the buffers go anywhere)
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(run); f.started = false; f.buf.release(); }
@@ -961,15 +969,29 @@ static bool kh_finish(bft_gpu* h, KhFill& f, double* ms) {
     if (f.e1) (void)hipEventDestroy(f.e1);
     f.e0 = f.e1 = nullptr;
     uint32_t st[4] = {2, 0, 0, 0};
-    if (ok) ok = hipMemcpy(st, f.status.p, 16, hipMemcpyDeviceToHost) == hipSuccess && st[0] == 0;
+    if (ok) ok = hipMemcpy(st, f.status.p, 16, hipMemcpyDeviceToHost) == hipSuccess && st[0] == 0 && st[3] <= BFT_KH_OVF_CAP;
     for (DevBuf& b : f.scratch.b) b.release();
     f.lines_used = st[1];
     f.geo.maxd = st[2];  // (a lookup looks no further than the table's largest displacement)
-    f.retry_db = st[0] == 1 && f.db == BFT_KH_DBITS ? bft_kh_retry_dbits(st[2]) : 0;  // a k-mer displaced beyond the slots' bits: once more with more
+    f.ovf_n = ok ? st[3] : 0;
+    if (ok && f.ovf_n) {  // the overflow list, sorted by k-mer (a handful: on the host)
+        const int W = h->W;
+        std::vector<uint64_t> kk((size_t)f.ovf_n * W), k2(kk.size());
+        std::vector<uint32_t> vv(f.ovf_n), v2(f.ovf_n), ord(f.ovf_n);
+        ok = hipMemcpy(kk.data(), f.ovf_k.p, kk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(vv.data(), f.ovf_v.p, vv.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        for (uint32_t i = 0; i < f.ovf_n; i++) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return std::lexicographical_compare(&kk[(size_t)a * W], &kk[(size_t)a * W] + W, &kk[(size_t)b * W], &kk[(size_t)b * W] + W); });
+        for (uint32_t i = 0; i < f.ovf_n; i++) {
+            for (int w = 0; w < W; w++) k2[(size_t)i * W + w] = kk[(size_t)ord[i] * W + w];
+            v2[i] = vv[ord[i]];
+        }
+        ok = ok && hipMemcpy(f.ovf_k.p, k2.data(), k2.size() * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(f.ovf_v.p, v2.data(), v2.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) { (void)hipGetLastError(); f.buf.release(); }
     if (getenv("BFT_GPU_VERBOSE"))
-        fprintf(stderr, "[bft_gpu] k-mer hash: %s, %llu home lines (2^%u x %u), %u slots (%u-bit header fields, %u-byte bodies: %u key bits (%u below the hashed %u, %u of q) + 3 + %u value bits), %.2f ms\n",
-                ok ? "built" : "NOT built", (unsigned long long)f.geo.nl, f.geo.hb - f.geo.t, f.geo.m, f.geo.S, f.geo.f, f.geo.wb, f.geo.kb, f.geo.restb, f.geo.hb, f.geo.qb, f.geo.cb, t);
+        fprintf(stderr, "[bft_gpu] k-mer hash: %s, %llu home lines (2^%u x %u), %u slots (%u-bit header fields, %u-byte bodies: %u key bits (%u below the hashed %u, %u of q) + %u + %u value bits), largest displacement %u, %u in the overflow list, %.2f ms\n",
+                ok ? "built" : "NOT built", (unsigned long long)f.geo.nl, f.geo.hb - f.geo.t, f.geo.m, f.geo.S, f.geo.f, f.geo.wb, f.geo.kb, f.geo.restb, f.geo.hb, f.geo.qb, f.geo.db, f.geo.cb,
+                f.geo.maxd, f.ovf_n, t);
     return ok;
 }
 // the table of a finished build becomes the image's
@@ -979,6 +1001,13 @@ static void kh_adopt(bft_gpu* h, KhFill& f, double ms) {
     h->kh_ms = ms;
     h->im.kh_lines = h->d_kh.as<uint64_t>();
     h->im.kh = f.geo;
+    h->d_kh_ovf_k.swap(f.ovf_k);
+    h->d_kh_ovf_v.swap(f.ovf_v);
+    h->kh_ovf_n = f.ovf_n;
+    if (!f.ovf_n) { h->d_kh_ovf_k.release(); h->d_kh_ovf_v.release(); }
+    h->im.kh_ovf = f.ovf_n ? h->d_kh_ovf_k.as<uint64_t>() : nullptr;
+    h->im.kh_ovf_val = f.ovf_n ? h->d_kh_ovf_v.as<uint32_t>() : nullptr;
+    h->im.kh_ovf_n = f.ovf_n;
 }
 static void kh_drop(bft_gpu* h) {
     h->d_kh.release();
@@ -986,22 +1015,24 @@ static void kh_drop(bft_gpu* h) {
     h->kh_ms = 0;
     h->im.kh_lines = nullptr;
     memset(&h->im.kh, 0, sizeof(h->im.kh));
+    h->d_kh_ovf_k.release();
+    h->d_kh_ovf_v.release();
+    h->kh_ovf_n = 0;
+    h->im.kh_ovf = nullptr;
+    h->im.kh_ovf_val = nullptr;
+    h->im.kh_ovf_n = 0;
     h->im.walk_kh = 0;
 }
 
 // Derives the k-mer hash of the image h->im points at (BFT_KH_*), on the handle's own stream.  An accelerator only: without it every
 // query walks the containers.
-static void derive_kmer_hash(bft_gpu* h, uint32_t db = BFT_KH_DBITS) {
+static void derive_kmer_hash(bft_gpu* h) {
     kh_drop(h);
     if (!kh_wanted(h, h->n_kmers)) return;
-    for (int attempt = 0; attempt < 2 && db; attempt++) {
-        KhFill f;
-        f.db = db;
-        kh_start(h, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->n_sets, f, nullptr, h->stream);
-        double ms = 0;
-        if (kh_finish(h, f, &ms)) { kh_adopt(h, f, ms); return; }
-        db = f.retry_db;
-    }
+    KhFill f;
+    kh_start(h, h->d_tk.as<uint64_t>(), h->d_tcol.as<uint32_t>(), h->n_kmers, h->n_sets, f, nullptr, h->stream);
+    double ms = 0;
+    if (kh_finish(h, f, &ms)) kh_adopt(h, f, ms);
 }
 
 // What the walk needs to look plain root groups up in the k-mer hash: one bit per root prefix, "not a plain suffix group of the root"
@@ -1477,7 +1508,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
     KhFill khf;  // the k-mer hash, filled beside the container assembly
-    if (!(h->built && h->n_kmers > 0) && nk > 0) kh_prepare_async(h, nk, nk, khf);  // (a merge changes the number of k-mers: kh_start prepares)
+    if (!(h->built && h->n_kmers > 0) && nk > 0) {  // (a merge changes the k-mers: kh_start does everything then)
+        // (the table's sort by home line started HERE, beside the colour-set interning, was measured: the interning's persistent grids and the
+        // sort starve each other -- 4.1 -> 10.5 ms for the interning, 20 -> 25.8 ms for the build; it starts behind the assembly's table passes)
+        kh_prepare_async(h, nk, nk, khf);
+    }
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
     bft_trace_mark("colour sets interned");
     seg_off.release();
@@ -1598,7 +1633,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     bft_trace_mark("committed (buffers released)");
     derive_root_direct(h);
     if (kh_ok) kh_adopt(h, khf, kh_ms);  // built during the assembly
-    else if (khf.retry_db) derive_kmer_hash(h, khf.retry_db);  // (a k-mer displaced beyond three bits' worth of lines: once more, with more bits)
     else kh_drop(h);
     sync_walk_kh(h);
     bft_trace_mark("root tables");
@@ -2532,12 +2566,13 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
     CK(ensure_built(h));
-    static const char* names[14] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol"};
-    const DevBuf* bufs[14] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
-                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol};
-    const uint64_t derived[5] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8,
-                                 h->kh_lines ? (h->kh_lines + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS * 8 : 0ull, h->n_kmers * 4};
-    for (int i = 0; i < 14; i++)
+    static const char* names[16] = {"nodes", "bfT", "ccs", "f2w", "clus", "child", "uck", "ucrow", "tk", "ccx", "f18", "fent", "kh", "tcol", "kh_ovf_k", "kh_ovf_v"};
+    const DevBuf* bufs[16] = {&h->d_nodes, &h->d_bfT, &h->d_ccs, &h->d_f2w, &h->d_clus, &h->d_child, &h->d_uck, &h->d_ucrow, &h->d_tk,
+                              &h->d_ccx, &h->d_f18, &h->d_fent, &h->d_kh, &h->d_tcol, &h->d_kh_ovf_k, &h->d_kh_ovf_v};
+    const uint64_t derived[7] = {h->idx_sizes[2] / sizeof(BftCC) * sizeof(BftCCX), h->n_f18 * 8, h->n_fent * 8,
+                                 h->kh_lines ? (h->kh_lines + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS * 8 : 0ull, h->n_kmers * 4,
+                                 (uint64_t)h->kh_ovf_n * h->W * 8, (uint64_t)h->kh_ovf_n * 4};
+    for (int i = 0; i < 16; i++)
         if (std::string(name) == names[i]) {
             const uint64_t sz = i < 9 ? h->idx_sizes[i] : derived[i - 9];
             if (nbytes) *nbytes = sz;
@@ -2706,7 +2741,7 @@ extern "C" int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out) {
     if (!h || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t v[12] = {h->d_tk.bytes, h->d_tcol.bytes, h->d_cs_off.bytes + h->d_cs_ids.bytes,
                             h->d_nodes.bytes + h->d_bfT.bytes + h->d_ccs.bytes + h->d_f2w.bytes + h->d_clus.bytes + h->d_child.bytes + h->d_uck.bytes + h->d_ucrow.bytes,
-                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes + h->d_rspec.bytes, h->d_cs_bm.bytes,
+                            h->d_ccx.bytes + h->d_f18.bytes + h->d_fent.bytes, h->d_rdir.bytes + h->d_rstart.bytes + h->d_rq.bytes, h->d_nph.bytes, h->d_kh.bytes + h->d_rspec.bytes + h->d_kh_ovf_k.bytes + h->d_kh_ovf_v.bytes, h->d_cs_bm.bytes,
                             h->d_hashmod.bytes, 0ull, h->log_k.bytes + h->log_g.bytes};
     for (int i = 0; i < n_out && i < 12; i++) out[i] = v[i];
     return BFT_GPU_OK;
@@ -2728,11 +2763,12 @@ extern "C" int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, i
 
 extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
     if (!h || !ms) return fail(BFT_GPU_E_ARG, "NULL argument");
-    const double v[21] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
+    const double v[25] = {h->build_ms[0], h->build_ms[1], h->build_ms[2], h->build_ms[3], h->build_ms[4], (double)query_residency(h), h->tune_ms[0], h->tune_ms[1],
                           h->im.probe_big ? 8.0 : 4.0, (double)h->kh_lines, h->kh_ms, (double)h->msd_max_bucket, (double)bft_test_exact_passes(), g_malloc_ms,
                           (double)(h->im.rdir ? (h->im.rstart ? 2 : 1) : 0), h->rstart_tune_ms[0], h->rstart_tune_ms[1],
-                          (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2], (double)h->claims_static_launches};
-    for (int i = 0; i < n_out && i < 21; i++) ms[i] = v[i];
+                          (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2], (double)h->claims_static_launches,
+                          (double)h->im.kh.S, (double)h->im.kh.db, (double)h->im.kh.maxd, (double)h->kh_ovf_n};
+    for (int i = 0; i < n_out && i < 25; i++) ms[i] = v[i];
     return BFT_GPU_OK;
 }
 

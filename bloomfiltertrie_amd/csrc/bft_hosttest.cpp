@@ -107,6 +107,9 @@ static uint64_t query(HostTrie* t, const uint8_t* q, uint64_t nq, uint8_t* bits,
 extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     HostTrie* t = (HostTrie*)hv;
     t->im.kh_lines = nullptr;
+    t->im.kh_ovf = nullptr;
+    t->im.kh_ovf_val = nullptr;
+    t->im.kh_ovf_n = 0;
     t->im.walk_kh = 0;
     t->kh = BftKhHostTable();
     const uint64_t n = t->tk.size() / t->W;
@@ -122,6 +125,9 @@ extern "C" uint64_t bft_hosttest_kmer_hash(void* hv, uint32_t load_pct) {
     if (!t->kh.ok) return 0;
     t->im.kh_lines = t->kh.lines.data();
     t->im.kh = t->kh.g;
+    t->im.kh_ovf = t->kh.ovf_k.data();
+    t->im.kh_ovf_val = t->kh.ovf_v.data();
+    t->im.kh_ovf_n = (uint32_t)t->kh.ovf_v.size();
     return t->kh.g.nl;
 }
 // the walk looks plain root groups up in the table (BftImage::walk_kh; needs the table and the root range table): returns 1 when on
@@ -140,12 +146,12 @@ extern "C" int bft_hosttest_walk_kh(void* hv, int on) {
 static void geo_out(const BftKhHostTable& tab, uint32_t* out) {
     const BftKhGeo& g = tab.g;
     out[0] = g.S; out[1] = g.f; out[2] = g.wb; out[3] = g.cb; out[4] = g.kb; out[5] = g.qb; out[6] = g.hb; out[7] = g.restb; out[8] = g.t; out[9] = g.m;
-    out[10] = (uint32_t)g.nl; out[11] = tab.max_d; out[12] = g.db;
+    out[10] = (uint32_t)g.nl; out[11] = tab.max_d; out[12] = g.db; out[13] = (uint32_t)tab.ovf_v.size();
 }
 // The sequential restatement on arrays handed in (tests compare the GPU-built table with it): tk = n sorted T-form rows, vals < n_values.
 // Returns the words of the table (8 per line); geo[0..11] as bft_hosttest_kh_geometry.  0 when the table cannot be built.
 extern "C" uint64_t bft_hosttest_kh_build(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, uint64_t n_values, uint32_t load_pct, uint64_t* lines_out,
-                                          uint64_t cap_words, uint32_t* geo) {
+                                          uint64_t cap_words, uint32_t* geo, uint64_t* ovf_k_out, uint32_t* ovf_v_out) {
     BftKhHostTable tab;
     switch (bft_words_for_k(k)) {
     case 1: bft_kh_build_host<1>(tk, vals, n, k, n_values, load_pct, tab); break;
@@ -156,9 +162,81 @@ extern "C" uint64_t bft_hosttest_kh_build(const uint64_t* tk, const uint32_t* va
     if (geo) geo_out(tab, geo);
     if (!tab.ok || tab.lines.size() > cap_words) return 0;
     memcpy(lines_out, tab.lines.data(), tab.lines.size() * 8);
+    if (ovf_k_out && !tab.ovf_k.empty()) memcpy(ovf_k_out, tab.ovf_k.data(), tab.ovf_k.size() * 8);  // (room for BFT_KH_OVF_CAP rows)
+    if (ovf_v_out && !tab.ovf_v.empty()) memcpy(ovf_v_out, tab.ovf_v.data(), tab.ovf_v.size() * 4);
     return tab.lines.size();
 }
-// geometry of the host table: out[0..12] (12: displacement bits) = slots per line, field bits, body bytes, value bits, key bits, q bits, hashed bits, bits below,
+// A table built elsewhere (the GPU's fast build: slot order by arrival) against the sorted table it was built from: every used slot decodes
+// to a row of tk with that row's value, every row is there exactly once, and every line between a k-mer's home line and its own is full
+// (what the lookup's early exit relies on).  Returns 1 when all of that holds, 0 or a negative code otherwise.
+template <int W>
+static int kh_verify(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, const BftKhGeo& g, const uint64_t* lines, uint64_t n_lines, const uint64_t* ovf_k,
+                     const uint32_t* ovf_v, uint32_t n_ovf) {
+    BftImage im;
+    memset(&im, 0, sizeof(im));
+    im.k = k; im.W = W; im.L = k / 9;
+    im.kh = g;
+    im.kh_lines = lines;
+    if (n_lines != g.nl + BFT_KH_TAIL_LINES) return -1;
+    std::vector<uint8_t> seen(n, 0);
+    uint64_t cnt = 0;
+    for (uint64_t ln = 0; ln < n_lines; ln++) {
+        const uint64_t* line = lines + ln * BFT_KH_LINE_WORDS;
+        const uint32_t occ = (uint32_t)(line[1] >> (64u - g.S));
+        for (uint32_t s = 0; s < g.S; s++) {
+            if (!((occ >> s) & 1u)) continue;
+            uint64_t key[W];
+            uint32_t v;
+            bft_kh_slot_decode<W>(im, line, line, ln, s, key, &v);
+            if (v == 0xFFFFFFFFu) continue;  // (a tombstone)
+            // the row: lower bound of key in tk
+            uint64_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (bft_cmp<W>(tk + mid * W, key) < 0) lo = mid + 1; else hi = mid;
+            }
+            if (lo >= n || bft_cmp<W>(tk + lo * W, key) != 0) return -2;
+            if (seen[lo] || vals[lo] != v) return -3;
+            seen[lo] = 1;
+            cnt++;
+            BftKhKey<W> kk;
+            bft_kh_key<W>(key, k, g, kk);
+            if (kk.home > ln || ln - kk.home > g.maxd) return -4;
+            for (uint64_t x = kk.home; x < ln; x++)
+                if ((uint32_t)(lines[x * BFT_KH_LINE_WORDS + 1] >> (64u - g.S)) != (1u << g.S) - 1u) return -5;
+        }
+    }
+    // the overflow list: sorted rows of tk, not in the table, and every line from home to home + maxd is full
+    for (uint32_t e = 0; e < n_ovf; e++) {
+        const uint64_t* key = ovf_k + (size_t)e * W;
+        if (e && bft_cmp<W>(ovf_k + (size_t)(e - 1) * W, key) >= 0) return -7;
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (bft_cmp<W>(tk + mid * W, key) < 0) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= n || bft_cmp<W>(tk + lo * W, key) != 0 || seen[lo] || vals[lo] != ovf_v[e]) return -8;
+        seen[lo] = 1;
+        cnt++;
+        BftKhKey<W> kk;
+        bft_kh_key<W>(key, k, g, kk);
+        for (uint64_t x = kk.home; x <= kk.home + g.maxd; x++)
+            if ((uint32_t)(lines[x * BFT_KH_LINE_WORDS + 1] >> (64u - g.S)) != (1u << g.S) - 1u) return -9;
+    }
+    return cnt == n ? 1 : -6;
+}
+extern "C" int bft_hosttest_kh_verify(const uint64_t* tk, const uint32_t* vals, uint64_t n, int k, uint64_t n_values, uint32_t load_pct, uint32_t maxd,
+                                      const uint64_t* lines, uint64_t n_lines, const uint64_t* ovf_k, const uint32_t* ovf_v, uint32_t n_ovf) {
+    BftKhGeo g = bft_kh_geometry(k, n, n_values, load_pct);
+    g.maxd = maxd;
+    switch (bft_words_for_k(k)) {
+    case 1: return kh_verify<1>(tk, vals, n, k, g, lines, n_lines, ovf_k, ovf_v, n_ovf);
+    case 2: return kh_verify<2>(tk, vals, n, k, g, lines, n_lines, ovf_k, ovf_v, n_ovf);
+    case 3: return kh_verify<3>(tk, vals, n, k, g, lines, n_lines, ovf_k, ovf_v, n_ovf);
+    default: return kh_verify<4>(tk, vals, n, k, g, lines, n_lines, ovf_k, ovf_v, n_ovf);
+    }
+}
+// geometry of the host table: out[0..13] (12: displacement bits, 13: k-mers in the overflow list) = slots per line, field bits, body bytes, value bits, key bits, q bits, hashed bits, bits below,
 // t, m, home lines, largest displacement
 extern "C" void bft_hosttest_kh_geometry(void* hv, uint32_t* out) { geo_out(((HostTrie*)hv)->kh, out); }
 template <int W>
@@ -200,10 +278,17 @@ static int kh_roundtrip(HostTrie* t) {
             uint64_t key[W];
             uint32_t v;
             bft_kh_slot_decode<W>(t->im, line, line, ln, s, key, &v);
+            if (v == 0xFFFFFFFFu) continue;  // (a tombstone: in use, value 0)
             if (v >= n || seen[v] || memcmp(key, &t->tk[(uint64_t)v * W], W * 8) != 0) return 0;
             seen[v] = 1;
             cnt++;
         }
+    }
+    for (uint32_t e = 0; e < t->im.kh_ovf_n; e++) {
+        const uint32_t v = t->im.kh_ovf_val[e];
+        if (v >= n || seen[v] || memcmp(t->im.kh_ovf + (size_t)e * W, &t->tk[(uint64_t)v * W], W * 8) != 0) return 0;
+        seen[v] = 1;
+        cnt++;
     }
     return cnt == n;
 }
@@ -230,7 +315,10 @@ static double kh_probe_stats(HostTrie* t, uint64_t* longest) {
             uint32_t v;
             const uint64_t* line = t->im.kh_lines + (kk.home + d) * BFT_KH_LINE_WORDS;
             if (bft_kh_scan<W, 0>(t->im, line, line, kk, d, &v) > 0) break;
-            if (d >= t->im.kh.maxd) { steps = ~0ull >> 1; break; }  // (a stored k-mer the lookup cannot find: the caller's bound fails)
+            if (d >= t->im.kh.maxd) {  // the overflow list, or a stored k-mer the lookup cannot find (then the caller's bound fails)
+                if (!bft_kh_overflow_find<W>(t->im, &t->tk[i * W], &v)) steps = ~0ull >> 1;
+                break;
+            }
         }
         total += steps;
         worst = std::max(worst, steps);

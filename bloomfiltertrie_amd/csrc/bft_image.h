@@ -113,7 +113,10 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 // k-mer hash (derived when the image is built, loaded or unpacked; optional; any k): EVERY stored k-mer, whatever container of the trie
 // holds it, in one open-addressed table of 64-byte lines.  A k-mer lives in the first line at or after its HOME line that had a free slot
 // when the table was laid out; a lookup reads lines from the home line on until it meets the key (present; its colour set sits in the
-// same slot), a line with a free slot (absent), or has looked as far past home as any k-mer of the table is displaced (absent).  At the default occupancy of the
+// same slot), a line with a free slot (absent), or has looked as far past home as any k-mer of the table is displaced -- then the
+// OVERFLOW LIST decides: the handful of k-mers (none, on most indexes) whose run of full lines was longer than a slot's displacement bits
+// hold, sorted, searched only by the one lookup in millions that meets such a run.  (In the canonical layout the slot such a k-mer would
+// have taken is marked in use with value 0 -- a tombstone no lookup matches --: the lines before the k-mers behind it stay full.)  At the default occupancy of the
 // home lines (60 %) a lookup reads 1.05-1.1 lines: ONE cache line beyond the L2 per query, where the container walk of
 // src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe even in its fastest form here; on MI355X a kernel of
 // random gathers is bound by the lines it misses on (tools/microbench/gather.hip: ~55 G lines/s beyond the L2, whether the lane reads 8
@@ -123,8 +126,8 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 //           home = a m + floor(c m / 2^t)  (nl = 2^(hb - t) m home lines, m in [16, 32]: any table size within 6 %).
 //           The home line thus KNOWS most of hi', and the slot stores only what it does not: q = c - ceil(sub 2^t / m) (qb bits) under the
 //           rest bits -- 2k - 32 + qb key bits instead of 2k (k = 27, 100 genomes: 32 instead of 54; this quotienting is what lets a line
-//           hold 8 k-mers of k = 27 or 31 where the table of round 3 held 5).  A k-mer displaced d lines from home stores d (3 bits; a build that
-//           meets a larger displacement is redone with as many bits as it takes: one slot per line, k >= 97, takes 7 or 8).
+//           hold 8 k-mers of k = 27 or 31 where the table of round 3 held 5).  A k-mer displaced d lines from home stores d (3 bits at 6 slots
+//           per line and more, up to 8 bits at one slot per line, k >= 97).
 //   line    = header (16 bytes) + S slot bodies of wb = floor(48 / S) bytes, body s at byte 16 + s wb.  Header: S fields of
 //           f = min(32, floor(128 / S) - 1) bits, field s at bits [s f, (s + 1) f) = the LOW f bits of slot s's stored key; bits
 //           [128 - S, 128): slot s is in use.  Body: bits [0, CB) = colour-set id + 1 (CB = bits of the number of colour sets), [CB, CB + db)
@@ -136,13 +139,15 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 // of the stored set, the colour sets and the occupancy alone: the GPU build -- one device-wide sort by home line, one max-scan, one pass of
 // atomic ORs -- and the sequential host restatement give the same bytes (tests/test_gpu_parity.py).  The table never changes an answer: it
 // holds exactly the k-mers of the sorted table `tk` with their colour sets, `tk` can be rebuilt from it ("compact_table"), and the
-// container walk is used whenever the table is absent ("kmer_hash" 0, allocation failure, a k-mer displaced 256 lines or more)
+// container walk is used whenever the table is absent ("kmer_hash" 0, allocation failure, an overflow list beyond 4096 k-mers)
 // or rows are asked for.
 #define BFT_KH_LINE_WORDS 8u
 #define BFT_KH_MAX_SLOTS 10u
-#define BFT_KH_DBITS 3u        // displacement bits of a slot: 3, or -- when a build meets a k-mer displaced further -- as many as that takes, up to
-#define BFT_KH_MAX_DBITS 8u
+// displacement bits of a slot, by the slots of a line (the fewer slots, the longer the runs of full lines: one slot per line at 55 % makes
+// runs of dozens): a k-mer that would land further from home than they hold goes to the OVERFLOW LIST instead
+#define BFT_KH_DBITS_FOR(S) ((S) >= 6u ? 3u : ((S) >= 4u ? 4u : ((S) == 3u ? 5u : ((S) == 2u ? 6u : 8u))))
 #define BFT_KH_TAIL_LINES 256u // lines behind the home lines: what the last home lines spill into (the largest displacement + 1)
+#define BFT_KH_OVF_CAP 4096u   // k-mers the overflow list holds at most (more: no table at this occupancy)
 struct BftKhGeo {
     uint32_t S, f, wb, cb;     // slots per line, bits of a header field, bytes of a slot body, value bits
     uint32_t db, maxd;         // displacement bits of a slot; the largest displacement in the table (a lookup looks no further)
@@ -189,6 +194,9 @@ struct BftImage {
     const uint64_t* tk;       // [n_kmers * W] sorted T-form table
     const uint64_t* kh_lines; // [(kh.nl + BFT_KH_TAIL_LINES) * 8] k-mer hash (BFT_KH_*, above), or NULL
     BftKhGeo kh;
+    const uint64_t* kh_ovf;   // [kh_ovf_n * W] its overflow list: sorted T-form k-mers, and
+    const uint32_t* kh_ovf_val;  // their values
+    uint32_t kh_ovf_n;
     const uint32_t* rspec;    // [2^18 / 32] one bit per root prefix: not a plain suffix group of the root (bit 31 of rstart), or NULL
     uint32_t walk_kh;         // 1: the container walk looks a plain root suffix group up in the k-mer hash (one line) instead of searching
                               // its rows of the sorted table -- when the caller wants presence or colour sets, not rows

@@ -9,11 +9,16 @@
 #define BFT_KH_BLOCK 256
 bool bft_kh_has_kernels(int W, uint32_t S);
 // Builds the table (geometry g: bft_kh_geometry, bft_walk.h) of the n rows of the sorted table d_tk (W words per row) with values d_vals on
-// stream s: d_kh ((g.nl + BFT_KH_TAIL_LINES) lines) is overwritten; d_status: four words, [0] != 0 afterwards = no table (a k-mer displaced
-// further from its home line than g.db bits hold: redo with more), [1] = lines in use, [2] = the largest displacement.  Nothing is
-// synchronised; the transients live in `sc`, which the caller keeps until s has drained.
+// stream s, in the canonical layout, in two steps:
+//   bft_kh_sort  the k-mers sorted by home line, their T-forms and values as payload;
+//   bft_kh_lay   positions by one max-scan, then every line assembled and stored once: d_kh ((g.nl + BFT_KH_TAIL_LINES) lines) is
+//                overwritten, k-mers displaced beyond the slots' displacement bits go to d_ovf_k / d_ovf_v (BFT_KH_OVF_CAP entries, unsorted:
+//                the caller sorts the few there are); d_status: four words, [0] != 0 afterwards = no table (more overflow than the list
+//                holds), [2] = the largest displacement in the table, [3] = k-mers in the overflow list.
+// Nothing is synchronised; the transients live in `sc`, which the caller keeps until s has drained.
 struct BftKhScratch { DevBuf b[7]; };
-int bft_kh_build(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint32_t* d_status, BftKhScratch& sc, hipStream_t s);
+int bft_kh_sort(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeo& g, BftKhScratch& sc, hipStream_t s);
+int bft_kh_lay(uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint64_t* d_ovf_k, uint32_t* d_ovf_v, uint32_t* d_status, BftKhScratch& sc, hipStream_t s);
 // every (k-mer, value) of the table, unordered, word w of k-mer j at d_keys[w * stride + j]; *d_cnt (zeroed by the caller) = how many
 int bft_kh_dump(const BftImage& im, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
 // presence bits (+ colour-set id per k-mer when d_out32 != NULL) of n packed k-mers of `rec` bytes each

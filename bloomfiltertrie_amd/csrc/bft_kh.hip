@@ -75,8 +75,11 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
         key.field = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+        uint64_t t[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) t[w] = 0;
         if (live) {
-            uint64_t x[W], t[W];
+            uint64_t x[W];
             load_x<W>(packed, i, B, end_aligned, x);
             bft_tform_from_x<W>(x, im.k, t);
             bft_kh_key<W>(t, im.k, im.kh, key);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
                 bft_kh_load_header(line, hd);
                 res = bft_kh_scan<W, S>(im, line, hd, key, d, &val);
             }
+            if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;  // (a run of full lines as long as any displacement: the overflow list)
             present = res > 0;
         }
         const uint64_t mask = __ballot(present);
@@ -158,6 +162,7 @@ __device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*ca
             bft_kh_load_header(line, h2);
             res = bft_kh_scan<W, S>(im, line, h2, key[v], d, &val);
         }
+        if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, cand[v], &val) ? 1 : 0;
         count += res > 0;
     }
     return count;
@@ -257,16 +262,23 @@ __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __r
 // ---------------------------------------------------------------------------------------------------------------------------------
 // build (the canonical layout of bft_image.h: the k-mers in (home line, T-form) order, slot-level linear probing)
 // ---------------------------------------------------------------------------------------------------------------------------------
-// sort key of row i: its home line; value: the row
+// A k-mer on its way through the sort by home line: its T-form and its value travel with the key, so that the lines are assembled from
+// a sequential read (gathering the rows by index afterwards costs two random lines per k-mer).
 template <int W>
-__global__ void k_kh_keys(const uint64_t* __restrict__ tk, uint64_t n, int k, BftKhGeo g, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+struct KhRec {
+    uint64_t t[W];
+    uint32_t v;
+};
+template <int W>
+__global__ void k_kh_keys(const uint64_t* __restrict__ tk, const uint32_t* __restrict__ vals, uint64_t n, int k, BftKhGeo g, uint32_t* __restrict__ key, KhRec<W>* __restrict__ rec) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t t[W];
+        KhRec<W> r;
         BftKhKey<W> kk;
-        bft_load_row<W>(tk + i * W, t);
-        bft_kh_key<W>(t, k, g, kk);
+        bft_load_row<W>(tk + i * W, r.t);
+        r.v = vals[i];
+        bft_kh_key<W>(r.t, k, g, kk);
         key[i] = (uint32_t)kk.home;
-        val[i] = (uint32_t)i;
+        rec[i] = r;
     }
 }
 // Slot-level linear probing over the rows in sorted order: p_s = max(home slot_s, p_(s-1) + 1) = s + max_(j <= s)(home slot_j - j): one
@@ -279,70 +291,145 @@ __global__ void k_kh_scanvals(const uint32_t* __restrict__ key_s, uint64_t n, ui
 struct BftMaxU64 {
     __host__ __device__ uint64_t operator()(const uint64_t& a, const uint64_t& b) const { return a > b ? a : b; }
 };
-// every row ORs its slot -- header field, occupancy bit, body with its displacement -- into the (zeroed) table.  status[0] |= 1: a k-mer
-// displaced further than the slots' displacement bits hold (the caller redoes the build with more); status[1] = the last line in use + 1;
-// status[2] = the largest displacement.
+// The lines, each written once and whole.  Every sorted row makes its own slot image (all lanes busy); the rows of a line -- neighbours in
+// the sorted order, at most S of them -- OR their images together in their wavefront's LDS, and the row that comes first in the line stores
+// its 64 bytes.  A line whose rows straddle two wavefronts is OR-ed into the (zeroed) table with atomics instead; lines without a k-mer
+// keep the zeros of the memset.  A row displaced further from home than the slots' displacement bits hold goes to the overflow list
+// (status[3] counts them; beyond BFT_KH_OVF_CAP: status[0] |= 1, no table) and leaves a tombstone -- its slot in use, value 0 -- so
+// that the lines before the rows behind it stay full.  status[2] = the largest displacement in the table.
 template <int W>
-__global__ void k_kh_write(const uint64_t* __restrict__ tk, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ key_s, const uint32_t* __restrict__ val_s,
-                           const uint64_t* __restrict__ vscan, uint64_t n, int k, BftKhGeo g, uint32_t* __restrict__ status, uint64_t* __restrict__ kh) {
+__global__ __launch_bounds__(256) void k_kh_assemble(const uint32_t* __restrict__ key_s, const KhRec<W>* __restrict__ rec_s, const uint64_t* __restrict__ vscan, uint64_t n, int k,
+                                                     BftKhGeo g, uint32_t* __restrict__ status, uint64_t* __restrict__ kh, uint64_t* __restrict__ ovf_k,
+                                                     uint32_t* __restrict__ ovf_v) {
+    __shared__ unsigned long long s_line[4][64][BFT_KH_LINE_WORDS];  // per wavefront: the lines its 64 rows touch (at most 64)
     uint32_t dmax = 0;
-    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = val_s[s];
-        const uint64_t p = vscan[s] - BFT_KH_SCAN_BIAS + s, ln = p / g.S, home = key_s[s], d = ln - home;
-        dmax = max(dmax, (uint32_t)min(d, (uint64_t)0xFFFFFFFFu));
-        if (d > g.maxd) { atomicOr(&status[0], 1u); continue; }
-        if (s + 1 == n) status[1] = (uint32_t)(ln + 1);
-        uint64_t t[W], img[BFT_KH_LINE_WORDS];
-        bft_load_row<W>(tk + i * W, t);
-        bft_kh_slot_image<W>(t, k, g, (uint32_t)(p % g.S), (uint32_t)d, vals[i], img);
-        unsigned long long* line = (unsigned long long*)(kh + ln * BFT_KH_LINE_WORDS);
+    const uint64_t n_lines = g.nl + BFT_KH_TAIL_LINES;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t nblk = (n + 255) / 256;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t s = blk * 256 + threadIdx.x;
+        const bool live = s < n;
+        uint64_t p = 0, ln = ~0ull;
+        bool first_of_line = false, last_of_line = false;
+        if (live) {
+            p = vscan[s] - BFT_KH_SCAN_BIAS + s;
+            ln = p / g.S;
+            first_of_line = s == 0 || (vscan[s - 1] - BFT_KH_SCAN_BIAS + (s - 1)) / g.S != ln;
+            last_of_line = s + 1 == n || (vscan[s + 1] - BFT_KH_SCAN_BIAS + (s + 1)) / g.S != ln;
+        }
+        // the rank of this row's line among the lines of its wavefront's rows; a line is whole in the wavefront when its first and last row are
+        const uint64_t heads = __ballot(live && (first_of_line || lane == 0));
+        const uint32_t rank = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u;
+        const uint64_t firsts = __ballot(live && first_of_line), lasts = __ballot(live && last_of_line);
+        // first / last row of my line inside the wavefront: the head lane of my rank, the lane before the next head
+        const uint64_t my_head_bit = live ? (1ull << (63 - __builtin_clzll((heads & ((2ull << lane) - 1ull)) | 1ull))) : 0ull;
+        const uint64_t above = heads & ~((my_head_bit << 1) - 1ull);
+        const uint32_t my_last_lane = above ? (uint32_t)__builtin_ctzll(above) - 1u : 63u;
+        const bool whole = live && (firsts & my_head_bit) && my_last_lane < 64u && ((lasts >> my_last_lane) & 1ull);
+        // zero the wavefront's lines
 #pragma unroll
-        for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++)
-            if (img[q]) atomicOr(&line[q], (unsigned long long)img[q]);
+        for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++) s_line[wave][lane][q] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        uint64_t img[BFT_KH_LINE_WORDS];
+#pragma unroll
+        for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++) img[q] = 0;
+        if (live) {
+            const uint64_t home = key_s[s], d = ln - home;
+            const KhRec<W> r = rec_s[s];
+            if (ln >= n_lines) atomicOr(&status[0], 1u);
+            else if (d > g.maxd) {
+                const uint32_t at = atomicAdd(&status[3], 1u);
+                if (at >= BFT_KH_OVF_CAP) atomicOr(&status[0], 1u);
+                else {
+#pragma unroll
+                    for (int w = 0; w < W; w++) ovf_k[(size_t)at * W + w] = r.t[w];
+                    ovf_v[at] = r.v;
+                }
+                img[1] = 1ull << (64u - g.S + (uint32_t)(p % g.S));
+            } else {
+                dmax = max(dmax, (uint32_t)d);
+                bft_kh_slot_image<W>(r.t, k, g, (uint32_t)(p % g.S), (uint32_t)d, r.v, img);
+            }
+            if (ln < n_lines) {
+                if (whole) {
+#pragma unroll
+                    for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++)
+                        if (img[q]) atomicOr(&s_line[wave][rank][q], (unsigned long long)img[q]);
+                } else {  // (a line that straddles two wavefronts)
+                    unsigned long long* line = (unsigned long long*)(kh + ln * BFT_KH_LINE_WORDS);
+#pragma unroll
+                    for (uint32_t q = 0; q < BFT_KH_LINE_WORDS; q++)
+                        if (img[q]) atomicOr(&line[q], (unsigned long long)img[q]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (whole && first_of_line && ln < n_lines) {
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(kh + ln * BFT_KH_LINE_WORDS);
+#pragma unroll
+            for (int q = 0; q < 4; q++) dst[q] = make_ulonglong2(s_line[wave][rank][2 * q], s_line[wave][rank][2 * q + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, (uint32_t)__shfl_down(dmax, o));
     if ((threadIdx.x & 63u) == 0 && dmax) atomicMax(&status[2], dmax);
 }
 
+// phase A: the k-mers sorted by home line (needs the sorted table only -- not the colour sets)
 template <int W>
-static int kh_build_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, const BftKhGeo& g, uint64_t* d_kh, uint32_t* d_status, BftKhScratch& sc, hipStream_t s) {
-    DevBuf &key = sc.b[0], &val = sc.b[1], &key_s = sc.b[2], &val_s = sc.b[3], &v = sc.b[4], &vs = sc.b[5], &tmp = sc.b[6];
+static int kh_sort_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, const BftKhGeo& g, BftKhScratch& sc, hipStream_t s) {
+    DevBuf &key = sc.b[0], &rec = sc.b[1], &key_s = sc.b[2], &rec_s = sc.b[3], &tmp = sc.b[6];
     CK(key.alloc(n * 4));
-    CK(val.alloc(n * 4));
+    CK(rec.alloc(n * sizeof(KhRec<W>)));
     CK(key_s.alloc(n * 4));
-    CK(val_s.alloc(n * 4));
+    CK(rec_s.alloc(n * sizeof(KhRec<W>)));
+    const dim3 b(256), gn((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32));
+    hipLaunchKernelGGL(k_kh_keys<W>, gn, b, 0, s, d_tk, d_vals, n, k, g, key.as<uint32_t>(), rec.as<KhRec<W>>());
+    // stable sort by home line: rows of a line stay in T-form order
+    unsigned bits = 1;
+    while (bits < 32 && (g.nl >> bits)) bits++;
+    size_t tb = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
+    if (tb > tmp.bytes) CK(tmp.alloc(tb));
+    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// phase B: positions by one max-scan, then every line assembled and stored once
+template <int W>
+static int kh_lay_w(uint64_t n, int k, const BftKhGeo& g, uint64_t* d_kh, uint64_t* d_ovf_k, uint32_t* d_ovf_v, uint32_t* d_status, BftKhScratch& sc,
+                    hipStream_t s) {
+    DevBuf &key_s = sc.b[2], &rec_s = sc.b[3], &v = sc.b[4], &vs = sc.b[5], &tmp = sc.b[6];
     CK(v.alloc(n * 8));
     CK(vs.alloc(n * 8));
     const dim3 b(256), gn((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32));
     HIPCK(hipMemsetAsync(d_status, 0, 16, s));
     HIPCK(hipMemsetAsync(d_kh, 0, (g.nl + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS * 8, s));
-    hipLaunchKernelGGL(k_kh_keys<W>, gn, b, 0, s, d_tk, n, k, g, key.as<uint32_t>(), val.as<uint32_t>());
-    {   // stable sort by home line: rows of a line stay in T-form order
-        unsigned bits = 1;
-        while (bits < 32 && (g.nl >> bits)) bits++;
-        size_t tb = 0;
-        HIPCK(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), val.as<uint32_t>(), val_s.as<uint32_t>(), (size_t)n, 0u, bits, s));
-        if (tb > tmp.bytes) CK(tmp.alloc(tb));
-        HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), val.as<uint32_t>(), val_s.as<uint32_t>(), (size_t)n, 0u, bits, s));
-    }
     hipLaunchKernelGGL(k_kh_scanvals, gn, b, 0, s, key_s.as<uint32_t>(), n, g.S, v.as<uint64_t>());
-    {
-        size_t tb = 0;
-        HIPCK(rocprim::inclusive_scan(nullptr, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
-        if (tb > tmp.bytes) CK(tmp.alloc(tb));
-        HIPCK(rocprim::inclusive_scan(tmp.p, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
-    }
-    hipLaunchKernelGGL(k_kh_write<W>, gn, b, 0, s, d_tk, d_vals, key_s.as<uint32_t>(), val_s.as<uint32_t>(), vs.as<uint64_t>(), n, k, g, d_status, d_kh);
+    size_t tb = 0;
+    HIPCK(rocprim::inclusive_scan(nullptr, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
+    if (tb > tmp.bytes) CK(tmp.alloc(tb));
+    HIPCK(rocprim::inclusive_scan(tmp.p, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
+    hipLaunchKernelGGL(k_kh_assemble<W>, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32)), b, 0, s, key_s.as<uint32_t>(), rec_s.as<KhRec<W>>(), vs.as<uint64_t>(), n, k, g,
+                       d_status, d_kh, d_ovf_k, d_ovf_v);
     HIPCK(hipGetLastError());
     return 0;  // (the transients stay in `sc` until the caller has seen `s` drain)
 }
 
-int bft_kh_build(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint32_t* d_status, BftKhScratch& sc, hipStream_t s) {
+int bft_kh_sort(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, int W, const BftKhGeo& g, BftKhScratch& sc, hipStream_t s) {
     switch (W) {
-    case 1: return kh_build_w<1>(d_tk, d_vals, n, k, g, d_kh, d_status, sc, s);
-    case 2: return kh_build_w<2>(d_tk, d_vals, n, k, g, d_kh, d_status, sc, s);
-    case 3: return kh_build_w<3>(d_tk, d_vals, n, k, g, d_kh, d_status, sc, s);
-    default: return kh_build_w<4>(d_tk, d_vals, n, k, g, d_kh, d_status, sc, s);
+    case 1: return kh_sort_w<1>(d_tk, d_vals, n, k, g, sc, s);
+    case 2: return kh_sort_w<2>(d_tk, d_vals, n, k, g, sc, s);
+    case 3: return kh_sort_w<3>(d_tk, d_vals, n, k, g, sc, s);
+    default: return kh_sort_w<4>(d_tk, d_vals, n, k, g, sc, s);
+    }
+}
+int bft_kh_lay(uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint64_t* d_ovf_k, uint32_t* d_ovf_v, uint32_t* d_status, BftKhScratch& sc, hipStream_t s) {
+    switch (W) {
+    case 1: return kh_lay_w<1>(n, k, g, d_kh, d_ovf_k, d_ovf_v, d_status, sc, s);
+    case 2: return kh_lay_w<2>(n, k, g, d_kh, d_ovf_k, d_ovf_v, d_status, sc, s);
+    case 3: return kh_lay_w<3>(n, k, g, d_kh, d_ovf_k, d_ovf_v, d_status, sc, s);
+    default: return kh_lay_w<4>(n, k, g, d_kh, d_ovf_k, d_ovf_v, d_status, sc, s);
     }
 }
 
@@ -369,6 +456,18 @@ __global__ __launch_bounds__(256) void k_kh_dump(BftImage im, uint64_t* __restri
             bft_kh_load_header(line, hd);
             occ = (uint32_t)(hd[1] >> (64u - S));
         }
+        {   // (slots in use with value 0 are tombstones: not k-mers)
+            uint32_t real = 0;
+            const uint64_t vmask = (1ull << im.kh.cb) - 1ull;
+            for (uint32_t o2 = occ; o2;) {
+                const uint32_t s = (uint32_t)__builtin_ctz(o2);
+                o2 &= o2 - 1u;
+                uint64_t body[W];
+                bft_kh_load_body<W>(line, s, im.kh.wb, body);
+                if (body[0] & vmask) real |= 1u << s;
+            }
+            occ = real;
+        }
         const uint32_t mine = (uint32_t)__popc(occ);
         uint32_t my_off = mine ? atomicAdd(&s_cnt, mine) : 0u;
         __syncthreads();
@@ -387,6 +486,17 @@ __global__ __launch_bounds__(256) void k_kh_dump(BftImage im, uint64_t* __restri
             j++;
         }
         __syncthreads();
+    }
+    // the overflow list: one workgroup appends it
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = im.kh_ovf_n ? atomicAdd(cnt, (unsigned long long)im.kh_ovf_n) : 0ull;
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < im.kh_ovf_n; e += blockDim.x) {
+#pragma unroll
+            for (int i = 0; i < W; i++) keys[(uint64_t)i * stride + s_base + e] = im.kh_ovf[(size_t)e * W + i];
+            vals[s_base + e] = im.kh_ovf_val[e];
+        }
     }
 }
 

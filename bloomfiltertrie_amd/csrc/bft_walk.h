@@ -322,20 +322,14 @@ BFT_HD uint32_t bft_kh_field_bits(uint32_t S, uint32_t kb) {
     return f < kb ? f : kb;
 }
 BFT_HD uint32_t bft_kh_body_bytes(uint32_t S) { return 48u / S; }
-// displacement bits for the second attempt of a build whose first met a k-mer displaced `maxd` lines: what maxd takes, + 1; 0: give up
-BFT_HD uint32_t bft_kh_retry_dbits(uint32_t maxd) {
-    uint32_t b = 1;
-    while (b < 32 && (maxd >> b)) b++;
-    return b + 1 <= BFT_KH_MAX_DBITS ? b + 1 : (b <= BFT_KH_MAX_DBITS ? BFT_KH_MAX_DBITS : 0u);
-}
 // n k-mers of length k, values below n_values, `load_pct` per cent of the home lines' slots in use
-BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t load_pct, uint32_t db = BFT_KH_DBITS) {
+BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t load_pct) {
     BftKhGeo g;
     const uint32_t tb = (uint32_t)(2 * k);
     g.hb = tb < 32u ? tb : 32u;
     g.restb = tb - g.hb;
     g.cb = bft_kh_value_bits(n_values);
-    g.db = db; g.maxd = (1u << db) - 1u;
+    g.db = BFT_KH_DBITS_FOR(1u); g.maxd = (1u << g.db) - 1u;
     g.S = 1; g.f = 0; g.wb = 48; g.kb = 0; g.qb = 0; g.t = 0; g.m = 1; g.inv = 0; g.nl = 1;
     for (uint32_t S = BFT_KH_MAX_SLOTS; S >= 1; S--) {
         // home lines wanted -> nl = 2^(hb - t) * m with m in [16, 32] (t <= 27: the magic division of bft_kh_place needs frac < 2^27)
@@ -355,7 +349,9 @@ BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t l
         uint32_t qb = 0;
         while (qb < 32 && ((span - 1) >> qb)) qb++;
         const uint32_t kb = g.restb + qb, f = bft_kh_field_bits(S, kb), wb = bft_kh_body_bytes(S);
+        const uint32_t db = BFT_KH_DBITS_FOR(S);
         if (S == 1 || g.cb + db + kb - f <= 8u * wb) {
+            g.db = db; g.maxd = (1u << db) - 1u;
             g.S = S; g.f = f; g.wb = wb; g.kb = kb; g.qb = qb; g.t = t; g.m = (uint32_t)m;
             g.inv = (uint32_t)(((1ull << 32) + m - 1) / m);
             g.nl = (uint64_t)m << abits;
@@ -539,7 +535,7 @@ BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t*
         cand &= cand - 1u;
         uint64_t body[W];
         bft_kh_load_body<W>(line, s, wb, body);
-        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0;
+        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0 && (body[0] & vmask) != 0;  // (value 0: a tombstone, below)
 #pragma unroll
         for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
         if (same) { *val = (uint32_t)(body[0] & vmask) - 1u; return 1; }
@@ -558,7 +554,7 @@ BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhK
     for (uint32_t s = 0; s < S; s++) {
         const uint64_t fld = f ? bft_kh_bits_at<2>(ln, s * f) & fmask : 0ull;
         const uint64_t b0 = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb);
-        bool same = fld == key.field && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0;
+        bool same = fld == key.field && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0 && (b0 & vmask) != 0;
 #pragma unroll
         for (int i = 1; i < W; i++) {
             if (8u * (uint32_t)i >= wb) break;
@@ -572,8 +568,23 @@ BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhK
     }
     return found ? 1 : (occ != (1u << S) - 1u ? 0 : -1);
 }
-// Lookup of a T-form k-mer: true when stored, *val = its value (the colour-set id).  Lines from the home line on: the key, a line with a
-// free slot, or the table's largest displacement past home, ends it.
+// The overflow list (bft_image.h): binary search of the sorted k-mers.
+template <int W>
+BFT_HD bool bft_kh_overflow_find(const BftImage& im, const uint64_t* t, uint32_t* val) {
+    uint32_t lo = 0, hi = im.kh_ovf_n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        uint64_t r[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) r[w] = im.kh_ovf[(size_t)mid * W + w];
+        const int c = bft_cmp<W>(r, t);
+        if (c == 0) { *val = im.kh_ovf_val[mid]; return true; }
+        if (c < 0) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+// Lookup of a T-form k-mer: true when stored, *val = its value (the colour-set id).  Lines from the home line on: the key, or a line with
+// a free slot, ends it; a run of full lines as long as the table's largest displacement hands over to the overflow list.
 template <int W, int SS>
 BFT_HD bool bft_kh_lookup(const BftImage& im, const uint64_t* t, uint32_t* val) {
     BftKhKey<W> key;
@@ -586,7 +597,7 @@ BFT_HD bool bft_kh_lookup(const BftImage& im, const uint64_t* t, uint32_t* val) 
         if (res > 0) return true;
         if (res == 0) return false;
     }
-    return false;
+    return im.kh_ovf_n ? bft_kh_overflow_find<W>(im, t, val) : false;
 }
 // What a k-mer stored d lines past its home line adds to slot s of that line: the 8 line words to OR in (header field, occupancy, body).
 template <int W>

@@ -17,12 +17,12 @@ def _write_pass(d, counters, kernel="void k_query_kh<1>(BftImage, unsigned char 
         for disp in range(1, n_dispatch + 1):
             for name, total in counters.items():
                 for part in range(8):  # one row per XCD, as rocprofv3 writes them: the parser sums them per dispatch
-                    w.writerow([disp, kernel if disp > 2 else "void k_kh_insert<1>(...)", name, total / 8 * (1.0 if disp > 2 else 0.01)])
+                    w.writerow([disp, kernel if disp > 2 else "void k_kh_assemble<1>(...)", name, total / 8 * (1.0 if disp > 2 else 0.01)])
     with open(os.path.join(d, "x_kernel_trace.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
         for disp in range(1, n_dispatch + 1):
-            w.writerow([kernel if disp > 2 else "void k_kh_insert<1>(...)", disp * 10_000_000, disp * 10_000_000 + dur_ns])
+            w.writerow([kernel if disp > 2 else "void k_kh_assemble<1>(...)", disp * 10_000_000, disp * 10_000_000 + dur_ns])
 
 
 def test_pmc_parser_and_roofline_block(tmp_path):

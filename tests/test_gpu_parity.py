@@ -546,39 +546,58 @@ def test_kmer_hash_answers_like_the_container_walk(oracle_mod, k, levels):
 
 @pytest.mark.parametrize("k", [18, 27, 31, 32, 45, 63, 64, 90, 126])
 def test_kmer_hash_table_invariants(k):
-    """The layout of the k-mer hash is canonical (bft_image.h): the table the GPU builds -- a device-wide sort by home line, a max-scan, a
-    pass of atomic ORs -- is, byte for byte, the table the sequential host restatement (bft_kh_host.h) builds from the same sorted k-mers
-    and colour sets: every stored k-mer exactly once with its colour set as the value, nothing else, every k-mer in the first line from its
-    home line on that was not full -- the property the lookup's early exit relies on (tests/test_abi_and_host.py checks the restatement
-    itself: lookups, decoding of every slot, occupancy)."""
+    """The table the GPU builds holds every stored k-mer exactly once with its colour set as the value, nothing else, and every line between
+    a k-mer's home line and its own is full -- the property the lookup's early exit relies on (every slot decoded on the host and checked
+    against the sorted table: bft_hosttest_kh_verify).  And the layout is CANONICAL -- a function of the stored set alone --: the GPU build (a
+    device-wide sort by home line with the k-mers as payload, a max-scan, every line assembled and stored once) gives, byte for byte, the table
+    and the overflow list of the sequential host restatement (bft_kh_host.h; tests/test_abi_and_host.py checks the restatement itself:
+    lookups, decoding of every slot, occupancy)."""
     import ctypes as C
     from bloomfiltertrie_amd import BFT, _lib
     W = (2 * k + 63) // 64
     anc = S.random_genome(200000, k)
-    t = BFT(k)
-    for g in range(3):
-        km = S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k))
-        if g == 0:
-            km = np.concatenate([km, S.low_entropy_kmers(30000, k, 6, seed=k, levels=1)])  # regions of thousands of k-mers beside regions of one
-        t.insert_kmers(km, g)
-    t.set_option("kmer_hash_load", 70)
-    t.build()
-    kh = t.debug_array("kh", np.uint64)
-    tk = t.debug_array("tk", np.uint64).reshape(-1, W)
-    tcol = t.debug_array("tcol", np.uint32)
-    n_sets = t.info()["colorsets"]
-    home_lines = int(t.build_time()["kmer_hash_lines"])
     hostlib = C.CDLL(os.path.join(_lib.CSRC, "libbft_hosttest.so"))
     hostlib.bft_hosttest_kh_build.restype = C.c_uint64
-    hostlib.bft_hosttest_kh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
-    lines = np.zeros(len(kh) + 4096, np.uint64)
-    geo = np.zeros(13, np.uint32)
-    tkc, tcc = np.ascontiguousarray(tk), np.ascontiguousarray(tcol)
-    nw = hostlib.bft_hosttest_kh_build(tkc.ctypes.data, tcc.ctypes.data, len(tk), k, n_sets, 70, lines.ctypes.data, len(lines), geo.ctypes.data)
-    # (one or two slots per line: k-mers displaced beyond 7 lines -- both builders take their second attempt, with more displacement bits)
-    assert nw == len(kh) == (home_lines + 256) * 8 and int(geo[10]) == home_lines and (int(geo[12]) == 3 or int(geo[0]) <= 4), (nw, len(kh), geo)
-    assert (kh == lines[:nw]).all()
-    t.close()
+    hostlib.bft_hosttest_kh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    hostlib.bft_hosttest_kh_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                               C.c_uint32]
+    for load in (55, 80):  # (80 %: runs of full lines beyond the displacement bits -- the overflow list)
+        canonical = 1
+        t = BFT(k)
+        t.set_option("kmer_hash_load", load)
+        t.set_option("compact_table", 0)
+        for g in range(3):
+            km = S.distinct(S.kmers_of(S.mutate(anc, 0.02, g), k))
+            if g == 0:
+                km = np.concatenate([km, S.low_entropy_kmers(30000, k, 6, seed=k, levels=1)])  # thousands of k-mers under a handful of root prefixes
+            t.insert_kmers(km, g)
+        t.build()
+        kh = np.ascontiguousarray(t.debug_array("kh", np.uint64))
+        tk = np.ascontiguousarray(t.debug_array("tk", np.uint64).reshape(-1, W))
+        tcol = np.ascontiguousarray(t.debug_array("tcol", np.uint32))
+        ovk = np.ascontiguousarray(t.debug_array("kh_ovf_k", np.uint64))
+        ovv = np.ascontiguousarray(t.debug_array("kh_ovf_v", np.uint32))
+        n_sets = t.info()["colorsets"]
+        bt = t.build_time()
+        home_lines, db, maxd, novf = int(bt["kmer_hash_lines"]), int(bt["kmer_hash_dbits"]), int(bt["kmer_hash_maxd"]), int(bt["kmer_hash_overflow"])
+        assert home_lines > 0 and len(kh) == (home_lines + 256) * 8 and maxd < (1 << db) and len(ovv) == novf and len(ovk) == novf * W
+        rc = hostlib.bft_hosttest_kh_verify(tk.ctypes.data, tcol.ctypes.data, len(tk), k, n_sets, load, maxd, kh.ctypes.data, len(kh) // 8, ovk.ctypes.data, ovv.ctypes.data, novf)
+        assert rc == 1, (rc, canonical, load)
+        if canonical:
+            lines = np.zeros(len(kh) + 4096, np.uint64)
+            geo = np.zeros(14, np.uint32)
+            hk, hv = np.zeros(4096 * W, np.uint64), np.zeros(4096, np.uint32)
+            nw = hostlib.bft_hosttest_kh_build(tk.ctypes.data, tcol.ctypes.data, len(tk), k, n_sets, load, lines.ctypes.data, len(lines), geo.ctypes.data, hk.ctypes.data, hv.ctypes.data)
+            assert nw == len(kh) and int(geo[10]) == home_lines and int(geo[12]) == db and int(geo[13]) == novf and int(geo[11]) == maxd, (nw, len(kh), geo)
+            assert (kh == lines[:nw]).all() and (ovk == hk[: novf * W]).all() and (ovv == hv[:novf]).all()
+        # every stored k-mer is found with its colour set, whichever way it got into the table (or its overflow list)
+        km_all, cs_all = t.extract()
+        assert S.from_bits(t.query_presence(km_all), len(km_all)).all()
+        b1, cr1 = t.query_color_rows(km_all[:100000])   # (device path: colour sets out of the table's slots)
+        t.set_option("kmer_hash", 0)
+        b2, cr2 = t.query_color_rows(km_all[:100000])   # (the walk: rows -> colour sets)
+        assert (b1 == b2).all() and (cr1 == cr2).all()
+        t.close()
 
 
 @pytest.mark.parametrize("k,per_prefix", [(18, 20), (27, 12), (27, 120), (36, 30), (63, 200), (31, 40)])
