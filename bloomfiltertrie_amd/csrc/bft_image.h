@@ -121,7 +121,10 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 // src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe even in its fastest form here; on MI355X a kernel of
 // random gathers is bound by the lines it misses on (tools/microbench/gather.hip: ~55 G lines/s beyond the L2, whether the lane reads 8
 // or 128 bytes of the line), so lines per query is the whole cost.
-//   key     The home line is computed from the top hb = min(32, 2k) bits of the T-form, hi, XOR-ed with a hash of the other bits (rest):
+//   key     The home line is computed from the top hb0 = min(32, 2k - 4) bits of the T-form WITHOUT the two bits of the k-mer's first
+//           nucleotide (hi, hb = hb0 - 2 bits; the two bits join the rest, on top), XOR-ed with a hash of the other bits WITHOUT the two bits of the
+//           last nucleotide: the four successors of a k-mer (src/branchingNode.c:16-112: its last k - 1 nucleotides + any fourth) share their
+//           home line and differ in two stored key bits, and so do its four predecessors -- a branching query reads two lines, not eight.
 //           hi' = perm(hi ^ mix(rest)) -- perm a fixed bijection that scatters: a bijection of hi for every rest --, split as (a | c), c the low t bits:
 //           home = a m + floor(c m / 2^t)  (nl = 2^(hb - t) m home lines, m in [16, 32]: any table size within 6 %).
 //           The home line thus KNOWS most of hi', and the slot stores only what it does not: q = c - ceil(sub 2^t / m) (qb bits) under the
@@ -152,7 +155,9 @@ struct BftKhGeo {
     uint32_t S, f, wb, cb;     // slots per line, bits of a header field, bytes of a slot body, value bits
     uint32_t db, maxd;         // displacement bits of a slot; the largest displacement in the table (a lookup looks no further)
     uint32_t kb, qb;           // bits of a stored key (rest bits + qb), bits of q
-    uint32_t hb, restb;        // hashed high bits of the T-form, bits below them
+    uint32_t hb, restb;        // hashed bits (the top hb0 bits of the T-form without the first nucleotide's two), bits of the rest (2k - hb)
+    uint32_t hb0, po;          // top bits of the T-form taken for hashing; where in them the first nucleotide sits (32: not in them -- k < 11)
+    uint64_t mm;               // mask of the rest's low word for mixing: without the last nucleotide (and the first, when it lies there)
     uint32_t t, m, inv;        // home = a m + floor(c m / 2^t); inv = ceil(2^32 / m)
     uint64_t nl;               // home lines
 };

@@ -56,6 +56,100 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {  // the valu
     default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);
     }
 }
+
+// The lines `home` of the four lanes of a quad, fetched together: one after the other, every lane loads ITS quarter (16 bytes) of the line of
+// the quad's lane r and puts it where it belongs in the wavefront's LDS block (64 lines, 80 bytes apart: headers and quarters then spread
+// over the banks); every lane then reads its own line's header from there, and the body of the slot whose header field matches.  Four load
+// instructions of 16 bytes a lane bring four whole lines -- the instructions a wavefront issues per line are what a kernel of random gathers
+// pays for (bft_image.h) -- and the line never passes through sixty-four selects on its way (round 4 had it gathered by DPP broadcasts into
+// registers and scanned slot by slot there: 430 vector instructions per k-mer of a loop of 800, which had become the limit).
+// Every lane of the wavefront calls this; a lane that is not `live` asks for nothing and finds zeros.
+#define BFT_KH_LDS_LINE 5u  // uint4s a line takes in LDS (4 + 1 of padding)
+__device__ __forceinline__ void kh_fetch_quad(const BftImage& im, uint64_t home, bool live, uint4* wave_lines) {
+    const uint32_t lane = threadIdx.x & 63u, ql = lane & 3u, q0 = lane & ~3u;
+    uint4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t lo = quad_bcast((uint32_t)home, r), hi = quad_bcast((uint32_t)(home >> 32), r), lv = quad_bcast(live ? 1u : 0u, r);
+        v[r] = make_uint4(0, 0, 0, 0);
+        if (lv) v[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(im.kh_lines) + ((((uint64_t)hi << 32) | lo) * 64ull) + 16u * ql);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) wave_lines[(q0 + (uint32_t)r) * BFT_KH_LDS_LINE + ql] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// body of slot s of the line at `mine` in LDS: W words from byte 16 + s wb on (aligned 8-byte reads, shifted)
+template <int W, int S>
+__device__ __forceinline__ void kh_lds_body(const uint4* mine, uint32_t s, uint64_t* body) {
+    constexpr uint32_t wb = 48u / (uint32_t)S;
+    const uint32_t off = 16u + s * wb, sh = (off & 7u) * 8u;
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(mine) + (off & ~7u));
+    uint64_t w[W + 1];
+#pragma unroll
+    for (int i = 0; i <= W; i++) w[i] = p[i];  // (never beyond the line's 80 bytes: bft_kh_has_kernels)
+#pragma unroll
+    for (int i = 0; i < W; i++) body[i] = sh ? (w[i] >> sh) | (w[i + 1] << (64u - sh)) : w[i];
+}
+// the slots of the line whose header field agrees with `field` under `keep`, and that are in use; *full = no slot is free
+template <int S>
+__device__ __forceinline__ uint32_t kh_lds_candidates(const uint4* mine, uint32_t field, uint32_t keep, bool* full) {
+    constexpr uint32_t f = bft_kh_field_bits((uint32_t)S), fmask = f < 32u ? (1u << f) - 1u : 0xFFFFFFFFu;
+    const uint4 h = mine[0];
+    const uint32_t hw[5] = {h.x, h.y, h.z, h.w, 0u};
+    const uint32_t occ = hw[3] >> (32u - (uint32_t)S);
+    uint32_t cand = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < (uint32_t)S; s++) {
+        constexpr uint32_t dummy = 0; (void)dummy;
+        const uint32_t o = s * f, wi = o >> 5, sh = o & 31u;
+        const uint32_t fld = (uint32_t)((((uint64_t)hw[wi + 1] << 32) | hw[wi]) >> sh) & fmask;
+        cand |= (((fld ^ field) & keep) == 0 ? 1u : 0u) << s;
+    }
+    *full = occ == (1u << (uint32_t)S) - 1u;
+    return cand & occ;
+}
+// the k-mer `key` in the line at `mine` (LDS), d lines past its home: 1 = found (*val), 0 = not here and a slot is free (absent), -1 = not here, line full
+template <int W, int S>
+__device__ __forceinline__ int kh_lds_scan(const BftImage& im, const uint4* mine, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
+    const uint32_t cb = im.kh.cb;
+    const uint64_t vmask = (1ull << cb) - 1ull;
+    bool full;
+    uint32_t cand = kh_lds_candidates<S>(mine, (uint32_t)key.field, 0xFFFFFFFFu, &full);
+    int found = 0;
+    while (cand) {  // (a second candidate: two slots whose keys share their low f bits -- once in thousands of lines)
+        const uint32_t s = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        uint64_t body[W];
+        kh_lds_body<W, S>(mine, s, body);
+        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0 && (body[0] & vmask) != 0;  // (value 0: a tombstone)
+#pragma unroll
+        for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
+        if (same) { *val = (uint32_t)(body[0] & vmask) - 1u; found = 1; }
+    }
+    return found ? 1 : (full ? -1 : 0);
+}
+// how many k-mers of the family (bft_kh_family) the line holds; -1: the line is full (the family may go on behind it), else 0
+template <int W, int S>
+__device__ __forceinline__ int kh_lds_count(const BftImage& im, const uint4* mine, const BftKhKey<W>& key, const BftKhFamily<W>& fam, uint32_t d, int* count) {
+    const uint32_t cb = im.kh.cb;
+    const uint64_t vmask = (1ull << cb) - 1ull;
+    bool full;
+    uint32_t cand = kh_lds_candidates<S>(mine, (uint32_t)key.field, (uint32_t)fam.fkeep, &full);
+    while (cand) {
+        const uint32_t s = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        uint64_t body[W];
+        kh_lds_body<W, S>(mine, s, body);
+        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & fam.bkeep[0]) == 0 && (body[0] & vmask) != 0;
+#pragma unroll
+        for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & fam.bkeep[i]) == 0;
+        *count += same ? 1 : 0;
+    }
+    return full ? -1 : 0;
+}
+
 template <int W, int S>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                           uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {
@@ -64,7 +158,9 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
     constexpr uint32_t WPB = BFT_KH_BLOCK / 64;  // presence words per block
     __shared__ uint32_t s_next[2];
     __shared__ uint64_t s_bits[BFT_KH_MAX_CLAIM * WPB];
-    const uint32_t ql = threadIdx.x & 3u;  // lane of its quad
+    __shared__ uint4 s_lines[WPB][64 * BFT_KH_LDS_LINE];
+    uint4* const wave_lines = s_lines[threadIdx.x >> 6];
+    const uint4* const mine = wave_lines + (threadIdx.x & 63u) * BFT_KH_LDS_LINE;
     KhClaims cl(ctr, chunk, nblk, s_next);
     cl.first();
     while (cl.blk < nblk) {
@@ -84,40 +180,11 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
             bft_tform_from_x<W>(x, im.k, t);
             bft_kh_key<W>(t, im.k, im.kh, key);
         }
-        // the home lines of the quad's four k-mers, one after the other: every lane loads ITS quarter of the line of lane r
-        uint32_t piece[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t lo = quad_bcast((uint32_t)key.home, r), hi = quad_bcast((uint32_t)(key.home >> 32), r), lv = quad_bcast(live ? 1u : 0u, r);
-#pragma unroll
-            for (int d = 0; d < 4; d++) piece[r][d] = 0;
-            if (lv) {
-                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(im.kh_lines) + ((((uint64_t)hi << 32) | lo) * 64ull) + 16u * ql);
-                piece[r][0] = v.x; piece[r][1] = v.y; piece[r][2] = v.z; piece[r][3] = v.w;
-            }
-        }
-        // every lane collects the four quarters of its own line (round r = its lane of the quad) from the lanes that loaded them
-        uint32_t mine[16];
-#pragma unroll
-        for (int d = 0; d < 16; d++) mine[d] = 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const uint32_t got = quad_bcast(piece[r][d], j);  // quarter j of the line of the quad's lane r
-                    if (ql == (uint32_t)r) mine[4 * j + d] = got;
-                }
-            }
-        }
+        kh_fetch_quad(im, key.home, live, wave_lines);
         bool present = false;
         uint32_t val = 0xFFFFFFFFu;
         if (live) {
-            uint64_t ln[BFT_KH_LINE_WORDS];
-#pragma unroll
-            for (int q = 0; q < 8; q++) ln[q] = (uint64_t)mine[2 * q] | ((uint64_t)mine[2 * q + 1] << 32);
-            int res = bft_kh_scan_full<W, S>(im, ln, key, 0u, &val);
+            int res = kh_lds_scan<W, S>(im, mine, key, 0u, &val);
             for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {  // full line without the key: on from the home line, on this lane's own (a few per cent)
                 const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
                 uint64_t hd[2];
@@ -140,30 +207,34 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
     cl.done();
 }
 
-// How many of four candidate k-mers are stored: the headers of the four home lines are loaded before any is looked at -- four
-// independent misses in flight instead of four dependent walks (src/presenceNode.c:15-1211 shares one descent between the four;
-// here there is no descent to share).  A candidate whose home line is full without holding it continues line by line (a few per cent).
+// How many of the four successors (or the four predecessors) of a k-mer are stored.  They share their home line and differ in two stored key
+// bits (bft_image.h: the bits that tell them apart are not hashed), so ONE line is fetched by the quad and looked through ONCE, the two bits
+// left out of the comparison: every slot that matches is one of the four (src/presenceNode.c:15-1211 shares one descent between the four;
+// here they share one line and one scan).  t0: the candidate whose wildcard nucleotide is 0; b: where the wildcard lies in the rest.  When the
+// line is full the lines behind it follow on the lane's own (a few per cent), and a run of full lines as long as any displacement hands the
+// four over to the overflow list.  Every lane of the wavefront calls this; `live` = this lane has candidates.
 template <int W, int S>
-__device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t (*cand)[W]) {
-    BftKhKey<W> key[4];
-    uint64_t hd[4][2];
+__device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t* t0, uint32_t b, int wild_word, int wild_shift, bool live, uint4* wave_lines) {
+    BftKhKey<W> key;
+    key.home = 0; key.field = 0;
 #pragma unroll
-    for (int v = 0; v < 4; v++) bft_kh_key<W>(cand[v], im.k, im.kh, key[v]);
-#pragma unroll
-    for (int v = 0; v < 4; v++) bft_kh_load_header(im.kh_lines + key[v].home * BFT_KH_LINE_WORDS, hd[v]);
+    for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+    if (live) bft_kh_key<W>(t0, im.k, im.kh, key);
+    kh_fetch_quad(im, key.home, live, wave_lines);
+    if (!live) return 0;
+    BftKhFamily<W> fam;
+    bft_kh_family<W>(im.kh, key, b, fam);
     int count = 0;
+    int res = kh_lds_count<W, S>(im, wave_lines + (threadIdx.x & 63u) * BFT_KH_LDS_LINE, key, fam, 0u, &count);
+    for (uint32_t d = 1; res < 0 && count < 4 && d <= im.kh.maxd; d++) res = bft_kh_count_line<W, S>(im, im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS, key, fam, d, &count);
+    if (res < 0 && count < 4 && im.kh_ovf_n) {
+        for (int v = 0; v < 4; v++) {
+            uint64_t c[W];
+            uint32_t val;
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-        uint32_t val;
-        int res = bft_kh_scan<W, S>(im, im.kh_lines + key[v].home * BFT_KH_LINE_WORDS, hd[v], key[v], 0u, &val);
-        for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {  // full line without the key: on from the home line
-            const uint64_t* line = im.kh_lines + (key[v].home + d) * BFT_KH_LINE_WORDS;
-            uint64_t h2[2];
-            bft_kh_load_header(line, h2);
-            res = bft_kh_scan<W, S>(im, line, h2, key[v], d, &val);
+            for (int w = 0; w < W; w++) c[w] = t0[w] | (w == wild_word ? (uint64_t)v << wild_shift : 0ull);
+            count += bft_kh_overflow_find<W>(im, c, &val) ? 1 : 0;
         }
-        if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, cand[v], &val) ? 1 : 0;
-        count += res > 0;
     }
     return count;
 }
@@ -182,44 +253,38 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
     const int k = im.k, L = im.L, rb = 2 * (k - 9 * L);
     __shared__ uint32_t s_next[2];
     __shared__ uint64_t s_bits[BFT_KH_BR_MAX_CLAIM * WPB];
+    __shared__ uint4 s_lines[WPB][64 * BFT_KH_LDS_LINE];
+    uint4* const wave_lines = s_lines[threadIdx.x >> 6];
     KhClaims cl(ctr, chunk, nblk, s_next);
     cl.first();
     while (cl.blk < nblk) {
         const uint64_t i = cl.blk * BFT_KH_BLOCK + threadIdx.x;
-        int branching = 0;
-        if (i < n) {
-            uint64_t x[W], y[W], t[W], cand[4][W];
-            load_x<W>(packed, i, B, end_aligned, x);
-            // successors: drop the first nucleotide, the last one is the wildcard (bits vo.. of the T-form's last word)
+        const bool live = i < n;
+        uint64_t x[W], y[W], t[W];
 #pragma unroll
-            for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
+        for (int w = 0; w < W; w++) x[w] = 0;
+        if (live) load_x<W>(packed, i, B, end_aligned, x);
+        // successors: drop the first nucleotide, the last one is the wildcard (bits vo.. of the T-form's last word)
+#pragma unroll
+        for (int w = 0; w < W; w++) y[w] = (x[w] >> 2) | (w + 1 < W ? x[w + 1] << 62 : 0ull);
+        bft_tform_from_x<W>(y, k, t);
+        const int vo = rb ? 0 : 2;
+        const int cr = kh_count4<W, S>(im, t, (uint32_t)vo, W - 1, vo, live, wave_lines);
+        int cl_ = 0;
+        const bool left = live && (counts || cr < 2);
+        if (__any(left)) {  // (the quad fetch is the whole wavefront's)
+            // predecessors: shift in a wildcard first nucleotide (bits 0..1 of the first digit), drop the last one
+#pragma unroll
+            for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
+            const int top = 2 * k - 64 * (W - 1);
+            if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
             bft_tform_from_x<W>(y, k, t);
-            const int vo = rb ? 0 : 2;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-#pragma unroll
-                for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == W - 1 ? (uint64_t)v << vo : 0ull);
-            }
-            const int cr = kh_count4<W, S>(im, cand);
-            int cl_ = 0;
-            if (counts || cr < 2) {
-                // predecessors: shift in a wildcard first nucleotide (bits 0..1 of the first digit), drop the last one
-#pragma unroll
-                for (int w = W - 1; w >= 0; w--) y[w] = (x[w] << 2) | (w > 0 ? x[w - 1] >> 62 : 0ull);
-                const int top = 2 * k - 64 * (W - 1);
-                if (top < 64) y[W - 1] &= (1ull << top) - 1ull;
-                bft_tform_from_x<W>(y, k, t);
-                const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-#pragma unroll
-                    for (int w = 0; w < W; w++) cand[v][w] = t[w] | (w == ow ? (uint64_t)v << osh : 0ull);
-                }
-                cl_ = kh_count4<W, S>(im, cand);
-            }
-            branching = cr > 1 || cl_ > 1;
-            if (counts) counts[i] = (uint8_t)((cr << 4) | cl_);  // (a wavefront's 64 bytes: one coalesced store)
+            const int o = rb + 18 * (L - 1), ow = W - 1 - (o >> 6), osh = o & 63;
+            // (the first nucleotide's bits sit on top of the rest when they come out of the hashed bits, else where they are)
+            cl_ = kh_count4<W, S>(im, t, im.kh.po < 32u ? im.kh.restb - 2u : (uint32_t)o, ow, osh, left, wave_lines);
         }
+        const int branching = live && (cr > 1 || cl_ > 1);
+        if (counts && live) counts[i] = (uint8_t)((cr << 4) | cl_);  // (a wavefront's 64 bytes: one coalesced store)
         const uint64_t mask = __ballot(branching);
         if ((threadIdx.x & 63u) == 0) s_bits[(cl.blk - cl.start) * WPB + (threadIdx.x >> 6)] = mask;
         if (cl.last_of_round()) {

@@ -316,18 +316,22 @@ BFT_HD uint32_t bft_kh_value_bits(uint64_t n_values) {  // values 0 .. n_values 
     while (b < 32 && (n_values >> b)) b++;
     return b;
 }
-BFT_HD uint32_t bft_kh_field_bits(uint32_t S, uint32_t kb) {
-    uint32_t f = 128u / S - 1u;
-    if (f > 32u) f = 32u;
-    return f < kb ? f : kb;
-}
+// bits of a header field: a function of the slots per line alone (the kernels know it at compile time)
+BFT_HD constexpr uint32_t bft_kh_field_bits(uint32_t S) { return 128u / S - 1u > 32u ? 32u : 128u / S - 1u; }
 BFT_HD uint32_t bft_kh_body_bytes(uint32_t S) { return 48u / S; }
 // n k-mers of length k, values below n_values, `load_pct` per cent of the home lines' slots in use
 BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t load_pct) {
     BftKhGeo g;
     const uint32_t tb = (uint32_t)(2 * k);
-    g.hb = tb < 32u ? tb : 32u;
-    g.restb = tb - g.hb;
+    {   // the last nucleotide (bits vo, vo + 1 of the T-form) and the first (bits o, o + 1) stay out of the home line
+        const uint32_t L = (uint32_t)k / 9u, rb = 2u * ((uint32_t)k - 9u * L), vo = rb ? 0u : 2u, o = rb + 18u * (L - 1u);
+        g.hb0 = tb - 4u < 32u ? tb - 4u : 32u;
+        const uint32_t restb0 = tb - g.hb0;
+        g.mm = ~(3ull << vo);
+        if (o >= restb0) { g.po = o - restb0; g.hb = g.hb0 - 2u; }
+        else { g.po = 32u; g.hb = g.hb0; g.mm &= ~(3ull << o); }
+        g.restb = tb - g.hb;
+    }
     g.cb = bft_kh_value_bits(n_values);
     g.db = BFT_KH_DBITS_FOR(1u); g.maxd = (1u << g.db) - 1u;
     g.S = 1; g.f = 0; g.wb = 48; g.kb = 0; g.qb = 0; g.t = 0; g.m = 1; g.inv = 0; g.nl = 1;
@@ -348,7 +352,8 @@ BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t l
         const uint64_t span = ((1ull << t) + m - 1) / m;
         uint32_t qb = 0;
         while (qb < 32 && ((span - 1) >> qb)) qb++;
-        const uint32_t kb = g.restb + qb, f = bft_kh_field_bits(S, kb), wb = bft_kh_body_bytes(S);
+        // (a stored key never has fewer bits than a header field: short keys -- k < 18 or so -- are padded with zeros on top)
+        const uint32_t f = bft_kh_field_bits(S), kb = g.restb + qb > f ? g.restb + qb : f, wb = bft_kh_body_bytes(S);
         const uint32_t db = BFT_KH_DBITS_FOR(S);
         if (S == 1 || g.cb + db + kb - f <= 8u * wb) {
             g.db = db; g.maxd = (1u << db) - 1u;
@@ -360,12 +365,14 @@ BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t l
     }
     return g;
 }
-// T-form k-mer -> its hashed high bits (hb of them) and the bits below, as W little-endian words
+// T-form k-mer -> its hashed bits (g.hb of them: the top hb0 bits without the first nucleotide's two) and the rest (g.restb bits: the bits
+// below the top hb0, the first nucleotide's two on top of them), as W little-endian words
 template <int W>
-BFT_HD uint32_t bft_kh_split(const uint64_t* t, int k, uint32_t hb, uint64_t* restle) {
+BFT_HD uint32_t bft_kh_split(const uint64_t* t, int k, const BftKhGeo& g, uint64_t* restle) {
 #pragma unroll
     for (int i = 0; i < W; i++) restle[i] = t[W - 1 - i];
     const int tb0 = 2 * k - 64 * (W - 1);  // bits of the T-form in its top word t[0]
+    const uint32_t hb = g.hb0;
     uint32_t hi;
     if (tb0 >= (int)hb) {
         hi = (uint32_t)(t[0] >> (tb0 - (int)hb));
@@ -376,13 +383,33 @@ BFT_HD uint32_t bft_kh_split(const uint64_t* t, int k, uint32_t hb, uint64_t* re
         restle[W - 1] = 0;
         restle[W > 1 ? W - 2 : 0] &= (1ull << (64 - below)) - 1ull;
     }
-    return hb < 32u ? hi & ((1u << hb) - 1u) : hi;
-}
-template <int W>
-BFT_HD uint32_t bft_kh_mix(const uint64_t* restle) {  // 32 well-mixed bits of the bits below
-    uint64_t h = restle[0] ^ 0x2545F4914F6CDD1Dull;
+    if (hb < 32u) hi &= (1u << hb) - 1u;
+    if (g.po < 32u) {  // the first nucleotide's bits leave the hashed ones for the top of the rest (an even position: never across two words)
+        const uint64_t e = (hi >> g.po) & 3u;
+        hi = (hi & ((1u << g.po) - 1u)) | ((hi >> (g.po + 2u)) << g.po);
+        const uint32_t at = g.restb - 2u, wi = at >> 6, sh = at & 63u;
 #pragma unroll
-    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + restle[w];
+        for (int i = 0; i < W; i++)
+            if ((uint32_t)i == wi) restle[i] |= e << sh;
+    }
+    return hi;
+}
+// 32 well-mixed bits of the rest -- without the bits of the k-mer's last and first nucleotide
+template <int W>
+BFT_HD uint32_t bft_kh_mix(const uint64_t* restle, const BftKhGeo& g) {
+    uint64_t r[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) r[i] = restle[i];
+    r[0] &= g.mm;
+    if (g.po < 32u) {
+        const uint32_t at = g.restb - 2u, wi = at >> 6, sh = at & 63u;
+#pragma unroll
+        for (int i = 0; i < W; i++)
+            if ((uint32_t)i == wi) r[i] &= ~(3ull << sh);
+    }
+    uint64_t h = r[0] ^ 0x2545F4914F6CDD1Dull;
+#pragma unroll
+    for (int w = 1; w < W; w++) h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull + r[w];
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;  // 64-bit finalizer (murmur3)
     return (uint32_t)(h >> 32);
 }
@@ -422,8 +449,8 @@ struct BftKhKey {
 template <int W>
 BFT_HD void bft_kh_key(const uint64_t* t, int k, const BftKhGeo& g, BftKhKey<W>& key) {
     uint64_t restle[W], kle[W];
-    const uint32_t hi = bft_kh_split<W>(t, k, g.hb, restle);
-    const uint32_t hp = bft_kh_perm(hi ^ bft_kh_mix<W>(restle), g.hb);
+    const uint32_t hi = bft_kh_split<W>(t, k, g, restle);
+    const uint32_t hp = bft_kh_perm(hi ^ bft_kh_mix<W>(restle, g), g.hb);
     const uint64_t a = g.t < 32u ? (uint64_t)(hp >> g.t) : 0ull, c = g.t < 32u ? (uint64_t)(hp & ((1u << g.t) - 1u)) : (uint64_t)hp;
     const uint64_t cm = c * g.m, sub = cm >> g.t, frac = cm & ((1ull << g.t) - 1ull);
     const uint64_t q = (frac * g.inv) >> 32;  // = frac / m (frac < 2^27, m <= 32)
@@ -519,7 +546,7 @@ BFT_HD void bft_kh_load_body(const uint64_t* line, uint32_t s, uint32_t wb, uint
 // a stored one two.  SS > 0: the slots per line as a compile-time constant (the kernels of bft_kh.hip); SS == 0: read from the image.
 template <int W, int SS>
 BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t* hd, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
-    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh.S, f = im.kh.f, wb = im.kh.wb, cb = im.kh.cb;
+    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh.S, f = SS > 0 ? bft_kh_field_bits(SS > 0 ? SS : 1) : im.kh.f, wb = SS > 0 ? 48u / (SS > 0 ? SS : 1) : im.kh.wb, cb = im.kh.cb;
     const uint64_t fmask = f ? (1ull << f) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
     const uint32_t occ = (uint32_t)(hd[1] >> (64u - S));  // bit s: slot s is in use
     uint32_t cand = 0;
@@ -545,8 +572,8 @@ BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t*
 // The same against a line that is already in registers (8 words): every offset a compile-time constant.
 template <int W, int SS>
 BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
-    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S;
-    const uint32_t f = im.kh.f, cb = im.kh.cb;
+    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S, f = bft_kh_field_bits(S);
+    const uint32_t cb = im.kh.cb;
     const uint64_t fmask = f ? (1ull << f) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
     const uint32_t occ = (uint32_t)(ln[1] >> (64u - S));
     int found = 0;
@@ -567,6 +594,79 @@ BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhK
         }
     }
     return found ? 1 : (occ != (1u << S) - 1u ? 0 : -1);
+}
+// The k-mers that differ from `key`'s only in the two bits b, b + 1 of the rest (the four successors of a k-mer: its last nucleotide; the four
+// predecessors: its first -- they share their home line, bft_image.h): the comparison masks without those two stored key bits.
+template <int W>
+struct BftKhFamily {
+    uint64_t fkeep, bkeep[W];
+};
+template <int W>
+BFT_HD void bft_kh_family(const BftKhGeo& g, const BftKhKey<W>& key, uint32_t b, BftKhFamily<W>& fam) {
+    fam.fkeep = g.f ? (1ull << g.f) - 1ull : 0ull;
+#pragma unroll
+    for (int i = 0; i < W; i++) fam.bkeep[i] = key.bmask[i];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; j++) {
+        const uint32_t pos = g.qb + b + j;
+        if (pos < g.f) fam.fkeep &= ~(1ull << pos);
+        else {
+            const uint32_t bp = pos - g.f + g.cb + g.db;
+#pragma unroll
+            for (int i = 0; i < W; i++)
+                if ((uint32_t)i == (bp >> 6)) fam.bkeep[i] &= ~(1ull << (bp & 63u));
+        }
+    }
+}
+// how many k-mers of the family line `ln` (in registers) holds, d lines past their home; returns -1 when the line is full (the family may go on behind it)
+template <int W, int SS>
+BFT_HD int bft_kh_count_full(const BftImage& im, const uint64_t* ln, const BftKhKey<W>& key, const BftKhFamily<W>& fam, uint32_t d, int* count) {
+    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S, f = bft_kh_field_bits(S);
+    const uint32_t cb = im.kh.cb;
+    const uint64_t vmask = (1ull << cb) - 1ull;
+    const uint32_t occ = (uint32_t)(ln[1] >> (64u - S));
+#pragma unroll
+    for (uint32_t s = 0; s < S; s++) {
+        const uint64_t fld = f ? bft_kh_bits_at<2>(ln, s * f) : 0ull;
+        const uint64_t b0 = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb);
+        bool same = ((fld ^ key.field) & fam.fkeep) == 0 && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & fam.bkeep[0]) == 0 && (b0 & vmask) != 0;
+#pragma unroll
+        for (int i = 1; i < W; i++) {
+            if (8u * (uint32_t)i >= wb) break;
+            const uint64_t b = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb + 64u * (uint32_t)i);
+            same = same && ((b ^ key.body[i]) & fam.bkeep[i]) == 0;
+        }
+        *count += same ? 1 : 0;
+    }
+    return occ != (1u << S) - 1u ? 0 : -1;
+}
+// the same on a line in memory: header first, the bodies of the slots whose fields match
+template <int W, int SS>
+BFT_HD int bft_kh_count_line(const BftImage& im, const uint64_t* line, const BftKhKey<W>& key, const BftKhFamily<W>& fam, uint32_t d, int* count) {
+    const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh.S, f = SS > 0 ? bft_kh_field_bits(SS > 0 ? SS : 1) : im.kh.f, wb = SS > 0 ? 48u / (SS > 0 ? SS : 1) : im.kh.wb, cb = im.kh.cb;
+    const uint64_t vmask = (1ull << cb) - 1ull;
+    uint64_t hd[2];
+    bft_kh_load_header(line, hd);
+    const uint32_t occ = (uint32_t)(hd[1] >> (64u - S));
+    uint32_t cand = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < (SS > 0 ? (uint32_t)SS : BFT_KH_MAX_SLOTS); s++) {
+        if (SS == 0 && s >= S) break;
+        const uint64_t fld = f ? bft_kh_bits_at<2>(hd, s * f) : 0ull;
+        cand |= (((fld ^ key.field) & fam.fkeep) == 0 ? 1u : 0u) << s;
+    }
+    cand &= occ;
+    while (cand) {
+        const uint32_t s = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        uint64_t body[W];
+        bft_kh_load_body<W>(line, s, wb, body);
+        bool same = ((body[0] ^ (key.body[0] | ((uint64_t)d << cb))) & fam.bkeep[0]) == 0 && (body[0] & vmask) != 0;
+#pragma unroll
+        for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & fam.bkeep[i]) == 0;
+        *count += same ? 1 : 0;
+    }
+    return occ != (1u << S) - 1u ? 0 : -1;
 }
 // The overflow list (bft_image.h): binary search of the sorted k-mers.
 template <int W>
@@ -650,14 +750,24 @@ BFT_HD void bft_kh_slot_decode(const BftImage& im, const uint64_t* line, const u
     const uint64_t home = ln - d, a = home / g.m, sub = home % g.m;
     const uint64_t c = ((sub << g.t) + g.m - 1) / g.m + q;
     const uint32_t hp = (uint32_t)((g.t < 32u ? a << g.t : 0ull) | c);
-    uint32_t hi = bft_kh_perm_inv(hp, g.hb) ^ bft_kh_mix<W>(restle);
+    uint32_t hi = bft_kh_perm_inv(hp, g.hb) ^ bft_kh_mix<W>(restle, g);
     if (g.hb < 32u) hi &= (1u << g.hb) - 1u;
-    // T = hi << restb | rest
+    uint32_t restb0 = g.restb;
+    if (g.po < 32u) {  // the first nucleotide's bits: from the top of the rest back into the hashed bits
+        restb0 = g.restb - 2u;
+        const uint32_t wi = restb0 >> 6, s2 = restb0 & 63u;
+        uint64_t e = 0;
+#pragma unroll
+        for (int i = 0; i < W; i++)
+            if ((uint32_t)i == wi) { e = (restle[i] >> s2) & 3ull; restle[i] &= ~(3ull << s2); }
+        hi = (hi & ((1u << g.po) - 1u)) | ((uint32_t)e << g.po) | ((hi >> g.po) << (g.po + 2u));
+    }
+    // T = hi << restb0 | rest
     uint64_t tl[W];
 #pragma unroll
     for (int i = 0; i < W; i++) tl[i] = restle[i];
     {
-        const uint32_t o = g.restb, wi = o >> 6, s2 = o & 63u;
+        const uint32_t o = restb0, wi = o >> 6, s2 = o & 63u;
 #pragma unroll
         for (int i = 0; i < W; i++) {
             if ((uint32_t)i == wi) tl[i] |= (uint64_t)hi << s2;

@@ -168,7 +168,8 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
         S_, f_, wb_, cb_, kb_, qb_, hb_, restb_, t_, m_, nl_, maxd_, db_, novf_ = (int(x) for x in geo)
         n_st = len(S.distinct(km))
         assert nl > 0
-        assert hb_ == min(32, 2 * k) and restb_ == 2 * k - hb_ and (1 << cb_) > n_st and kb_ == restb_ + qb_ and f_ == min(32, 128 // S_ - 1, kb_)
+        # (hashed: the top min(32, 2k - 4) bits without the first nucleotide's two -- those lie below them only for k < 11)
+        assert hb_ == min(32, 2 * k - 4) - (2 if k >= 11 else 0) and restb_ == 2 * k - hb_ and (1 << cb_) > n_st and f_ == min(32, 128 // S_ - 1) and kb_ == max(restb_ + qb_, f_)
         assert wb_ == 48 // S_ and cb_ + db_ + kb_ - f_ <= 8 * wb_ and nl == nl_ == (m_ << (hb_ - t_)) and t_ <= 27 and 2 <= m_ <= 32
         assert db_ == (3 if S_ >= 6 else 4 if S_ >= 4 else 5 if S_ == 3 else 6 if S_ == 2 else 8) and maxd_ < (1 << db_)
         assert nl * S_ * load >= n_st * 100 and (1 << qb_) >= -(-(1 << t_) // m_) and novf_ <= (0 if load <= 60 else 4096)
