@@ -1695,19 +1695,8 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
         attr_devs.fetch_or(dev_bit, std::memory_order_release);
     }
     // rec: bytes per input record (B, or 8W for the zero-padded word records of the sequence path); load_x reads that many
-    if (h->im.walk_kh && PROBE == 0) {  // ("walk_hash": launch_query leaves im.walk_kh set only for this)
-        static std::atomic<uint64_t> attr_h{0};
-        if (!(attr_h.load(std::memory_order_acquire) & dev_bit)) {
-            HIPCK(hipFuncSetAttribute((const void*)k_query6h<W, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 << 10));
-            attr_h.fetch_or(dev_bit, std::memory_order_release);
-        }
-        const uint64_t wgc = (n_chunks + BFT_BLOCK6 / 64 - 1) / (BFT_BLOCK6 / 64);
-        const dim3 gridh((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wgc, 512ull * h->opt_grid_mult)));
-        size_t ldsh = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
-        hipLaunchKernelGGL((k_query6h<W, STAGED>), gridh, dim3(BFT_BLOCK6), ldsh, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
-        HIPCK(hipGetLastError());
-        return 0;
-    }
+    if (h->im.walk_kh && PROBE == 0)  // ("walk_hash": launch_query leaves im.walk_kh set only for this)
+        return bft_walkh_query(h->im, d_kmers, n, rec, d_bits64, d_rows, ctr, (uint32_t)h->opt_grid_mult, s);
     if (res == 1) hipLaunchKernelGGL((k_query<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
     else if (res == 3) hipLaunchKernelGGL((k_query6<W, STAGED, PROBE>), grid, dim3(BFT_BLOCK6), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);
     else hipLaunchKernelGGL((k_query8<W, 1024, STAGED, PROBE>), grid, dim3(1024), lds, s, h->im, d_kmers, n, rec, d_bits64, d_rows, ctr);

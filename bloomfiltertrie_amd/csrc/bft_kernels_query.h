@@ -9,6 +9,7 @@
 
 #include "bft_kernels_load.h"
 #include "bft_claims.h"
+#include "bft_kh_dev.h"
 
 template <int W>
 __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
@@ -57,14 +58,20 @@ struct BftRootLds {
 // slowest wavefront.
 #define BFT_WALK_PASSES 16u   // passes of 64 k-mers per chunk: one 128-byte line of presence bits
 
-template <int W, int BLOCK, bool STAGED, int PROBE, bool WKH = false>
+// KS > 0 (with WKH: the kernel of "walk_hash", bft_walkh.hip): the slots per line of the k-mer hash.  Plain root groups are then looked up
+// HERE, all lanes of the wavefront together -- the line fetched by the quad and scanned in LDS like k_query_kh's (bft_kh_dev.h) -- and only the
+// special prefixes walk; the 64 KiB hash table of the Bloom filters stays in global memory (the few parked lanes read it through the L2) and
+// its LDS holds the wavefronts' lines.
+template <int W, int BLOCK, bool STAGED, int PROBE, bool WKH = false, int KS = 0>
 __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                            uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
     extern __shared__ __align__(16) uint8_t lds[];
-    uint32_t* l_hm = (uint32_t*)lds;
-    uint8_t* l_bf = lds + BFT_LDS_HM_BYTES;
+    uint32_t* l_hm = KS > 0 ? const_cast<uint32_t*>(im.hashmod) : (uint32_t*)lds;
+    uint8_t* l_bf = KS > 0 ? lds : lds + BFT_LDS_HM_BYTES;
     constexpr uint32_t WPW = BLOCK / 64;  // wavefronts per workgroup
     __shared__ uint64_t s_bits[WPW][BFT_WALK_PASSES];
+    __shared__ uint4 s_lines[KS > 0 ? WPW : 1][KS > 0 ? 64 * BFT_KH_LDS_LINE : 1];
+    uint4* const wave_lines = s_lines[KS > 0 ? threadIdx.x >> 6 : 0];
     const BftNode root = im.nodes[0];
     // the root's Bloom block and CC headers are only read when the root level goes through the containers: with the derived
     // root tables (im.rdir) that LDS space holds the queue of deferred lanes instead (below)
@@ -72,9 +79,11 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     const uint32_t bf_bytes = stage_root ? ((BFT_MODULO_HASH * (uint32_t)root.bf_wb + 15u) & ~15u) : 0u;
     BftCCX* l_cc = (BftCCX*)(l_bf + bf_bytes);
     {
-        const uint4* g = (const uint4*)im.hashmod;
-        uint4* l = (uint4*)l_hm;
-        for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        if (KS == 0) {
+            const uint4* g = (const uint4*)im.hashmod;
+            uint4* l = (uint4*)l_hm;
+            for (uint32_t i = threadIdx.x; i < BFT_LDS_HM_BYTES / 16; i += BLOCK) l[i] = g[i];
+        }
         if (stage_root) {
             const uint64_t* gb = (const uint64_t*)(im.bfT + (size_t)root.bf_off * 8);
             uint64_t* lb = (uint64_t*)l_bf;
@@ -132,6 +141,35 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
             int present = 0;
             bool parked = false;
             uint64_t t[W];
+            if constexpr (WKH && KS > 0) {
+                bool hashed = false;
+                BftKhKey<W> key;
+                key.home = 0; key.field = 0;
+#pragma unroll
+                for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+                if (i < n) {
+                    uint64_t x[W];
+                    load_x<W>(packed, i, B, end_aligned, x);
+                    bft_tform_from_x<W>(x, im.k, t);
+                    const uint32_t r = bft_digit<W>(t, im.k, 0);
+                    if ((im.rspec[r >> 5] >> (r & 31u)) & 1u) parked = true;  // child Node / UC rows under this prefix: the containers
+                    else { hashed = true; bft_kh_key<W>(t, im.k, im.kh, key); }
+                }
+                kh_fetch_quad(im, key.home, hashed, wave_lines);
+                if (hashed) {
+                    uint32_t val = 0;
+                    int res = kh_lds_scan<W, KS>(im, wave_lines + lane * BFT_KH_LDS_LINE, key, 0u, &val);
+                    for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {
+                        const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
+                        uint64_t hd[2];
+                        bft_kh_load_header(line, hd);
+                        res = bft_kh_scan<W, KS>(im, line, hd, key, d, &val);
+                    }
+                    if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;
+                    present = res > 0;
+                    if (rows) rows[i] = present ? (im.emit_cs ? val : 0u) : BFT_ABSENT_ROW;
+                }
+            } else
             if (i < n) {
                 uint64_t x[W];
                 load_x<W>(packed, i, B, end_aligned, x);
@@ -217,15 +255,6 @@ __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6
                                                                                                  uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
                                                                                                  uint32_t* __restrict__ ctr) {
     query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
-}
-
-// k_query6h: k_query6 with the lookup of plain root groups in the k-mer hash compiled in (4-row probes: only the few special prefixes
-// search sorted rows at all) -- the kernel of "walk_hash".
-template <int W, bool STAGED>
-__global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6h(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                                                                                  uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
-                                                                                                  uint32_t* __restrict__ ctr) {
-    query_body<W, BFT_BLOCK6, STAGED, 0, true>(im, packed, n, B, bits64, rows, ctr);
 }
 
 // Batched isBranchingRight / isBranchingLeft (src/branchingNode.c:16-112, :240-340; loop of src/file_io.c:943-998):

@@ -30,3 +30,7 @@ int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int
 // colour set of every k-mer position of a chunk of sequences (the arrays of query_sequences_core)
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
                uint32_t n_seqs, int canonical, uint32_t* d_csout, uint32_t* d_ctr, uint32_t chunk, hipStream_t s);
+
+// bft_walkh.hip: the container walk with plain root groups looked up in the k-mer hash ("walk_hash"): presence bits (and colour sets when
+// im.emit_cs) of n k-mers of `rec` bytes; d_ctr: the stream's claim counters or NULL
+int bft_walkh_query(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_rows, uint32_t* d_ctr, uint32_t grid_mult, hipStream_t s);
