@@ -196,7 +196,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
     cl.done();
 }
 
-// Sequence positions: the colour set of a position sits in the slot that says the k-mer is stored -- one line per position, nothing staged.
+// Sequence positions: the colour set of a position sits in the slot that says the k-mer is stored -- one line per position, fetched by the quad.
 template <int W, int S>
 __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
                                                 const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
@@ -204,21 +204,42 @@ __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __r
     const uint64_t P = pos_off[n_seqs];
     const uint64_t nblk = (P + 255) / 256;
     __shared__ uint32_t s_next[2];
+    __shared__ uint4 s_lines[4][64 * BFT_KH_LDS_LINE];
+    uint4* const wave_lines = s_lines[threadIdx.x >> 6];
     KhClaims cl(ctr, chunk, nblk, s_next);  // (the number of positions is only known on the device: the grid is the resident one, rounds beyond nblk are empty)
     cl.first();
     for (; cl.blk < nblk; cl.advance()) {
         const uint64_t p = cl.blk * 256 + threadIdx.x;
-        if (p >= P) continue;
-        uint32_t lo = tile_seq[p >> 6];
-        while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
         uint32_t cs = 0xFFFFFFFFu;
         uint64_t x[W], t[W];
-        if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
-            bft_tform_from_x<W>(x, im.k, t);
-            uint32_t val;
-            if (bft_kh_lookup<W, S>(im, t, &val)) cs = val;
+        BftKhKey<W> key;
+        key.home = 0; key.field = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+        bool live = false;
+        if (p < P) {
+            uint32_t lo = tile_seq[p >> 6];
+            while (lo + 1 < n_seqs && pos_off[lo + 1] <= p) lo++;
+            if (seq_window<W>(codes, bad, seq_off[lo] + (p - pos_off[lo]), im.k, canonical, x)) {
+                bft_tform_from_x<W>(x, im.k, t);
+                bft_kh_key<W>(t, im.k, im.kh, key);
+                live = true;
+            }
         }
-        csout[p] = cs;
+        kh_fetch_quad(im, key.home, live, wave_lines);  // (the whole wavefront's: bft_kh_dev.h)
+        if (live) {
+            uint32_t val = 0;
+            int res = kh_lds_scan<W, S>(im, wave_lines + (threadIdx.x & 63u) * BFT_KH_LDS_LINE, key, 0u, &val);
+            for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {
+                const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
+                uint64_t hd[2];
+                bft_kh_load_header(line, hd);
+                res = bft_kh_scan<W, S>(im, line, hd, key, d, &val);
+            }
+            if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;
+            if (res > 0) cs = val;
+        }
+        if (p < P) csout[p] = cs;
     }
     cl.done();
 }
