@@ -1541,6 +1541,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         bft_gpu* h; const uint64_t* tk; const uint32_t* tcol; uint64_t nk, n_sets; KhFill* f;
         static void run(void* c, hipStream_t s) { KhStart* k = (KhStart*)c; kh_start(k->h, k->tk, k->tcol, k->nk, k->n_sets, *k->f, s, nullptr); }
     } khs{h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, n_sets, &khf};
+    // (started HERE instead -- beside the root's table passes -- the sort-based table build was measured too: 17.2-18.4 ms against 17.0)
     const BftAssembleHook hook{tk.p ? &KhStart::run : nullptr, &khs};
     bft_trace_mark("merge / bookkeeping");
     double t2 = now_ms();
@@ -2139,13 +2140,41 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
         // (round-up method, exact on u32)
         // (16-byte rows and up, 16-byte aligned output: the 16-bytes-per-lane kernel, whose tiles are a multiple of 16 k-mers)
         const bool wide16 = rowbytes >= 16 && ((uintptr_t)d_out & 15u) == 0;
-        const uint32_t tile_rows = wide16 ? std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(16u, ((32768u / rowbytes) + 15u) & ~15u))
-                                          : std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(4u, ((32768u / rowbytes) + 3u) & ~3u));
+        uint32_t tile_rows = std::min<uint32_t>(CR_MAX_TILE_ROWS, std::max<uint32_t>(4u, ((32768u / rowbytes) + 3u) & ~3u));
+        if (wide16) {
+            // tiles of the 16-byte kernel belong to wavefronts, which answer 64 x CR16_UNROLL chunks of 16 bytes per turn: among the tiles of
+            // 16..64 KiB of output (a multiple of 16 k-mers, at most CR16_WAVE_ROWS) the one whose last turn is the fullest
+            const uint32_t per_turn = 64u * CR16_UNROLL;
+            double best = -1.0;
+            tile_rows = 16u;
+            for (uint32_t tr = 16u; tr <= CR16_WAVE_ROWS; tr += 16u) {
+                const uint64_t bytes = (uint64_t)tr * rowbytes;
+                if (bytes > (64u << 10) && best >= 0.0) break;
+                if (bytes < (16u << 10) && tr + 16u <= CR16_WAVE_ROWS && (uint64_t)(tr + 16u) * rowbytes <= (64u << 10)) continue;
+                const uint64_t nch = (bytes + 15u) / 16u, turns = (nch + per_turn - 1) / per_turn;
+                const double eff = (double)nch / (double)(turns * per_turn);
+                if (eff >= best) { best = eff; tile_rows = tr; }
+            }
+        }
         uint32_t div_l = 0;
         while ((1ull << div_l) < rowbytes) div_l++;
         const uint32_t div_m = div_l ? (uint32_t)(((1ull << 32) * ((1ull << div_l) - rowbytes)) / rowbytes + 1ull) : 0u;
         const uint64_t tiles = (n + tile_rows - 1) / tile_rows;
-        const dim3 cgrid((unsigned)std::min<uint64_t>(tiles, 256ull * 8));
+        dim3 cgrid((unsigned)std::min<uint64_t>(tiles, 256ull * 8));
+        if (wide16) {
+            // the tiles are dealt out by workgroup number: a grid larger than what is resident would run its last workgroups -- with all
+            // their tiles -- behind the others (82 registers: five workgroups per CU, not eight)
+            static std::atomic<int> resident16{0};
+            int r = resident16.load(std::memory_order_relaxed);
+            if (!r) {
+                int per_cu = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_color_rows_bm16, 256, 0) != hipSuccess || per_cu < 1) { per_cu = 4; (void)hipGetLastError(); }
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) { cus = 256; (void)hipGetLastError(); }
+                r = per_cu * cus;
+                resident16.store(r, std::memory_order_relaxed);
+            }
+            cgrid = dim3((unsigned)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)r));
+        }
         if (wide16)
             hipLaunchKernelGGL(k_color_rows_bm16, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
                                div_l, d_out);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __r
 // A k-mer on its way through the sort by home line: its T-form and its value travel with the key, so that the lines are assembled from
 // a sequential read (gathering the rows by index afterwards costs two random lines per k-mer).
 template <int W>
-struct KhRec {
+struct __attribute__((packed, aligned(4))) KhRec {  // (8 W + 4 bytes, no padding: the sort moves it three times)
     uint64_t t[W];
     uint32_t v;
 };

@@ -81,6 +81,45 @@ __global__ __launch_bounds__(1024) void block(const uint64_t* __restrict__ tab, 
     }
 }
 
+// quadline: one whole 64-byte line per lane and round, fetched the way k_query_kh fetches home lines (round 4): the four lanes of a quad load
+// 16 bytes each of ONE lane's line, four instructions bring the quad's four lines -- every line is requested once, whole, by one
+// instruction.  lane64: the same lines, every lane loading its own with four 16-byte loads (four instructions touch 64 lines each).
+// The next round's line depends on nothing that was loaded (the product kernel's k-mers are independent): seeds only.
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int j) {
+    switch (j) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xF, 0xF, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xF, 0xF, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);
+    }
+}
+template <bool QUAD>
+__global__ __launch_bounds__(1024) void lines(const uint64_t* __restrict__ tab, uint64_t mask, int rounds, uint64_t n, uint64_t* out) {
+    const uint64_t lmask = mask / 8;  // lines - 1
+    const uint32_t ql = threadIdx.x & 3u;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t acc = 0;
+        for (int r = 0; r < rounds; r++) {
+            const uint64_t ln = mix(i * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xD1B54A32D192ED03ull) & lmask;
+            if (QUAD) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint64_t l = ((uint64_t)quad_bcast((uint32_t)(ln >> 32), q) << 32) | quad_bcast((uint32_t)ln, q);
+                    const ulonglong2 w = *(const ulonglong2*)(tab + l * 8 + 2 * ql);
+                    acc += w.x ^ w.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const ulonglong2 w = *(const ulonglong2*)(tab + ln * 8 + 2 * q);
+                    acc += w.x ^ w.y;
+                }
+            }
+        }
+        out[i] = acc;
+    }
+}
+
 typedef void (*kern_t)(const uint64_t*, uint64_t, int, uint64_t, uint64_t*);
 static double run(kern_t k, const uint64_t* tab, uint64_t mask, int rounds, uint64_t n, uint64_t* out, int grid) {
     hipEvent_t a, b;
@@ -121,6 +160,7 @@ int main(int argc, char** argv) {
             {"chase_dep8", chase<1, 8>, 1}, {"chase_dep8_quarter_lanes", chase<4, 8>, 0.25}, {"chase_dep16", chase<1, 16>, 1},
             {"indep2", indep<2>, 2}, {"indep4", indep<4>, 4}, {"indep8", indep<8>, 8},
             {"block32", block<32>, 1}, {"block64", block<64>, 1}, {"block128", block<128>, 1},
+            {"lines64_by_lane", lines<false>, 1}, {"lines64_by_quad", lines<true>, 1},
         };
         for (auto& x : v) {
             const double ms = run(x.k, tab, words - 1, rounds, n, out, grid);
