@@ -263,6 +263,28 @@ extern "C" int64_t bft_hosttest_query_kh(void* hv, const uint8_t* q, uint64_t nq
     default: return (int64_t)query_kh<4>(t, q, nq, bits, vals);
     }
 }
+// home line of every packed k-mer under the host table's geometry (what a lookup computes first): successors / predecessors of a k-mer share it
+template <int W>
+static void kh_homes(HostTrie* t, const uint8_t* q, uint64_t nq, uint64_t* out) {
+    std::vector<uint64_t> tq;
+    to_tform<W>(q, nq, t->B, t->k, tq);
+    for (uint64_t i = 0; i < nq; i++) {
+        BftKhKey<W> kk;
+        bft_kh_key<W>(&tq[i * W], t->k, t->im.kh, kk);
+        out[i] = kk.home;
+    }
+}
+extern "C" int bft_hosttest_kh_homes(void* hv, const uint8_t* q, uint64_t nq, uint64_t* out) {
+    HostTrie* t = (HostTrie*)hv;
+    if (!t->im.kh_lines) return -1;
+    switch (t->W) {
+    case 1: kh_homes<1>(t, q, nq, out); break;
+    case 2: kh_homes<2>(t, q, nq, out); break;
+    case 3: kh_homes<3>(t, q, nq, out); break;
+    default: kh_homes<4>(t, q, nq, out); break;
+    }
+    return 0;
+}
 // every slot of the host table decoded back (bft_kh_slot_decode, what "compact_table" rebuilds the sorted table from): 1 when the decoded
 // (k-mer, value) pairs are exactly the rows of the sorted table with their row numbers
 template <int W>

@@ -79,6 +79,7 @@ def hostlib(built):
     lib.bft_hosttest_kh_geometry.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_walk_kh.argtypes = [C.c_void_p, C.c_int]
     lib.bft_hosttest_kh_roundtrip.argtypes = [C.c_void_p]
+    lib.bft_hosttest_kh_homes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.bft_hosttest_kh_probe_stats.restype = C.c_double
     lib.bft_hosttest_kh_probe_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.bft_hosttest_node_hash.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -176,6 +177,19 @@ def _host_check(hostlib, oracle_mod, km, k, seed=0):
         got = hostlib.bft_hosttest_query_kh(h, q.ctypes.data, len(q), bits8.ctypes.data, rows8.ctypes.data)
         assert got == int(S.from_bits(bits, len(q)).sum()) and (bits8 == bits).all() and (rows8 == rows).all(), load
         assert hostlib.bft_hosttest_kh_roundtrip(h) == 1, load
+        # the four successors of a k-mer (its last k - 1 nucleotides + any fourth) share their home line, and so do its four predecessors:
+        # what lets a branching query read two lines instead of eight (src/branchingNode.c:16-112, :240-340)
+        if load == 60:
+            fam = []
+            for row in S.unpack_codes(q[:64], k):
+                fam += [np.concatenate([row[1:], [c]]) for c in range(4)] + [np.concatenate([[c], row[:-1]]) for c in range(4)]
+            fq = np.ascontiguousarray(S.pack_codes(np.array(fam, dtype=np.uint8)))
+            homes = np.zeros(len(fq), np.uint64)
+            assert hostlib.bft_hosttest_kh_homes(h, fq.ctypes.data, len(fq), homes.ctypes.data) == 0
+            homes = homes.reshape(-1, 2, 4)
+            assert (homes == homes[:, :, :1]).all(), k
+            if nl > 256 and len(q) >= 64:
+                assert len(np.unique(homes[:, :, 0])) > homes.shape[0]  # (the families do not all land on a few lines)
         # ... and the container walk that looks plain root groups up in the table (the table's values are the rows here)
         hostlib.bft_hosttest_root_direct(h, 2)
         if hostlib.bft_hosttest_walk_kh(h, 1):

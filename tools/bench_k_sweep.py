@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Presence throughput against k on the config-2 generator (10 genomes of 2 Mbp, 1 % SNPs; 10^8 resident queries, 50 % present /
-50 % SNP mutants), every answer of a 500 000-query slice checked against set membership.  k % 9 != 0 are the extension."""
+50 % SNP mutants; half / a quarter as many beyond k = 32 / 64), every answer of a 500 000-query slice checked against set membership.
+k % 9 != 0 are the extension; k = 72 / 99 / 126 are the three- and four-word keys (one to four slots per line of the k-mer hash)."""
 import json
 import os
 import sys
@@ -18,7 +19,7 @@ def main():
     dev = torch.device("cuda", 0)
     nq = 100_000_000
     out = []
-    for k in (18, 21, 27, 31, 36, 45, 54, 63):
+    for k in (18, 21, 27, 31, 32, 36, 45, 54, 63, 64, 72, 99, 126):
         anc = S.random_genome(2_000_000, 1234)
         gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]
         t = BFT(k)
@@ -26,7 +27,7 @@ def main():
             t.insert_kmers(km, g)
         t.build()
         union = S.distinct(np.concatenate(gk))
-        n = nq if k <= 32 else nq // 2
+        n = nq if k <= 32 else (nq // 2 if k <= 64 else nq // 4)
         dq = make_queries_on_device(union, k, n, 5, dev)
         dbits = torch.zeros(((n + 63) // 64) * 8, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
@@ -42,7 +43,8 @@ def main():
         info = t.info()
         bt = t.build_time()
         out.append({"k": k, "queries": n, "ms": round(ms / cnt, 3), "G_kmers_per_s": round(n / (ms / cnt) / 1e6, 2), "ok": ok, "kmers": info["kmers"],
-                    "nodes": info["nodes"], "image_MB": round(info["image_bytes"] / 1e6, 1), "wgs": int(bt["query_wgs_per_cu"]), "probe": int(bt["query_probe_rows"])})
+                    "nodes": info["nodes"], "image_MB": round(info["image_bytes"] / 1e6, 1), "kh_slots": int(bt["kmer_hash_slots"]), "kh_maxd": int(bt["kmer_hash_maxd"]), "kh_overflow": int(bt["kmer_hash_overflow"]),
+                    "kh_bytes_per_kmer": round(t.footprint()["kmer_hash"] / max(1, info["kmers"]), 2)})
         print(json.dumps(out[-1]), flush=True)
         t.close()
         del dq, dbits

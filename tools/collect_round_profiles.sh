@@ -16,6 +16,7 @@ from tools import pmc_live
 out = {}
 for wl, nq, kb in (("cfg4", 125_000_000, 7), ("cfg4k31", 125_000_000, 8), ("cfg2", 100_000_000, 7)):
     out[wl] = pmc_live.collect(wl, nq, 3, "k_query", kmer_bytes=kb)
+out["cfg4_walk_hash"] = pmc_live.collect("cfg4", 125_000_000, 3, "k_query", opts=("walk_hash=1",), kmer_bytes=7)
 out["cfg4_walk"] = pmc_live.collect("cfg4", 125_000_000, 3, "k_query", opts=("kmer_hash=0",), kmer_bytes=7)
 json.dump(out, open(os.path.join(sys.argv[1], "pmc_query.json"), "w"), indent=1)
 PY
@@ -32,4 +33,12 @@ BFT_GPU_TRACE_BUILD=1 python3 tools/bench_insert.py --reserve --sample 100000 2>
 BFT_GPU_TRACE_BUILD=1 python3 tools/bench_insert.py --reserve --k 31 --sample 100000 2>&1 >/dev/null | grep "bft_gpu build" | tail -n 26 > "$OUT/build_config3_k31_host_marks.txt"
 python3 tools/bench_sequences.py 2>&1 | strip | grep "^{" > "$OUT/sequences.json"
 python3 tools/bench_color_rows.py 2>&1 | strip | grep "^{" > "$OUT/color_rows.jsonl"
+python3 tools/bench_color_rows.py cfg4 2>&1 | strip | grep "^{" >> "$OUT/color_rows.jsonl"
+# config 5's kernels under the counters (branching through the k-mer hash, colour rows), and the microbenchmarks they are priced against
+bash tools/pmc_collect_config5.sh > "$OUT/pmc_config5.log" 2>&1
+cp gpurun_out/pmc/config5/pmc_k_branching.json "$OUT/pmc_config5_branching.json"; cp gpurun_out/pmc/config5/pmc_k_color_rows_bm.json "$OUT/pmc_config5_color_rows.json"
+cp gpurun_out/pmc/config5/kernel_stats.txt "$OUT/config5_kernel_stats.txt"
+tools/microbench/gather 2 64 1024 8192 > "$OUT/microbench_gather.jsonl" 2>&1
+tools/microbench/stream > "$OUT/microbench_stream.jsonl" 2>&1
+python3 tools/probe_fill.py 27 2>&1 | strip | grep "^{" > "$OUT/kmer_hash_build.json"
 ls -la "$OUT"
