@@ -96,6 +96,8 @@ def main():
     t0 = time.perf_counter()
     t.build()
     t_build = time.perf_counter() - t0
+    breakdown = {k_: round(v, 1) for k_, v in t.build_time().items()}  # of THIS build (a later build of the handle overwrites the library's record)
+    info_built = t.info()
     del batches
     # one more genome onto the finished index (-add_genomes): its run is sorted and merged into the index, not everything re-sorted
     add = None
@@ -137,12 +139,13 @@ def main():
     ok_presence = bool((np.unpackbits(bits, bitorder="little")[:ns].astype(bool) == exp.any(axis=1)).all())
     out = {
         "metric": "M (k-mer, genome) pairs/sec inserted (insertKmers bulk build)",
-        "workload": f"k={args.k}, {args.genomes} genomes x {args.genome_len} nt, {args.snp_rate:.0%} SNPs, ids ascending",
-        "reserved": args.reserve, "warmed_up": True, "inserts": "synchronised per call" if args.sync_inserts else "stream-ordered (bft_gpu_insert_kmers_dev_async)", "pairs_in": npairs_in, "pairs_distinct": info["pairs"], "distinct_kmers": info["kmers"], "colorsets": info["colorsets"],
+        "workload": f"k={args.k}, {args.genomes - (1 if add else 0)} genomes x {args.genome_len} nt, {args.snp_rate:.0%} SNPs, ids ascending"
+                    + (" (+ one more genome added afterwards: add_one_genome; parity is checked on the index with it)" if add else ""),
+        "reserved": args.reserve, "warmed_up": True, "inserts": "synchronised per call" if args.sync_inserts else "stream-ordered (bft_gpu_insert_kmers_dev_async)", "pairs_in": npairs_in, "pairs_distinct": info_built["pairs"], "distinct_kmers": info_built["kmers"], "colorsets": info_built["colorsets"],
         "insert_s": round(t_ins, 4), "build_s": round(t_build, 4),
         "value": round(npairs_in / (t_ins + t_build) / 1e6, 2), "unit": "M pairs/s",
-        "build_breakdown_ms": {k_: round(v, 1) for k_, v in t.build_time().items()},
-        "trie": {x: info[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
+        "build_breakdown_ms": breakdown,
+        "trie": {x: info_built[x] for x in ("nodes", "ccs", "child_nodes", "prefixes", "uc_rows", "root_ccs", "image_bytes")},
         "add_one_genome": add,
         "parity": {"counts": bool(ok_counts), "presence_sample": ok_presence, "colors_sample": ok_colors, "sample": ns},
     }
