@@ -157,14 +157,16 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   ONE cache line per k-mer instead of a container walk (src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe).  Any
  *   k; derived when an image is built, loaded or unpacked; rows (bft_gpu_query_rows) always come from the walk.  0: no table, every query walks
  *   the containers and searches the sorted table.
- * "kmer_hash_load" (55): occupancy of the table's home lines in per cent, 10..80 (55: 1.06 lines read per lookup, 15 bytes per k-mer at k = 27).
+ * "kmer_hash_load" (55): occupancy of the table's home lines in per cent, 10..80 (55: 1.09 lines read per lookup, 15 bytes per k-mer at k = 27).
  * "walk_hash" (0, default; 1: presence / colour queries are answered by the container walk, k_query6h, whose root level looks PLAIN suffix groups up in
  *   their hashed form -- the table above: one line -- and walks the containers for the rest: child Nodes, the root's UC).
  * "query_dynamic" (1, default): the query kernels deal their blocks of k-mers out in rounds: the first by workgroup (wavefront) number, the others
  *   claimed from a counter (one pair per stream that launches them, allocated when the first image is built) -- workgroups are bound to an XCD by
  *   their number, and a static split makes the launch as slow as the XCD that reaches the table slowest; "query_chunk" (4) blocks of 256 per round
  *   of the k-mer hash kernels; batches below "query_dynamic_min" (2^16) k-mers are split statically; a handle queried on more than 32 streams
- *   runs the extra streams' launches static (counted: bft_gpu_build_time entry 20).  0: always static.
+ *   runs the extra streams' launches static (counted: bft_gpu_build_time entry 20).  0: always static.  The last workgroup of a launch resets the
+ *   stream's pair for the next one: launches of ONE handle on ONE stream must not run concurrently (two host threads, or a captured graph replayed
+ *   while a direct launch is in flight) -- use one stream per thread, as for any stream-ordered API.
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
