@@ -2120,9 +2120,11 @@ static int ensure_cs_bitmaps(bft_gpu* h) {
     const uint64_t rowbytes = (h->im.nb_genomes + 7) / 8, nsets = h->n_sets;
     if (rowbytes && nsets && nsets * rowbytes <= (4ull << 30)) {
         const uint64_t stride = (rowbytes + 3) & ~3ull;  // dword-aligned dictionary rows (k_color_rows_bm)
-        CK(h->d_cs_bm.alloc_zero(nsets * stride, h->stream));
+        // (CS_BM_SLACK zero bytes in front of the first row and behind the last: k_color_rows_bm16 loads 16 bytes from up to 15 bytes before a row
+        // and up to its last byte)
+        CK(h->d_cs_bm.alloc_zero(nsets * stride + 2 * CS_BM_SLACK, h->stream));
         hipLaunchKernelGGL(k_cs_bitmaps, dim3(grid_for((nsets + 255) / 256)), dim3(256), 0, h->stream, h->im.cs_off, h->im.cs_ids, h->im.cs_w, nsets, (uint32_t)stride,
-                           h->d_cs_bm.as<uint8_t>());
+                           h->d_cs_bm.as<uint8_t>() + CS_BM_SLACK);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));  // the row kernel may run on a caller's stream
         h->has_cs_bm = true;
@@ -2149,6 +2151,7 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
             tile_rows = 16u;
             for (uint32_t tr = 16u; tr <= CR16_WAVE_ROWS; tr += 16u) {
                 const uint64_t bytes = (uint64_t)tr * rowbytes;
+                // (tiles of 2-4, 4-8, 8-16 and 128-256 KiB were measured on config 5: 0.29-0.32 ms per GB written, no better than these)
                 if (bytes > (64u << 10) && best >= 0.0) break;
                 if (bytes < (16u << 10) && tr + 16u <= CR16_WAVE_ROWS && (uint64_t)(tr + 16u) * rowbytes <= (64u << 10)) continue;
                 const uint64_t nch = (bytes + 15u) / 16u, turns = (nch + per_turn - 1) / per_turn;
@@ -2176,13 +2179,13 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
             cgrid = dim3((unsigned)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)r));
         }
         if (wide16)
-            hipLaunchKernelGGL(k_color_rows_bm16, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+            hipLaunchKernelGGL(k_color_rows_bm16, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>() + CS_BM_SLACK, (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
                                div_l, d_out);
         else if (rowbytes >= 4)
-            hipLaunchKernelGGL(k_color_rows_bm<true>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+            hipLaunchKernelGGL(k_color_rows_bm<true>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>() + CS_BM_SLACK, (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
                                div_l, d_out);
         else
-            hipLaunchKernelGGL(k_color_rows_bm<false>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>(), (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
+            hipLaunchKernelGGL(k_color_rows_bm<false>, cgrid, dim3(256), 0, s, d_rowidx, h->d_cs_bm.as<uint8_t>() + CS_BM_SLACK, (rowbytes + 3) & ~3u, n, rowbytes, tile_rows, div_m,
                                div_l, d_out);
     }
     else

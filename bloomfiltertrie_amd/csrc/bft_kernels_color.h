@@ -2,6 +2,7 @@
 // Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
 // the host code there).
 #pragma once
+#define CS_BM_SLACK 32u  // zero bytes in front of and behind the bitmap dictionary (bft_gpu.hip, ensure_cs_bitmaps)
 __global__ void k_color_counts(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ cs_off,
                                uint64_t n, uint64_t* __restrict__ counts) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -158,13 +159,20 @@ __global__ __launch_bounds__(256) void k_color_rows_bm(const uint32_t* __restric
 }
 
 // The same rows, 16 output bytes per lane (rowbytes >= 16, `out` 16-byte aligned, tile_rows a multiple of 16: tiles start 16-byte
-// aligned): a quarter of the address arithmetic per byte and 16-byte stores.  The chunk starts at byte b of k-mer q's row: five
-// source dwords (one 16-byte + one 4-byte load at 4-byte alignment) and four funnel shifts; a chunk that straddles into the next
-// k-mer's row (one in rowbytes / 16) takes that row's first 16 bytes and a 128-bit byte shift -- selects and 64-bit shifts,
-// executed by every lane: no branch.
-// (one chunk per lane and turn: 64 registers, eight wavefronts per SIMD -- with two or four chunks per turn the kernel holds five and the
-// stores' acknowledgements are waited for in the open: 0.33 / 0.35 ms per GB written against 0.27; writing row by row with unaligned 16-byte
-// stores instead of splicing rows into aligned chunks was measured too: 0.43 ms)
+// aligned): 16-byte non-temporal stores at aligned addresses.  The chunk starts at byte b of k-mer q's row: ONE unaligned 16-byte load at
+// that byte of the dictionary row (the hardware takes unaligned loads, and loads are not what this kernel waits for); a chunk that straddles
+// into the next k-mer's row (one in rowbytes / 16) takes that row's first bytes by a second unaligned load that starts `take` bytes BEFORE
+// the row -- the bytes land where they belong -- and the two are merged under a byte mask: no funnel shifts, no splicing by selects
+// (round 3's form: five aligned source dwords, four funnel shifts, a 128-bit byte shift by selects and 64-bit shifts: 0.18 ms of arithmetic per
+// GB written beside 0.23 ms of stores).
+// What bounds it (config 5: 250-byte rows out of a 75 MB dictionary, 1 GB written per 4x10^6 k-mers): 0.28-0.29 ms = 3.5-3.6 TB/s written.  A
+// plain fill writes 4.6-4.8 TB/s, but this kernel's data comes out of a table that does not fit the L2: tools/microbench/stream.hip's
+// `expand_nt` -- every 16 bytes written are read from a pseudo-random 256-byte row of a 75 MiB source -- writes 3.49 TB/s (5.0 from a 4 MiB
+// source, 2.8 from 512 MiB): the kernel runs at the rate of its shape.  On the way there (per GB written): workgroup tiles with barriers
+// 0.36 ms (a barrier waits for the wavefront's stores); loads and stores share one in-order counter, so the next turn's loads are issued
+// ahead of this turn's stores (0.33); one chunk per lane and turn = eight or more wavefronts per SIMD instead of five (0.285); the
+// arithmetic (funnel shifts and 128-bit splices of round 3's form, 0.18 ms alone) replaced by unaligned loads: no further gain -- it was no
+// longer the limit; row-by-row unaligned STORES: 0.43.
 #define CR16_UNROLL 1
 #define CR16_WAVE_ROWS 1024u
 __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restrict__ csid, const uint8_t* __restrict__ bm, uint32_t stride, uint64_t n,
@@ -175,9 +183,8 @@ __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restr
     // waits for all of a wavefront's memory operations -- and for the next tile's colour-set ids to arrive: the kernel took the time of its
     // arithmetic PLUS the time of its stores, 0.35 ms per GB written where either alone takes 0.18 / 0.23.)
     __shared__ uint32_t s_cs_all[4][CR16_WAVE_ROWS + 1];  // dictionary row (dword offset) of each k-mer of the wavefront's tile (BFT_ABSENT_ROW: absent)
-    struct __attribute__((packed, aligned(4))) Quad { uint32_t a, b, c, d; };
+    struct __attribute__((packed, aligned(1))) QuadU { uint32_t a, b, c, d; };
     const uint64_t ntiles = (n + tile_rows - 1) / tile_rows;
-    const uint32_t* bmw = (const uint32_t*)bm;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* const s_cs = s_cs_all[wave];
     for (uint64_t tile = (uint64_t)blockIdx.x * 4u + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4u) {
@@ -197,8 +204,8 @@ __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restr
         // in-order counter (vmcnt), so a wavefront that stores and then loads cannot use what it loaded before its stores are acknowledged --
         // the kernel took the time of its arithmetic plus the time of its stores (0.35 ms per GB where either alone takes 0.18 / 0.23).
         struct Turn {
-            uint32_t take[CR16_UNROLL], sh[CR16_UNROLL], c0[CR16_UNROLL], s4[CR16_UNROLL];
-            Quad sq[CR16_UNROLL], nx[CR16_UNROLL];
+            uint32_t take[CR16_UNROLL];
+            QuadU a[CR16_UNROLL], nx[CR16_UNROLL];
         };
         auto fetch = [&](uint32_t i0, Turn& T) {
 #pragma unroll
@@ -208,14 +215,12 @@ __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restr
                 const uint32_t q = (t + ((byte - t) >> 1)) >> (div_l - 1u);  // rowbytes >= 16: div_l >= 4
                 const uint32_t b = byte - q * rowbytes;
                 T.take[u] = rowbytes - b;  // bytes of the chunk that belong to k-mer q (>= 16: all of it)
-                T.sh[u] = 8u * (b & 3u);
-                T.c0[u] = s_cs[q];
+                const uint32_t c0 = s_cs[q];
                 const uint32_t c1 = T.take[u] < 16u ? s_cs[q + 1] : BFT_ABSENT_ROW;
-                const uint32_t* src = bmw + (T.c0[u] != BFT_ABSENT_ROW ? T.c0[u] : 0u) + (b >> 2);
-                T.sq[u] = *reinterpret_cast<const Quad*>(src);  // (the dictionary carries slack behind its last row)
-                T.s4[u] = src[4];
-                if (c1 != BFT_ABSENT_ROW) T.nx[u] = *reinterpret_cast<const Quad*>(bmw + c1);
-                else T.nx[u] = Quad{0u, 0u, 0u, 0u};
+                T.a[u] = QuadU{0u, 0u, 0u, 0u};
+                T.nx[u] = QuadU{0u, 0u, 0u, 0u};
+                if (c0 != BFT_ABSENT_ROW) T.a[u] = *reinterpret_cast<const QuadU*>(bm + 4ull * c0 + b);          // (slack behind the last row)
+                if (c1 != BFT_ABSENT_ROW) T.nx[u] = *reinterpret_cast<const QuadU*>(bm + 4ull * c1 - T.take[u]);  // (slack in front of the first)
             }
         };
         auto emit = [&](uint32_t i0, const Turn& T) {
@@ -224,28 +229,16 @@ __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restr
                 const uint32_t i = i0 + (uint32_t)u * 64u;
                 if (i >= nch) continue;
                 const uint32_t byte = i * 16u;
-                // the chunk out of k-mer q's row: 128 bits from bit sh of the five source dwords
-                uint32_t v0 = __funnelshift_r(T.sq[u].a, T.sq[u].b, T.sh[u]), v1 = __funnelshift_r(T.sq[u].b, T.sq[u].c, T.sh[u]);
-                uint32_t v2 = __funnelshift_r(T.sq[u].c, T.sq[u].d, T.sh[u]), v3 = __funnelshift_r(T.sq[u].d, T.s4[u], T.sh[u]);
-                if (T.c0[u] == BFT_ABSENT_ROW) v0 = v1 = v2 = v3 = 0u;
                 const uint32_t tk = min(T.take[u], 16u);
-                // the next row's first bytes moved up by tk bytes: whole dwords by selects, the rest by 64-bit shifts
-                const uint32_t d = tk >> 2, r = 8u * (tk & 3u);
-                uint32_t y0 = T.nx[u].a, y1 = T.nx[u].b, y2 = T.nx[u].c, y3 = T.nx[u].d;
-                if (d & 1u) { y3 = y2; y2 = y1; y1 = y0; y0 = 0u; }
-                if (d & 2u) { y3 = y1; y2 = y0; y1 = 0u; y0 = 0u; }
-                if (d & 4u) { y3 = y2 = y1 = y0 = 0u; }
-                const uint32_t z3 = (uint32_t)((((uint64_t)y3 << 32) | y2) >> (32u - r)), z2 = (uint32_t)((((uint64_t)y2 << 32) | y1) >> (32u - r));
-                const uint32_t z1 = (uint32_t)((((uint64_t)y1 << 32) | y0) >> (32u - r)), z0 = y0 << r;
                 // bytes [0, tk) from this row, [tk, 16) from the next: per-dword masks
                 const uint64_t keep_lo = tk >= 8u ? ~0ull : (1ull << (8u * tk)) - 1ull;                  // bytes 0..7
                 const uint64_t keep_hi = tk >= 16u ? ~0ull : (tk <= 8u ? 0ull : (1ull << (8u * (tk - 8u))) - 1ull);  // bytes 8..15
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4 o;
-                o.x = (v0 & (uint32_t)keep_lo) | z0;
-                o.y = (v1 & (uint32_t)(keep_lo >> 32)) | z1;
-                o.z = (v2 & (uint32_t)keep_hi) | z2;
-                o.w = (v3 & (uint32_t)(keep_hi >> 32)) | z3;
+                o.x = (T.a[u].a & (uint32_t)keep_lo) | (T.nx[u].a & ~(uint32_t)keep_lo);
+                o.y = (T.a[u].b & (uint32_t)(keep_lo >> 32)) | (T.nx[u].b & ~(uint32_t)(keep_lo >> 32));
+                o.z = (T.a[u].c & (uint32_t)keep_hi) | (T.nx[u].c & ~(uint32_t)keep_hi);
+                o.w = (T.a[u].d & (uint32_t)(keep_hi >> 32)) | (T.nx[u].d & ~(uint32_t)(keep_hi >> 32));
                 if (byte + 16u <= total) __builtin_nontemporal_store(o, (u32x4*)(tout + byte));
                 else {
                     const uint32_t w[4] = {o.x, o.y, o.z, o.w};  // the last chunk of the whole batch

@@ -47,8 +47,9 @@ typedef BftClaims<BFT_KH_MIN_CLAIM> KhClaims;
 //     chain of dependent loads is not what binds.
 // So the line is fetched by the QUAD: the four lanes of a quad load 16 bytes each of ONE lane's home line -- one instruction brings
 // sixteen whole lines per wavefront instead of a quarter of sixty-four, so four instructions bring the 64 lines with a quarter of the
-// tag lookups each, every line is requested once and whole, and nothing is read twice.  The pieces reach their owner lane through DPP
-// quad permutes (no LDS, no memory), which then scans its line out of registers (bft_kh_scan_full).
+// tag lookups each, every line is requested once and whole, and nothing is read twice.  The pieces go to the wavefront's LDS, where the
+// owner lane reads its header and the body of the slot that matches (bft_kh_dev.h; gathered into registers by DPP and scanned there the
+// kernel was bound by its own instructions: 48 G k-mers/s against 52.5).
 template <int W, int S>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                           uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {

@@ -569,32 +569,6 @@ BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t*
     }
     return occ != (1u << S) - 1u ? 0 : -1;
 }
-// The same against a line that is already in registers (8 words): every offset a compile-time constant.
-template <int W, int SS>
-BFT_HD int bft_kh_scan_full(const BftImage& im, const uint64_t* ln, const BftKhKey<W>& key, uint32_t d, uint32_t* val) {
-    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S, f = bft_kh_field_bits(S);
-    const uint32_t cb = im.kh.cb;
-    const uint64_t fmask = f ? (1ull << f) - 1ull : 0ull, vmask = (1ull << cb) - 1ull;
-    const uint32_t occ = (uint32_t)(ln[1] >> (64u - S));
-    int found = 0;
-#pragma unroll
-    for (uint32_t s = 0; s < S; s++) {
-        const uint64_t fld = f ? bft_kh_bits_at<2>(ln, s * f) & fmask : 0ull;
-        const uint64_t b0 = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb);
-        bool same = fld == key.field && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & key.bmask[0]) == 0 && (b0 & vmask) != 0;
-#pragma unroll
-        for (int i = 1; i < W; i++) {
-            if (8u * (uint32_t)i >= wb) break;
-            const uint64_t b = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb + 64u * (uint32_t)i);
-            same = same && ((b ^ key.body[i]) & key.bmask[i]) == 0;  // (bmask is zero beyond the body's bits)
-        }
-        if (same) {
-            *val = (uint32_t)(b0 & vmask) - 1u;
-            found = 1;
-        }
-    }
-    return found ? 1 : (occ != (1u << S) - 1u ? 0 : -1);
-}
 // The k-mers that differ from `key`'s only in the two bits b, b + 1 of the rest (the four successors of a k-mer: its last nucleotide; the four
 // predecessors: its first -- they share their home line, bft_image.h): the comparison masks without those two stored key bits.
 template <int W>
@@ -618,29 +592,8 @@ BFT_HD void bft_kh_family(const BftKhGeo& g, const BftKhKey<W>& key, uint32_t b,
         }
     }
 }
-// how many k-mers of the family line `ln` (in registers) holds, d lines past their home; returns -1 when the line is full (the family may go on behind it)
-template <int W, int SS>
-BFT_HD int bft_kh_count_full(const BftImage& im, const uint64_t* ln, const BftKhKey<W>& key, const BftKhFamily<W>& fam, uint32_t d, int* count) {
-    constexpr uint32_t S = (uint32_t)SS, wb = 48u / S, f = bft_kh_field_bits(S);
-    const uint32_t cb = im.kh.cb;
-    const uint64_t vmask = (1ull << cb) - 1ull;
-    const uint32_t occ = (uint32_t)(ln[1] >> (64u - S));
-#pragma unroll
-    for (uint32_t s = 0; s < S; s++) {
-        const uint64_t fld = f ? bft_kh_bits_at<2>(ln, s * f) : 0ull;
-        const uint64_t b0 = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb);
-        bool same = ((fld ^ key.field) & fam.fkeep) == 0 && ((occ >> s) & 1u) && ((b0 ^ (key.body[0] | ((uint64_t)d << cb))) & fam.bkeep[0]) == 0 && (b0 & vmask) != 0;
-#pragma unroll
-        for (int i = 1; i < W; i++) {
-            if (8u * (uint32_t)i >= wb) break;
-            const uint64_t b = bft_kh_bits_at<BFT_KH_LINE_WORDS>(ln, 128u + 8u * s * wb + 64u * (uint32_t)i);
-            same = same && ((b ^ key.body[i]) & fam.bkeep[i]) == 0;
-        }
-        *count += same ? 1 : 0;
-    }
-    return occ != (1u << S) - 1u ? 0 : -1;
-}
-// the same on a line in memory: header first, the bodies of the slots whose fields match
+// how many k-mers of the family the line `line` (in memory) holds, d lines past their home: header first, the bodies of the slots whose fields
+// match; returns -1 when the line is full (the family may go on behind it)
 template <int W, int SS>
 BFT_HD int bft_kh_count_line(const BftImage& im, const uint64_t* line, const BftKhKey<W>& key, const BftKhFamily<W>& fam, uint32_t d, int* count) {
     const uint32_t S = SS > 0 ? (uint32_t)SS : im.kh.S, f = SS > 0 ? bft_kh_field_bits(SS > 0 ? SS : 1) : im.kh.f, wb = SS > 0 ? 48u / (SS > 0 ? SS : 1) : im.kh.wb, cb = im.kh.cb;

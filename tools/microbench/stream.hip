@@ -26,6 +26,16 @@ __global__ __launch_bounds__(256) void k_copy(const u32x4* __restrict__ src, u32
         if (NT) __builtin_nontemporal_store(v, &dst[i]); else dst[i] = v;
     }
 }
+// the shape of k_color_rows_bm16: every 16 bytes written are read from a SMALL source (the 75 MB bitmap dictionary of config 5: L2 /
+// Infinity Cache hits, no HBM reads) -- a fill whose data comes through the caches.  src_n16 = 16-byte words of the source.
+__global__ __launch_bounds__(256) void k_expand(const u32x4* __restrict__ src, uint64_t src_n16, u32x4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t hsh = (uint32_t)(i >> 4) * 0x9E3779B1u;
+        const uint64_t j = (((uint64_t)hsh * (uint32_t)(src_n16 / 16)) >> 32) * 16 + (i & 15);  // a pseudo-random 256-byte row of the source, 16 lanes per row
+        const u32x4 v = src[j];
+        __builtin_nontemporal_store(v, &dst[i]);
+    }
+}
 template <class F>
 static double timeit(F f) {
     hipEvent_t a, b;
@@ -54,5 +64,10 @@ int main() {
     printf("{\"kernel\": \"copy\", \"bytes_read_plus_written\": %llu, \"ms\": %.4f, \"GBps\": %.0f}\n", (unsigned long long)(2 * bytes), ms, 2 * bytes / ms / 1e6);
     ms = timeit([&] { hipLaunchKernelGGL(k_copy<true>, g, t, 0, 0, (const u32x4*)a, (u32x4*)b, n16); });
     printf("{\"kernel\": \"copy_nt\", \"bytes_read_plus_written\": %llu, \"ms\": %.4f, \"GBps\": %.0f}\n", (unsigned long long)(2 * bytes), ms, 2 * bytes / ms / 1e6);
+    for (uint64_t src_mb : {4ull, 75ull, 512ull}) {
+        const uint64_t sn16 = (src_mb << 20) / 16;
+        ms = timeit([&] { hipLaunchKernelGGL(k_expand, g, t, 0, 0, (const u32x4*)a, sn16, (u32x4*)b, n16); });
+        printf("{\"kernel\": \"expand_nt\", \"source_MiB\": %llu, \"bytes_written\": %llu, \"ms\": %.4f, \"GBps_written\": %.0f}\n", (unsigned long long)src_mb, (unsigned long long)bytes, ms, bytes / ms / 1e6);
+    }
     return 0;
 }
