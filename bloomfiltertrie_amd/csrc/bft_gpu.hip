@@ -1437,7 +1437,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             // the ids beside the keys, then the buckets -- where the composite does fit, the bucket's number being implied
             bool done = false;
             h->msd_max_bucket = 0;
-            if (h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2) && (2 * h->k - std::min(18, 2 * h->k)) + gb <= 64) {
+            // (not at k = 32: the split would sort the bit range [46, 64), and rocPRIM's radix sort mis-sorts ranges that start above bit 0 and end at
+            // bit 64 -- the same defect the composite path avoids by staying within 63 bits; found by tools/stress_parity.py, k = 32 with build_msd = 2)
+            if (h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2) && (2 * h->k - std::min(18, 2 * h->k)) + gb <= 64 && 2 * h->k < 64) {
                 if (h->max_gid_seen < 256) CK(split_dedupe_w1<uint8_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
                 else if (h->max_gid_seen < 65536) CK(split_dedupe_w1<uint16_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
                 else CK(split_dedupe_w1<uint32_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));

@@ -248,7 +248,7 @@ def test_host_index_invariants_a7(hostlib, oracle_mod):
 
 
 # ---- extension beyond the reference: k that is not a multiple of 9 (the reference rejects it, src/main.c:61-63) ----
-@pytest.mark.parametrize("k", [10, 13, 17, 22, 31, 35, 40, 64, 125])
+@pytest.mark.parametrize("k", [10, 13, 17, 22, 31, 32, 35, 40, 64, 125])
 def test_host_index_any_k_ground_truth(hostlib, k):
     km = np.ascontiguousarray(S.distinct(S.kmers_of(S.random_genome(60000, 7 + k), k)))
     h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
@@ -262,7 +262,7 @@ def test_host_index_any_k_ground_truth(hostlib, k):
     hostlib.bft_hosttest_free(h)
 
 
-@pytest.mark.parametrize("k,levels", [(31, 1), (31, 3), (22, 2), (40, 3), (17, 1)])
+@pytest.mark.parametrize("k,levels", [(31, 1), (31, 3), (22, 2), (40, 3), (17, 1), (32, 1), (32, 2), (64, 2)])
 def test_host_index_any_k_deep(hostlib, k, levels):
     km = np.ascontiguousarray(S.low_entropy_kmers(50000, k, 24, seed=k + levels, levels=levels))
     h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)

@@ -542,6 +542,33 @@ def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
     assert redone[3] >= n_pref if k > 9 else redone[3] == 0, redone  # (k = 9: the split covers every bit, nothing is sorted in a bucket)
 
 
+def test_k32_builds_through_the_device_wide_sort_when_buckets_are_forced():
+    """k = 32: the root-prefix split of (k-mer, id) pairs would sort the bit range [46, 64), which rocPRIM's radix sort mis-sorts (ranges that
+    start above bit 0 and end at bit 64): "build_msd" 2 must not take it.  Found by tools/stress_parity.py (wrong presence bits, then a
+    memory fault in the bucket kernels).  Same image, extraction and answers as the device-wide sort."""
+    k = 32
+    base = S.low_entropy_kmers(12000, k, 12, 17, levels=1)
+    rng = np.random.default_rng(5)
+    parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.6]) for _ in range(4)]
+    q = np.ascontiguousarray(np.concatenate([base, S.snp_mutants(base[::3], k, 3)]))
+    truth = np.zeros(len(q), bool)
+    for p in parts:
+        truth |= S.member(q, p)
+    outs = []
+    for msd in (0, 2):
+        t = BFT(k)
+        t.set_option("build_msd", msd)
+        for g, p in enumerate(parts):
+            t.insert_kmers(p, g)
+        t.build()
+        assert t.build_time()["sort_max_bucket"] == 0  # (no bucket was sorted: the split was not taken)
+        bits = S.from_bits(t.query_presence(q), len(q)).astype(bool)
+        assert (bits == truth).all(), msd
+        outs.append(t.extract())
+        t.close()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
 @pytest.mark.parametrize("k", [27, 31, 18, 45, 63])
 def test_compact_table_drops_and_restores_the_sorted_table(k, tmp_path):
     """"compact_table": once the k-mer hash holds every (k-mer, colour set) the sorted table and the colour set per k-mer leave HBM;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check against ground truth kept in Python dictionaries: random k, genome counts, insertion orders (ascending /
-shuffled ids, duplicate batches, incremental rebuilds), then presence, colour sets, colour rows (host and device calls), sequence
+shuffled ids, duplicate batches, incremental rebuilds), then presence, colour sets, colour rows (host and device calls), branching, sequence
 queries (host and device calls) -- across the build paths (composite / narrow-id / general sort) and the derived tables.
-usage: stress_parity.py [rounds] [seed]"""
+usage: stress_parity.py [rounds] [seed] [first round]"""
 import math
 import os
 import sys
@@ -15,11 +15,13 @@ from bloomfiltertrie_amd import BFT, synth as S, _lib as L  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+verbose = bool(os.environ.get("STRESS_VERBOSE"))
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
-for r in range(rounds):
+for r in range(first, rounds):
     rng = np.random.default_rng(seed0 * 1000 + r)
-    k = int(rng.choice([13, 18, 21, 27, 27, 31, 31, 36, 45, 63]))
+    k = int(rng.choice([13, 18, 21, 27, 27, 31, 31, 32, 36, 45, 63, 64, 72, 99, 126]))
     ngen = int(rng.choice([1, 2, 4, 5, 9, 40, 130, 300]))
     glen = int(rng.integers(3000, 30000))
     deep = min(int(rng.integers(0, 3)), max(0, k // 9 - 1))
@@ -38,6 +40,10 @@ for r in range(rounds):
     if shuffled:
         rng.shuffle(order)
     t = BFT(k)
+    if verbose:
+        print(f"round {r} starts: k={k} genomes={ngen} glen={glen} deep={deep} shuffled={shuffled}", flush=True)
+        _so = t.set_option
+        t.set_option = lambda n_, v_: (print("  option", n_, v_, flush=True), _so(n_, v_))[1]
     if rng.random() < 0.3:
         t.set_option("kmer_hash", 0)
     if rng.random() < 0.3:
@@ -50,6 +56,8 @@ for r in range(rounds):
         t.set_option("kmer_hash_load", int(rng.choice([20, 65, 80])))
     if rng.random() < 0.4:
         t.set_option("compact_table", 1)                                   # the sorted table leaves HBM whenever the k-mer hash can stand in for it
+    for ov in os.environ.get("STRESS_OPTS", "").split():  # (bisecting a failure: options applied on top of the round's own)
+        t.set_option(ov.split("=")[0], int(ov.split("=")[1]))
     cut = int(rng.integers(0, ngen + 1))
     use_async = bool(rng.random() < 0.4)
     for j, gi in enumerate(order):
@@ -90,6 +98,20 @@ for r in range(rounds):
     assert (np.unpackbits(drows.cpu().numpy(), axis=1, bitorder="little")[:, :ngen] == exp_rows).all(), ("rows dev", r, k, ngen)
     assert (S.from_bits(dbits.cpu().numpy(), len(q)).astype(bool) == exp_pres).all()
     assert (S.from_bits(t.query_presence(q), len(q)).astype(bool) == exp_pres).all()  # (after the colour-set launch: rows mode is back)
+    # branching (src/file_io.c:943-998): successors / predecessors counted among the stored k-mers, whether or not the k-mer itself is stored
+    stored_keys = set(S.row_keys(np.ascontiguousarray(base[present_any])).tolist())
+    qs = np.ascontiguousarray(q[rng.integers(0, len(q), 400)])
+    codes = S.unpack_codes(qs, k)
+    nbr = np.zeros((len(qs), 2), dtype=np.int64)
+    for c in range(4):
+        suc = np.concatenate([codes[:, 1:], np.full((len(qs), 1), c, np.uint8)], axis=1)
+        pre = np.concatenate([np.full((len(qs), 1), c, np.uint8), codes[:, :-1]], axis=1)
+        nbr[:, 0] += np.array([key in stored_keys for key in S.row_keys(S.pack_codes(suc)).tolist()])
+        nbr[:, 1] += np.array([key in stored_keys for key in S.row_keys(S.pack_codes(pre)).tolist()])
+    bb, cnt = t.query_branching(qs, with_counts=True)
+    assert (cnt == ((nbr[:, 0] << 4) | nbr[:, 1])).all(), ("branching counts", r, k, ngen)
+    assert (S.from_bits(bb, len(qs)).astype(bool) == ((nbr[:, 0] > 1) | (nbr[:, 1] > 1))).all(), ("branching bits", r, k, ngen)
+    assert (S.from_bits(t.query_branching(qs), len(qs)).astype(bool) == ((nbr[:, 0] > 1) | (nbr[:, 1] > 1))).all(), ("branching bits, no counts", r, k, ngen)
     b3, rws, sets = t.query_rows(q)
     ek, ecs = t.extract()
     assert (ek[rws[exp_pres]] == q[exp_pres]).all() and (ecs[rws[exp_pres]] == sets[exp_pres]).all(), ("rows", r, k, ngen)
