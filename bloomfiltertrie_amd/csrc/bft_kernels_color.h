@@ -165,14 +165,14 @@ __global__ __launch_bounds__(256) void k_color_rows_bm(const uint32_t* __restric
 // the row -- the bytes land where they belong -- and the two are merged under a byte mask: no funnel shifts, no splicing by selects
 // (round 3's form: five aligned source dwords, four funnel shifts, a 128-bit byte shift by selects and 64-bit shifts: 0.18 ms of arithmetic per
 // GB written beside 0.23 ms of stores).
-// What bounds it (config 5: 250-byte rows out of a 75 MB dictionary, 1 GB written per 4x10^6 k-mers): 0.28-0.29 ms = 3.5-3.6 TB/s written.  A
-// plain fill writes 4.6-4.8 TB/s, but this kernel's data comes out of a table that does not fit the L2: tools/microbench/stream.hip's
-// `expand_nt` -- every 16 bytes written are read from a pseudo-random 256-byte row of a 75 MiB source -- writes 3.49 TB/s (5.0 from a 4 MiB
-// source, 2.8 from 512 MiB): the kernel runs at the rate of its shape.  On the way there (per GB written): workgroup tiles with barriers
-// 0.36 ms (a barrier waits for the wavefront's stores); loads and stores share one in-order counter, so the next turn's loads are issued
-// ahead of this turn's stores (0.33); one chunk per lane and turn = eight or more wavefronts per SIMD instead of five (0.285); the
-// arithmetic (funnel shifts and 128-bit splices of round 3's form, 0.18 ms alone) replaced by unaligned loads: no further gain -- it was no
-// longer the limit; row-by-row unaligned STORES: 0.43.
+// Measured on config 5 (250-byte rows out of a 75 MB dictionary, 1.016 GB written per 4x10^6 k-mers; rocprofv3 kernel trace,
+// profiles/r04/config5_kernel_stats.txt): 0.259 ms = 3.9 TB/s written = 0.85 of a plain fill (4.55-4.66 TB/s, tools/microbench/stream.hip).
+// The kernel's data comes out of a table that does not fit the L2: `expand_nt` of the same microbenchmark -- every 16 bytes written are read
+// from a uniformly random 256-byte row of a 75 MiB source -- writes 3.49 TB/s (5.0 from a 4 MiB source); the real batch does better than
+// that because popular colour sets repeat.  On the way here (per GB written): workgroup tiles with barriers 0.36 ms (a barrier waits for
+// the wavefront's stores); loads and stores share one in-order counter, so the next turn's loads are issued ahead of this turn's stores
+// (0.33); one chunk per lane and turn = eight wavefronts per SIMD instead of five (0.28); the funnel shifts and 128-bit splices of round 3's
+// form replaced by unaligned loads, 49 registers (0.255).  Row-by-row unaligned STORES: 0.43.  Tiles of 2 ... 256 KB: no difference.
 #define CR16_UNROLL 1
 #define CR16_WAVE_ROWS 1024u
 __global__ __launch_bounds__(256) void k_color_rows_bm16(const uint32_t* __restrict__ csid, const uint8_t* __restrict__ bm, uint32_t stride, uint64_t n,
