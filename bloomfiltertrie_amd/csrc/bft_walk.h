@@ -335,32 +335,45 @@ BFT_HD BftKhGeo bft_kh_geometry(int k, uint64_t n, uint64_t n_values, uint32_t l
     g.cb = bft_kh_value_bits(n_values);
     g.db = BFT_KH_DBITS_FOR(1u); g.maxd = (1u << g.db) - 1u;
     g.S = 1; g.f = 0; g.wb = 48; g.kb = 0; g.qb = 0; g.t = 0; g.m = 1; g.inv = 0; g.nl = 1;
+    // Every number of slots per line, twice: with as many home lines as the occupancy asks for (nl = 2^(hb - t) m, m in [16, 32]: any size
+    // within 6 %), and with that number rounded up to a power of two -- m lines per 2^t values of c cost q up to one bit more than log2 says
+    // unless m is a power of two, and that bit can be the one a body lacks (config 5: k = 63, 3x10^5 colour sets -- four slots per line fit
+    // with 2^22 lines where 4.05x10^6 lines allow three).  The geometry with the fewest lines wins (ties: more slots, then the exact size).
+    uint64_t best_nl = ~0ull;
     for (uint32_t S = BFT_KH_MAX_SLOTS; S >= 1; S--) {
-        // home lines wanted -> nl = 2^(hb - t) * m with m in [16, 32] (t <= 27: the magic division of bft_kh_place needs frac < 2^27)
-        const uint64_t per = (uint64_t)S * load_pct;
-        uint64_t want = (n * 100ull + per - 1) / per;
-        if (want < 1) want = 1;
-        uint32_t lg = 0;
-        while ((want >> (lg + 1)) != 0) lg++;  // floor(log2(want))
-        uint32_t abits = lg > 4 ? lg - 4 : 0;   // bits of the part `a` of the hashed high bits
-        if (abits > g.hb) abits = g.hb;
-        if (g.hb - abits > 27u) abits = g.hb - 27u;
-        const uint32_t t = g.hb - abits;
-        uint64_t m = (want + (1ull << abits) - 1) >> abits;
-        if (m < 2) m = 2;  // (m = 1 has no 32-bit magic number; a table is never smaller than 2^(hb - 27) * 2 lines)
-        // q < ceil(2^t / m): its bits
-        const uint64_t span = ((1ull << t) + m - 1) / m;
-        uint32_t qb = 0;
-        while (qb < 32 && ((span - 1) >> qb)) qb++;
-        // (a stored key never has fewer bits than a header field: short keys -- k < 18 or so -- are padded with zeros on top)
-        const uint32_t f = bft_kh_field_bits(S), kb = g.restb + qb > f ? g.restb + qb : f, wb = bft_kh_body_bytes(S);
-        const uint32_t db = BFT_KH_DBITS_FOR(S);
-        if (S == 1 || g.cb + db + kb - f <= 8u * wb) {
-            g.db = db; g.maxd = (1u << db) - 1u;
-            g.S = S; g.f = f; g.wb = wb; g.kb = kb; g.qb = qb; g.t = t; g.m = (uint32_t)m;
-            g.inv = (uint32_t)(((1ull << 32) + m - 1) / m);
-            g.nl = (uint64_t)m << abits;
-            break;
+        for (uint32_t pow2 = 0; pow2 < 2; pow2++) {
+            // (t <= 27: the magic division of bft_kh_key needs frac < 2^27)
+            const uint64_t per = (uint64_t)S * load_pct;
+            uint64_t want = (n * 100ull + per - 1) / per;
+            if (want < 1) want = 1;
+            uint32_t lg = 0;
+            while ((want >> (lg + 1)) != 0) lg++;  // floor(log2(want))
+            if (pow2) {
+                if (want == (1ull << lg)) continue;  // (already a power of two: the exact geometry is this one)
+                lg++;
+                want = 1ull << lg;
+            }
+            uint32_t abits = lg > 4 ? lg - 4 : 0;   // bits of the part `a` of the hashed high bits
+            if (abits > g.hb) abits = g.hb;
+            if (g.hb - abits > 27u) abits = g.hb - 27u;
+            const uint32_t t = g.hb - abits;
+            uint64_t m = (want + (1ull << abits) - 1) >> abits;
+            if (m < 2) m = 2;  // (m = 1 has no 32-bit magic number; a table is never smaller than 2^(hb - 27) * 2 lines)
+            // q < ceil(2^t / m): its bits
+            const uint64_t span = ((1ull << t) + m - 1) / m;
+            uint32_t qb = 0;
+            while (qb < 32 && ((span - 1) >> qb)) qb++;
+            // (a stored key never has fewer bits than a header field: short keys -- k < 18 or so -- are padded with zeros on top)
+            const uint32_t f = bft_kh_field_bits(S), kb = g.restb + qb > f ? g.restb + qb : f, wb = bft_kh_body_bytes(S);
+            const uint32_t db = BFT_KH_DBITS_FOR(S);
+            const uint64_t nl = m << abits;
+            if ((S == 1 || g.cb + db + kb - f <= 8u * wb) && nl < best_nl) {
+                best_nl = nl;
+                g.db = db; g.maxd = (1u << db) - 1u;
+                g.S = S; g.f = f; g.wb = wb; g.kb = kb; g.qb = qb; g.t = t; g.m = (uint32_t)m;
+                g.inv = (uint32_t)(((1ull << 32) + m - 1) / m);
+                g.nl = nl;
+            }
         }
     }
     return g;
