@@ -167,22 +167,46 @@ __global__ __launch_bounds__(64 * SEQ_TALLY_WAVES) void k_seq_tally(const uint32
         for (uint32_t win0 = 0; win0 < G; win0 += win) {
             const uint32_t wn = min(win, G - win0);
             for (uint32_t j = lane; j < wn; j += 64) cnt[j] = 0;
-            for (uint64_t base = 0; base < m; base += 64) {  // m is wavefront-uniform: every lane takes every turn
-                const uint32_t cs = base + lane < m ? csin[pa + base + lane] : 0xFFFFFFFFu;
-                const uint32_t pcs = __shfl_up(cs, 1);
-                const bool boundary = lane == 0 || pcs != cs;
-                const uint64_t bmask = __ballot(boundary);
-                if (boundary && cs != 0xFFFFFFFFu) {
-                    const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
-                    const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-                    const uint32_t q1 = cs_off[cs + 1];
-                    for (uint32_t q = cs_off[cs]; q < q1; q += 8) {  // eight ids per step, loaded together
-                        uint32_t id[8];
+            // Two passes of 64 positions per turn, their loads issued together -- colour sets of both, then the list bounds of both, then the
+            // first eight ids of both: a 150-nt read is one turn of three dependent round trips where pass after pass made six (1.33 -> 1.05 ms
+            // per 10^6 reads).  Two SEQUENCES per turn as well were measured: 1.17 ms -- the chain's latency is no longer what is left.
+            for (uint64_t base = 0; base < m; base += 128) {  // m is wavefront-uniform: every lane takes every turn
+                uint32_t cs[2], len[2], qa[2], qb[2];
+                bool act[2];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) id[j] = bft_cs_id_at(cs_ids, cs_w, min(q + (uint32_t)j, q1 - 1u));
+                for (int u = 0; u < 2; u++) cs[u] = base + 64u * u + lane < m ? csin[pa + base + 64u * u + lane] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t pcs = __shfl_up(cs[u], 1);
+                    const bool boundary = lane == 0 || pcs != cs[u];
+                    const uint64_t bmask = __ballot(boundary);
+                    const uint64_t above = lane == 63 ? 0ull : bmask >> (lane + 1);
+                    len[u] = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+                    act[u] = boundary && cs[u] != 0xFFFFFFFFu;
+                    qa[u] = qb[u] = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (act[u]) { qa[u] = cs_off[cs[u]]; qb[u] = cs_off[cs[u] + 1]; }
+                uint32_t id[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) id[u][j] = act[u] && qb[u] > qa[u] ? bft_cs_id_at(cs_ids, cs_w, min(qa[u] + (uint32_t)j, qb[u] - 1u)) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (!act[u]) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (qa[u] + (uint32_t)j < qb[u] && id[u][j] - win0 < wn) atomicAdd(&cnt[id[u][j] - win0], len[u]);
+                    for (uint32_t q = qa[u] + 8u; q < qb[u]; q += 8) {  // (sets of more than eight genomes: eight ids per step, loaded together)
+                        uint32_t more[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) more[j] = bft_cs_id_at(cs_ids, cs_w, min(q + (uint32_t)j, qb[u] - 1u));
 #pragma unroll
                         for (int j = 0; j < 8; j++)
-                            if (q + (uint32_t)j < q1 && id[j] - win0 < wn) atomicAdd(&cnt[id[j] - win0], len);
+                            if (q + (uint32_t)j < qb[u] && more[j] - win0 < wn) atomicAdd(&cnt[more[j] - win0], len[u]);
                     }
                 }
             }
