@@ -42,6 +42,7 @@ __device__ __forceinline__ void kh_fetch_quad(const BftImage& im, uint64_t home,
 template <int W, int S>
 __device__ __forceinline__ void kh_lds_body(const uint4* mine, uint32_t s, uint64_t* body) {
     constexpr uint32_t wb = 48u / (uint32_t)S;
+    static_assert(((16u + ((uint32_t)S - 1u) * wb) & ~7u) + 8u * ((uint32_t)W + 1u) <= 16u * BFT_KH_LDS_LINE, "the body reads of the last slot stay inside the line's LDS bytes");
     const uint32_t off = 16u + s * wb, sh = (off & 7u) * 8u;
     const uint64_t* p = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(mine) + (off & ~7u));
     uint64_t w[W + 1];
