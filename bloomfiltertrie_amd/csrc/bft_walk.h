@@ -553,6 +553,22 @@ BFT_HD void bft_kh_load_body(const uint64_t* line, uint32_t s, uint32_t wb, uint
         }
     }
 }
+// A full line, d >= 1 lines past the home line of the k-mer(s) looked for, that does not hold them: may the search stop here?  The table is
+// filled in (home line, T-form) order, so the displacements of a line's entries do not increase from slot to slot; when the LAST slot's entry
+// is displaced by less than d, its home line lies behind the one looked for, every k-mer of that home line lies before it -- in the lines
+// already seen -- and the k-mer is absent (an overflowed k-mer cannot be concerned: its place would lie more than maxd lines from home,
+// behind this entry).  A tombstone in the last slot says nothing: the search goes on.  One more load from the line, on the rare path only;
+// with one or two slots per line (k >= 97) it halves the lines an absent k-mer costs.
+template <int W>
+BFT_HD bool bft_kh_line_ends_search(const BftImage& im, const uint64_t* line, uint32_t S, uint32_t wb, uint32_t d) {
+    if (d == 0) return false;
+    uint64_t b0[1];
+    bft_kh_load_body<1>(line, S - 1u, wb, b0);
+    const uint32_t cb = im.kh.cb;
+    const uint64_t v = b0[0] & ((1ull << cb) - 1ull);
+    const uint32_t dl = (uint32_t)(b0[0] >> cb) & ((1u << im.kh.db) - 1u);
+    return v != 0 && dl < d;
+}
 // One line, `d` lines past the k-mer's home line, against the k-mer: 1 = found (*val = its value), 0 = not here and the line has a free
 // slot (absent), -1 = not here, line full.  The header (16 bytes: S fields of f bits -- the low key bits of the slots --, the S occupancy
 // bits on top) says which slots can hold the k-mer at all; only those slots' bodies are read: an absent k-mer costs one load instruction,
@@ -580,7 +596,8 @@ BFT_HD int bft_kh_scan(const BftImage& im, const uint64_t* line, const uint64_t*
         for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & key.bmask[i]) == 0;
         if (same) { *val = (uint32_t)(body[0] & vmask) - 1u; return 1; }
     }
-    return occ != (1u << S) - 1u ? 0 : -1;
+    if (occ != (1u << S) - 1u) return 0;
+    return bft_kh_line_ends_search<W>(im, line, S, wb, d) ? 0 : -1;
 }
 // The k-mers that differ from `key`'s only in the two bits b, b + 1 of the rest (the four successors of a k-mer: its last nucleotide; the four
 // predecessors: its first -- they share their home line, bft_image.h): the comparison masks without those two stored key bits.
@@ -632,7 +649,8 @@ BFT_HD int bft_kh_count_line(const BftImage& im, const uint64_t* line, const Bft
         for (int i = 1; i < W; i++) same = same && ((body[i] ^ key.body[i]) & fam.bkeep[i]) == 0;
         *count += same ? 1 : 0;
     }
-    return occ != (1u << S) - 1u ? 0 : -1;
+    if (occ != (1u << S) - 1u) return 0;
+    return bft_kh_line_ends_search<W>(im, line, S, wb, d) ? 0 : -1;
 }
 // The overflow list (bft_image.h): binary search of the sorted k-mers.
 template <int W>
