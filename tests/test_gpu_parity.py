@@ -249,7 +249,7 @@ def test_bft_files_both_directions(oracle_mod, tmp_path, k, levels, ngen):
     assert all((a == b).all() for a, b in zip(t3.query_colors(q), exp))
 
 
-@pytest.mark.parametrize("k,deep", [(9, 0), (18, 0), (27, 0), (27, 2), (36, 0), (36, 3), (63, 0), (126, 0)])
+@pytest.mark.parametrize("k,deep", [(9, 0), (18, 0), (27, 0), (27, 2), (36, 0), (36, 3), (63, 0), (72, 0), (99, 2), (126, 0)])
 def test_branching(oracle_mod, k, deep):
     if deep:
         km = S.low_entropy_kmers(40000, k, 16, seed=k, levels=deep)
@@ -266,6 +266,25 @@ def test_branching(oracle_mod, k, deep):
     assert (bits == obits).all()
     assert (t.query_branching(q) == obits).all()  # early-exit variant
     assert int(np.unpackbits(bits, bitorder="little")[: len(q)].sum()) == onbr
+
+
+@pytest.mark.parametrize("k,load", [(27, 80), (63, 80), (99, 80), (27, 20), (126, 70)])
+def test_branching_at_other_occupancies(oracle_mod, k, load):
+    """The four successors (predecessors) of a k-mer share their home line in the k-mer hash and are counted by one masked scan: at 80 % the
+    families run over several full lines (the scan goes on line by line, stops where the table's home order says so, and asks the overflow
+    list after a run of full lines), at 20 % nearly every line has a free slot.  Counts and bits == the oracle's."""
+    anc = S.random_genome(30000, 5)
+    km = S.distinct(np.concatenate([S.kmers_of(g, k) for g in (anc, S.mutate(anc, 0.05, 1), S.mutate(anc, 0.05, 2), S.mutate(anc, 0.05, 3))]))
+    t, o = _bft(k), oracle_mod.OracleBFT(k)
+    t.set_option("kmer_hash_load", load)
+    t.insert_kmers(km, 0)
+    o.insert_kmers(km, 0)
+    q = _queries(km, k, seed=4)
+    obits, ocounts, onbr = o.query_branching(q)
+    bits, counts = t.query_branching(q, with_counts=True)
+    assert t.build_time()["kmer_hash_lines"] > 0
+    assert (counts == ocounts).all() and (bits == obits).all()
+    assert (t.query_branching(q) == obits).all()
 
 
 @pytest.mark.parametrize("k,canonical", [(27, False), (27, True), (63, True), (18, False)])
