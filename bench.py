@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (6.3 TB/s a
 # profiles/r04/microbench_gather.jsonl.  The 0.67 GB k-mer hash of the config-4 share lies partly inside the Infinity Cache: the kernel is priced
 # against the higher figure, so that `frac` stays a fraction.
 GATHER_CEILING_G = 59.4
+GATHER_CEILING_1GIB_G = 56.0  # the same microbenchmark on a 1 GiB table (nothing of it inside the Infinity Cache)
 GATHER_CEILING_SRC = "profiles/r04/microbench_gather.jsonl (indep4/8, 64 MiB table: the fabric's request rate; 56.0 at 1 GiB, whole lines by quads 54.7)"
 PMC_FALLBACK = "r04/pmc_query.json"
 
@@ -165,7 +166,10 @@ def roofline_block(pmc, nq, avg_ms, launches, kernel, kmer_bytes, live):
     if mpq:
         rate = mpq * nq / (avg_ms * 1e-3) / 1e9
         out["gather"] = {"l2_misses_per_query": mpq, "l2_requests_per_query": pmc.get("l2_requests_per_query"), "G_misses_per_s": round(rate, 1),
-                         "ceiling_G_per_s": GATHER_CEILING_G, "frac": round(rate / GATHER_CEILING_G, 3), "ceiling_source": GATHER_CEILING_SRC}
+                         "ceiling_G_per_s": GATHER_CEILING_G, "frac": round(rate / GATHER_CEILING_G, 3), "ceiling_source": GATHER_CEILING_SRC,
+                         "ceiling_1GiB_table_G_per_s": GATHER_CEILING_1GIB_G, "frac_of_1GiB_ceiling": round(rate / GATHER_CEILING_1GIB_G, 3),
+                         "note": "two ceilings, both measured: the table of the headline index (0.67 GB) lies partly inside the 256 MiB Infinity Cache, so the true bound "
+                                 "is between them; a value above 1 against the 1 GiB figure says exactly that"}
     return out
 
 
@@ -442,27 +446,58 @@ def main():
         out["roofline"]["ref_scan_bytes_avoided"] = round(ref_scan / out["roofline"]["hbm_bytes_per_query"], 2)
 
     if secondary:
-        # ---- the same index through the container walk: presenceKmer's root level (root range / direct tables) -> a plain suffix group in
-        # its hashed form (one line of the k-mer hash), or -- child Node, root UC -- Bloom probe / node prefix hash -> filter2 rank -> cluster
-        # -> prefix entry -> suffix-group probes of the sorted rows (k_query6h); and with every suffix group searched in the sorted table ----
+        # ---- the same index through the container walk, three ways, each with its own counters (bft_gpu_set_option names in `options`):
+        #   pure         the kernels the north star names and nothing else: Bloom probe of the root's bit-sliced filters staged in LDS -> filter2 bit +
+        #                rank-in-word -> cluster -> prefix entry -> suffix-group search / node UC (src/presenceNode.c:1284-1576, 1578-1821), every level
+        #                through the containers: no k-mer hash, no derived root tables, no node prefix hash
+        #   sorted_table the same walk with the derived root tables (rstart / rdir / rq) in front of the root's containers
+        #   walk_hash    plain root groups looked up in their hashed form (one line of the k-mer hash, k_query6h), special prefixes walk
+        # `roofline.frac` of the pure row prices the launch with SURVEY 8(d)'s algorithmic bytes -- B(k) + 1/8 + S, S = the bytes the reference's scan
+        # dereferences per query on this index (the oracle's counting mode) -- so that it says how the kernel stands against the reference's own
+        # traffic model; `counters` beside it is the HBM traffic the device layout really causes ----
         try:
-            bft.set_option("walk_hash", 1)
+            rows = [("pure", (("kmer_hash", 0), ("root_direct", 0), ("node_hash", 0)), "k_query", "cfg4_walk_pure"),
+                    ("sorted_table", (("kmer_hash", 0),), "k_query", "cfg4_walk"),
+                    ("walk_hash", (("walk_hash", 1),), "k_query6h", "cfg4_walk_hash")]
+            defaults = {"kmer_hash": 1, "root_direct": 3, "node_hash": 1, "walk_hash": 0}
+            cw = {}
             bits_w = torch.zeros_like(dbits)
-            ms_w = timed_launches(bft, dq.data_ptr(), nq, bits_w.data_ptr(), stream, max(3, args.steps // 2))
-            out["container_walk"] = {"value": round(nq / ms_w / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms_w, 4), "same_bits": bool(torch.equal(bits_w, dbits)),
-                                     "note": "bft_gpu_set_option(walk_hash, 1): the container walk answers (k_query6h); plain suffix groups of the root are looked up in their "
-                                             "hashed form (the k-mer hash: one line), special prefixes (child Nodes, root UC) walk the containers and probe sorted rows"}
-            if std:
-                pmc_w, live_w = pmc_for("cfg4", nq, B, allow_live=not args.no_pmc, opts=("walk_hash=1",), stored_key="cfg4_walk_hash")
-                out["container_walk"]["roofline"] = roofline_block(pmc_w, nq, ms_w, max(3, args.steps // 2), "k_query6h", B, live_w)
-            bft.set_option("walk_hash", 0)
-            bft.set_option("kmer_hash", 0)
-            ms_s = timed_launches(bft, dq.data_ptr(), nq, bits_w.data_ptr(), stream, 3)
-            out["container_walk"]["sorted_table_only"] = {"value": round(nq / ms_s / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms_s, 4),
-                                                          "same_bits": bool(torch.equal(bits_w, dbits)),
-                                                          "note": "bft_gpu_set_option(kmer_hash, 0): no hashed form at all; every suffix group by block probes of the sorted table "
-                                                                  "from a guess interpolated inside its quarter (k_query6)"}
-            bft.set_option("kmer_hash", 1)
+            for label, opts, kern, stored in rows:
+                try:
+                    for nm, v in opts:
+                        bft.set_option(nm, v)
+                    bits_w.zero_()
+                    ms_w = timed_launches(bft, dq.data_ptr(), nq, bits_w.data_ptr(), stream, 3)
+                    row = {"value": round(nq / ms_w / 1e3, 3), "unit": "M k-mers/s", "ms_per_launch": round(ms_w, 4), "same_bits": bool(torch.equal(bits_w, dbits)),
+                           "options": {nm: v for nm, v in opts}}
+                    if std:
+                        pmc_w, live_w = pmc_for("cfg4", nq, B, allow_live=not args.no_pmc, opts=tuple(f"{nm}={v}" for nm, v in opts), stored_key=stored)
+                        rl = roofline_block(pmc_w, nq, ms_w, 3, kern, B, live_w)
+                        if label != "walk_hash":
+                            rl.pop("design_bytes_per_query", None)
+                            rl.pop("wasted", None)
+                        row["lines_per_query"] = (rl.get("gather") or {}).get("l2_misses_per_query")
+                        if label == "pure" and ref_scan:
+                            # achieved = algorithmic bytes per launch / launch time, algorithmic bytes = B(k) + 1/8 + S
+                            ach = ref_scan * nq / (ms_w * 1e-3) / 1e9
+                            row["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                               "traffic": rl.get("traffic"), "kernel": kern, "avg_launch_ms": round(ms_w, 4), "launches": 3,
+                                               "algorithmic_bytes_per_query": ref_scan,
+                                               "algorithmic_bytes_are": "SURVEY 8(d): B(k) + 1/8 + S, S = bytes the reference's presenceKmer/findCluster scan dereferences per query "
+                                                                        "on this index (the oracle's counting mode, `reference_scan_bytes_per_query`)",
+                                               "note": "a frac above what the counters say means the device layout (bit-sliced Bloom blocks: 2 loads instead of 2 per CC scanned; "
+                                                       "rank in the filter2 word; fused prefix entries) moves fewer bytes than the reference's scan for the same answer",
+                                               "counters": rl}
+                        else:
+                            row["roofline"] = rl
+                    cw[label] = row
+                finally:
+                    for nm, _ in opts:
+                        bft.set_option(nm, defaults[nm])
+            cw["note"] = ("three forms of the container walk on the headline index and batch; `pure` = the kernels BASELINE.json's north star names (CC prefix match with popcnt "
+                          "rank/select, UC suffix scan, Bloom probe of LDS-staged blocks); `sorted_table` adds the derived root tables; `walk_hash` answers plain root groups from "
+                          "their hashed form.  The headline (`value`) is none of these: it is the k-mer hash alone (k_query_kh)")
+            out["container_walk"] = cw
             del bits_w
         except Exception as e:
             out["container_walk"] = dict(out.get("container_walk") or {}, error=repr(e))
@@ -546,6 +581,42 @@ def main():
             out["sequence_queries"] = {"error": repr(e)}
         if b2 is not None:
             b2.close()
+        torch.cuda.empty_cache()
+
+        # ---- BASELINE configs[2]: the insertKmers build path (src/insertNode.c:18-36), 100 genomes / 2x10^8 pairs from HBM-resident batches: the protocol
+        # of tools/bench_insert.py (every batch generated before the clock starts; timed region = 100 stream-ordered insert calls + bft_gpu_build), with
+        # the GPU time and the algorithmic bytes of every stage (bft_gpu_build_stages) and the oracle's insertKmers timed beside it ----
+        try:
+            from tools import bench_insert
+            ia = argparse.Namespace(k=k, genomes=genomes, genome_len=args.genome_len, snp_rate=args.snp_rate, sample=400_000, reserve=True, sync_inserts=False,
+                                    add_genome=False, opt=[], stages=True, cpu_baseline=0 if args.no_cpu_baseline else 8)
+            out["insert"] = bench_insert.measure(ia)
+        except Exception as e:
+            out["insert"] = {"error": repr(e)}
+
+    # ---- the N > 1 path with one rank, in a child process (this one never initialised RCCL): process group over RCCL, the image blob packed and
+    # broadcast (always_copy: the rank unpacks the received blob instead of keeping its own handle), presence bitmaps all_gathered with the overlap
+    # pipeline, gathered shard == own bits, every answer checked -- so that the code an 8-GPU run takes is executed in every bench run ----
+    if secondary and not args.force_dist:
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--steps", "3", "--warmup", "1", "--genomes", "10", "--queries", "20000000",
+                   "--no-secondary", "--no-cpu-baseline", "--no-pmc"]
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                d = json.loads(line[-1])
+                out["dist_path_check"] = {"ok": bool(d.get("parity_ok")), "backend": "nccl (RCCL)", "world_size": 1, "replicate": "broadcast of the packed image, unpacked (always_copy)",
+                                          "gather": "all_gather of the presence bitmaps, overlapped with the next step's kernel (GatherPipeline)",
+                                          "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "answers_checked": d.get("answers_checked_per_gpu"),
+                                          "workload": "10-genome index, 2x10^7 queries, 3 steps", "seconds": round(time.perf_counter() - t0, 1),
+                                          "note": "one rank: what RCCL does between ranks over xGMI is NOT exercised; the process-group, blob, unpack and gather code is"}
+            else:
+                out["dist_path_check"] = {"ok": False, "rc": r.returncode, "stderr_tail": r.stderr.decode(errors="replace")[-400:]}
+        except Exception as e:
+            out["dist_path_check"] = {"ok": False, "error": repr(e)}
 
     if use_dist:
         dist.destroy_process_group()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "bft_gpu_footprint": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "bft_gpu_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "bft_gpu_build_time": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
+    "bft_gpu_build_stages": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "bft_gpu_extract": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bft_gpu_colorset": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bft_gpu_query_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P]),
@@ -60,6 +61,8 @@ SIGNATURES = {
     "bft_gpu_group_query_color_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_group_query_branching": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_group_member_device": (C.c_int, [_P, C.c_int]),
+    "bft_gpu_group_member_footprint": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
+    "bft_gpu_group_member_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "bft_gpu_group_query_presence_dev": (C.c_int, [_P, _P, _P, _P, _P]),
     "bft_gpu_group_query_color_rows_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "bft_gpu_group_query_branching_dev": (C.c_int, [_P, _P, _P, _P, _P, _P]),

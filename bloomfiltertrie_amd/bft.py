@@ -249,6 +249,17 @@ class BFT:
                          "sort_max_bucket", "intern_exact_passes", "process_hipmalloc_ms", "root_tables", "tune_root_direct_ms", "tune_root_range_ms", "node_hash_keys", "node_hash_dropped", "tune_2wg768_ms",
                          "claims_static_launches", "kmer_hash_slots", "kmer_hash_dbits", "kmer_hash_maxd", "kmer_hash_overflow"], list(out)))
 
+    def build_stages(self):
+        """[(stage name, GPU ms, algorithmic bytes)] of the last build (set_option("build_stages", 1) before it)."""
+        n = C.c_int()
+        _lib.check(self._lib.bft_gpu_build_stages(self._h, None, 0, None, None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        names = C.create_string_buffer(256 * n.value)
+        ms, by = (C.c_double * n.value)(), (C.c_double * n.value)()
+        _lib.check(self._lib.bft_gpu_build_stages(self._h, names, len(names), ms, by, n.value, C.byref(n)))
+        return list(zip(names.value.decode().split("\n")[:n.value], list(ms), list(by)))
+
     FOOTPRINT_FIELDS = ["kmer_table", "colorset_per_kmer", "colorset_dictionary", "containers", "flat_ccs", "root_tables", "node_prefix_hash", "kmer_hash",
                         "dictionary_bitmaps", "hash_table", "pair_store", "insertion_log"]
 
@@ -342,22 +353,34 @@ class BFTGroup:
     def member_device(self, i):
         return self._lib.bft_gpu_group_member_device(self._g, i)
 
-    @staticmethod
-    def _ptrs(vals):
+    def member_footprint(self, i):
+        out = (C.c_uint64 * 12)()
+        _lib.check(self._lib.bft_gpu_group_member_footprint(self._g, i, out, 12))
+        return dict(zip(BFT.FOOTPRINT_FIELDS, [int(x) for x in out]))
+
+    def _ptrs(self, vals):
+        # the C side indexes bft_gpu_group_size(g) entries of every array: a shorter list would be an out-of-bounds host read
+        if len(vals) != self.size():
+            raise ValueError(f"one entry per slot of the group expected ({self.size()}), got {len(vals)}")
         return (C.c_void_p * len(vals))(*[C.c_void_p(v) if v else None for v in vals])
+
+    def _counts(self, n):
+        if len(n) != self.size():
+            raise ValueError(f"one batch size per slot of the group expected ({self.size()}), got {len(n)}")
+        return (C.c_uint64 * len(n))(*n)
 
     def query_presence_dev(self, d_kmers, n, d_bits, streams=None):
         """d_kmers / d_bits / streams: device pointers (ints) per slot; n: k-mers per slot"""
-        ns = (C.c_uint64 * len(n))(*n)
+        ns = self._counts(n)
         _lib.check(self._lib.bft_gpu_group_query_presence_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(streams) if streams else None))
 
     def query_color_rows_dev(self, d_kmers, n, d_bits, d_rows, d_scratch, streams=None):
-        ns = (C.c_uint64 * len(n))(*n)
+        ns = self._counts(n)
         _lib.check(self._lib.bft_gpu_group_query_color_rows_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(d_rows), self._ptrs(d_scratch),
                                                                 self._ptrs(streams) if streams else None))
 
     def query_branching_dev(self, d_kmers, n, d_bits, d_counts=None, streams=None):
-        ns = (C.c_uint64 * len(n))(*n)
+        ns = self._counts(n)
         _lib.check(self._lib.bft_gpu_group_query_branching_dev(self._g, self._ptrs(d_kmers), ns, self._ptrs(d_bits), self._ptrs(d_counts) if d_counts else None,
                                                                self._ptrs(streams) if streams else None))
 

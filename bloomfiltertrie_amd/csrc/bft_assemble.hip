@@ -506,6 +506,8 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(scan.wait());
         const uint64_t A = scan.get(0);
         bft_trace_mark("  level: active rows");
+        const std::string lv = "containers depth " + std::to_string(d) + ": ";
+        bft_stage((lv + "active rows").c_str(), (double)M * 12, s);
         // ---- prefixes and keys ----
         DevBuf head, khead, ppos, kpos;
         CK(head.alloc(A * 4));
@@ -523,6 +525,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             K = scan.get(1);
         }
         bft_trace_mark("  level: prefix flags + scans");
+        bft_stage((lv + "prefix flags + scans").c_str(), (double)A * (8.0 * W + 8 + 16), s);
         DevBuf pref_r, pref_row, pref_node, pref_key, pref_cnt, key_val, key_row, key_node, key_cnt, node_kb;
         CK(pref_r.alloc(P * 4));
         CK(pref_row.alloc(P * 4));
@@ -579,6 +582,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         out.max_ccs_per_node = std::max<uint64_t>(out.max_ccs_per_node, scan.get(1));
         if (d == 0) out.root_ncc = scan.get(2);
         bft_trace_mark("  level: scatter, CC assignment");
+        bft_stage((lv + "prefix scatter, CC assignment").c_str(), (double)A * (8.0 * W + 16) + (double)P * 24 + (double)K * 24, s);
         // (the passes over the whole table and the root's CC assignment -- ONE workgroup claiming CC after CC, bound by latency: 0.8 ms
         // alone, 3.5 ms beside a kernel that saturates the memory system -- are done: what follows is a chain of small kernels and
         // counts read back, which leaves most of the GPU to whatever the caller starts beside it now)
@@ -596,10 +600,10 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             int mbits = 1;
             while (mbits < 32 && (M >> mbits)) mbits++;
             size_t tb = 0;
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
+            BFT_RADIX_SORT(0, 17 + mbits, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
             DevBuf tmp;
             CK(tmp.alloc(tb));
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
+            BFT_RADIX_SORT(0, 17 + mbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
         }  // (no synchronisation: what is released here is only handed out again in the order of this stream, bft_pool_alloc)
         skey.release(); iota.release();
 
@@ -643,6 +647,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         out.n_prefixes += scan.get(5);
         out.n_ccs_s4 += scan.get(6);
         bft_trace_mark("  level: sort by (node, CC), runs, cluster flags");
+        bft_stage((lv + "sort by (node, CC), runs, cluster flags").c_str(), (double)P * (12.0 * 2 * 4 + 60), s);
         DevBuf clus_q, clus_len, multi, cpos;
         CK(clus_q.alloc(Q * 4));
         CK(clus_len.alloc(Q * 4));
@@ -656,6 +661,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
             CK(scan.run(multi.as<uint32_t>(), cpos.as<uint32_t>(), Q, &E));
         }
         bft_trace_mark("  level: clusters");
+        bft_stage((lv + "clusters").c_str(), (double)P * 8 + (double)Q * 24, s);
         if (T_f2w + F2 > 0xFFFFFFFFull || T_clus + Q > 0xFFFFFFFFull || T_child + E > 0xFFFFFFFFull || T_uc + UCR > 0xFFFFFFFFull)
             return bft_fail(BFT_GPU_E_LIMIT, "index array offset overflow (u32)");
 
@@ -698,6 +704,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         const uint64_t BF8 = scan.get(0);
         if (d == 0) out.root_uc = scan.get(1);
         bft_trace_mark("  level: entries, node records");
+        bft_stage((lv + "entries, ranks, UC rows, node records").c_str(), (double)P * 60 + (double)(F2 + Q + E) * 8 + (double)UCR * (8.0 * W + 4), s);
         if (T_bf8 + BF8 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "Bloom block offset overflow");
         CK(sg.bfT.alloc(BF8 * 8));
         hipLaunchKernelGGL(k_node_records, G(M), node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(),
@@ -1198,6 +1205,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     uint32_t nbad = 0;
     const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
     hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, g_weak_signature ? 1 : 0, sig.as<uint64_t>(), iota.as<uint32_t>());
+    bft_stage("colour sets: signatures", (double)np * 4 + (double)nk * (4 + 8 + 4), s);
 
     // ---- by a hash of the signatures (kernels above).  The table starts at nk / 8 slots (a pan-genome has far fewer distinct lists than
     // k-mers) and is retried at 2 nk when more than half of it fills: then every list may be distinct. ----
@@ -1217,6 +1225,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
             hipLaunchKernelGGL(k_cs_hash_insert, grid, block, 0, s, sig.as<uint64_t>(), (uint32_t)nk, tab.as<CsSlot>(), (uint32_t)(n_slots - 1), slot_of.as<uint32_t>(),
                                cnt.as<uint32_t>());
             CK(scan.publish(cnt.as<uint32_t>(), 2, 0));
+            bft_stage("colour sets: hash of the signatures", (double)nk * (8 + 4) + (double)n_slots * 16, s);
             CK(scan.wait());
             if (scan.get(1) == 0 && scan.get(0) * 2 <= n_slots) done = true;
             else if (n_slots >= 2 * nk) break;  // (cannot happen: at most nk signatures in 2 nk slots)
@@ -1232,21 +1241,24 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
             const dim3 tgrid(bft_grid_for((n_slots + ABLK - 1) / ABLK)), sgrid(bft_grid_for((n_sets + ABLK - 1) / ABLK));
             hipLaunchKernelGGL(k_cs_hash_compact, tgrid, block, 0, s, tab.as<CsSlot>(), (uint32_t)n_slots, keys.as<uint64_t>(), slots.as<uint32_t>(), cnt.as<uint32_t>() + 2);
             size_t tb = 0;
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
+            BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
             CK(tmp.alloc(tb));
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
+            BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
             hipLaunchKernelGGL(k_cs_hash_ids, sgrid, block, 0, s, slots_s.as<uint32_t>(), (uint32_t)n_sets, tab.as<CsSlot>(), d_seg_off, rep.as<uint32_t>(), len.as<uint32_t>());
             CK(d_cs_off.alloc((n_sets + 1) * 4));
             CK(scan.enqueue(len.as<uint32_t>(), d_cs_off.as<uint32_t>(), n_sets, 0, true));
             hipLaunchKernelGGL(k_cs_hash_tcol, grid, block, 0, s, slot_of.as<uint32_t>(), tab.as<CsSlot>(), (uint32_t)nk, d_tcol.as<uint32_t>());
+            bft_stage("colour sets: distinct signatures sorted, ids, set per k-mer", (double)n_slots * 16 + (double)n_sets * (12 * 2 * 8 + 24) + (double)nk * 8, s);
             CK(scan.wait());
             n_ids = scan.get(0);
             CK(d_cs_ids.alloc(n_ids * 4));
             hipLaunchKernelGGL(k_cs_hash_copy, sgrid, block, 0, s, rep.as<uint32_t>(), d_cs_off.as<uint32_t>(), (uint32_t)n_sets, d_seg_off, d_pg, d_cs_ids.as<uint32_t>());
+            bft_stage("colour sets: dictionary copied", (double)n_ids * 8 + (double)n_sets * 12, s);
             HIPCK(hipMemsetAsync(bad.p, 0, 4, s));
             hipLaunchKernelGGL(k_cs_verify, grid, block, 0, s, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
                                bad.as<uint32_t>());
             CK(scan.publish(bad.as<uint32_t>(), 1, 1));
+            bft_stage("colour sets: every list verified", (double)np * 8 + (double)nk * 12, s);
             CK(scan.wait());
             nbad = (uint32_t)scan.get(1);
             done = nbad == 0;  // (else: two different lists with one signature -- the sorted path below compares the lists)
@@ -1268,9 +1280,9 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     // (begin_bit = 16, end_bit = 64 -- the high bits -- faulted inside the library sort on ROCm 7.2 for n of a few 10^4; a bit
     // range that starts at 0, as every other sort of this library uses, does not.)
     size_t tb = 0;
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
+    BFT_RADIX_SORT(0, 48, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
     CK(tmp.alloc(tb));
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
+    BFT_RADIX_SORT(0, 48, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
     for (int exact = 1; exact < 2; exact++) {
         g_exact_passes++;
         hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, exact, head.as<uint32_t>(), len.as<uint32_t>());

@@ -13,34 +13,47 @@
 // 256 k-mers is answered in ~11 us by 2048 workgroups) fewer than four blocks per claim saturate the counter (a block per claim: 5.9 ms per
 // launch, two: 3.4, against 2.6), and more than four widen the window of the query stream the resident workgroups read at a time (2.61 /
 // 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64).
-// ctr == NULL: static rounds only (round r of workgroup b = blocks [(b + r G) chunk, +chunk)), same loop, same whole-line stores.
-// ctr[0]: blocks claimed so far beyond the first round; ctr[1]: workgroups that are done -- the last one zeroes both for the next launch
-// on the stream.  One launch at a time per counter pair (the host keeps a pair per stream and handle: launches of one handle on one
-// stream from two host threads at once, or a captured graph replayed beside a live launch, would share it -- not supported).
+// ctr.p == NULL: static rounds only (round r of workgroup b = blocks [(b + r G) chunk, +chunk)), same loop, same whole-line stores.
+// The counter is ONE 64-bit word per (handle, stream) that only ever grows, and every launch is given its own range of it (round 5; rounds 3-4
+// had the last workgroup of a launch zero a 32-bit pair for the next one -- a launch that never finished left it non-zero and every later launch
+// on the stream silently skipped blocks): the host hands the kernel `base`, the value the counter stands at when the launch's first claim is
+// made, and moves its own copy on by a bound on what the launch can claim (blocks + one claim per workgroup beyond them).  A workgroup raises
+// the counter to `base` (atomicMax) before its first claim, so whatever an earlier launch left behind -- it can only be BELOW this launch's base
+// -- is irrelevant; a claim's value minus `base` = blocks claimed so far beyond the first round.  Nothing is reset, nothing counts the workgroups
+// that are done.  One launch at a time per counter (the host keeps one per stream and handle: launches of one handle on one stream from two host
+// threads at once, or a captured graph replayed beside a live launch, would share a range -- not supported).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+struct BftClaimCtr {
+    unsigned long long* p;    // the stream's counter, or NULL: static rounds
+    unsigned long long base;  // where this launch's range of it starts
+};
+
 template <uint32_t MINC>
 struct BftClaims {
-    uint32_t* ctr;
+    unsigned long long* ctr;
+    unsigned long long base;
     uint32_t chunk;
     uint64_t nblk;
     uint32_t* s_next;  // two words of LDS: first block and size of the claim in flight
     uint64_t blk, blk_end, start;  // the block being answered; end and first block of the round it belongs to
 
     // (a batch the first round covers needs no counter at all: it runs exactly like the static split)
-    __device__ __forceinline__ BftClaims(uint32_t* c, uint32_t ch, uint64_t nb, uint32_t* lds2)
-        : ctr((uint64_t)gridDim.x * ch >= nb ? nullptr : c), chunk(ch), nblk(nb), s_next(lds2), blk(0), blk_end(0), start(0) {}
+    __device__ __forceinline__ BftClaims(BftClaimCtr c, uint32_t ch, uint64_t nb, uint32_t* lds2)
+        : ctr((uint64_t)gridDim.x * ch >= nb ? nullptr : c.p), base(c.base), chunk(ch), nblk(nb), s_next(lds2), blk(0), blk_end(0), start(0) {}
 
     __device__ __forceinline__ void claim(uint64_t from) {
         const uint64_t rem = nblk - min(nblk, from);
         const uint32_t want = (uint32_t)max((uint64_t)min(chunk, MINC), min((uint64_t)chunk, rem / (2ull * gridDim.x)));
         s_next[1] = want;
-        s_next[0] = atomicAdd(&ctr[0], want);
+        s_next[0] = (uint32_t)(atomicAdd(ctr, (unsigned long long)want) - base);
     }
-    // the first round: static
+    // the first round: static (and the counter enters this launch's range before the thread's first claim: same thread, same address --
+    // the two atomics are ordered)
     __device__ __forceinline__ void first() {
+        if (ctr && threadIdx.x == 0) atomicMax(ctr, base);
         blk = start = (uint64_t)blockIdx.x * chunk;
         blk_end = min(nblk, blk + chunk);
     }
@@ -72,11 +85,6 @@ struct BftClaims {
         blk += nb;
         if (blk >= blk_end) take();
     }
-    // after the loop: every workgroup has made its last claim once the last one gets here
-    __device__ __forceinline__ void done() {
-        if (ctr && threadIdx.x == 0 && atomicAdd(&ctr[1], 1u) == gridDim.x - 1u) {
-            ctr[0] = 0u;
-            ctr[1] = 0u;
-        }
-    }
+    // after the loop: nothing to do (the counter is never reset, see above)
+    __device__ __forceinline__ void done() {}
 };

@@ -22,6 +22,17 @@ int bft_fail(int code, const std::string& msg);  // records the thread's last er
         if (rc_ != 0) return rc_; \
     } while (0)
 
+// Every radix sort of the library goes through this: rocPRIM's radix sort (ROCm 7.2) mis-sorts a bit range that starts above bit 0 AND ends at
+// bit 64 (found twice: composites of [2, 64) bits at k = 31, tests/test_gpu_parity.py::test_any_k_against_ground_truth; the root-prefix split of
+// (k-mer, id) pairs over [46, 64) at k = 32, tools/stress_parity.py) -- the callers route around such ranges (composites stay within 63 bits, k = 32
+// takes the device-wide sort); the check makes a range that slips through fail loudly instead of building a wrong index.
+#define BFT_RADIX_SORT(begin_bit, end_bit, call)                                                                                      \
+    do {                                                                                                                              \
+        if ((unsigned)(begin_bit) != 0u && (unsigned)(end_bit) >= 64u)                                                               \
+            return bft_fail(BFT_GPU_E_ARG, "internal: radix sort over the bit range [b, 64) with b > 0 (mis-sorted by the library)"); \
+        HIPCK(call);                                                                                                                  \
+    } while (0)
+
 // Device-memory cache behind DevBuf (bft_gpu.hip).  hipFree synchronises the device and costs ~0.1 ms per call on
 // large blocks; a bulk build releases dozens of temporaries.  Released blocks are kept (per device, tagged with the
 // stream of the ABI call that released them) and handed out again to requests of a similar size.  A block released
@@ -103,6 +114,9 @@ struct BftDeviceIndex {
 };
 bool bft_trace_on(void);
 void bft_trace_mark(const char* what);  // BFT_GPU_TRACE_BUILD=1 (nullptr: start of a build)
+// "build_stages" 1: a stage of the running build ends here on stream s; bytes = what its algorithm reads + writes (0: not a streaming
+// stage).  A name that starts with '+' marks work on a side stream, timed from the build's start.  No-op unless the option is on.
+void bft_stage(const char* name, double bytes, hipStream_t s);
 // after_table_passes: called once, when the first level's passes over the whole sorted table and its CC assignment are done on `s`
 struct BftAssembleHook {
     void (*after_table_passes)(void* ctx, hipStream_t s);

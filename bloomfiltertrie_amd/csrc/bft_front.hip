@@ -468,6 +468,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
     HIPCK(hipGetLastError());
+    bft_stage("bucket sorts in LDS (+ scan of the counts)", (double)n * 16 + (d_vals ? (double)n * vw : 0.0), s);
     HIPCK(hipStreamSynchronize(s));
     const uint64_t total = pin.p[1];
     if (n_redone) *n_redone = (uint32_t)pin.p[2];
@@ -481,6 +482,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     hipLaunchKernelGGL(k_bucket_emit, grid, block, 0, s, d_c, d_boff, nb, gb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(), pg.as<uint32_t>(), d_vals ? 1 : 0, split_bit - gb,
                        (uint32_t)nk, (uint32_t)np);
     HIPCK(hipGetLastError());
+    bft_stage("bucket emit (k-mers, offsets, genome ids)", (double)n * 8 + (double)nk * 12 + (double)np * 4, s);
     *done = true;
     return 0;
 }

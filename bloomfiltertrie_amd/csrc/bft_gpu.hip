@@ -63,6 +63,25 @@ void bft_trace_mark(const char* what) {
     g_trace_last = t;
 }
 
+// Stage record of a build ("build_stages" 1): bft_stage() drops an event on the build's stream where a stage ends and notes the
+// bytes the stage's algorithm reads + writes (from its own array sizes); bft_gpu_build resolves the events into GPU time per stage
+// when it is done (bft_gpu_build_stages).  The host's waits between stages are inside the figures: a stage is what the stream spent
+// between two marks.  One build at a time per thread.
+namespace {
+struct StageMark { std::string name; double bytes; hipEvent_t ev; };
+thread_local bool t_stages_on = false;
+thread_local std::vector<StageMark> t_stage_marks;
+thread_local std::vector<hipEvent_t> t_stage_pool;
+}  // namespace
+void bft_stage(const char* name, double bytes, hipStream_t s) {
+    if (!t_stages_on) return;
+    hipEvent_t ev = nullptr;
+    if (!t_stage_pool.empty()) { ev = t_stage_pool.back(); t_stage_pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); t_stage_pool.push_back(ev); return; }
+    t_stage_marks.push_back({name, bytes, ev});
+}
+
 // device code, by topic
 #include "bft_kernels_query.h"
 #include "bft_kernels_seq.h"
@@ -241,6 +260,8 @@ struct bft_gpu {
             if (ring_ev[i]) (void)hipEventDestroy(ring_ev[i]);
         if (ring) (void)hipHostFree(ring);
         if (kh_ctr) (void)hipFree(kh_ctr);
+        for (int i = 0; i < KH_CTR_SLOTS; i++)
+            if (kh_ctr_ev[i]) (void)hipEventDestroy(kh_ctr_ev[i]);
     }
 
     // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
@@ -322,14 +343,23 @@ struct bft_gpu {
     uint32_t opt_query_chunk = 4;  // largest claim, in blocks of 256 k-mers (4 = every claim: the smaller the window of the query stream the
                                    // resident workgroups read at a time, the better -- 2.61 / 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64)
     static constexpr int KH_CTR_SLOTS = 32;
-    uint32_t* kh_ctr = nullptr;  // (its own hipMalloc, not a block of the cache: nothing that was released while still in flight may write here)
+    unsigned long long* kh_ctr = nullptr;  // (its own hipMalloc, not a block of the cache: nothing that was released while still in flight may write here)
     hipStream_t kh_ctr_stream[KH_CTR_SLOTS] = {};
+    unsigned long long kh_ctr_base[KH_CTR_SLOTS] = {};  // where the next launch's range of the slot's counter starts (bft_claims.h)
+    uint64_t kh_ctr_tick[KH_CTR_SLOTS] = {};            // last use: a handle queried on more streams than slots recycles the least recently used
+    uint64_t kh_ctr_clock = 0;
+    hipEvent_t kh_ctr_ev[KH_CTR_SLOTS] = {};            // end of the slot's last launch (recorded only once every slot is in use)
+    int kh_ctr_pending = -1;
     int kh_ctr_used = 0;
     bool kh_ctr_failed = false;
     DevBuf sq_codes, sq_bad, sq_npos, sq_poff, sq_tmp, sq_cs, sq_tile;  // scratch of the sequence queries (grown, never shrunk)
     hipStream_t sq_stream = nullptr;
     bool sq_used = false;
+    uint64_t sq_units = 0;  // bound on the blocks of k-mer positions the sequence kernel deals out (claim_counters)
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
+    bool opt_build_stages = false;      // "build_stages": the next builds record GPU time and bytes per stage (bft_gpu_build_stages)
+    struct Stage { std::string name; double ms, bytes; };
+    std::vector<Stage> stages;          // of the last build
 };
 
 static int grid_for(uint64_t nblk) { return bft_grid_for(nblk); }
@@ -635,19 +665,19 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
             CK(g2.alloc(total * 4));
             size_t tb = 0;
             const int gb = bits_for(h->max_gid_seen);
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
+            BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
             CK(tmp1.alloc(tb));
-            HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
+            BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
             kin = k2.as<uint64_t>();
             gin = g2.as<uint32_t>();
         }
         size_t tb = 0;
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
+        BFT_RADIX_SORT(0, 2 * h->k, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
         if (tb > tmp1.bytes) {
             HIPCK(hipStreamSynchronize(h->stream));
             CK(tmp1.alloc(tb));
         }
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
+        BFT_RADIX_SORT(0, 2 * h->k, hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));
         return 0;
@@ -662,15 +692,15 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
     const int grid = grid_for((total + 255) / 256);
     hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, h->stream, perm.as<uint32_t>(), total);
     size_t tb32 = 0, tb64 = 0;
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb32, kg.as<uint32_t>(), kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 32, h->stream));
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb64, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 64, h->stream));
+    BFT_RADIX_SORT(0, 32, hipcub::DeviceRadixSort::SortPairs(nullptr, tb32, kg.as<uint32_t>(), kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 32, h->stream));
+    BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(nullptr, tb64, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 64, h->stream));
     CK(tmp.alloc(std::max(tb32, tb64)));
     // pass 0: genome id (least significant); skipped when the input is already in genome-id order
     // (ids inserted in non-decreasing order, as the reference requires: the stable key passes keep it)
     if (!g_already_ordered) {
         size_t tb = tmp.bytes;
         const int gb = bits_for(h->max_gid_seen);
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, g, kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, gb, h->stream));
+        BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, g, kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, gb, h->stream));
         perm.swap(perm2);
     }
     // passes over the key words, least significant word (W-1) first
@@ -678,7 +708,7 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
         const int nbits = (w == 0) ? (2 * h->k - 64 * (W - 1)) : 64;
         hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, keys + (uint64_t)w * stride, perm.as<uint32_t>(), ku.as<uint64_t>(), total);
         size_t tb = tmp.bytes;
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
+        BFT_RADIX_SORT(0, nbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
         perm.swap(perm2);
     }
     for (int w = 0; w < W; w++)
@@ -954,8 +984,11 @@ static void kh_start(bft_gpu* h, const uint64_t* d_tk, const uint32_t* d_tcol, u
     bool ok = true;
     if (after && after != run) ok = hipEventRecord(f.ew, after) == hipSuccess && hipStreamWaitEvent(run, f.ew, 0) == hipSuccess;
     ok = ok && hipEventRecord(f.e0, run) == hipSuccess;
+    if (run != h->stream) bft_stage("+k-mer hash build starts (side stream)", 0, run);
     ok = ok && bft_kh_sort(d_tk, d_tcol, nk, h->k, h->W, f.geo, f.scratch, run) == 0 && bft_kh_lay(nk, h->k, h->W, f.geo, f.buf.as<uint64_t>(), f.ovf_k.as<uint64_t>(), f.ovf_v.as<uint32_t>(), f.status.as<uint32_t>(), f.scratch, run) == 0 &&
          hipEventRecord(f.e1, run) == hipSuccess;
+    // (keys: table in, records out; the sort's passes over the records; the lines written once)
+    bft_stage(run != h->stream ? "+k-mer hash build ends (side stream)" : "k-mer hash build", (double)nk * (8.0 * h->W + 4) * 8 + (double)f.geo.nl * 64, run);
     f.s2 = run;
     f.started = true;  // (whatever was enqueued is waited for before the buffers go anywhere)
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(run); f.started = false; f.buf.release(); }
@@ -1091,9 +1124,9 @@ static int ensure_table(bft_gpu* h) {
     if (got != n) return fail(BFT_GPU_E_HIP, "k-mer hash does not hold the index (compact_table)");
     if (W == 1) {
         size_t tb = 0;
-        HIPCK(rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+        BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
         CK(tmp.alloc(tb));
-        HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+        BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
     } else {  // two-word keys: the build's permutation sort (words apart, as the dump wrote them), then rows of two words
         DevBuf sorted;
         CK(sorted.alloc(n * W * 8));
@@ -1306,9 +1339,9 @@ static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32
     const BftNarrowIds<GT> nar{src_g};
     auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
     size_t tb = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
+    BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
     CK(tmp.alloc(tb));
-    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
+    BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
     HIPCK(hipGetLastError());
     tmp.release();
     return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npg, nk, np);
@@ -1333,11 +1366,12 @@ static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* sr
     const BftNarrowIds<VT> nar{src_g};
     auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
     size_t tb = 0;
-    HIPCK(rocprim::radix_sort_pairs<Msd9>(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
+    BFT_RADIX_SORT(rest, (unsigned)(2 * h->k), rocprim::radix_sort_pairs<Msd9>(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
     CK(tmp.alloc(tb));
-    HIPCK(rocprim::radix_sort_pairs<Msd9>(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
+    BFT_RADIX_SORT(rest, (unsigned)(2 * h->k), rocprim::radix_sort_pairs<Msd9>(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
     hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(),
                        maxb.as<uint32_t>());
+    bft_stage("split (root-prefix, 2 x 9 bits, pairs)", (double)total * (12 + 12 + 2 * (8 + sizeof(VT)) + (8 + sizeof(VT))), h->stream);
     tmp.release();
     uint32_t mx = 0;
     CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done,
@@ -1345,6 +1379,36 @@ static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* sr
     h->msd_max_bucket = mx;
     return 0;
 }
+
+// "build_stages": the marks of one bft_gpu_build (bft_stage) become the handle's stage table when the build returns, however it returns
+struct StageScope {
+    bft_gpu* h;
+    explicit StageScope(bft_gpu* hh) : h(hh) {
+        t_stages_on = h->opt_build_stages;
+        t_stage_marks.clear();
+        if (t_stages_on) bft_stage("start", 0, h->stream);
+    }
+    ~StageScope() {
+        if (!t_stages_on) return;
+        t_stages_on = false;
+        h->stages.clear();
+        (void)hipStreamSynchronize(h->stream);
+        if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+        for (size_t i = 0; i < t_stage_marks.size(); i++) {
+            float ms = 0;
+            // a mark on the second stream ("+name": work that runs beside the main chain) is timed from the build's start
+            const bool side = !t_stage_marks[i].name.empty() && t_stage_marks[i].name[0] == '+';
+            size_t prev = 0;
+            if (!side) for (size_t j = i; j-- > 0;) if (t_stage_marks[j].name[0] != '+') { prev = j; break; }
+            if (i > 0 && hipEventSynchronize(t_stage_marks[i].ev) == hipSuccess &&
+                hipEventElapsedTime(&ms, t_stage_marks[prev].ev, t_stage_marks[i].ev) == hipSuccess)
+                h->stages.push_back({t_stage_marks[i].name, (double)ms, t_stage_marks[i].bytes});
+            (void)hipGetLastError();
+        }
+        for (auto& m : t_stage_marks) t_stage_pool.push_back(m.ev);
+        t_stage_marks.clear();
+    }
+};
 
 extern "C" int bft_gpu_build(bft_gpu* h) {
     if (!h) return fail(BFT_GPU_E_ARG, "NULL handle");
@@ -1356,6 +1420,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     const uint64_t total = h->log_n;  // the run: what was inserted since the last build
     double t0 = now_ms();
     bft_trace_mark(nullptr);
+    StageScope stage_scope(h);
 
     DevBuf tk, seg_off, npg;
     uint64_t nk = 0, np = 0;
@@ -1392,11 +1457,13 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 CK(maxb.alloc_zero(4, h->stream));
                 // (9-bit digits: the 18 bits in two onesweep passes instead of the three that rocPRIM's 8-bit default takes -- 2.76 ms
                 // against 3.79 on 2 x 10^8 keys, tools/microbench/msd_sort.hip)
-                HIPCK(rocprim::radix_sort_keys<Msd9>(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                BFT_RADIX_SORT((unsigned)gb + rest, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys<Msd9>(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
                 CK(tmp.alloc(tb));
-                HIPCK(rocprim::radix_sort_keys<Msd9>(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                BFT_RADIX_SORT((unsigned)gb + rest, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys<Msd9>(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
+                // (histogram: the log, 12 B per pair; pass 1: the log in, composites out; pass 2: composites in and out)
+                bft_stage("split (root-prefix, 2 x 9 bits)", (double)total * (12 + 12 + 8 + 8 + 8), h->stream);
                 uint32_t mx = 0;
                 CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx,
                                      &done, &h->front_redone));
@@ -1404,13 +1471,13 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 if (done) pos.release();
             }
             if (!done) {
-            HIPCK(rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            BFT_RADIX_SORT((unsigned)gb, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
             const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
             auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
             HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
             if (std::max(tb, tb2) > tmp.bytes) CK(tmp.alloc(std::max(tb, tb2)));
             tb = tb2 = tmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            BFT_RADIX_SORT((unsigned)gb, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
             HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
             uint64_t last_pos = 0, last_c[2] = {0, 0};
             HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1500,6 +1567,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         }
     }
     bft_trace_mark("sort + dedupe done");
+    bft_stage("sort + dedupe (rest)", 0, h->stream);
     double t1 = now_ms();
 
     // 4. colour sets: signature sort + exact run detection + verification, all on the GPU
@@ -1517,6 +1585,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
     bft_trace_mark("colour sets interned");
+    bft_stage("colour sets (rest)", 0, h->stream);
     seg_off.release();
     npg.release();
     // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
@@ -1546,6 +1615,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     // (started HERE instead -- beside the root's table passes -- the sort-based table build was measured too: 17.2-18.4 ms against 17.0)
     const BftAssembleHook hook{tk.p ? &KhStart::run : nullptr, &khs};
     bft_trace_mark("merge / bookkeeping");
+    bft_stage("merge into the index", 0, h->stream);
     double t2 = now_ms();
 
     // 5. containers, level by level, on the GPU
@@ -1553,20 +1623,24 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     BftDeviceIndex idx;
     CK(bft_assemble_gpu(tk.as<uint64_t>(), nk, h->k, h->d_hashmod.as<uint32_t>(), h->stream, idx, &hook));
     bft_trace_mark("containers assembled");
+    bft_stage("containers: concatenation", 0, h->stream);
     double t3 = now_ms();
     DevBuf n_ccx, n_f18buf, n_fentbuf;
     uint64_t n_f18 = 0, n_fent = 0;
     CK(bft_flatten_gpu(idx.ccs.as<BftCC>(), idx.n_ccs, idx.f2w.as<uint64_t>(), idx.clus.as<uint64_t>(), idx.child.as<uint64_t>(), h->opt_flat_min, h->stream,
                        n_ccx, n_f18buf, n_fentbuf, n_f18, n_fent));
     bft_trace_mark("flat forms");
+    bft_stage("flat forms of the big CCs", (double)(n_f18 + n_fent) * 8, h->stream);
     const uint32_t new_cs_w = id_width(h->max_gid_seen);
     DevBuf n_cs_ids_w;
     CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
     CK(wait_foreign_stream(h));  // queries a caller still has in flight on its own stream read the arrays released below
     bft_trace_mark("ids narrowed, foreign stream waited");
+    bft_stage("dictionary ids narrowed", (double)n_ids * (4 + new_cs_w), h->stream);
     double kh_ms = 0;
     const bool kh_ok = kh_finish(h, khf, &kh_ms);
     bft_trace_mark("k-mer hash fill waited");
+    bft_stage("wait for the k-mer hash build", 0, h->stream);
     if (h->inject_build_failure) {
         h->inject_build_failure = false;
         return fail(BFT_GPU_E_LIMIT, "injected build failure (test hook)");
@@ -1639,12 +1713,14 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     else kh_drop(h);
     sync_walk_kh(h);
     bft_trace_mark("root tables");
+    bft_stage("root tables", 0, h->stream);
     derive_node_hash(h);
     default_launch_shape(h);
     I[12] = image_bytes(h);
     h->table_dropped = false;
     drop_table(h);  // ("compact_table")
     bft_trace_mark("launch shape; done");
+    bft_stage("node hash, launch shape, compact table", 0, h->stream);
     if (bft_trace_on()) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         fprintf(stderr, "[bft_gpu build] cache of released blocks: %zu blocks, %.1f MB; this process so far: %llu hipMalloc (%.2f ms), %llu hipFree on release (%.2f ms)\n", g_pool.size(),
@@ -1673,7 +1749,8 @@ static int query_residency(const bft_gpu* h) {
     return h->tuned_wgs ? h->tuned_wgs : 2;
 }
 
-static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n);
+static BftClaimCtr claim_counters(bft_gpu* h, hipStream_t s, uint64_t n, uint64_t units);
+static void claims_launched(bft_gpu* h, hipStream_t s);
 template <int W, bool STAGED, int PROBE>
 static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_rows, hipStream_t s, int rec) {
     // LDS: hash table + root Bloom block (<= 64 CCs) + root CC headers: at most two workgroups fit a CU (160 KB).  With
@@ -1687,7 +1764,7 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
     // chunks of 1024 k-mers per wavefront (query_body): the first by wavefront number, the others claimed from the stream's counter pair
     const uint64_t n_chunks = (n + 1023) / 1024, wg_chunks = (n_chunks + block / 64 - 1) / (block / 64);
-    uint32_t* ctr = claim_counters(h, s, n);
+    const BftClaimCtr ctr = claim_counters(h, s, n, n_chunks);
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wg_chunks, resident * h->opt_grid_mult)));
     static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
     const uint64_t dev_bit = 1ull << (h->device & 63);
@@ -1736,6 +1813,7 @@ static int launch_query_walk(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uin
     }
     h->im.walk_kh = keep;
     CK(rc);
+    claims_launched(h, s);
     CK(timing_end(h, s, e0, e1));
     return 0;
 }
@@ -1752,29 +1830,57 @@ static void ensure_claim_counters(bft_gpu* h) {
         h->kh_ctr_failed = true;
     }
 }
-// The claim counters of stream s (see struct bft_gpu), or NULL: every round of blocks is dealt out by workgroup number.  A handle keeps a
-// pair for each of the first KH_CTR_SLOTS streams it is queried on; launches on a stream beyond them run static rounds and are counted
+// The claim counter of stream s (see struct bft_gpu) with the range this launch may use, or {NULL}: every round of blocks is dealt out by
+// workgroup number.  units: what the launch deals out (blocks of 256 k-mers, chunks of 1024) -- the slot's base moves on by that plus what the
+// resident workgroups can claim beyond it, so the next launch starts above anything this one can leave behind, finished or not
+// (bft_claims.h).  A handle keeps a counter for each of KH_CTR_SLOTS streams; queried on more, it hands the least recently used slot to the
+// new stream once that slot's last launch is known to be over (an event per slot), else the launch runs static rounds and is counted
 // (bft_gpu_build_time, entry 20: nothing is silent).
-static uint32_t* claim_counters(bft_gpu* h, hipStream_t s, uint64_t n) {
+static BftClaimCtr claim_counters(bft_gpu* h, hipStream_t s, uint64_t n, uint64_t units) {
     static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
-    if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || !h->kh_ctr) return nullptr;
+    if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || !h->kh_ctr) return BftClaimCtr{nullptr, 0};
     int slot = -1;
     for (int i = 0; i < h->kh_ctr_used; i++)
         if (h->kh_ctr_stream[i] == s) slot = i;
-    if (slot < 0) {
-        if (h->kh_ctr_used == bft_gpu::KH_CTR_SLOTS) { h->claims_static_launches++; return nullptr; }
+    if (slot < 0 && h->kh_ctr_used < bft_gpu::KH_CTR_SLOTS) {
         slot = h->kh_ctr_used++;
         h->kh_ctr_stream[slot] = s;
     }
-    return h->kh_ctr + 2 * slot;
+    if (slot < 0) {  // every slot taken: the least recently used one, if its stream has nothing of ours in flight any more
+        int lru = 0;
+        for (int i = 1; i < bft_gpu::KH_CTR_SLOTS; i++)
+            if (h->kh_ctr_tick[i] < h->kh_ctr_tick[lru]) lru = i;
+        if (h->kh_ctr_ev[lru] && hipEventQuery(h->kh_ctr_ev[lru]) == hipSuccess) {
+            slot = lru;
+            h->kh_ctr_stream[slot] = s;
+        } else {
+            (void)hipGetLastError();
+            h->claims_static_launches++;
+            return BftClaimCtr{nullptr, 0};
+        }
+    }
+    h->kh_ctr_tick[slot] = ++h->kh_ctr_clock;
+    h->kh_ctr_pending = slot;  // (claims_launched records the slot's event behind the launch)
+    const BftClaimCtr c{h->kh_ctr + slot, h->kh_ctr_base[slot]};
+    h->kh_ctr_base[slot] += units + ((unsigned long long)1 << 24);  // (2^24: more than the resident workgroups x the largest claim)
+    return c;
+}
+// behind a launch that was given a counter: where the slot's last use ends (only looked at when the slots run out)
+static void claims_launched(bft_gpu* h, hipStream_t s) {
+    const int slot = h->kh_ctr_pending;
+    h->kh_ctr_pending = -1;
+    if (slot < 0 || h->kh_ctr_used < bft_gpu::KH_CTR_SLOTS) return;  // (no event traffic until the slots are all in use)
+    if (!h->kh_ctr_ev[slot] && hipEventCreateWithFlags(&h->kh_ctr_ev[slot], hipEventDisableTiming) != hipSuccess) { h->kh_ctr_ev[slot] = nullptr; (void)hipGetLastError(); return; }
+    if (hipEventRecord(h->kh_ctr_ev[slot], s) != hipSuccess) (void)hipGetLastError();
 }
 
 // Presence (and, with im.emit_cs, the colour set of every found k-mer into d_out32) through the k-mer hash.
 static int launch_query_kh(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint32_t* d_out32, hipStream_t s, int rec) {
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
-    CK(bft_kh_query(h->im, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, claim_counters(h, s, n), h->opt_query_chunk, s));
+    CK(bft_kh_query(h->im, h->opt_grid_mult, d_kmers, n, rec, d_bits64, d_out32, claim_counters(h, s, n, (n + 255) / 256), h->opt_query_chunk, s));
     HIPCK(hipGetLastError());
+    claims_launched(h, s);
     CK(timing_end(h, s, e0, e1));
     return 0;
 }
@@ -1948,7 +2054,8 @@ static int launch_branching(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint
     hipEvent_t e0, e1;
     CK(timing_begin(h, s, &e0, &e1));
     if (h->im.kh_lines != nullptr) {  // eight candidates per k-mer, each one cache line of the k-mer hash, four in flight at a time
-        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8), h->opt_query_chunk, s));
+        CK(bft_kh_branching(h->im, d_kmers, n, h->B, d_bits64, d_counts, claim_counters(h, s, n * 8, (n + 255) / 256), h->opt_query_chunk, s));
+        claims_launched(h, s);
         CK(timing_end(h, s, e0, e1));
         return 0;
     }
@@ -2169,7 +2276,8 @@ static int launch_color_rows(bft_gpu* h, uint32_t* d_rowidx, uint64_t n, uint32_
         if (wide16) {
             // the tiles are dealt out by workgroup number: a grid larger than what is resident would run its last workgroups -- with all
             // their tiles -- behind the others (82 registers: five workgroups per CU, not eight)
-            static std::atomic<int> resident16{0};
+            static std::atomic<int> resident16_dev[64];  // per device: CU count and partition mode may differ between the GPUs of a process
+            std::atomic<int>& resident16 = resident16_dev[h->device & 63];
             int r = resident16.load(std::memory_order_relaxed);
             if (!r) {
                 int per_cu = 0, cus = 0;
@@ -2275,7 +2383,8 @@ static int launch_seq_walk_w(bft_gpu* h, uint32_t ns, int canonical, const uint6
     const bool staged = h->root_ncc >= 1 && h->root_ncc <= BFT_LDS_ROOT_MAX_CC;
     if (h->im.kh_lines != nullptr) {
         return bft_kh_seq(h->im, h->sq_codes.as<uint64_t>(), h->sq_bad.as<uint32_t>(), d_soff, h->sq_poff.as<uint64_t>(), h->sq_tile.as<uint32_t>(), ns, canonical,
-                          h->sq_cs.as<uint32_t>(), claim_counters(h, s, h->opt_query_dynamic_min), h->opt_query_chunk, s);
+                          h->sq_cs.as<uint32_t>(), claim_counters(h, s, h->opt_query_dynamic_min, h->sq_units), h->opt_query_chunk, s);
+        // (claims_launched: the caller, behind the launch)
     }
     return staged ? launch_seq_walk_k<W, true, 0>(h, ns, canonical, d_soff, s) : launch_seq_walk_k<W, false, 0>(h, ns, canonical, d_soff, s);
 }
@@ -2318,12 +2427,14 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
         size_t tb = h->sq_tmp.bytes;
         HIPCK(hipcub::DeviceScan::ExclusiveSum(h->sq_tmp.p, tb, h->sq_npos.as<uint64_t>(), h->sq_poff.as<uint64_t>(), (int)(ns + 1), s));
         hipLaunchKernelGGL(k_seq_tiles, dim3(256 * 4), dim3(256), 0, s, h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->sq_tile.as<uint32_t>());
+        h->sq_units = total_chars / 256 + 2;  // (k-mer positions <= characters: the blocks the kernel can deal out)
         switch (h->W) {
         case 1: CK(launch_seq_walk_w<1>(h, (uint32_t)ns, canonical, soff, s)); break;
         case 2: CK(launch_seq_walk_w<2>(h, (uint32_t)ns, canonical, soff, s)); break;
         case 3: CK(launch_seq_walk_w<3>(h, (uint32_t)ns, canonical, soff, s)); break;
         default: CK(launch_seq_walk_w<4>(h, (uint32_t)ns, canonical, soff, s)); break;
         }
+        claims_launched(h, s);
         const uint32_t win = std::min<uint32_t>(SEQ_TALLY_G, (G + 63u) & ~63u);  // counters per wavefront: all genomes up to 2048
         hipLaunchKernelGGL(k_seq_tally, dim3((unsigned)std::min<uint64_t>((ns + SEQ_TALLY_WAVES - 1) / SEQ_TALLY_WAVES, 256ull * 16)), dim3(64 * SEQ_TALLY_WAVES),
                            (size_t)SEQ_TALLY_WAVES * win * 4, s, h->sq_cs.as<uint32_t>(), h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->im.cs_off, h->im.cs_ids, h->im.cs_w, G, rowbytes,
@@ -2517,6 +2628,7 @@ extern "C" int bft_gpu_image_pack(bft_gpu* h, void* d_blob, uint64_t cap, void* 
         else HIPCK(hipMemcpyAsync(d + p.off[i], p.names.data(), n, hipMemcpyHostToDevice, s));  // section 12: the genome names (host)
     }
     HIPCK(hipStreamSynchronize(s));  // the header and the names are host temporaries
+    drop_table(h);  // ("compact_table": ensure_built brought the sorted table back for the blob; the source is a group member like the others)
     return BFT_GPU_OK;
 }
 
@@ -2580,6 +2692,8 @@ extern "C" int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int dev
     h->info[12] = image_bytes(h);
     h->built = true;
     ensure_claim_counters(h);
+    h->table_dropped = false;
+    drop_table(h);  // ("compact_table", the default: the replica's k-mer hash was derived from the blob's sorted table, which need not stay)
     *out = h;
     return BFT_GPU_OK;
 }
@@ -2735,6 +2849,18 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
         h->inject_build_failure = value != 0;
     } else if (nm == "timing") {
         h->timing = value != 0;
+    } else if (nm == "test_stale_claims") {  // test hook (tests/test_gpu_parity.py): every claim counter as a launch that never finished can leave it --
+        // anywhere up to the end of the range it was given, i.e. the next launch's base (1: one below it, 2: exactly there, 3: where it started)
+        if (value < 1 || value > 3) return fail(BFT_GPU_E_ARG, "test_stale_claims must be 1, 2 or 3");
+        ENTER(h);
+        if (h->kh_ctr) {
+            HIPCK(hipDeviceSynchronize());
+            unsigned long long v[bft_gpu::KH_CTR_SLOTS];
+            for (int i = 0; i < bft_gpu::KH_CTR_SLOTS; i++) v[i] = value == 3 ? 0ull : h->kh_ctr_base[i] - (value == 1 && h->kh_ctr_base[i] ? 1ull : 0ull);
+            HIPCK(hipMemcpy(h->kh_ctr, v, sizeof(v), hipMemcpyHostToDevice));
+        }
+    } else if (nm == "build_stages") {
+        h->opt_build_stages = value != 0;
     } else if (nm == "flat_min") {
         if (value < 1 || value > 65536) return fail(BFT_GPU_E_ARG, "flat_min must be in [1,65536]");
         h->opt_flat_min = (uint32_t)value;
@@ -2792,6 +2918,22 @@ extern "C" int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out) {
                           (double)h->nph_inserted, (double)h->nph_dropped, h->tune_ms[2], (double)h->claims_static_launches,
                           (double)h->im.kh.S, (double)h->im.kh.db, (double)h->im.kh.maxd, (double)h->kh_ovf_n};
     for (int i = 0; i < n_out && i < 25; i++) ms[i] = v[i];
+    return BFT_GPU_OK;
+}
+
+extern "C" int bft_gpu_build_stages(bft_gpu* h, char* names, uint32_t names_cap, double* ms, double* bytes, int cap, int* n_out) {
+    if (!h || !n_out) return fail(BFT_GPU_E_ARG, "NULL argument");
+    *n_out = (int)h->stages.size();
+    std::string all;
+    for (const auto& st : h->stages) { all += st.name; all += '\n'; }
+    if (names) {
+        if (all.size() + 1 > names_cap) return fail(BFT_GPU_E_NOSPACE, "names buffer too small");
+        memcpy(names, all.c_str(), all.size() + 1);
+    }
+    for (int i = 0; i < cap && i < (int)h->stages.size(); i++) {
+        if (ms) ms[i] = h->stages[i].ms;
+        if (bytes) bytes[i] = h->stages[i].bytes;
+    }
     return BFT_GPU_OK;
 }
 

@@ -111,11 +111,22 @@ extern "C" int bft_gpu_group_member_device(bft_gpu_group* g, int i) {
     return g->devices[(size_t)i];
 }
 
+extern "C" int bft_gpu_group_member_footprint(bft_gpu_group* g, int i, uint64_t* out, int n_out) {
+    if (!g || i < 0 || i >= (int)g->members.size()) return bft_fail(BFT_GPU_E_ARG, "bad group slot");
+    return bft_gpu_footprint(g->members[(size_t)i], out, n_out);
+}
+extern "C" int bft_gpu_group_member_info(bft_gpu_group* g, int i, uint64_t* out, int n_out) {
+    if (!g || i < 0 || i >= (int)g->members.size()) return bft_fail(BFT_GPU_E_ARG, "bad group slot");
+    return bft_gpu_info(g->members[(size_t)i], out, n_out);
+}
+
 // ---- device-resident batches: member i answers the batch that lies in ITS GPU's memory, on ITS stream.  Nothing here waits for a GPU and no
 // host thread is started: every member's call only enqueues (the single-GPU *_dev entry points are stream-ordered), so the members of the
 // group run side by side.  streams may be NULL (every member's own stream) and so may streams[i].
 extern "C" int bft_gpu_group_query_presence_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* hip_streams) {
     if (!g || !d_kmers || !n || !d_present_bits) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    for (size_t i = 0; i < g->members.size(); i++)  // every slot is checked before anything is enqueued on any member
+        if (n[i] && (!d_kmers[i] || !d_present_bits[i])) return bft_fail(BFT_GPU_E_ARG, "NULL device pointer for a slot with k-mers");
     for (size_t i = 0; i < g->members.size(); i++)
         if (n[i]) CK(bft_gpu_query_presence_dev(g->members[i], d_kmers[i], n[i], d_present_bits[i], hip_streams ? hip_streams[i] : nullptr));
     return BFT_GPU_OK;
@@ -124,12 +135,16 @@ extern "C" int bft_gpu_group_query_color_rows_dev(bft_gpu_group* g, const void* 
                                                   void* const* d_scratch_rows_u32, void* const* hip_streams) {
     if (!g || !d_kmers || !n || !d_present_bits || !d_rows || !d_scratch_rows_u32) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     for (size_t i = 0; i < g->members.size(); i++)
+        if (n[i] && (!d_kmers[i] || !d_present_bits[i] || !d_rows[i] || !d_scratch_rows_u32[i])) return bft_fail(BFT_GPU_E_ARG, "NULL device pointer for a slot with k-mers");
+    for (size_t i = 0; i < g->members.size(); i++)
         if (n[i]) CK(bft_gpu_query_color_rows_dev(g->members[i], d_kmers[i], n[i], d_present_bits[i], d_rows[i], d_scratch_rows_u32[i], hip_streams ? hip_streams[i] : nullptr));
     return BFT_GPU_OK;
 }
 extern "C" int bft_gpu_group_query_branching_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_branching_bits, void* const* d_counts,
                                                  void* const* hip_streams) {
     if (!g || !d_kmers || !n || !d_branching_bits) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
+    for (size_t i = 0; i < g->members.size(); i++)
+        if (n[i] && (!d_kmers[i] || !d_branching_bits[i])) return bft_fail(BFT_GPU_E_ARG, "NULL device pointer for a slot with k-mers");
     for (size_t i = 0; i < g->members.size(); i++)
         if (n[i]) CK(bft_gpu_query_branching_dev(g->members[i], d_kmers[i], n[i], d_branching_bits[i], d_counts ? d_counts[i] : nullptr, hip_streams ? hip_streams[i] : nullptr));
     return BFT_GPU_OK;

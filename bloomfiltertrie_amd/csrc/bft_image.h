@@ -117,7 +117,7 @@ static_assert(__builtin_offsetof(BftCCX, flat) == __builtin_offsetof(BftCC, pad0
 // OVERFLOW LIST decides: the handful of k-mers (none, on most indexes) whose run of full lines was longer than a slot's displacement bits
 // hold, sorted, searched only by the one lookup in millions that meets such a run.  (In the canonical layout the slot such a k-mer would
 // have taken is marked in use with value 0 -- a tombstone no lookup matches --: the lines before the k-mers behind it stay full.)  At the default occupancy of the
-// home lines (60 %) a lookup reads 1.05-1.1 lines: ONE cache line beyond the L2 per query, where the container walk of
+// home lines (55 %: "kmer_hash_load") a lookup reads 1.09 lines: ONE cache line beyond the L2 per query, where the container walk of
 // src/presenceNode.c:1284-1921 costs a line per level and per suffix-group probe even in its fastest form here; on MI355X a kernel of
 // random gathers is bound by the lines it misses on (tools/microbench/gather.hip: ~55 G lines/s beyond the L2, whether the lane reads 8
 // or 128 bytes of the line), so lines per query is the whole cost.

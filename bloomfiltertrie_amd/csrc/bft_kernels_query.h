@@ -50,7 +50,7 @@ struct BftRootLds {
 #define BFT_LDS_ROOT_MAX_CC 64u
 
 // The batch is dealt out WAVEFRONT by wavefront, in chunks of 1024 k-mers = 16 passes of 64 = the 16 presence words of one 128-byte line
-// of the bitmap: the first chunk of a wavefront by its number, the others claimed from ctr[0] (NULL: all by number; see bft_claims.h for
+// of the bitmap: the first chunk of a wavefront by its number, the others claimed from the stream's counter (NULL: all by number; see bft_claims.h for
 // why batches are claimed at all).  A wavefront gathers the words of its chunk in its own 128 bytes of LDS and stores the line with one
 // instruction.  Nothing here makes the wavefronts of a workgroup wait for each other: a barrier per pass costs this latency-bound kernel
 // 10-30 %, and rounds of four blocks per WORKGROUP (three barriers per round, the scheme of k_query_kh) took 7.6 ms where this takes
@@ -64,7 +64,7 @@ struct BftRootLds {
 // its LDS holds the wavefronts' lines.
 template <int W, int BLOCK, bool STAGED, int PROBE, bool WKH = false, int KS = 0>
 __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __restrict__ packed, uint64_t n, int B,
-                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
+                                           uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows, BftClaimCtr cc) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint32_t* l_hm = KS > 0 ? const_cast<uint32_t*>(im.hashmod) : (uint32_t*)lds;
     uint8_t* l_bf = KS > 0 ? lds : lds + BFT_LDS_HM_BYTES;
@@ -99,7 +99,8 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
     const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK, nwords = (n + 63) / 64;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t n_waves = (uint64_t)gridDim.x * WPW;
-    if (n_waves >= n_chunks) ctr = nullptr;  // (the first round covers the batch: no counter involved)
+    unsigned long long* ctr = n_waves >= n_chunks ? nullptr : cc.p;  // (the first round covers the batch: no counter involved)
+    if (ctr && lane == 0) atomicMax(ctr, cc.base);  // (bft_claims.h: the counter enters this launch's range before the wavefront's first claim)
     uint64_t chunk = (uint64_t)blockIdx.x * WPW + wave;
     uint32_t next_claim = 0;
     volatile uint64_t* my_bits = s_bits[wave];
@@ -191,7 +192,7 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
             if (lane == 0) my_bits[pass] = mask;
             // the claim for the next chunk travels while this one is answered (sent after the first pass: at the start of a launch
             // every wavefront would ask at the same instant)
-            if (pass == 0 && ctr && lane == 0) next_claim = atomicAdd(&ctr[0], 1u);
+            if (pass == 0 && ctr && lane == 0) next_claim = (uint32_t)(atomicAdd(ctr, 1ull) - cc.base);
             const uint64_t pm = __ballot(parked);
             if (pm) {
                 const uint32_t np = (uint32_t)__popcll(pm);
@@ -223,11 +224,6 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
         chunk = ctr ? n_waves + (uint64_t)__builtin_amdgcn_readfirstlane(next_claim) : chunk + n_waves;
     }
     if (qn) drain(false);
-    // ctr[1] counts the wavefronts that are done; the last one zeroes the pair for the next launch on the stream
-    if (ctr && lane == 0 && atomicAdd(&ctr[1], 1u) == (uint32_t)n_waves - 1u) {
-        ctr[0] = 0u;
-        ctr[1] = 0u;
-    }
 }
 
 // Two builds of the same body.  k_query: registers as the compiler likes them (106 SGPRs: the BftImage pointers live in
@@ -238,13 +234,13 @@ __device__ __forceinline__ void query_body(const BftImage& im, const uint8_t* __
 // from the image (-1; the other workgroup sizes): the 4-row code alone fits the 64 VGPRs of k_query8 without spilling.
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) void k_query(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                 uint32_t* __restrict__ rows, uint32_t* __restrict__ ctr) {
+                                                 uint32_t* __restrict__ rows, BftClaimCtr ctr) {
     query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 template <int W, int BLOCK, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_query8(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                                                                              uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
-                                                                                             uint32_t* __restrict__ ctr) {
+                                                                                             BftClaimCtr ctr) {
     query_body<W, BLOCK, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 // k_query6: the arrangement in between -- two 768-thread workgroups per CU, 6 wavefronts per SIMD with 84 VGPRs each.  The walk
@@ -253,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 template <int W, bool STAGED, int PROBE>
 __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                                                                                  uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
-                                                                                                 uint32_t* __restrict__ ctr) {
+                                                                                                 BftClaimCtr ctr) {
     query_body<W, BFT_BLOCK6, STAGED, PROBE>(im, packed, n, B, bits64, rows, ctr);
 }
 

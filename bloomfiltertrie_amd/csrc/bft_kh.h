@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bft_claims.h"
 #include "bft_dev.h"
 #include "bft_image.h"
 
@@ -22,15 +23,15 @@ int bft_kh_lay(uint64_t n, int k, int W, const BftKhGeo& g, uint64_t* d_kh, uint
 // every (k-mer, value) of the table, unordered, word w of k-mer j at d_keys[w * stride + j]; *d_cnt (zeroed by the caller) = how many
 int bft_kh_dump(const BftImage& im, uint64_t* d_keys, uint64_t stride, uint32_t* d_vals, unsigned long long* d_cnt, hipStream_t s);
 // presence bits (+ colour-set id per k-mer when d_out32 != NULL) of n packed k-mers of `rec` bytes each
-// d_ctr: NULL, or two zeroed 32-bit words that no other launch in flight uses -- the rounds of `chunk` blocks of 256 k-mers after the first
+// d_ctr: {NULL}, or the stream's claim counter with this launch's base (bft_claims.h) -- the rounds of `chunk` blocks of 256 k-mers after the first
 // are then claimed instead of dealt out by workgroup number (bft_claims.h), and the kernel leaves the words zeroed
-int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
+int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, BftClaimCtr d_ctr, uint32_t chunk,
                  hipStream_t s);
-int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s);
+int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s);
 // colour set of every k-mer position of a chunk of sequences (the arrays of query_sequences_core)
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
-               uint32_t n_seqs, int canonical, uint32_t* d_csout, uint32_t* d_ctr, uint32_t chunk, hipStream_t s);
+               uint32_t n_seqs, int canonical, uint32_t* d_csout, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s);
 
 // bft_walkh.hip: the container walk with plain root groups looked up in the k-mer hash ("walk_hash"): presence bits (and colour sets when
 // im.emit_cs) of n k-mers of `rec` bytes; d_ctr: the stream's claim counters or NULL
-int bft_walkh_query(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_rows, uint32_t* d_ctr, uint32_t grid_mult, hipStream_t s);
+int bft_walkh_query(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_rows, BftClaimCtr d_ctr, uint32_t grid_mult, hipStream_t s);

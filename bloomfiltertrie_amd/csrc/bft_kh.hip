@@ -52,7 +52,7 @@ typedef BftClaims<BFT_KH_MIN_CLAIM> KhClaims;
 // kernel was bound by its own instructions: 48 G k-mers/s against 52.5).
 template <int W, int S>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                          uint32_t* __restrict__ out32, uint32_t* __restrict__ ctr, uint32_t chunk) {
+                                                          uint32_t* __restrict__ out32, BftClaimCtr ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, nwords = (n + 63) / 64;
     constexpr uint32_t WPB = BFT_KH_BLOCK / 64;  // presence words per block
@@ -146,7 +146,7 @@ __device__ __forceinline__ int kh_count4(const BftImage& im, const uint64_t* t0,
 #define BFT_KH_BR_MAX_CLAIM 16u
 template <int W, int S>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
-                                                              uint8_t* __restrict__ counts, uint32_t* __restrict__ ctr, uint32_t chunk) {
+                                                              uint8_t* __restrict__ counts, BftClaimCtr ctr, uint32_t chunk) {
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     const uint64_t nblk = (n + BFT_KH_BLOCK - 1) / BFT_KH_BLOCK, nwords = (n + 63) / 64;
     constexpr uint32_t WPB = BFT_KH_BLOCK / 64;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_branching_kh(BftImage im, cons
 template <int W, int S>
 __global__ __launch_bounds__(256) void k_seq_kh(BftImage im, const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bad, const uint64_t* __restrict__ seq_off,
                                                 const uint64_t* __restrict__ pos_off, const uint32_t* __restrict__ tile_seq, uint32_t n_seqs, int canonical,
-                                                uint32_t* __restrict__ csout, uint32_t* __restrict__ ctr, uint32_t chunk) {
+                                                uint32_t* __restrict__ csout, BftClaimCtr ctr, uint32_t chunk) {
     const uint64_t P = pos_off[n_seqs];
     const uint64_t nblk = (P + 255) / 256;
     __shared__ uint32_t s_next[2];
@@ -375,9 +375,9 @@ static int kh_sort_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, i
     unsigned bits = 1;
     while (bits < 32 && (g.nl >> bits)) bits++;
     size_t tb = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
+    BFT_RADIX_SORT(0u, bits, rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
     if (tb > tmp.bytes) CK(tmp.alloc(tb));
-    HIPCK(rocprim::radix_sort_pairs(tmp.p, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
+    BFT_RADIX_SORT(0u, bits, rocprim::radix_sort_pairs(tmp.p, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -520,27 +520,27 @@ static dim3 kh_round_grid(uint64_t n, uint32_t chunk, int mult, bool claimed) {
     return dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(rounds, resident)));
 }
 
-int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, uint32_t* d_ctr, uint32_t chunk,
+int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, BftClaimCtr d_ctr, uint32_t chunk,
                  hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
     chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
-    const dim3 grid = kh_round_grid(n, chunk, grid_mult, d_ctr != nullptr);
+    const dim3 grid = kh_round_grid(n, chunk, grid_mult, d_ctr.p != nullptr);
     KH_DISPATCH(im.W, (int)im.kh.S, hipLaunchKernelGGL((k_query_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk));
     HIPCK(hipGetLastError());
     return 0;
 }
 
-int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
+int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s) {
     const dim3 block(BFT_KH_BLOCK);
     chunk = std::max(1u, std::min(chunk, BFT_KH_BR_MAX_CLAIM));
-    const dim3 grid = kh_round_grid(n, chunk, 1, d_ctr != nullptr);
+    const dim3 grid = kh_round_grid(n, chunk, 1, d_ctr.p != nullptr);
     KH_DISPATCH(im.W, (int)im.kh.S, hipLaunchKernelGGL((k_branching_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, B, d_bits64, d_counts, d_ctr, chunk));
     HIPCK(hipGetLastError());
     return 0;
 }
 
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,
-               uint32_t n_seqs, int canonical, uint32_t* d_csout, uint32_t* d_ctr, uint32_t chunk, hipStream_t s) {
+               uint32_t n_seqs, int canonical, uint32_t* d_csout, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s) {
     const dim3 grid(256 * 8), block(256);
     chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
     KH_DISPATCH(im.W, (int)im.kh.S,

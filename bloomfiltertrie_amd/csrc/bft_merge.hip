@@ -308,10 +308,10 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
         int abits = 1;  // (old set + 1) sits above the run's 32 bits
         while (abits < 32 && ((a.n_sets + 1) >> abits)) abits++;
         size_t tb = 0;
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
+        BFT_RADIX_SORT(0, 32 + abits, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
         DevBuf tmp;
         CK(tmp.alloc(tb));
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
+        BFT_RADIX_SORT(0, 32 + abits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
         HIPCK(hipStreamSynchronize(s));
     }
     key.release(); iota.release();

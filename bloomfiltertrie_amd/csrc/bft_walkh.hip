@@ -18,12 +18,12 @@
 template <int W, int S>
 __global__ __launch_bounds__(BFT_BLOCK6) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_query6h(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B,
                                                                                                   uint64_t* __restrict__ bits64, uint32_t* __restrict__ rows,
-                                                                                                  uint32_t* __restrict__ ctr) {
+                                                                                                  BftClaimCtr ctr) {
     query_body<W, BFT_BLOCK6, false, 0, true, S>(im, packed, n, B, bits64, rows, ctr);
 }
 
 // n k-mers of `rec` bytes each; d_ctr: the stream's claim counters (NULL: chunks by wavefront number)
-int bft_walkh_query(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_rows, uint32_t* d_ctr, uint32_t grid_mult, hipStream_t s) {
+int bft_walkh_query(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_rows, BftClaimCtr d_ctr, uint32_t grid_mult, hipStream_t s) {
     if (!im.walk_kh || !im.rspec || !im.rdir) return bft_fail(BFT_GPU_E_STATE, "walk_hash: no hashed root groups in this image");
     const uint64_t n_chunks = (n + 64ull * BFT_WALK_PASSES - 1) / (64ull * BFT_WALK_PASSES);
     const uint64_t wgc = (n_chunks + BFT_BLOCK6 / 64 - 1) / (BFT_BLOCK6 / 64);

@@ -163,10 +163,13 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  * "query_dynamic" (1, default): the query kernels deal their blocks of k-mers out in rounds: the first by workgroup (wavefront) number, the others
  *   claimed from a counter (one pair per stream that launches them, allocated when the first image is built) -- workgroups are bound to an XCD by
  *   their number, and a static split makes the launch as slow as the XCD that reaches the table slowest; "query_chunk" (4) blocks of 256 per round
- *   of the k-mer hash kernels; batches below "query_dynamic_min" (2^16) k-mers are split statically; a handle queried on more than 32 streams
- *   runs the extra streams' launches static (counted: bft_gpu_build_time entry 20).  0: always static.  The last workgroup of a launch resets the
- *   stream's pair for the next one: launches of ONE handle on ONE stream must not run concurrently (two host threads, or a captured graph replayed
- *   while a direct launch is in flight) -- use one stream per thread, as for any stream-ordered API.
+ *   of the k-mer hash kernels; batches below "query_dynamic_min" (2^16) k-mers are split statically.  The counter of a (handle, stream) pair is one
+ *   64-bit word that only grows: every launch gets its own range of it and raises it to the range's start itself, so a launch that never finished
+ *   (a fault, a killed process sharing nothing) cannot make a later one skip blocks -- nothing is reset by anyone (round 5; "test_stale_claims" is
+ *   the test hook that leaves the counters where such a launch would).  A handle keeps counters for 32 streams; queried on more, the least recently
+ *   used slot moves to the new stream once its last launch has completed, else that launch runs static and is counted (bft_gpu_build_time entry 20).
+ *   0: always static.  Launches of ONE handle on ONE stream must not run concurrently (two host threads, or a captured graph replayed while a direct
+ *   launch is in flight): they would share a range -- use one stream per thread, as for any stream-ordered API.
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),
@@ -190,7 +193,8 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   0, default = LDS atomics + order check + ballot fallback, 1 = ballots only, 2 = the check always fails), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
  *   pairs, so that a series of insert calls never re-allocates it), "flush_pairs" (the log is merged into the index before it holds this many pairs:
  *   2^30 by default, 1024..2^30).
- * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on). */
+ * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on).
+ * "build_stages" (0/1: bft_gpu_build records GPU time and algorithmic bytes per stage, see bft_gpu_build_stages). */
 int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value);
 
 /* Test hook: raw device->host copy of one array of the image ("nodes", "bfT", "ccs", "f2w", "clus",
@@ -209,6 +213,13 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
  * ms[14]=root tables in use (0 / 1 / 2, see "root_direct"), ms[15..16]="tune": time with the direct table alone / with the range table, ms[17]=keys in the
  * node prefix hash, ms[18]=keys it dropped (full bucket: those lookups take the container path), ms[19]="tune": time with residency 3. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
+/* The last bft_gpu_build stage by stage, when bft_gpu_set_option(h, "build_stages", 1) was set before it: names = the stage names, one per
+ * line (NUL-terminated; names_cap bytes), ms[i] = GPU time of stage i (HIP events on the build's stream: the time the stream spent between the end
+ * of the previous stage and the end of this one, the host's waits for counts included), bytes[i] = the bytes the stage's algorithm reads + writes,
+ * from its own array sizes (0: a chain of small kernels, not a streaming stage).  Names that start with '+' ran on the build's second stream beside
+ * the main chain and are timed from the build's start.  *n_out = number of stages; any of names / ms / bytes may be NULL.  Replaces nothing in the
+ * reference (insertKmers has no instrumentation, src/insertNode.c:18-36): this is what bench.py's `insert` block is made of. */
+int bft_gpu_build_stages(bft_gpu* h, char* names, uint32_t names_cap, double* ms, double* bytes, int cap, int* n_out);
 
 /* iterate_over_kmers-style dump (include/bft.h:166): copies every stored k-mer (packed layout,
  * ascending T-form order) and its colour-set id; either pointer may be NULL. */
@@ -264,6 +275,9 @@ int bft_gpu_group_query_branching(bft_gpu_group* g, const uint8_t* kmers, uint64
  * side; the caller synchronises its streams (a caller that owns one shard per GPU -- the partition of bft_gpu_group_shard or any other -- keeps
  * every buffer where it is produced and consumed: the resident rate of every GPU, not the host link's).  n[i] == 0 skips slot i. */
 int bft_gpu_group_member_device(bft_gpu_group* g, int i);
+/* bft_gpu_footprint / bft_gpu_info of slot i's handle (the replicas belong to the group: this is how their residency is inspected) */
+int bft_gpu_group_member_footprint(bft_gpu_group* g, int i, uint64_t* out, int n_out);
+int bft_gpu_group_member_info(bft_gpu_group* g, int i, uint64_t* out, int n_out);
 int bft_gpu_group_query_presence_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* hip_streams);
 int bft_gpu_group_query_color_rows_dev(bft_gpu_group* g, const void* const* d_kmers, const uint64_t* n, void* const* d_present_bits, void* const* d_rows,
                                        void* const* d_scratch_rows_u32, void* const* hip_streams);

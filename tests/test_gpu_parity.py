@@ -726,6 +726,12 @@ def test_device_group_answers_like_one_handle(k, devices):
         b2, c2 = t.query_branching(q[:50_000], with_counts=True)
         assert (b1 == b2).all() and (c1 == c2).all(), n
     assert (S.from_bits(grp.query_presence(base), len(base)) == S.member(base, allk)).all()
+    # "compact_table" (the default) holds for every member, the source included: the sorted table that travelled in the blob, and the one the
+    # source brought back to pack it, are not resident once the group exists; rows bring a member's table back, the next presence call not
+    for i in range(grp.size()):
+        fp = grp.member_footprint(i)
+        assert fp["kmer_hash"] > 0 and fp["kmer_table"] <= 8 and fp["colorset_per_kmer"] <= 8, (i, fp)
+    assert t.footprint()["kmer_table"] <= 8
     grp.close()
     with pytest.raises(Exception):
         BFTGroup(t, [99])
@@ -781,4 +787,86 @@ def test_device_group_on_resident_batches(k):
     grp.query_presence_dev([dq[0].data_ptr(), 0, dq[2].data_ptr()], [ns[0], 0, ns[2]], [bits[0].data_ptr(), 0, bits[2].data_ptr()], None)
     torch.cuda.synchronize()
     grp.close()
+    t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [27, 63])
+def test_claim_counters_survive_an_unfinished_launch(k):
+    """The query kernels claim their blocks from a per-stream counter (bft_claims.h).  The counter only grows and every launch raises it to the start
+    of its own range, so a launch that never finished -- its counter left anywhere inside the range it was given -- cannot make the next one skip
+    blocks: "test_stale_claims" leaves every counter one below the next base / exactly there / back at zero, and presence (k-mer hash, container walk
+    with and without hashed root groups), branching and sequence queries still answer whole batches, bit for bit as before."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    anc = S.random_genome(150000, 3 * k)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.02, 70 + g), k)) for g in range(4)]
+    t = BFT(k)
+    for g, km in enumerate(gk):
+        t.insert_kmers(km, g)
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(k)
+    base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])
+    q = np.ascontiguousarray(base[rng.integers(0, len(base), 3_000_000)])  # (claims start at 2^16 k-mers; the resident grid covers 2^21 in its first round)
+    truth = S.member(q, allk)
+    dq = torch.from_numpy(q).cuda()
+    nq = len(q)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def presence():
+        bits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
+        t.query_presence_dev(dq.data_ptr(), nq, bits.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return bits.cpu().numpy()[: (nq + 7) // 8]
+
+    ref = presence()
+    assert (S.from_bits(ref, nq) == truth).all()
+    br_ref = t.query_branching(q[:1_000_000], with_counts=True)
+    for mode in (1, 2, 3, 1):
+        for opts in ((), (("walk_hash", 1),), (("kmer_hash", 0),)):
+            for nm, v in opts:
+                t.set_option(nm, v)
+            presence()  # (a launch on this form first, so that its stream slot exists and has moved on)
+            t.set_option("test_stale_claims", mode)
+            assert (presence() == ref).all(), (mode, opts)
+            assert (presence() == ref).all(), (mode, opts)  # ... and the one after it
+            for nm, v in opts:
+                t.set_option(nm, {"walk_hash": 0, "kmer_hash": 1}[nm])
+        t.set_option("test_stale_claims", mode)
+        b, c = t.query_branching(q[:1_000_000], with_counts=True)
+        assert (b == br_ref[0]).all() and (c == br_ref[1]).all(), mode
+    t.close()
+
+
+@pytest.mark.gpu
+def test_more_streams_than_claim_slots():
+    """A handle keeps a claim counter for 32 streams; a 33rd stream takes over the least recently used slot once that slot's last launch is over
+    (rounds 3-4 sent every launch beyond the 32nd stream down the static split for the life of the handle).  48 streams, each queried twice:
+    same bits everywhere, and no launch that had to run static once the earlier ones have drained."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    anc = S.random_genome(150000, 9)
+    km = S.distinct(S.kmers_of(anc, k))
+    t = BFT(k)
+    t.insert_kmers(km, 0)
+    rng = np.random.default_rng(1)
+    base = np.concatenate([km, S.snp_mutants(km, k, 2)])
+    q = np.ascontiguousarray(base[rng.integers(0, len(base), 3_000_000)])
+    dq = torch.from_numpy(q).cuda()
+    nq = len(q)
+    ref = None
+    streams = [torch.cuda.Stream() for _ in range(48)]
+    for rnd in range(2):
+        for st in streams:
+            bits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t.query_presence_dev(dq.data_ptr(), nq, bits.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            got = bits.cpu().numpy()
+            if ref is None:
+                ref = got
+                assert (S.from_bits(ref[: (nq + 7) // 8], nq) == S.member(q, km)).all()
+            assert (got == ref).all()
+    assert t.build_time()["claims_static_launches"] == 0
     t.close()

@@ -37,6 +37,46 @@ def keys_of(packed):
     return pad.view(torch.int64).reshape(n)
 
 
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
+HBM_ACHIEVABLE_GBS = 6300.0  # ... and what a streaming kernel reaches
+
+
+def stage_table(t, pairs_in):
+    """bft_gpu_build_stages of the last build -> rows with GB/s against the achievable and the peak HBM rate.  A stage's bytes are what its
+    algorithm reads + writes, from its own array sizes (csrc: the bft_stage() calls); 0 = a chain of small kernels / host round trips."""
+    rows = []
+    for name, ms, by in t.build_stages():
+        r = {"stage": name, "ms": round(ms, 3)}
+        if by > 0 and ms > 0:
+            gbs = by / (ms * 1e-3) / 1e9
+            r.update({"bytes": round(by), "bytes_per_pair": round(by / max(1, pairs_in), 2), "GB_s": round(gbs, 1),
+                      "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 3), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 3)})
+        rows.append(r)
+    return rows
+
+
+def cpu_insert_baseline(k, genome_len, snp_rate, genomes=8):
+    """The oracle's insertKmers (oracle/bft_oracle.c: orc_insert_kmers, the restated container selection of src/insertNode.c:18-423) on the first
+    `genomes` genomes of the same generator family, one thread: pairs/s."""
+    from oracle import oracle as O
+    from bloomfiltertrie_amd import synth as S
+    anc = S.random_genome(genome_len, 4242)
+    o = O.OracleBFT(k)
+    n = 0
+    t = 0.0
+    for gid in range(genomes):
+        km = S.kmers_of(S.mutate(anc, snp_rate, 100 + gid), k)
+        t0 = time.perf_counter()
+        o.insert_kmers(km, gid)
+        t += time.perf_counter() - t0
+        n += len(km)
+    st = o.stats() if hasattr(o, "stats") else {}
+    o.close()
+    return {"value": round(n / t / 1e6, 3), "unit": "M pairs/s", "cores": 1, "kind": "port",
+            "sample": f"the oracle's insertKmers on {genomes} genomes of {genome_len} nt ({n} pairs, ids ascending), one thread, {t:.1f} s",
+            "oracle_trie": {k_: st[k_] for k_ in list(st)[:6]} if isinstance(st, dict) else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, default=27)
@@ -48,7 +88,14 @@ def main():
     ap.add_argument("--sync-inserts", action="store_true", help="bft_gpu_insert_kmers_dev (synchronised per call) instead of the stream-ordered bft_gpu_insert_kmers_dev_async")
     ap.add_argument("--add-genome", action="store_true", help="after the build, insert one more genome and time the incremental build (a merge)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to bft_gpu_set_option before the inserts (repeatable)")
+    ap.add_argument("--stages", action="store_true", help="per-stage GPU time and bytes of the build (bft_gpu_build_stages)")
+    ap.add_argument("--cpu-baseline", type=int, default=0, help="also time the oracle's insertKmers on this many genomes (one thread)")
     args = ap.parse_args()
+    print(json.dumps(measure(args)))
+
+
+def measure(args):
+    """args: the namespace of main() (bench.py builds one for its `insert` block)"""
     import torch
     from bloomfiltertrie_amd import BFT
     dev = torch.device("cuda", 0)
@@ -65,6 +112,8 @@ def main():
         warm.query_presence(w[:1000].cpu().numpy())
         del w
     t = BFT(args.k)
+    if args.stages:
+        t.set_option("build_stages", 1)
     for o in args.opt:
         name, val = o.split("=")
         t.set_option(name, int(val))
@@ -97,6 +146,8 @@ def main():
     t.build()
     t_build = time.perf_counter() - t0
     breakdown = {k_: round(v, 1) for k_, v in t.build_time().items()}  # of THIS build (a later build of the handle overwrites the library's record)
+    stages = stage_table(t, npairs_in) if args.stages else None
+    t.set_option("build_stages", 0)
     info_built = t.info()
     del batches
     # one more genome onto the finished index (-add_genomes): its run is sorted and merged into the index, not everything re-sorted
@@ -149,7 +200,22 @@ def main():
         "add_one_genome": add,
         "parity": {"counts": bool(ok_counts), "presence_sample": ok_presence, "colors_sample": ok_colors, "sample": ns},
     }
-    print(json.dumps(out))
+    if stages is not None:
+        main_ms = sum(r["ms"] for r in stages if not r["stage"].startswith("+"))
+        by = sum(r.get("bytes", 0) for r in stages if not r["stage"].startswith("+"))
+        out["stages"] = stages
+        out["roofline"] = {"bound": "hbm", "achieved": round(by / (main_ms * 1e-3) / 1e9, 1) if main_ms else None, "peak": HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS,
+                           "unit": "GB/s", "frac": round(by / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if main_ms else None, "traffic": None,
+                           "gpu_ms_main_stream": round(main_ms, 3), "algorithmic_bytes": round(by), "bytes_per_pair": round(by / max(1, npairs_in), 1),
+                           "note": "whole build: the algorithmic bytes of the streaming stages (the others -- chains of small kernels, host round trips -- count as time with no bytes) "
+                                   "over the GPU time of the build's main stream; per stage under `stages` ('+': the k-mer hash build on the side stream, from the build's start)"}
+    if args.cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_insert_baseline(args.k, args.genome_len, args.snp_rate, args.cpu_baseline)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    t.close()
+    return out
 
 
 if __name__ == "__main__":
