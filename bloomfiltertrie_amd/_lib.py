@@ -31,6 +31,7 @@ SIGNATURES = {
     "bft_gpu_query_presence": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "bft_gpu_query_presence_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_query_colors": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bft_gpu_query_colors_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_query_color_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_query_branching": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     "bft_gpu_query_branching_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P]),

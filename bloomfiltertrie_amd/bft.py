@@ -189,6 +189,12 @@ class BFT:
         _lib.check(self._lib.bft_gpu_query_color_rows(self._h, kmers.ctypes.data, n, bits.ctypes.data, rows.ctypes.data))
         return bits, rows
 
+    def query_colors_dev(self, d_kmers_ptr, n, d_bits_ptr, d_offsets_ptr, d_ids_ptr, ids_cap, d_needed_ptr=0, stream=None):
+        """Device-resident id lists (bft_gpu_query_colors_dev): offsets (n + 1 uint64) and ids (uint32) in HBM, no synchronisation; nothing is
+        written to the ids when they number more than ids_cap (*d_needed_ptr says how many)."""
+        _lib.check(self._lib.bft_gpu_query_colors_dev(self._h, C.c_void_p(d_kmers_ptr), n, C.c_void_p(d_bits_ptr), C.c_void_p(d_offsets_ptr),
+                                                      C.c_void_p(d_ids_ptr or 0), ids_cap, C.c_void_p(d_needed_ptr or 0), C.c_void_p(stream or 0)))
+
     def query_color_rows_dev(self, d_kmers_ptr, n, d_bits_ptr, d_rows_ptr, d_scratch_u32_ptr, stream=None):
         """Device-resident colour rows (bft_gpu_query_color_rows_dev): n x CEIL(nb_genomes/8) bytes at d_rows_ptr, no synchronisation."""
         _lib.check(self._lib.bft_gpu_query_color_rows_dev(self._h, C.c_void_p(d_kmers_ptr), n, C.c_void_p(d_bits_ptr), C.c_void_p(d_rows_ptr),

@@ -16,9 +16,11 @@
 // The arrays are bit-identical to the host restatement bft_index.cpp (tests/test_gpu_build.py).
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
+#include "bft_cs_sig.h"
 #include "bft_dev.h"
 #include "bft_image.h"
 #include "bft_index.h"
@@ -261,6 +263,79 @@ __global__ __launch_bounds__(ABLK) void k_assign_cc(const uint32_t* __restrict__
         if (tid == 0) node_ncc[m] = ncc;
         __syncthreads();
     }
+}
+
+// The same for a level that is ONE node (the root: up to 2^14 Bloom keys, two dozen CCs on a pan-genome index): one workgroup of 1024 threads
+// with the node's keys in LDS -- both hash positions of a key in one word, bit 31 = assigned -- so a CC costs the workgroup LDS passes and ballots
+// instead of two passes of dependent global loads (key_cc -> key_val -> hashmod) by 256 threads.  Same seeds (the first <= 255 unassigned keys
+// in prefix order), same claims, same Bloom bitsets.  (A version with the keys in registers, 16 per thread, spilt 1306 VGPRs at the 128 a
+// 1024-thread workgroup may use and was slower than the kernel it replaced.)
+#define AONE_BLK 1024
+#define AONE_MAXKEYS 16384u
+__global__ __launch_bounds__(AONE_BLK) void k_assign_cc_one(const uint32_t* __restrict__ key_val, const uint32_t* __restrict__ key_cnt,
+                                                            const uint32_t* __restrict__ node_kb, const uint32_t* __restrict__ nd_lo,
+                                                            const uint32_t* __restrict__ nd_hi, const uint32_t* __restrict__ hashmod,
+                                                            int32_t* __restrict__ key_cc, uint32_t* __restrict__ node_ncc,
+                                                            const uint32_t* __restrict__ node_ccb, uint32_t* __restrict__ cc_bits) {
+    extern __shared__ uint32_t hm[];  // AONE_MAXKEYS words
+    __shared__ uint32_t bits[48];
+    __shared__ uint32_t wsum[AONE_BLK / 64];
+    __shared__ uint32_t s_total;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t kb = node_kb[0], ke = node_kb[1], nkeys = ke - kb;
+    for (uint32_t i = tid; i < nkeys; i += AONE_BLK) hm[i] = hashmod[key_val[kb + i]];  // (positions below 1504: bit 31 is free)
+    uint32_t U = nd_hi[0] - nd_lo[0], ncc = 0;
+    __syncthreads();
+    while (U >= BFT_NB_KMERS_PER_UC) {
+        if (tid < 48) bits[tid] = 0;
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+        uint32_t running = 0;
+        for (uint32_t base = 0; base < nkeys && running < BFT_NB_KMERS_PER_UC; base += AONE_BLK) {
+            const uint32_t i = base + tid;
+            const uint32_t v = i < nkeys ? hm[i] : 0x80000000u;
+            const bool un = !(v >> 31);
+            const uint64_t bal = __ballot(un);
+            const uint32_t inwave = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wave] = (uint32_t)__builtin_popcountll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < AONE_BLK / 64; w++) {
+                const uint32_t x = wsum[w];
+                if (w < wave) before += x;
+                total += x;
+            }
+            const uint32_t rank = running + before + inwave;
+            if (un && rank < BFT_NB_KMERS_PER_UC) {
+                const uint32_t h1 = v & 0xFFFFu, h2 = v >> 16;
+                atomicOr(&bits[h1 >> 5], 1u << (h1 & 31));
+                atomicOr(&bits[h2 >> 5], 1u << (h2 & 31));
+            }
+            running += total;
+            __syncthreads();
+        }
+        __syncthreads();
+        uint32_t local = 0;
+        for (uint32_t i = tid; i < nkeys; i += AONE_BLK) {
+            const uint32_t v = hm[i];
+            if (v >> 31) continue;
+            const uint32_t h1 = v & 0xFFFFu, h2 = v >> 16;
+            if (((bits[h1 >> 5] >> (h1 & 31)) & 1u) && ((bits[h2 >> 5] >> (h2 & 31)) & 1u)) {
+                key_cc[kb + i] = (int32_t)ncc;
+                hm[i] = v | 0x80000000u;
+                local += key_cnt[kb + i];  // (read once per key: when it is claimed)
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0 && local) atomicAdd(&s_total, local);
+        __syncthreads();
+        U -= s_total;
+        if (cc_bits && tid < 48) cc_bits[(size_t)(node_ccb[0] + ncc) * 48 + tid] = bits[tid];
+        ncc++;
+        __syncthreads();
+    }
+    if (tid == 0) node_ncc[0] = ncc;
 }
 
 __global__ void k_sort_keys(const uint32_t* __restrict__ pref_node, const uint32_t* __restrict__ pref_key, const int32_t* __restrict__ key_cc,
@@ -567,6 +642,19 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(scan.run(ub.as<uint32_t>(), ubb.as<uint32_t>(), M, nullptr));
         CK(cc_bits.alloc((A / BFT_NB_KMERS_PER_UC + M) * 48 * 4));  // (the sum of the upper bounds is at most that: no count to wait for)
         const dim3 ngrid((unsigned)std::min<uint64_t>(M, 65535ull * 16));
+        if (M == 1 && K <= AONE_MAXKEYS) {  // (one node: its keys in the LDS of one large workgroup)
+            static std::atomic<uint64_t> attr_devs{0};  // the attribute is per device: one bit per device it was set on
+            int dev = 0;
+            HIPCK(hipGetDevice(&dev));
+            const uint64_t dev_bit = 1ull << (dev & 63);
+            if (!(attr_devs.load(std::memory_order_acquire) & dev_bit)) {
+                HIPCK(hipFuncSetAttribute((const void*)k_assign_cc_one, hipFuncAttributeMaxDynamicSharedMemorySize, AONE_MAXKEYS * 4));
+                attr_devs.fetch_or(dev_bit, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(k_assign_cc_one, dim3(1), dim3(AONE_BLK), AONE_MAXKEYS * 4, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
+                               nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
+                               ubb.as<uint32_t>(), cc_bits.as<uint32_t>());
+        } else
         hipLaunchKernelGGL(k_assign_cc, ngrid, dim3(ABLK), 0, s, key_val.as<uint32_t>(), key_cnt.as<uint32_t>(), node_kb.as<uint32_t>(),
                            nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
                            ubb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
@@ -851,10 +939,7 @@ __global__ __launch_bounds__(ABLK) void k_flat_ranks(const BftCCX* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // colour sets
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-    return x;
-}
+// (the signature function itself: bft_cs_sig.h)
 
 // The genome-id lists of the index are bimodal (a k-mer of the shared ancestor sits in most genomes, a k-mer around a SNP in
 // one), so one-thread-per-list loops leave most lanes idle for the length of the longest list of the wavefront.  The lists
@@ -889,11 +974,11 @@ __global__ __launch_bounds__(ABLK) void k_cs_sig(const uint32_t* __restrict__ se
             const uint32_t e = e0 + lane;
             const bool in = e < end;
             const uint32_t s = wave_list_of(in ? e : end - 1, a);
-            if (in) atomicAdd(&acc[w0 + s], (unsigned long long)mix64((uint64_t)pg[e] + 0x632BE59BD9B4E019ULL));
+            if (in) atomicAdd(&acc[w0 + s], (unsigned long long)bft_cs_term(pg[e]));
         }
         if (valid) {
             // (weak: a test hook -- the signature of a list is its length, so that different lists collide and the exact pass must run)
-            sig[i] = weak ? (uint64_t)(b - a) : mix64((uint64_t)acc[threadIdx.x] ^ ((uint64_t)(b - a) * 0x9E3779B97F4A7C15ULL));
+            sig[i] = bft_cs_finish((uint64_t)acc[threadIdx.x], b - a, weak);
             iota[i] = i;
         }
     }
@@ -1199,11 +1284,11 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     }
     Scan scan(s);
     DevBuf sig, iota, bad;
-    CK(sig.alloc(nk * 8));
     CK(iota.alloc(nk * 4));
     CK(bad.alloc(4));
     uint32_t nbad = 0;
     const dim3 grid(bft_grid_for((nk + ABLK - 1) / ABLK)), block(ABLK);
+    CK(sig.alloc(nk * 8));
     hipLaunchKernelGGL(k_cs_sig, grid, block, 0, s, d_seg_off, d_pg, (uint32_t)nk, g_weak_signature ? 1 : 0, sig.as<uint64_t>(), iota.as<uint32_t>());
     bft_stage("colour sets: signatures", (double)np * 4 + (double)nk * (4 + 8 + 4), s);
 

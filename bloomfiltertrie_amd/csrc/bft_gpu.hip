@@ -355,7 +355,10 @@ struct bft_gpu {
     DevBuf sq_codes, sq_bad, sq_npos, sq_poff, sq_tmp, sq_cs, sq_tile;  // scratch of the sequence queries (grown, never shrunk)
     hipStream_t sq_stream = nullptr;
     bool sq_used = false;
-    uint64_t sq_units = 0;  // bound on the blocks of k-mer positions the sequence kernel deals out (claim_counters)
+    uint64_t sq_units = 0;
+    DevBuf qc_cs, qc_tmp;            // scratch of the resident colour-list queries: colour-set id per k-mer, the scan's temporary (grown, never shrunk)
+    hipStream_t qc_stream = nullptr;
+    bool qc_used = false;  // bound on the blocks of k-mer positions the sequence kernel deals out (claim_counters)
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
     bool opt_build_stages = false;      // "build_stages": the next builds record GPU time and bytes per stage (bft_gpu_build_stages)
     struct Stage { std::string name; double ms, bytes; };
@@ -2173,41 +2176,85 @@ static int query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t m, DevBuf& dk, 
     return 0;
 }
 
+// get_annotation + get_list_id_genomes for a resident batch (src/bft.c:363-387, 622-641; src/annotation.c:2086-2250): the k-mer hash hands out
+// the colour-set id of every found k-mer (emit_cs: the same line that answers presence), the lists' lengths are scanned into offsets straight
+// from the dictionary, and the wavefronts stream the ids out.  No row, no sorted table ("compact_table" stays), no host round trip.
+static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
+                       hipStream_t s, bool fill) {
+    if (h->qc_used && h->qc_stream != s) HIPCK(hipStreamSynchronize(h->qc_stream));  // (the scratch belongs to the handle: one stream at a time)
+    const BftCsLen probe{nullptr, nullptr, 0};
+    auto it0 = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0ull), probe);
+    size_t tb = 0;
+    HIPCK(rocprim::exclusive_scan(nullptr, tb, it0, d_offsets, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s));
+    if (h->qc_cs.bytes < n * 4 || h->qc_tmp.bytes < tb) {
+        if (h->qc_used) HIPCK(hipStreamSynchronize(s));
+        if (h->qc_cs.bytes < n * 4) CK(h->qc_cs.alloc(n * 4 + n / 2));
+        if (h->qc_tmp.bytes < tb) CK(h->qc_tmp.alloc(tb + tb / 2));
+    }
+    h->qc_used = true;
+    h->qc_stream = s;
+    uint32_t* d_cs = h->qc_cs.as<uint32_t>();
+    {   // (the k-mer hash has the colour set in the line that answers presence; the walk, on an image without the table, takes it from tcol[row])
+        h->im.emit_cs = 1;
+        const int rc = launch_query(h, d_kmers, n, d_bits64, d_cs, s);
+        h->im.emit_cs = 0;
+        CK(rc);
+    }
+    const BftCsLen len{d_cs, h->im.cs_off, n};
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0ull), len);
+    size_t tb2 = h->qc_tmp.bytes;
+    HIPCK(rocprim::exclusive_scan(h->qc_tmp.p, tb2, it, d_offsets, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s));
+    if (fill) {
+        hipLaunchKernelGGL(k_color_fill_cs, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_cs, h->im.cs_off, h->im.cs_ids, h->im.cs_w, d_offsets, n, ids_cap, d_ids, d_needed);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int bft_gpu_query_colors_dev(bft_gpu* h, const void* d_kmers, uint64_t n, void* d_present_bits, void* d_offsets, void* d_ids, uint64_t ids_cap,
+                                        void* d_ids_needed, void* hip_stream) {
+    if (!h || !d_offsets || ((!d_kmers || !d_present_bits) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
+    ENTER(h);
+    CK(ensure_built(h, false));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    if (n == 0) {
+        HIPCK(hipMemsetAsync(d_offsets, 0, 8, s));
+        if (d_ids_needed) HIPCK(hipMemsetAsync(d_ids_needed, 0, 8, s));
+        return note_foreign_stream(h, s);
+    }
+    CK(colors_core(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint64_t*)d_offsets, (uint32_t*)d_ids, ids_cap, (uint64_t*)d_ids_needed, s, true));
+    return note_foreign_stream(h, s);
+}
+
+// The host-buffer form: the resident one on staged chunks.
 extern "C" int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint64_t* offsets,
                                     uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed) {
     if (!h || !offsets || ((!kmers) && n)) return fail(BFT_GPU_E_ARG, "NULL argument");
     ENTER(h);
-    CK(ensure_built(h));
+    CK(ensure_built(h, false));
     const uint64_t chunk = 1ull << 24;
     const uint64_t mc = std::min(n, chunk);
-    DevBuf dk, db, dr, dcnt, doff, dids, tmp;
+    DevBuf dk, db, doff, dids;
     CK(dk.alloc(mc * h->B));
     CK(db.alloc(((mc + 63) / 64) * 8));
-    CK(dr.alloc(mc * 4));
-    CK(dcnt.alloc((mc + 1) * 8));
     CK(doff.alloc((mc + 1) * 8));
-    size_t tb = 0;
-    HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dcnt.as<uint64_t>(), doff.as<uint64_t>(), (int)(mc + 1), h->stream));
-    CK(tmp.alloc(tb));
     uint64_t total = 0;
     bool overflow = false;
     for (uint64_t a = 0; a < n; a += chunk) {
         const uint64_t m = std::min(chunk, n - a);
-        CK(query_rows(h, kmers + a * h->B, m, dk, db, dr, present_bits ? present_bits + a / 8 : nullptr));
-        const int grid = grid_for((m + 255) / 256);
-        hipLaunchKernelGGL(k_color_counts, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, m, dcnt.as<uint64_t>());
-        HIPCK(hipMemsetAsync(dcnt.as<uint64_t>() + m, 0, 8, h->stream));
-        size_t tb2 = tmp.bytes;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, dcnt.as<uint64_t>(), doff.as<uint64_t>(), (int)(m + 1), h->stream));
+        HIPCK(hipMemcpyAsync(dk.p, kmers + a * h->B, m * h->B, hipMemcpyHostToDevice, h->stream));
+        CK(colors_core(h, dk.as<uint8_t>(), m, db.as<uint64_t>(), doff.as<uint64_t>(), nullptr, 0, nullptr, h->stream, false));
+        if (present_bits) HIPCK(hipMemcpyAsync(present_bits + a / 8, db.p, (m + 7) / 8, hipMemcpyDeviceToHost, h->stream));
         HIPCK(hipMemcpyAsync(offsets + a, doff.p, (m + 1) * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
         const uint64_t cnt = offsets[a + m];
-        for (uint64_t i = 0; i <= m; i++) offsets[a + i] += total;  // chunk-local -> global
+        if (total)
+            for (uint64_t i = 0; i <= m; i++) offsets[a + i] += total;  // chunk-local -> global
         if (!overflow && ids && total + cnt <= ids_cap) {
             if (cnt) {
                 CK(dids.alloc(cnt * 4));
-                hipLaunchKernelGGL(k_color_fill, dim3(grid), dim3(256), 0, h->stream, dr.as<uint32_t>(), h->im.tcol, h->im.cs_off, h->im.cs_ids, h->im.cs_w,
-                                   doff.as<uint64_t>(), m, dids.as<uint32_t>());
+                hipLaunchKernelGGL(k_color_fill_cs, dim3(grid_for((m + 255) / 256)), dim3(256), 0, h->stream, h->qc_cs.as<uint32_t>(), h->im.cs_off, h->im.cs_ids, h->im.cs_w,
+                                   doff.as<uint64_t>(), m, cnt, dids.as<uint32_t>(), (uint64_t*)nullptr);
                 HIPCK(hipMemcpyAsync(ids + total, dids.p, cnt * 4, hipMemcpyDeviceToHost, h->stream));
                 HIPCK(hipStreamSynchronize(h->stream));
             }

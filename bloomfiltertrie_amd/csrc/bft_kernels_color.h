@@ -28,6 +28,54 @@ __global__ void k_color_fill(const uint32_t* __restrict__ rows, const uint32_t* 
     }
 }
 
+// ---- id lists out of colour-set ids (what the k-mer hash hands out with emit_cs: no row, no sorted table) ----
+// length of k-mer i's id list as the input "iterator" of the offsets' scan (entry n: 0, so that offsets[n] = the total)
+struct BftCsLen {
+    const uint32_t* cs;  // colour-set id per k-mer, BFT_ABSENT_ROW for an absent one
+    const uint32_t* cs_off;
+    uint64_t n;
+    __host__ __device__ uint64_t operator()(uint64_t i) const {
+        if (i >= n) return 0;
+        const uint32_t c = cs[i];
+        return c == BFT_ABSENT_ROW ? 0ull : (uint64_t)(cs_off[c + 1] - cs_off[c]);
+    }
+};
+// The lists of 64 consecutive k-mers are one contiguous range of `ids`: the wavefront streams that range -- every output element finds its k-mer
+// by a search over the lanes' start offsets (6 shuffles) and copies its id out of the dictionary: coalesced stores, whatever the lists' lengths.
+// offsets[n] beyond ids_cap: nothing is written (the caller reads *needed).
+__global__ __launch_bounds__(256) void k_color_fill_cs(const uint32_t* __restrict__ cs, const uint32_t* __restrict__ cs_off, const void* __restrict__ cs_ids, uint32_t cs_w,
+                                                        const uint64_t* __restrict__ offsets, uint64_t n, uint64_t ids_cap, uint32_t* __restrict__ ids,
+                                                        uint64_t* __restrict__ needed) {
+    const uint64_t total = offsets[n];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && needed) *needed = total;
+    if (total > ids_cap || !ids) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nblk = (n + 255) / 256;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const uint64_t i = blk * 256 + threadIdx.x;
+        const bool valid = i < n;
+        const uint64_t a = offsets[valid ? i : n], b = offsets[valid ? i + 1 : n];
+        uint32_t src = 0;
+        if (valid && b > a) src = cs_off[cs[i]];
+        const uint64_t base = __shfl(a, 0), end = __shfl(b, 63);
+        for (uint64_t e0 = base; e0 < end; e0 += 64) {
+            const uint64_t e = e0 + lane;
+            const bool in = e < end;
+            const uint64_t ee = in ? e : end - 1;
+            uint32_t lo = 0, hi = 63;  // the last lane whose list starts at or before ee (starts are non-decreasing over the lanes)
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                const uint64_t am = __shfl(a, mid);
+                if (am <= ee) lo = mid; else hi = mid - 1;
+            }
+            const uint64_t as = __shfl(a, lo);
+            const uint32_t ss = __shfl(src, lo);
+            if (in) ids[e] = bft_cs_id_at(cs_ids, cs_w, ss + (uint32_t)(e - as));
+        }
+    }
+}
+
 // colour-set dictionary as bitmaps, built once per image: one row per set, CEIL(G/8) bytes padded to a multiple of 4
 // (`stride`) so that the row kernel reads it with aligned dword loads
 __global__ void k_cs_bitmaps(const uint32_t* __restrict__ cs_off, const void* __restrict__ cs_ids, uint32_t cs_w, uint64_t n_sets, uint32_t stride,

@@ -98,6 +98,15 @@ int bft_gpu_query_presence_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmer
  * BFT_GPU_E_NOSPACE is returned. */
 int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
                          uint64_t* offsets, uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed);
+/* The same on a RESIDENT batch, without synchronisation (runs on hip_stream; NULL = the handle's stream): d_present_bits as in
+ * bft_gpu_query_presence_dev, d_offsets = nb_kmers + 1 uint64 (offsets[nb_kmers] = the number of ids), d_ids = room for ids_cap uint32; *d_ids_needed
+ * (device, may be NULL) receives the number of ids -- when it exceeds ids_cap NOTHING is written to d_ids (offsets and bits are complete): size
+ * the buffer and call again, or pass d_ids = NULL / ids_cap = 0 first to learn the size.  The colour set of every found k-mer comes out of the line
+ * of the k-mer hash that answers presence (no row, no sorted table: "compact_table" stays in force), the lists' lengths are scanned into the
+ * offsets straight from the dictionary, and the ids are streamed out wavefront by wavefront.  Scratch (4 bytes per k-mer) belongs to the
+ * handle: calls of one handle on different streams are serialised by the library. */
+int bft_gpu_query_colors_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_present_bits, void* d_offsets, void* d_ids, uint64_t ids_cap,
+                             void* d_ids_needed, void* hip_stream);
 /* Fixed-width variant = the CSV row of src/file_io.c:744-765 before formatting: row i is
  * CEIL(nb_genomes/8) bytes, genome g -> bit g%8 of byte g/8 (all zero for absent k-mers). */
 int bft_gpu_query_color_rows(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, uint8_t* present_bits,
@@ -211,7 +220,8 @@ int bft_gpu_kernel_time(bft_gpu* h, double* ms, uint64_t* launches, int reset);
  * tuned), ms[8]=rows per suffix-group probe in use (4 or 8), ms[9]=lines of the k-mer hash (0 = none), ms[10]=GPU time of its fill, ms[11]=largest root-prefix bucket of the last sort (0: one device-wide sort),
  * ms[12]=times the colour-set interning had to compare lists (signature collisions), ms[13]=ms this process has spent in hipMalloc so far,
  * ms[14]=root tables in use (0 / 1 / 2, see "root_direct"), ms[15..16]="tune": time with the direct table alone / with the range table, ms[17]=keys in the
- * node prefix hash, ms[18]=keys it dropped (full bucket: those lookups take the container path), ms[19]="tune": time with residency 3. */
+ * node prefix hash, ms[18]=keys it dropped (full bucket: those lookups take the container path), ms[19]="tune": time with residency 3,
+ * ms[20]=query launches that wanted a claim counter and ran static, ms[21..24]=k-mer hash: slots per line, displacement bits, largest displacement, overflow list. */
 int bft_gpu_build_time(bft_gpu* h, double* ms, int n_out);
 /* The last bft_gpu_build stage by stage, when bft_gpu_set_option(h, "build_stages", 1) was set before it: names = the stage names, one per
  * line (NUL-terminated; names_cap bytes), ms[i] = GPU time of stage i (HIP events on the build's stream: the time the stream spent between the end

@@ -727,3 +727,4 @@ def test_a_bucket_beyond_the_capacity_falls_back_to_the_device_wide_sort(k, gids
     for name in ARRAYS:
         assert (a[0][name] == b[0][name]).all(), name
     assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
+

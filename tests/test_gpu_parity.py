@@ -713,6 +713,12 @@ def test_device_group_answers_like_one_handle(k, devices):
         t.insert_kmers(km, g)
     grp = BFTGroup(t, devices)
     assert grp.size() == len(devices)
+    # "compact_table" (the default) holds for every member, the source included: the sorted table that travelled in the blob, and the one the
+    # source brought back to pack it, are not resident once the group exists (small host batches and rows bring a member's table back later)
+    for i in range(grp.size()):
+        fp = grp.member_footprint(i)
+        assert fp["kmer_hash"] > 0 and fp["kmer_table"] <= 8 and fp["colorset_per_kmer"] <= 8, (i, fp)
+    assert t.footprint()["kmer_table"] <= 8
     allk = S.distinct(np.concatenate(gk))
     rng = np.random.default_rng(k)
     base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])
@@ -726,12 +732,6 @@ def test_device_group_answers_like_one_handle(k, devices):
         b2, c2 = t.query_branching(q[:50_000], with_counts=True)
         assert (b1 == b2).all() and (c1 == c2).all(), n
     assert (S.from_bits(grp.query_presence(base), len(base)) == S.member(base, allk)).all()
-    # "compact_table" (the default) holds for every member, the source included: the sorted table that travelled in the blob, and the one the
-    # source brought back to pack it, are not resident once the group exists; rows bring a member's table back, the next presence call not
-    for i in range(grp.size()):
-        fp = grp.member_footprint(i)
-        assert fp["kmer_hash"] > 0 and fp["kmer_table"] <= 8 and fp["colorset_per_kmer"] <= 8, (i, fp)
-    assert t.footprint()["kmer_table"] <= 8
     grp.close()
     with pytest.raises(Exception):
         BFTGroup(t, [99])
@@ -869,4 +869,56 @@ def test_more_streams_than_claim_slots():
                 assert (S.from_bits(ref[: (nq + 7) // 8], nq) == S.member(q, km)).all()
             assert (got == ref).all()
     assert t.build_time()["claims_static_launches"] == 0
+    t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,ngen", [(27, 12), (63, 300), (18, 3)])
+def test_resident_id_lists_through_the_kmer_hash(k, ngen):
+    """bft_gpu_query_colors_dev: get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641) on a resident batch -- offsets and ids in HBM equal
+    the oracle's lists; the sorted table is NOT brought back ("compact_table": the hash line holds the colour set), a buffer that is too small gets
+    nothing but the count, and the same call answers through the container walk (kmer_hash 0)."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    from oracle import oracle as O
+    anc = S.random_genome(40000, k + ngen)
+    t, o = BFT(k), O.OracleBFT(k)
+    rng = np.random.default_rng(k)
+    base = S.distinct(S.kmers_of(anc, k))
+    for g in range(ngen):
+        km = np.ascontiguousarray(base[rng.random(len(base)) < (0.9 if g % 7 == 0 else 0.05)])
+        t.insert_kmers(km, g)
+        o.insert_kmers(km, g)
+    t.build()
+    allk, _ = o.extract()
+    q = np.concatenate([allk[::3], S.snp_mutants(allk[::5], k, 1)])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    obits, ooff, oids = o.query_colors(q)
+    n = len(q)
+    dq = torch.from_numpy(q).cuda()
+    for form in ("kmer_hash", "walk"):
+        if form == "walk":
+            t.set_option("kmer_hash", 0)
+        else:
+            assert t.footprint()["kmer_table"] <= 8
+        bits = torch.zeros(((n + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
+        off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+        need = torch.zeros(1, dtype=torch.int64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        small = torch.full((16,), -1, dtype=torch.int32, device="cuda")
+        t.query_colors_dev(dq.data_ptr(), n, bits.data_ptr(), off.data_ptr(), small.data_ptr(), 16, need.data_ptr(), stream)  # too small: only the count
+        torch.cuda.synchronize()
+        total = int(need.item())
+        assert total == len(oids) and total > 16 and (small == -1).all()
+        ids = torch.zeros(total, dtype=torch.int32, device="cuda")
+        t.query_colors_dev(dq.data_ptr(), n, bits.data_ptr(), off.data_ptr(), ids.data_ptr(), total, need.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert (bits.cpu().numpy()[: (n + 7) // 8] == obits).all(), form
+        assert (off.cpu().numpy().astype(np.uint64) == ooff).all(), form
+        assert (ids.cpu().numpy().astype(np.uint32) == oids).all(), form
+        if form == "kmer_hash":
+            assert t.footprint()["kmer_table"] <= 8  # (the resident call never needs the sorted table)
+            hb, hoff, hids = t.query_colors(q)  # the host entry point is the same path on staged chunks
+            assert (hb == obits).all() and (hoff == ooff).all() and (hids == oids).all()
+            assert t.footprint()["kmer_table"] <= 8
     t.close()
