@@ -1272,7 +1272,7 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
 // one signature -- sends the build through the sorted path, where runs of equal lists are found by comparing the lists themselves.
 // Two different sets can therefore never share an id, and two equal sets always do.
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
-                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint) {
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint, BftInternTail* tail, bool exact) {
     n_sets = 0;
     n_ids = 0;
     CK(d_tcol.alloc(nk * 4));
@@ -1295,7 +1295,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     // ---- by a hash of the signatures (kernels above).  The table starts at nk / 8 slots (a pan-genome has far fewer distinct lists than
     // k-mers) and is retried at 2 nk when more than half of it fills: then every list may be distinct. ----
     bool done = false;
-    {
+    if (!exact) {
         DevBuf tab, slot_of, cnt, keys, keys_s, slots, slots_s, rep, len, tmp;
         CK(slot_of.alloc(nk * 4));
         CK(cnt.alloc(3 * 4));
@@ -1337,6 +1337,25 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
             CK(scan.wait());
             n_ids = scan.get(0);
             CK(d_cs_ids.alloc(n_ids * 4));
+            if (tail && tail->side && tail->pin.p &&
+                (tail->done || hipEventCreateWithFlags(&tail->done, hipEventDisableTiming) == hipSuccess) &&
+                (tail->ready || hipEventCreateWithFlags(&tail->ready, hipEventDisableTiming) == hipSuccess)) {
+                // the copy and the verification on the side stream, behind everything enqueued so far; the caller collects the verdict later
+                hipStream_t t2 = tail->side;
+                tail->rep.swap(rep);
+                CK(tail->bad.alloc_zero(4, s));
+                HIPCK(hipEventRecord(tail->ready, s));
+                HIPCK(hipStreamWaitEvent(t2, tail->ready, 0));
+                hipLaunchKernelGGL(k_cs_hash_copy, sgrid, block, 0, t2, tail->rep.as<uint32_t>(), d_cs_off.as<uint32_t>(), (uint32_t)n_sets, d_seg_off, d_pg, d_cs_ids.as<uint32_t>());
+                hipLaunchKernelGGL(k_cs_verify, grid, block, 0, t2, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
+                                   tail->bad.as<uint32_t>());
+                hipLaunchKernelGGL(k_publish, dim3(1), dim3(PIN_SLOTS), 0, t2, tail->bad.as<uint32_t>(), 1, tail->pin.p);
+                HIPCK(hipGetLastError());
+                HIPCK(hipEventRecord(tail->done, t2));
+                bft_stage("+colour sets: dictionary copied, every list verified (side stream)", (double)n_ids * 8 + (double)n_sets * 12 + (double)np * 8 + (double)nk * 12, t2);
+                tail->pending = true;
+                return 0;  // (tab, slot_of ... go back to the cache under this stream's tag: what reads them was enqueued on s before this point)
+            }
             hipLaunchKernelGGL(k_cs_hash_copy, sgrid, block, 0, s, rep.as<uint32_t>(), d_cs_off.as<uint32_t>(), (uint32_t)n_sets, d_seg_off, d_pg, d_cs_ids.as<uint32_t>());
             bft_stage("colour sets: dictionary copied", (double)n_ids * 8 + (double)n_sets * 12, s);
             HIPCK(hipMemsetAsync(bad.p, 0, 4, s));

@@ -130,8 +130,34 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
                     hipStream_t s, DevBuf& ccx, DevBuf& f18, DevBuf& fent, uint64_t& n_f18, uint64_t& n_fent);
 void bft_test_weak_signature(bool on);            // test hook: every list's signature = its length (collisions galore)
 unsigned long long bft_test_exact_passes(void);   // how many times the interning had to fall back to comparing the lists
+// The interning's tail -- the dictionary entries copied out of their representatives' lists, then EVERY k-mer's list compared with the entry it was
+// given -- is a third of its time (1.2 of 3.4 ms on config 3) and nothing of the build needs its result before the commit: with `side` set it is
+// enqueued on that stream (behind the interning's kernels) and bft_intern_colors_gpu returns at once; the caller keeps d_seg_off / d_pg alive, makes
+// whatever reads the dictionary wait for `done`, and calls wait() before it commits -- *collisions != 0: two different lists shared a signature and
+// the interning must be run again with exact = true (lists compared; on the caller's stream, nothing deferred).
+struct BftInternTail {
+    hipStream_t side = nullptr;
+    hipEvent_t done = nullptr, ready = nullptr;
+    bool pending = false;
+    DevBuf rep, bad;  // (what the deferred kernels read and write besides the outputs)
+    PinBlock pin;
+    ~BftInternTail() {
+        if (pending && side) (void)hipStreamSynchronize(side);
+        if (done) (void)hipEventDestroy(done);
+        if (ready) (void)hipEventDestroy(ready);
+    }
+    int wait(uint32_t* collisions) {
+        *collisions = 0;
+        if (!pending) return 0;
+        HIPCK(hipEventSynchronize(done));
+        pending = false;
+        *collisions = (uint32_t)pin.p[0];
+        return 0;
+    }
+};
 int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint64_t nk, uint64_t np, hipStream_t s, DevBuf& d_tcol,
-                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint = 0);
+                          DevBuf& d_cs_off, DevBuf& d_cs_ids, uint64_t& n_sets, uint64_t& n_ids, uint64_t distinct_hint = 0, BftInternTail* tail = nullptr,
+                          bool exact = false);
 
 // Merging a sorted run of newly inserted k-mers into the built index (bft_merge.hip).  A "run" = sorted distinct T-form k-mers, a
 // colour-set id per k-mer and the dictionary those ids refer to -- what the index itself is made of.

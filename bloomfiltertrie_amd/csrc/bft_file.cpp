@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -28,6 +29,18 @@
 #include "bft_walk.h"
 
 namespace {
+
+// BFT_GPU_TRACE_IO=1: where the writer and the loader spend their time (stderr)
+struct IoTrace {
+    bool on = getenv("BFT_GPU_TRACE_IO") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bft_gpu io] %8.1f ms (+%.1f) %s\n", std::chrono::duration<double, std::milli>(t - t0).count(), std::chrono::duration<double, std::milli>(t - last).count(), what);
+        last = t;
+    }
+};
 
 // How many host threads the writer and the loader use: BFT_GPU_IO_THREADS, else the hardware's (at most 32; a container's CPU quota may grant
 // fewer cores than it shows -- oversubscribing them costs little here).
@@ -467,6 +480,7 @@ struct Reader {
 }  // namespace
 
 bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
+    IoTrace tr;
     out = BftFileContent();
     Reader R;
     {
@@ -514,8 +528,10 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
     R.k = out.k;
     R.out = &out;
     PNode root;
+    tr.mark("load: file read");
     if (!R.err) R.parse_node(root, out.k);
     if (R.err) { err = R.msg; return false; }
+    tr.mark("load: container tree parsed (rows left in place)");
     // second pass: the root's UC on this thread, the 128-prefix blocks of its CCs over the pool
     const unsigned nt = io_threads();
     std::vector<Emitter> em(nt);
@@ -541,6 +557,7 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
         });
     for (const Emitter& e : em)
         if (e.err) { err = e.msg; return false; }
+    tr.mark("load: k-mers and genome ids rebuilt");
     // the threads' outputs, genome by genome (the order of a genome's k-mers does not matter: insertKmers takes a set)
     out.per_genome.assign((size_t)nbg, std::vector<uint8_t>());
     for (const Emitter& e : em) out.n_kmers += e.n_kmers;
@@ -555,6 +572,7 @@ bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
                 std::vector<uint8_t>().swap(e.per_genome[g]);
             }
     });
+    tr.mark("load: per-genome batches gathered");
     return true;
 }
 
@@ -821,8 +839,10 @@ struct Writer {
 void bft_annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) { annot_encode(ids, n, out); }
 
 bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) {
+    IoTrace tr;
     AnnotCache ann;
     ann.build(im);
+    tr.mark("write: annotations of the colour sets encoded");
     Parts parts;
     Writer w(im, ann);
     w.par = &parts;
@@ -847,24 +867,60 @@ bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) 
     }
     w.write_node(0, 0, 0);
     if (w.err) { err = "inconsistent image"; return false; }
+    tr.mark("write: the root's CCs walked (headers, filters; blocks and child Nodes deferred)");
     // the deferred parts: UC blocks and child-Node subtrees of the root's CCs, every thread with a Writer of its own
+    // The pool fills the deferred parts (jobs are taken in file order); this thread streams the parts to the file in order as they complete --
+    // the file's pages are written by ONE stream (tmpfs and most file systems serialise page allocation: 32 threads writing side by side
+    // took longer than one) while the others still fill what comes behind.
     const unsigned nt = io_threads();
     std::vector<std::unique_ptr<Writer>> ws;
     for (unsigned t = 0; t < nt; t++) ws.emplace_back(new Writer(im, ann));
     std::atomic<bool> bad{false};
-    parallel_jobs(parts.jobs.size(), [&](size_t j, unsigned t) {
+    const size_t nparts = parts.bufs.size(), njobs = parts.jobs.size();
+    std::unique_ptr<std::atomic<uint8_t>[]> ready(new std::atomic<uint8_t>[nparts]);
+    for (size_t i = 0; i < nparts; i++) ready[i].store(1);
+    for (size_t j = 0; j < njobs; j++) ready[parts.job_buf[j]].store(0);
+    std::atomic<size_t> next{0};
+    auto work = [&](unsigned t) {
         Writer& x = *ws[t];
-        x.out = &parts.bufs[parts.job_buf[j]];
-        parts.jobs[j](x);
-        if (x.err) bad = true;
-    });
-    if (bad) { err = "inconsistent image"; return false; }
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= njobs) break;
+            x.out = &parts.bufs[parts.job_buf[j]];
+            parts.jobs[j](x);
+            if (x.err) bad = true;
+            ready[parts.job_buf[j]].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) {
+        try { th.emplace_back(work, t); } catch (...) { break; }
+    }
     FILE* f = fopen(path, "wb");
+    bool ok = f != nullptr;
+    if (th.empty()) work(0);  // (no thread to be had: fill first, then write)
+    for (size_t i = 0; i < nparts && ok; i++) {
+        while (!ready[i].load(std::memory_order_acquire)) {
+            // (help with a job instead of spinning, if any is left)
+            const size_t j = next.fetch_add(1);
+            if (j < njobs) {
+                Writer& x = *ws[0];
+                x.out = &parts.bufs[parts.job_buf[j]];
+                parts.jobs[j](x);
+                if (x.err) bad = true;
+                ready[parts.job_buf[j]].store(1, std::memory_order_release);
+            } else
+                std::this_thread::yield();
+        }
+        std::vector<uint8_t>& b = parts.bufs[i];
+        if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
+        std::vector<uint8_t>().swap(b);  // (written: its memory goes back while the rest is still being filled)
+    }
+    for (std::thread& x : th) x.join();
+    if (f && fclose(f) != 0) ok = false;
+    tr.mark("write: parts filled by the pool and streamed to the file in order");
     if (!f) { err = std::string("cannot create ") + path; return false; }
-    bool ok = true;
-    for (const std::vector<uint8_t>& b : parts.bufs)
-        if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) { ok = false; break; }
-    if (fclose(f) != 0) ok = false;
+    if (bad) { err = "inconsistent image"; return false; }
     if (!ok) { err = "write error"; return false; }
     return true;
 }

@@ -2,7 +2,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bft_image.h"
@@ -15,13 +17,27 @@ struct BftFileContent {  // what a .bft holds, as the GPU build wants it
 };
 bool bft_file_read(const char* path, BftFileContent& out, std::string& err);
 
+// a vector whose resize() leaves trivially constructible elements uninitialised: the big arrays of the host image are filled by a copy from
+// the device right away, and zeroing a gigabyte first is a page fault per 4 KB for nothing
+template <class T>
+struct BftDefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = BftDefaultInit<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T>
+using BftBigVec = std::vector<T, BftDefaultInit<T>>;
+
 struct BftHostImage {  // host copy of the device image, for serialisation
     int k = 0, r1 = 0, r2 = 0;
     std::vector<std::string> genomes;
     std::vector<BftNode> nodes;
     std::vector<BftCC> ccs;
-    std::vector<uint64_t> f2w, clus, child, tk;
-    std::vector<uint32_t> ucrow, tcol, cs_off, cs_ids;
+    std::vector<uint64_t> f2w, clus, child;
+    std::vector<uint32_t> ucrow, cs_off;
+    BftBigVec<uint64_t> tk;            // sorted T-form k-mers
+    BftBigVec<uint32_t> tcol, cs_ids;  // colour set per k-mer; the dictionary's genome ids
 };
 bool bft_file_write(const char* path, const BftHostImage& im, std::string& err);
 

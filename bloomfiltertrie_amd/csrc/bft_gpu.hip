@@ -1581,16 +1581,28 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     DevBuf n_tcol, n_cs_off, n_cs_ids;  // built aside, like every array of the new image
     KhFill khf;  // the k-mer hash, filled beside the container assembly
+    if (!h->stream2 && nk > 0) {  // (the second stream, made here: the helper thread below and the interning's tail both use it)
+        int lo = 0, hi = 0;  // (numerically larger = lower priority)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); }
+    }
     if (!(h->built && h->n_kmers > 0) && nk > 0) {  // (a merge changes the k-mers: kh_start does everything then)
         // (the table's sort by home line started HERE, beside the colour-set interning, was measured: the interning's persistent grids and the
         // sort starve each other -- 4.1 -> 10.5 ms for the interning, 20 -> 25.8 ms for the build; it starts behind the assembly's table passes)
         kh_prepare_async(h, nk, nk, khf);
     }
-    CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids));
+    // (the interning's tail -- dictionary copy + verification of every list -- goes to the second stream, idle until the k-mer hash build starts
+    // behind the first level's table passes; its verdict is collected before the commit.  A merge reads the dictionary at once: not deferred.)
+    const bool merging = h->built && h->n_kmers > 0 && nk > 0;
+    BftInternTail tail;
+    tail.side = merging ? nullptr : h->stream2;
+    CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids, 0, &tail));
     bft_trace_mark("colour sets interned");
     bft_stage("colour sets (rest)", 0, h->stream);
-    seg_off.release();
-    npg.release();
+    if (!tail.pending) {
+        seg_off.release();
+        npg.release();
+    }
     // 4b. an index exists already: the run is merged into it (bft_merge.hip) -- k-mers by position, colour sets by union
     uint64_t total_pairs = np;
     if (h->built && h->n_kmers > 0 && nk > 0) {
@@ -1634,6 +1646,20 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                        n_ccx, n_f18buf, n_fentbuf, n_f18, n_fent));
     bft_trace_mark("flat forms");
     bft_stage("flat forms of the big CCs", (double)(n_f18 + n_fent) * 8, h->stream);
+    bool kh_redo = false;
+    {   // the interning's deferred tail: done long ago; two lists with one signature (never seen outside the test hook) -> the exact interning
+        uint32_t collisions = 0;
+        CK(tail.wait(&collisions));
+        if (collisions) {
+            double ms_ = 0;
+            (void)kh_finish(h, khf, &ms_);  // (the table under construction holds the wrong colour sets, and reads the arrays replaced below)
+            khf.buf.release();
+            kh_redo = true;
+            CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids, 0, nullptr, true));
+        }
+        seg_off.release();
+        npg.release();
+    }
     const uint32_t new_cs_w = id_width(h->max_gid_seen);
     DevBuf n_cs_ids_w;
     CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
@@ -1641,7 +1667,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     bft_trace_mark("ids narrowed, foreign stream waited");
     bft_stage("dictionary ids narrowed", (double)n_ids * (4 + new_cs_w), h->stream);
     double kh_ms = 0;
-    const bool kh_ok = kh_finish(h, khf, &kh_ms);
+    const bool kh_ok = !kh_redo && kh_finish(h, khf, &kh_ms);
     bft_trace_mark("k-mer hash fill waited");
     bft_stage("wait for the k-mer hash build", 0, h->stream);
     if (h->inject_build_failure) {
@@ -1714,6 +1740,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     derive_root_direct(h);
     if (kh_ok) kh_adopt(h, khf, kh_ms);  // built during the assembly
     else kh_drop(h);
+    if (kh_redo) derive_kmer_hash(h);  // (after the exact interning: from the committed table and colour sets)
     sync_walk_kh(h);
     bft_trace_mark("root tables");
     bft_stage("root tables", 0, h->stream);
@@ -2553,6 +2580,14 @@ extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
     int rc = 0;
     for (const std::string& g : fc.genomes) h->genomes.push_back(g);
     const size_t B = (size_t)h->B;
+    {   // the log for every pair of the file at once (it would otherwise grow by doubling: a copy and a synchronisation per step)
+        uint64_t pairs = 0;
+        for (const auto& v : fc.per_genome) pairs += v.size() / B;
+        if (pairs && pairs <= h->opt_flush_pairs && hipSetDevice(device) == hipSuccess) {
+            bft_pool_set_stream(device, h->stream);
+            (void)log_reserve(h, pairs);  // (a failure here only means the log grows as usual)
+        }
+    }
     for (size_t g = 0; g < fc.per_genome.size() && rc == 0; g++)
         if (!fc.per_genome[g].empty()) rc = bft_gpu_insert_kmers(h, fc.per_genome[g].data(), fc.per_genome[g].size() / B, (uint32_t)g);
     if (rc == 0) rc = bft_gpu_build(h);
@@ -2565,9 +2600,9 @@ extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
     return BFT_GPU_OK;
 }
 
-template <class T>
-static int download(const DevBuf& d, uint64_t bytes, std::vector<T>& v) {
-    v.assign(bytes / sizeof(T), T());
+template <class T, class A>
+static int download(const DevBuf& d, uint64_t bytes, std::vector<T, A>& v) {
+    v.resize(bytes / sizeof(T));
     if (bytes) HIPCK(hipMemcpy(v.data(), d.p, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2576,7 +2611,10 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     if (!h || !path) return fail(BFT_GPU_E_ARG, "NULL argument");
     if (!bft_reference_k(h->k)) return fail(BFT_GPU_E_ARG, "the .bft format requires k % 9 == 0 (reference src/main.c:61-63)");
     ENTER(h);
+    static const bool io_trace = getenv("BFT_GPU_TRACE_IO") != nullptr;
+    const double t_io0 = now_ms();
     CK(ensure_built(h));
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms write: index built, sorted table resident\n", now_ms() - t_io0);
     BftHostImage hi;
     hi.k = h->k;
     hi.r1 = h->r1;
@@ -2591,9 +2629,34 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     CK(download(h->d_ucrow, h->idx_sizes[7], hi.ucrow));
     CK(download(h->d_tk, h->idx_sizes[8], hi.tk));
     CK(download(h->d_tcol, h->n_kmers * 4, hi.tcol));
-    CK(host_colorsets(h));
-    hi.cs_off = h->cs_off;
-    hi.cs_ids = h->cs_ids;
+    {   // the dictionary: offsets as they are, the ids widened to 32 bits (resident in 1, 2 or 4 bytes) by a few host threads
+        CK(download(h->d_cs_off, (h->n_sets + 1) * 4, hi.cs_off));
+        hi.cs_ids.resize(h->n_ids);
+        if (h->cs_w == 4) {
+            if (h->n_ids) HIPCK(hipMemcpy(hi.cs_ids.data(), h->d_cs_ids.p, h->n_ids * 4, hipMemcpyDeviceToHost));
+        } else if (h->n_ids) {
+            BftBigVec<uint8_t> raw;
+            raw.resize(h->n_ids * h->cs_w);
+            HIPCK(hipMemcpy(raw.data(), h->d_cs_ids.p, raw.size(), hipMemcpyDeviceToHost));
+            const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            const uint64_t per = (h->n_ids + nt - 1) / nt;
+            const uint32_t w = h->cs_w;
+            uint32_t* dst = hi.cs_ids.data();
+            auto widen = [&raw, dst, w](uint64_t a, uint64_t b) {
+                if (w == 1) for (uint64_t i = a; i < b; i++) dst[i] = raw[i];
+                else { const uint16_t* r16 = (const uint16_t*)raw.data(); for (uint64_t i = a; i < b; i++) dst[i] = r16[i]; }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) {
+                const uint64_t a = std::min<uint64_t>(h->n_ids, t * per), b = std::min<uint64_t>(h->n_ids, a + per);
+                if (a >= b) break;
+                try { th.emplace_back(widen, a, b); } catch (...) { widen(a, b); }
+            }
+            widen(0, std::min<uint64_t>(h->n_ids, per));
+            for (std::thread& x : th) x.join();
+        }
+    }
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms write: image arrays on the host\n", now_ms() - t_io0);
     std::string err;
     try {
         if (!bft_file_write(path, hi, err)) return fail(BFT_GPU_E_IO, err);

@@ -530,7 +530,8 @@ extern "C" int bft_hosttest_write_bft(void* hv, const char* path) {
     hi.k = t->k; hi.r1 = BFT_DEFAULT_R1; hi.r2 = BFT_DEFAULT_R2;
     hi.genomes = {"genome_0"};
     hi.nodes = t->idx.nodes; hi.ccs = t->idx.ccs; hi.f2w = t->idx.f2w; hi.clus = t->idx.clus; hi.child = t->idx.child;
-    hi.ucrow = t->idx.ucrow; hi.tk = t->tk; hi.tcol = t->tcol; hi.cs_off = t->cs_off; hi.cs_ids = t->cs_ids;
+    hi.ucrow = t->idx.ucrow; hi.cs_off = t->cs_off;
+    hi.tk.assign(t->tk.begin(), t->tk.end()); hi.tcol.assign(t->tcol.begin(), t->tcol.end()); hi.cs_ids.assign(t->cs_ids.begin(), t->cs_ids.end());
     std::string err;
     return bft_file_write(path, hi, err) ? 0 : -1;
 }
