@@ -21,7 +21,7 @@ roofline: `traffic` = HBM bytes per launch from hardware counters collected IN T
 child processes after the timed region -- same library, same workload generator and seed as the timed batch --: FETCH_SIZE + WRITE_SIZE as
 counted, `traffic_counted`, plus a calibrated correction for the coalesced query stream the fetch counter tallies at half, `stream_correction`),
 `achieved` = traffic / mean kernel time (HIP events on the launch stream), `frac` = achieved / 8 TB/s -- an estimate resting on that
-calibration, not a bound.  Without a profiler the figures come from profiles/r04/pmc_query.json when its source hash matches the library's,
+calibration, not a bound.  Without a profiler the figures come from profiles/r05/pmc_query.json when its source hash matches the library's,
 else `frac` is null and `pmc_stale` true.  `gather` = L2 misses per second against the measured random-gather ceiling of the chip -- the
 limit that binds this kernel.  The container walk ("walk_hash": plain root groups in hashed form, special prefixes
 through the containers) gets the same block of its own under `container_walk.roofline`.
@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (6.3 TB/s a
 GATHER_CEILING_G = 59.4
 GATHER_CEILING_1GIB_G = 56.0  # the same microbenchmark on a 1 GiB table (nothing of it inside the Infinity Cache)
 GATHER_CEILING_SRC = "profiles/r04/microbench_gather.jsonl (indep4/8, 64 MiB table: the fabric's request rate; 56.0 at 1 GiB, whole lines by quads 54.7)"
-PMC_FALLBACK = "r04/pmc_query.json"
+PMC_FALLBACK = "r05/pmc_query.json"
 
 
 def parse():

@@ -18,12 +18,19 @@ for wl, nq, kb in (("cfg4", 125_000_000, 7), ("cfg4k31", 125_000_000, 8), ("cfg2
     out[wl] = pmc_live.collect(wl, nq, 3, "k_query", kmer_bytes=kb)
 out["cfg4_walk_hash"] = pmc_live.collect("cfg4", 125_000_000, 3, "k_query", opts=("walk_hash=1",), kmer_bytes=7)
 out["cfg4_walk"] = pmc_live.collect("cfg4", 125_000_000, 3, "k_query", opts=("kmer_hash=0",), kmer_bytes=7)
+out["cfg4_walk_pure"] = pmc_live.collect("cfg4", 125_000_000, 3, "k_query", opts=("kmer_hash=0", "root_direct=0", "node_hash=0"), kmer_bytes=7)
 json.dump(out, open(os.path.join(sys.argv[1], "pmc_query.json"), "w"), indent=1)
 PY
 python3 tools/bench_config5.py 2>&1 | strip | tail -n 1 > "$OUT/config5.json"
 python3 tools/bench_k_sweep.py 2>&1 | strip > "$OUT/k_sweep.jsonl"
-python3 tools/bench_insert.py --reserve --add-genome 2>&1 | strip | tail -n 1 > "$OUT/insert_config3.json"
-python3 tools/bench_insert.py --reserve --add-genome --k 31 2>&1 | strip | tail -n 1 > "$OUT/insert_config3_k31.json"
+python3 tools/bench_insert.py --reserve --add-genome --stages --warm-pool --cpu-baseline 8 2>&1 | strip | tail -n 1 > "$OUT/insert_config3.json"
+python3 tools/bench_insert.py --reserve --add-genome --stages --warm-pool --k 31 2>&1 | strip | tail -n 1 > "$OUT/insert_config3_k31.json"
+python3 tools/bench_config5_build.py 2>&1 | strip | tail -n 1 > "$OUT/config5_build.json"
+python3 tools/pmc_build.py "$OUT/pmc_build.json" > "$OUT/pmc_build.txt" 2>&1
+BFT_GPU_TRACE_IO=1 python3 tools/bench_bft_file.py 100 2> "$OUT/bft_file_100_trace.txt" | strip | tail -n 1 > "$OUT/bft_file_100.json"
+python3 tools/bench_bft_file.py 10 2>&1 | strip | tail -n 1 > "$OUT/bft_file_10.json"
+python3 tools/bench_color_lists.py cfg4 2>&1 | strip | grep "^{" > "$OUT/color_lists_cfg4.json"
+python3 tools/bench_color_lists.py cfg2 100000000 2>&1 | strip | grep "^{" > "$OUT/color_lists_cfg2.json"
 bash tools/profile_build_trace.sh "${1:-final}/build_config3" --reserve > /dev/null 2>&1
 # one build as a timeline: kernels with start offsets and idle gaps (tools/build_timeline.py), and the host's own marks (BFT_GPU_TRACE_BUILD)
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/build_tl" -- python3 "$ROOT/tools/bench_insert.py" --reserve --sample 100000 > /dev/null 2>&1 )
