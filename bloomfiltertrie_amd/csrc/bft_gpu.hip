@@ -335,11 +335,11 @@ struct bft_gpu {
     double tune_ms[3] = {0, 0, 0};  // best time of the tuning batch per residency 1 / 2 / 3
     int opt_grid_mult = 1;    // grid = resident workgroups x this
     // The k-mer hash kernels claim their blocks of k-mers from a counter instead of splitting them by workgroup number (k_query_kh,
-    // bft_kh.hip): one counter pair per stream that launches them -- launches of one stream follow each other, so a pair has one user at
-    // a time, and the kernel leaves it zeroed.  Streams beyond the slots, and batches too small to matter, take the static split.
+    // bft_kh.hip): one counter per stream that launches them -- launches of one stream follow each other, so a counter has one user at
+    // a time; it only grows, every launch with a range of its own (bft_claims.h).  Batches too small to matter take the static split.
     int opt_query_dynamic = 1;
     uint64_t opt_query_dynamic_min = (uint64_t)1 << 16;  // batches below this many k-mers (lines of work for the branching kernel) keep the static split
-    uint64_t claims_static_launches = 0;  // launches that wanted a counter pair and found every slot taken by other streams
+    uint64_t claims_static_launches = 0;  // launches that wanted a counter and found every slot taken by streams with work still in flight
     uint32_t opt_query_chunk = 4;  // largest claim, in blocks of 256 k-mers (4 = every claim: the smaller the window of the query stream the
                                    // resident workgroups read at a time, the better -- 2.61 / 2.62 / 2.65 / 2.70 ms at 4 / 16 / 32 / 64)
     static constexpr int KH_CTR_SLOTS = 32;
@@ -1178,18 +1178,15 @@ static void derive_root_direct(bft_gpu* h) {
     tmp.rdir = nullptr;
     tmp.debug_stop = 0;
     hipLaunchKernelGGL(k_root_direct, dim3((1u << 18) / 256), dim3(256), 0, h->stream, tmp, h->d_rdir.as<uint64_t>());
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    if (hipGetLastError() != hipSuccess) { (void)hipStreamSynchronize(h->stream); return; }
+    // (ONE wait for the three tables, at whichever point this function is left: the kernels follow each other on the handle's stream, and a caller's
+    // stream must not meet a table that is still being written)
     h->im.rdir = h->d_rdir.as<uint64_t>();
-    if (h->opt_root_direct < 2) return;
+    if (h->opt_root_direct < 2) { if (hipStreamSynchronize(h->stream) != hipSuccess) h->im.rdir = nullptr; return; }
     const size_t rs_bytes = ((1u << 18) + 2) * 4;
-    if (h->d_rstart.bytes < rs_bytes && h->d_rstart.alloc(rs_bytes) != 0) return;
+    if (h->d_rstart.bytes < rs_bytes && h->d_rstart.alloc(rs_bytes) != 0) { if (hipStreamSynchronize(h->stream) != hipSuccess) h->im.rdir = nullptr; return; }
     tmp.rdir = h->im.rdir;
-    uint32_t root_uc_n = 0;  // rows of the root's UC (BftNode::uc_n of node 0)
-    {
-        BftNode nd0;
-        if (hipMemcpy(&nd0, h->d_nodes.p, sizeof(nd0), hipMemcpyDeviceToHost) != hipSuccess) return;
-        root_uc_n = nd0.uc_n;
-    }
+    const uint32_t root_uc_n = (uint32_t)h->info[14];  // rows of the root's UC (BftNode::uc_n of node 0: bft_gpu_info entry 14, set by the build / the blob)
     const dim3 g((1u << 18) / 256 + 1), b(256);
     switch (h->W) {
     case 1: hipLaunchKernelGGL(k_root_ranges<1>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
@@ -1198,12 +1195,14 @@ static void derive_root_direct(bft_gpu* h) {
     default: hipLaunchKernelGGL(k_root_ranges<4>, g, b, 0, h->stream, tmp, root_uc_n, h->d_rstart.as<uint32_t>()); break;
     }
     hipLaunchKernelGGL(k_root_ranges_check, g, b, 0, h->stream, h->im.rdir, h->d_rstart.as<uint32_t>());
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    if (hipGetLastError() != hipSuccess) return;  // (no wait here: the stream is synchronised below, or by whoever uses the tables next)
     h->rstart_ok = true;
     h->im.rstart = h->d_rstart.as<uint32_t>();  // (mode 3: tune_residency decides whether it stays)
     h->rq_ok = false;
-    if (!h->opt_root_quartiles || h->L < 2) return;
-    if (h->d_rq.bytes < (4u << 18) && h->d_rq.alloc(4u << 18) != 0) return;
+    if (!h->opt_root_quartiles || h->L < 2 || (h->d_rq.bytes < (4u << 18) && h->d_rq.alloc(4u << 18) != 0)) {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { h->im.rdir = nullptr; h->im.rstart = nullptr; h->rstart_ok = false; }
+        return;
+    }
     tmp.rstart = h->im.rstart;
     const dim3 gq((1u << 18) / 256);
     switch (h->W) {
@@ -1212,7 +1211,7 @@ static void derive_root_direct(bft_gpu* h) {
     case 3: hipLaunchKernelGGL(k_root_quartiles<3>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
     default: hipLaunchKernelGGL(k_root_quartiles<4>, gq, b, 0, h->stream, tmp, h->d_rstart.as<uint32_t>(), h->d_rq.as<uint32_t>()); break;
     }
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { h->im.rdir = nullptr; h->im.rstart = nullptr; h->rstart_ok = false; return; }
     h->rq_ok = true;
     h->im.rq = h->d_rq.as<uint32_t>();
 }
@@ -1792,7 +1791,7 @@ static int launch_query_k(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64
     size_t lds = BFT_LDS_HM_BYTES + ((size_t)BFT_MODULO_HASH * 8 + 15) / 16 * 16 + BFT_LDS_ROOT_MAX_CC * sizeof(BftCCX);
     if (wgs == 1) lds = std::max<size_t>(lds, 84u << 10);
     const uint64_t resident = 256ull * (uint64_t)wgs;  // 256 CUs x resident workgroups per CU
-    // chunks of 1024 k-mers per wavefront (query_body): the first by wavefront number, the others claimed from the stream's counter pair
+    // chunks of 1024 k-mers per wavefront (query_body): the first by wavefront number, the others claimed from the stream's counter
     const uint64_t n_chunks = (n + 1023) / 1024, wg_chunks = (n_chunks + block / 64 - 1) / (block / 64);
     const BftClaimCtr ctr = claim_counters(h, s, n, n_chunks);
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wg_chunks, resident * h->opt_grid_mult)));

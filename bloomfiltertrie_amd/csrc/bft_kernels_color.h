@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void k_color_fill_cs(const uint32_t* __restric
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const uint64_t i = blk * 256 + threadIdx.x;
         const bool valid = i < n;
-        const uint64_t a = offsets[valid ? i : n], b = offsets[valid ? i + 1 : n];
+        const uint64_t a = offsets[valid ? i : n];
+        uint64_t b = __shfl_down(a, 1);  // (the next lane's start is this lane's end: one load of the offsets per k-mer, not two)
+        if (lane == 63u) b = offsets[valid ? i + 1 : n];
         uint32_t src = 0;
         if (valid && b > a) src = cs_off[cs[i]];
         const uint64_t base = __shfl(a, 0), end = __shfl(b, 63);
