@@ -95,6 +95,33 @@ def test_product_writer_loaded_by_oracle(oracle_mod, hostlib, tmp_path, k, level
     assert nk == len(km) and sorted(S.row_keys(per[0]).tolist()) == sorted(S.row_keys(km).tolist())
 
 
+@pytest.mark.parametrize("k,levels,n", [(27, 1, 120000), (36, 2, 60000), (63, 3, 30000)])
+def test_writer_and_reader_do_not_depend_on_the_thread_count(hostlib, tmp_path, k, levels, n):
+    """The writer emits the file as ordered parts filled by a pool of host threads (UC blocks and child-Node subtrees of the root's CCs) and the
+    loader rebuilds the k-mers block by block in parallel (csrc/bft_file.cpp; BFT_GPU_IO_THREADS): one thread, three and the default give the same
+    bytes, and the same k-mers back."""
+    km = np.ascontiguousarray(S.low_entropy_kmers(n, k, 40, seed=n + k, levels=levels))
+    h = hostlib.bft_hosttest_build(km.ctypes.data, len(km), k, 0, 0)
+    blobs, reads = [], []
+    try:
+        for nt in ("1", "3", None):
+            if nt is None:
+                os.environ.pop("BFT_GPU_IO_THREADS", None)
+            else:
+                os.environ["BFT_GPU_IO_THREADS"] = nt
+            path = str(tmp_path / f"t{nt}.bft")
+            assert hostlib.bft_hosttest_write_bft(h, path.encode()) == 0
+            blobs.append(open(path, "rb").read())
+            kk, nk, per = _product_read(hostlib, path)
+            assert nk == len(km)
+            reads.append(np.sort(S.row_keys(per[0])))
+    finally:
+        os.environ.pop("BFT_GPU_IO_THREADS", None)
+        hostlib.bft_hosttest_free(h)
+    assert blobs[0] == blobs[1] == blobs[2]
+    assert (reads[0] == reads[1]).all() and (reads[0] == reads[2]).all() and (reads[0] == np.sort(S.row_keys(km))).all()
+
+
 def test_config1_file_size_matches_reference_run(oracle_mod, tmp_path):
     """`bft build 27` on the config-1 genome wrote a 6.36 MB .bft."""
     random.seed(1)

@@ -728,3 +728,30 @@ def test_a_bucket_beyond_the_capacity_falls_back_to_the_device_wide_sort(k, gids
         assert (a[0][name] == b[0][name]).all(), name
     assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
 
+
+
+def test_build_stages_table():
+    """bft_gpu_build_stages ("build_stages" 1): the GPU time of the last build stage by stage -- HIP events on the build's stream, the algorithmic
+    bytes of the streaming stages beside them; off by default (no table, no events)."""
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    anc = S.random_genome(300000, 21)
+    t = BFT(k)
+    t.insert_kmers(S.distinct(S.kmers_of(anc, k)), 0)
+    t.build()
+    assert t.build_stages() == []
+    t.set_option("build_stages", 1)
+    t.set_option("build_msd", 2)
+    for g in range(1, 4):
+        t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.01, g), k)), g)
+    t.build()  # (a merge into the first index)
+    st = t.build_stages()
+    names = [n for n, _, _ in st]
+    assert len(st) >= 10 and all(ms >= 0 for _, ms, _ in st) and sum(ms for n, ms, _ in st if not n.startswith("+")) > 0
+    assert any("merge into the index" in n for n in names) and any(n.startswith("containers depth 0") for n in names) and any("root tables" in n for n in names)
+    assert any(by > 0 for _, _, by in st)
+    t.set_option("build_stages", 0)
+    t.insert_kmers(S.distinct(S.kmers_of(S.mutate(anc, 0.01, 9), k)), 4)
+    t.build()
+    assert [n for n, _, _ in t.build_stages()] == names  # (the table of the last build that recorded one stays)
+    t.close()

@@ -752,6 +752,10 @@ def test_device_group_on_resident_batches(k):
         t.insert_kmers(km, g)
     grp = BFTGroup(t, [0, 0, 0])
     assert [grp.member_device(i) for i in range(3)] == [0, 0, 0] and grp.member_device(3) == -1
+    with pytest.raises(ValueError):  # (one entry per slot: the C side indexes bft_gpu_group_size entries of every array)
+        grp.query_presence_dev([0, 0], [0, 0, 0], [0, 0, 0])
+    with pytest.raises(Exception):  # (a slot with k-mers and no buffers is refused before anything is enqueued)
+        grp.query_presence_dev([0, 0, 0], [64, 0, 0], [0, 0, 0])
     allk = S.distinct(np.concatenate(gk))
     rng = np.random.default_rng(k)
     base = np.concatenate([allk, S.snp_mutants(allk, k, 2)])

@@ -19,10 +19,14 @@ def main():
     dev = torch.device("cuda", 0)
     nq = 100_000_000
     out = []
-    for k in (18, 21, 27, 31, 32, 36, 45, 54, 63, 64, 72, 99, 126):
+    ks = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (18, 21, 27, 31, 32, 36, 45, 54, 63, 64, 72, 99, 126)
+    load = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # "kmer_hash_load" (0: the default)
+    for k in ks:
         anc = S.random_genome(2_000_000, 1234)
         gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 1000 + g), k)) for g in range(10)]
         t = BFT(k)
+        if load:
+            t.set_option("kmer_hash_load", load)
         for g, km in enumerate(gk):
             t.insert_kmers(km, g)
         t.build()
@@ -42,7 +46,7 @@ def main():
         ms, cnt = t.kernel_time(reset=True)
         info = t.info()
         bt = t.build_time()
-        out.append({"k": k, "queries": n, "ms": round(ms / cnt, 3), "G_kmers_per_s": round(n / (ms / cnt) / 1e6, 2), "ok": ok, "kmers": info["kmers"],
+        out.append({"k": k, "kmer_hash_load": load or 55, "queries": n, "ms": round(ms / cnt, 3), "G_kmers_per_s": round(n / (ms / cnt) / 1e6, 2), "ok": ok, "kmers": info["kmers"],
                     "nodes": info["nodes"], "image_MB": round(info["image_bytes"] / 1e6, 1), "kh_slots": int(bt["kmer_hash_slots"]), "kh_maxd": int(bt["kmer_hash_maxd"]), "kh_overflow": int(bt["kmer_hash_overflow"]),
                     "kh_bytes_per_kmer": round(t.footprint()["kmer_hash"] / max(1, info["kmers"]), 2)})
         print(json.dumps(out[-1]), flush=True)
