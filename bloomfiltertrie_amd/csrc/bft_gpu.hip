@@ -267,6 +267,13 @@ struct bft_gpu {
     // pending insert log (SoA: W key arrays of log_cap entries, then genome ids)
     DevBuf log_k, log_g;
     uint64_t log_n = 0, log_cap = 0;
+    // One-word keys with room for a genome id beside them (k <= 28: 63 - 2k >= 7 bits) are logged as the COMPOSITES T << log_gb | genome the build's
+    // root-prefix split sorts: 8 bytes per pair written at insert time and read by the split's histogram and first pass instead of 12 (no id array:
+    // log_g stays empty).  A genome id beyond 2^log_gb, ids that do not ascend, or the general sort ("build_composite" 0) turn the log back
+    // into k-mers + ids first (k_log_decompose).
+    bool log_comp = false;
+    uint32_t log_gb = 0;
+    int opt_comp_log = 1;  // "composite_log": 0 = always k-mers + ids (a test hook: same image)
 
     uint64_t n_pairs = 0;  // distinct (k-mer, genome) pairs the index holds = sum of the sizes of its k-mers' colour sets
 
@@ -535,7 +542,30 @@ extern "C" int bft_gpu_add_genome(bft_gpu* h, const char* name, uint32_t* id_gen
 // ------------------------------------------------------------------------------------------------
 // insertion log
 // ------------------------------------------------------------------------------------------------
+static uint32_t log_comp_bits(const bft_gpu* h) {  // id bits of a composite log, 0: this handle logs k-mers + ids
+    const int room = 63 - 2 * h->k;
+    return (h->W == 1 && h->opt_comp_log && !h->opt_no_composite && room >= 7) ? (uint32_t)std::min(room, 24) : 0u;
+}
+// composites -> k-mers + ids, for whatever cannot take composites (the id array is allocated here)
+static int log_decompose(bft_gpu* h) {
+    if (!h->log_comp) return 0;
+    CK(wait_foreign_stream(h));
+    DevBuf ng;
+    CK(ng.alloc(std::max<uint64_t>(h->log_cap, 1) * 4));
+    if (h->log_n) {
+        hipLaunchKernelGGL(k_log_decompose, dim3(grid_for((h->log_n + 255) / 256)), dim3(256), 0, h->stream, h->log_k.as<uint64_t>(), h->log_n, h->log_gb, ng.as<uint32_t>());
+        HIPCK(hipGetLastError());
+    }
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->log_g.swap(ng);
+    h->log_comp = false;
+    return 0;
+}
 static int log_reserve(bft_gpu* h, uint64_t need) {
+    if (h->log_n == 0 && h->log_cap == 0) {  // an empty log: its format is decided here
+        h->log_gb = log_comp_bits(h);
+        h->log_comp = h->log_gb != 0;
+    }
     if (need <= h->log_cap) return 0;
     uint64_t ncap = std::max<uint64_t>(need, h->log_cap * 2);
     ncap = std::max<uint64_t>(ncap, 1 << 16);
@@ -544,12 +574,12 @@ static int log_reserve(bft_gpu* h, uint64_t need) {
     CK(wait_foreign_stream(h));
     DevBuf nk, ng;
     CK(nk.alloc(ncap * h->W * 8));
-    CK(ng.alloc(ncap * 4));
+    if (!h->log_comp) CK(ng.alloc(ncap * 4));
     if (h->log_n) {
         for (int w = 0; w < h->W; w++)
             HIPCK(hipMemcpyAsync(nk.as<uint64_t>() + (uint64_t)w * ncap, h->log_k.as<uint64_t>() + (uint64_t)w * h->log_cap,
                                  h->log_n * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPCK(hipMemcpyAsync(ng.p, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (!h->log_comp) HIPCK(hipMemcpyAsync(ng.p, h->log_g.p, h->log_n * 4, hipMemcpyDeviceToDevice, h->stream));
     }
     // (also without a copy: a fresh block may come from the cache with work of this handle's stream still queued on it, and the
     // next writer may be a caller's stream, which is not ordered behind ours)
@@ -564,7 +594,7 @@ template <int W>
 static int launch_pack(bft_gpu* h, const uint8_t* d_packed, uint64_t n, uint32_t gid, hipStream_t s) {
     const uint64_t nblk = (n + BFT_BLOCK - 1) / BFT_BLOCK;
     hipLaunchKernelGGL(k_pack_to_tform<W>, dim3(grid_for(nblk)), dim3(BFT_BLOCK), 0, s, d_packed, n, h->B,
-                       h->k, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid);
+                       h->k, h->log_k.as<uint64_t>(), h->log_cap, h->log_n, h->log_g.as<uint32_t>(), gid, h->log_comp ? h->log_gb : 0u);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -586,6 +616,7 @@ static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_g
     }
     if (h->log_n && h->log_n + n > h->opt_flush_pairs) CK(bft_gpu_build(h));
     CK(log_reserve(h, h->log_n + n));
+    if (h->log_comp && (id_genome >> h->log_gb) != 0) CK(log_decompose(h));  // (an id the composites have no room for)
     const hipStream_t run = ordered ? s : h->stream;
     const uint8_t* p = (const uint8_t*)d_kmers;
     switch (h->W) {
@@ -1417,6 +1448,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     ENTER(h);
     if (h->built && h->log_n == 0) return BFT_GPU_OK;
     CK(wait_foreign_stream(h));  // batches still being packed into the log on a caller's stream (bft_gpu_insert_kmers_dev_async)
+    if (h->log_comp && (!h->log_g_sorted || h->opt_no_composite)) CK(log_decompose(h));  // (only the composite path below takes a log of composites)
     if (h->built) CK(ensure_table(h));  // ("compact_table": the merge reads the index's sorted table)
     const int W = h->W;
     const uint64_t total = h->log_n;  // the run: what was inserted since the last build
@@ -1434,14 +1466,14 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         const uint64_t* src_k = h->log_k.as<uint64_t>();
         const uint32_t* src_g = h->log_g.as<uint32_t>();
         const uint64_t src_stride = h->log_cap;
-        const int gb = bits_for(h->max_gid_seen);
+        const int gb = h->log_comp ? (int)h->log_gb : bits_for(h->max_gid_seen);  // (a log of composites: their id field as logged)
         // (composites of up to 63 bits: rocPRIM's radix sort mis-sorts the bit range [2, 64) -- found by test_any_k_against_ground_truth[31-0])
         if (W == 1 && h->log_g_sorted && 2 * h->k + gb <= 63 && !h->opt_no_composite) {
             // 2c + 3c. composite path (bft_kernels_build.h): sort (T << gb | genome) on the T bits, flags on the fly, one scan
             DevBuf cs, tmp, pos;
             CK(cs.alloc(total * 8));
             CK(pos.alloc(total * 8));
-            const BftCompose comp{src_k, src_g, (uint32_t)gb};
+            const BftCompose comp{src_k, h->log_comp ? nullptr : src_g, (uint32_t)gb};
             auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), comp);
             size_t tb = 0, tb2 = 0;
             // MSD first: a stable sort on the top 18 bits of T (the rotated root prefix: 2^18 buckets of ~10^3 composites on a
@@ -1465,7 +1497,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
                 // (histogram: the log, 12 B per pair; pass 1: the log in, composites out; pass 2: composites in and out)
-                bft_stage("split (root-prefix, 2 x 9 bits)", (double)total * (12 + 12 + 8 + 8 + 8), h->stream);
+                bft_stage("split (root-prefix, 2 x 9 bits)", (double)total * ((h->log_comp ? 8 : 12) * 2 + 8 + 8 + 8), h->stream);
                 uint32_t mx = 0;
                 CK(bft_front_buckets(cs.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx,
                                      &done, &h->front_redone));
@@ -1703,6 +1735,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->d_tk.swap(tk);
     h->n_pairs = np;
     h->log_n = 0;
+    h->log_comp = false;
     h->log_g_sorted = true;
     h->n_kmers = nk;
     h->idx_sizes[0] = idx.n_nodes * sizeof(BftNode); h->idx_sizes[1] = idx.n_bf8 * 8; h->idx_sizes[2] = idx.n_ccs * sizeof(BftCC);
@@ -2968,6 +3001,10 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
             for (int i = 0; i < bft_gpu::KH_CTR_SLOTS; i++) v[i] = value == 3 ? 0ull : h->kh_ctr_base[i] - (value == 1 && h->kh_ctr_base[i] ? 1ull : 0ull);
             HIPCK(hipMemcpy(h->kh_ctr, v, sizeof(v), hipMemcpyHostToDevice));
         }
+    } else if (nm == "composite_log") {  // 1 (default): one-word keys with room for an id are logged as composites; 0: always k-mers + ids (test hook: same image)
+        if (h->log_n) return fail(BFT_GPU_E_STATE, "composite_log: the insertion log is not empty");
+        h->opt_comp_log = value != 0;
+        if (h->log_cap) { h->log_k.release(); h->log_g.release(); h->log_cap = 0; }  // (a reserved, empty log: its format is decided again)
     } else if (nm == "build_stages") {
         h->opt_build_stages = value != 0;
     } else if (nm == "flat_min") {

@@ -43,7 +43,7 @@ struct BftCompose {  // input "iterator" of the sort: composite i from the inser
     const uint64_t* k;
     const uint32_t* g;
     uint32_t gb;
-    __host__ __device__ uint64_t operator()(uint32_t i) const { return (k[i] << gb) | (uint64_t)g[i]; }
+    __host__ __device__ uint64_t operator()(uint32_t i) const { return g ? (k[i] << gb) | (uint64_t)g[i] : k[i]; }  // (g == NULL: the log already holds composites)
 };
 struct BftPairFlags {  // input of the scan: (first pair of its k-mer) << 32 | (first pair of its (k-mer, genome))
     const uint64_t* c;

@@ -14,15 +14,28 @@
 template <int W>
 __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __restrict__ packed, uint64_t n, int B, int k,
                                                              uint64_t* __restrict__ out, uint64_t stride, uint64_t off,
-                                                             uint32_t* __restrict__ gout, uint32_t gid) {
+                                                             uint32_t* __restrict__ gout, uint32_t gid, uint32_t cgb) {
+    // cgb != 0 (one-word keys only): the log holds COMPOSITES T << cgb | genome -- what the build's root-prefix split sorts -- and no id array
     const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
     for (uint64_t i = blockIdx.x * (uint64_t)BFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BFT_BLOCK) {
         uint64_t x[W], t[W];
         load_x<W>(packed, i, B, end_aligned, x);
         bft_tform_from_x<W>(x, k, t);
+        if (W == 1 && cgb) {
+            out[off + i] = (t[0] << cgb) | (uint64_t)gid;
+            continue;
+        }
 #pragma unroll
         for (int w = 0; w < W; w++) out[(uint64_t)w * stride + off + i] = t[w];
         gout[off + i] = gid;
+    }
+}
+// a log of composites back into T-form k-mers and their ids (in place + the id array)
+static __global__ void k_log_decompose(uint64_t* __restrict__ log_k, uint64_t n, uint32_t cgb, uint32_t* __restrict__ log_g) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = log_k[i];
+        log_g[i] = (uint32_t)(c & ((1ull << cgb) - 1ull));
+        log_k[i] = c >> cgb;
     }
 }
 

@@ -197,7 +197,10 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   and they stay until the next build or until the option is set again.  No effect on a handle without a k-mer hash ("kmer_hash" 0).  0: the table stays.)
  * Build: "build_composite" (1, default: one-word keys whose genome ids arrive ascending take the root-prefix front end -- as 8-byte composites
  *   k-mer << bits | genome where that fits 63 bits, as (k-mer, id) pairs whose composite is formed inside a bucket otherwise; 0: the general key + value
- *   sort -- same image either way, a test hook), "build_msd" (1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
+ *   sort -- same image either way, a test hook), "composite_log" (1, default: where a one-word key leaves 7 bits or more for the id, k <= 28, the
+ *   insertion log itself holds those composites -- 8 bytes per pending pair instead of 12, and the root-prefix split reads them as they are;
+ *   an id beyond the room, ids that do not ascend or "build_composite" 0 turn the log back into k-mers + ids; 0: always k-mers + ids --
+ *   same image, a test hook; only while the log is empty), "build_msd"(1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
  *   device-wide sort; 2: buckets at any size -- same image, test hooks), "test_front_rank_mode" (process-wide test hook: how a bucket ranks its digits:
  *   0, default = LDS atomics + order check + ballot fallback, 1 = ballots only, 2 = the check always fails), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
  *   pairs, so that a series of insert calls never re-allocates it), "flush_pairs" (the log is merged into the index before it holds this many pairs:

@@ -225,19 +225,22 @@ def test_flat_form_matches_host_restatement(hostlib, flat_min):
         hostlib.bft_hosttest_free(h)
 
 
-@pytest.mark.parametrize("k,ngen", [(27, 3), (27, 130), (31, 2), (31, 4), (31, 300), (18, 40)])
+@pytest.mark.parametrize("k,ngen", [(27, 3), (27, 130), (27, 600), (31, 2), (31, 4), (31, 300), (18, 40)])
 def test_composite_sort_builds_the_same_image(k, ngen):
     """One-word keys with ascending genome ids are sorted as (T << bits | genome) composites when that fits 63 bits
     ("build_composite" 1, the default) -- root-prefix buckets first, then every bucket on its own ("build_msd" 2 forces that at this
     small size; 0 = one device-wide sort) -- and by the general key + value sort otherwise: every array of the image, the colour
-    sets and the extraction are identical -- including an incremental build and duplicate (k-mer, genome) pairs."""
+    sets and the extraction are identical -- including an incremental build and duplicate (k-mer, genome) pairs.  Where the key leaves
+    7 bits or more (k <= 28) the insertion log itself holds the composites ("composite_log" 1, the default; 0 = k-mers + ids): 600 genomes
+    at k = 27 pass the 512 ids a composite has room for, so that log is turned back into k-mers + ids half way."""
     from bloomfiltertrie_amd import BFT
     base = S.distinct(S.kmers_of(S.random_genome(30000, 5 + k), k))
     rng = np.random.default_rng(k + ngen)
     parts = [np.ascontiguousarray(base[rng.random(len(base)) < 0.3]) for _ in range(ngen)]
     imgs = []
-    for comp, msd in ((1, 2), (0, 0), (1, 0)):
+    for comp, msd, clog in ((1, 2, 1), (0, 0, 1), (1, 0, 1), (1, 2, 0)):
         t = BFT(k)
+        t.set_option("composite_log", clog)
         t.set_option("build_composite", comp)
         t.set_option("build_msd", msd)
         half = ngen // 2
