@@ -7,7 +7,7 @@ from . import synth  # noqa: F401
 
 
 def __getattr__(name):
-    if name in ("BFT", "BFTGroup", "create_cdbg", "shard"):
+    if name in ("BFT", "BFTGroup", "create_cdbg", "shard", "cache_release"):
         from . import bft
         return getattr(bft, name)
     raise AttributeError(name)

@@ -22,6 +22,7 @@ SIGNATURES = {
     "bft_gpu_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "bft_gpu_create_seeded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "bft_gpu_free": (None, [_P]),
+    "bft_gpu_cache_release": (C.c_uint64, []),
     "bft_gpu_add_genome": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint32)]),
     "bft_gpu_genome_name": (C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_uint32]),
     "bft_gpu_insert_kmers": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),

@@ -398,6 +398,11 @@ def shard(n, parts, i):
     return a.value, b.value
 
 
+def cache_release():
+    """bft_gpu_cache_release: the library's cache of released device blocks back to the HIP runtime; returns the bytes"""
+    return int(_lib.load().bft_gpu_cache_release())
+
+
 def create_cdbg(k, device=0):
     """create_cdbg(k, treshold_compression) (include/bft.h:62)."""
     return BFT(k, device)

@@ -561,11 +561,8 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
     DevBuf nd_lo, nd_hi;
     CK(nd_lo.alloc(4));
     CK(nd_hi.alloc(4));
-    {
-        const uint32_t z = 0, nn = (uint32_t)n;
-        HIPCK(hipMemcpyAsync(nd_lo.p, &z, 4, hipMemcpyHostToDevice, s));
-        HIPCK(hipMemcpyAsync(nd_hi.p, &nn, 4, hipMemcpyHostToDevice, s));
-    }
+    hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, nd_lo.as<uint32_t>(), 0u);  // (the root: every row)
+    hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, nd_hi.as<uint32_t>(), (uint32_t)n);
     uint64_t M = 1;
     uint64_t T_nodes = 0, T_ccs = 0, T_f2w = 0, T_clus = 0, T_child = 0, T_bf8 = 0, T_uc = 0;
 #define G(nelem) dim3(bft_grid_for(((uint64_t)(nelem) + ABLK - 1) / ABLK)), dim3(ABLK), 0, s
@@ -578,8 +575,8 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(node_off.alloc((M + 1) * 4));
         hipLaunchKernelGGL(k_sizes, G(M), nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), nsz.as<uint32_t>(), (uint32_t)M);
         CK(scan.enqueue(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, 0, true));
-        CK(scan.wait());
-        const uint64_t A = scan.get(0);
+        if (d) CK(scan.wait());  // (the root's rows are all of them: nothing to wait for; the slot is written again only behind this scan)
+        const uint64_t A = d ? scan.get(0) : n;
         bft_trace_mark("  level: active rows");
         const std::string lv = "containers depth " + std::to_string(d) + ": ";
         bft_stage((lv + "active rows").c_str(), (double)M * 12, s);
@@ -1184,6 +1181,12 @@ __global__ void k_cs_hash_ids(const uint32_t* __restrict__ slots_s, uint32_t n_s
     }
 }
 
+// the dictionary's ids in the width the resident image keeps them in (behind the verification, on the side stream)
+template <class T>
+__global__ void k_cs_narrow(const uint32_t* __restrict__ in, uint64_t n, T* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (T)in[i];
+}
+
 // dictionary entries: the lanes of a wavefront copy each representative's list together, 64 ids at a time
 __global__ __launch_bounds__(ABLK) void k_cs_hash_copy(const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cs_off, uint32_t n_sets, const uint32_t* __restrict__ seg_off,
                                                        const uint32_t* __restrict__ pg, uint32_t* __restrict__ cs_ids) {
@@ -1344,15 +1347,19 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
                 hipStream_t t2 = tail->side;
                 tail->rep.swap(rep);
                 CK(tail->bad.alloc_zero(4, s));
+                if (tail->narrow_w < 4) CK(tail->narrow.alloc(n_ids * tail->narrow_w));  // (before `ready`: whatever held the block last was enqueued on s)
                 HIPCK(hipEventRecord(tail->ready, s));
                 HIPCK(hipStreamWaitEvent(t2, tail->ready, 0));
                 hipLaunchKernelGGL(k_cs_hash_copy, sgrid, block, 0, t2, tail->rep.as<uint32_t>(), d_cs_off.as<uint32_t>(), (uint32_t)n_sets, d_seg_off, d_pg, d_cs_ids.as<uint32_t>());
                 hipLaunchKernelGGL(k_cs_verify, grid, block, 0, t2, d_tcol.as<uint32_t>(), d_cs_off.as<uint32_t>(), d_cs_ids.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk,
                                    tail->bad.as<uint32_t>());
                 hipLaunchKernelGGL(k_publish, dim3(1), dim3(PIN_SLOTS), 0, t2, tail->bad.as<uint32_t>(), 1, tail->pin.p);
+                if (n_ids && tail->narrow_w == 1) hipLaunchKernelGGL(k_cs_narrow<uint8_t>, grid, block, 0, t2, d_cs_ids.as<uint32_t>(), n_ids, tail->narrow.as<uint8_t>());
+                if (n_ids && tail->narrow_w == 2) hipLaunchKernelGGL(k_cs_narrow<uint16_t>, grid, block, 0, t2, d_cs_ids.as<uint32_t>(), n_ids, tail->narrow.as<uint16_t>());
                 HIPCK(hipGetLastError());
                 HIPCK(hipEventRecord(tail->done, t2));
-                bft_stage("+colour sets: dictionary copied, every list verified (side stream)", (double)n_ids * 8 + (double)n_sets * 12 + (double)np * 8 + (double)nk * 12, t2);
+                bft_stage("+colour sets: dictionary copied, every list verified, ids narrowed (side stream)",
+                          (double)n_ids * 8 + (double)n_sets * 12 + (double)np * 8 + (double)nk * 12 + (tail->narrow_w < 4 ? (double)n_ids * (4 + tail->narrow_w) : 0.0), t2);
                 tail->pending = true;
                 return 0;  // (tab, slot_of ... go back to the cache under this stream's tag: what reads them was enqueued on s before this point)
             }

@@ -141,6 +141,8 @@ struct BftInternTail {
     bool pending = false;
     DevBuf rep, bad;  // (what the deferred kernels read and write besides the outputs)
     PinBlock pin;
+    uint32_t narrow_w = 4;  // in: bytes per genome id of the resident dictionary (1 / 2: the deferred tail also writes `narrow`, the dictionary's ids in that width)
+    DevBuf narrow;
     ~BftInternTail() {
         if (pending && side) (void)hipStreamSynchronize(side);
         if (done) (void)hipEventDestroy(done);

@@ -115,6 +115,8 @@ size_t pool_max_bytes() {
     return v;
 }
 constexpr size_t POOL_MAX_BLOCKS = 256;
+// tag of a block whose stream was synchronised and destroyed since (a closed handle's): nothing to wait for, whoever takes it
+const hipStream_t POOL_DRAINED = (hipStream_t)(uintptr_t)1;
 double g_malloc_ms = 0;          // time spent in hipMalloc by this process (diagnostic: bft_gpu_build_time)
 uint64_t g_malloc_calls = 0;
 double g_free_ms = 0;            // ... and in hipFree
@@ -157,7 +159,7 @@ int bft_pool_alloc(void** p, size_t n, size_t* cap) {
     }
     if (take.p) {
         // released under another stream: its work must have drained before the block is written again
-        if (take.stream != t_pool_stream && hipStreamSynchronize(take.stream) != hipSuccess) {
+        if (take.stream != t_pool_stream && take.stream != POOL_DRAINED && hipStreamSynchronize(take.stream) != hipSuccess) {
             pool_free_block(take);
             take.p = nullptr;
         }
@@ -213,20 +215,33 @@ void bft_pool_release(void* p, size_t cap) {
 }
 
 void bft_pool_drop_stream(hipStream_t s) {
-    std::vector<PoolBlock> mine;
+    // (the caller has synchronised s and destroys it next: its blocks stay in the cache -- the next handle's build of the same size finds them,
+    // where a hipMalloc of a gigabyte block costs from a millisecond to 0.4 s depending on the box -- but must never be waited for on s again)
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PoolBlock& b : g_pool)
+        if (b.stream == s) b.stream = POOL_DRAINED;
+}
+
+extern "C" uint64_t bft_gpu_cache_release(void) {
+    std::vector<PoolBlock> all;
+    uint64_t bytes = 0;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (size_t i = 0; i < g_pool.size();) {
-            if (g_pool[i].stream == s) {
-                mine.push_back(g_pool[i]);
-                g_pool_bytes -= g_pool[i].cap;
-                g_pool[i] = g_pool.back();
-                g_pool.pop_back();
-            } else
-                i++;
-        }
+        all.swap(g_pool);
+        bytes = g_pool_bytes;
+        g_pool_bytes = 0;
     }
-    for (const PoolBlock& b : mine) pool_free_block(b);
+    for (const PoolBlock& b : all) {
+        if (b.stream != POOL_DRAINED) {  // (released under a live handle's stream: what was enqueued before the release may still read it)
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != b.device) (void)hipSetDevice(b.device);
+            (void)hipStreamSynchronize(b.stream);
+            if (cur != b.device && cur >= 0) (void)hipSetDevice(cur);
+        }
+        pool_free_block(b);
+    }
+    return bytes;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,7 +370,7 @@ struct bft_gpu {
     unsigned long long kh_ctr_base[KH_CTR_SLOTS] = {};  // where the next launch's range of the slot's counter starts (bft_claims.h)
     uint64_t kh_ctr_tick[KH_CTR_SLOTS] = {};            // last use: a handle queried on more streams than slots recycles the least recently used
     uint64_t kh_ctr_clock = 0;
-    hipEvent_t kh_ctr_ev[KH_CTR_SLOTS] = {};            // end of the slot's last launch (recorded only once every slot is in use)
+    hipEvent_t kh_ctr_ev[KH_CTR_SLOTS] = {};            // end of the slot's last launch (recorded once half of the slots are in use)
     int kh_ctr_pending = -1;
     int kh_ctr_used = 0;
     bool kh_ctr_failed = false;
@@ -519,7 +534,7 @@ extern "C" void bft_gpu_free(bft_gpu* h) {
     if (s) (void)hipStreamSynchronize(s);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
     delete h;                      // its buffers go to the cache under this stream's tag ...
-    bft_pool_drop_stream(s);       // ... and are given back to the runtime here
+    bft_pool_drop_stream(s);       // ... which is replaced by "drained" here (bft_gpu_cache_release gives the cache back to the runtime)
     bft_pool_set_stream(-1, nullptr);
     if (s) (void)hipStreamDestroy(s);
 }
@@ -1627,6 +1642,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     const bool merging = h->built && h->n_kmers > 0 && nk > 0;
     BftInternTail tail;
     tail.side = merging ? nullptr : h->stream2;
+    tail.narrow_w = id_width(h->max_gid_seen);  // (the tail also leaves the dictionary in the width the image keeps)
     CK(bft_intern_colors_gpu(seg_off.as<uint32_t>(), npg.as<uint32_t>(), nk, np, h->stream, n_tcol, n_cs_off, n_cs_ids, n_sets, n_ids, 0, &tail));
     bft_trace_mark("colour sets interned");
     bft_stage("colour sets (rest)", 0, h->stream);
@@ -1693,10 +1709,17 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     }
     const uint32_t new_cs_w = id_width(h->max_gid_seen);
     DevBuf n_cs_ids_w;
-    CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
+    bool narrowed_here = false;
+    if (!kh_redo && tail.narrow.p && tail.narrow_w == new_cs_w) {  // (done by the interning's tail on the side stream)
+        n_cs_ids_w.swap(tail.narrow);
+        n_cs_ids.release();
+    } else {
+        CK(narrow_ids(n_cs_ids, n_ids, new_cs_w, h->stream, n_cs_ids_w));
+        narrowed_here = new_cs_w < 4;
+    }
     CK(wait_foreign_stream(h));  // queries a caller still has in flight on its own stream read the arrays released below
     bft_trace_mark("ids narrowed, foreign stream waited");
-    bft_stage("dictionary ids narrowed", (double)n_ids * (4 + new_cs_w), h->stream);
+    bft_stage("dictionary ids narrowed", narrowed_here ? (double)n_ids * (4 + new_cs_w) : 0.0, h->stream);
     double kh_ms = 0;
     const bool kh_ok = !kh_redo && kh_finish(h, khf, &kh_ms);
     bft_trace_mark("k-mer hash fill waited");
@@ -1912,7 +1935,10 @@ static BftClaimCtr claim_counters(bft_gpu* h, hipStream_t s, uint64_t n, uint64_
         int lru = 0;
         for (int i = 1; i < bft_gpu::KH_CTR_SLOTS; i++)
             if (h->kh_ctr_tick[i] < h->kh_ctr_tick[lru]) lru = i;
-        if (h->kh_ctr_ev[lru] && hipEventQuery(h->kh_ctr_ev[lru]) == hipSuccess) {
+        // (a slot last used before the handle started recording events -- its stream may be gone by now, so there is nothing to ask but the device:
+        // once per such slot at most)
+        const bool over = h->kh_ctr_ev[lru] ? hipEventQuery(h->kh_ctr_ev[lru]) == hipSuccess : hipDeviceSynchronize() == hipSuccess;
+        if (over) {
             slot = lru;
             h->kh_ctr_stream[slot] = s;
         } else {
@@ -1931,7 +1957,7 @@ static BftClaimCtr claim_counters(bft_gpu* h, hipStream_t s, uint64_t n, uint64_
 static void claims_launched(bft_gpu* h, hipStream_t s) {
     const int slot = h->kh_ctr_pending;
     h->kh_ctr_pending = -1;
-    if (slot < 0 || h->kh_ctr_used < bft_gpu::KH_CTR_SLOTS) return;  // (no event traffic until the slots are all in use)
+    if (slot < 0 || h->kh_ctr_used < bft_gpu::KH_CTR_SLOTS / 2) return;  // (no event traffic on a handle that is queried on a few streams)
     if (!h->kh_ctr_ev[slot] && hipEventCreateWithFlags(&h->kh_ctr_ev[slot], hipEventDisableTiming) != hipSuccess) { h->kh_ctr_ev[slot] = nullptr; (void)hipGetLastError(); return; }
     if (hipEventRecord(h->kh_ctr_ev[slot], s) != hipSuccess) (void)hipGetLastError();
 }

@@ -2,6 +2,14 @@
 // Device code of libbft_gpu.so, included by bft_gpu.hip only (one translation unit: the kernels are templates launched from
 // the host code there).
 #pragma once
+// a log of composites back into T-form k-mers and their ids (in place + the id array)
+__global__ void k_log_decompose(uint64_t* __restrict__ log_k, uint64_t n, uint32_t cgb, uint32_t* __restrict__ log_g) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = log_k[i];
+        log_g[i] = (uint32_t)(c & ((1ull << cgb) - 1ull));
+        log_k[i] = c >> cgb;
+    }
+}
 __global__ void k_iota(uint32_t* p, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
 }

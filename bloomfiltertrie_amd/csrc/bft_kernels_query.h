@@ -30,14 +30,6 @@ __global__ __launch_bounds__(BFT_BLOCK) void k_pack_to_tform(const uint8_t* __re
         gout[off + i] = gid;
     }
 }
-// a log of composites back into T-form k-mers and their ids (in place + the id array)
-static __global__ void k_log_decompose(uint64_t* __restrict__ log_k, uint64_t n, uint32_t cgb, uint32_t* __restrict__ log_g) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t c = log_k[i];
-        log_g[i] = (uint32_t)(c & ((1ull << cgb) - 1ull));
-        log_k[i] = c >> cgb;
-    }
-}
 
 // The hash table (64 KiB) and the root node's bit-sliced Bloom block and CC headers live in LDS:
 // every query of a batch reads them, and a divergent LDS read costs a few cycles where a divergent

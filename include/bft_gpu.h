@@ -50,8 +50,12 @@ const char* bft_gpu_version(void);
  * the reference's un-seeded rand() values (include/CC.h:246-248) unless r1/r2 > 0 are given. */
 int bft_gpu_create(int k, int device, bft_gpu** out);
 int bft_gpu_create_seeded(int k, int device, int r1, int r2, bft_gpu** out);
-/* freeBFT_Root (include/CC.h:260-268) / free_cdbg (include/bft.h:63) */
+/* freeBFT_Root (include/CC.h:260-268) / free_cdbg (include/bft.h:63).  The handle's device blocks go to the library's cache of released
+ * blocks (bounded: BFT_GPU_POOL_MAX_MB, by default an eighth of the device's memory), where the next handle's build finds them. */
 void bft_gpu_free(bft_gpu* h);
+/* Gives every cached device block back to the HIP runtime (for a process that has finished building and wants the memory for something else --
+ * torch's allocator cannot see these blocks); returns the bytes released.  No reference counterpart: free() is the reference's only allocator. */
+uint64_t bft_gpu_cache_release(void);
 
 /* add_genomes_BFT_Root (include/CC.h:307-338): register a genome name; returns its id in *id_genome
  * (ids are 0-based and increase, as the reference's nb_genomes-1). */

@@ -843,12 +843,24 @@ def test_claim_counters_survive_an_unfinished_launch(k):
 
 
 @pytest.mark.gpu
+def _hip_runtime():
+    """the HIP runtime this process already has loaded (torch's): raw streams beyond torch's pool of 32"""
+    import ctypes
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return ctypes.CDLL(line.split()[-1])
+    raise RuntimeError("no libamdhip64 mapped")
+
+
 def test_more_streams_than_claim_slots():
-    """A handle keeps a claim counter for 32 streams; a 33rd stream takes over the least recently used slot once that slot's last launch is over
-    (rounds 3-4 sent every launch beyond the 32nd stream down the static split for the life of the handle).  48 streams, each queried twice:
-    same bits everywhere, and no launch that had to run static once the earlier ones have drained."""
+    """A handle keeps a claim counter for 32 streams; a further stream takes over the least recently used slot once that slot's last launch is over
+    (rounds 3-4 sent every launch beyond the 32nd stream down the static split for the life of the handle).  Streams made with hipStreamCreate
+    (torch.cuda.Stream() hands out a pool of 32 again and again): 40 streams used once and DESTROYED -- a request-per-stream server --, then 40 new
+    ones, each queried twice: same bits everywhere, and not one launch that ran static."""
+    import ctypes
     import torch
     from bloomfiltertrie_amd import BFT
+    hip = _hip_runtime()
     k = 27
     anc = S.random_genome(150000, 9)
     km = S.distinct(S.kmers_of(anc, k))
@@ -860,18 +872,38 @@ def test_more_streams_than_claim_slots():
     dq = torch.from_numpy(q).cuda()
     nq = len(q)
     ref = None
-    streams = [torch.cuda.Stream() for _ in range(48)]
+    seen = set()
+
+    def new_stream():
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        return st
+
+    def ask(st):
+        nonlocal ref
+        bits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        t.query_presence_dev(dq.data_ptr(), nq, bits.data_ptr(), st.value)
+        assert hip.hipStreamSynchronize(st) == 0
+        got = bits.cpu().numpy()
+        if ref is None:
+            ref = got
+            assert (S.from_bits(ref[: (nq + 7) // 8], nq) == S.member(q, km)).all()
+        assert (got == ref).all()
+
+    for _ in range(40):  # one request, one stream
+        st = new_stream()
+        seen.add(st.value)
+        ask(st)
+        assert hip.hipStreamDestroy(st) == 0
+    streams = [new_stream() for _ in range(40)]
     for rnd in range(2):
         for st in streams:
-            bits = torch.zeros(((nq + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            t.query_presence_dev(dq.data_ptr(), nq, bits.data_ptr(), st.cuda_stream)
-            st.synchronize()
-            got = bits.cpu().numpy()
-            if ref is None:
-                ref = got
-                assert (S.from_bits(ref[: (nq + 7) // 8], nq) == S.member(q, km)).all()
-            assert (got == ref).all()
+            seen.add(st.value)
+            ask(st)
+    for st in streams:
+        assert hip.hipStreamDestroy(st) == 0
+    assert len(seen) > 32  # (more distinct streams than slots: the slots did change hands)
     assert t.build_time()["claims_static_launches"] == 0
     t.close()
 
