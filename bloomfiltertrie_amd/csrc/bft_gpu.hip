@@ -755,14 +755,17 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
     // passes over the key words, least significant word (W-1) first
     for (int w = W - 1; w >= 0; w--) {
         const int nbits = (w == 0) ? (2 * h->k - 64 * (W - 1)) : 64;
-        hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, keys + (uint64_t)w * stride, perm.as<uint32_t>(), ku.as<uint64_t>(), total);
+        const uint64_t* kin = keys + (uint64_t)w * stride;
+        if (w != W - 1 || !g_already_ordered) {  // (the first pass of an id-ordered log: the permutation is still the identity, the word is sorted where it lies)
+            hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, kin, perm.as<uint32_t>(), ku.as<uint64_t>(), total);
+            kin = ku.as<uint64_t>();
+        }
         size_t tb = tmp.bytes;
-        BFT_RADIX_SORT(0, nbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
+        BFT_RADIX_SORT(0, nbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin, ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
         perm.swap(perm2);
     }
-    for (int w = 0; w < W; w++)
-        hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, keys + (uint64_t)w * stride, perm.as<uint32_t>(), okeys + (uint64_t)w * ostride, total);
-    hipLaunchKernelGGL(k_gather<uint32_t>, dim3(grid), dim3(256), 0, h->stream, g, perm.as<uint32_t>(), og, total);
+    // (one pass over the permutation for every word and the id, instead of a pass each)
+    hipLaunchKernelGGL(k_gather_pairs, dim3(grid), dim3(256), 0, h->stream, keys, stride, W, g, perm.as<uint32_t>(), okeys, ostride, og, total);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     return 0;

@@ -18,6 +18,16 @@ __global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ 
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
 }
 
+// the sorted pairs: every key word and the genome id of entry perm[i] (SoA in, SoA out)
+__global__ void k_gather_pairs(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, const uint32_t* __restrict__ perm,
+                               uint64_t* __restrict__ okeys, uint64_t ostride, uint32_t* __restrict__ og, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = perm[i];
+        for (int w = 0; w < W; w++) okeys[(uint64_t)w * ostride + i] = keys[(uint64_t)w * stride + p];
+        og[i] = g[p];
+    }
+}
+
 // sorted (T, g) pairs -> head-of-k-mer flag and keep-pair flag
 __global__ void k_flags(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, uint64_t n,
                         uint32_t* __restrict__ head, uint32_t* __restrict__ keep) {
