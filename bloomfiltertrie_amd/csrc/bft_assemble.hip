@@ -548,6 +548,14 @@ __global__ __launch_bounds__(ABLK) void k_bloom_slice(const uint32_t* __restrict
     }
 }
 
+// the per-depth segments into the final arrays (every size is a multiple of 4 bytes)
+struct ConcatJob { uint32_t* dst; const uint32_t* src; uint64_t words; };
+struct ConcatJobs { ConcatJob j[8 * 14]; int n; };  // (k <= 126: 14 levels at most, 8 arrays each)
+__global__ __launch_bounds__(ABLK) void k_concat(const ConcatJobs jobs) {
+    const ConcatJob j = jobs.j[blockIdx.y];
+    for (uint64_t i = blockIdx.x * (uint64_t)ABLK + threadIdx.x; i < j.words; i += (uint64_t)gridDim.x * ABLK) j.dst[i] = j.src[i];
+}
+
 struct Seg {  // per-depth output segments, concatenated at the end
     DevBuf nodes, bfT, ccs, f2w, clus, child, uck, ucrow;
     uint64_t n_nodes = 0, n_bf8 = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_uc = 0;
@@ -815,9 +823,13 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
     CK(out.child.alloc(T_child * 8));
     CK(out.uck.alloc(T_uc * W * 8));
     CK(out.ucrow.alloc(T_uc * 4));
+    // one kernel for every (depth, array) piece: up to 8 L stream-ordered copies of a few microseconds each cost their launch gaps
     uint64_t o_n = 0, o_b = 0, o_c = 0, o_f = 0, o_q = 0, o_e = 0, o_u = 0;
+    ConcatJobs jobs;
+    jobs.n = 0;
+    uint64_t most = 0;
     for (Seg& g : segs) {
-#define CP(dst, src, off, nbytes) if (nbytes) HIPCK(hipMemcpyAsync((uint8_t*)(dst).p + (off), (src).p, (nbytes), hipMemcpyDeviceToDevice, s))
+#define CP(dst, src, off, nbytes) if (nbytes) { jobs.j[jobs.n++] = ConcatJob{(uint32_t*)((uint8_t*)(dst).p + (off)), (const uint32_t*)(src).p, (uint64_t)(nbytes) / 4}; most = std::max<uint64_t>(most, (uint64_t)(nbytes) / 4); }
         CP(out.nodes, g.nodes, o_n * sizeof(BftNode), g.n_nodes * sizeof(BftNode));
         CP(out.bfT, g.bfT, o_b * 8, g.n_bf8 * 8);
         CP(out.ccs, g.ccs, o_c * sizeof(BftCC), g.n_ccs * sizeof(BftCC));
@@ -829,7 +841,12 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
 #undef CP
         o_n += g.n_nodes; o_b += g.n_bf8; o_c += g.n_ccs; o_f += g.n_f2w; o_q += g.n_clus; o_e += g.n_child; o_u += g.n_uc;
     }
-    HIPCK(hipStreamSynchronize(s));
+    if (jobs.n) {
+        const unsigned gx = (unsigned)std::min<uint64_t>(1024, std::max<uint64_t>(1, (most + ABLK * 4 - 1) / (ABLK * 4)));
+        hipLaunchKernelGGL(k_concat, dim3(gx, (unsigned)jobs.n), dim3(ABLK), 0, s, jobs);
+        HIPCK(hipGetLastError());
+    }
+    // (no wait: the segments go back to the cache under this stream's tag, and the caller goes on in this stream)
     out.n_nodes = T_nodes; out.n_ccs = T_ccs; out.n_f2w = T_f2w; out.n_clus = T_clus; out.n_child = T_child; out.n_bf8 = T_bf8; out.n_uc = T_uc;
     return 0;
 }
@@ -861,36 +878,62 @@ __global__ void k_ccx(const BftCC* __restrict__ ccs, const uint32_t* __restrict_
 
 #define FLAT_MAX_F2W 352  // filter2 words of one CC: ceil(2^14 / 48) = 342 (s = 4), 22 (s = 8)
 
-// one workgroup per flat CC: walk the clusters in p_u order, emit every prefix entry in r order and set bit r
-__global__ __launch_bounds__(ABLK) void k_flat_fill(const BftCCX* __restrict__ ccx, uint32_t C, const uint64_t* __restrict__ f2w, const uint64_t* __restrict__ clus,
-                                                    const uint64_t* __restrict__ child, uint64_t* __restrict__ f18, uint64_t* __restrict__ fent) {
-    __shared__ uint32_t wpos[FLAT_MAX_F2W];
+// One workgroup per flat CC: walk the clusters in p_u order, emit every prefix entry in r order and set bit r.  A work item is a QUARTER of a
+// filter2 word (12 of its 48 prefixes): 1024 threads with a dozen clusters each, where a thread per word walked up to 96 one after the other
+// (0.36 ms for config 3's 21 root CCs, all of it latency).
+#define FLAT_BLK 1024
+#define FLAT_Q 4                                    // items per filter2 word
+#define FLAT_QBITS (BFT_F2_BITS_PER_WORD / FLAT_Q)  // 12
+static_assert(BFT_F2_BITS_PER_WORD % FLAT_Q == 0, "a filter2 word splits into equal parts");
+__global__ __launch_bounds__(FLAT_BLK) void k_flat_fill(const BftCCX* __restrict__ ccx, uint32_t C, const uint64_t* __restrict__ f2w, const uint64_t* __restrict__ clus,
+                                                        const uint64_t* __restrict__ child, uint64_t* __restrict__ f18, uint64_t* __restrict__ fent) {
+    __shared__ uint32_t ipos[FLAT_MAX_F2W * FLAT_Q];
+    __shared__ uint32_t wtot[FLAT_BLK / 64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     for (uint32_t c = blockIdx.x; c < C; c += gridDim.x) {
         const BftCCX cc = ccx[c];
         if (!cc.flat) continue;  // uniform over the workgroup
-        const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD;
-        for (uint32_t w = threadIdx.x; w < nw; w += ABLK) {
+        const uint32_t nw = ((1u << (18 - cc.s)) + BFT_F2_BITS_PER_WORD - 1) / BFT_F2_BITS_PER_WORD, ni = nw * FLAT_Q;
+        // entries of every item
+        for (uint32_t it = threadIdx.x; it < ni; it += FLAT_BLK) {
+            const uint32_t w = it / FLAT_Q, q = it % FLAT_Q;
             const uint64_t fw = f2w[cc.f2_off + w];
-            uint64_t bits = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
-            uint32_t clu = (uint32_t)(fw >> 48), n = 0;
+            const uint64_t all = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+            uint64_t bits = (all >> (q * FLAT_QBITS)) & ((1ull << FLAT_QBITS) - 1ull);
+            uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(all & ((1ull << (q * FLAT_QBITS)) - 1ull)), n = 0;
             for (; bits; bits &= bits - 1, clu++) {
                 const uint64_t e = clus[cc.clus_off + clu];
                 n += (e & BFT_CLUS_MULTI) ? (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
             }
-            wpos[w] = n;
+            ipos[it] = n;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            for (uint32_t w = 0; w < nw; w++) { const uint32_t n = wpos[w]; wpos[w] = acc; acc += n; }
+        // exclusive scan of ipos[0, ni): a run of `per` items per thread, wavefront scans of the runs' sums, the wavefronts' totals by the first lanes
+        {
+            const uint32_t per = (ni + FLAT_BLK - 1) / FLAT_BLK, i0 = threadIdx.x * per, i1 = i0 + per < ni ? i0 + per : ni;
+            uint32_t sum = 0;
+            for (uint32_t i = i0; i < i1; i++) sum += ipos[i];
+            uint32_t inc = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(inc, d);
+                if ((int)lane >= d) inc += v;
+            }
+            if (lane == 63) wtot[wv] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t v = 0; v < wv; v++) base += wtot[v];
+            uint32_t acc = base + inc - sum;
+            for (uint32_t i = i0; i < i1; i++) { const uint32_t n = ipos[i]; ipos[i] = acc; acc += n; }
         }
         __syncthreads();
-        for (uint32_t w = threadIdx.x; w < nw; w += ABLK) {
+        for (uint32_t it = threadIdx.x; it < ni; it += FLAT_BLK) {
+            const uint32_t w = it / FLAT_Q, q = it % FLAT_Q;
             const uint64_t fw = f2w[cc.f2_off + w];
-            uint64_t bits = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
-            uint32_t clu = (uint32_t)(fw >> 48), pos = wpos[w];
+            const uint64_t all = fw & ((1ull << BFT_F2_BITS_PER_WORD) - 1ull);
+            uint64_t bits = (all >> (q * FLAT_QBITS)) & ((1ull << FLAT_QBITS) - 1ull);
+            uint32_t clu = (uint32_t)(fw >> 48) + (uint32_t)__builtin_popcountll(all & ((1ull << (q * FLAT_QBITS)) - 1ull)), pos = ipos[it];
             for (; bits; bits &= bits - 1, clu++) {
-                const uint32_t pu = w * BFT_F2_BITS_PER_WORD + (uint32_t)__builtin_ctzll(bits);
+                const uint32_t pu = w * BFT_F2_BITS_PER_WORD + q * FLAT_QBITS + (uint32_t)__builtin_ctzll(bits);
                 const uint64_t e = clus[cc.clus_off + clu];
                 const uint32_t len = (e & BFT_CLUS_MULTI) ? (uint32_t)((e >> BFT_CLUS_LEN_SHIFT) & 0xFFFFu) : 1u;
                 for (uint32_t j = 0; j < len; j++) {
@@ -1251,9 +1294,11 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
     CK(foff.alloc(n_ccs * 4));
     const dim3 grid(bft_grid_for((n_ccs + ABLK - 1) / ABLK)), block(ABLK);
     hipLaunchKernelGGL(k_flat_flags, grid, block, 0, s, d_ccs, C, flat_min, flag.as<uint32_t>(), cnt.as<uint32_t>());
-    uint64_t nflat = 0;
-    CK(scan.run(flag.as<uint32_t>(), fidx.as<uint32_t>(), n_ccs, &nflat));
-    CK(scan.run(cnt.as<uint32_t>(), foff.as<uint32_t>(), n_ccs, &n_fent));
+    CK(scan.enqueue(flag.as<uint32_t>(), fidx.as<uint32_t>(), n_ccs, 0));
+    CK(scan.enqueue(cnt.as<uint32_t>(), foff.as<uint32_t>(), n_ccs, 1));
+    CK(scan.wait());  // (one wait for both counts)
+    const uint64_t nflat = scan.get(0);
+    n_fent = scan.get(1);
     n_f18 = nflat * BFT_F18_WORDS;
     if (n_f18 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "flat prefix bitmaps exceed 2^32 words");
     CK(f18.alloc_zero(n_f18 * 8, s));
@@ -1261,12 +1306,11 @@ int bft_flatten_gpu(const BftCC* d_ccs, uint64_t n_ccs, const uint64_t* d_f2w, c
     hipLaunchKernelGGL(k_ccx, grid, block, 0, s, d_ccs, flag.as<uint32_t>(), fidx.as<uint32_t>(), foff.as<uint32_t>(), C, ccx.as<BftCCX>());
     if (nflat) {
         const dim3 g2((unsigned)std::min<uint64_t>(n_ccs, 65535));
-        hipLaunchKernelGGL(k_flat_fill, g2, block, 0, s, ccx.as<BftCCX>(), C, d_f2w, d_clus, d_child, f18.as<uint64_t>(), fent.as<uint64_t>());
+        hipLaunchKernelGGL(k_flat_fill, g2, dim3(FLAT_BLK), 0, s, ccx.as<BftCCX>(), C, d_f2w, d_clus, d_child, f18.as<uint64_t>(), fent.as<uint64_t>());
         hipLaunchKernelGGL(k_flat_ranks, g2, block, 0, s, ccx.as<BftCCX>(), C, f18.as<uint64_t>());
     }
     HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s));
-    return 0;
+    return 0;  // (no wait: the caller goes on in this stream, and what is released here is handed out again in its order)
 }
 
 // Interning of the colour sets (sorted genome-id list of each distinct k-mer, CSR seg_off/pg) into a dictionary: a 64-bit signature

@@ -1678,6 +1678,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         static void run(void* c, hipStream_t s) { KhStart* k = (KhStart*)c; kh_start(k->h, k->tk, k->tcol, k->nk, k->n_sets, *k->f, s, nullptr); }
     } khs{h, tk.as<uint64_t>(), n_tcol.as<uint32_t>(), nk, n_sets, &khf};
     // (started HERE instead -- beside the root's table passes -- the sort-based table build was measured too: 17.2-18.4 ms against 17.0)
+    // (and earlier still -- behind the root's prefix scans, or before them: 15.7 ms each way, round 5: the build is bound by the device's total work,
+    // not by either stream's chain)
     const BftAssembleHook hook{tk.p ? &KhStart::run : nullptr, &khs};
     bft_trace_mark("merge / bookkeeping");
     bft_stage("merge into the index", 0, h->stream);
