@@ -589,7 +589,8 @@ def main():
         try:
             from tools import bench_insert
             ia = argparse.Namespace(k=k, genomes=genomes, genome_len=args.genome_len, snp_rate=args.snp_rate, sample=400_000, reserve=True, sync_inserts=False,
-                                    add_genome=False, opt=[], stages=True, warm_pool=False, cpu_baseline=0 if args.no_cpu_baseline else 8)
+                                    add_genome=False, opt=[], stages=True, warm_pool=True, cpu_baseline=0 if args.no_cpu_baseline else 8)  # (warm_pool: the same build once before,
+            # on a handle that is closed again -- the steady state of a process that builds repeatedly: every block size of this build is in the library's cache)
             out["insert"] = bench_insert.measure(ia)
         except Exception as e:
             out["insert"] = {"error": repr(e)}

@@ -2629,6 +2629,7 @@ extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
     if (!path || !out) return fail(BFT_GPU_E_ARG, "NULL argument");
     *out = nullptr;
     DeviceScope ds_;
+    const double t_load0 = now_ms();
     BftFileContent fc;
     std::string err;
     try {  // sizes come from an untrusted file: an allocation failure is an I/O error of this call, not the end of the process
@@ -2651,9 +2652,15 @@ extern "C" int bft_gpu_load_bft(const char* path, int device, bft_gpu** out) {
             (void)log_reserve(h, pairs);  // (a failure here only means the log grows as usual)
         }
     }
+    static const bool io_trace = getenv("BFT_GPU_TRACE_IO") != nullptr;
+    const double t_io0 = now_ms();
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms load: file decoded, handle created, log reserved\n", t_io0 - t_load0);
     for (size_t g = 0; g < fc.per_genome.size() && rc == 0; g++)
         if (!fc.per_genome[g].empty()) rc = bft_gpu_insert_kmers(h, fc.per_genome[g].data(), fc.per_genome[g].size() / B, (uint32_t)g);
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms load: every genome's k-mers inserted (host batches)\n", now_ms() - t_io0);
     if (rc == 0) rc = bft_gpu_build(h);
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms load: index built\n", now_ms() - t_io0);
+    bft_dispose_async(fc);  // (the decoded k-mers of every genome)
     if (rc != 0) {
         const std::string keep = g_err;
         bft_gpu_free(h);
@@ -2728,6 +2735,8 @@ extern "C" int bft_gpu_write_bft(bft_gpu* h, const char* path) {
     } catch (const std::exception& e) {
         return fail(BFT_GPU_E_IO, std::string("write_BFT: ") + e.what());
     }
+    if (io_trace) fprintf(stderr, "[bft_gpu io] %8.1f ms write: file written and closed\n", now_ms() - t_io0);
+    bft_dispose_async(hi);  // (the host copy of the image: gigabytes of vectors)
     return BFT_GPU_OK;
 }
 
