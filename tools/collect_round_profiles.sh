@@ -48,5 +48,6 @@ cp gpurun_out/pmc/config5/kernel_stats.txt "$OUT/config5_kernel_stats.txt"
 tools/microbench/gather 2 64 1024 8192 > "$OUT/microbench_gather.jsonl" 2>&1
 tools/microbench/stream > "$OUT/microbench_stream.jsonl" 2>&1
 [ -x tools/microbench/seg_sort ] && tools/microbench/seg_sort > "$OUT/microbench_seg_sort.jsonl" 2>&1
+[ -x tools/microbench/kh_sort ] && tools/microbench/kh_sort > "$OUT/microbench_kh_sort.jsonl" 2>&1
 python3 tools/probe_fill.py 27 2>&1 | strip | grep "^{" > "$OUT/kmer_hash_build.json"
 ls -la "$OUT"
