@@ -785,3 +785,14 @@ def test_closed_handles_leave_their_blocks_in_the_cache():
     assert released > len(km) * 8  # (the closed handles' table alone is that large)
     assert torch.cuda.mem_get_info()[0] >= free0 + released // 2
     assert cache_release() == 0
+    # with a handle alive: the transients of its build are cached under its own stream; released, and the handle builds on
+    t = BFT(k)
+    t.insert_kmers(km, 0)
+    t.build()
+    assert cache_release() > 0
+    t.insert_kmers(km[::3], 1)
+    t.build()
+    assert (S.from_bits(t.query_presence(q), len(q)) == answers[0]).all()
+    _, off, ids = t.query_colors(km[:3])  # (k-mer 0 is in both genomes, 1 and 2 in the first only)
+    assert off.tolist() == [0, 2, 3, 4] and ids[:4].tolist() == [0, 1, 0, 0]
+    t.close()
