@@ -140,7 +140,9 @@ int bft_gpu_query_sequences_dev(bft_gpu* h, const void* d_seqs, const void* d_se
 
 /* load_BFT / read_BFT_Root (include/bft.h:176, src/write_to_disk.c:260-776): parse a reference .bft file
  * (compressed == 0; annotation modes 0/1/2 and extended-annotation bytes) and build the GPU image from its
- * k-mers and colour sets, with the file's Bloom seeds and genome names. */
+ * k-mers and colour sets, with the file's Bloom seeds and genome names.  The file is mapped and decoded by a pool of host threads
+ * (BFT_GPU_IO_THREADS); it must not be truncated by another process while the call runs (a mapped page that no longer exists is a SIGBUS, as
+ * with any mmap reader).  Both calls give the host memory they used back on a detached thread after they have returned. */
 int bft_gpu_load_bft(const char* path, int device, bft_gpu** out);
 /* write_BFT / write_BFT_Root (include/bft.h:175, src/write_to_disk.c:21-258): serialise the image in the
  * reference's container layout so that the reference's `bft load` reads it back (invariants of SURVEY.md A.7). */
