@@ -60,20 +60,22 @@ __global__ __launch_bounds__(256) void k_color_fill_cs(const uint32_t* __restric
         uint32_t src = 0;
         if (valid && b > a) src = cs_off[cs[i]];
         const uint64_t base = __shfl(a, 0), end = __shfl(b, 63);
-        for (uint64_t e0 = base; e0 < end; e0 += 64) {
-            const uint64_t e = e0 + lane;
-            const bool in = e < end;
-            const uint64_t ee = in ? e : end - 1;
-            uint32_t lo = 0, hi = 63;  // the last lane whose list starts at or before ee (starts are non-decreasing over the lanes)
+        // (positions relative to the wavefront's first: 64 lists of < 2^24 ids each fit 32 bits -- one shuffle per step of the search, not two)
+        const uint32_t ar = (uint32_t)(a - base), span = (uint32_t)(end - base);
+        for (uint32_t r0 = 0; r0 < span; r0 += 64) {
+            const uint32_t r = r0 + lane;
+            const bool in = r < span;
+            const uint32_t rr = in ? r : span - 1;
+            uint32_t lo = 0, hi = 63;  // the last lane whose list starts at or before rr (starts are non-decreasing over the lanes)
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
-                const uint64_t am = __shfl(a, mid);
-                if (am <= ee) lo = mid; else hi = mid - 1;
+                const uint32_t am = __shfl(ar, mid);
+                if (am <= rr) lo = mid; else hi = mid - 1;
             }
-            const uint64_t as = __shfl(a, lo);
+            const uint32_t as = __shfl(ar, lo);
             const uint32_t ss = __shfl(src, lo);
-            if (in) ids[e] = bft_cs_id_at(cs_ids, cs_w, ss + (uint32_t)(e - as));
+            if (in) ids[base + r] = bft_cs_id_at(cs_ids, cs_w, ss + (r - as));
         }
     }
 }
