@@ -8,6 +8,7 @@ import ctypes as C
 import os
 import random
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -171,3 +172,12 @@ def test_reference_shaped_annotations(oracle_mod, hostlib, tmp_path, k, levels, 
     assert kk == k and n == len(S.distinct(np.concatenate(gk)))
     for g in range(ngen):
         assert sorted(S.row_keys(per[g]).tolist()) == sorted(S.row_keys(gk[g]).tolist())
+
+
+def test_reader_survives_mutated_files(hostlib):
+    """tools/fuzz_bft_reader.py: truncated files, flipped bytes and extreme values in 2- and 4-byte fields of valid files at five k / depth
+    combinations -- the reader rejects or accepts each one without crashing (a batch runs in a process of its own: a crash fails the run)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_bft_reader.py"), "2", "120", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert b"fuzz OK" in r.stdout
