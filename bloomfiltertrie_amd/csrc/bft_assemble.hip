@@ -574,17 +574,26 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
     uint64_t M = 1;
     uint64_t T_nodes = 0, T_ccs = 0, T_f2w = 0, T_clus = 0, T_child = 0, T_bf8 = 0, T_uc = 0;
 #define G(nelem) dim3(bft_grid_for(((uint64_t)(nelem) + ABLK - 1) / ABLK)), dim3(ABLK), 0, s
+    // Waits for counts per depth: prefixes + keys, CCs, clusters + child nodes, Bloom blocks (+ the child entries and the NEXT depth's active rows,
+    // read with that last one: their arrays are sized by an upper bound / prepared a depth early) -- four, where rounds 3-4 took six or seven.
+    DevBuf nsz_c, node_off_c;  // the next depth's node sizes and their scan, prepared behind this depth's entries
+    uint64_t A_c = 0;
     for (int d = 0; d < L && M > 0; d++) {
         const int last_level = d == L - 1;
         Seg sg;
         // ---- active rows ----
         DevBuf nsz, node_off;
-        CK(nsz.alloc(M * 4));
-        CK(node_off.alloc((M + 1) * 4));
-        hipLaunchKernelGGL(k_sizes, G(M), nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), nsz.as<uint32_t>(), (uint32_t)M);
-        CK(scan.enqueue(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, 0, true));
-        if (d) CK(scan.wait());  // (the root's rows are all of them: nothing to wait for; the slot is written again only behind this scan)
-        const uint64_t A = d ? scan.get(0) : n;
+        uint64_t A = n;  // (the root's rows are all of them)
+        if (d == 0) {
+            CK(nsz.alloc(M * 4));
+            CK(node_off.alloc((M + 1) * 4));
+            hipLaunchKernelGGL(k_sizes, G(M), nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), nsz.as<uint32_t>(), (uint32_t)M);
+            CK(scan.enqueue(nsz.as<uint32_t>(), node_off.as<uint32_t>(), M, 0, true));  // (nothing to wait for; the slot is written again only behind this scan)
+        } else {
+            nsz.swap(nsz_c);
+            node_off.swap(node_off_c);
+            A = A_c;
+        }
         bft_trace_mark("  level: active rows");
         const std::string lv = "containers depth " + std::to_string(d) + ": ";
         bft_stage((lv + "active rows").c_str(), (double)M * 12, s);
@@ -746,23 +755,23 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(clus_len.alloc(Q * 4));
         CK(multi.alloc(Q * 4));
         CK(cpos.alloc(Q * 4));
-        uint64_t E = 0;
         if (Q) {
             hipLaunchKernelGGL(k_cluster_scatter, G(P), chead.as<uint32_t>(), cidx.as<uint32_t>(), (uint32_t)P, clus_q.as<uint32_t>());
             hipLaunchKernelGGL(k_cluster_len, G(Q), clus_q.as<uint32_t>(), (uint32_t)Q, skey_s.as<uint64_t>(), node_ccb.as<uint32_t>(), cc_qe.as<uint32_t>(),
                                clus_len.as<uint32_t>(), multi.as<uint32_t>());
-            CK(scan.run(multi.as<uint32_t>(), cpos.as<uint32_t>(), Q, &E));
         }
+        // (E, the entries of the multi-prefix clusters, is read with the depth's last counts: every prefix lies in one cluster, so P bounds it)
+        CK(scan.enqueue(multi.as<uint32_t>(), cpos.as<uint32_t>(), Q, 2));
         bft_trace_mark("  level: clusters");
         bft_stage((lv + "clusters").c_str(), (double)P * 8 + (double)Q * 24, s);
-        if (T_f2w + F2 > 0xFFFFFFFFull || T_clus + Q > 0xFFFFFFFFull || T_child + E > 0xFFFFFFFFull || T_uc + UCR > 0xFFFFFFFFull)
+        if (T_f2w + F2 > 0xFFFFFFFFull || T_clus + Q > 0xFFFFFFFFull || T_uc + UCR > 0xFFFFFFFFull)
             return bft_fail(BFT_GPU_E_LIMIT, "index array offset overflow (u32)");
 
         // ---- outputs of this depth ----
         CK(sg.ccs.alloc(C * sizeof(BftCC)));
         CK(sg.f2w.alloc_zero(F2 * 8, s));
         CK(sg.clus.alloc(Q * 8));
-        CK(sg.child.alloc(E * 8));
+        CK(sg.child.alloc(P * 8));  // (upper bound; E of them are used and concatenated)
         CK(sg.uck.alloc(UCR * W * 8));
         CK(sg.ucrow.alloc(UCR * 4));
         CK(sg.nodes.alloc(M * sizeof(BftNode)));
@@ -793,9 +802,18 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(scan.run(node_ucn.as<uint32_t>(), node_ucoff.as<uint32_t>(), M, nullptr));
         CK(scan.enqueue(node_bf8.as<uint32_t>(), node_bfoff.as<uint32_t>(), M, 0));
         if (d == 0) CK(scan.publish(node_ucn.as<uint32_t>(), 1, 1));
+        if (Mnext && !last_level) {  // the next depth's node sizes and active rows, a depth early (next_lo / next_hi are k_entries' output)
+            CK(nsz_c.alloc(Mnext * 4));
+            CK(node_off_c.alloc((Mnext + 1) * 4));
+            hipLaunchKernelGGL(k_sizes, G(Mnext), next_lo.as<uint32_t>(), next_hi.as<uint32_t>(), nsz_c.as<uint32_t>(), (uint32_t)Mnext);
+            CK(scan.enqueue(nsz_c.as<uint32_t>(), node_off_c.as<uint32_t>(), Mnext, 3, true));
+        }
         CK(scan.wait());
-        const uint64_t BF8 = scan.get(0);
+        const uint64_t BF8 = scan.get(0), E = scan.get(2);
+        A_c = (Mnext && !last_level) ? scan.get(3) : 0;
         if (d == 0) out.root_uc = scan.get(1);
+        if (E > P) return bft_fail(BFT_GPU_E_LIMIT, "assembly: more cluster entries than prefixes");  // (cannot happen: the bound above)
+        if (T_child + E > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "index array offset overflow (u32)");
         bft_trace_mark("  level: entries, node records");
         bft_stage((lv + "entries, ranks, UC rows, node records").c_str(), (double)P * 60 + (double)(F2 + Q + E) * 8 + (double)UCR * (8.0 * W + 4), s);
         if (T_bf8 + BF8 > 0xFFFFFFFFull) return bft_fail(BFT_GPU_E_LIMIT, "Bloom block offset overflow");
