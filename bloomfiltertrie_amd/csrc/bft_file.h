@@ -1,6 +1,8 @@
 // bft_file.h -- reader / writer of the reference's .bft files; see bft_file.cpp.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+#include <sys/mman.h>
 
 #include <memory>
 #include <string>
@@ -34,10 +36,27 @@ void bft_dispose_async(T& obj) {
 
 // a vector whose resize() leaves trivially constructible elements uninitialised: the big arrays of the host image are filled by a copy from
 // the device right away, and zeroing a gigabyte first is a page fault per 4 KB for nothing
+// ... and blocks of 8 MB and more are 2 MB-aligned and advised to be backed by huge pages (where the kernel grants them on madvise): the copy from
+// the device then faults 512 times fewer pages in, and giving the block back unmaps as many fewer.
 template <class T>
 struct BftDefaultInit : std::allocator<T> {
     template <class U> struct rebind { using other = BftDefaultInit<U>; };
     using std::allocator<T>::allocator;
+    static constexpr size_t HUGE_FROM = (size_t)8 << 20, HUGE_ALIGN = (size_t)2 << 20;
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= HUGE_FROM) {
+            void* p = nullptr;
+            const size_t padded = (bytes + HUGE_ALIGN - 1) / HUGE_ALIGN * HUGE_ALIGN;
+            if (posix_memalign(&p, HUGE_ALIGN, padded) != 0 || !p) throw std::bad_alloc();
+            (void)madvise(p, padded, MADV_HUGEPAGE);
+            return static_cast<T*>(p);
+        }
+        void* p = malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) noexcept { free(p); }
     template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
     template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
 };
