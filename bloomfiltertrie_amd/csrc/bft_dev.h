@@ -40,7 +40,7 @@ int bft_fail(int code, const std::string& msg);  // records the thread's last er
 int bft_pool_alloc(void** p, size_t n, size_t* cap);
 void bft_pool_release(void* p, size_t cap);
 void bft_pool_set_stream(int device, hipStream_t s);  // the stream of the current ABI call (thread-local)
-void bft_pool_drop_stream(hipStream_t s);             // the stream is about to be destroyed: free what it tagged
+void bft_pool_drop_stream(hipStream_t s);             // the stream was synchronised and is about to be destroyed: its blocks stay cached, tagged as drained
 
 struct DevBuf {
     void* p = nullptr;
