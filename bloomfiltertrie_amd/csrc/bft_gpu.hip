@@ -288,6 +288,10 @@ struct bft_gpu {
     // into k-mers + ids first (k_log_decompose).
     bool log_comp = false;
     uint32_t log_gb = 0;
+    // the insert calls behind the log: positions [lb_end[j - 1], lb_end[j]) carry genome lb_gid[j] -- the multi-word sort reads a pair's id out of this
+    // table (a search in a few cached words) instead of gathering it from the log (a fabric request per pair)
+    std::vector<uint64_t> lb_end;
+    std::vector<uint32_t> lb_gid;
     int opt_comp_log = 1;  // "composite_log": 0 = always k-mers + ids (a test hook: same image)
 
     uint64_t n_pairs = 0;  // distinct (k-mer, genome) pairs the index holds = sum of the sizes of its k-mers' colour sets
@@ -645,6 +649,8 @@ static int insert_dev(bft_gpu* h, const void* d_kmers, uint64_t n, uint32_t id_g
     if (h->log_n > 0 && id_genome < h->log_last_gid) h->log_g_sorted = false;
     h->log_last_gid = id_genome;
     h->log_n += n;
+    if (!h->lb_gid.empty() && h->lb_gid.back() == id_genome) h->lb_end.back() = h->log_n;
+    else { h->lb_end.push_back(h->log_n); h->lb_gid.push_back(id_genome); }
     h->max_gid_seen = std::max(h->max_gid_seen, id_genome);
     h->any_insert = true;
     return BFT_GPU_OK;
@@ -700,7 +706,7 @@ static int bits_for(uint64_t v) {
 // Stable LSD sort of `total` entries by (keys word 0..W-1 as one big integer, then g).
 // keys: SoA with stride `stride`.  Result in okeys (stride ostride) / og.
 static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const uint32_t* g, uint64_t total, uint64_t* okeys,
-                      uint64_t ostride, uint32_t* og, bool g_already_ordered) {
+                      uint64_t ostride, uint32_t* og, bool g_already_ordered, bool is_log = false) {
     const int W = h->W;
     const int n = (int)total;
     if (W == 1) {
@@ -764,8 +770,17 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
         BFT_RADIX_SORT(0, nbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin, ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
         perm.swap(perm2);
     }
-    // (one pass over the permutation for every word and the id, instead of a pass each)
-    hipLaunchKernelGGL(k_gather_pairs, dim3(grid), dim3(256), 0, h->stream, keys, stride, W, g, perm.as<uint32_t>(), okeys, ostride, og, total);
+    // (one pass over the permutation for every word and the id, instead of a pass each; the ids of the LOG come out of the table of its insert calls)
+    DevBuf lbe, lbg;
+    uint32_t nlb = 0;
+    if (is_log && !h->lb_end.empty() && h->lb_end.size() <= (1u << 16) && h->lb_end.back() == total) {
+        nlb = (uint32_t)h->lb_end.size();
+        CK(lbe.alloc(nlb * 8));
+        CK(lbg.alloc(nlb * 4));
+        HIPCK(hipMemcpyAsync(lbe.p, h->lb_end.data(), nlb * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(lbg.p, h->lb_gid.data(), nlb * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_gather_pairs, dim3(grid), dim3(256), 0, h->stream, keys, stride, W, g, perm.as<uint32_t>(), okeys, ostride, og, total, lbe.as<uint64_t>(), lbg.as<uint32_t>(), nlb);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     return 0;
@@ -1576,7 +1591,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
         CK(sg.alloc(total * 4));
-        CK(sort_pairs(h, src_k, src_stride, src_g, total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted));
+        CK(sort_pairs(h, src_k, src_stride, src_g, total, sk.as<uint64_t>(), total, sg.as<uint32_t>(), h->log_g_sorted, true));
         ck.release();
         cg.release();
         // (the insertion log stays until the new image is committed below: a failed build loses nothing)
@@ -1763,6 +1778,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
     h->d_tk.swap(tk);
     h->n_pairs = np;
     h->log_n = 0;
+    h->lb_end.clear();
+    h->lb_gid.clear();
     h->log_comp = false;
     h->log_g_sorted = true;
     h->n_kmers = nk;

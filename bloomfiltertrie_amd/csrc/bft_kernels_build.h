@@ -19,12 +19,22 @@ __global__ void k_gather(const T* __restrict__ in, const uint32_t* __restrict__ 
 }
 
 // the sorted pairs: every key word and the genome id of entry perm[i] (SoA in, SoA out)
+// nlb != 0: the id of position p is that of the insert call it came with -- the first of the nlb calls that ends behind p (lb_end ascending)
 __global__ void k_gather_pairs(const uint64_t* __restrict__ keys, uint64_t stride, int W, const uint32_t* __restrict__ g, const uint32_t* __restrict__ perm,
-                               uint64_t* __restrict__ okeys, uint64_t ostride, uint32_t* __restrict__ og, uint64_t n) {
+                               uint64_t* __restrict__ okeys, uint64_t ostride, uint32_t* __restrict__ og, uint64_t n, const uint64_t* __restrict__ lb_end,
+                               const uint32_t* __restrict__ lb_gid, uint32_t nlb) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t p = perm[i];
         for (int w = 0; w < W; w++) okeys[(uint64_t)w * ostride + i] = keys[(uint64_t)w * stride + p];
-        og[i] = g[p];
+        if (nlb) {
+            uint32_t lo = 0, hi = nlb - 1;  // first call with lb_end > p
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (lb_end[mid] > p) hi = mid; else lo = mid + 1;
+            }
+            og[i] = lb_gid[lo];
+        } else
+            og[i] = g[p];
     }
 }
 
