@@ -5,20 +5,29 @@
 // every device-wide sort of it was a rocPRIM / hipCUB call (42 % of a config-3 build's device time).  This is the replacement, written for
 // the part it runs on:
 //
-//   * LSD passes of up to 9 bits, "onesweep" style: ONE read and ONE write of the array per pass, the global position of a tile's keys found
-//     by a decoupled look-back over the tiles before it instead of a second pass over per-tile histograms;
-//   * a tile (THREADS x IPT keys, up to 12288) is RANKED in registers (wavefront ballots: stable by construction), REORDERED IN LDS and
-//     written out by digit runs, so that a digit's keys leave as one contiguous piece instead of one transaction per key;
-//   * the look-back runs in EIGHT INDEPENDENT CHAINS, one per XCD: the input of a pass is cut into eight contiguous ranges, a workgroup takes
-//     its tiles from the range of the XCD it runs on (HW_REG_XCC_ID; any other workgroup may steal: placement is never a matter of
-//     correctness), and the histogram kernel counts per (chain, digit) so that every chain knows where its digits start.  Neighbouring
-//     tiles of a chain write neighbouring pieces of every digit's output: the partial lines at the seams meet in ONE L2 instead of being
-//     written back, byte-masked, by two.  For the passes after the first the chains are ranges of the previous pass's digit (its top
-//     three bits), which the one histogram kernel in front of all passes can count from the keys alone;
+//   * LSD passes of up to 9 bits with ONE read and ONE write of the array per pass ("onesweep"), behind ONE histogram kernel that reads the
+//     keys once for all passes;
+//   * a tile (THREADS x IPT keys, up to 12288) is ranked in registers, REORDERED IN LDS and written out by digit runs, so that a digit's keys
+//     leave as one contiguous piece instead of one transaction per key;
+//   * THE FIRST PASS NEEDS NO LOOK-BACK: the input is cut into one contiguous range of tiles per workgroup, the histogram kernel (same
+//     ranges) counts per (range, digit), a scan over the ranges tells every workgroup where its keys of every digit start, and the workgroup
+//     carries those positions from tile to tile in LDS.  Consecutive tiles of a range write consecutive pieces of every digit's output from
+//     the same CU: the partial lines at their seams meet in one L2;
+//   * the later passes read an array whose order the histogram kernel cannot know, so their tiles find their place by a decoupled
+//     look-back -- but in up to 64 INDEPENDENT CHAINS instead of one: chain c of pass p is the stretch of its input that holds the keys
+//     whose PREVIOUS digit has the top bits c (a contiguous stretch: the previous pass sorted on that digit), and the histogram kernel can
+//     count per (chain, digit) from the keys alone.  A chain is worked on by the few workgroups of one XCD (HW_REG_XCC_ID picks the chains
+//     a workgroup prefers; any workgroup may take any tile, placement is never a matter of correctness), so a look-back is one round trip
+//     of four tile states instead of one per resident workgroup, and neighbouring tiles again share an L2;
 //   * tile states are 32-bit words {flag:2, count:30}, four digits per 16-byte write-through (sc1) store / load (MI355X_MICROARCH.md,
-//     inter-workgroup visibility: narrow sc1 stores are a fabric write each); the aggregate is published before the tile looks back;
-//   * the next tile's keys are loaded into the registers the current tile's keys have just left (they sit in LDS by then), so the memory
-//     system is never idle while a tile is ranked.
+//     inter-workgroup visibility: narrow sc1 stores are a fabric write each); a tile publishes its counts before it looks back;
+//   * tiles are claimed from a counter per chain one tile AHEAD (the returning atomic travels while a tile is worked on), and the next
+//     tile's keys are loaded into the registers the current tile's keys have just left (they sit in LDS by then);
+//   * ranks: a key's rank among the keys of its digit in its wavefront comes from ONE returning LDS atomic per lane on the wavefront's own
+//     counters (rounds of 64 keys: the atomics of a wavefront are served in the order they were issued).  Inside one instruction the
+//     lanes that share a digit are served in lane order on this hardware -- measured, not documented -- which is what makes the sort
+//     stable; bft_rs::rank_mode() checks that behaviour on the device once per process (k_rs_selftest) and every sort falls back to ranks
+//     from wavefront ballots (stable by construction, ~0.35 ms more per pass over 2 x 10^8 keys) if it does not hold or "sort_ballots" is set.
 //
 // n < 2^30 per call (the callers' arrays are rows and pairs counted in 32 bits; the insertion log is flushed before 2^30 pairs).
 #pragma once
@@ -33,30 +42,44 @@ namespace bft_rs {
 
 constexpr int DBITS = 9;
 constexpr int DIGITS = 1 << DBITS;
-constexpr int CHAINS = 8;
 constexpr int MAXP = 8;
+constexpr int MAXCB = 6;  // up to 64 chains
 constexpr uint32_t ST_VAL = 0x3FFFFFFFu;
 constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct NoVal {};
 
 struct Plan {
     int P;
-    uint32_t bit[MAXP], nbits[MAXP], csh[MAXP];  // csh: chain of the NEXT pass = digit >> csh
+    uint32_t bit[MAXP], nbits[MAXP];
+    uint32_t cb[MAXP];    // chains of pass p = 2^cb[p] (p >= 1): the top cb bits of digit p - 1
+    uint32_t hoff[MAXP];  // words: where pass p's counters start in a histogram workgroup's block ([1 or chains][2^nbits])
+    uint32_t hwords;
 };
 static inline Plan make_plan(unsigned begin_bit, unsigned end_bit) {
     Plan pl;
     const unsigned bits = end_bit - begin_bit;
     pl.P = (int)((bits + DBITS - 1) / DBITS);
-    unsigned b = begin_bit;
+    unsigned b = begin_bit, maxnb = 0;
     for (int p = 0; p < pl.P; p++) {
         const unsigned left = end_bit - b, nb = (left + (pl.P - p) - 1) / (pl.P - p);
         pl.bit[p] = b;
         pl.nbits[p] = nb;
-        pl.csh[p] = nb > 3 ? nb - 3 : 0;
+        maxnb = std::max(maxnb, nb);
         b += nb;
     }
-    for (int p = pl.P; p < MAXP; p++) pl.bit[p] = pl.nbits[p] = pl.csh[p] = 0;
+    // chains: as many as the histogram kernel's LDS holds counters for (128 KB), at most 64
+    unsigned cb = MAXCB;
+    while (cb > 0 && (size_t)(pl.P - 1) * ((size_t)1 << (cb + maxnb)) * 4 > 128 * 1024) cb--;
+    uint32_t o = 0;
+    for (int p = 0; p < MAXP; p++) {
+        if (p >= pl.P) { pl.bit[p] = pl.nbits[p] = pl.cb[p] = pl.hoff[p] = 0; continue; }
+        pl.cb[p] = p == 0 ? 0 : std::min<unsigned>(cb, pl.nbits[p - 1]);
+        pl.hoff[p] = o;
+        o += (1u << pl.cb[p]) << pl.nbits[p];
+    }
+    pl.hwords = o;
     return pl;
 }
 
@@ -79,170 +102,200 @@ __device__ __forceinline__ uint32_t digit_of(K key, uint32_t bit, uint32_t mask)
 
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// scratch of one sort call (u32 words)
-struct Layout {
-    size_t heads, states, zero_words;  // [P][CHAINS]; [P][max_tiles][DIGITS]  -- zeroed before every call
-    size_t cnt, base, chain, partial, total_words;
-    uint32_t max_tiles, hist_wgs;
-};
-static inline Layout make_layout(uint64_t n, int P, uint32_t tile, uint32_t hist_wgs) {
-    Layout L;
-    L.max_tiles = (uint32_t)((n + tile - 1) / tile) + CHAINS;
-    L.hist_wgs = hist_wgs;
-    size_t o = 0;
-    L.heads = o; o += (size_t)P * CHAINS;
-    o = (o + 3) & ~(size_t)3;
-    L.states = o; o += (size_t)P * L.max_tiles * DIGITS;
-    L.zero_words = o;
-    L.cnt = o; o += (size_t)P * CHAINS * DIGITS;
-    L.base = o; o += (size_t)P * CHAINS * DIGITS;
-    L.chain = o; o += (size_t)(P + 1) * 2 * (CHAINS + 1);  // per pass: chain_start[9], tile_first[9]
-    o = (o + 3) & ~(size_t)3;
-    L.partial = o; o += (size_t)hist_wgs * P * CHAINS * DIGITS;
-    L.total_words = o;
-    return L;
-}
-
-// ---- histogram of every pass's digits, per (chain, digit), in one read of the keys ------------------------------------------------------
-// grid = CHAINS x wg_per_chain; workgroup (c, i) counts a slice of chain c of the INPUT (chain c = keys [c per0, (c + 1) per0)).
+// ---- histogram of every pass's digits in one read of the keys ---------------------------------------------------------------------------
+// Workgroup r counts range r of the input (tiles [r tpr, (r + 1) tpr)): pass 0 per digit, the later passes per (chain, digit).
 template <class K, class In, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_rs_hist(In in, uint32_t n, Plan pl, uint32_t per0, uint32_t wg_per_chain, uint32_t* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t h[];  // [P][CHAINS][DIGITS]
-    const uint32_t tid = threadIdx.x, words = (uint32_t)pl.P * CHAINS * DIGITS;
-    for (uint32_t i = tid; i < words; i += THREADS) h[i] = 0;
+__global__ __launch_bounds__(THREADS) void k_rs_hist(In in, uint32_t n, Plan pl, uint32_t range_len, uint32_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t h[];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < pl.hwords; i += THREADS) h[i] = 0;
     __syncthreads();
-    const uint32_t c = blockIdx.x / wg_per_chain, wi = blockIdx.x % wg_per_chain;
-    const uint64_t lo64 = (uint64_t)c * per0;
-    const uint32_t lo = (uint32_t)(lo64 < n ? lo64 : n), hi = (uint32_t)(lo64 + per0 < n ? lo64 + per0 : n), len = hi - lo;
+    const uint64_t a64 = (uint64_t)blockIdx.x * range_len;
+    const uint32_t a = (uint32_t)(a64 < n ? a64 : n), b = (uint32_t)(a64 + range_len < n ? a64 + range_len : n);
     constexpr uint32_t U = 8;
-    uint32_t sl = (len + wg_per_chain - 1) / wg_per_chain;
-    sl = (sl + THREADS * U - 1) / (THREADS * U) * (THREADS * U);
-    const uint64_t a64 = (uint64_t)lo + (uint64_t)wi * sl;
-    const uint32_t a = (uint32_t)(a64 < hi ? a64 : hi), b = (uint32_t)(a64 + sl < hi ? a64 + sl : hi);
     for (uint32_t i0 = a; i0 < b; i0 += THREADS * U) {
         K key[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t idx = i0 + u * THREADS + tid;
-            key[u] = idx < b ? in.key(idx) : K(0);
+            key[u] = in.key(idx < b ? idx : a);
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t idx = i0 + u * THREADS + tid;
             if (idx < b) {
-                uint32_t ch = c;
+                uint32_t prev = 0;
                 for (int p = 0; p < pl.P; p++) {
                     const uint32_t d = digit_of(key[u], pl.bit[p], (1u << pl.nbits[p]) - 1u);
-                    atomicAdd(&h[((uint32_t)p * CHAINS + ch) * DIGITS + d], 1u);
-                    ch = d >> pl.csh[p];
+                    const uint32_t ch = p ? prev >> (pl.nbits[p - 1] - pl.cb[p]) : 0u;
+                    atomicAdd(&h[pl.hoff[p] + (ch << pl.nbits[p]) + d], 1u);
+                    prev = d;
                 }
             }
         }
     }
     __syncthreads();
-    uint32_t* out = partial + (size_t)blockIdx.x * words;
-    for (uint32_t i = tid; i < words; i += THREADS) out[i] = h[i];
+    uint32_t* out = partial + (size_t)blockIdx.x * pl.hwords;
+    for (uint32_t i = tid; i < pl.hwords; i += THREADS) out[i] = h[i];
 }
 
-// cnt[w] = sum over the histogram workgroups
-__global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t words, uint32_t* __restrict__ cnt) {
+// the chain counters of the later passes: cnt[w] += sum over a slice of the histogram workgroups (grid.y slices; cnt zeroed)
+__global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t stride, uint32_t first, uint32_t words, uint32_t* __restrict__ cnt) {
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
+    const uint32_t per = (nwg + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * per, g1 = min(nwg, g0 + per);
     uint32_t s = 0;
 #pragma unroll 8
-    for (uint32_t g = 0; g < nwg; g++) s += partial[(size_t)g * words + w];
-    cnt[w] = s;
+    for (uint32_t g = g0; g < g1; g++) s += partial[(size_t)g * stride + first + w];
+    if (s) atomicAdd(&cnt[w], s);
 }
 
-// one workgroup of DIGITS threads per pass: where every (chain, digit) of the pass starts in its output; the chains and tiles of the NEXT pass
-__global__ __launch_bounds__(DIGITS) void k_rs_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base, uint32_t* __restrict__ chain, Plan pl, uint32_t n,
-                                                   uint32_t per0, uint32_t tile) {
-    __shared__ uint32_t wsum[DIGITS / 64];
-    __shared__ uint32_t dbase[DIGITS + 1];
-    const uint32_t p = blockIdx.x, d = threadIdx.x, lane = d & 63u, wave = d >> 6;
-    const uint32_t* c0 = cnt + (size_t)p * CHAINS * DIGITS;
-    uint32_t cc[CHAINS], tot = 0;
+// One workgroup per digit: exclusive scan of the digit's counts over the rows (ranges of pass 0, chains of a later pass), in place; the
+// digit's total.  rows <= 1024.
+__global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ m, uint32_t stride, uint32_t rows, uint32_t* __restrict__ tot) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t v[4], s = 0;
 #pragma unroll
-    for (int c = 0; c < CHAINS; c++) { cc[c] = c0[c * DIGITS + d]; tot += cc[c]; }
-    uint32_t inc = tot;
+    for (int q = 0; q < 4; q++) {
+        const uint32_t r = tid * 4 + q;
+        v[q] = r < rows ? m[(size_t)r * stride + d] : 0u;
+        s += v[q];
+    }
+    uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if ((int)lane >= o) inc += v;
+        const uint32_t x = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += x;
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; w++) before += wsum[w];
-    uint32_t run = before + inc - tot;
-    dbase[d] = run;
-    if (d == DIGITS - 1) dbase[DIGITS] = n;
-    uint32_t* b0 = base + (size_t)p * CHAINS * DIGITS;
+    uint32_t run = inc - s;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
 #pragma unroll
-    for (int c = 0; c < CHAINS; c++) { b0[c * DIGITS + d] = run; run += cc[c]; }
+    for (int q = 0; q < 4; q++) {
+        const uint32_t r = tid * 4 + q;
+        if (r < rows) m[(size_t)r * stride + d] = run;
+        run += v[q];
+    }
+    if (tid == 255) tot[d] = run;
+}
+
+// One workgroup per pass: where every digit starts in the pass's output; the chains and tiles of the NEXT pass.
+// chain table of a pass: start[65], tile_first[65]
+constexpr int CT = 2 * ((1 << MAXCB) + 1);
+__global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict__ tot, uint32_t* __restrict__ dbase, uint32_t* __restrict__ chain, Plan pl, uint32_t n, uint32_t tile) {
+    __shared__ uint32_t wsum[DIGITS / 64];
+    __shared__ uint32_t db[DIGITS + 1];
+    const uint32_t p = blockIdx.x, d = threadIdx.x, lane = d & 63u, wave = d >> 6, nd = 1u << pl.nbits[p];
+    const uint32_t t = d < nd ? tot[p * DIGITS + d] : 0u;
+    uint32_t inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += x;
+    }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    if (d == 0) {
-        // chains of pass p + 1: ranges of this pass's digit; of pass 0: ranges of the input
-        uint32_t* cs = chain + (size_t)(p + 1) * 2 * (CHAINS + 1);
-        const uint32_t ndig = 1u << pl.nbits[p];
-        for (uint32_t c = 0; c <= CHAINS; c++) {
-            const uint32_t first = c << pl.csh[p];
-            cs[c] = (c < CHAINS && first < ndig) ? dbase[first] : n;
-        }
-        uint32_t t = 0;
-        for (uint32_t c = 0; c <= CHAINS; c++) {
-            cs[CHAINS + 1 + c] = t;
-            if (c < CHAINS) t += (cs[c + 1] - cs[c] + tile - 1) / tile;
-        }
-        if (p == 0) {
-            uint32_t* c0s = chain;
-            for (uint32_t c = 0; c <= CHAINS; c++) {
-                const uint64_t v = (uint64_t)c * per0;
-                c0s[c] = (uint32_t)(v < n ? v : n);
-            }
-            t = 0;
-            for (uint32_t c = 0; c <= CHAINS; c++) {
-                c0s[CHAINS + 1 + c] = t;
-                if (c < CHAINS) t += (c0s[c + 1] - c0s[c] + tile - 1) / tile;
-            }
+    uint32_t run = inc - t;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+    db[d] = run;
+    dbase[p * DIGITS + d] = run;
+    __syncthreads();
+    if (p + 1 < (uint32_t)pl.P && d == 0) {
+        uint32_t* cs = chain + (size_t)(p + 1) * CT;
+        const uint32_t nch = 1u << pl.cb[p + 1], sh = pl.nbits[p] - pl.cb[p + 1];
+        for (uint32_t c = 0; c <= nch; c++) cs[c] = c < nch ? db[c << sh] : n;
+        uint32_t tf = 0;
+        for (uint32_t c = 0; c <= nch; c++) {
+            cs[(1 << MAXCB) + 1 + c] = tf;
+            if (c < nch) tf += (cs[c + 1] - cs[c] + tile - 1) / tile;
         }
     }
+}
+
+// ---- do the lanes of one LDS atomic instruction that hit one address get their turns in lane order? ------------------------------------
+__global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) {
+    __shared__ uint32_t c[64];
+    const uint32_t lane = threadIdx.x;
+    uint32_t wrong = 0;
+    c[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t x = 0x9E3779B9u * (blockIdx.x + 1);
+    for (int it = 0; it < 512; it++) {
+        // every lane picks one of `groups` addresses (1 .. 64 groups: from all lanes on one address to a permutation) from a sequence every lane computes
+        x = x * 1664525u + 1013904223u;
+        const uint32_t groups = 1u + ((x >> 9) % 64u);
+        uint32_t y = x ^ (lane * 0x85EBCA6Bu);
+        y ^= y >> 15; y *= 0x2C1B3C6Du; y ^= y >> 12;
+        const uint32_t a = y % groups;
+        const bool on = ((x >> (lane & 31u)) & 1u) || (it & 1);  // some lanes sit out
+        uint32_t r = 0;
+        if (on) r = atomicAdd(&c[a], 1u);
+        // what the ranks must be: my position among the active lanes below me with my address, plus the counter's value before
+        uint64_t peers = __ballot(on);
+        for (int b = 0; b < 6; b++) {
+            const bool bit = (a >> b) & 1u;
+            const uint64_t bj = __ballot(bit);
+            peers &= bit ? bj : ~bj;
+        }
+        const int leader = on ? __builtin_ctzll(peers) : (int)lane;
+        const uint32_t r0 = __shfl(r, leader);
+        if (on && r != r0 + (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull))) wrong++;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (wrong) atomicAdd(bad, wrong);
 }
 
 // ---- one pass --------------------------------------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef BFT_RS_KO
+#define BFT_RS_KO 0  // (microbenchmark only: knock-outs -- 1 no look-back, 2 no stores of the reordered tile; wrong results)
+#endif
 
-template <class K, class V, class In, int THREADS, int IPT>
-__global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, V* __restrict__ ov, uint32_t bit, uint32_t nbits, const uint32_t* __restrict__ chain_start,
-                                                     const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ base, uint32_t* __restrict__ heads,
-                                                     uint32_t* __restrict__ states, uint32_t states_bytes) {
+// RANGED: the first pass (no look-back: workgroup r owns the tiles [r tpr, (r + 1) tpr) and knows from `rows` where its keys of every digit
+// start).  !RANGED: tiles claimed from the chains' counters, positions by look-back.  BALLOT: ranks from wavefront ballots.
+template <class K, class V, class In, int THREADS, int IPT, bool RANGED, bool BALLOT>
+__global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, V* __restrict__ ov, uint32_t n, uint32_t bit, uint32_t nbits, const uint32_t* __restrict__ rows,
+                                                     uint32_t row_stride, const uint32_t* __restrict__ dbase, uint32_t tpr, const uint32_t* __restrict__ chain_start,
+                                                     const uint32_t* __restrict__ tile_first, uint32_t nch, uint32_t* __restrict__ heads, uint32_t* __restrict__ states,
+                                                     uint32_t states_bytes) {
     constexpr bool HASV = !std::is_same<V, NoVal>::value;
     constexpr int WAVES = THREADS / 64, TILE = THREADS * IPT;
     constexpr int DT = THREADS < DIGITS ? THREADS : DIGITS, DPT = DIGITS / DT;  // the threads that own DPT digits each (scan of the tile's counts)
     constexpr int LBT = DIGITS / 4, LB = 4;                                     // look-back threads (four digits each), tiles fetched per round
     static_assert(THREADS >= LBT && THREADS % 64 == 0, "workgroup too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    K* lk = reinterpret_cast<K*>(smem);
-    constexpr size_t OFF_V = align16(sizeof(K) * (size_t)TILE);
+    K* lk = reinterpret_cast<K*>(smem);  // [TILE + 1] (the last slot takes the writes of the lanes beyond a partial tile)
+    constexpr size_t OFF_V = align16(sizeof(K) * (size_t)(TILE + 1));
     V* lv = reinterpret_cast<V*>(smem + OFF_V);
-    constexpr size_t OFF_C = OFF_V + (HASV ? align16(sizeof(V) * (size_t)TILE) : 0);
+    constexpr size_t OFF_C = OFF_V + (HASV ? align16(sizeof(V) * (size_t)(TILE + 1)) : 0);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + OFF_C);  // [WAVES][DIGITS]
     uint32_t* tstart = cnt + WAVES * DIGITS;                    // [DIGITS] first slot of a digit in the reordered tile
     uint32_t* tcnt = tstart + DIGITS;                           // [DIGITS] keys of a digit in the tile
-    uint32_t* gpos = tcnt + DIGITS;                             // [DIGITS] global position of slot 0 as seen from a digit: out = gpos[d] + slot
-    uint32_t* wsum = gpos + DIGITS;                             // [16]
+    uint32_t* gpos = tcnt + DIGITS;                             // [DIGITS] out = gpos[d] + slot
+    uint32_t* grun = gpos + DIGITS;                             // [DIGITS] RANGED: where the range's next key of a digit goes
+    uint32_t* wsum = grun + DIGITS;                             // [16]
     uint32_t* shd = wsum + 16;                                  // [4] the tile claimed next: chain, number
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t mask = (1u << nbits) - 1u;
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(states, 0, (int)states_bytes, 0x00020000);
 
-    uint32_t home = xcc_id();
-    auto claim = [&](uint32_t& cc, uint32_t& jj) -> bool {  // (thread 0)
-        for (int t = 0; t < CHAINS; t++) {
-            const uint32_t c2 = (home + t) & (CHAINS - 1);
-            const uint32_t nt = tile_first[c2 + 1] - tile_first[c2];
+    // ---- which tiles
+    const uint32_t total_tiles = (n + TILE - 1) / TILE;
+    uint32_t rt_end = 0;  // RANGED: the range's end
+    uint32_t home = 0;    // !RANGED (thread 0): the chain claimed from
+    uint32_t pend_j = 0;  //                     the claim in flight (a tile number of chain `home`)
+    auto pref_chain = [&](uint32_t k) -> uint32_t {  // the k-th chain in this workgroup's order of preference: its XCD's chains first
+        if (nch < 8) return (home + k) % nch;
+        const uint32_t per = nch >> 3, res = ((home & 7u) + k / per) & 7u, sub = ((home >> 3) + k % per) % per;
+        return res + 8u * sub;
+    };
+    auto chain_tiles = [&](uint32_t c) -> uint32_t { return tile_first[c + 1] - tile_first[c]; };
+    auto claim_slow = [&](uint32_t& cc, uint32_t& jj) -> bool {  // (thread 0) the home chain is used up: any chain
+        for (uint32_t k = 1; k < nch; k++) {
+            const uint32_t c2 = pref_chain(k), nt = chain_tiles(c2);
             if (nt == 0) continue;
             const uint32_t j2 = atomicAdd(&heads[c2], 1u);
             if (j2 < nt) { cc = c2; jj = j2; home = c2; return true; }
@@ -251,37 +304,52 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     };
     K key[IPT];
     V val[IPT];
-    auto load_tile = [&](uint32_t c, uint32_t j, uint32_t& tn) {
-        const uint32_t a0 = chain_start[c] + j * (uint32_t)TILE, rem = chain_start[c + 1] - a0;
-        tn = rem < (uint32_t)TILE ? rem : (uint32_t)TILE;
+    uint32_t a0 = 0, tile_n = 0;
+    auto load_tile = [&](uint32_t c, uint32_t j) {
+        uint32_t rem;
+        if (RANGED) { a0 = j * (uint32_t)TILE; rem = n - a0; }
+        else { a0 = chain_start[c] + j * (uint32_t)TILE; rem = chain_start[c + 1] - a0; }
+        tile_n = rem < (uint32_t)TILE ? rem : (uint32_t)TILE;
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
             const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
-            if (idx < tn) {
-                key[r] = in.key(a0 + idx);
-                if constexpr (HASV) val[r] = in.val(a0 + idx);
-            } else
-                key[r] = K(0);
+            const uint32_t at = a0 + (idx < tile_n ? idx : 0u);  // (lanes beyond a partial tile read its first key: no branch, nothing out of bounds)
+            key[r] = in.key(at);
+            if constexpr (HASV) val[r] = in.val(at);
         }
     };
 
-    if (tid == 0) {
-        uint32_t cc = 0xFFFFFFFFu, jj = 0;
-        if (!claim(cc, jj)) cc = 0xFFFFFFFFu;
-        shd[0] = cc;
-        shd[1] = jj;
+    uint32_t cur_c = 0, cur_j = 0;
+    if (RANGED) {
+        cur_j = blockIdx.x * tpr;
+        rt_end = min(total_tiles, cur_j + tpr);
+        if (cur_j >= rt_end) return;
+        for (uint32_t d = tid; d < DIGITS; d += THREADS) grun[d] = d <= mask ? dbase[d] + rows[(size_t)blockIdx.x * row_stride + d] : 0u;
+    } else {
+        if (tid == 0) {
+            const uint32_t x = xcc_id();
+            home = nch < 8 ? (blockIdx.x % nch) : x + 8u * ((blockIdx.x >> 3) % (nch >> 3));
+            uint32_t cc = NONE, jj = 0;
+            const uint32_t nt = chain_tiles(home);
+            const uint32_t j0 = nt ? atomicAdd(&heads[home], 1u) : 0u;
+            if (nt && j0 < nt) { cc = home; jj = j0; }
+            else if (!claim_slow(cc, jj)) cc = NONE;
+            shd[0] = cc;
+            shd[1] = jj;
+            if (cc != NONE) pend_j = atomicAdd(&heads[home], 1u);  // the tile after it
+        }
+        __syncthreads();
+        cur_c = shd[0];
+        cur_j = shd[1];
+        if (cur_c == NONE) return;
     }
-    __syncthreads();
-    uint32_t cur_c = shd[0], cur_j = shd[1], tile_n = 0;
-    if (cur_c == 0xFFFFFFFFu) return;
-    load_tile(cur_c, cur_j, tile_n);
-    __syncthreads();  // (shd is rewritten below)
+    load_tile(cur_c, cur_j);
+    __syncthreads();  // (shd is rewritten below; grun is read behind barriers)
 
     for (;;) {
-        // the tile after this one: claimed now, used once this tile's keys sit in LDS
-        if (tid == 0) {
-            uint32_t cc = 0xFFFFFFFFu, jj = 0;
-            if (!claim(cc, jj)) cc = 0xFFFFFFFFu;
+        if (!RANGED && tid == 0) {  // the claim made a tile ago has long returned
+            uint32_t cc = home, jj = pend_j;
+            if (jj >= chain_tiles(home) && !claim_slow(cc, jj)) cc = NONE;
             shd[0] = cc;
             shd[1] = jj;
         }
@@ -290,44 +358,56 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         for (int q = 0; q < DIGITS / 64; q++) cnt[wave * DIGITS + q * 64 + lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         uint32_t rank[IPT];
+        if (BALLOT) {
+            const uint64_t lt_mask = (1ull << lane) - 1ull;
+            uint32_t b0v[IPT];
+            int leader[IPT];
 #pragma unroll
-        for (int r = 0; r < IPT; r++) {
-            const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
-            const bool valid = idx < tile_n;
-            const uint32_t d = digit_of(key[r], bit, mask);
-            uint64_t peers = __ballot(valid);
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+                const bool valid = idx < tile_n;
+                const uint32_t d = digit_of(key[r], bit, mask);
+                uint64_t peers = __ballot(valid);
 #pragma unroll
-            for (int b = 0; b < DBITS; b++) {
-                if (b < (int)nbits) {
+                for (int b = 0; b < DBITS; b++) {  // (bits beyond the digit are zero in every lane: they change nothing)
                     const bool on = (d >> b) & 1u;
                     const uint64_t bj = __ballot(on);
                     peers &= on ? bj : ~bj;
                 }
+                leader[r] = valid ? __builtin_ctzll(peers) : (int)lane;
+                rank[r] = (uint32_t)__builtin_popcountll(peers & lt_mask);
+                b0v[r] = 0;
+                if (valid && (int)lane == leader[r]) b0v[r] = atomicAdd(&cnt[wave * DIGITS + d], (uint32_t)__builtin_popcountll(peers));
             }
-            const int leader = valid ? __builtin_ctzll(peers) : (int)lane;
-            uint32_t b0 = 0;
-            if (valid && (int)lane == leader) {
-                b0 = cnt[wave * DIGITS + d];
-                cnt[wave * DIGITS + d] = b0 + (uint32_t)__builtin_popcountll(peers);
+#pragma unroll
+            for (int r = 0; r < IPT; r++) rank[r] += __shfl(b0v[r], leader[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+                rank[r] = 0;
+                if (idx < tile_n) rank[r] = atomicAdd(&cnt[wave * DIGITS + digit_of(key[r], bit, mask)], 1u);
             }
-            b0 = __shfl(b0, leader);
-            rank[r] = b0 + (uint32_t)__builtin_popcountll(peers & lt_mask);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __syncthreads();  // B
-        const uint32_t nxt_c = shd[0], nxt_j = shd[1];
+        uint32_t nxt_c = 0, nxt_j = 0;
+        bool more;
+        if (RANGED) { nxt_j = cur_j + 1; more = nxt_j < rt_end; }
+        else { nxt_c = shd[0]; nxt_j = shd[1]; more = nxt_c != NONE; }
         // ---- per digit: counts of the waves -> starts of (digit, wave) relative to the digit; the digit's total
         uint32_t s[DPT], tot = 0, inc = 0;
         if (tid < DT) {
 #pragma unroll
             for (int q = 0; q < DPT; q++) {
                 const uint32_t d = tid * DPT + q;
-                uint32_t run = 0;
+                uint32_t cw[WAVES], run = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) cw[w] = cnt[w * DIGITS + d];  // (every read first: the loads in flight together, not one round trip each)
 #pragma unroll
                 for (int w = 0; w < WAVES; w++) {
-                    const uint32_t c = cnt[w * DIGITS + d];
                     cnt[w * DIGITS + d] = run;
-                    run += c;
+                    run += cw[w];
                 }
                 s[q] = run;
                 tot += run;
@@ -349,48 +429,53 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             uint32_t start = before + inc - tot;
 #pragma unroll
             for (int q = 0; q < DPT; q++) {
-                tstart[tid * DPT + q] = start;
-                tcnt[tid * DPT + q] = s[q];
+                const uint32_t d = tid * DPT + q;
+                tstart[d] = start;
+                if (RANGED) {  // the range's running positions: no look-back
+                    const uint32_t g = grun[d];
+                    gpos[d] = g - start;
+                    grun[d] = g + s[q];
+                } else
+                    tcnt[d] = s[q];
                 start += s[q];
             }
         }
         __syncthreads();  // E
-        // ---- publish the tile's counts, start looking back
-        const uint32_t tile_g = tile_first[cur_c] + cur_j;
+        // ---- publish the tile's counts, start looking back; claim the tile after the next
+        const uint32_t tile_g = RANGED ? 0u : tile_first[cur_c] + cur_j;
         uint32_t my[4] = {0, 0, 0, 0}, ex[4] = {0, 0, 0, 0};
         u32x4 xb[LB];
-        if (tid < LBT) {
+        if (!RANGED && tid < LBT) {
             const uint32_t fl = cur_j == 0 ? ST_INC : ST_AGG;
 #pragma unroll
             for (int q = 0; q < 4; q++) my[q] = tcnt[tid * 4 + q];
             u32x4 a;
             a.x = fl | my[0]; a.y = fl | my[1]; a.z = fl | my[2]; a.w = fl | my[3];
             __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
-            if (cur_j > 0) {
+            if (cur_j > 0 && !(BFT_RS_KO & 1)) {
 #pragma unroll
                 for (int i = 0; i < LB; i++) {
                     const uint32_t pj = cur_j - 1 >= (uint32_t)i ? cur_j - 1 - i : 0u;
                     xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - cur_j + pj) * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
                 }
             }
+            if (tid == 0 && more && nxt_c == home) pend_j = atomicAdd(&heads[home], 1u);
         }
         // ---- reorder in LDS
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
             const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
-            if (idx < tile_n) {
-                const uint32_t d = digit_of(key[r], bit, mask);
-                const uint32_t slot = tstart[d] + cnt[wave * DIGITS + d] + rank[r];
-                lk[slot] = key[r];
-                if constexpr (HASV) lv[slot] = val[r];
-            }
+            const uint32_t d = digit_of(key[r], bit, mask);
+            const uint32_t slot = idx < tile_n ? tstart[d] + cnt[wave * DIGITS + d] + rank[r] : (uint32_t)TILE;
+            lk[slot] = key[r];
+            if constexpr (HASV) lv[slot] = val[r];
         }
         // ---- the next tile's keys: into the registers this tile's keys have just left
         const uint32_t this_n = tile_n;
-        if (nxt_c != 0xFFFFFFFFu) load_tile(nxt_c, nxt_j, tile_n);
+        if (more) load_tile(nxt_c, nxt_j);
         // ---- finish the look-back
-        if (tid < LBT) {
-            if (cur_j > 0) {
+        if (!RANGED && tid < LBT) {
+            if (cur_j > 0 && !(BFT_RS_KO & 1)) {
                 uint32_t done = 0;
                 uint32_t pj = cur_j - 1;  // the tile xb[0] stands for
                 for (;;) {
@@ -413,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                         pj--;  // (tile 0 of a chain is published inclusive: `done` is complete before pj wraps)
                     }
                     if (done == 15u) break;
-                    if (stall) __builtin_amdgcn_s_sleep(4);
+                    if (stall) __builtin_amdgcn_s_sleep(2);
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < LB; i++) {
@@ -426,7 +511,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                 __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) gpos[tid * 4 + q] = base[cur_c * DIGITS + tid * 4 + q] + ex[q] - tstart[tid * 4 + q];
+            for (int q = 0; q < 4; q++) {
+                const uint32_t d = tid * 4 + q;
+                gpos[d] = (d <= mask ? dbase[d] + rows[cur_c * row_stride + d] : 0u) + ex[q] - tstart[d];
+            }
         }
         __syncthreads();  // G
         // ---- write out: slot by slot, i.e. digit run by digit run
@@ -436,14 +524,16 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             if (slot < this_n) {
                 const K kk = lk[slot];
                 const uint32_t pos = gpos[digit_of(kk, bit, mask)] + slot;
-                ok[pos] = kk;
-                if constexpr (HASV) ov[pos] = lv[slot];
+                if (!(BFT_RS_KO & 2) || kk == K(12345)) {
+                    ok[pos] = kk;
+                    if constexpr (HASV) ov[pos] = lv[slot];
+                }
             }
         }
-        if (nxt_c == 0xFFFFFFFFu) break;
+        if (!more) break;
         cur_c = nxt_c;
         cur_j = nxt_j;
-        // (no barrier: the next round writes shd before B -- every thread has read it behind B of this round --, the counters before B, everything else behind E)
+        // (no barrier: the next round writes shd before B -- every thread has read it behind B of this round --, the counters before B, the rest behind D)
     }
 }
 
@@ -457,8 +547,8 @@ __global__ void k_rs_copy(In in, uint32_t n, K* __restrict__ ok, V* __restrict__
 
 template <class K, class V, int THREADS, int IPT>
 constexpr size_t pass_lds_bytes() {
-    return align16(sizeof(K) * (size_t)THREADS * IPT) + (std::is_same<V, NoVal>::value ? 0 : align16(sizeof(V) * (size_t)THREADS * IPT)) +
-           ((size_t)(THREADS / 64) * DIGITS + 3 * DIGITS + 16 + 4) * 4;
+    return align16(sizeof(K) * ((size_t)THREADS * IPT + 1)) + (std::is_same<V, NoVal>::value ? 0 : align16(sizeof(V) * ((size_t)THREADS * IPT + 1))) +
+           ((size_t)(THREADS / 64) * DIGITS + 4 * DIGITS + 16 + 4) * 4;
 }
 
 static inline int cu_count() {
@@ -471,6 +561,32 @@ static inline int cu_count() {
     }
     return n;
 }
+
+// 0: ranks from LDS atomics (the device passed the lane-order check), 1: from ballots.  force >= 0 sets it ("sort_ballots" option, tests).
+static inline int rank_mode(hipStream_t s, int force = -1) {
+    static int mode = -1;
+    if (force >= 0) { mode = force; return mode; }
+    if (mode >= 0) return mode;
+    uint32_t* d = nullptr;
+    uint32_t bad = 1;
+    if (hipMalloc((void**)&d, 4) == hipSuccess) {
+        if (hipMemsetAsync(d, 0, 4, s) == hipSuccess) {
+            hipLaunchKernelGGL(k_rs_selftest, dim3(512), dim3(64), 0, s, d);
+            if (hipMemcpyAsync(&bad, d, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) bad = 1;
+        }
+        (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+    mode = bad ? 1 : 0;
+    return mode;
+}
+
+// scratch of one sort call (u32 words)
+struct Layout {
+    size_t heads, cnt, states, zero_words;  // zeroed before every call: [P][64]; the later passes' (chain, digit) counters; [P - 1][max_tiles][DIGITS]
+    size_t tot, dbase, chain, partial, total_words;
+    uint32_t max_tiles, ranges;
+};
 
 // Stable sort of n (key, value) pairs on the key bits [begin_bit, end_bit).  The input is read through `in` (once by the histogram kernel,
 // once by the first pass); the result lands in out_k / out_v; tmp_k / tmp_v (n entries each) carry the passes in between and may be NULL
@@ -488,50 +604,79 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         return 0;
     }
     if (pl.P > 1 && (!tmp_k || (!std::is_same<V, NoVal>::value && !tmp_v))) return bft_fail(BFT_GPU_E_ARG, "internal: radix sort without a second buffer");
+    const bool ballot = rank_mode(s) != 0;
     const int cus = cu_count();
-    const uint32_t tiles = (uint32_t)((n + TILE - 1) / TILE);
-    const uint32_t per0 = (tiles + CHAINS - 1) / CHAINS * TILE;
-    // histogram workgroups: enough to stream (1024 threads x 8 keys a turn), no more than the input has turns
-    constexpr int HT = 1024;
-    uint32_t wpc = (uint32_t)std::max(1, cus / CHAINS);
-    while (wpc > 1 && (uint64_t)CHAINS * wpc * HT * 8 > n * 2) wpc >>= 1;
-    const Layout L = make_layout(n, pl.P, TILE, CHAINS * wpc);
-    if (scratch.bytes < L.total_words * 4) CK(scratch.alloc(L.total_words * 4));
-    uint32_t* W = scratch.as<uint32_t>();
-    HIPCK(hipMemsetAsync(W, 0, L.zero_words * 4, s));
-    const size_t hist_lds = (size_t)pl.P * CHAINS * DIGITS * 4;
-    {
-        static bool attr_h = false;
-        if (!attr_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_hist<K, In, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXP * CHAINS * DIGITS * 4); attr_h = true; }
-    }
-    hipLaunchKernelGGL((k_rs_hist<K, In, HT>), dim3(CHAINS * wpc), dim3(HT), hist_lds, s, in, (uint32_t)n, pl, per0, wpc, W + L.partial);
-    const uint32_t words = (uint32_t)pl.P * CHAINS * DIGITS;
-    hipLaunchKernelGGL(k_rs_reduce, dim3((words + 255) / 256), dim3(256), 0, s, W + L.partial, CHAINS * wpc, words, W + L.cnt);
-    hipLaunchKernelGGL(k_rs_scan, dim3(pl.P), dim3(DIGITS), 0, s, W + L.cnt, W + L.base, W + L.chain, pl, (uint32_t)n, per0, TILE);
-    HIPCK(hipGetLastError());
     constexpr size_t lds = pass_lds_bytes<K, V, THREADS, IPT>();
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / THREADS));
-    const uint32_t grid = std::min<uint32_t>(tiles + CHAINS, (uint32_t)(cus * per_cu));
+    const uint32_t tiles = (uint32_t)((n + TILE - 1) / TILE);
+    const uint32_t wgs = std::min<uint32_t>(tiles, (uint32_t)std::min(1024, cus * per_cu));  // (<= 1024 ranges: k_rs_rowscan)
+    const uint32_t tpr = (tiles + wgs - 1) / wgs, ranges = (tiles + tpr - 1) / tpr;
+    Layout L;
+    {
+        L.max_tiles = tiles + (1u << MAXCB);
+        L.ranges = ranges;
+        size_t o = 0;
+        L.heads = o; o += (size_t)pl.P * (1 << MAXCB);
+        L.cnt = o; o += pl.hwords;  // (the part of pass 0 is unused: its rows are the histogram workgroups' own blocks)
+        o = (o + 3) & ~(size_t)3;
+        L.states = o; o += (size_t)(pl.P - 1) * L.max_tiles * DIGITS;
+        L.zero_words = o;
+        L.tot = o; o += (size_t)pl.P * DIGITS;
+        L.dbase = o; o += (size_t)pl.P * DIGITS;
+        L.chain = o; o += (size_t)(pl.P + 1) * CT;
+        o = (o + 3) & ~(size_t)3;
+        L.partial = o; o += (size_t)ranges * pl.hwords;
+        L.total_words = o;
+    }
+    if (scratch.bytes < L.total_words * 4) CK(scratch.alloc(L.total_words * 4));
+    uint32_t* W = scratch.as<uint32_t>();
+    HIPCK(hipMemsetAsync(W, 0, L.zero_words * 4, s));
+    constexpr int HT = 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_hist<K, In, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipLaunchKernelGGL((k_rs_hist<K, In, HT>), dim3(ranges), dim3(HT), (size_t)pl.hwords * 4, s, in, (uint32_t)n, pl, tpr * TILE, W + L.partial);
+    // pass 0: per digit, the ranges' counts -> where each range's keys of the digit start (in place in the histogram blocks)
+    hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << pl.nbits[0]), dim3(256), 0, s, W + L.partial + pl.hoff[0], pl.hwords, ranges, W + L.tot);
+    if (pl.P > 1) {
+        const uint32_t words = pl.hwords - pl.hoff[1];
+        hipLaunchKernelGGL(k_rs_reduce, dim3((words + 255) / 256, std::max(1u, std::min(8u, ranges / 32u))), dim3(256), 0, s, W + L.partial, ranges, pl.hwords, pl.hoff[1], words,
+                           W + L.cnt + pl.hoff[1]);
+        for (int p = 1; p < pl.P; p++)
+            hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << pl.nbits[p]), dim3(256), 0, s, W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], 1u << pl.cb[p], W + L.tot + (size_t)p * DIGITS);
+    }
+    hipLaunchKernelGGL(k_rs_digits, dim3(pl.P), dim3(DIGITS), 0, s, W + L.tot, W + L.dbase, W + L.chain, pl, (uint32_t)n, TILE);
+    HIPCK(hipGetLastError());
     const K* src_k = nullptr;
     const V* src_v = nullptr;
     for (int p = 0; p < pl.P; p++) {
         const bool to_out = ((pl.P - 1 - p) % 2) == 0;
         K* dk = to_out ? out_k : tmp_k;
         V* dv = to_out ? out_v : tmp_v;
-        const uint32_t* ch = W + L.chain + (size_t)p * 2 * (CHAINS + 1);
-        uint32_t* st = W + L.states + (size_t)p * L.max_tiles * DIGITS;
-        const uint32_t st_bytes = L.max_tiles * DIGITS * 4;
+        const uint32_t* ch = W + L.chain + (size_t)p * CT;
         if (p == 0) {
-            static bool attr0 = false;
-            if (!attr0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, In, THREADS, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
-            hipLaunchKernelGGL((k_rs_pass<K, V, In, THREADS, IPT>), dim3(grid), dim3(THREADS), lds, s, in, dk, dv, pl.bit[p], pl.nbits[p], ch, ch + CHAINS + 1,
-                               W + L.base + (size_t)p * CHAINS * DIGITS, W + L.heads + (size_t)p * CHAINS, st, st_bytes);
+#define BFT_RS_LAUNCH0(BAL)                                                                                                                                            \
+    do {                                                                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, In, THREADS, IPT, true, BAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_rs_pass<K, V, In, THREADS, IPT, true, BAL>), dim3(ranges), dim3(THREADS), lds, s, in, dk, dv, (uint32_t)n, pl.bit[0], pl.nbits[0],       \
+                           W + L.partial + pl.hoff[0], pl.hwords, W + L.dbase, tpr, ch, ch, 1u, W + L.heads, W + L.states, 16u);                                       \
+    } while (0)
+            if (ballot) BFT_RS_LAUNCH0(true);
+            else BFT_RS_LAUNCH0(false);
+#undef BFT_RS_LAUNCH0
         } else {
-            static bool attr1 = false;
-            if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-            hipLaunchKernelGGL((k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT>), dim3(grid), dim3(THREADS), lds, s, PtrIn<K, V>{src_k, src_v}, dk, dv, pl.bit[p], pl.nbits[p], ch,
-                               ch + CHAINS + 1, W + L.base + (size_t)p * CHAINS * DIGITS, W + L.heads + (size_t)p * CHAINS, st, st_bytes);
+            uint32_t* st = W + L.states + (size_t)(p - 1) * L.max_tiles * DIGITS;
+            const uint32_t st_bytes = L.max_tiles * DIGITS * 4;
+            const uint32_t grid = std::min<uint32_t>(tiles + (1u << pl.cb[p]), (uint32_t)(cus * per_cu));
+#define BFT_RS_LAUNCH1(BAL)                                                                                                                                                      \
+    do {                                                                                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL>), dim3(grid), dim3(THREADS), lds, s, PtrIn<K, V>{src_k, src_v}, dk, dv, (uint32_t)n,         \
+                           pl.bit[p], pl.nbits[p], W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], W + L.dbase + (size_t)p * DIGITS, 0u, ch, ch + (1 << MAXCB) + 1, 1u << pl.cb[p],  \
+                           W + L.heads + (size_t)p * (1 << MAXCB), st, st_bytes);                                                                                                \
+    } while (0)
+            if (ballot) BFT_RS_LAUNCH1(true);
+            else BFT_RS_LAUNCH1(false);
+#undef BFT_RS_LAUNCH1
         }
         src_k = dk;
         src_v = dv;
@@ -543,12 +688,18 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
 // the tile shape by the bytes of an entry: large arrays stream through 1024-thread workgroups, one per CU, with the largest tile the LDS
 // holds (a digit's piece of a tile is TILE / 512 entries: the longer, the fewer partial lines); small arrays take 256-thread workgroups so
 // that there are tiles for every CU
+#ifndef BFT_RS_BIG_THREADS
+#define BFT_RS_BIG_THREADS 1024
+#endif
 template <class K, class V, class In>
 int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
     constexpr size_t E = sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V));
     constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
     constexpr int IPT_SMALL = E <= 8 ? 16 : E <= 16 ? 8 : E <= 32 ? 4 : 2;
-    if (n >= (1u << 22)) return sort_cfg<K, V, In, 1024, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+#ifdef BFT_RS_BIG_IPT
+    if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+#endif
+    if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
     return sort_cfg<K, V, In, 256, IPT_SMALL>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
 }
 

@@ -115,15 +115,19 @@ static float time_it(F f, int reps = 5) {
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     int fails = 0;
+    const bool nocheck = argc > 1 && !strcmp(argv[1], "bench");
+    if (!nocheck)
     for (uint64_t n : {1ull, 63ull, 64ull, 65ull, 2047ull, 4096ull, 4097ull, 100000ull, 1000003ull, 5000011ull}) {
         fails += check_case<uint64_t, uint32_t>(n, 7, 25, 0, "u64+u32 18 bits");
         fails += check_case<uint64_t, bft_rs::NoVal>(n, 0, 64, 0, "u64 keys 64 bits");
     }
+    if (!nocheck) {
     fails += check_case<uint32_t, Rec12>(3000017, 0, 24, 0, "u32+rec12 24 bits");
     fails += check_case<uint64_t, uint32_t>(3000017, 3, 14, 1, "u64+u32 11 bits few digits");
     fails += check_case<uint64_t, uint32_t>(6000017, 20, 38, 2, "u64+u32 18 bits heavy digit");
     fails += check_case<uint64_t, uint8_t>(4500000, 44, 62, 0, "u64+u8 18 bits");
     fails += check_case<uint32_t, bft_rs::NoVal>(1234567, 5, 5, 0, "no bits (copy)");
+    }
     if (fails) { printf("{\"failed_checks\": %d}\n", fails); return 1; }
     if (quick) return 0;
     DevBuf scratch;
@@ -142,6 +146,18 @@ int main(int argc, char** argv) {
         unsigned nb = 0;
         HCK(hipMemcpy(&nb, bad, 4, hipMemcpyDeviceToHost));
         printf("{\"what\": \"root-prefix split, 2e8 composites, bits [%u, %u)\", \"impl\": \"bft_rs\", \"ms\": %.3f, \"GBps_40B\": %.0f, \"bad\": %u}\n", lo, hi, ms, n * 40.0 / ms / 1e6, nb);
+#ifdef BFT_RS_PROF
+        {
+            unsigned long long z[16] = {0}, pr[16];
+            HCK(hipMemcpyToSymbol(HIP_SYMBOL(bft_rs::g_rs_prof), z, sizeof(z)));
+            (void)bft_rs::sort<uint64_t, bft_rs::NoVal>(bft_rs::PtrIn<uint64_t, bft_rs::NoVal>{in, nullptr}, n, out, (bft_rs::NoVal*)nullptr, tmp, (bft_rs::NoVal*)nullptr, lo, hi, 0, scratch);
+            HCK(hipDeviceSynchronize());
+            HCK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(bft_rs::g_rs_prof), sizeof(pr)));
+            const char* nm[9] = {"loop->claim", "rank(+load wait)", "barrier B", "scan C,D,E", "publish+lb issue+scatter", "next load issue", "look-back finish", "barrier G", "write-out"};
+            double tot = 0; for (int i = 0; i < 9; i++) tot += (double)pr[i];
+            for (int i = 0; i < 9; i++) printf("{\"phase\": \"%s\", \"share\": %.3f, \"Mticks\": %.1f}\n", nm[i], pr[i] / tot, pr[i] / 1e6);
+        }
+#endif
         size_t tb = 0;
         (void)rocprim::radix_sort_keys<Msd9>(nullptr, tb, in, out, (size_t)n, lo, hi, 0);
         void* t2;
