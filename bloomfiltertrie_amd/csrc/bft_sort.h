@@ -19,7 +19,7 @@
 //     count per (chain, digit) from the keys alone.  A chain is worked on by the few workgroups of one XCD (HW_REG_XCC_ID picks the chains
 //     a workgroup prefers; any workgroup may take any tile, placement is never a matter of correctness), so a look-back is one round trip
 //     of four tile states instead of one per resident workgroup, and neighbouring tiles again share an L2;
-//   * tile states are 32-bit words {flag:2, count:30}, four digits per 16-byte write-through (sc1) store / load (MI355X_MICROARCH.md,
+//   * tile states are 32-bit words {inclusive:1, count + 1:31}, four digits per 16-byte write-through (sc1) store / load (MI355X_MICROARCH.md,
 //     inter-workgroup visibility: narrow sc1 stores are a fabric write each); a tile publishes its counts before it looks back;
 //   * tiles are claimed from a counter per chain one tile AHEAD (the returning atomic travels while a tile is worked on), and the next
 //     tile's keys are loaded into the registers the current tile's keys have just left (they sit in LDS by then);
@@ -29,7 +29,7 @@
 //     stable; bft_rs::rank_mode() checks that behaviour on the device once per process (k_rs_selftest) and every sort falls back to ranks
 //     from wavefront ballots (stable by construction, ~0.35 ms more per pass over 2 x 10^8 keys) if it does not hold or "sort_ballots" is set.
 //
-// n < 2^30 per call (the callers' arrays are rows and pairs counted in 32 bits; the insertion log is flushed before 2^30 pairs).
+// n < 2^31 per call (the callers' arrays are rows and pairs counted in 32 bits; the insertion log is flushed at 2^30 pairs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,8 +44,9 @@ constexpr int DBITS = 9;
 constexpr int DIGITS = 1 << DBITS;
 constexpr int MAXP = 8;
 constexpr int MAXCB = 6;  // up to 64 chains
-constexpr uint32_t ST_VAL = 0x3FFFFFFFu;
-constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30;
+// a tile's state per digit: 0 = not published; otherwise count + 1 in the low 31 bits, bit 31 set when the count includes every tile before it
+constexpr uint32_t ST_VAL = 0x7FFFFFFFu;
+constexpr uint32_t ST_AGG = 1u, ST_INC = 0x80000001u;  // (added to a count)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct NoVal {};
@@ -202,14 +203,25 @@ __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict
     db[d] = run;
     dbase[p * DIGITS + d] = run;
     __syncthreads();
-    if (p + 1 < (uint32_t)pl.P && d == 0) {
+    if (p + 1 < (uint32_t)pl.P) {  // (uniform)
+        __shared__ uint32_t cst[(1 << MAXCB) + 1];
         uint32_t* cs = chain + (size_t)(p + 1) * CT;
         const uint32_t nch = 1u << pl.cb[p + 1], sh = pl.nbits[p] - pl.cb[p + 1];
-        for (uint32_t c = 0; c <= nch; c++) cs[c] = c < nch ? db[c << sh] : n;
-        uint32_t tf = 0;
-        for (uint32_t c = 0; c <= nch; c++) {
-            cs[(1 << MAXCB) + 1 + c] = tf;
-            if (c < nch) tf += (cs[c + 1] - cs[c] + tile - 1) / tile;
+        if (d <= nch) {
+            cst[d] = d < nch ? db[d << sh] : n;
+            cs[d] = cst[d];
+        }
+        __syncthreads();
+        if (d < 64) {  // (wave 0: tiles per chain -> first tile of every chain)
+            const uint32_t nt = d < nch ? (cst[d + 1] - cst[d] + tile - 1) / tile : 0u;
+            uint32_t ti = nt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(ti, o);
+                if ((int)d >= o) ti += x;
+            }
+            if (d < nch) cs[(1 << MAXCB) + 1 + d] = ti - nt;
+            if (d == nch - 1) cs[(1 << MAXCB) + 1 + nch] = ti;
         }
     }
 }
@@ -249,13 +261,22 @@ __global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) 
 
 // ---- one pass --------------------------------------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef BFT_RS_PROF  // (microbenchmark only: cycles per phase of a tile, summed over the tiles of every workgroup's thread 0)
+__device__ unsigned long long g_rs_prof[2][16];
+#define RS_T(i) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_rs_prof[RANGED ? 0 : 1][i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define RS_T(i) do {} while (0)
+#endif
+#ifndef BFT_RS_LB_MODE
+#define BFT_RS_LB_MODE 2  // where a tile looks back: 0 before it is reordered in LDS, 1 behind that, 2 behind that and before the look-back threads load the next tile
+#endif
 #ifndef BFT_RS_KO
 #define BFT_RS_KO 0  // (microbenchmark only: knock-outs -- 1 no look-back, 2 no stores of the reordered tile; wrong results)
 #endif
 
 // RANGED: the first pass (no look-back: workgroup r owns the tiles [r tpr, (r + 1) tpr) and knows from `rows` where its keys of every digit
 // start).  !RANGED: tiles claimed from the chains' counters, positions by look-back.  BALLOT: ranks from wavefront ballots.
-template <class K, class V, class In, int THREADS, int IPT, bool RANGED, bool BALLOT>
+template <class K, class V, class In, int THREADS, int IPT, bool RANGED, bool BALLOT, int LBG>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, V* __restrict__ ov, uint32_t n, uint32_t bit, uint32_t nbits, const uint32_t* __restrict__ rows,
                                                      uint32_t row_stride, const uint32_t* __restrict__ dbase, uint32_t tpr, const uint32_t* __restrict__ chain_start,
                                                      const uint32_t* __restrict__ tile_first, uint32_t nch, uint32_t* __restrict__ heads, uint32_t* __restrict__ states,
@@ -277,6 +298,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     uint32_t* grun = gpos + DIGITS;                             // [DIGITS] RANGED: where the range's next key of a digit goes
     uint32_t* wsum = grun + DIGITS;                             // [16]
     uint32_t* shd = wsum + 16;                                  // [4] the tile claimed next: chain, number
+    uint32_t* lbs = shd + 4;                                    // [LBG][LBT][5] what a look-back group found in its window: four sums, meta
+    static_assert(LBG >= 1 && LBG * LBT <= THREADS, "look-back groups");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
@@ -346,18 +369,20 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     load_tile(cur_c, cur_j);
     __syncthreads();  // (shd is rewritten below; grun is read behind barriers)
 
+#ifdef BFT_RS_PROF
+    unsigned long long t_prev = clock64();
+#endif
     for (;;) {
-        if (!RANGED && tid == 0) {  // the claim made a tile ago has long returned
-            uint32_t cc = home, jj = pend_j;
-            if (jj >= chain_tiles(home) && !claim_slow(cc, jj)) cc = NONE;
-            shd[0] = cc;
-            shd[1] = jj;
-        }
+        RS_T(0);
         // ---- rank: wave w owns the tile's keys [w 64 IPT, (w + 1) 64 IPT), key (round r, lane l) = r 64 + l of them
 #pragma unroll
         for (int q = 0; q < DIGITS / 64; q++) cnt[wave * DIGITS + q * 64 + lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        uint32_t rank[IPT];
+        RS_T(1);
+        uint32_t rk2[(IPT + 1) / 2];  // ranks, two to a register (a tile holds fewer than 2^16 keys)
+#pragma unroll
+        for (int r = 0; r < (IPT + 1) / 2; r++) rk2[r] = 0;
+        static_assert(TILE < 65536, "ranks are kept in 16 bits");
         if (BALLOT) {
             const uint64_t lt_mask = (1ull << lane) - 1ull;
             uint32_t b0v[IPT];
@@ -375,22 +400,31 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                     peers &= on ? bj : ~bj;
                 }
                 leader[r] = valid ? __builtin_ctzll(peers) : (int)lane;
-                rank[r] = (uint32_t)__builtin_popcountll(peers & lt_mask);
+                rk2[r >> 1] |= (uint32_t)__builtin_popcountll(peers & lt_mask) << (16 * (r & 1));
                 b0v[r] = 0;
                 if (valid && (int)lane == leader[r]) b0v[r] = atomicAdd(&cnt[wave * DIGITS + d], (uint32_t)__builtin_popcountll(peers));
             }
 #pragma unroll
-            for (int r = 0; r < IPT; r++) rank[r] += __shfl(b0v[r], leader[r]);
+            for (int r = 0; r < IPT; r++) rk2[r >> 1] += __shfl(b0v[r], leader[r]) << (16 * (r & 1));
         } else {
 #pragma unroll
             for (int r = 0; r < IPT; r++) {
                 const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
-                rank[r] = 0;
-                if (idx < tile_n) rank[r] = atomicAdd(&cnt[wave * DIGITS + digit_of(key[r], bit, mask)], 1u);
+                uint32_t v = 0;
+                if (idx < tile_n) v = atomicAdd(&cnt[wave * DIGITS + digit_of(key[r], bit, mask)], 1u);
+                rk2[r >> 1] |= v << (16 * (r & 1));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (!RANGED && tid == 0) {  // the claim made a tile ago has returned by now (asked for here and not at the loop's top: behind it the
+            uint32_t cc = home, jj = pend_j;  // stores of the last tile are in flight, and a wavefront's memory operations return in order)
+            if (jj >= chain_tiles(home) && !claim_slow(cc, jj)) cc = NONE;
+            shd[0] = cc;
+            shd[1] = jj;
+        }
+        RS_T(2);
         __syncthreads();  // B
+        RS_T(3);
         uint32_t nxt_c = 0, nxt_j = 0;
         bool more;
         if (RANGED) { nxt_j = cur_j + 1; more = nxt_j < rt_end; }
@@ -420,6 +454,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             }
             if (lane == 63) wsum[wave] = inc;
         }
+        RS_T(4);
         __syncthreads();  // D
         if (tid < DT) {
             uint32_t before = 0;
@@ -441,95 +476,164 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             }
         }
         __syncthreads();  // E
+        RS_T(5);
         // ---- publish the tile's counts, start looking back; claim the tile after the next
         const uint32_t tile_g = RANGED ? 0u : tile_first[cur_c] + cur_j;
         uint32_t my[4] = {0, 0, 0, 0}, ex[4] = {0, 0, 0, 0};
         u32x4 xb[LB];
-        if (!RANGED && tid < LBT) {
-            const uint32_t fl = cur_j == 0 ? ST_INC : ST_AGG;
+        const uint32_t lg = tid / LBT, lt = tid % LBT;  // look-back group, thread of it: digits 4 lt .. 4 lt + 3; group g looks at the tiles cur_j - 1 - (g LB + i)
+        if (!RANGED && tid < LBG * LBT) {
+            if (lg == 0) {
+                const uint32_t fl = cur_j == 0 ? ST_INC : ST_AGG;
 #pragma unroll
-            for (int q = 0; q < 4; q++) my[q] = tcnt[tid * 4 + q];
-            u32x4 a;
-            a.x = fl | my[0]; a.y = fl | my[1]; a.z = fl | my[2]; a.w = fl | my[3];
-            __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
+                for (int q = 0; q < 4; q++) my[q] = tcnt[lt * 4 + q];
+                u32x4 a;
+                a.x = fl + my[0]; a.y = fl + my[1]; a.z = fl + my[2]; a.w = fl + my[3];
+                __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
+            }
+#if BFT_RS_LB_MODE == 0
             if (cur_j > 0 && !(BFT_RS_KO & 1)) {
 #pragma unroll
                 for (int i = 0; i < LB; i++) {
-                    const uint32_t pj = cur_j - 1 >= (uint32_t)i ? cur_j - 1 - i : 0u;
-                    xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - cur_j + pj) * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
+                    const uint32_t o = lg * LB + i;
+                    if (o < cur_j) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - 1u - o) * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
+                    else { xb[i].x = ST_INC; xb[i].y = ST_INC; xb[i].z = ST_INC; xb[i].w = ST_INC; }  // (before the chain's first tile: nothing)
                 }
             }
+#endif
             if (tid == 0 && more && nxt_c == home) pend_j = atomicAdd(&heads[home], 1u);
         }
+        RS_T(6);
         // ---- reorder in LDS
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
             const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
             const uint32_t d = digit_of(key[r], bit, mask);
-            const uint32_t slot = idx < tile_n ? tstart[d] + cnt[wave * DIGITS + d] + rank[r] : (uint32_t)TILE;
+            const uint32_t slot = idx < tile_n ? tstart[d] + cnt[wave * DIGITS + d] + ((rk2[r >> 1] >> (16 * (r & 1))) & 0xFFFFu) : (uint32_t)TILE;
             lk[slot] = key[r];
             if constexpr (HASV) lv[slot] = val[r];
         }
+#if BFT_RS_LB_MODE != 0
+        if (!RANGED && tid < LBG * LBT) {
+            if (cur_j > 0 && !(BFT_RS_KO & 1)) {
+#pragma unroll
+                for (int i = 0; i < LB; i++) {
+                    const uint32_t o = lg * LB + i;
+                    if (o < cur_j) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - 1u - o) * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
+                    else { xb[i].x = ST_INC; xb[i].y = ST_INC; xb[i].z = ST_INC; xb[i].w = ST_INC; }  // (before the chain's first tile: nothing)
+                }
+            }
+        }
+#endif
+        RS_T(7);
         // ---- the next tile's keys: into the registers this tile's keys have just left
         const uint32_t this_n = tile_n;
+#if BFT_RS_LB_MODE != 2
         if (more) load_tile(nxt_c, nxt_j);
-        // ---- finish the look-back
-        if (!RANGED && tid < LBT) {
-            if (cur_j > 0 && !(BFT_RS_KO & 1)) {
-                uint32_t done = 0;
-                uint32_t pj = cur_j - 1;  // the tile xb[0] stands for
-                for (;;) {
-                    bool stall = false;
+#else
+        if (more && (RANGED || tid >= LBG * LBT)) load_tile(nxt_c, nxt_j);  // (the look-back threads: once they have looked back -- their registers are taken until then)
+#endif
+        RS_T(8);
+        // ---- finish the look-back: every group sums its window up to the first tile that knows its inclusive counts (per digit), or up
+        // to a tile that has not published yet; group 0 puts the windows together, and goes on alone in the rare case that is not enough
+        if (!RANGED && cur_j > 0 && !(BFT_RS_KO & 1)) {
+            uint32_t done = 0, used = 0;  // digits that met an inclusive state; window entries taken in
+            if (tid < LBG * LBT) {
 #pragma unroll
-                    for (int i = 0; i < LB; i++) {
-                        if (done == 15u || stall) break;
-                        const u32x4 x = xb[i];
-                        const uint32_t xv[4] = {x.x, x.y, x.z, x.w};
-                        bool wait = false;
+                for (int i = 0; i < LB; i++) {
+                    if (done == 15u || used != (uint32_t)i) break;
+                    const u32x4 x = xb[i];
+                    const uint32_t xv[4] = {x.x, x.y, x.z, x.w};
+                    bool wait = false;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) wait |= !((done >> q) & 1u) && (xv[q] >> 30) == 0u;
-                        if (wait) { stall = true; break; }
+                    for (int q = 0; q < 4; q++) wait |= !((done >> q) & 1u) && xv[q] == 0u;
+                    if (wait) break;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (!((done >> q) & 1u)) {
+                            ex[q] += (xv[q] & ST_VAL) - 1u;
+                            if (xv[q] >> 31) done |= 1u << q;
+                        }
+                    used = i + 1;
+                }
+                if (LBG > 1) {
+                    uint32_t* o = lbs + (lg * LBT + lt) * 5;
+                    o[0] = ex[0]; o[1] = ex[1]; o[2] = ex[2]; o[3] = ex[3];
+                    o[4] = done | (used << 4);
+                }
+            }
+            if (LBG > 1) __syncthreads();
+            if (tid < LBT) {
+                uint32_t pj;  // the next tile to look at, if any is left to
+                if (LBG > 1) {
+                    bool blocked = done != 15u && used < (uint32_t)LB;
+                    uint32_t seen = used;
+                    for (int g2 = 1; g2 < LBG && done != 15u && !blocked; g2++) {
+                        const uint32_t* o = lbs + (g2 * LBT + lt) * 5;
+                        const uint32_t meta = o[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            if (!((done >> q) & 1u)) {
-                                ex[q] += xv[q] & ST_VAL;
-                                if ((xv[q] >> 30) == 2u) done |= 1u << q;
-                            }
-                        pj--;  // (tile 0 of a chain is published inclusive: `done` is complete before pj wraps)
+                            if (!((done >> q) & 1u)) ex[q] += o[q];
+                        done |= meta & 15u;
+                        seen += meta >> 4;
+                        blocked = (meta >> 4) < (uint32_t)LB;
                     }
-                    if (done == 15u) break;
-                    if (stall) __builtin_amdgcn_s_sleep(2);
+                    pj = cur_j - 1u - seen;
+                } else
+                    pj = cur_j - 1u - used;
+                while (done != 15u) {  // (one tile at a time; tile 0 of a chain is published inclusive: `done` is complete before pj wraps)
                     asm volatile("" ::: "memory");
+                    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - cur_j + pj) * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
+                    const uint32_t xv[4] = {x.x, x.y, x.z, x.w};
+                    bool wait = false;
 #pragma unroll
-                    for (int i = 0; i < LB; i++) {
-                        const uint32_t pi = pj >= (uint32_t)i ? pj - i : 0u;
-                        xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - cur_j + pi) * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
-                    }
+                    for (int q = 0; q < 4; q++) wait |= !((done >> q) & 1u) && xv[q] == 0u;
+                    if (wait) { __builtin_amdgcn_s_sleep(2); continue; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (!((done >> q) & 1u)) {
+                            ex[q] += (xv[q] & ST_VAL) - 1u;
+                            if (xv[q] >> 31) done |= 1u << q;
+                        }
+                    pj--;
                 }
                 u32x4 a;
-                a.x = ST_INC | (ex[0] + my[0]); a.y = ST_INC | (ex[1] + my[1]); a.z = ST_INC | (ex[2] + my[2]); a.w = ST_INC | (ex[3] + my[3]);
-                __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + tid * 4u) * 4u), 0, 16);
+                a.x = ST_INC + (ex[0] + my[0]); a.y = ST_INC + (ex[1] + my[1]); a.z = ST_INC + (ex[2] + my[2]); a.w = ST_INC + (ex[3] + my[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
             }
+        }
+#if BFT_RS_LB_MODE == 2
+        if (!RANGED && more && tid < LBG * LBT) load_tile(nxt_c, nxt_j);
+#endif
+        if (!RANGED && tid < LBT) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t d = tid * 4 + q;
                 gpos[d] = (d <= mask ? dbase[d] + rows[cur_c * row_stride + d] : 0u) + ex[q] - tstart[d];
             }
         }
+        RS_T(9);
         __syncthreads();  // G
-        // ---- write out: slot by slot, i.e. digit run by digit run
+        RS_T(10);
+        // ---- write out: slot by slot, i.e. digit run by digit run (in two halves: all of a tile's LDS reads scheduled ahead of its stores
+        // cost more registers than the kernel has beside the next tile's keys)
+        constexpr int WH = (IPT % 2 == 0 && IPT >= 8) ? 2 : 1;
+#pragma unroll 1
+        for (int h = 0; h < WH; h++) {
 #pragma unroll
-        for (int i = 0; i < IPT; i++) {
-            const uint32_t slot = i * THREADS + tid;
-            if (slot < this_n) {
-                const K kk = lk[slot];
-                const uint32_t pos = gpos[digit_of(kk, bit, mask)] + slot;
-                if (!(BFT_RS_KO & 2) || kk == K(12345)) {
-                    ok[pos] = kk;
-                    if constexpr (HASV) ov[pos] = lv[slot];
+            for (int i2 = 0; i2 < IPT / WH; i2++) {
+                const uint32_t slot = (uint32_t)(h * (IPT / WH) + i2) * THREADS + tid;
+                if (slot < this_n) {
+                    const K kk = lk[slot];
+                    const uint32_t pos = gpos[digit_of(kk, bit, mask)] + slot;
+                    if (!(BFT_RS_KO & 2) || kk == K(12345)) {
+                        ok[pos] = kk;
+                        if constexpr (HASV) ov[pos] = lv[slot];
+                    }
                 }
             }
         }
+        RS_T(11);
         if (!more) break;
         cur_c = nxt_c;
         cur_j = nxt_j;
@@ -548,7 +652,7 @@ __global__ void k_rs_copy(In in, uint32_t n, K* __restrict__ ok, V* __restrict__
 template <class K, class V, int THREADS, int IPT>
 constexpr size_t pass_lds_bytes() {
     return align16(sizeof(K) * ((size_t)THREADS * IPT + 1)) + (std::is_same<V, NoVal>::value ? 0 : align16(sizeof(V) * ((size_t)THREADS * IPT + 1))) +
-           ((size_t)(THREADS / 64) * DIGITS + 4 * DIGITS + 16 + 4) * 4;
+           ((size_t)(THREADS / 64) * DIGITS + 4 * DIGITS + 16 + 4 + (size_t)(THREADS / (DIGITS / 4)) * (DIGITS / 4) * 5) * 4;
 }
 
 static inline int cu_count() {
@@ -593,7 +697,7 @@ struct Layout {
 // for a one-pass sort.  `in` may read out_k / out_v only when the number of passes is even.  V = NoVal: keys only.
 template <class K, class V, class In, int THREADS, int IPT>
 int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
-    if (n >= (1ull << 30)) return bft_fail(BFT_GPU_E_LIMIT, "internal: radix sort of 2^30 entries or more");
+    if (n >= (1ull << 31) - 1) return bft_fail(BFT_GPU_E_LIMIT, "internal: radix sort of 2^31 entries or more");
     if (end_bit < begin_bit || end_bit - begin_bit > (unsigned)(MAXP * DBITS) || end_bit > sizeof(K) * 8) return bft_fail(BFT_GPU_E_ARG, "internal: radix sort bit range");
     constexpr uint32_t TILE = (uint32_t)THREADS * IPT;
     const Plan pl = make_plan(begin_bit, end_bit);
@@ -656,8 +760,8 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         if (p == 0) {
 #define BFT_RS_LAUNCH0(BAL)                                                                                                                                            \
     do {                                                                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, In, THREADS, IPT, true, BAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_rs_pass<K, V, In, THREADS, IPT, true, BAL>), dim3(ranges), dim3(THREADS), lds, s, in, dk, dv, (uint32_t)n, pl.bit[0], pl.nbits[0],       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, In, THREADS, IPT, true, BAL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_rs_pass<K, V, In, THREADS, IPT, true, BAL, 1>), dim3(ranges), dim3(THREADS), lds, s, in, dk, dv, (uint32_t)n, pl.bit[0], pl.nbits[0],       \
                            W + L.partial + pl.hoff[0], pl.hwords, W + L.dbase, tpr, ch, ch, 1u, W + L.heads, W + L.states, 16u);                                       \
     } while (0)
             if (ballot) BFT_RS_LAUNCH0(true);
@@ -666,16 +770,26 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         } else {
             uint32_t* st = W + L.states + (size_t)(p - 1) * L.max_tiles * DIGITS;
             const uint32_t st_bytes = L.max_tiles * DIGITS * 4;
-            const uint32_t grid = std::min<uint32_t>(tiles + (1u << pl.cb[p]), (uint32_t)(cus * per_cu));
-#define BFT_RS_LAUNCH1(BAL)                                                                                                                                                      \
-    do {                                                                                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL>), dim3(grid), dim3(THREADS), lds, s, PtrIn<K, V>{src_k, src_v}, dk, dv, (uint32_t)n,         \
-                           pl.bit[p], pl.nbits[p], W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], W + L.dbase + (size_t)p * DIGITS, 0u, ch, ch + (1 << MAXCB) + 1, 1u << pl.cb[p],  \
-                           W + L.heads + (size_t)p * (1 << MAXCB), st, st_bytes);                                                                                                \
+#define BFT_RS_LAUNCH1(BAL, G)                                                                                                                                                      \
+    do {                                                                                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL, G>), dim3(grid), dim3(THREADS), lds, s, PtrIn<K, V>{src_k, src_v}, dk, dv, (uint32_t)n,         \
+                           pl.bit[p], pl.nbits[p], W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], W + L.dbase + (size_t)p * DIGITS, 0u, ch, ch + (1 << MAXCB) + 1, 1u << pl.cb[p],     \
+                           W + L.heads + (size_t)p * (1 << MAXCB), st, st_bytes);                                                                                                   \
     } while (0)
-            if (ballot) BFT_RS_LAUNCH1(true);
-            else BFT_RS_LAUNCH1(false);
+            // (a tile looks back over the tiles its chain's other workgroups are working on: one group of look-back threads sees four of them per
+            // round trip, all the groups of the workgroup THREADS / 32 -- the grid is kept within what they see at once)
+            constexpr int GMAX = THREADS / (DIGITS / 4);
+            const uint32_t nchp = 1u << pl.cb[p];
+            uint32_t grid = std::min<uint32_t>(tiles + nchp, (uint32_t)(cus * per_cu));
+            if (grid <= nchp * 4u) {
+                if (ballot) BFT_RS_LAUNCH1(true, 1);
+                else BFT_RS_LAUNCH1(false, 1);
+            } else {
+                grid = std::min<uint32_t>(grid, nchp * 4u * GMAX);
+                if (ballot) BFT_RS_LAUNCH1(true, GMAX);
+                else BFT_RS_LAUNCH1(false, GMAX);
+            }
 #undef BFT_RS_LAUNCH1
         }
         src_k = dk;
@@ -695,12 +809,12 @@ template <class K, class V, class In>
 int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
     constexpr size_t E = sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V));
     constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
-    constexpr int IPT_SMALL = E <= 8 ? 16 : E <= 16 ? 8 : E <= 32 ? 4 : 2;
+    constexpr int IPT_SMALL = E <= 8 ? 8 : E <= 16 ? 4 : E <= 32 ? 2 : 1;
 #ifdef BFT_RS_BIG_IPT
     if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
 #endif
     if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
-    return sort_cfg<K, V, In, 256, IPT_SMALL>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+    return sort_cfg<K, V, In, 512, IPT_SMALL>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
 }
 
 }  // namespace bft_rs

@@ -148,14 +148,16 @@ int main(int argc, char** argv) {
         printf("{\"what\": \"root-prefix split, 2e8 composites, bits [%u, %u)\", \"impl\": \"bft_rs\", \"ms\": %.3f, \"GBps_40B\": %.0f, \"bad\": %u}\n", lo, hi, ms, n * 40.0 / ms / 1e6, nb);
 #ifdef BFT_RS_PROF
         {
-            unsigned long long z[16] = {0}, pr[16];
+            unsigned long long z[2][16] = {{0}}, pr[2][16];
             HCK(hipMemcpyToSymbol(HIP_SYMBOL(bft_rs::g_rs_prof), z, sizeof(z)));
             (void)bft_rs::sort<uint64_t, bft_rs::NoVal>(bft_rs::PtrIn<uint64_t, bft_rs::NoVal>{in, nullptr}, n, out, (bft_rs::NoVal*)nullptr, tmp, (bft_rs::NoVal*)nullptr, lo, hi, 0, scratch);
             HCK(hipDeviceSynchronize());
             HCK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(bft_rs::g_rs_prof), sizeof(pr)));
-            const char* nm[9] = {"loop->claim", "rank(+load wait)", "barrier B", "scan C,D,E", "publish+lb issue+scatter", "next load issue", "look-back finish", "barrier G", "write-out"};
-            double tot = 0; for (int i = 0; i < 9; i++) tot += (double)pr[i];
-            for (int i = 0; i < 9; i++) printf("{\"phase\": \"%s\", \"share\": %.3f, \"Mticks\": %.1f}\n", nm[i], pr[i] / tot, pr[i] / 1e6);
+            const char* nm[12] = {"loop top", "claim publish + zero counters", "rank (+ wait for the loads)", "barrier B", "scan part 1", "barriers D, E + part 2", "publish + look-back loads", "reorder in LDS", "next loads issued", "look-back finish", "barrier G", "write-out"};
+            for (int k = 0; k < 2; k++) {
+                double tot = 0; for (int i = 0; i < 12; i++) tot += (double)pr[k][i];
+                for (int i = 0; i < 12; i++) printf("{\"pass\": \"%s\", \"phase\": \"%s\", \"share\": %.3f, \"Mticks\": %.1f}\n", k ? "chains" : "ranged", nm[i], pr[k][i] / tot, pr[k][i] / 1e6);
+            }
         }
 #endif
         size_t tb = 0;
