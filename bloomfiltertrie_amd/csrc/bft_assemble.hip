@@ -8,13 +8,12 @@
 //     k_assign_cc              one workgroup per node: CCs are opened while >= 255 k-mers are unassigned; the
 //                              first <= 255 unassigned keys seed the Bloom filter (LDS bitset, atomicOr), every
 //                              unassigned key the filter holds is claimed (first-BF-positive rule)
-//     hipCUB radix sort        prefixes grouped by (node, CC), prefix order kept
+//     radix sort (bft_sort.h)  prefixes grouped by (node, CC), prefix order kept
 //     k_runs / k_clusters      CC boundaries, filter2 clusters (runs of equal p_u)
 //     k_entries                prefix entries {p_v | count | row-or-child-node}, filter2 bits (atomicOr), child nodes
 //     k_ranks                  running rank into each filter2 word
 //     k_uc_rows, k_bloom_slice node UC rows; bit-sliced Bloom block of each node
 // The arrays are bit-identical to the host restatement bft_index.cpp (tests/test_gpu_build.py).
-#include <hipcub/hipcub.hpp>
 
 #include <atomic>
 #include <mutex>
@@ -24,6 +23,8 @@
 #include "bft_dev.h"
 #include "bft_image.h"
 #include "bft_index.h"
+#include "bft_scan.h"
+#include "bft_sort.h"
 #include "bft_walk.h"
 
 #define ABLK 256
@@ -58,11 +59,7 @@ struct Scan {
             if (tail) hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, out, 0u);
             return 0;
         }
-        size_t tb = 0;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
-        if (tb > tmp.bytes) CK(tmp.alloc(tb));
-        tb = tmp.bytes;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
+        CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp));
         hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, in, out, n, pin.p + slot, tail ? 1 : 0);
         return 0;
     }
@@ -81,11 +78,7 @@ struct Scan {
     int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {
         if (!total) {
             if (n == 0) return 0;
-            size_t tb = 0;
-            HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
-            if (tb > tmp.bytes) CK(tmp.alloc(tb));
-            tb = tmp.bytes;
-            HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
+            CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp));
             return 0;
         }
         CK(enqueue(in, out, n, 0));
@@ -701,11 +694,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                skey.as<uint64_t>(), iota.as<uint32_t>());
             int mbits = 1;
             while (mbits < 32 && (M >> mbits)) mbits++;
-            size_t tb = 0;
-            BFT_RADIX_SORT(0, 17 + mbits, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
-            DevBuf tmp;
-            CK(tmp.alloc(tb));
-            BFT_RADIX_SORT(0, 17 + mbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, skey.as<uint64_t>(), skey_s.as<uint64_t>(), iota.as<uint32_t>(), sp.as<uint32_t>(), (int)P, 0, 17 + mbits, s));
+            CK((bft_rs::sort_pairs<uint64_t, uint32_t>(skey.as<uint64_t>(), iota.as<uint32_t>(), P, skey_s.as<uint64_t>(), sp.as<uint32_t>(), 0, 17 + mbits, s)));
         }  // (no synchronisation: what is released here is only handed out again in the order of this stream, bft_pool_alloc)
         skey.release(); iota.release();
 

@@ -151,11 +151,15 @@ __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ 
     if (s) atomicAdd(&cnt[w], s);
 }
 
-// One workgroup per digit: exclusive scan of the digit's counts over the rows (ranges of pass 0, chains of a later pass), in place; the
-// digit's total.  rows <= 1024.
-__global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ m, uint32_t stride, uint32_t rows, uint32_t* __restrict__ tot) {
+// One workgroup per (digit, pass): exclusive scan of the digit's counts over the rows (ranges of pass 0 -- in place in the histogram
+// workgroups' blocks --, chains of a later pass), in place; the digit's total.  rows <= 1024.
+__global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ partial, uint32_t* __restrict__ cnt, Plan pl, uint32_t ranges, uint32_t* __restrict__ tot_all) {
     __shared__ uint32_t wsum[4];
-    const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t d = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (d >= (1u << pl.nbits[p])) return;
+    uint32_t* m = p == 0 ? partial + pl.hoff[0] : cnt + pl.hoff[p];
+    const uint32_t stride = p == 0 ? pl.hwords : 1u << pl.nbits[p], rows = p == 0 ? ranges : 1u << pl.cb[p];
+    uint32_t* tot = tot_all + p * DIGITS;
     uint32_t v[4], s = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -316,14 +320,27 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         return res + 8u * sub;
     };
     auto chain_tiles = [&](uint32_t c) -> uint32_t { return tile_first[c + 1] - tile_first[c]; };
-    auto claim_slow = [&](uint32_t& cc, uint32_t& jj) -> bool {  // (thread 0) the home chain is used up: any chain
-        for (uint32_t k = 1; k < nch; k++) {
-            const uint32_t c2 = pref_chain(k), nt = chain_tiles(c2);
-            if (nt == 0) continue;
-            const uint32_t j2 = atomicAdd(&heads[c2], 1u);
-            if (j2 < nt) { cc = c2; jj = j2; home = c2; return true; }
+    // the home chain is used up: any chain.  Called by the whole FIRST WAVEFRONT (uniformly): lane k looks at the k-th chain of the workgroup's
+    // order of preference -- one round trip says which chains have tiles left -- and the claims are then tried in that order.
+    auto claim_slow = [&](uint32_t& cc, uint32_t& jj) -> bool {
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(home);
+        home = h0;
+        const uint32_t k = lane, c2 = k < nch ? pref_chain(k) : 0u;
+        const uint32_t nt = k < nch ? chain_tiles(c2) : 0u;
+        uint32_t hd = NONE;
+        if (nt) hd = __hip_atomic_load(&heads[c2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t open = __ballot(nt && hd < nt);
+        bool got = false;
+        while (open && !got) {
+            const int l = __builtin_ctzll(open);
+            open &= open - 1ull;
+            uint32_t j2 = 0;
+            if ((int)lane == l) j2 = atomicAdd(&heads[c2], 1u);
+            j2 = __shfl(j2, l);
+            const uint32_t ntl = __shfl(nt, l), cl = __shfl(c2, l);
+            if (j2 < ntl) { cc = cl; jj = j2; home = cl; got = true; }
         }
-        return false;
+        return got;
     };
     K key[IPT];
     V val[IPT];
@@ -349,17 +366,22 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         if (cur_j >= rt_end) return;
         for (uint32_t d = tid; d < DIGITS; d += THREADS) grun[d] = d <= mask ? dbase[d] + rows[(size_t)blockIdx.x * row_stride + d] : 0u;
     } else {
-        if (tid == 0) {
+        if (wave == 0) {  // (uniform in the wavefront; lane 0 keeps `home` and the claim in flight)
             const uint32_t x = xcc_id();
             home = nch < 8 ? (blockIdx.x % nch) : x + 8u * ((blockIdx.x >> 3) % (nch >> 3));
             uint32_t cc = NONE, jj = 0;
             const uint32_t nt = chain_tiles(home);
-            const uint32_t j0 = nt ? atomicAdd(&heads[home], 1u) : 0u;
-            if (nt && j0 < nt) { cc = home; jj = j0; }
-            else if (!claim_slow(cc, jj)) cc = NONE;
-            shd[0] = cc;
-            shd[1] = jj;
-            if (cc != NONE) pend_j = atomicAdd(&heads[home], 1u);  // the tile after it
+            uint32_t j0 = 0;
+            if (nt && lane == 0) j0 = atomicAdd(&heads[home], 2u);  // this tile and the one after it
+            j0 = __builtin_amdgcn_readfirstlane(j0);
+            if (nt && j0 < nt) { cc = home; jj = j0; pend_j = j0 + 1u; }
+            else if (claim_slow(cc, jj)) {
+                uint32_t pj = 0;
+                if (lane == 0) pj = atomicAdd(&heads[home], 1u);
+                pend_j = __builtin_amdgcn_readfirstlane(pj);
+            } else
+                cc = NONE;
+            if (lane == 0) { shd[0] = cc; shd[1] = jj; }
         }
         __syncthreads();
         cur_c = shd[0];
@@ -416,11 +438,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (!RANGED && tid == 0) {  // the claim made a tile ago has returned by now (asked for here and not at the loop's top: behind it the
-            uint32_t cc = home, jj = pend_j;  // stores of the last tile are in flight, and a wavefront's memory operations return in order)
+        if (!RANGED && wave == 0) {  // the claim made a tile ago has returned by now (asked for here and not at the loop's top: behind it the
+            uint32_t cc = home, jj = __builtin_amdgcn_readfirstlane(pend_j);  // stores of the last tile are in flight, and a wavefront's memory operations return in order)
             if (jj >= chain_tiles(home) && !claim_slow(cc, jj)) cc = NONE;
-            shd[0] = cc;
-            shd[1] = jj;
+            if (lane == 0) { shd[0] = cc; shd[1] = jj; }
         }
         RS_T(2);
         __syncthreads();  // B
@@ -501,7 +522,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                 }
             }
 #endif
-            if (tid == 0 && more && nxt_c == home) pend_j = atomicAdd(&heads[home], 1u);
+            if (tid == 0 && more) pend_j = atomicAdd(&heads[nxt_c], 1u);  // (nxt_c is the chain the first wavefront claims from now: `home`)
         }
         RS_T(6);
         // ---- reorder in LDS
@@ -641,6 +662,133 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     }
 }
 
+// ---- an array that is ONE tile: every pass in the LDS of one workgroup, one launch ----------------------------------------------------------
+template <class K, class V, class In, int THREADS, int IPT, bool BALLOT>
+__global__ __launch_bounds__(THREADS) void k_rs_tiny(In in, K* __restrict__ ok, V* __restrict__ ov, uint32_t n, Plan pl) {
+    constexpr bool HASV = !std::is_same<V, NoVal>::value;
+    constexpr int WAVES = THREADS / 64, TILE = THREADS * IPT;
+    constexpr int DT = THREADS < DIGITS ? THREADS : DIGITS, DPT = DIGITS / DT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    K* lk = reinterpret_cast<K*>(smem);
+    constexpr size_t OFF_V = align16(sizeof(K) * (size_t)(TILE + 1));
+    V* lv = reinterpret_cast<V*>(smem + OFF_V);
+    constexpr size_t OFF_C = OFF_V + (HASV ? align16(sizeof(V) * (size_t)(TILE + 1)) : 0);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + OFF_C);  // [WAVES][DIGITS]
+    uint32_t* tstart = cnt + WAVES * DIGITS;                    // [DIGITS]
+    uint32_t* wsum = tstart + DIGITS;                           // [16]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    K key[IPT];
+    V val[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+        const uint32_t at = idx < n ? idx : 0u;
+        key[r] = in.key(at);
+        if constexpr (HASV) val[r] = in.val(at);
+    }
+    for (int p = 0; p < pl.P; p++) {
+        const uint32_t bit = pl.bit[p], mask = (1u << pl.nbits[p]) - 1u;
+#pragma unroll
+        for (int q = 0; q < DIGITS / 64; q++) cnt[wave * DIGITS + q * 64 + lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t rank[IPT];
+        if (BALLOT) {
+            const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+                const bool valid = idx < n;
+                const uint32_t d = digit_of(key[r], bit, mask);
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < DBITS; b++) {
+                    const bool on = (d >> b) & 1u;
+                    const uint64_t bj = __ballot(on);
+                    peers &= on ? bj : ~bj;
+                }
+                const int leader = valid ? __builtin_ctzll(peers) : (int)lane;
+                uint32_t b0 = 0;
+                if (valid && (int)lane == leader) b0 = atomicAdd(&cnt[wave * DIGITS + d], (uint32_t)__builtin_popcountll(peers));
+                rank[r] = __shfl(b0, leader) + (uint32_t)__builtin_popcountll(peers & lt_mask);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+                rank[r] = 0;
+                if (idx < n) rank[r] = atomicAdd(&cnt[wave * DIGITS + digit_of(key[r], bit, mask)], 1u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __syncthreads();
+        uint32_t sq[DPT], tot = 0, inc = 0;
+        if (tid < DT) {
+#pragma unroll
+            for (int q = 0; q < DPT; q++) {
+                const uint32_t d = tid * DPT + q;
+                uint32_t cw[WAVES], run = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) cw[w] = cnt[w * DIGITS + d];
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) {
+                    cnt[w * DIGITS + d] = run;
+                    run += cw[w];
+                }
+                sq[q] = run;
+                tot += run;
+            }
+            inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(inc, o);
+                if ((int)lane >= o) inc += v;
+            }
+            if (lane == 63) wsum[wave] = inc;
+        }
+        __syncthreads();
+        if (tid < DT) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int w = 0; w < DT / 64; w++)
+                if (w < (int)wave) before += wsum[w];
+            uint32_t start = before + inc - tot;
+#pragma unroll
+            for (int q = 0; q < DPT; q++) {
+                tstart[tid * DPT + q] = start;
+                start += sq[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+            const uint32_t d = digit_of(key[r], bit, mask);
+            const uint32_t slot = idx < n ? tstart[d] + cnt[wave * DIGITS + d] + rank[r] : (uint32_t)TILE;
+            lk[slot] = key[r];
+            if constexpr (HASV) lv[slot] = val[r];
+        }
+        __syncthreads();
+        if (p + 1 < pl.P) {  // the next pass ranks the new order
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t idx = wave * 64u * IPT + r * 64u + lane;
+                const uint32_t at = idx < n ? idx : 0u;
+                key[r] = lk[at];
+                if constexpr (HASV) val[r] = lv[at];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const uint32_t slot = i * THREADS + tid;
+        if (slot < n) {
+            ok[slot] = lk[slot];
+            if constexpr (HASV) ov[slot] = lv[slot];
+        }
+    }
+}
+
 template <class K, class V, class In>
 __global__ void k_rs_copy(In in, uint32_t n, K* __restrict__ ok, V* __restrict__ ov) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -716,6 +864,57 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     const uint32_t tiles = (uint32_t)((n + TILE - 1) / TILE);
     const uint32_t wgs = std::min<uint32_t>(tiles, (uint32_t)std::min(1024, cus * per_cu));  // (<= 1024 ranges: k_rs_rowscan)
     const uint32_t tpr = (tiles + wgs - 1) / wgs, ranges = (tiles + tpr - 1) / tpr;
+    constexpr int HT = 1024;
+    if (tiles == 1) {  // one tile: every pass in one workgroup's LDS
+        if (ballot) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_tiny<K, V, In, THREADS, IPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_rs_tiny<K, V, In, THREADS, IPT, true>), dim3(1), dim3(THREADS), lds, s, in, out_k, out_v, (uint32_t)n, pl);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_tiny<K, V, In, THREADS, IPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_rs_tiny<K, V, In, THREADS, IPT, false>), dim3(1), dim3(THREADS), lds, s, in, out_k, out_v, (uint32_t)n, pl);
+        }
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    if (n < BFT_RS_CHAIN_MIN || pl.P == 1) {
+        // Passes that each count their own digit first: a histogram kernel per pass (one more read of the keys), and no pass ever looks back --
+        // every workgroup owns a contiguous range of tiles in every pass.  For arrays of up to a few 10^7 entries the extra read costs less than
+        // the look-back's round trips and the chains' bookkeeping.
+        const size_t words = (size_t)2 * DIGITS + (size_t)CT * 2 + (size_t)ranges * DIGITS + 8;
+        if (scratch.bytes < words * 4) CK(scratch.alloc(words * 4));
+        uint32_t* W = scratch.as<uint32_t>();
+        uint32_t *tot = W, *dbase = W + DIGITS, *chain = W + 2 * DIGITS, *partial = W + 2 * DIGITS + 2 * CT;
+        const K* src_k = nullptr;
+        const V* src_v = nullptr;
+        for (int p = 0; p < pl.P; p++) {
+            const bool to_out = ((pl.P - 1 - p) % 2) == 0;
+            K* dk = to_out ? out_k : tmp_k;
+            V* dv = to_out ? out_v : tmp_v;
+            const Plan p1 = make_plan(pl.bit[p], pl.bit[p] + pl.nbits[p]);
+#define BFT_RS_ONEPASS(INTYPE, INVAL, BAL)                                                                                                                                     \
+    do {                                                                                                                                                                       \
+        hipLaunchKernelGGL((k_rs_hist<K, INTYPE, HT>), dim3(ranges), dim3(HT), (size_t)p1.hwords * 4, s, INVAL, (uint32_t)n, p1, tpr * TILE, partial);                          \
+        hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << p1.nbits[0], 1), dim3(256), 0, s, partial, partial, p1, ranges, tot);                                                       \
+        hipLaunchKernelGGL(k_rs_digits, dim3(1), dim3(DIGITS), 0, s, tot, dbase, chain, p1, (uint32_t)n, TILE);                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL((k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>), dim3(ranges), dim3(THREADS), lds, s, INVAL, dk, dv, (uint32_t)n, p1.bit[0], p1.nbits[0],      \
+                           partial, p1.hwords, dbase, tpr, chain, chain, 1u, chain, chain, 16u);                                                                               \
+    } while (0)
+            if (p == 0) {
+                if (ballot) BFT_RS_ONEPASS(In, in, true);
+                else BFT_RS_ONEPASS(In, in, false);
+            } else {
+                const PtrIn<K, V> pin{src_k, src_v};
+                if (ballot) BFT_RS_ONEPASS(decltype(pin), pin, true);
+                else BFT_RS_ONEPASS(decltype(pin), pin, false);
+            }
+#undef BFT_RS_ONEPASS
+            src_k = dk;
+            src_v = dv;
+        }
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     Layout L;
     {
         L.max_tiles = tiles + (1u << MAXCB);
@@ -736,18 +935,17 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     if (scratch.bytes < L.total_words * 4) CK(scratch.alloc(L.total_words * 4));
     uint32_t* W = scratch.as<uint32_t>();
     HIPCK(hipMemsetAsync(W, 0, L.zero_words * 4, s));
-    constexpr int HT = 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_hist<K, In, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     hipLaunchKernelGGL((k_rs_hist<K, In, HT>), dim3(ranges), dim3(HT), (size_t)pl.hwords * 4, s, in, (uint32_t)n, pl, tpr * TILE, W + L.partial);
-    // pass 0: per digit, the ranges' counts -> where each range's keys of the digit start (in place in the histogram blocks)
-    hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << pl.nbits[0]), dim3(256), 0, s, W + L.partial + pl.hoff[0], pl.hwords, ranges, W + L.tot);
+    // per digit: the ranges' counts (pass 0, in place in the histogram blocks) and the chains' (later passes) -> where each of them starts inside the digit
+    uint32_t maxnb = 0;
+    for (int p = 0; p < pl.P; p++) maxnb = std::max(maxnb, pl.nbits[p]);
     if (pl.P > 1) {
         const uint32_t words = pl.hwords - pl.hoff[1];
         hipLaunchKernelGGL(k_rs_reduce, dim3((words + 255) / 256, std::max(1u, std::min(8u, ranges / 32u))), dim3(256), 0, s, W + L.partial, ranges, pl.hwords, pl.hoff[1], words,
                            W + L.cnt + pl.hoff[1]);
-        for (int p = 1; p < pl.P; p++)
-            hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << pl.nbits[p]), dim3(256), 0, s, W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], 1u << pl.cb[p], W + L.tot + (size_t)p * DIGITS);
     }
+    hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << maxnb, pl.P), dim3(256), 0, s, W + L.partial, W + L.cnt, pl, ranges, W + L.tot);
     hipLaunchKernelGGL(k_rs_digits, dim3(pl.P), dim3(DIGITS), 0, s, W + L.tot, W + L.dbase, W + L.chain, pl, (uint32_t)n, TILE);
     HIPCK(hipGetLastError());
     const K* src_k = nullptr;
@@ -799,9 +997,14 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     return 0;
 }
 
-// the tile shape by the bytes of an entry: large arrays stream through 1024-thread workgroups, one per CU, with the largest tile the LDS
-// holds (a digit's piece of a tile is TILE / 512 entries: the longer, the fewer partial lines); small arrays take 256-thread workgroups so
-// that there are tiles for every CU
+// The tile shape by the bytes of an entry: 1024-thread workgroups, one per CU, with the largest tile the LDS holds (a digit's piece of a tile
+// is TILE / 512 entries: the longer, the fewer partial lines).  By size: one tile -> one launch, every pass in LDS (k_rs_tiny); up to
+// BFT_RS_CHAIN_MIN entries -> a histogram kernel and a ranged pass per digit; beyond -> one histogram kernel, a ranged first pass, chained
+// passes behind it (2 x 10^8 composites: 2.2-2.3 ms against 2.75 with a histogram per pass; 1.6 x 10^6 pairs, eight passes: 0.18 ms against
+// 0.43 chained -- and 0.27 for rocPRIM's onesweep --; 4.5 x 10^7 k-mer hash records: 1.33 against 1.50).
+#ifndef BFT_RS_CHAIN_MIN
+#define BFT_RS_CHAIN_MIN (1u << 23)
+#endif
 #ifndef BFT_RS_BIG_THREADS
 #define BFT_RS_BIG_THREADS 1024
 #endif
@@ -809,12 +1012,31 @@ template <class K, class V, class In>
 int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
     constexpr size_t E = sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V));
     constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
-    constexpr int IPT_SMALL = E <= 8 ? 8 : E <= 16 ? 4 : E <= 32 ? 2 : 1;
 #ifdef BFT_RS_BIG_IPT
-    if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+    return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+#else
+    return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
 #endif
-    if (n >= (1u << 22)) return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
-    return sort_cfg<K, V, In, 512, IPT_SMALL>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+}
+
+// the same with the buffers between the passes and the scratch taken from the device-memory cache for the duration of the call (they go back
+// to it stream-ordered: DevBuf)
+template <class K, class V, class In>
+int sort_in(In in, uint64_t n, K* out_k, V* out_v, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
+    DevBuf tk, tv, scratch;
+    if (make_plan(begin_bit, end_bit).P > 1 && n) {
+        CK(tk.alloc(n * sizeof(K)));
+        if (!std::is_same<V, NoVal>::value) CK(tv.alloc(n * sizeof(V)));
+    }
+    return sort<K, V, In>(in, n, out_k, out_v, tk.as<K>(), tv.as<V>(), begin_bit, end_bit, s, scratch);
+}
+template <class K, class V>
+int sort_pairs(const K* in_k, const V* in_v, uint64_t n, K* out_k, V* out_v, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
+    return sort_in<K, V, PtrIn<K, V>>(PtrIn<K, V>{in_k, in_v}, n, out_k, out_v, begin_bit, end_bit, s);
+}
+template <class K>
+int sort_keys(const K* in_k, uint64_t n, K* out_k, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
+    return sort_in<K, NoVal, PtrIn<K, NoVal>>(PtrIn<K, NoVal>{in_k, nullptr}, n, out_k, (NoVal*)nullptr, begin_bit, end_bit, s);
 }
 
 }  // namespace bft_rs

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../bloomfiltertrie_amd/csrc/bft_sort.h"
+#include "../../bloomfiltertrie_amd/csrc/bft_scan.h"
 
 static std::string g_err;
 int bft_fail(int code, const std::string& msg) { g_err = msg; fprintf(stderr, "fail: %s\n", msg.c_str()); return code; }
@@ -94,6 +95,37 @@ __global__ void k_check_kh(const uint32_t* p, const Rec12* r, uint64_t n, unsign
 using Msd9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                         rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9, rocprim::block_radix_rank_algorithm::match>>;
 
+struct FlagIn {  // flags computed on the fly, two counts in one word (what the de-duplication scans)
+    const uint64_t* k;
+    __device__ uint64_t operator()(uint64_t i) const { const uint64_t a = k[i], b = i ? k[i - 1] : ~a; return ((uint64_t)((a >> 9) != (b >> 9)) << 32) | (uint64_t)(a != b); }
+};
+template <class T>
+static int check_scan(uint64_t n, int what) {
+    std::vector<T> h(n), want(n), got(n);
+    for (uint64_t i = 0; i < n; i++) h[i] = (T)(what == 2 ? (mix(i) & 0xFFFFFFFFFFull) : (mix(i) % 7));
+    T run = what == 2 ? (T)5 : (T)0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (what == 0) { want[i] = run; run += h[i]; }                          // exclusive sum
+        else if (what == 1) { run += h[i]; want[i] = run; }                     // inclusive sum
+        else { run = std::max(run, h[i]); want[i] = run; }                      // inclusive max, init 5
+    }
+    T *d, *o;
+    HCK(hipMalloc(&d, n * sizeof(T) + 16)); HCK(hipMalloc(&o, n * sizeof(T) + 16));
+    HCK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    DevBuf sc;
+    int rc;
+    if (what == 0) rc = bft_scan::exclusive_sum_ptr<T>(d, o, n, 0, sc);
+    else if (what == 1) rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Sum, true>(bft_scan::PtrIn<T>{d}, o, n, (T)0, bft_scan::Sum(), 0, sc);
+    else rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Max, true>(bft_scan::PtrIn<T>{d}, o, n, (T)5, bft_scan::Max(), 0, sc);
+    if (rc) return 1;
+    HCK(hipMemcpy(got.data(), o, n * sizeof(T), hipMemcpyDeviceToHost));
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) bad += got[i] != want[i];
+    printf("{\"check\": \"scan %s u%d\", \"n\": %llu, \"bad\": %llu}\n", what == 0 ? "exclusive sum" : what == 1 ? "inclusive sum" : "inclusive max", (int)sizeof(T) * 8, (unsigned long long)n, (unsigned long long)bad);
+    hipFree(d); hipFree(o);
+    return bad ? 1 : 0;
+}
+
 template <class F>
 static float time_it(F f, int reps = 5) {
     hipEvent_t a, b;
@@ -128,6 +160,13 @@ int main(int argc, char** argv) {
     fails += check_case<uint64_t, uint8_t>(4500000, 44, 62, 0, "u64+u8 18 bits");
     fails += check_case<uint32_t, bft_rs::NoVal>(1234567, 5, 5, 0, "no bits (copy)");
     }
+    if (!nocheck)
+        for (uint64_t n : {1ull, 63ull, 4096ull, 4097ull, 1000003ull, 30000001ull}) {
+            fails += check_scan<uint32_t>(n, 0);
+            fails += check_scan<uint64_t>(n, 0);
+            fails += check_scan<uint32_t>(n, 1);
+            fails += check_scan<uint64_t>(n, 2);
+        }
     if (fails) { printf("{\"failed_checks\": %d}\n", fails); return 1; }
     if (quick) return 0;
     DevBuf scratch;
@@ -190,6 +229,21 @@ int main(int argc, char** argv) {
         printf("{\"what\": \"k-mer hash sort\", \"impl\": \"rocprim default\", \"ms\": %.3f}\n", ms);
         fflush(stdout);
         hipFree(t2); hipFree(in); hipFree(out); hipFree(tmp); hipFree(ri); hipFree(ro); hipFree(rt);
+    }
+    {   // scans: 4.46e7 u64 (the k-mer hash's running maximum), 2e8 flags on the fly
+        const uint64_t n = 44600000ull;
+        uint64_t *in, *out;
+        HCK(hipMalloc(&in, n * 8)); HCK(hipMalloc(&out, n * 8));
+        hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, in, n, 10);
+        float ms = time_it([&] { (void)bft_scan::scan<uint64_t, bft_scan::PtrIn<uint64_t>, bft_scan::Max, true>(bft_scan::PtrIn<uint64_t>{in}, out, n, 0ull, bft_scan::Max(), 0, scratch); });
+        printf("{\"what\": \"inclusive max-scan, 4.46e7 u64\", \"impl\": \"bft_scan\", \"ms\": %.3f, \"GBps\": %.0f}\n", ms, n * 16.0 / ms / 1e6);
+        size_t tb = 0;
+        (void)rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, rocprim::maximum<uint64_t>(), 0);
+        void* t2;
+        HCK(hipMalloc(&t2, tb));
+        ms = time_it([&] { (void)rocprim::inclusive_scan(t2, tb, in, out, (size_t)n, rocprim::maximum<uint64_t>(), 0); });
+        printf("{\"what\": \"inclusive max-scan, 4.46e7 u64\", \"impl\": \"rocprim\", \"ms\": %.3f}\n", ms);
+        hipFree(t2); hipFree(in); hipFree(out);
     }
     {   // a small sort: 1.6e6 64-bit keys + u32
         const uint64_t n = 1600000ull;
