@@ -1379,10 +1379,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
             CK(len.alloc(n_sets * 4));
             const dim3 tgrid(bft_grid_for((n_slots + ABLK - 1) / ABLK)), sgrid(bft_grid_for((n_sets + ABLK - 1) / ABLK));
             hipLaunchKernelGGL(k_cs_hash_compact, tgrid, block, 0, s, tab.as<CsSlot>(), (uint32_t)n_slots, keys.as<uint64_t>(), slots.as<uint32_t>(), cnt.as<uint32_t>() + 2);
-            size_t tb = 0;
-            BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
-            CK(tmp.alloc(tb));
-            BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.as<uint64_t>(), keys_s.as<uint64_t>(), slots.as<uint32_t>(), slots_s.as<uint32_t>(), (int)n_sets, 0, 64, s));
+            CK((bft_rs::sort_pairs<uint64_t, uint32_t>(keys.as<uint64_t>(), slots.as<uint32_t>(), n_sets, keys_s.as<uint64_t>(), slots_s.as<uint32_t>(), 0, 64, s)));
             hipLaunchKernelGGL(k_cs_hash_ids, sgrid, block, 0, s, slots_s.as<uint32_t>(), (uint32_t)n_sets, tab.as<CsSlot>(), d_seg_off, rep.as<uint32_t>(), len.as<uint32_t>());
             CK(d_cs_off.alloc((n_sets + 1) * 4));
             CK(scan.enqueue(len.as<uint32_t>(), d_cs_off.as<uint32_t>(), n_sets, 0, true));
@@ -1439,12 +1436,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     // Equal lists only have to end up next to each other: the low 48 bits of the signature order them (6 radix passes instead
     // of 8).  Two different lists that agree on those bits could at worst split a run of equal lists, i.e. cost a duplicate
     // dictionary entry (expected once in ~10^14 / n_sets^2 builds); k_cs_heads still compares whole signatures and lists.
-    // (begin_bit = 16, end_bit = 64 -- the high bits -- faulted inside the library sort on ROCm 7.2 for n of a few 10^4; a bit
-    // range that starts at 0, as every other sort of this library uses, does not.)
-    size_t tb = 0;
-    BFT_RADIX_SORT(0, 48, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
-    CK(tmp.alloc(tb));
-    BFT_RADIX_SORT(0, 48, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, sig.as<uint64_t>(), sig_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)nk, 0, 48, s));
+    CK((bft_rs::sort_pairs<uint64_t, uint32_t>(sig.as<uint64_t>(), iota.as<uint32_t>(), nk, sig_s.as<uint64_t>(), order.as<uint32_t>(), 0, 48, s)));
     for (int exact = 1; exact < 2; exact++) {
         g_exact_passes++;
         hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, exact, head.as<uint32_t>(), len.as<uint32_t>());

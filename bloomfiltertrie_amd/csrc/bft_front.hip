@@ -20,9 +20,8 @@
 // bucket's k-mers share are dropped inside the bucket, which makes room for the id.
 // One read and one write of the array for all the remaining bits, where a device-wide LSD sort spends a pass per 8 bits
 // (rocPRIM: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms; these kernels: 3.0 ms).
-#include <hipcub/hipcub.hpp>
-
 #include "bft_dev.h"
+#include "bft_scan.h"
 
 #define FB_BLOCK 256
 #define FB_WAVES (FB_BLOCK / 64)
@@ -462,10 +461,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     else if (mx <= 256u * 12u) FB_LAUNCH(12);
     else FB_LAUNCH(16);
 #undef FB_LAUNCH
-    size_t tb = 0;
-    HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
-    CK(tmp.alloc(tb));
-    HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, counts.as<uint64_t>(), bases.as<uint64_t>(), (int)(nb + 1), s));
+    CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
     HIPCK(hipGetLastError());
     bft_stage("bucket sorts in LDS (+ scan of the counts)", (double)n * 16 + (d_vals ? (double)n * vw : 0.0), s);

@@ -10,11 +10,9 @@
 //   bft_kernels_build.h  de-duplication of sorted (k-mer, genome) pairs for the bulk build
 //   bft_kernels_color.h  batched get_annotation + get_list_id_genomes (src/bft.c:363-387, 622-641)
 //   bft_walk.h           the per-k-mer walk itself (shared with the host-side test helper)
-// The bulk build sorts with hipCUB's device radix sort (a ROCm library primitive); colour-set interning and container
+// The bulk build sorts and scans with the library's own kernels (bft_sort.h, bft_scan.h); colour-set interning and container
 // assembly are the kernels of bft_assemble.hip -- see DESIGN.md "Insertion".
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -33,6 +31,8 @@
 #include "bft_image.h"
 #include "bft_index.h"
 #include "bft_kh.h"
+#include "bft_scan.h"
+#include "bft_sort.h"
 #include "bft_walk.h"
 
 #define BFT_BLOCK 256
@@ -41,6 +41,7 @@
 // (the reference's own annotation codec holds 6 bits per byte, include/log2.h:45-50: 2^24 ids already take 4-byte entries).
 #define BFT_MAX_GENOME_ID (1u << 24)
 
+int bft_rs::g_bft_rs_rank_mode = -1;  // how bft_sort.h ranks: 0 LDS atomics (lane order checked on the device), 1 ballots ("sort_ballots")
 static thread_local std::string g_err;
 int bft_fail(int code, const std::string& msg) {
     g_err = msg;
@@ -708,54 +709,38 @@ static int bits_for(uint64_t v) {
 static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const uint32_t* g, uint64_t total, uint64_t* okeys,
                       uint64_t ostride, uint32_t* og, bool g_already_ordered, bool is_log = false) {
     const int W = h->W;
-    const int n = (int)total;
     if (W == 1) {
         // one-word keys: sort the (key, genome) pairs themselves; the radix sort is stable, so a genome-id pass
         // first (skipped when the ids already ascend) followed by the key pass gives (T, genome) order
-        DevBuf k2, g2, tmp1;
+        DevBuf k2, g2;
         const uint64_t* kin = keys;
         const uint32_t* gin = g;
         if (!g_already_ordered) {
             CK(k2.alloc(total * 8));
             CK(g2.alloc(total * 4));
-            size_t tb = 0;
             const int gb = bits_for(h->max_gid_seen);
-            BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
-            CK(tmp1.alloc(tb));
-            BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, gin, g2.as<uint32_t>(), kin, k2.as<uint64_t>(), n, 0, gb, h->stream));
+            CK((bft_rs::sort_pairs<uint32_t, uint64_t>(gin, kin, total, g2.as<uint32_t>(), k2.as<uint64_t>(), 0, gb, h->stream)));
             kin = k2.as<uint64_t>();
             gin = g2.as<uint32_t>();
         }
-        size_t tb = 0;
-        BFT_RADIX_SORT(0, 2 * h->k, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
-        if (tb > tmp1.bytes) {
-            HIPCK(hipStreamSynchronize(h->stream));
-            CK(tmp1.alloc(tb));
-        }
-        BFT_RADIX_SORT(0, 2 * h->k, hipcub::DeviceRadixSort::SortPairs(tmp1.p, tb, kin, okeys, gin, og, n, 0, 2 * h->k, h->stream));
+        CK((bft_rs::sort_pairs<uint64_t, uint32_t>(kin, gin, total, okeys, og, 0, 2 * h->k, h->stream)));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));
         return 0;
     }
-    DevBuf perm, perm2, ku, ku2, kg, kg2, tmp;
+    DevBuf perm, perm2, ku, ku2, kg2;
     CK(perm.alloc(total * 4));
     CK(perm2.alloc(total * 4));
     CK(ku.alloc(total * 8));
     CK(ku2.alloc(total * 8));
-    CK(kg.alloc(total * 4));
-    CK(kg2.alloc(total * 4));
     const int grid = grid_for((total + 255) / 256);
     hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, h->stream, perm.as<uint32_t>(), total);
-    size_t tb32 = 0, tb64 = 0;
-    BFT_RADIX_SORT(0, 32, hipcub::DeviceRadixSort::SortPairs(nullptr, tb32, kg.as<uint32_t>(), kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 32, h->stream));
-    BFT_RADIX_SORT(0, 64, hipcub::DeviceRadixSort::SortPairs(nullptr, tb64, ku.as<uint64_t>(), ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, 64, h->stream));
-    CK(tmp.alloc(std::max(tb32, tb64)));
     // pass 0: genome id (least significant); skipped when the input is already in genome-id order
     // (ids inserted in non-decreasing order, as the reference requires: the stable key passes keep it)
     if (!g_already_ordered) {
-        size_t tb = tmp.bytes;
+        CK(kg2.alloc(total * 4));
         const int gb = bits_for(h->max_gid_seen);
-        BFT_RADIX_SORT(0, gb, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, g, kg2.as<uint32_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, gb, h->stream));
+        CK((bft_rs::sort_pairs<uint32_t, uint32_t>(g, perm.as<uint32_t>(), total, kg2.as<uint32_t>(), perm2.as<uint32_t>(), 0, gb, h->stream)));
         perm.swap(perm2);
     }
     // passes over the key words, least significant word (W-1) first
@@ -766,8 +751,7 @@ static int sort_pairs(bft_gpu* h, const uint64_t* keys, uint64_t stride, const u
             hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, h->stream, kin, perm.as<uint32_t>(), ku.as<uint64_t>(), total);
             kin = ku.as<uint64_t>();
         }
-        size_t tb = tmp.bytes;
-        BFT_RADIX_SORT(0, nbits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin, ku2.as<uint64_t>(), perm.as<uint32_t>(), perm2.as<uint32_t>(), n, 0, nbits, h->stream));
+        CK((bft_rs::sort_pairs<uint64_t, uint32_t>(kin, perm.as<uint32_t>(), total, ku2.as<uint64_t>(), perm2.as<uint32_t>(), 0, nbits, h->stream)));
         perm.swap(perm2);
     }
     // (one pass over the permutation for every word and the id, instead of a pass each; the ids of the LOG come out of the table of its insert calls)
@@ -1190,10 +1174,7 @@ static int ensure_table(bft_gpu* h) {
     HIPCK(hipStreamSynchronize(h->stream));
     if (got != n) return fail(BFT_GPU_E_HIP, "k-mer hash does not hold the index (compact_table)");
     if (W == 1) {
-        size_t tb = 0;
-        BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(nullptr, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
-        CK(tmp.alloc(tb));
-        BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(tmp.p, tb, keys.as<uint64_t>(), tk.as<uint64_t>(), vals.as<uint32_t>(), tcol.as<uint32_t>(), (uint32_t)n, 0u, (unsigned)(2 * h->k), h->stream));
+        CK((bft_rs::sort_pairs<uint64_t, uint32_t>(keys.as<uint64_t>(), vals.as<uint32_t>(), n, tk.as<uint64_t>(), tcol.as<uint32_t>(), 0u, (unsigned)(2 * h->k), h->stream)));
     } else {  // two-word keys: the build's permutation sort (words apart, as the dump wrote them), then rows of two words
         DevBuf sorted;
         CK(sorted.alloc(n * W * 8));
@@ -1366,11 +1347,7 @@ static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t tota
     DevBuf tmp, pos;
     CK(pos.alloc(total * 8));
     const BftPairFlags2<GT> pf{sk, sg};
-    auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
-    size_t tb2 = 0;
-    HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-    CK(tmp.alloc(tb2));
-    HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+    CK((bft_scan::exclusive_sum<uint64_t>(pf, pos.as<uint64_t>(), total, h->stream, tmp)));
     uint64_t last_pos = 0, last_k[2] = {0, 0};
     GT last_g[2] = {0, 0};
     HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1399,46 +1376,31 @@ static int dedupe_w1(bft_gpu* h, const uint64_t* sk, const GT* sg, uint64_t tota
 template <class GT>
 static int sort_dedupe_w1_narrow(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, DevBuf& tk, DevBuf& seg_off, DevBuf& npg,
                                  uint64_t& nk, uint64_t& np) {
-    DevBuf sk, sg, tmp;
+    DevBuf sk, sg;
     CK(sk.alloc(total * 8));
     CK(sg.alloc(total * sizeof(GT)));
-    const BftNarrowIds<GT> nar{src_g};
-    auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
-    size_t tb = 0;
-    BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
-    CK(tmp.alloc(tb));
-    BFT_RADIX_SORT(0u, (unsigned)(2 * h->k), rocprim::radix_sort_pairs(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sg.as<GT>(), (uint32_t)total, 0u, (unsigned)(2 * h->k), h->stream));
+    CK((bft_rs::sort_in<uint64_t, GT>(BftPairIn<GT>{src_k, src_g}, total, sk.as<uint64_t>(), sg.as<GT>(), 0u, (unsigned)(2 * h->k), h->stream)));
     HIPCK(hipGetLastError());
-    tmp.release();
     return dedupe_w1<GT>(h, sk.as<uint64_t>(), sg.as<GT>(), total, tk, seg_off, npg, nk, np);
 }
 
 // The same front end for ordered one-word keys whose composite does not fit 63 bits (k = 31 beyond a couple of genomes, k = 27 beyond
 // 512): a stable key + value sort on the 18 root-prefix bits -- the ids travel beside the keys, narrowed to VT --, then the buckets
 // (bft_front.hip), where the bits a bucket's k-mers share make room for the id.  done = false: a bucket is too large, nothing was built.
-using Msd9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
-                                                                            rocprim::block_radix_rank_algorithm::match>>;
 template <class VT>
 static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* src_g, uint64_t total, int gb, DevBuf& tk, DevBuf& seg_off, DevBuf& npg,
                            uint64_t& nk, uint64_t& np, bool& done) {
     done = false;
     const unsigned top = (unsigned)std::min(18, 2 * h->k), rest = (unsigned)(2 * h->k) - top;
-    DevBuf sk, sv, tmp, boff, maxb;
+    DevBuf sk, sv, boff, maxb;
     CK(sk.alloc(total * 8));
     CK(sv.alloc(total * sizeof(VT)));
     CK(boff.alloc(((1u << top) + 1) * 4));
     CK(maxb.alloc_zero(4, h->stream));
-    const BftNarrowIds<VT> nar{src_g};
-    auto vin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), nar);
-    size_t tb = 0;
-    BFT_RADIX_SORT(rest, (unsigned)(2 * h->k), rocprim::radix_sort_pairs<Msd9>(nullptr, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
-    CK(tmp.alloc(tb));
-    BFT_RADIX_SORT(rest, (unsigned)(2 * h->k), rocprim::radix_sort_pairs<Msd9>(tmp.p, tb, src_k, sk.as<uint64_t>(), vin, sv.as<VT>(), (uint32_t)total, rest, (unsigned)(2 * h->k), h->stream));
+    CK((bft_rs::sort_in<uint64_t, VT>(BftPairIn<VT>{src_k, src_g}, total, sk.as<uint64_t>(), sv.as<VT>(), rest, (unsigned)(2 * h->k), h->stream)));
     hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(),
                        maxb.as<uint32_t>());
     bft_stage("split (root-prefix, 2 x 9 bits, pairs)", (double)total * (12 + 12 + 2 * (8 + sizeof(VT)) + (8 + sizeof(VT))), h->stream);
-    tmp.release();
     uint32_t mx = 0;
     CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done,
                          &h->front_redone, sv.p, (uint32_t)sizeof(VT)));
@@ -1507,8 +1469,6 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             CK(cs.alloc(total * 8));
             CK(pos.alloc(total * 8));
             const BftCompose comp{src_k, h->log_comp ? nullptr : src_g, (uint32_t)gb};
-            auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), comp);
-            size_t tb = 0, tb2 = 0;
             // MSD first: a stable sort on the top 18 bits of T (the rotated root prefix: 2^18 buckets of ~10^3 composites on a
             // pan-genome index), then every bucket on its own on the remaining bits, in LDS, with the duplicates flagged and counted
             // on the way (bft_front.hip) -- one read and one write of the array instead of the four or five full passes those
@@ -1522,11 +1482,10 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 DevBuf boff, maxb;
                 CK(boff.alloc(((1u << top) + 1) * 4));
                 CK(maxb.alloc_zero(4, h->stream));
-                // (9-bit digits: the 18 bits in two onesweep passes instead of the three that rocPRIM's 8-bit default takes -- 2.76 ms
-                // against 3.79 on 2 x 10^8 keys, tools/microbench/msd_sort.hip)
-                BFT_RADIX_SORT((unsigned)gb + rest, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys<Msd9>(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
-                CK(tmp.alloc(tb));
-                BFT_RADIX_SORT((unsigned)gb + rest, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys<Msd9>(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream));
+                // (the library's own partition, bft_sort.h: one histogram kernel, a first pass that needs no look-back, a second in 64 chains;
+                // the composites are formed from the log by the kernels that read it; `pos` carries them between the two passes)
+                CK((bft_rs::sort<uint64_t, bft_rs::NoVal, BftCompose>(comp, total, cs.as<uint64_t>(), (bft_rs::NoVal*)nullptr, pos.as<uint64_t>(), (bft_rs::NoVal*)nullptr,
+                                                                      (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream, tmp)));
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
                                    boff.as<uint32_t>(), maxb.as<uint32_t>());
                 // (histogram: the log, 12 B per pair; pass 1: the log in, composites out; pass 2: composites in and out)
@@ -1538,14 +1497,11 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 if (done) pos.release();
             }
             if (!done) {
-            BFT_RADIX_SORT((unsigned)gb, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys(nullptr, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
+            if (!pos.p) CK(pos.alloc(total * 8));
+            CK((bft_rs::sort<uint64_t, bft_rs::NoVal, BftCompose>(comp, total, cs.as<uint64_t>(), (bft_rs::NoVal*)nullptr, pos.as<uint64_t>(), (bft_rs::NoVal*)nullptr, (unsigned)gb,
+                                                                  (unsigned)(gb + 2 * h->k), h->stream, tmp)));
             const BftPairFlags pf{cs.as<uint64_t>(), (uint32_t)gb};
-            auto fin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), pf);
-            HIPCK(rocprim::exclusive_scan(nullptr, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
-            if (std::max(tb, tb2) > tmp.bytes) CK(tmp.alloc(std::max(tb, tb2)));
-            tb = tb2 = tmp.bytes;
-            BFT_RADIX_SORT((unsigned)gb, (unsigned)(gb + 2 * h->k), rocprim::radix_sort_keys(tmp.p, tb, cin, cs.as<uint64_t>(), (uint32_t)total, (unsigned)gb, (unsigned)(gb + 2 * h->k), h->stream));
-            HIPCK(rocprim::exclusive_scan(tmp.p, tb2, fin, pos.as<uint64_t>(), (uint64_t)0, (size_t)total, rocprim::plus<uint64_t>(), h->stream));
+            CK((bft_scan::exclusive_sum<uint64_t>(pf, pos.as<uint64_t>(), total, h->stream, tmp)));
             uint64_t last_pos = 0, last_c[2] = {0, 0};
             HIPCK(hipMemcpyAsync(&last_pos, pos.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCK(hipMemcpyAsync(&last_c[1], cs.as<uint64_t>() + total - 1, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1607,11 +1563,9 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         CK(posP.alloc(total * 4));
         const int grid = grid_for((total + 255) / 256);
         hipLaunchKernelGGL(k_flags, dim3(grid), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, W, sg.as<uint32_t>(), total, head.as<uint32_t>(), keep.as<uint32_t>());
-        size_t tb = 0;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, head.as<uint32_t>(), posK.as<uint32_t>(), (int)total, h->stream));
-        CK(tmp.alloc(tb));
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, head.as<uint32_t>(), posK.as<uint32_t>(), (int)total, h->stream));
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, keep.as<uint32_t>(), posP.as<uint32_t>(), (int)total, h->stream));
+        CK(bft_scan::exclusive_sum_ptr<uint32_t>(head.as<uint32_t>(), posK.as<uint32_t>(), total, h->stream, tmp));
+        DevBuf tmp2;  // (a scratch of its own: the first scan may still be running on the stream)
+        CK(bft_scan::exclusive_sum_ptr<uint32_t>(keep.as<uint32_t>(), posP.as<uint32_t>(), total, h->stream, tmp2));
         uint32_t lastK[2], lastP[2];
         HIPCK(hipMemcpyAsync(&lastK[0], posK.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(hipMemcpyAsync(&lastK[1], head.as<uint32_t>() + total - 1, 4, hipMemcpyDeviceToHost, h->stream));
@@ -2289,10 +2243,7 @@ static int query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t m, DevBuf& dk, 
 static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
                        hipStream_t s, bool fill) {
     if (h->qc_used && h->qc_stream != s) HIPCK(hipStreamSynchronize(h->qc_stream));  // (the scratch belongs to the handle: one stream at a time)
-    const BftCsLen probe{nullptr, nullptr, 0};
-    auto it0 = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0ull), probe);
-    size_t tb = 0;
-    HIPCK(rocprim::exclusive_scan(nullptr, tb, it0, d_offsets, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s));
+    const size_t tb = ((n + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
     if (h->qc_cs.bytes < n * 4 || h->qc_tmp.bytes < tb) {
         if (h->qc_used) HIPCK(hipStreamSynchronize(s));
         if (h->qc_cs.bytes < n * 4) CK(h->qc_cs.alloc(n * 4 + n / 2));
@@ -2308,9 +2259,7 @@ static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
         CK(rc);
     }
     const BftCsLen len{d_cs, h->im.cs_off, n};
-    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0ull), len);
-    size_t tb2 = h->qc_tmp.bytes;
-    HIPCK(rocprim::exclusive_scan(h->qc_tmp.p, tb2, it, d_offsets, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s));
+    CK((bft_scan::exclusive_sum<uint64_t>(len, d_offsets, n + 1, s, h->qc_tmp)));
     if (fill) {
         hipLaunchKernelGGL(k_color_fill_cs, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_cs, h->im.cs_off, h->im.cs_ids, h->im.cs_w, d_offsets, n, ids_cap, d_ids, d_needed);
         HIPCK(hipGetLastError());
@@ -2557,8 +2506,7 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
     const uint64_t chunk = 1ull << 30;
     const uint64_t cmax = std::min(chunk, n_seqs);
     const uint64_t n_cw = (total_chars + 31) / 32;  // code words of the blob (32 characters each)
-    size_t scan_bytes = 0;
-    HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(cmax + 1), s));
+    const size_t scan_bytes = ((cmax + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
     CK(need(h->sq_codes, (n_cw + BFT_MAX_W + 2) * 8));
     CK(need(h->sq_bad, (n_cw + BFT_MAX_W + 2) * 4));
     CK(need(h->sq_npos, (cmax + 1) * 8));
@@ -2578,8 +2526,7 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
         const uint64_t ns = std::min(chunk, n_seqs - a);
         const uint64_t* soff = d_seq_off + a;
         hipLaunchKernelGGL(k_seq_plan, dim3(grid_for((ns + 256) / 256)), dim3(256), 0, s, soff, ns, h->k, h->sq_npos.as<uint64_t>());
-        size_t tb = h->sq_tmp.bytes;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(h->sq_tmp.p, tb, h->sq_npos.as<uint64_t>(), h->sq_poff.as<uint64_t>(), (int)(ns + 1), s));
+        CK(bft_scan::exclusive_sum_ptr<uint64_t>(h->sq_npos.as<uint64_t>(), h->sq_poff.as<uint64_t>(), ns + 1, s, h->sq_tmp));
         hipLaunchKernelGGL(k_seq_tiles, dim3(256 * 4), dim3(256), 0, s, h->sq_poff.as<uint64_t>(), (uint32_t)ns, h->sq_tile.as<uint32_t>());
         h->sq_units = total_chars / 256 + 2;  // (k-mer positions <= characters: the blocks the kernel can deal out)
         switch (h->W) {
@@ -2932,6 +2879,9 @@ extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     } else if (nm == "build_msd") {
         if (value < 0 || value > 2) return fail(BFT_GPU_E_ARG, "build_msd must be 0, 1 or 2");
         h->opt_msd = (int)value;
+    } else if (nm == "sort_ballots") {  // how the library's radix sort ranks the keys of a wavefront (bft_sort.h); process-wide
+        if (value != 0 && value != 1) return fail(BFT_GPU_E_ARG, "sort_ballots must be 0 (LDS atomics if the device serves them in lane order: checked once) or 1 (wavefront ballots)");
+        bft_rs::g_bft_rs_rank_mode = value ? 1 : -1;
     } else if (nm == "reserve_pairs") {
         // room for this many not-yet-built (k-mer, genome) pairs in the insertion log, so that a long series of insertKmers
         // batches never re-allocates it (a caller usually knows the total: line 2 of a kmers_comp file, README.md:166-170)

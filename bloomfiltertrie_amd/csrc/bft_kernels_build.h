@@ -72,6 +72,15 @@ struct BftCompose {  // input "iterator" of the sort: composite i from the inser
     const uint32_t* g;
     uint32_t gb;
     __host__ __device__ uint64_t operator()(uint32_t i) const { return g ? (k[i] << gb) | (uint64_t)g[i] : k[i]; }  // (g == NULL: the log already holds composites)
+    __device__ uint64_t key(uint32_t i) const { return (*this)(i); }  // (as the input of bft_rs::sort)
+    __device__ bft_rs::NoVal val(uint32_t) const { return bft_rs::NoVal{}; }
+};
+template <class GT>
+struct BftPairIn {  // input of the sorts that move (k-mer, id) pairs: the log's k-mers, its ids narrowed to GT
+    const uint64_t* k;
+    const uint32_t* g;
+    __device__ uint64_t key(uint32_t i) const { return k[i]; }
+    __device__ GT val(uint32_t i) const { return (GT)g[i]; }
 };
 struct BftPairFlags {  // input of the scan: (first pair of its k-mer) << 32 | (first pair of its (k-mer, genome))
     const uint64_t* c;

@@ -6,8 +6,6 @@
 #include <algorithm>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include "bft_dev.h"
 #include "bft_image.h"
 #include "bft_kh.h"
@@ -16,6 +14,8 @@
 #include "bft_kernels_load.h"
 #include "bft_kernels_seqwin.h"
 #include "bft_kh_dev.h"
+#include "bft_scan.h"
+#include "bft_sort.h"
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // queries
@@ -255,27 +255,35 @@ struct __attribute__((packed, aligned(4))) KhRec {  // (8 W + 4 bytes, no paddin
     uint64_t t[W];
     uint32_t v;
 };
+// what the sort by home line reads: row i of the sorted table as (home line, {T-form, value}) -- computed on the fly, twice (the sort's
+// histogram kernel and its first pass), instead of being written out and read back
 template <int W>
-__global__ void k_kh_keys(const uint64_t* __restrict__ tk, const uint32_t* __restrict__ vals, uint64_t n, int k, BftKhGeo g, uint32_t* __restrict__ key, KhRec<W>* __restrict__ rec) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        KhRec<W> r;
+struct KhSortIn {
+    const uint64_t* tk;
+    const uint32_t* vals;
+    int k;
+    BftKhGeo g;
+    __device__ __forceinline__ uint32_t key(uint32_t i) const {
+        uint64_t t[W];
         BftKhKey<W> kk;
-        bft_load_row<W>(tk + i * W, r.t);
-        r.v = vals[i];
-        bft_kh_key<W>(r.t, k, g, kk);
-        key[i] = (uint32_t)kk.home;
-        rec[i] = r;
+        bft_load_row<W>(tk + (uint64_t)i * W, t);
+        bft_kh_key<W>(t, k, g, kk);
+        return (uint32_t)kk.home;
     }
-}
+    __device__ __forceinline__ KhRec<W> val(uint32_t i) const {
+        KhRec<W> r;
+        bft_load_row<W>(tk + (uint64_t)i * W, r.t);
+        r.v = vals[i];
+        return r;
+    }
+};
 // Slot-level linear probing over the rows in sorted order: p_s = max(home slot_s, p_(s-1) + 1) = s + max_(j <= s)(home slot_j - j): one
 // device-wide inclusive max-scan of (bias + home slot_j - j).
 #define BFT_KH_SCAN_BIAS (1ull << 40)
-__global__ void k_kh_scanvals(const uint32_t* __restrict__ key_s, uint64_t n, uint32_t S, uint64_t* __restrict__ v) {
-    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x)
-        v[s] = BFT_KH_SCAN_BIAS + (uint64_t)key_s[s] * S - s;
-}
-struct BftMaxU64 {
-    __host__ __device__ uint64_t operator()(const uint64_t& a, const uint64_t& b) const { return a > b ? a : b; }
+struct KhScanIn {  // (the scan's input, from the sorted home lines)
+    const uint32_t* key_s;
+    uint32_t S;
+    __device__ __forceinline__ uint64_t operator()(uint64_t s) const { return BFT_KH_SCAN_BIAS + (uint64_t)key_s[s] * S - s; }
 };
 // The lines, each written once and whole.  Every sorted row makes its own slot image (all lanes busy); the rows of a line -- neighbours in
 // the sorted order, at most S of them -- OR their images together in their wavefront's LDS, and the row that comes first in the line stores
@@ -365,19 +373,16 @@ __global__ __launch_bounds__(256) void k_kh_assemble(const uint32_t* __restrict_
 template <int W>
 static int kh_sort_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, int k, const BftKhGeo& g, BftKhScratch& sc, hipStream_t s) {
     DevBuf &key = sc.b[0], &rec = sc.b[1], &key_s = sc.b[2], &rec_s = sc.b[3], &tmp = sc.b[6];
-    CK(key.alloc(n * 4));
-    CK(rec.alloc(n * sizeof(KhRec<W>)));
-    CK(key_s.alloc(n * 4));
-    CK(rec_s.alloc(n * sizeof(KhRec<W>)));
-    const dim3 b(256), gn((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32));
-    hipLaunchKernelGGL(k_kh_keys<W>, gn, b, 0, s, d_tk, d_vals, n, k, g, key.as<uint32_t>(), rec.as<KhRec<W>>());
-    // stable sort by home line: rows of a line stay in T-form order
+    // stable sort by home line: rows of a line stay in T-form order (key / rec: the buffers between the passes)
     unsigned bits = 1;
     while (bits < 32 && (g.nl >> bits)) bits++;
-    size_t tb = 0;
-    BFT_RADIX_SORT(0u, bits, rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
-    if (tb > tmp.bytes) CK(tmp.alloc(tb));
-    BFT_RADIX_SORT(0u, bits, rocprim::radix_sort_pairs(tmp.p, tb, key.as<uint32_t>(), key_s.as<uint32_t>(), rec.as<KhRec<W>>(), rec_s.as<KhRec<W>>(), (size_t)n, 0u, bits, s));
+    CK(key_s.alloc(n * 4));
+    CK(rec_s.alloc(n * sizeof(KhRec<W>)));
+    if (bft_rs::make_plan(0u, bits).P > 1) {
+        CK(key.alloc(n * 4));
+        CK(rec.alloc(n * sizeof(KhRec<W>)));
+    }
+    CK((bft_rs::sort<uint32_t, KhRec<W>, KhSortIn<W>>(KhSortIn<W>{d_tk, d_vals, k, g}, n, key_s.as<uint32_t>(), rec_s.as<KhRec<W>>(), key.as<uint32_t>(), rec.as<KhRec<W>>(), 0u, bits, s, tmp)));
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -385,17 +390,12 @@ static int kh_sort_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, i
 template <int W>
 static int kh_lay_w(uint64_t n, int k, const BftKhGeo& g, uint64_t* d_kh, uint64_t* d_ovf_k, uint32_t* d_ovf_v, uint32_t* d_status, BftKhScratch& sc,
                     hipStream_t s) {
-    DevBuf &key_s = sc.b[2], &rec_s = sc.b[3], &v = sc.b[4], &vs = sc.b[5], &tmp = sc.b[6];
-    CK(v.alloc(n * 8));
+    DevBuf &key_s = sc.b[2], &rec_s = sc.b[3], &vs = sc.b[5], &tmp = sc.b[6];
     CK(vs.alloc(n * 8));
-    const dim3 b(256), gn((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32));
+    const dim3 b(256);
     HIPCK(hipMemsetAsync(d_status, 0, 16, s));
     HIPCK(hipMemsetAsync(d_kh, 0, (g.nl + BFT_KH_TAIL_LINES) * BFT_KH_LINE_WORDS * 8, s));
-    hipLaunchKernelGGL(k_kh_scanvals, gn, b, 0, s, key_s.as<uint32_t>(), n, g.S, v.as<uint64_t>());
-    size_t tb = 0;
-    HIPCK(rocprim::inclusive_scan(nullptr, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
-    if (tb > tmp.bytes) CK(tmp.alloc(tb));
-    HIPCK(rocprim::inclusive_scan(tmp.p, tb, v.as<uint64_t>(), vs.as<uint64_t>(), (size_t)n, BftMaxU64(), s));
+    CK((bft_scan::scan<uint64_t, KhScanIn, bft_scan::Max, true>(KhScanIn{key_s.as<uint32_t>(), g.S}, vs.as<uint64_t>(), n, 0ull, bft_scan::Max(), s, tmp)));
     hipLaunchKernelGGL(k_kh_assemble<W>, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 32)), b, 0, s, key_s.as<uint32_t>(), rec_s.as<KhRec<W>>(), vs.as<uint64_t>(), n, k, g,
                        d_status, d_kh, d_ovf_k, d_ovf_v);
     HIPCK(hipGetLastError());

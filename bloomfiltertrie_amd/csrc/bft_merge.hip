@@ -13,10 +13,11 @@
 //                     build uses (bft_intern_colors_gpu), so equal sets share one id however they came about.
 // An insertion into a 2x10^8-pair index then costs a merge of its k-mers, not a re-sort of every pair, and the number of pairs an
 // index can hold is not bounded by what one sort can take (the log is flushed into the index before it reaches 2^30 pairs).
-#include <hipcub/hipcub.hpp>
 
 #include "bft_dev.h"
 #include "bft_image.h"
+#include "bft_scan.h"
+#include "bft_sort.h"
 #include "bft_walk.h"
 
 #define MBLK 256
@@ -32,11 +33,7 @@ struct Scan32 {
     explicit Scan32(hipStream_t st) : s(st) {}
     int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {
         if (n == 0) { if (total) *total = 0; return 0; }
-        size_t tb = 0;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
-        if (tb > tmp.bytes) CK(tmp.alloc(tb));
-        tb = tmp.bytes;
-        HIPCK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s));
+        CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp));
         if (total) {
             uint32_t a = 0, b = 0;
             HIPCK(hipMemcpyAsync(&a, in + n - 1, 4, hipMemcpyDeviceToHost, s));
@@ -307,11 +304,7 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
     {
         int abits = 1;  // (old set + 1) sits above the run's 32 bits
         while (abits < 32 && ((a.n_sets + 1) >> abits)) abits++;
-        size_t tb = 0;
-        BFT_RADIX_SORT(0, 32 + abits, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
-        DevBuf tmp;
-        CK(tmp.alloc(tb));
-        BFT_RADIX_SORT(0, 32 + abits, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint64_t>(), key_s.as<uint64_t>(), iota.as<uint32_t>(), order.as<uint32_t>(), (int)n_b, 0, 32 + abits, s));
+        CK((bft_rs::sort_pairs<uint64_t, uint32_t>(key.as<uint64_t>(), iota.as<uint32_t>(), n_b, key_s.as<uint64_t>(), order.as<uint32_t>(), 0, 32 + abits, s)));
         HIPCK(hipStreamSynchronize(s));
     }
     key.release(); iota.release();

@@ -38,6 +38,14 @@
 
 #include "bft_dev.h"
 
+// (see bft_rs::sort for the two)
+#ifndef BFT_RS_CHAIN_MIN
+#define BFT_RS_CHAIN_MIN (1u << 23)
+#endif
+#ifndef BFT_RS_BIG_THREADS
+#define BFT_RS_BIG_THREADS 1024
+#endif
+
 namespace bft_rs {
 
 constexpr int DBITS = 9;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(In in, uint32_t n, Plan pl,
 }
 
 // the chain counters of the later passes: cnt[w] += sum over a slice of the histogram workgroups (grid.y slices; cnt zeroed)
-__global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t stride, uint32_t first, uint32_t words, uint32_t* __restrict__ cnt) {
+static __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t stride, uint32_t first, uint32_t words, uint32_t* __restrict__ cnt) {
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
     const uint32_t per = (nwg + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * per, g1 = min(nwg, g0 + per);
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ 
 
 // One workgroup per (digit, pass): exclusive scan of the digit's counts over the rows (ranges of pass 0 -- in place in the histogram
 // workgroups' blocks --, chains of a later pass), in place; the digit's total.  rows <= 1024.
-__global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ partial, uint32_t* __restrict__ cnt, Plan pl, uint32_t ranges, uint32_t* __restrict__ tot_all) {
+static __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ partial, uint32_t* __restrict__ cnt, Plan pl, uint32_t ranges, uint32_t* __restrict__ tot_all) {
     __shared__ uint32_t wsum[4];
     const uint32_t d = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (d >= (1u << pl.nbits[p])) return;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ parti
 // One workgroup per pass: where every digit starts in the pass's output; the chains and tiles of the NEXT pass.
 // chain table of a pass: start[65], tile_first[65]
 constexpr int CT = 2 * ((1 << MAXCB) + 1);
-__global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict__ tot, uint32_t* __restrict__ dbase, uint32_t* __restrict__ chain, Plan pl, uint32_t n, uint32_t tile) {
+static __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict__ tot, uint32_t* __restrict__ dbase, uint32_t* __restrict__ chain, Plan pl, uint32_t n, uint32_t tile) {
     __shared__ uint32_t wsum[DIGITS / 64];
     __shared__ uint32_t db[DIGITS + 1];
     const uint32_t p = blockIdx.x, d = threadIdx.x, lane = d & 63u, wave = d >> 6, nd = 1u << pl.nbits[p];
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict
 }
 
 // ---- do the lanes of one LDS atomic instruction that hit one address get their turns in lane order? ------------------------------------
-__global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) {
+static __global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) {
     __shared__ uint32_t c[64];
     const uint32_t lane = threadIdx.x;
     uint32_t wrong = 0;
@@ -815,8 +823,9 @@ static inline int cu_count() {
 }
 
 // 0: ranks from LDS atomics (the device passed the lane-order check), 1: from ballots.  force >= 0 sets it ("sort_ballots" option, tests).
+extern int g_bft_rs_rank_mode;  // (one per process: bft_gpu.hip; -1 = not checked yet)
 static inline int rank_mode(hipStream_t s, int force = -1) {
-    static int mode = -1;
+    int& mode = g_bft_rs_rank_mode;
     if (force >= 0) { mode = force; return mode; }
     if (mode >= 0) return mode;
     uint32_t* d = nullptr;
@@ -1002,12 +1011,6 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
 // BFT_RS_CHAIN_MIN entries -> a histogram kernel and a ranged pass per digit; beyond -> one histogram kernel, a ranged first pass, chained
 // passes behind it (2 x 10^8 composites: 2.2-2.3 ms against 2.75 with a histogram per pass; 1.6 x 10^6 pairs, eight passes: 0.18 ms against
 // 0.43 chained -- and 0.27 for rocPRIM's onesweep --; 4.5 x 10^7 k-mer hash records: 1.33 against 1.50).
-#ifndef BFT_RS_CHAIN_MIN
-#define BFT_RS_CHAIN_MIN (1u << 23)
-#endif
-#ifndef BFT_RS_BIG_THREADS
-#define BFT_RS_BIG_THREADS 1024
-#endif
 template <class K, class V, class In>
 int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
     constexpr size_t E = sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V));

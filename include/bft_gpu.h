@@ -208,7 +208,9 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   an id beyond the room, ids that do not ascend or "build_composite" 0 turn the log back into k-mers + ids; 0: always k-mers + ids --
  *   same image, a test hook; only while the log is empty), "build_msd"(1, default: root-prefix buckets + bucket sorts from 2^20 pairs on; 0: one
  *   device-wide sort; 2: buckets at any size -- same image, test hooks), "test_front_rank_mode" (process-wide test hook: how a bucket ranks its digits:
- *   0, default = LDS atomics + order check + ballot fallback, 1 = ballots only, 2 = the check always fails), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
+ *   0, default = LDS atomics + order check + ballot fallback, 1 = ballots only, 2 = the check always fails), "sort_ballots" (process-wide: how the library's own
+ *   radix sort -- csrc/bft_sort.h -- ranks the keys of a wavefront: 0, default = one LDS atomic per key once the device has shown that it serves the lanes of such an
+ *   instruction in lane order, 1 = wavefront ballots, stable by construction; same image), "reserve_pairs" (room in the insertion log for this many pending (k-mer, genome)
  *   pairs, so that a series of insert calls never re-allocates it), "flush_pairs" (the log is merged into the index before it holds this many pairs:
  *   2^30 by default, 1024..2^30).
  * "timing" (0/1: record HIP events around query kernels; off until this option or the first bft_gpu_kernel_time call turns it on).

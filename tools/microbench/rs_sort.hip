@@ -13,6 +13,7 @@
 #include "../../bloomfiltertrie_amd/csrc/bft_sort.h"
 #include "../../bloomfiltertrie_amd/csrc/bft_scan.h"
 
+int bft_rs::g_bft_rs_rank_mode = -1;
 static std::string g_err;
 int bft_fail(int code, const std::string& msg) { g_err = msg; fprintf(stderr, "fail: %s\n", msg.c_str()); return code; }
 int bft_pool_alloc(void** p, size_t n, size_t* cap) { *cap = n; return hipMalloc(p, n) == hipSuccess ? 0 : -1; }
