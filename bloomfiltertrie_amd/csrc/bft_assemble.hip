@@ -694,7 +694,7 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                                skey.as<uint64_t>(), iota.as<uint32_t>());
             int mbits = 1;
             while (mbits < 32 && (M >> mbits)) mbits++;
-            CK((bft_rs::sort_pairs<uint64_t, uint32_t>(skey.as<uint64_t>(), iota.as<uint32_t>(), P, skey_s.as<uint64_t>(), sp.as<uint32_t>(), 0, 17 + mbits, s)));
+            CK((bft_rs::sort_pairs<uint64_t, uint32_t, bft_rs::SHAPE_LIGHT>(skey.as<uint64_t>(), iota.as<uint32_t>(), P, skey_s.as<uint64_t>(), sp.as<uint32_t>(), 0, 17 + mbits, s)));
         }  // (no synchronisation: what is released here is only handed out again in the order of this stream, bft_pool_alloc)
         skey.release(); iota.release();
 
@@ -1379,7 +1379,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
             CK(len.alloc(n_sets * 4));
             const dim3 tgrid(bft_grid_for((n_slots + ABLK - 1) / ABLK)), sgrid(bft_grid_for((n_sets + ABLK - 1) / ABLK));
             hipLaunchKernelGGL(k_cs_hash_compact, tgrid, block, 0, s, tab.as<CsSlot>(), (uint32_t)n_slots, keys.as<uint64_t>(), slots.as<uint32_t>(), cnt.as<uint32_t>() + 2);
-            CK((bft_rs::sort_pairs<uint64_t, uint32_t>(keys.as<uint64_t>(), slots.as<uint32_t>(), n_sets, keys_s.as<uint64_t>(), slots_s.as<uint32_t>(), 0, 64, s)));
+            CK((bft_rs::sort_pairs<uint64_t, uint32_t, bft_rs::SHAPE_LIGHT>(keys.as<uint64_t>(), slots.as<uint32_t>(), n_sets, keys_s.as<uint64_t>(), slots_s.as<uint32_t>(), 0, 64, s)));
             hipLaunchKernelGGL(k_cs_hash_ids, sgrid, block, 0, s, slots_s.as<uint32_t>(), (uint32_t)n_sets, tab.as<CsSlot>(), d_seg_off, rep.as<uint32_t>(), len.as<uint32_t>());
             CK(d_cs_off.alloc((n_sets + 1) * 4));
             CK(scan.enqueue(len.as<uint32_t>(), d_cs_off.as<uint32_t>(), n_sets, 0, true));
@@ -1436,7 +1436,7 @@ int bft_intern_colors_gpu(const uint32_t* d_seg_off, const uint32_t* d_pg, uint6
     // Equal lists only have to end up next to each other: the low 48 bits of the signature order them (6 radix passes instead
     // of 8).  Two different lists that agree on those bits could at worst split a run of equal lists, i.e. cost a duplicate
     // dictionary entry (expected once in ~10^14 / n_sets^2 builds); k_cs_heads still compares whole signatures and lists.
-    CK((bft_rs::sort_pairs<uint64_t, uint32_t>(sig.as<uint64_t>(), iota.as<uint32_t>(), nk, sig_s.as<uint64_t>(), order.as<uint32_t>(), 0, 48, s)));
+    CK((bft_rs::sort_pairs<uint64_t, uint32_t, bft_rs::SHAPE_LIGHT>(sig.as<uint64_t>(), iota.as<uint32_t>(), nk, sig_s.as<uint64_t>(), order.as<uint32_t>(), 0, 48, s)));
     for (int exact = 1; exact < 2; exact++) {
         g_exact_passes++;
         hipLaunchKernelGGL(k_cs_heads, grid, block, 0, s, sig_s.as<uint64_t>(), order.as<uint32_t>(), d_seg_off, d_pg, (uint32_t)nk, exact, head.as<uint32_t>(), len.as<uint32_t>());

@@ -415,6 +415,292 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
     }
 }
 
+
+// ---- two-word keys (33 <= k <= 64) --------------------------------------------------------------------------------------------------------
+// insertKmer_Node_special (src/insertNode.c:241-423) for keys of two words.  The split hands over items (hk, lo, id): hk = the top 64 bits of
+// the T-form, left-aligned (its top 18 bits = the root prefix = the bucket), lo = the 2k - 64 bits below them, id = the genome.  Inside a
+// bucket 46 + (2k - 64) key bits are left -- 108 at k = 63: twelve 9-bit passes where a one-word bucket takes four.  But a pan-genome
+// bucket holds few DISTINCT k-mers (config 5: one locus, ~2000 items of ~450 k-mers), so the items are GROUPED first and only the distinct
+// k-mers are ordered:
+//   1. every item gets a 27-bit hash of its key bits; (hash << 13 | position in the bucket) is sorted on the hash by the same three LDS
+//      radix passes the one-word buckets use (radix_passes): equal k-mers end up next to each other, in insertion order (ascending ids);
+//   2. an item that differs from its left neighbour starts a k-mer; two DIFFERENT neighbours with one hash are a collision: the bucket
+//      is done again with another seed (expected for ~10^-3 of the buckets, four seeds);
+//   3. the distinct k-mers (at most half the capacity) go to LDS and are ranked by comparison -- m^2 / 256 comparisons of 16 bytes per
+//      thread: ~3 us at m = 450 --; a scan over the ranks gives every k-mer's place among the bucket's kept pairs;
+//   4. the items go back in place in (k-mer, id) order, duplicated pairs dropped; counts as for one-word buckets; k_bucket2_emit
+//      then streams k-mers, offsets and ids out.
+struct __attribute__((packed, aligned(4))) BftItem2 {
+    uint64_t lo;
+    uint32_t id;
+};
+
+__device__ __forceinline__ uint32_t hash27(uint64_t a, uint64_t b, uint32_t seed) {
+    uint64_t x = (a ^ (0x9E3779B97F4A7C15ull * (seed + 1))) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 29;
+    x += b * 0x94D049BB133111EBull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 37);
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__shfl((uint32_t)(v >> 32), l) << 32) | (uint32_t)__shfl((uint32_t)v, l);
+}
+
+// fail[0]: buckets that could not be done here (beyond the capacity, more than half of it distinct, four colliding seeds): the caller falls
+// back to the device-wide sort.  min_n / max_n: the sizes this launch takes (the variants differ in EMAX).
+template <int EMAX>
+__global__ __launch_bounds__(FB_BLOCK, (EMAX <= 8 ? 4 : EMAX <= 16 ? 2 : 1)) void k_bucket2_sort(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, uint32_t nb,
+                                                                                          uint64_t* __restrict__ counts, uint32_t* __restrict__ fail, uint32_t min_n, uint32_t max_n) {
+    constexpr uint32_t CAP = FB_BLOCK * EMAX, MC = CAP / 2;
+    __shared__ uint64_t keys[CAP];                 // the sort's exchange buffer, then the distinct k-mers: (hk46, lo) x MC
+    __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];  // digit counters, then ranks of the distinct k-mers (MC <= 4 x 512 words at EMAX = 16; EMAX = 32: see dextra)
+    __shared__ uint32_t dkoff[MC + 1];             // first kept pair of a distinct k-mer (in hash order)
+    __shared__ uint32_t lenr[MC];                  // pairs of the k-mer of a rank, then its first pair among the bucket's
+    __shared__ uint32_t drank_x[EMAX > 16 ? MC : 1];
+    __shared__ uint32_t wtot[FB_WAVES];
+    __shared__ uint64_t wlast_k[FB_WAVES][2];
+    __shared__ uint32_t wlast_i[FB_WAVES], wlast_h[FB_WAVES];
+    __shared__ uint32_t w_nh[FB_WAVES], w_nk[FB_WAVES];
+    __shared__ uint32_t s_flag;
+    uint32_t* drank = EMAX > 16 ? drank_x : &cnt[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
+        if (n < min_n || n > max_n) continue;
+        if (n == 0) {
+            if (tid == 0) counts[b] = 0;
+            continue;
+        }
+        if (n > CAP) {  // (excluded by the caller; counted in case)
+            if (tid == 0) { counts[b] = 0; atomicAdd(fail, 1u); }
+            continue;
+        }
+        const uint32_t E = (n + FB_BLOCK - 1) / FB_BLOCK;  // rounds
+        const uint32_t wbase = wave * E * 64u;
+        bool ok = false;
+        uint64_t ihk[EMAX], ilo[EMAX];
+        uint32_t iid[EMAX];
+        uint32_t hidx[EMAX], kidx[EMAX];  // per item: index of its k-mer among the distinct ones (hash order); index among the kept pairs
+        uint64_t flags_head = 0, flags_keep = 0;  // bit r: the item of round r starts a k-mer / is kept
+        uint32_t m = 0, np = 0;
+        for (uint32_t seed = 0; seed < 4 && !ok; seed++) {
+            // 1. hash + position, sorted on the hash
+            uint64_t key[EMAX];
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                key[r] = ~0ull;
+                if (r < E && idx < n) {
+                    const uint64_t a = hk[a0 + idx] & ((1ull << 46) - 1ull);
+                    const uint64_t l = it[a0 + idx].lo;
+                    key[r] = ((uint64_t)hash27(a, l, seed) << 13) | idx;
+                }
+            }
+            radix_passes<true, EMAX>(key, keys, cnt, wtot, n, E, 13, 40);  // (ranks from ballots: stable by construction -- the order of equal hashes IS the result here)
+            __syncthreads();
+            // 2. the items in hash order; neighbours: lane - 1 of the round, lane 63 of the round before, the last item of the wavefront before
+            if (tid == 0) s_flag = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                ihk[r] = 0; ilo[r] = 0; iid[r] = 0;
+                if (r < E && idx < n) {
+                    const uint32_t src = (uint32_t)(key[r] & 0x1FFFu);
+                    ihk[r] = hk[a0 + src] & ((1ull << 46) - 1ull);
+                    const BftItem2 x = it[a0 + src];
+                    ilo[r] = x.lo;
+                    iid[r] = x.id;
+                }
+            }
+            {   // the last item of every wavefront, for the first of the next
+                const uint32_t nw = wbase < n ? min(n - wbase, E * 64u) : 0u;  // items of this wavefront
+                if (nw) {
+                    const uint32_t lr = (nw - 1) / 64u, ll = (nw - 1) % 64u;
+                    uint64_t lk = 0, llo = 0;
+                    uint32_t li = 0, lh = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
+                        if (r == lr) { lk = ihk[r]; llo = ilo[r]; li = iid[r]; lh = (uint32_t)(key[r] >> 13); }
+                    if (lane == ll) { wlast_k[wave][0] = lk; wlast_k[wave][1] = llo; wlast_i[wave] = li; wlast_h[wave] = lh; }
+                }
+            }
+            __syncthreads();
+            flags_head = 0;
+            flags_keep = 0;
+            uint32_t nh_w = 0, nk_w = 0;
+            bool coll = false;
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                const bool valid = r < E && idx < n;
+                uint64_t pk = shfl64(ihk[r], (int)((lane + 63u) & 63u)), pl = shfl64(ilo[r], (int)((lane + 63u) & 63u));
+                uint32_t pi = __shfl(iid[r], (int)((lane + 63u) & 63u)), ph = __shfl((uint32_t)(key[r] >> 13), (int)((lane + 63u) & 63u));
+                // (lane 0: lane 63 of the round before -- every round but a wavefront's last is full --, or the last item of the wavefront before; the
+                // shuffles by every lane: no lane-dependent control flow around them)
+                const uint64_t qk = r ? shfl64(ihk[r ? r - 1 : 0], 63) : 0ull, ql = r ? shfl64(ilo[r ? r - 1 : 0], 63) : 0ull;
+                const uint32_t qi = r ? __shfl(iid[r ? r - 1 : 0], 63) : 0u, qh = r ? __shfl((uint32_t)(key[r ? r - 1 : 0] >> 13), 63) : 0u;
+                if (lane == 0) {
+                    if (r > 0) { pk = qk; pl = ql; pi = qi; ph = qh; }
+                    else if (wave > 0) { pk = wlast_k[wave - 1][0]; pl = wlast_k[wave - 1][1]; pi = wlast_i[wave - 1]; ph = wlast_h[wave - 1]; }
+                }
+                const bool first = idx == 0;
+                const bool same = valid && !first && pk == ihk[r] && pl == ilo[r];
+                const bool head = valid && !same, keep = valid && (!same || pi != iid[r]);
+                coll |= valid && !first && !same && ph == (uint32_t)(key[r] >> 13);
+                const uint64_t hm = __ballot(head), km = __ballot(keep);
+                hidx[r] = nh_w + (uint32_t)__builtin_popcountll(hm & lt_mask) + (head ? 1u : 0u);  // (inclusive: heads up to and including me, in the wavefront)
+                kidx[r] = nk_w + (uint32_t)__builtin_popcountll(km & lt_mask);                     // (exclusive)
+                nh_w += (uint32_t)__builtin_popcountll(hm);
+                nk_w += (uint32_t)__builtin_popcountll(km);
+                flags_head |= (uint64_t)head << r;
+                flags_keep |= (uint64_t)keep << r;
+            }
+            if (__ballot(coll) && lane == 0) s_flag = 1;
+            if (lane == 0) { w_nh[wave] = nh_w; w_nk[wave] = nk_w; }
+            __syncthreads();
+            ok = s_flag == 0;
+            uint32_t hb = 0, kb = 0;
+            m = 0; np = 0;
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++) {
+                if (w < (int)wave) { hb += w_nh[w]; kb += w_nk[w]; }
+                m += w_nh[w];
+                np += w_nk[w];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) { hidx[r] += hb; kidx[r] += kb; }  // hidx: 1-based index of the item's k-mer
+            __syncthreads();  // (s_flag, w_nh are rewritten by the next seed / bucket)
+        }
+        if (!ok || m > MC) {
+            if (tid == 0) { counts[b] = 0; atomicAdd(fail, 1u); }
+            continue;
+        }
+        // 3. the distinct k-mers to LDS (over the exchange buffer: every wavefront holds its items in registers), ranked by comparison
+        uint64_t* dk = keys;
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
+            if ((flags_head >> r) & 1ull) {
+                dk[2 * (hidx[r] - 1)] = ihk[r];
+                dk[2 * (hidx[r] - 1) + 1] = ilo[r];
+                dkoff[hidx[r] - 1] = kidx[r];
+            }
+        if (tid == 0) dkoff[m] = np;
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += FB_BLOCK) {
+            const uint64_t a = dk[2 * i], c = dk[2 * i + 1];
+            uint32_t rk = 0;
+            for (uint32_t j = 0; j < m; j++) {
+                const uint64_t x = dk[2 * j], y = dk[2 * j + 1];
+                rk += (x < a || (x == a && y < c)) ? 1u : 0u;
+            }
+            drank[i] = rk;
+        }
+        __syncthreads();
+        // lengths by rank -> starts by rank (a scan over m <= MC values, FB_BLOCK x (MC / FB_BLOCK) each)
+        for (uint32_t i = tid; i < m; i += FB_BLOCK) lenr[drank[i]] = dkoff[i + 1] - dkoff[i];
+        __syncthreads();
+        {
+            constexpr uint32_t PT = MC / FB_BLOCK;
+            uint32_t v[PT], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < PT; q++) {
+                const uint32_t i = tid * PT + q;
+                v[q] = i < m ? lenr[i] : 0u;
+                sum += v[q];
+            }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(inc, o);
+                if ((int)lane >= o) inc += y;
+            }
+            if (lane == 63) wtot[wave] = inc;
+            __syncthreads();
+            uint32_t run = inc - sum;
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++)
+                if (w < (int)wave) run += wtot[w];
+#pragma unroll
+            for (uint32_t q = 0; q < PT; q++) {
+                const uint32_t i = tid * PT + q;
+                if (i < m) lenr[i] = run;
+                run += v[q];
+            }
+        }
+        __syncthreads();
+        // 4. back in place, in (k-mer, id) order
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
+            if ((flags_keep >> r) & 1ull) {
+                const uint32_t hi = hidx[r] - 1;
+                const uint32_t dest = a0 + lenr[drank[hi]] + (kidx[r] - dkoff[hi]);
+                hk[dest] = ((uint64_t)b << 46) | ihk[r];
+                BftItem2 x;
+                x.lo = ilo[r];
+                x.id = iid[r];
+                it[dest] = x;
+            }
+        if (tid == 0) counts[b] = ((uint64_t)m << 32) | np;
+        __syncthreads();
+    }
+}
+
+// bases[b] = exclusive scan of counts (k-mers << 32 | pairs).  Every bucket places its k-mers (two words: the T-form back from hk and lo), the offset
+// of each k-mer's first genome id, and the genome ids of its pairs (the bucket's first `pairs` items, in (k-mer, id) order).
+__global__ __launch_bounds__(FB_BLOCK) void k_bucket2_emit(const uint64_t* __restrict__ hk, const BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, uint32_t nb,
+                                                           const uint64_t* __restrict__ counts, const uint64_t* __restrict__ bases, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off,
+                                                           uint32_t* __restrict__ pg, uint32_t sh, uint32_t nk, uint32_t np) {  // sh = 2k - 64: bits of lo
+    __shared__ uint32_t w_nk[FB_WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (blockIdx.x == 0 && tid == 0) seg_off[nk] = np;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t a0 = boff[b], n = (uint32_t)counts[b];  // (the kept pairs)
+        if (n == 0) continue;
+        const uint64_t base = bases[b];
+        uint32_t kbase = (uint32_t)(base >> 32);
+        const uint32_t pbase = (uint32_t)base;
+        for (uint32_t r0 = 0; r0 < n; r0 += FB_BLOCK) {
+            const uint32_t idx = r0 + tid;
+            const bool valid = idx < n;
+            uint64_t a = 0, l = 0, pa = 0, pl = 0;
+            uint32_t id = 0;
+            if (valid) {
+                a = hk[a0 + idx];
+                const BftItem2 x = it[a0 + idx];
+                l = x.lo;
+                id = x.id;
+                if (idx) { pa = hk[a0 + idx - 1]; pl = it[a0 + idx - 1].lo; }
+            }
+            const bool head = valid && (idx == 0 || a != pa || l != pl);
+            const uint64_t hm = __ballot(head);
+            if (lane == 0) w_nk[wave] = (uint32_t)__builtin_popcountll(hm);
+            __syncthreads();
+            uint32_t kb = kbase, tk_all = 0;
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++) {
+                if (w < (int)wave) kb += w_nk[w];
+                tk_all += w_nk[w];
+            }
+            if (valid) pg[pbase + idx] = id;
+            if (head) {
+                const uint32_t q = kb + (uint32_t)__builtin_popcountll(hm & lt_mask);
+                // T-form: hk holds its top 64 bits left-aligned, lo the sh bits below them
+                const uint64_t t0 = sh == 64 ? a : a >> (64 - sh);
+                const uint64_t t1 = sh == 64 ? l : ((a << sh) | l);
+                tk[2ull * q] = t0;
+                tk[2ull * q + 1] = t1;
+                seg_off[q] = pbase + idx;
+            }
+            kbase += tk_all;
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 uint32_t bft_front_bucket_capacity(void) { return FB_CAP; }
@@ -479,6 +765,54 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
                        (uint32_t)nk, (uint32_t)np);
     HIPCK(hipGetLastError());
     bft_stage("bucket emit (k-mers, offsets, genome ids)", (double)n * 8 + (double)nk * 12 + (double)np * 4, s);
+    *done = true;
+    return 0;
+}
+
+uint32_t bft_front2_bucket_capacity(void) { return FB_BLOCK * 32; }
+
+// the two-word front end behind the split (items grouped by the top 18 bits of hk): see k_bucket2_sort
+int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t* d_boff, uint32_t nb, int k, hipStream_t s, DevBuf& tk, DevBuf& seg_off, DevBuf& pg, uint64_t& nk, uint64_t& np,
+                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done) {
+    *done = false;
+    BftItem2* d_it = (BftItem2*)d_items;
+    PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets that failed
+    if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (front end counts)");
+    DevBuf counts, bases, tmp, fail;
+    CK(counts.alloc(((uint64_t)nb + 1) * 8));
+    CK(bases.alloc(((uint64_t)nb + 1) * 8));
+    CK(fail.alloc_zero(4, s));
+    HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
+    HIPCK(hipStreamSynchronize(s));
+    const uint32_t mx = (uint32_t)pin.p[0];
+    *max_bucket = mx;
+    if (mx > FB_BLOCK * 32) return 0;
+    const dim3 block(FB_BLOCK);
+    // by size: the variants differ in the items a thread holds (registers, LDS, workgroups per CU)
+    hipLaunchKernelGGL(k_bucket2_sort<8>, dim3(std::min<uint32_t>(nb, 256u * 8u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), 0u, FB_BLOCK * 8u);
+    if (mx > FB_BLOCK * 8u)
+        hipLaunchKernelGGL(k_bucket2_sort<16>, dim3(std::min<uint32_t>(nb, 256u * 8u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), FB_BLOCK * 8u + 1u,
+                           FB_BLOCK * 16u);
+    if (mx > FB_BLOCK * 16u)
+        hipLaunchKernelGGL(k_bucket2_sort<32>, dim3(std::min<uint32_t>(nb, 256u * 4u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), FB_BLOCK * 16u + 1u,
+                           FB_BLOCK * 32u);
+    CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, fail.as<uint32_t>(), pin.p + 1);
+    HIPCK(hipGetLastError());
+    bft_stage("two-word buckets: grouped by hash, distinct k-mers ranked", (double)n * 2 * 20, s);
+    HIPCK(hipStreamSynchronize(s));
+    if (pin.p[2] != 0) return 0;  // (a bucket beyond this front end: the caller sorts device-wide)
+    const uint64_t total = pin.p[1];
+    nk = total >> 32;
+    np = total & 0xFFFFFFFFull;
+    CK(tk.alloc(nk * 16));
+    CK(seg_off.alloc((nk + 1) * 4));
+    CK(pg.alloc(np * 4));
+    hipLaunchKernelGGL(k_bucket2_emit, dim3(std::min<uint32_t>(nb, 256u * 16u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), bases.as<uint64_t>(), tk.as<uint64_t>(),
+                       seg_off.as<uint32_t>(), pg.as<uint32_t>(), (uint32_t)(2 * k - 64), (uint32_t)nk, (uint32_t)np);
+    HIPCK(hipGetLastError());
+    bft_stage("two-word buckets: emit (k-mers, offsets, genome ids)", (double)np * 24 + (double)nk * 20, s);
     *done = true;
     return 0;
 }

@@ -1397,9 +1397,20 @@ static int split_dedupe_w1(bft_gpu* h, const uint64_t* src_k, const uint32_t* sr
     CK(sv.alloc(total * sizeof(VT)));
     CK(boff.alloc(((1u << top) + 1) * 4));
     CK(maxb.alloc_zero(4, h->stream));
-    CK((bft_rs::sort_in<uint64_t, VT>(BftPairIn<VT>{src_k, src_g}, total, sk.as<uint64_t>(), sv.as<VT>(), rest, (unsigned)(2 * h->k), h->stream)));
-    hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(),
-                       maxb.as<uint32_t>());
+    {
+        DevBuf tk2, tv2, scratch;
+        const bft_rs::Plan spl = bft_rs::make_plan(rest, (unsigned)(2 * h->k));
+        if (spl.P > 1) {
+            CK(tk2.alloc(total * 8));
+            CK(tv2.alloc(total * sizeof(VT)));
+        }
+        const uint32_t* dbase = nullptr;
+        CK((bft_rs::sort<uint64_t, VT, BftPairIn<VT>>(BftPairIn<VT>{src_k, src_g}, total, sk.as<uint64_t>(), sv.as<VT>(), tk2.as<uint64_t>(), tv2.as<VT>(), rest, (unsigned)(2 * h->k),
+                                                      h->stream, scratch, &dbase)));
+        hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, sk.as<uint64_t>(), total, (uint32_t)rest, 1u << top, boff.as<uint32_t>(), dbase,
+                           spl.P ? spl.nbits[spl.P - 1] : 0u, top);
+        hipLaunchKernelGGL(k_msd_max, dim3(((1u << top) + 255) / 256), dim3(256), 0, h->stream, boff.as<uint32_t>(), 1u << top, maxb.as<uint32_t>());
+    }
     bft_stage("split (root-prefix, 2 x 9 bits, pairs)", (double)total * (12 + 12 + 2 * (8 + sizeof(VT)) + (8 + sizeof(VT))), h->stream);
     uint32_t mx = 0;
     CK(bft_front_buckets(sk.as<uint64_t>(), total, boff.as<uint32_t>(), 1u << top, (uint32_t)gb, (uint32_t)gb + rest, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done,
@@ -1484,10 +1495,13 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
                 CK(maxb.alloc_zero(4, h->stream));
                 // (the library's own partition, bft_sort.h: one histogram kernel, a first pass that needs no look-back, a second in 64 chains;
                 // the composites are formed from the log by the kernels that read it; `pos` carries them between the two passes)
+                const uint32_t* dbase = nullptr;  // (where the last pass's digit -- the top bits of the prefix -- changes: in `tmp`)
                 CK((bft_rs::sort<uint64_t, bft_rs::NoVal, BftCompose>(comp, total, cs.as<uint64_t>(), (bft_rs::NoVal*)nullptr, pos.as<uint64_t>(), (bft_rs::NoVal*)nullptr,
-                                                                      (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream, tmp)));
+                                                                      (unsigned)gb + rest, (unsigned)(gb + 2 * h->k), h->stream, tmp, &dbase)));
+                const bft_rs::Plan spl = bft_rs::make_plan((unsigned)gb + rest, (unsigned)(gb + 2 * h->k));
                 hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << top) + 1 + 255) / 256), dim3(256), 0, h->stream, cs.as<uint64_t>(), total, (uint32_t)(gb + rest), 1u << top,
-                                   boff.as<uint32_t>(), maxb.as<uint32_t>());
+                                   boff.as<uint32_t>(), dbase, spl.P ? spl.nbits[spl.P - 1] : 0u, top);
+                hipLaunchKernelGGL(k_msd_max, dim3(((1u << top) + 255) / 256), dim3(256), 0, h->stream, boff.as<uint32_t>(), 1u << top, maxb.as<uint32_t>());
                 // (histogram: the log, 12 B per pair; pass 1: the log in, composites out; pass 2: composites in and out)
                 bft_stage("split (root-prefix, 2 x 9 bits)", (double)total * ((h->log_comp ? 8 : 12) * 2 + 8 + 8 + 8), h->stream);
                 uint32_t mx = 0;
@@ -1544,6 +1558,31 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             ck.release();
             cg.release();
         } else {
+        bool done2 = false;
+        if (W == 2 && h->log_g_sorted && h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2)) {
+            // 2w. two-word keys (33 <= k <= 64) whose ids arrived ascending: the root-prefix split on the top 18 bits of the T-form -- moving (top 64
+            // bits, the bits below, id) --, then every bucket on its own: grouped by a hash of its key bits, only the distinct k-mers ordered (bft_front.hip)
+            DevBuf hk, items, hk2, items2, boff, maxb, scratch;
+            CK(hk.alloc(total * 8));
+            CK(items.alloc(total * sizeof(BftSplit2Val)));
+            CK(hk2.alloc(total * 8));
+            CK(items2.alloc(total * sizeof(BftSplit2Val)));
+            CK(boff.alloc(((1u << 18) + 1) * 4));
+            CK(maxb.alloc_zero(4, h->stream));
+            const BftSplit2In in2{src_k, src_k + src_stride, src_g, (uint32_t)(2 * h->k - 64)};
+            const uint32_t* dbase = nullptr;
+            CK((bft_rs::sort<uint64_t, BftSplit2Val, BftSplit2In>(in2, total, hk.as<uint64_t>(), items.as<BftSplit2Val>(), hk2.as<uint64_t>(), items2.as<BftSplit2Val>(), 46u, 64u, h->stream,
+                                                                  scratch, &dbase)));
+            hipLaunchKernelGGL(k_msd_bounds, dim3(((1u << 18) + 1 + 255) / 256), dim3(256), 0, h->stream, hk.as<uint64_t>(), total, 46u, 1u << 18, boff.as<uint32_t>(), dbase, 9u, 18u);
+            hipLaunchKernelGGL(k_msd_max, dim3(((1u << 18) + 255) / 256), dim3(256), 0, h->stream, boff.as<uint32_t>(), 1u << 18, maxb.as<uint32_t>());
+            bft_stage("split (root-prefix, 2 x 9 bits, two-word keys)", (double)total * (20 + 8 + 20 * 4), h->stream);
+            hk2.release();
+            items2.release();
+            uint32_t mx = 0;
+            CK(bft_front2_buckets(hk.as<uint64_t>(), items.p, total, boff.as<uint32_t>(), 1u << 18, h->k, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done2));
+            h->msd_max_bucket = mx;
+        }
+        if (!done2) {
         // 2. sort by (T, genome)
         CK(sk.alloc(total * W * 8));
         CK(sg.alloc(total * 4));
@@ -1584,6 +1623,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         HIPCK(hipMemcpyAsync(seg_off.as<uint32_t>() + nk, &np32, 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(h->stream));
+        }
         }
         }
     }

@@ -75,6 +75,25 @@ struct BftCompose {  // input "iterator" of the sort: composite i from the inser
     __device__ uint64_t key(uint32_t i) const { return (*this)(i); }  // (as the input of bft_rs::sort)
     __device__ bft_rs::NoVal val(uint32_t) const { return bft_rs::NoVal{}; }
 };
+// two-word keys: what the root-prefix split moves -- the top 64 bits of the T-form (left-aligned: their top 18 bits are the root prefix) as the
+// key, the bits below them and the genome id as the value (bft_front.hip: BftItem2)
+struct __attribute__((packed, aligned(4))) BftSplit2Val {
+    uint64_t lo;
+    uint32_t id;
+};
+struct BftSplit2In {
+    const uint64_t* k0;  // word 0 (most significant), word 1 of the log
+    const uint64_t* k1;
+    const uint32_t* g;
+    uint32_t sh;  // 2k - 64: the bits of word 1 that belong to the T-form's low part once the top 64 are taken (2 .. 64)
+    __device__ uint64_t key(uint32_t i) const { return sh == 64 ? k0[i] : (k0[i] << (64 - sh)) | (k1[i] >> sh); }
+    __device__ BftSplit2Val val(uint32_t i) const {
+        BftSplit2Val v;
+        v.lo = sh == 64 ? k1[i] : (k1[i] & ((1ull << sh) - 1ull));
+        v.id = g[i];
+        return v;
+    }
+};
 template <class GT>
 struct BftPairIn {  // input of the sorts that move (k-mer, id) pairs: the log's k-mers, its ids narrowed to GT
     const uint64_t* k;
@@ -92,24 +111,31 @@ struct BftPairFlags {  // input of the scan: (first pair of its k-mer) << 32 | (
     }
 };
 // root-prefix buckets of the composites sorted on their top bits: off[r] = first composite whose prefix is >= r (r = 0..nb), and the
-// size of the largest bucket
-__global__ void k_msd_bounds(const uint64_t* __restrict__ c, uint64_t n, uint32_t shift, uint32_t nb, uint32_t* __restrict__ off, uint32_t* __restrict__ max_bucket) {
+// size of the largest bucket.  dbase (optional): where the top `dbits` bits of the prefix change -- the last pass of the sort that made the
+// order left that table behind (bft_rs::sort, last_dbase) --: a bucket is then searched inside its digit's stretch (19 steps instead of 28
+// on 2 x 10^8 composites).  One search per bucket (a bucket ends where the next one starts); k_msd_max takes the sizes from the offsets.
+__global__ void k_msd_bounds(const uint64_t* __restrict__ c, uint64_t n, uint32_t shift, uint32_t nb, uint32_t* __restrict__ off, const uint32_t* __restrict__ dbase, uint32_t dbits,
+                             uint32_t top_bits) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nb) return;
     uint64_t lo = 0, hi = n;
+    if (dbase && r < nb) {
+        const uint32_t d = r >> (top_bits - dbits);
+        lo = dbase[d];
+        hi = d + 1 < (1u << dbits) ? dbase[d + 1] : n;
+    } else if (r == nb)
+        lo = n;
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         if ((c[mid] >> shift) < (uint64_t)r) lo = mid + 1; else hi = mid;
     }
     off[r] = (uint32_t)lo;
-    if (r < nb) {  // this bucket's end = the next one's start: found by the same search
-        uint64_t lo2 = lo, hi2 = n;
-        while (lo2 < hi2) {
-            const uint64_t mid = (lo2 + hi2) >> 1;
-            if ((c[mid] >> shift) < (uint64_t)r + 1) lo2 = mid + 1; else hi2 = mid;
-        }
-        atomicMax(max_bucket, (uint32_t)(lo2 - lo));
-    }
+}
+__global__ void k_msd_max(const uint32_t* __restrict__ off, uint32_t nb, uint32_t* __restrict__ max_bucket) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t m = r < nb ? off[r + 1] - off[r] : 0u;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o));
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax(max_bucket, m);
 }
 __global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_t n, const uint64_t* __restrict__ pos, uint32_t* __restrict__ pg,
                             uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {

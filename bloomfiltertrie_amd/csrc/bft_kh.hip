@@ -382,7 +382,7 @@ static int kh_sort_w(const uint64_t* d_tk, const uint32_t* d_vals, uint64_t n, i
         CK(key.alloc(n * 4));
         CK(rec.alloc(n * sizeof(KhRec<W>)));
     }
-    CK((bft_rs::sort<uint32_t, KhRec<W>, KhSortIn<W>>(KhSortIn<W>{d_tk, d_vals, k, g}, n, key_s.as<uint32_t>(), rec_s.as<KhRec<W>>(), key.as<uint32_t>(), rec.as<KhRec<W>>(), 0u, bits, s, tmp)));
+    CK((bft_rs::sort<uint32_t, KhRec<W>, KhSortIn<W>, bft_rs::SHAPE_BACK>(KhSortIn<W>{d_tk, d_vals, k, g}, n, key_s.as<uint32_t>(), rec_s.as<KhRec<W>>(), key.as<uint32_t>(), rec.as<KhRec<W>>(), 0u, bits, s, tmp)));
     HIPCK(hipGetLastError());
     return 0;
 }

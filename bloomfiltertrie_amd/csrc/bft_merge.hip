@@ -304,7 +304,7 @@ int merge_w(const BftRun& a, const BftRun& b, hipStream_t s, BftRunOut& out) {
     {
         int abits = 1;  // (old set + 1) sits above the run's 32 bits
         while (abits < 32 && ((a.n_sets + 1) >> abits)) abits++;
-        CK((bft_rs::sort_pairs<uint64_t, uint32_t>(key.as<uint64_t>(), iota.as<uint32_t>(), n_b, key_s.as<uint64_t>(), order.as<uint32_t>(), 0, 32 + abits, s)));
+        CK((bft_rs::sort_pairs<uint64_t, uint32_t, bft_rs::SHAPE_LIGHT>(key.as<uint64_t>(), iota.as<uint32_t>(), n_b, key_s.as<uint64_t>(), order.as<uint32_t>(), 0, 32 + abits, s)));
         HIPCK(hipStreamSynchronize(s));
     }
     key.release(); iota.release();

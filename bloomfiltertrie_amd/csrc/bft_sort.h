@@ -279,9 +279,6 @@ __device__ unsigned long long g_rs_prof[2][16];
 #else
 #define RS_T(i) do {} while (0)
 #endif
-#ifndef BFT_RS_LB_MODE
-#define BFT_RS_LB_MODE 2  // where a tile looks back: 0 before it is reordered in LDS, 1 behind that, 2 behind that and before the look-back threads load the next tile
-#endif
 #ifndef BFT_RS_KO
 #define BFT_RS_KO 0  // (microbenchmark only: knock-outs -- 1 no look-back, 2 no stores of the reordered tile; wrong results)
 #endif
@@ -310,7 +307,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     uint32_t* grun = gpos + DIGITS;                             // [DIGITS] RANGED: where the range's next key of a digit goes
     uint32_t* wsum = grun + DIGITS;                             // [16]
     uint32_t* shd = wsum + 16;                                  // [4] the tile claimed next: chain, number
-    uint32_t* lbs = shd + 4;                                    // [LBG][LBT][5] what a look-back group found in its window: four sums, meta
+    uint32_t* lbs = cnt;  // [LBG][LBT][5] what a look-back group found in its window (four sums, meta): in the counters, which are free between a tile's reordering and the next tile's ranking
+    static_assert(LBG * LBT * 5 <= WAVES * DIGITS, "look-back windows do not fit the counters");
     static_assert(LBG >= 1 && LBG * LBT <= THREADS, "look-back groups");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -520,16 +518,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                 a.x = fl + my[0]; a.y = fl + my[1]; a.z = fl + my[2]; a.w = fl + my[3];
                 __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
             }
-#if BFT_RS_LB_MODE == 0
-            if (cur_j > 0 && !(BFT_RS_KO & 1)) {
-#pragma unroll
-                for (int i = 0; i < LB; i++) {
-                    const uint32_t o = lg * LB + i;
-                    if (o < cur_j) xb[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)(((tile_g - 1u - o) * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
-                    else { xb[i].x = ST_INC; xb[i].y = ST_INC; xb[i].z = ST_INC; xb[i].w = ST_INC; }  // (before the chain's first tile: nothing)
-                }
-            }
-#endif
             if (tid == 0 && more) pend_j = atomicAdd(&heads[nxt_c], 1u);  // (nxt_c is the chain the first wavefront claims from now: `home`)
         }
         RS_T(6);
@@ -542,7 +530,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             lk[slot] = key[r];
             if constexpr (HASV) lv[slot] = val[r];
         }
-#if BFT_RS_LB_MODE != 0
         if (!RANGED && tid < LBG * LBT) {
             if (cur_j > 0 && !(BFT_RS_KO & 1)) {
 #pragma unroll
@@ -553,20 +540,16 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                 }
             }
         }
-#endif
         RS_T(7);
         // ---- the next tile's keys: into the registers this tile's keys have just left
         const uint32_t this_n = tile_n;
-#if BFT_RS_LB_MODE != 2
-        if (more) load_tile(nxt_c, nxt_j);
-#else
         if (more && (RANGED || tid >= LBG * LBT)) load_tile(nxt_c, nxt_j);  // (the look-back threads: once they have looked back -- their registers are taken until then)
-#endif
         RS_T(8);
         // ---- finish the look-back: every group sums its window up to the first tile that knows its inclusive counts (per digit), or up
         // to a tile that has not published yet; group 0 puts the windows together, and goes on alone in the rare case that is not enough
         if (!RANGED && cur_j > 0 && !(BFT_RS_KO & 1)) {
             uint32_t done = 0, used = 0;  // digits that met an inclusive state; window entries taken in
+            if (LBG > 1) __syncthreads();  // (the window summaries go where the counters are: every wavefront has reordered its keys by now)
             if (tid < LBG * LBT) {
 #pragma unroll
                 for (int i = 0; i < LB; i++) {
@@ -631,9 +614,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
                 __builtin_amdgcn_raw_buffer_store_b128(a, srsrc, (int)((tile_g * (uint32_t)DIGITS + lt * 4u) * 4u), 0, 16);
             }
         }
-#if BFT_RS_LB_MODE == 2
         if (!RANGED && more && tid < LBG * LBT) load_tile(nxt_c, nxt_j);
-#endif
         if (!RANGED && tid < LBT) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -808,9 +789,19 @@ __global__ void k_rs_copy(In in, uint32_t n, K* __restrict__ ok, V* __restrict__
 template <class K, class V, int THREADS, int IPT>
 constexpr size_t pass_lds_bytes() {
     return align16(sizeof(K) * ((size_t)THREADS * IPT + 1)) + (std::is_same<V, NoVal>::value ? 0 : align16(sizeof(V) * ((size_t)THREADS * IPT + 1))) +
-           ((size_t)(THREADS / 64) * DIGITS + 4 * DIGITS + 16 + 4 + (size_t)(THREADS / (DIGITS / 4)) * (DIGITS / 4) * 5) * 4;
+           ((size_t)(THREADS / 64) * DIGITS + 4 * DIGITS + 16 + 4) * 4;
 }
 
+// the dynamic-LDS limit of a kernel, raised once per device (the call costs the host tens of microseconds: between two passes that is a gap on the GPU)
+template <auto KERNEL>
+static inline void lds_limit(int bytes) {
+    static unsigned done[1] = {0u};  // (bit d: device d has the limit; a kernel is launched with one size)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+    if (done[0] & (1u << dev)) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[0] |= 1u << dev;
+}
 static inline int cu_count() {
     static int n = 0;
     if (!n) {
@@ -853,7 +844,8 @@ struct Layout {
 // once by the first pass); the result lands in out_k / out_v; tmp_k / tmp_v (n entries each) carry the passes in between and may be NULL
 // for a one-pass sort.  `in` may read out_k / out_v only when the number of passes is even.  V = NoVal: keys only.
 template <class K, class V, class In, int THREADS, int IPT>
-int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
+int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch, const uint32_t** last_dbase) {
+    if (last_dbase) *last_dbase = nullptr;
     if (n >= (1ull << 31) - 1) return bft_fail(BFT_GPU_E_LIMIT, "internal: radix sort of 2^31 entries or more");
     if (end_bit < begin_bit || end_bit - begin_bit > (unsigned)(MAXP * DBITS) || end_bit > sizeof(K) * 8) return bft_fail(BFT_GPU_E_ARG, "internal: radix sort bit range");
     constexpr uint32_t TILE = (uint32_t)THREADS * IPT;
@@ -873,13 +865,13 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     const uint32_t tiles = (uint32_t)((n + TILE - 1) / TILE);
     const uint32_t wgs = std::min<uint32_t>(tiles, (uint32_t)std::min(1024, cus * per_cu));  // (<= 1024 ranges: k_rs_rowscan)
     const uint32_t tpr = (tiles + wgs - 1) / wgs, ranges = (tiles + tpr - 1) / tpr;
-    constexpr int HT = 1024;
+    constexpr int HT = THREADS;  // (the histogram kernel in the shape of the passes: a 1024-thread workgroup waits long for a CU beside another stream's small ones)
     if (tiles == 1) {  // one tile: every pass in one workgroup's LDS
         if (ballot) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_tiny<K, V, In, THREADS, IPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_limit<&k_rs_tiny<K, V, In, THREADS, IPT, true>>((int)lds);
             hipLaunchKernelGGL((k_rs_tiny<K, V, In, THREADS, IPT, true>), dim3(1), dim3(THREADS), lds, s, in, out_k, out_v, (uint32_t)n, pl);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_tiny<K, V, In, THREADS, IPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_limit<&k_rs_tiny<K, V, In, THREADS, IPT, false>>((int)lds);
             hipLaunchKernelGGL((k_rs_tiny<K, V, In, THREADS, IPT, false>), dim3(1), dim3(THREADS), lds, s, in, out_k, out_v, (uint32_t)n, pl);
         }
         HIPCK(hipGetLastError());
@@ -905,7 +897,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         hipLaunchKernelGGL((k_rs_hist<K, INTYPE, HT>), dim3(ranges), dim3(HT), (size_t)p1.hwords * 4, s, INVAL, (uint32_t)n, p1, tpr * TILE, partial);                          \
         hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << p1.nbits[0], 1), dim3(256), 0, s, partial, partial, p1, ranges, tot);                                                       \
         hipLaunchKernelGGL(k_rs_digits, dim3(1), dim3(DIGITS), 0, s, tot, dbase, chain, p1, (uint32_t)n, TILE);                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        lds_limit<&k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>>((int)lds);   \
         hipLaunchKernelGGL((k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>), dim3(ranges), dim3(THREADS), lds, s, INVAL, dk, dv, (uint32_t)n, p1.bit[0], p1.nbits[0],      \
                            partial, p1.hwords, dbase, tpr, chain, chain, 1u, chain, chain, 16u);                                                                               \
     } while (0)
@@ -922,6 +914,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
             src_v = dv;
         }
         HIPCK(hipGetLastError());
+        if (last_dbase) *last_dbase = dbase;
         return 0;
     }
     Layout L;
@@ -944,7 +937,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     if (scratch.bytes < L.total_words * 4) CK(scratch.alloc(L.total_words * 4));
     uint32_t* W = scratch.as<uint32_t>();
     HIPCK(hipMemsetAsync(W, 0, L.zero_words * 4, s));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_hist<K, In, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    lds_limit<&k_rs_hist<K, In, HT>>(160 * 1024 - 64);
     hipLaunchKernelGGL((k_rs_hist<K, In, HT>), dim3(ranges), dim3(HT), (size_t)pl.hwords * 4, s, in, (uint32_t)n, pl, tpr * TILE, W + L.partial);
     // per digit: the ranges' counts (pass 0, in place in the histogram blocks) and the chains' (later passes) -> where each of them starts inside the digit
     uint32_t maxnb = 0;
@@ -967,7 +960,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         if (p == 0) {
 #define BFT_RS_LAUNCH0(BAL)                                                                                                                                            \
     do {                                                                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, In, THREADS, IPT, true, BAL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        lds_limit<&k_rs_pass<K, V, In, THREADS, IPT, true, BAL, 1>>((int)lds); \
         hipLaunchKernelGGL((k_rs_pass<K, V, In, THREADS, IPT, true, BAL, 1>), dim3(ranges), dim3(THREADS), lds, s, in, dk, dv, (uint32_t)n, pl.bit[0], pl.nbits[0],       \
                            W + L.partial + pl.hoff[0], pl.hwords, W + L.dbase, tpr, ch, ch, 1u, W + L.heads, W + L.states, 16u);                                       \
     } while (0)
@@ -979,7 +972,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
             const uint32_t st_bytes = L.max_tiles * DIGITS * 4;
 #define BFT_RS_LAUNCH1(BAL, G)                                                                                                                                                      \
     do {                                                                                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        lds_limit<&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL, G>>((int)lds); \
         hipLaunchKernelGGL((k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, BAL, G>), dim3(grid), dim3(THREADS), lds, s, PtrIn<K, V>{src_k, src_v}, dk, dv, (uint32_t)n,         \
                            pl.bit[p], pl.nbits[p], W + L.cnt + pl.hoff[p], 1u << pl.nbits[p], W + L.dbase + (size_t)p * DIGITS, 0u, ch, ch + (1 << MAXCB) + 1, 1u << pl.cb[p],     \
                            W + L.heads + (size_t)p * (1 << MAXCB), st, st_bytes);                                                                                                   \
@@ -1003,6 +996,7 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         src_v = dv;
     }
     HIPCK(hipGetLastError());
+    if (last_dbase) *last_dbase = W + L.dbase + (size_t)(pl.P - 1) * DIGITS;
     return 0;
 }
 
@@ -1011,31 +1005,45 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
 // BFT_RS_CHAIN_MIN entries -> a histogram kernel and a ranged pass per digit; beyond -> one histogram kernel, a ranged first pass, chained
 // passes behind it (2 x 10^8 composites: 2.2-2.3 ms against 2.75 with a histogram per pass; 1.6 x 10^6 pairs, eight passes: 0.18 ms against
 // 0.43 chained -- and 0.27 for rocPRIM's onesweep --; 4.5 x 10^7 k-mer hash records: 1.33 against 1.50).
-template <class K, class V, class In>
-int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch) {
+// *last_dbase (optional): where, in `scratch`, the last pass's digits start in the output (512 words; NULL for an array of one tile)
+// SHAPE: BIG (default) -- 1024-thread workgroups, the largest tile the LDS holds, one workgroup per CU; LIGHT -- 256 threads and ~40 KB of LDS,
+// for the sorts of 10^4 .. 10^7 entries on the build's main stream; BACK -- 1024 threads and ~105 KB, for the k-mer hash's sort on the
+// build's second stream: a BACK and a LIGHT workgroup fit one CU together, so the persistent workgroups of the one sort do not keep the
+// other's from being placed (side by side in the BIG shape the (node, CC) sorts of the assembly took 1.6 ms instead of 0.3).
+enum { SHAPE_BIG = 0, SHAPE_LIGHT = 1, SHAPE_BACK = 2 };
+template <class K, class V, class In, int SHAPE = SHAPE_BIG>
+int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned begin_bit, unsigned end_bit, hipStream_t s, DevBuf& scratch, const uint32_t** last_dbase = nullptr) {
     constexpr size_t E = sizeof(K) + (std::is_same<V, NoVal>::value ? 0 : sizeof(V));
-    constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
+    if constexpr (SHAPE == SHAPE_LIGHT) {
+        constexpr int IPT = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
+        return sort_cfg<K, V, In, 256, IPT>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);
+    } else if constexpr (SHAPE == SHAPE_BACK) {
+        constexpr int IPT = E <= 8 ? 8 : E <= 12 ? 5 : E <= 16 ? 4 : E <= 24 ? 3 : E <= 32 ? 2 : 1;
+        return sort_cfg<K, V, In, 1024, IPT>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);
+    } else {
+        constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
 #ifdef BFT_RS_BIG_IPT
-    return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+        return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);
 #else
-    return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch);
+        return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, IPT_BIG>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);
 #endif
+    }
 }
 
 // the same with the buffers between the passes and the scratch taken from the device-memory cache for the duration of the call (they go back
 // to it stream-ordered: DevBuf)
-template <class K, class V, class In>
+template <class K, class V, class In, int SHAPE = SHAPE_BIG>
 int sort_in(In in, uint64_t n, K* out_k, V* out_v, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
     DevBuf tk, tv, scratch;
     if (make_plan(begin_bit, end_bit).P > 1 && n) {
         CK(tk.alloc(n * sizeof(K)));
         if (!std::is_same<V, NoVal>::value) CK(tv.alloc(n * sizeof(V)));
     }
-    return sort<K, V, In>(in, n, out_k, out_v, tk.as<K>(), tv.as<V>(), begin_bit, end_bit, s, scratch);
+    return sort<K, V, In, SHAPE>(in, n, out_k, out_v, tk.as<K>(), tv.as<V>(), begin_bit, end_bit, s, scratch);
 }
-template <class K, class V>
+template <class K, class V, int SHAPE = SHAPE_BIG>
 int sort_pairs(const K* in_k, const V* in_v, uint64_t n, K* out_k, V* out_v, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
-    return sort_in<K, V, PtrIn<K, V>>(PtrIn<K, V>{in_k, in_v}, n, out_k, out_v, begin_bit, end_bit, s);
+    return sort_in<K, V, PtrIn<K, V>, SHAPE>(PtrIn<K, V>{in_k, in_v}, n, out_k, out_v, begin_bit, end_bit, s);
 }
 template <class K>
 int sort_keys(const K* in_k, uint64_t n, K* out_k, unsigned begin_bit, unsigned end_bit, hipStream_t s) {

@@ -795,4 +795,40 @@ def test_closed_handles_leave_their_blocks_in_the_cache():
     assert (S.from_bits(t.query_presence(q), len(q)) == answers[0]).all()
     _, off, ids = t.query_colors(km[:3])  # (k-mer 0 is in both genomes, 1 and 2 in the first only)
     assert off.tolist() == [0, 2, 3, 4] and ids[:4].tolist() == [0, 1, 0, 0]
-    t.close()
+    t.close()@pytest.mark.gpu
+@pytest.mark.parametrize("k,ngen,glen,rate", [(36, 40, 6000, 0.01), (45, 300, 700, 0.01), (63, 1200, 260, 0.01), (63, 24, 20000, 0.2), (64, 64, 3000, 0.02)])
+def test_two_word_front_end_builds_the_same_image(k, ngen, glen, rate):
+    """Two-word keys (33 <= k <= 64) with ascending genome ids: the root-prefix split on the top 18 T bits, then every bucket grouped by a
+    hash of its key bits and only its distinct k-mers ordered (bft_front.hip: k_bucket2_sort; "build_msd" 2 forces it at this size) against
+    the device-wide sort of every word ("build_msd" 0): every array of the image, the colour sets and the extraction are identical --
+    buckets of one locus with hundreds of copies (many genomes of a short ancestor), buckets of a few all-distinct k-mers (few genomes, many
+    SNPs), duplicate pairs, and an incremental build on top."""
+    from bloomfiltertrie_amd import BFT
+    anc = S.random_genome(glen, 1000 + k)
+    parts = [S.distinct(S.kmers_of(S.mutate(anc, rate, 7 * k + g), k)) for g in range(ngen)]
+    imgs = []
+    for msd in (2, 0):
+        t = BFT(k)
+        t.set_option("build_msd", msd)
+        half = ngen // 2
+        for g in range(half):
+            t.insert_kmers(parts[g], g)
+            if g == 1:
+                t.insert_kmers(parts[g][::3], g)  # duplicates of the same pairs
+        t.build()
+        if msd == 2:
+            assert t.build_time()["sort_max_bucket"] > 0  # (the front end ran: it reports its largest bucket)
+        for g in range(half, ngen):
+            t.insert_kmers(parts[g], g)
+        t.build()
+        ek, ecs = t.extract()
+        imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs, [t.colorset(c) for c in sorted(set(ecs.tolist()))[:200]], t.info()))
+        t.close()
+    a, b = imgs
+    for name in ARRAYS:
+        assert (a[0][name] == b[0][name]).all(), name
+    assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
+    assert a[4]["kmers"] == b[4]["kmers"] == len(S.distinct(np.concatenate(parts))) and a[4]["pairs"] == b[4]["pairs"] == sum(len(x) for x in parts)
+
+
+

@@ -160,6 +160,7 @@ int main(int argc, char** argv) {
     fails += check_case<uint64_t, uint32_t>(6000017, 20, 38, 2, "u64+u32 18 bits heavy digit");
     fails += check_case<uint64_t, uint8_t>(4500000, 44, 62, 0, "u64+u8 18 bits");
     fails += check_case<uint32_t, bft_rs::NoVal>(1234567, 5, 5, 0, "no bits (copy)");
+    fails += check_case<uint64_t, uint32_t>(20000003, 3, 40, 0, "u64+u32 37 bits, chained");
     }
     if (!nocheck)
         for (uint64_t n : {1ull, 63ull, 4096ull, 4097ull, 1000003ull, 30000001ull}) {
@@ -216,7 +217,9 @@ int main(int argc, char** argv) {
         HCK(hipMalloc(&in, n * 4)); HCK(hipMalloc(&out, n * 4)); HCK(hipMalloc(&tmp, n * 4));
         HCK(hipMalloc(&ri, n * 12)); HCK(hipMalloc(&ro, n * 12)); HCK(hipMalloc(&rt, n * 12));
         hipLaunchKernelGGL(k_fill_kh, dim3(4096), dim3(256), 0, 0, in, ri, n);
-        float ms = time_it([&] { (void)bft_rs::sort<uint32_t, Rec12>(bft_rs::PtrIn<uint32_t, Rec12>{in, ri}, n, out, ro, tmp, rt, 0, 24, 0, scratch); });
+        float ms = time_it([&] { (void)bft_rs::sort<uint32_t, Rec12, bft_rs::PtrIn<uint32_t, Rec12>, bft_rs::SHAPE_BACK>(bft_rs::PtrIn<uint32_t, Rec12>{in, ri}, n, out, ro, tmp, rt, 0, 24, 0, scratch); });
+        printf("{\"what\": \"k-mer hash sort, 4.46e7 x (u32 + 12 B), 24 bits\", \"impl\": \"bft_rs back shape\", \"ms\": %.3f}\n", ms);
+        ms = time_it([&] { (void)bft_rs::sort<uint32_t, Rec12>(bft_rs::PtrIn<uint32_t, Rec12>{in, ri}, n, out, ro, tmp, rt, 0, 24, 0, scratch); });
         HCK(hipMemset(bad, 0, 4));
         hipLaunchKernelGGL(k_check_kh, dim3(4096), dim3(256), 0, 0, out, ro, n, bad);
         unsigned nb = 0;
@@ -255,6 +258,12 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, in, n, 10);
         float ms = time_it([&] { (void)bft_rs::sort<uint64_t, uint32_t>(bft_rs::PtrIn<uint64_t, uint32_t>{in, vi}, n, out, vo, tmp, vt, 0, 64, 0, scratch); });
         printf("{\"what\": \"small sort, 1.6e6 x (u64 + u32), 64 bits\", \"impl\": \"bft_rs\", \"ms\": %.3f}\n", ms);
+        ms = time_it([&] { (void)bft_rs::sort<uint64_t, uint32_t, bft_rs::PtrIn<uint64_t, uint32_t>, bft_rs::SHAPE_LIGHT>(bft_rs::PtrIn<uint64_t, uint32_t>{in, vi}, n, out, vo, tmp, vt, 0, 64, 0, scratch); });
+        printf("{\"what\": \"small sort, 1.6e6 x (u64 + u32), 64 bits\", \"impl\": \"bft_rs light shape\", \"ms\": %.3f}\n", ms);
+        ms = time_it([&] { (void)bft_rs::sort<uint64_t, uint32_t, bft_rs::PtrIn<uint64_t, uint32_t>, bft_rs::SHAPE_LIGHT>(bft_rs::PtrIn<uint64_t, uint32_t>{in, vi}, n, out, vo, tmp, vt, 0, 30, 0, scratch); });
+        printf("{\"what\": \"small sort, 1.6e6 x (u64 + u32), 30 bits\", \"impl\": \"bft_rs light shape\", \"ms\": %.3f}\n", ms);
+        ms = time_it([&] { (void)bft_rs::sort<uint64_t, uint32_t, bft_rs::PtrIn<uint64_t, uint32_t>>(bft_rs::PtrIn<uint64_t, uint32_t>{in, vi}, n, out, vo, tmp, vt, 0, 30, 0, scratch); });
+        printf("{\"what\": \"small sort, 1.6e6 x (u64 + u32), 30 bits\", \"impl\": \"bft_rs\", \"ms\": %.3f}\n", ms);
         size_t tb = 0;
         (void)rocprim::radix_sort_pairs(nullptr, tb, in, out, vi, vo, (size_t)n, 0u, 64u, 0);
         void* t2;
