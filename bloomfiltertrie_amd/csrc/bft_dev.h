@@ -190,8 +190,8 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
 // *done = false: that bucket is beyond bft_front_bucket_capacity() and nothing was produced (d_c may have been reordered inside its
 // buckets); *n_redone: buckets whose order check failed and that were sorted again)
 // two-word keys (33 <= k <= 64): d_hk = the top 64 bits of the T-form, left-aligned, grouped by their top 18 bits (d_boff); d_items = {lo: the 2k - 64
-// bits below, id: the genome} (12 bytes each) beside them.  *done = false: a bucket is beyond bft_front2_bucket_capacity(), holds more distinct
-// k-mers than half of it, or kept colliding: nothing was produced (the arrays may have been reordered inside their buckets).
+// bits below, id: the genome} (12 bytes each) beside them.  *done = false: a bucket is beyond bft_front2_bucket_capacity(): nothing was produced
+// (the arrays may have been reordered inside their buckets); *n_redone as bft_front_buckets'.
 uint32_t bft_front2_bucket_capacity(void);
 int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t* d_boff, uint32_t nb, int k, hipStream_t s, DevBuf& tk, DevBuf& seg_off, DevBuf& pg, uint64_t& nk, uint64_t& np,
-                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done);
+                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone);

@@ -22,6 +22,7 @@
 // (rocPRIM: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms; these kernels: 3.0 ms).
 #include "bft_dev.h"
 #include "bft_scan.h"
+#include "bft_sort.h"
 
 #define FB_BLOCK 256
 #define FB_WAVES (FB_BLOCK / 64)
@@ -418,284 +419,531 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
 
 // ---- two-word keys (33 <= k <= 64) --------------------------------------------------------------------------------------------------------
 // insertKmer_Node_special (src/insertNode.c:241-423) for keys of two words.  The split hands over items (hk, lo, id): hk = the top 64 bits of
-// the T-form, left-aligned (its top 18 bits = the root prefix = the bucket), lo = the 2k - 64 bits below them, id = the genome.  Inside a
-// bucket 46 + (2k - 64) key bits are left -- 108 at k = 63: twelve 9-bit passes where a one-word bucket takes four.  But a pan-genome
-// bucket holds few DISTINCT k-mers (config 5: one locus, ~2000 items of ~450 k-mers), so the items are GROUPED first and only the distinct
-// k-mers are ordered:
-//   1. every item gets a 27-bit hash of its key bits; (hash << 13 | position in the bucket) is sorted on the hash by the same three LDS
-//      radix passes the one-word buckets use (radix_passes): equal k-mers end up next to each other, in insertion order (ascending ids);
-//   2. an item that differs from its left neighbour starts a k-mer; two DIFFERENT neighbours with one hash are a collision: the bucket
-//      is done again with another seed (expected for ~10^-3 of the buckets, four seeds);
-//   3. the distinct k-mers (at most half the capacity) go to LDS and are ranked by comparison -- m^2 / 256 comparisons of 16 bytes per
-//      thread: ~3 us at m = 450 --; a scan over the ranks gives every k-mer's place among the bucket's kept pairs;
-//   4. the items go back in place in (k-mer, id) order, duplicated pairs dropped; counts as for one-word buckets; k_bucket2_emit
-//      then streams k-mers, offsets and ids out.
+// the T-form, left-aligned (its top 18 bits = the root prefix = the bucket), lo = the sh = 2k - 64 bits below them, id = the genome.  Inside
+// a bucket 46 + sh key bits are left (108 at k = 63): the same stable LSD radix sort in LDS as for one-word buckets, over two words -- the
+// items in registers (five per item), 9-bit digits first over lo, then over the low 46 bits of hk, ranks from LDS atomics (checked over the
+// whole order, ballots on failure), one exchange per pass in two steps so that the buffer holds 12 bytes per item instead of 20.
+// (Built and measured first, and dropped: grouping a bucket's items by a 27-bit hash of their key bits -- three passes over 8-byte entries --
+// and ordering only the distinct k-mers, a quarter of the items on a pan-genome, by comparison.  The ranking alone is m^2 comparisons of
+// 16 bytes: 35 x 10^3 wavefront instructions per bucket of 1850 items / 445 k-mers where these thirteen passes take 13 x 10^3 all told;
+// 7.0 ms for config 5's 19 x 10^3 buckets.)
 struct __attribute__((packed, aligned(4))) BftItem2 {
     uint64_t lo;
     uint32_t id;
 };
 
-__device__ __forceinline__ uint32_t hash27(uint64_t a, uint64_t b, uint32_t seed) {
-    uint64_t x = (a ^ (0x9E3779B97F4A7C15ull * (seed + 1))) * 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 29;
-    x += b * 0x94D049BB133111EBull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 31;
-    return (uint32_t)(x >> 37);
-}
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, int l) {
-    return ((uint64_t)(uint32_t)__shfl((uint32_t)(v >> 32), l) << 32) | (uint32_t)__shfl((uint32_t)v, l);
-}
-
-// fail[0]: buckets that could not be done here (beyond the capacity, more than half of it distinct, four colliding seeds): the caller falls
-// back to the device-wide sort.  min_n / max_n: the sizes this launch takes (the variants differ in EMAX).
-template <int EMAX>
-__global__ __launch_bounds__(FB_BLOCK, (EMAX <= 8 ? 4 : EMAX <= 16 ? 2 : 1)) void k_bucket2_sort(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, uint32_t nb,
-                                                                                          uint64_t* __restrict__ counts, uint32_t* __restrict__ fail, uint32_t min_n, uint32_t max_n) {
-    constexpr uint32_t CAP = FB_BLOCK * EMAX, MC = CAP / 2;
-    __shared__ uint64_t keys[CAP];                 // the sort's exchange buffer, then the distinct k-mers: (hk46, lo) x MC
-    __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];  // digit counters, then ranks of the distinct k-mers (MC <= 4 x 512 words at EMAX = 16; EMAX = 32: see dextra)
-    __shared__ uint32_t dkoff[MC + 1];             // first kept pair of a distinct k-mer (in hash order)
-    __shared__ uint32_t lenr[MC];                  // pairs of the k-mer of a rank, then its first pair among the bucket's
-    __shared__ uint32_t drank_x[EMAX > 16 ? MC : 1];
-    __shared__ uint32_t wtot[FB_WAVES];
-    __shared__ uint64_t wlast_k[FB_WAVES][2];
-    __shared__ uint32_t wlast_i[FB_WAVES], wlast_h[FB_WAVES];
-    __shared__ uint32_t w_nh[FB_WAVES], w_nk[FB_WAVES];
-    __shared__ uint32_t s_flag;
-    uint32_t* drank = EMAX > 16 ? drank_x : &cnt[0][0];
+template <bool BALLOT, int EMAX>
+__device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&klo)[EMAX], uint32_t (&kid)[EMAX], bool from_hi, uint32_t bit, int nbits, uint64_t* buf8, uint32_t* buf4,
+                                            uint32_t (*cnt)[FB_DIGITS], uint32_t* wtot, uint32_t n, uint32_t E) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
-        if (n < min_n || n > max_n) continue;
-        if (n == 0) {
-            if (tid == 0) counts[b] = 0;
-            continue;
+    const uint32_t wbase = wave * E * 64u;
+    const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+    for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[wave][lane * (FB_DIGITS / 64) + j] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t rank[EMAX];
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+        rank[r] = 0;
+        if (r >= E) continue;  // (uniform)
+        const uint32_t idx = wbase + r * 64u + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
+        if (BALLOT) {
+            const uint64_t peers = match_digit(d, valid, nbits);
+            if (valid) {
+                const int leader = __builtin_ctzll(peers);
+                uint32_t base = 0;
+                if ((int)lane == leader) {
+                    base = cnt[wave][d];
+                    cnt[wave][d] = base + (uint32_t)__builtin_popcountll(peers);
+                }
+                base = __shfl(base, leader);
+                rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
+            }
+        } else if (valid) {
+            rank[r] = atomicAdd(&cnt[wave][d], 1u);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    {   // digit(s) of this thread: counts of the four wavefronts -> start of (digit, wavefront) in the bucket
+        constexpr int DPT = FB_DIGITS / FB_BLOCK;
+        uint32_t cw[DPT][FB_WAVES], tot = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++) { cw[j][w] = cnt[w][tid * DPT + j]; tot += cw[j][w]; }
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += v;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < FB_WAVES; w++)
+            if (w < (int)wave) before += wtot[w];
+        uint32_t start = before + inc - tot;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; w++) { cnt[w][tid * DPT + j] = start; start += cw[j][w]; }
+        }
+    }
+    __syncthreads();
+    // the exchange: every item to its place; hk and id first, lo behind them through the same buffer
+    uint32_t dst[EMAX];
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+        const uint32_t idx = wbase + r * 64u + lane;
+        dst[r] = 0xFFFFFFFFu;
+        if (r < E && idx < n) {
+            dst[r] = cnt[wave][(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask] + rank[r];
+            buf8[dst[r]] = khi[r];
+            buf4[dst[r]] = kid[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+        const uint32_t idx = wbase + r * 64u + lane;
+        if (r < E && idx < n) { khi[r] = buf8[idx]; kid[r] = buf4[idx]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
+        if (dst[r] != 0xFFFFFFFFu) buf8[dst[r]] = klo[r];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+        const uint32_t idx = wbase + r * 64u + lane;
+        if (r < E && idx < n) klo[r] = buf8[idx];
+    }
+    __syncthreads();
+}
+
+template <bool BALLOT, int EMAX>
+__device__ __forceinline__ void radix_passes2(uint64_t (&khi)[EMAX], uint64_t (&klo)[EMAX], uint32_t (&kid)[EMAX], uint32_t sh, uint64_t* buf8, uint32_t* buf4, uint32_t (*cnt)[FB_DIGITS],
+                                              uint32_t* wtot, uint32_t n, uint32_t E) {
+    for (uint32_t bit = 0; bit < sh; bit += FB_DBITS) radix_pass2<BALLOT, EMAX>(khi, klo, kid, false, bit, (int)min((uint32_t)FB_DBITS, sh - bit), buf8, buf4, cnt, wtot, n, E);
+    for (uint32_t bit = 0; bit < 46u; bit += FB_DBITS) radix_pass2<BALLOT, EMAX>(khi, klo, kid, true, bit, (int)min((uint32_t)FB_DBITS, 46u - bit), buf8, buf4, cnt, wtot, n, E);
+}
+
+// the non-empty buckets by size class (lists[c * nb ..], n_lists[c]): up to 64 items (class 5: k_bucket2_tiny), up to 512 / 1024 / 2048 -- a wavefront each, 8 / 16 / 32 items per lane --,
+// up to 4096 / 8192 -- a workgroup each --, so that the sort kernels walk real buckets only (those of a pan-genome are a few per cent of the 2^18 root
+// prefixes); the empty ones get their zero counts here
+#define FB2_CLASSES 6
+__global__ void k_bucket2_lists(const uint32_t* __restrict__ boff, uint32_t nb, uint32_t* __restrict__ lists, uint32_t* __restrict__ n_lists, uint64_t* __restrict__ counts) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t n = b < nb ? boff[b + 1] - boff[b] : 0u;
+    if (b < nb && n == 0) counts[b] = 0;
+    const int cls = n == 0 ? -1 : n <= 64u ? 5 : n <= 512u ? 0 : n <= 1024u ? 1 : n <= 2048u ? 2 : n <= 4096u ? 3 : 4;
+    __shared__ uint32_t s_cnt[FB2_CLASSES], s_base[FB2_CLASSES];
+    if (threadIdx.x < FB2_CLASSES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int c = 0; c < FB2_CLASSES; c++) {  // (a slot in the workgroup's part of the class's list: one atomic per wavefront in LDS, one per workgroup on the list's counter)
+        const uint64_t mk = __ballot(cls == c);
+        if (!mk) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(mk)) base = atomicAdd(&s_cnt[c], (uint32_t)__builtin_popcountll(mk));
+        base = __shfl(base, __builtin_ctzll(mk));
+        if (cls == c) mine = base + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < FB2_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&n_lists[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (cls >= 0) lists[(size_t)cls * nb + s_base[cls] + mine] = b;
+}
+
+// a bucket of up to 64 items, one per lane of ONE wavefront: every item's rank by comparison with the others (a uniform loop over the items,
+// each broadcast from its lane), ties in lane order (= insertion order: ascending ids).  On a pan-genome most non-empty buckets are of this kind --
+// the few copies of a locus whose root prefix carries a SNP: 2.3 x 10^5 of config 5's 2.5 x 10^5 buckets, a dozen items each; thirteen radix passes
+// apiece took 1.8 ms.
+__global__ __launch_bounds__(FB_BLOCK) void k_bucket2_tiny(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
+                                                           const uint32_t* __restrict__ n_list, uint64_t* __restrict__ counts) {
+    __shared__ uint64_t s_h[FB_WAVES][64], s_l[FB_WAVES][64];
+    __shared__ uint32_t s_i[FB_WAVES][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t m46 = (1ull << 46) - 1ull;
+    const uint32_t n_b = *n_list;
+    for (uint32_t li = blockIdx.x * FB_WAVES + wave; li < n_b; li += gridDim.x * FB_WAVES) {
+        const uint32_t b = list[li], a0 = boff[b], n = boff[b + 1] - a0;
+        uint64_t h = ~0ull, l = ~0ull;
+        uint32_t id = 0;
+        if (lane < n) {
+            const BftItem2 x = it[a0 + lane];
+            h = hk[a0 + lane] & m46;
+            l = x.lo;
+            id = x.id;
+        }
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint64_t bh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, (int)j);
+            const uint64_t bl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(l >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)l, (int)j);
+            const bool less = bh < h || (bh == h && bl < l), eq = bh == h && bl == l;
+            rank += (less || (eq && j < lane)) ? 1u : 0u;
+        }
+        if (lane < n) { s_h[wave][rank] = h; s_l[wave][rank] = l; s_i[wave][rank] = id; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t nk = 0, np = 0;
+        if (lane < n) {
+            h = s_h[wave][lane]; l = s_l[wave][lane]; id = s_i[wave][lane];
+            const bool head = lane == 0 || s_h[wave][lane - 1] != h || s_l[wave][lane - 1] != l;
+            nk = head;
+            np = head || s_i[wave][lane - 1] != id;
+            hk[a0 + lane] = ((uint64_t)b << 46) | h;
+            BftItem2 x;
+            x.lo = l;
+            x.id = id;
+            it[a0 + lane] = x;
+        }
+        for (int o = 32; o > 0; o >>= 1) { nk += __shfl_down(nk, o); np += __shfl_down(np, o); }
+        if (lane == 0) counts[b] = ((uint64_t)nk << 32) | np;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next bucket overwrites the slots)
+    }
+}
+
+// ONE WAVEFRONT per bucket of up to 64 EW items: no barrier anywhere (the LDS operations of a wavefront are in order), the items in registers
+// (five per item), per pass: ranks from one LDS atomic per item, a 512-digit scan by shuffles, the exchange word by word through 8 bytes per
+// item of LDS.  (With a workgroup per bucket the thirteen passes of k = 63 cost seven barriers each: 12.4 ms for config 5's 19 x 10^3 buckets.)
+template <int EW>
+__global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
+                                                                const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone) {
+    __shared__ uint64_t buf_all[FB_WAVES][64 * EW];
+    __shared__ uint32_t cnt_all[FB_WAVES][FB_DIGITS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint64_t m46 = (1ull << 46) - 1ull;
+    uint64_t* buf = buf_all[wave];
+    uint32_t* cnt = cnt_all[wave];
+    const uint32_t n_b = *n_list;
+    for (uint32_t li = blockIdx.x * FB_WAVES + wave; li < n_b; li += gridDim.x * FB_WAVES) {
+        const uint32_t b = list[li], a0 = boff[b], n = boff[b + 1] - a0;
+        const uint32_t E = (n + 63u) / 64u;  // rounds: slot (round r, lane l) = item r 64 + l of the bucket
+        uint64_t khi[EW], klo[EW];
+        uint32_t kid[EW];
+        bool sorted = false;
+        for (int attempt = (mode == 1 ? 1 : 0); attempt < 2 && !sorted; attempt++) {  // 0: ranks from LDS atomics, checked; 1: from ballots
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                const uint32_t idx = r * 64u + lane;
+                khi[r] = ~0ull; klo[r] = ~0ull; kid[r] = 0;
+                if (r < E && idx < n) {
+                    const BftItem2 x = it[a0 + idx];
+                    khi[r] = hk[a0 + idx] & m46;
+                    klo[r] = x.lo;
+                    kid[r] = x.id;
+                }
+            }
+            const uint32_t np_lo = (sh + FB_DBITS - 1) / FB_DBITS, np_hi = (46u + FB_DBITS - 1) / FB_DBITS;
+            for (uint32_t p = 0; p < np_lo + np_hi; p++) {
+                const bool from_hi = p >= np_lo;
+                const uint32_t bit = (from_hi ? p - np_lo : p) * FB_DBITS, width = from_hi ? 46u : sh;
+                const int nbits = (int)min((uint32_t)FB_DBITS, width - bit);
+                const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+                for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[lane * (FB_DIGITS / 64) + j] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t rank[EW];
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    rank[r] = 0;
+                    if (r >= E) continue;  // (uniform)
+                    const bool valid = r * 64u + lane < n;
+                    const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
+                    if (attempt == 0) {
+                        if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
+                    } else {
+                        const uint64_t peers = match_digit(d, valid, nbits);
+                        if (valid) {
+                            const int leader = __builtin_ctzll(peers);
+                            uint32_t base = 0;
+                            if ((int)lane == leader) {
+                                base = cnt[d];
+                                cnt[d] = base + (uint32_t)__builtin_popcountll(peers);
+                            }
+                            base = __shfl(base, leader);
+                            rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                {   // the lane's digits: counts -> starts
+                    constexpr int DPL = FB_DIGITS / 64;
+                    uint32_t cw[DPL], tot = 0;
+#pragma unroll
+                    for (int j = 0; j < DPL; j++) { cw[j] = cnt[lane * DPL + j]; tot += cw[j]; }
+                    uint32_t inc = tot;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t v = __shfl_up(inc, o);
+                        if ((int)lane >= o) inc += v;
+                    }
+                    uint32_t start = inc - tot;
+#pragma unroll
+                    for (int j = 0; j < DPL; j++) { cnt[lane * DPL + j] = start; start += cw[j]; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++)  // (rank becomes the item's new slot)
+                    if (r < E && r * 64u + lane < n) rank[r] += cnt[(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask];
+                // the exchange, word by word through the wavefront's 8 bytes per item
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+#pragma unroll
+                    for (uint32_t r = 0; r < (uint32_t)EW; r++)
+                        if (r < E && r * 64u + lane < n) buf[rank[r]] = f == 0 ? khi[r] : f == 1 ? klo[r] : (uint64_t)kid[r];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                    for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                        const uint32_t idx = r * 64u + lane;
+                        if (r < E && idx < n) {
+                            const uint64_t v = buf[idx];
+                            if (f == 0) khi[r] = v; else if (f == 1) klo[r] = v; else kid[r] = (uint32_t)v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+            sorted = true;
+            if (attempt == 0) {  // in order over the key AND the ids (a stable sort keeps equal k-mers in insertion order: ascending ids)?
+                int off = mode == 2;
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+                    // the left neighbour: lane - 1 of the round, or lane 63 of the round before
+                    const uint32_t idx = r * 64u + lane;
+                    uint64_t ph = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)khi[r], (int)((lane + 63u) & 63u));
+                    uint64_t pl = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)klo[r], (int)((lane + 63u) & 63u));
+                    uint32_t pi = __shfl(kid[r], (int)((lane + 63u) & 63u));
+                    const uint32_t rp = r ? r - 1 : 0;
+                    const uint64_t qh = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)khi[rp], 63);
+                    const uint64_t ql = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)klo[rp], 63);
+                    const uint32_t qi = __shfl(kid[rp], 63);
+                    if (lane == 0) { ph = qh; pl = ql; pi = qi; }
+                    if (r < E && idx < n && idx) off |= ph > khi[r] || (ph == khi[r] && (pl > klo[r] || (pl == klo[r] && pi > kid[r])));
+                }
+                sorted = __ballot(off != 0) == 0ull;
+                if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
+            }
+        }
+        uint32_t nk = 0, np = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EW; r++) {
+            const uint32_t idx = r * 64u + lane;
+            uint64_t ph = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)khi[r], (int)((lane + 63u) & 63u));
+            uint64_t pl = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)klo[r], (int)((lane + 63u) & 63u));
+            uint32_t pi = __shfl(kid[r], (int)((lane + 63u) & 63u));
+            const uint32_t rp = r ? r - 1 : 0;
+            const uint64_t qh = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)khi[rp], 63);
+            const uint64_t ql = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)klo[rp], 63);
+            const uint32_t qi = __shfl(kid[rp], 63);
+            if (lane == 0) { ph = qh; pl = ql; pi = qi; }
+            if (r < E && idx < n) {
+                const bool head = idx == 0 || ph != khi[r] || pl != klo[r];
+                nk += head;
+                np += head || pi != kid[r];
+                hk[a0 + idx] = ((uint64_t)b << 46) | khi[r];
+                BftItem2 x;
+                x.lo = klo[r];
+                x.id = kid[r];
+                it[a0 + idx] = x;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { nk += __shfl_down(nk, o); np += __shfl_down(np, o); }
+        if (lane == 0) counts[b] = ((uint64_t)nk << 32) | np;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next bucket overwrites buf)
+    }
+}
+
+// mode as k_bucket_sort's: 0 = ranks from LDS atomics, the order checked, ballots on failure; 1 = ballots only; 2 = the check always fails
+template <int EMAX>
+__global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
+                                                           const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone,
+                                                           uint32_t* __restrict__ fail) {
+    constexpr uint32_t CAP = FB_BLOCK * EMAX;
+    __shared__ uint64_t buf8[CAP];
+    __shared__ uint32_t buf4[CAP];
+    __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];
+    __shared__ uint32_t wtot[FB_WAVES];
+    __shared__ uint32_t s_nk, s_np;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t m46 = (1ull << 46) - 1ull;
+    const uint32_t n_b = *n_list;
+    for (uint32_t li = blockIdx.x; li < n_b; li += gridDim.x) {
+        const uint32_t b = list[li], a0 = boff[b], n = boff[b + 1] - a0;
         if (n > CAP) {  // (excluded by the caller; counted in case)
             if (tid == 0) { counts[b] = 0; atomicAdd(fail, 1u); }
             continue;
         }
         const uint32_t E = (n + FB_BLOCK - 1) / FB_BLOCK;  // rounds
         const uint32_t wbase = wave * E * 64u;
-        bool ok = false;
-        uint64_t ihk[EMAX], ilo[EMAX];
-        uint32_t iid[EMAX];
-        uint32_t hidx[EMAX], kidx[EMAX];  // per item: index of its k-mer among the distinct ones (hash order); index among the kept pairs
-        uint64_t flags_head = 0, flags_keep = 0;  // bit r: the item of round r starts a k-mer / is kept
-        uint32_t m = 0, np = 0;
-        for (uint32_t seed = 0; seed < 4 && !ok; seed++) {
-            // 1. hash + position, sorted on the hash
-            uint64_t key[EMAX];
+        uint64_t khi[EMAX], klo[EMAX];
+        uint32_t kid[EMAX];
+        auto load = [&]() {
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
                 const uint32_t idx = wbase + r * 64u + lane;
-                key[r] = ~0ull;
+                khi[r] = ~0ull; klo[r] = ~0ull; kid[r] = 0;
                 if (r < E && idx < n) {
-                    const uint64_t a = hk[a0 + idx] & ((1ull << 46) - 1ull);
-                    const uint64_t l = it[a0 + idx].lo;
-                    key[r] = ((uint64_t)hash27(a, l, seed) << 13) | idx;
+                    const BftItem2 x = it[a0 + idx];
+                    khi[r] = hk[a0 + idx] & m46;
+                    klo[r] = x.lo;
+                    kid[r] = x.id;
                 }
             }
-            radix_passes<true, EMAX>(key, keys, cnt, wtot, n, E, 13, 40);  // (ranks from ballots: stable by construction -- the order of equal hashes IS the result here)
-            __syncthreads();
-            // 2. the items in hash order; neighbours: lane - 1 of the round, lane 63 of the round before, the last item of the wavefront before
-            if (tid == 0) s_flag = 0;
+        };
+        // in order over the key AND the ids (equal k-mers must have kept their insertion order -- ascending ids --, which only a stable sort does)?
+        auto out_of_order = [&]() -> int {
+            int off = 0;
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
                 const uint32_t idx = wbase + r * 64u + lane;
-                ihk[r] = 0; ilo[r] = 0; iid[r] = 0;
-                if (r < E && idx < n) {
-                    const uint32_t src = (uint32_t)(key[r] & 0x1FFFu);
-                    ihk[r] = hk[a0 + src] & ((1ull << 46) - 1ull);
-                    const BftItem2 x = it[a0 + src];
-                    ilo[r] = x.lo;
-                    iid[r] = x.id;
-                }
-            }
-            {   // the last item of every wavefront, for the first of the next
-                const uint32_t nw = wbase < n ? min(n - wbase, E * 64u) : 0u;  // items of this wavefront
-                if (nw) {
-                    const uint32_t lr = (nw - 1) / 64u, ll = (nw - 1) % 64u;
-                    uint64_t lk = 0, llo = 0;
-                    uint32_t li = 0, lh = 0;
-#pragma unroll
-                    for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
-                        if (r == lr) { lk = ihk[r]; llo = ilo[r]; li = iid[r]; lh = (uint32_t)(key[r] >> 13); }
-                    if (lane == ll) { wlast_k[wave][0] = lk; wlast_k[wave][1] = llo; wlast_i[wave] = li; wlast_h[wave] = lh; }
-                }
+                if (r < E && idx < n) { buf8[idx] = khi[r]; buf4[idx] = kid[r]; }
             }
             __syncthreads();
-            flags_head = 0;
-            flags_keep = 0;
-            uint32_t nh_w = 0, nk_w = 0;
-            bool coll = false;
+            uint64_t ph[EMAX];
+            uint32_t pi[EMAX];
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
                 const uint32_t idx = wbase + r * 64u + lane;
-                const bool valid = r < E && idx < n;
-                uint64_t pk = shfl64(ihk[r], (int)((lane + 63u) & 63u)), pl = shfl64(ilo[r], (int)((lane + 63u) & 63u));
-                uint32_t pi = __shfl(iid[r], (int)((lane + 63u) & 63u)), ph = __shfl((uint32_t)(key[r] >> 13), (int)((lane + 63u) & 63u));
-                // (lane 0: lane 63 of the round before -- every round but a wavefront's last is full --, or the last item of the wavefront before; the
-                // shuffles by every lane: no lane-dependent control flow around them)
-                const uint64_t qk = r ? shfl64(ihk[r ? r - 1 : 0], 63) : 0ull, ql = r ? shfl64(ilo[r ? r - 1 : 0], 63) : 0ull;
-                const uint32_t qi = r ? __shfl(iid[r ? r - 1 : 0], 63) : 0u, qh = r ? __shfl((uint32_t)(key[r ? r - 1 : 0] >> 13), 63) : 0u;
-                if (lane == 0) {
-                    if (r > 0) { pk = qk; pl = ql; pi = qi; ph = qh; }
-                    else if (wave > 0) { pk = wlast_k[wave - 1][0]; pl = wlast_k[wave - 1][1]; pi = wlast_i[wave - 1]; ph = wlast_h[wave - 1]; }
+                ph[r] = 0; pi[r] = 0;
+                if (r < E && idx < n && idx) { ph[r] = buf8[idx - 1]; pi[r] = buf4[idx - 1]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                if (r < E && idx < n) buf8[idx] = klo[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+                const uint32_t idx = wbase + r * 64u + lane;
+                if (r < E && idx < n && idx) {
+                    const uint64_t pl = buf8[idx - 1];
+                    off |= ph[r] > khi[r] || (ph[r] == khi[r] && (pl > klo[r] || (pl == klo[r] && pi[r] > kid[r])));
                 }
+            }
+            return __syncthreads_or(off);
+        };
+        load();
+        bool sorted = false;
+        if (mode != 1) {
+            radix_passes2<false, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
+            sorted = !(out_of_order() | (mode == 2));
+            if (!sorted) {
+                if (tid == 0) atomicAdd(n_redone, 1u);
+                load();  // (the insertion order again)
+            }
+        }
+        if (!sorted) radix_passes2<true, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
+        // duplicates against the left neighbour; the bucket back in place, sorted
+        if (tid == 0) { s_nk = 0; s_np = 0; }
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (r < E && idx < n) { buf8[idx] = khi[r]; buf4[idx] = kid[r]; }
+        }
+        __syncthreads();
+        uint32_t headm = 0, samem = 0;  // bit r: hk differs from the left neighbour's / (hk, id) equal to it
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (r < E && idx < n) {
                 const bool first = idx == 0;
-                const bool same = valid && !first && pk == ihk[r] && pl == ilo[r];
-                const bool head = valid && !same, keep = valid && (!same || pi != iid[r]);
-                coll |= valid && !first && !same && ph == (uint32_t)(key[r] >> 13);
-                const uint64_t hm = __ballot(head), km = __ballot(keep);
-                hidx[r] = nh_w + (uint32_t)__builtin_popcountll(hm & lt_mask) + (head ? 1u : 0u);  // (inclusive: heads up to and including me, in the wavefront)
-                kidx[r] = nk_w + (uint32_t)__builtin_popcountll(km & lt_mask);                     // (exclusive)
-                nh_w += (uint32_t)__builtin_popcountll(hm);
-                nk_w += (uint32_t)__builtin_popcountll(km);
-                flags_head |= (uint64_t)head << r;
-                flags_keep |= (uint64_t)keep << r;
-            }
-            if (__ballot(coll) && lane == 0) s_flag = 1;
-            if (lane == 0) { w_nh[wave] = nh_w; w_nk[wave] = nk_w; }
-            __syncthreads();
-            ok = s_flag == 0;
-            uint32_t hb = 0, kb = 0;
-            m = 0; np = 0;
-#pragma unroll
-            for (int w = 0; w < FB_WAVES; w++) {
-                if (w < (int)wave) { hb += w_nh[w]; kb += w_nk[w]; }
-                m += w_nh[w];
-                np += w_nk[w];
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < (uint32_t)EMAX; r++) { hidx[r] += hb; kidx[r] += kb; }  // hidx: 1-based index of the item's k-mer
-            __syncthreads();  // (s_flag, w_nh are rewritten by the next seed / bucket)
-        }
-        if (!ok || m > MC) {
-            if (tid == 0) { counts[b] = 0; atomicAdd(fail, 1u); }
-            continue;
-        }
-        // 3. the distinct k-mers to LDS (over the exchange buffer: every wavefront holds its items in registers), ranked by comparison
-        uint64_t* dk = keys;
-#pragma unroll
-        for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
-            if ((flags_head >> r) & 1ull) {
-                dk[2 * (hidx[r] - 1)] = ihk[r];
-                dk[2 * (hidx[r] - 1) + 1] = ilo[r];
-                dkoff[hidx[r] - 1] = kidx[r];
-            }
-        if (tid == 0) dkoff[m] = np;
-        __syncthreads();
-        for (uint32_t i = tid; i < m; i += FB_BLOCK) {
-            const uint64_t a = dk[2 * i], c = dk[2 * i + 1];
-            uint32_t rk = 0;
-            for (uint32_t j = 0; j < m; j++) {
-                const uint64_t x = dk[2 * j], y = dk[2 * j + 1];
-                rk += (x < a || (x == a && y < c)) ? 1u : 0u;
-            }
-            drank[i] = rk;
-        }
-        __syncthreads();
-        // lengths by rank -> starts by rank (a scan over m <= MC values, FB_BLOCK x (MC / FB_BLOCK) each)
-        for (uint32_t i = tid; i < m; i += FB_BLOCK) lenr[drank[i]] = dkoff[i + 1] - dkoff[i];
-        __syncthreads();
-        {
-            constexpr uint32_t PT = MC / FB_BLOCK;
-            uint32_t v[PT], sum = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < PT; q++) {
-                const uint32_t i = tid * PT + q;
-                v[q] = i < m ? lenr[i] : 0u;
-                sum += v[q];
-            }
-            uint32_t inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = __shfl_up(inc, o);
-                if ((int)lane >= o) inc += y;
-            }
-            if (lane == 63) wtot[wave] = inc;
-            __syncthreads();
-            uint32_t run = inc - sum;
-#pragma unroll
-            for (int w = 0; w < FB_WAVES; w++)
-                if (w < (int)wave) run += wtot[w];
-#pragma unroll
-            for (uint32_t q = 0; q < PT; q++) {
-                const uint32_t i = tid * PT + q;
-                if (i < m) lenr[i] = run;
-                run += v[q];
+                const uint64_t ph = first ? 0ull : buf8[idx - 1];
+                const uint32_t pi = first ? 0u : buf4[idx - 1];
+                if (first || ph != khi[r]) headm |= 1u << r;
+                if (!first && ph == khi[r] && pi == kid[r]) samem |= 1u << r;
             }
         }
         __syncthreads();
-        // 4. back in place, in (k-mer, id) order
 #pragma unroll
-        for (uint32_t r = 0; r < (uint32_t)EMAX; r++)
-            if ((flags_keep >> r) & 1ull) {
-                const uint32_t hi = hidx[r] - 1;
-                const uint32_t dest = a0 + lenr[drank[hi]] + (kidx[r] - dkoff[hi]);
-                hk[dest] = ((uint64_t)b << 46) | ihk[r];
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (r < E && idx < n) buf8[idx] = klo[r];
+        }
+        __syncthreads();
+        uint32_t nk = 0, np = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < (uint32_t)EMAX; r++) {
+            const uint32_t idx = wbase + r * 64u + lane;
+            if (r < E && idx < n) {
+                const bool lo_diff = idx == 0 || buf8[idx - 1] != klo[r];
+                const bool head = ((headm >> r) & 1u) || lo_diff;
+                const bool dup = ((samem >> r) & 1u) && !lo_diff;
+                nk += head;
+                np += !dup;
+                hk[a0 + idx] = ((uint64_t)b << 46) | khi[r];
                 BftItem2 x;
-                x.lo = ilo[r];
-                x.id = iid[r];
-                it[dest] = x;
+                x.lo = klo[r];
+                x.id = kid[r];
+                it[a0 + idx] = x;
             }
-        if (tid == 0) counts[b] = ((uint64_t)m << 32) | np;
+        }
+        for (int o = 32; o > 0; o >>= 1) { nk += __shfl_down(nk, o); np += __shfl_down(np, o); }
+        if (lane == 0) { atomicAdd(&s_nk, nk); atomicAdd(&s_np, np); }
+        __syncthreads();
+        if (tid == 0) counts[b] = ((uint64_t)s_nk << 32) | s_np;
         __syncthreads();
     }
 }
 
 // bases[b] = exclusive scan of counts (k-mers << 32 | pairs).  Every bucket places its k-mers (two words: the T-form back from hk and lo), the offset
-// of each k-mer's first genome id, and the genome ids of its pairs (the bucket's first `pairs` items, in (k-mer, id) order).
+// of each k-mer's first genome id, and the genome ids of its distinct pairs (the bucket lies sorted by (k-mer, id): duplicates are neighbours).
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_emit(const uint64_t* __restrict__ hk, const BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, uint32_t nb,
-                                                           const uint64_t* __restrict__ counts, const uint64_t* __restrict__ bases, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off,
-                                                           uint32_t* __restrict__ pg, uint32_t sh, uint32_t nk, uint32_t np) {  // sh = 2k - 64: bits of lo
-    __shared__ uint32_t w_nk[FB_WAVES];
+                                                           const uint64_t* __restrict__ bases, uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off, uint32_t* __restrict__ pg, uint32_t sh,
+                                                           uint32_t nk, uint32_t np) {  // sh = 2k - 64: bits of lo
+    __shared__ uint32_t w_nk[FB_WAVES], w_np[FB_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     if (blockIdx.x == 0 && tid == 0) seg_off[nk] = np;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t a0 = boff[b], n = (uint32_t)counts[b];  // (the kept pairs)
+        const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
         if (n == 0) continue;
         const uint64_t base = bases[b];
-        uint32_t kbase = (uint32_t)(base >> 32);
-        const uint32_t pbase = (uint32_t)base;
+        uint32_t kbase = (uint32_t)(base >> 32), pbase = (uint32_t)base;
         for (uint32_t r0 = 0; r0 < n; r0 += FB_BLOCK) {
             const uint32_t idx = r0 + tid;
             const bool valid = idx < n;
             uint64_t a = 0, l = 0, pa = 0, pl = 0;
-            uint32_t id = 0;
+            uint32_t id = 0, pid = 0;
             if (valid) {
                 a = hk[a0 + idx];
                 const BftItem2 x = it[a0 + idx];
                 l = x.lo;
                 id = x.id;
-                if (idx) { pa = hk[a0 + idx - 1]; pl = it[a0 + idx - 1].lo; }
+                if (idx) { pa = hk[a0 + idx - 1]; const BftItem2 y = it[a0 + idx - 1]; pl = y.lo; pid = y.id; }
             }
-            const bool head = valid && (idx == 0 || a != pa || l != pl);
-            const uint64_t hm = __ballot(head);
-            if (lane == 0) w_nk[wave] = (uint32_t)__builtin_popcountll(hm);
+            const bool head = valid && (idx == 0 || a != pa || l != pl), keep = valid && (head || id != pid);
+            const uint64_t hm = __ballot(head), km = __ballot(keep);
+            if (lane == 0) { w_nk[wave] = (uint32_t)__builtin_popcountll(hm); w_np[wave] = (uint32_t)__builtin_popcountll(km); }
             __syncthreads();
-            uint32_t kb = kbase, tk_all = 0;
+            uint32_t kb = kbase, pb = pbase, tk_all = 0, tp_all = 0;
 #pragma unroll
             for (int w = 0; w < FB_WAVES; w++) {
-                if (w < (int)wave) kb += w_nk[w];
+                if (w < (int)wave) { kb += w_nk[w]; pb += w_np[w]; }
                 tk_all += w_nk[w];
+                tp_all += w_np[w];
             }
-            if (valid) pg[pbase + idx] = id;
+            const uint32_t prank = pb + (uint32_t)__builtin_popcountll(km & lt_mask);
+            if (keep) pg[prank] = id;
             if (head) {
                 const uint32_t q = kb + (uint32_t)__builtin_popcountll(hm & lt_mask);
                 // T-form: hk holds its top 64 bits left-aligned, lo the sh bits below them
-                const uint64_t t0 = sh == 64 ? a : a >> (64 - sh);
-                const uint64_t t1 = sh == 64 ? l : ((a << sh) | l);
-                tk[2ull * q] = t0;
-                tk[2ull * q + 1] = t1;
-                seg_off[q] = pbase + idx;
+                tk[2ull * q] = sh == 64 ? a : a >> (64 - sh);
+                tk[2ull * q + 1] = sh == 64 ? l : ((a << sh) | l);
+                seg_off[q] = prank;
             }
             kbase += tk_all;
+            pbase += tp_all;
             __syncthreads();
         }
     }
@@ -773,35 +1021,54 @@ uint32_t bft_front2_bucket_capacity(void) { return FB_BLOCK * 32; }
 
 // the two-word front end behind the split (items grouped by the top 18 bits of hk): see k_bucket2_sort
 int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t* d_boff, uint32_t nb, int k, hipStream_t s, DevBuf& tk, DevBuf& seg_off, DevBuf& pg, uint64_t& nk, uint64_t& np,
-                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done) {
+                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone) {
     *done = false;
     BftItem2* d_it = (BftItem2*)d_items;
-    PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets that failed
+    PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets that failed, [3] buckets sorted again
     if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (front end counts)");
-    DevBuf counts, bases, tmp, fail;
+    DevBuf counts, bases, tmp, fail, redone, lists, n_lists;
     CK(counts.alloc(((uint64_t)nb + 1) * 8));
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
     CK(fail.alloc_zero(4, s));
+    CK(redone.alloc_zero(4, s));
+    CK(lists.alloc((size_t)FB2_CLASSES * nb * 4));
+    CK(n_lists.alloc_zero(32, s));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
+    const dim3 block(FB_BLOCK);
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
-    HIPCK(hipStreamSynchronize(s));
+    hipEvent_t ev;
+    HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, s);
+    // (the size of the largest bucket travels to the host while the lists are made and the buckets of a wavefront each -- all of them, usually -- are sorted)
+    hipLaunchKernelGGL(k_bucket2_lists, dim3((nb + FB_BLOCK - 1) / FB_BLOCK), block, 0, s, d_boff, nb, lists.as<uint32_t>(), n_lists.as<uint32_t>(), counts.as<uint64_t>());
+    const uint32_t sh = (uint32_t)(2 * k - 64);
+#define FB2_WAVE(EW_, CLS, GRID)                                                                                                                                                \
+    hipLaunchKernelGGL(k_bucket2_sort_wave<EW_>, dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
+                       g_rank_mode, redone.as<uint32_t>())
+#define FB2_LAUNCH(EM, CLS, GRID)                                                                                                                                           \
+    hipLaunchKernelGGL(k_bucket2_sort<EM>, dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
+                       g_rank_mode, redone.as<uint32_t>(), fail.as<uint32_t>())
+    hipLaunchKernelGGL(k_bucket2_tiny, dim3(256u * 8u), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)5 * nb, n_lists.as<uint32_t>() + 5, counts.as<uint64_t>());
+    FB2_WAVE(8, 0, 256u * 8u);
+    FB2_WAVE(16, 1, 256u * 4u);
+    FB2_WAVE(32, 2, 256u * 2u);
+    if (e == hipSuccess) e = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    HIPCK(e);
     const uint32_t mx = (uint32_t)pin.p[0];
     *max_bucket = mx;
     if (mx > FB_BLOCK * 32) return 0;
-    const dim3 block(FB_BLOCK);
-    // by size: the variants differ in the items a thread holds (registers, LDS, workgroups per CU)
-    hipLaunchKernelGGL(k_bucket2_sort<8>, dim3(std::min<uint32_t>(nb, 256u * 8u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), 0u, FB_BLOCK * 8u);
-    if (mx > FB_BLOCK * 8u)
-        hipLaunchKernelGGL(k_bucket2_sort<16>, dim3(std::min<uint32_t>(nb, 256u * 8u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), FB_BLOCK * 8u + 1u,
-                           FB_BLOCK * 16u);
-    if (mx > FB_BLOCK * 16u)
-        hipLaunchKernelGGL(k_bucket2_sort<32>, dim3(std::min<uint32_t>(nb, 256u * 4u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), fail.as<uint32_t>(), FB_BLOCK * 16u + 1u,
-                           FB_BLOCK * 32u);
+    if (mx > 2048u) FB2_LAUNCH(16, 3, 256u * 4u);
+    if (mx > 4096u) FB2_LAUNCH(32, 4, 256u * 2u);
+#undef FB2_WAVE
+#undef FB2_LAUNCH
     CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, fail.as<uint32_t>(), pin.p + 1);
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, redone.as<uint32_t>(), pin.p + 3);
     HIPCK(hipGetLastError());
-    bft_stage("two-word buckets: grouped by hash, distinct k-mers ranked", (double)n * 2 * 20, s);
+    bft_stage("two-word buckets: sorts in LDS (+ scan of the counts)", (double)n * 2 * 20, s);
     HIPCK(hipStreamSynchronize(s));
+    if (n_redone) *n_redone = (uint32_t)pin.p[3];
     if (pin.p[2] != 0) return 0;  // (a bucket beyond this front end: the caller sorts device-wide)
     const uint64_t total = pin.p[1];
     nk = total >> 32;
@@ -809,10 +1076,10 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     CK(tk.alloc(nk * 16));
     CK(seg_off.alloc((nk + 1) * 4));
     CK(pg.alloc(np * 4));
-    hipLaunchKernelGGL(k_bucket2_emit, dim3(std::min<uint32_t>(nb, 256u * 16u)), block, 0, s, d_hk, d_it, d_boff, nb, counts.as<uint64_t>(), bases.as<uint64_t>(), tk.as<uint64_t>(),
-                       seg_off.as<uint32_t>(), pg.as<uint32_t>(), (uint32_t)(2 * k - 64), (uint32_t)nk, (uint32_t)np);
+    hipLaunchKernelGGL(k_bucket2_emit, dim3(std::min<uint32_t>(nb, 256u * 16u)), block, 0, s, d_hk, d_it, d_boff, nb, bases.as<uint64_t>(), tk.as<uint64_t>(), seg_off.as<uint32_t>(),
+                       pg.as<uint32_t>(), sh, (uint32_t)nk, (uint32_t)np);
     HIPCK(hipGetLastError());
-    bft_stage("two-word buckets: emit (k-mers, offsets, genome ids)", (double)np * 24 + (double)nk * 20, s);
+    bft_stage("two-word buckets: emit (k-mers, offsets, genome ids)", (double)n * 20 + (double)np * 4 + (double)nk * 20, s);
     *done = true;
     return 0;
 }

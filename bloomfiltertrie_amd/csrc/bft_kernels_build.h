@@ -132,10 +132,16 @@ __global__ void k_msd_bounds(const uint64_t* __restrict__ c, uint64_t n, uint32_
     off[r] = (uint32_t)lo;
 }
 __global__ void k_msd_max(const uint32_t* __restrict__ off, uint32_t nb, uint32_t* __restrict__ max_bucket) {
+    __shared__ uint32_t wm[16];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t m = r < nb ? off[r + 1] - off[r] : 0u;
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o));
-    if ((threadIdx.x & 63u) == 0 && m) atomicMax(max_bucket, m);
+    if ((threadIdx.x & 63u) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // (one atomic per workgroup: 4096 on one word took 47 us)
+        for (uint32_t w = 1; w < (blockDim.x >> 6); w++) m = max(m, wm[w]);
+        if (m) atomicMax(max_bucket, m);
+    }
 }
 __global__ void k_scatter_c(const uint64_t* __restrict__ c, uint32_t gb, uint64_t n, const uint64_t* __restrict__ pos, uint32_t* __restrict__ pg,
                             uint64_t* __restrict__ tk, uint32_t* __restrict__ seg_off) {
