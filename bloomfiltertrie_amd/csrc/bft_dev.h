@@ -194,4 +194,4 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
 // (the arrays may have been reordered inside their buckets); *n_redone as bft_front_buckets'.
 uint32_t bft_front2_bucket_capacity(void);
 int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t* d_boff, uint32_t nb, int k, hipStream_t s, DevBuf& tk, DevBuf& seg_off, DevBuf& pg, uint64_t& nk, uint64_t& np,
-                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone);
+                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone, uint32_t max_gid);

@@ -612,7 +612,8 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_tiny(uint64_t* __restrict_
 // ONE WAVEFRONT per bucket of up to 64 EW items: no barrier anywhere (the LDS operations of a wavefront are in order), the items in registers
 // (five per item), per pass: ranks from one LDS atomic per item, a 512-digit scan by shuffles, the exchange word by word through 8 bytes per
 // item of LDS.  (With a workgroup per bucket the thirteen passes of k = 63 cost seven barriers each: 12.4 ms for config 5's 19 x 10^3 buckets.)
-template <int EW>
+// PACK: genome ids below 2^18 ride in the 18 free bits on top of hk's 46: four registers and two exchanged words per item instead of five and three
+template <int EW, bool PACK>
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone) {
     __shared__ uint64_t buf_all[FB_WAVES][64 * EW];
@@ -627,18 +628,20 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
         const uint32_t b = list[li], a0 = boff[b], n = boff[b + 1] - a0;
         const uint32_t E = (n + 63u) / 64u;  // rounds: slot (round r, lane l) = item r 64 + l of the bucket
         uint64_t khi[EW], klo[EW];
-        uint32_t kid[EW];
+        uint32_t kid[PACK ? 1 : EW];
         bool sorted = false;
         for (int attempt = (mode == 1 ? 1 : 0); attempt < 2 && !sorted; attempt++) {  // 0: ranks from LDS atomics, checked; 1: from ballots
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                 const uint32_t idx = r * 64u + lane;
-                khi[r] = ~0ull; klo[r] = ~0ull; kid[r] = 0;
+                khi[r] = ~0ull; klo[r] = ~0ull;
+                if (!PACK) kid[r] = 0;
                 if (r < E && idx < n) {
                     const BftItem2 x = it[a0 + idx];
                     khi[r] = hk[a0 + idx] & m46;
                     klo[r] = x.lo;
-                    kid[r] = x.id;
+                    if (PACK) khi[r] |= (uint64_t)x.id << 46;
+                    else kid[r] = x.id;
                 }
             }
             const uint32_t np_lo = (sh + FB_DBITS - 1) / FB_DBITS, np_hi = (46u + FB_DBITS - 1) / FB_DBITS;
@@ -696,17 +699,17 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                     if (r < E && r * 64u + lane < n) rank[r] += cnt[(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask];
                 // the exchange, word by word through the wavefront's 8 bytes per item
 #pragma unroll
-                for (int f = 0; f < 3; f++) {
+                for (int f = 0; f < (PACK ? 2 : 3); f++) {
 #pragma unroll
                     for (uint32_t r = 0; r < (uint32_t)EW; r++)
-                        if (r < E && r * 64u + lane < n) buf[rank[r]] = f == 0 ? khi[r] : f == 1 ? klo[r] : (uint64_t)kid[r];
+                        if (r < E && r * 64u + lane < n) buf[rank[r]] = f == 0 ? khi[r] : f == 1 ? klo[r] : (uint64_t)kid[PACK ? 0 : r];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
                     for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                         const uint32_t idx = r * 64u + lane;
                         if (r < E && idx < n) {
                             const uint64_t v = buf[idx];
-                            if (f == 0) khi[r] = v; else if (f == 1) klo[r] = v; else kid[r] = (uint32_t)v;
+                            if (f == 0) khi[r] = v; else if (f == 1) klo[r] = v; else kid[PACK ? 0 : r] = (uint32_t)v;
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -721,13 +724,18 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                     const uint32_t idx = r * 64u + lane;
                     uint64_t ph = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)khi[r], (int)((lane + 63u) & 63u));
                     uint64_t pl = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)klo[r], (int)((lane + 63u) & 63u));
-                    uint32_t pi = __shfl(kid[r], (int)((lane + 63u) & 63u));
+                    uint32_t pi = PACK ? 0u : __shfl(kid[PACK ? 0 : r], (int)((lane + 63u) & 63u));
                     const uint32_t rp = r ? r - 1 : 0;
                     const uint64_t qh = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)khi[rp], 63);
                     const uint64_t ql = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)klo[rp], 63);
-                    const uint32_t qi = __shfl(kid[rp], 63);
+                    const uint32_t qi = PACK ? 0u : __shfl(kid[PACK ? 0 : rp], 63);
                     if (lane == 0) { ph = qh; pl = ql; pi = qi; }
-                    if (r < E && idx < n && idx) off |= ph > khi[r] || (ph == khi[r] && (pl > klo[r] || (pl == klo[r] && pi > kid[r])));
+                    if (r < E && idx < n && idx) {
+                        // (PACK: the id sits above the 46 key bits of hk: the order is (hk46, lo, id))
+                        const uint64_t a46 = khi[r] & m46, p46 = ph & m46;
+                        const uint32_t ai = PACK ? (uint32_t)(khi[r] >> 46) : kid[PACK ? 0 : r], bi = PACK ? (uint32_t)(ph >> 46) : pi;
+                        off |= p46 > a46 || (p46 == a46 && (pl > klo[r] || (pl == klo[r] && bi > ai)));
+                    }
                 }
                 sorted = __ballot(off != 0) == 0ull;
                 if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
@@ -739,20 +747,22 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
             const uint32_t idx = r * 64u + lane;
             uint64_t ph = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)khi[r], (int)((lane + 63u) & 63u));
             uint64_t pl = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[r] >> 32), (int)((lane + 63u) & 63u)) << 32) | (uint32_t)__shfl((uint32_t)klo[r], (int)((lane + 63u) & 63u));
-            uint32_t pi = __shfl(kid[r], (int)((lane + 63u) & 63u));
+            uint32_t pi = PACK ? 0u : __shfl(kid[PACK ? 0 : r], (int)((lane + 63u) & 63u));
             const uint32_t rp = r ? r - 1 : 0;
             const uint64_t qh = ((uint64_t)(uint32_t)__shfl((uint32_t)(khi[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)khi[rp], 63);
             const uint64_t ql = ((uint64_t)(uint32_t)__shfl((uint32_t)(klo[rp] >> 32), 63) << 32) | (uint32_t)__shfl((uint32_t)klo[rp], 63);
-            const uint32_t qi = __shfl(kid[rp], 63);
+            const uint32_t qi = PACK ? 0u : __shfl(kid[PACK ? 0 : rp], 63);
             if (lane == 0) { ph = qh; pl = ql; pi = qi; }
             if (r < E && idx < n) {
-                const bool head = idx == 0 || ph != khi[r] || pl != klo[r];
+                const uint64_t a46 = khi[r] & m46;
+                const uint32_t ai = PACK ? (uint32_t)(khi[r] >> 46) : kid[PACK ? 0 : r], bi = PACK ? (uint32_t)(ph >> 46) : pi;
+                const bool head = idx == 0 || (ph & m46) != a46 || pl != klo[r];
                 nk += head;
-                np += head || pi != kid[r];
-                hk[a0 + idx] = ((uint64_t)b << 46) | khi[r];
+                np += head || bi != ai;
+                hk[a0 + idx] = ((uint64_t)b << 46) | a46;
                 BftItem2 x;
                 x.lo = klo[r];
-                x.id = kid[r];
+                x.id = ai;
                 it[a0 + idx] = x;
             }
         }
@@ -1021,8 +1031,9 @@ uint32_t bft_front2_bucket_capacity(void) { return FB_BLOCK * 32; }
 
 // the two-word front end behind the split (items grouped by the top 18 bits of hk): see k_bucket2_sort
 int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t* d_boff, uint32_t nb, int k, hipStream_t s, DevBuf& tk, DevBuf& seg_off, DevBuf& pg, uint64_t& nk, uint64_t& np,
-                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone) {
+                       const uint32_t* d_max_bucket, uint32_t* max_bucket, bool* done, uint32_t* n_redone, uint32_t max_gid) {
     *done = false;
+    const bool pack = max_gid < (1u << 18);  // (ids that fit the 18 free bits above hk's 46: k_bucket2_sort_wave)
     BftItem2* d_it = (BftItem2*)d_items;
     PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets that failed, [3] buckets sorted again
     if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (front end counts)");
@@ -1043,8 +1054,12 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     hipLaunchKernelGGL(k_bucket2_lists, dim3((nb + FB_BLOCK - 1) / FB_BLOCK), block, 0, s, d_boff, nb, lists.as<uint32_t>(), n_lists.as<uint32_t>(), counts.as<uint64_t>());
     const uint32_t sh = (uint32_t)(2 * k - 64);
 #define FB2_WAVE(EW_, CLS, GRID)                                                                                                                                                \
-    hipLaunchKernelGGL(k_bucket2_sort_wave<EW_>, dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
-                       g_rank_mode, redone.as<uint32_t>())
+    do {                                                                                                                                                                       \
+        if (pack) hipLaunchKernelGGL((k_bucket2_sort_wave<EW_, true>), dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, \
+                                     counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>());                                                                               \
+        else hipLaunchKernelGGL((k_bucket2_sort_wave<EW_, false>), dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh,   \
+                                counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>());                                                                                    \
+    } while (0)
 #define FB2_LAUNCH(EM, CLS, GRID)                                                                                                                                           \
     hipLaunchKernelGGL(k_bucket2_sort<EM>, dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
                        g_rank_mode, redone.as<uint32_t>(), fail.as<uint32_t>())

@@ -1579,7 +1579,7 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             hk2.release();
             items2.release();
             uint32_t mx = 0;
-            CK(bft_front2_buckets(hk.as<uint64_t>(), items.p, total, boff.as<uint32_t>(), 1u << 18, h->k, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done2, &h->front_redone));
+            CK(bft_front2_buckets(hk.as<uint64_t>(), items.p, total, boff.as<uint32_t>(), 1u << 18, h->k, h->stream, tk, seg_off, npg, nk, np, maxb.as<uint32_t>(), &mx, &done2, &h->front_redone, h->max_gid_seen));
             h->msd_max_bucket = mx;
         }
         if (!done2) {

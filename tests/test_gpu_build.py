@@ -795,11 +795,14 @@ def test_closed_handles_leave_their_blocks_in_the_cache():
     assert (S.from_bits(t.query_presence(q), len(q)) == answers[0]).all()
     _, off, ids = t.query_colors(km[:3])  # (k-mer 0 is in both genomes, 1 and 2 in the first only)
     assert off.tolist() == [0, 2, 3, 4] and ids[:4].tolist() == [0, 1, 0, 0]
-    t.close()@pytest.mark.gpu
+    t.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,ngen,glen,rate", [(36, 40, 6000, 0.01), (45, 300, 700, 0.01), (63, 1200, 260, 0.01), (63, 24, 20000, 0.2), (64, 64, 3000, 0.02)])
 def test_two_word_front_end_builds_the_same_image(k, ngen, glen, rate):
-    """Two-word keys (33 <= k <= 64) with ascending genome ids: the root-prefix split on the top 18 T bits, then every bucket grouped by a
-    hash of its key bits and only its distinct k-mers ordered (bft_front.hip: k_bucket2_sort; "build_msd" 2 forces it at this size) against
+    """Two-word keys (33 <= k <= 64) with ascending genome ids: the root-prefix split on the top 18 T bits, then every bucket on its own in LDS
+    over the two words (bft_front.hip: k_bucket2_tiny / k_bucket2_sort_wave / k_bucket2_sort by size; "build_msd" 2 forces it at this size) against
     the device-wide sort of every word ("build_msd" 0): every array of the image, the colour sets and the extraction are identical --
     buckets of one locus with hundreds of copies (many genomes of a short ancestor), buckets of a few all-distinct k-mers (few genomes, many
     SNPs), duplicate pairs, and an incremental build on top."""
