@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <condition_variable>
 #include <chrono>
 #include <deque>
 #include <functional>
@@ -31,6 +33,24 @@
 
 #include "bft_index.h"
 #include "bft_walk.h"
+
+// the disposer threads in flight (bft_file.h)
+static std::mutex g_disp_mu;
+static std::condition_variable g_disp_cv;
+static int g_disp_n = 0;
+void bft_dispose_begin(void) {
+    std::lock_guard<std::mutex> lk(g_disp_mu);
+    g_disp_n++;
+}
+void bft_dispose_end(void) {
+    std::lock_guard<std::mutex> lk(g_disp_mu);
+    if (--g_disp_n == 0) g_disp_cv.notify_all();
+}
+void bft_dispose_drain(void) {
+    std::unique_lock<std::mutex> lk(g_disp_mu);
+    g_disp_cv.wait(lk, [] { return g_disp_n == 0; });
+}
+__attribute__((destructor)) static void bft_dispose_at_unload(void) { bft_dispose_drain(); }
 
 namespace {
 
@@ -56,24 +76,41 @@ unsigned io_threads() {
     const unsigned hc = std::thread::hardware_concurrency();
     return std::max(1u, std::min(hc ? hc : 8u, 32u));
 }
-// jobs 0 .. n-1 over the threads (the calling thread takes part)
+// joins what it holds when it goes out of scope, however that happens (an exception on the calling thread must not meet joinable threads)
+struct ThreadJoiner {
+    std::vector<std::thread> th;
+    ~ThreadJoiner() {
+        for (std::thread& x : th)
+            if (x.joinable()) x.join();
+    }
+};
+// jobs 0 .. n-1 over the threads (the calling thread takes part).  An exception inside a job -- an allocation a hostile file asks for -- stops the
+// hand-out of jobs and is thrown again, as std::bad_alloc, on the CALLING thread once every worker is back: the caller's try / catch sees it, and
+// nothing reaches std::terminate.
 template <class F>
 void parallel_jobs(size_t n, F f) {
     const unsigned nt = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, n));
     std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
     auto work = [&](unsigned t) {
-        for (;;) {
-            const size_t j = next.fetch_add(1);
-            if (j >= n) break;
-            f(j, t);
+        try {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= n || failed.load(std::memory_order_relaxed)) break;
+                f(j, t);
+            }
+        } catch (...) {
+            failed = true;
         }
     };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) {
-        try { th.emplace_back(work, t); } catch (...) { break; }  // (no thread to be had: the others do its share)
+    {
+        ThreadJoiner pool;
+        for (unsigned t = 1; t < nt; t++) {
+            try { pool.th.emplace_back(work, t); } catch (...) { break; }  // (no thread to be had: the others do its share)
+        }
+        work(0);
     }
-    work(0);
-    for (std::thread& x : th) x.join();
+    if (failed) throw std::bad_alloc();
 }
 
 
@@ -521,16 +558,30 @@ struct ReadStateGuard {
     ReadState* p;
     ~ReadStateGuard() {
         ReadState* q = p;
+        bft_dispose_begin();
         try {
-            std::thread([q] { delete q; }).detach();
+            std::thread([q] { delete q; bft_dispose_end(); }).detach();
         } catch (...) {
             delete q;
+            bft_dispose_end();
         }
     }
 };
 }  // namespace
 
+static bool file_read_impl(const char* path, BftFileContent& out, std::string& err);
+// (an allocation an untrusted file asks for is an I/O error of the call, on whichever thread it fails: parallel_jobs hands the workers' to this one)
 bool bft_file_read(const char* path, BftFileContent& out, std::string& err) {
+    try {
+        return file_read_impl(path, out, err);
+    } catch (const std::bad_alloc&) {
+        err = "out of memory while reading the file";
+    } catch (const std::exception& e) {
+        err = e.what();
+    }
+    return false;
+}
+static bool file_read_impl(const char* path, BftFileContent& out, std::string& err) {
     IoTrace tr;
     out = BftFileContent();
     ReadStateGuard guard{new ReadState};
@@ -882,7 +933,18 @@ struct Writer {
 
 void bft_annot_encode(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out) { annot_encode(ids, n, out); }
 
+static bool file_write_impl(const char* path, const BftHostImage& im, std::string& err);
 bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) {
+    try {
+        return file_write_impl(path, im, err);
+    } catch (const std::bad_alloc&) {
+        err = "out of memory while writing the file";
+    } catch (const std::exception& e) {
+        err = e.what();
+    }
+    return false;
+}
+static bool file_write_impl(const char* path, const BftHostImage& im, std::string& err) {
     IoTrace tr;
     AnnotCache ann;
     ann.build(im);
@@ -925,42 +987,48 @@ bool bft_file_write(const char* path, const BftHostImage& im, std::string& err) 
     for (size_t i = 0; i < nparts; i++) ready[i].store(1);
     for (size_t j = 0; j < njobs; j++) ready[parts.job_buf[j]].store(0);
     std::atomic<size_t> next{0};
-    auto work = [&](unsigned t) {
-        Writer& x = *ws[t];
-        for (;;) {
-            const size_t j = next.fetch_add(1);
-            if (j >= njobs) break;
+    // (a job that throws -- an allocation failure -- marks its part ready and the file bad: the streaming thread never waits for it, and nothing
+    // leaves a worker as an exception)
+    auto one_job = [&](Writer& x, size_t j) {
+        try {
             x.out = &parts.bufs[parts.job_buf[j]];
             parts.jobs[j](x);
             if (x.err) bad = true;
-            ready[parts.job_buf[j]].store(1, std::memory_order_release);
+        } catch (...) {
+            bad = true;
+        }
+        ready[parts.job_buf[j]].store(1, std::memory_order_release);
+    };
+    auto work = [&](unsigned t) {
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= njobs) break;
+            one_job(*ws[t], j);
         }
     };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) {
-        try { th.emplace_back(work, t); } catch (...) { break; }
-    }
-    FILE* f = fopen(path, "wb");
-    bool ok = f != nullptr;
-    if (th.empty()) work(0);  // (no thread to be had: fill first, then write)
-    for (size_t i = 0; i < nparts && ok; i++) {
-        while (!ready[i].load(std::memory_order_acquire)) {
-            // (help with a job instead of spinning, if any is left)
-            const size_t j = next.fetch_add(1);
-            if (j < njobs) {
-                Writer& x = *ws[0];
-                x.out = &parts.bufs[parts.job_buf[j]];
-                parts.jobs[j](x);
-                if (x.err) bad = true;
-                ready[parts.job_buf[j]].store(1, std::memory_order_release);
-            } else
-                std::this_thread::yield();
+    FILE* f = nullptr;
+    bool ok = false;
+    {
+        ThreadJoiner pool;
+        for (unsigned t = 1; t < nt; t++) {
+            try { pool.th.emplace_back(work, t); } catch (...) { break; }
         }
-        std::vector<uint8_t>& b = parts.bufs[i];
-        if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
-        std::vector<uint8_t>().swap(b);  // (written: its memory goes back while the rest is still being filled)
+        f = fopen(path, "wb");
+        ok = f != nullptr;
+        if (pool.th.empty()) work(0);  // (no thread to be had: fill first, then write)
+        for (size_t i = 0; i < nparts && ok && !bad; i++) {
+            while (!ready[i].load(std::memory_order_acquire)) {
+                // (help with a job instead of spinning, if any is left)
+                const size_t j = next.fetch_add(1);
+                if (j < njobs) one_job(*ws[0], j);
+                else std::this_thread::yield();
+            }
+            std::vector<uint8_t>& b = parts.bufs[i];
+            if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
+            std::vector<uint8_t>().swap(b);  // (written: its memory goes back while the rest is still being filled)
+        }
+        if (!ok || bad) next.store(njobs);  // (nothing more to fill)
     }
-    for (std::thread& x : th) x.join();
     if (f && fclose(f) != 0) ok = false;
     tr.mark("write: parts filled by the pool and streamed to the file in order");
     if (!f) { err = std::string("cannot create ") + path; return false; }

@@ -21,16 +21,23 @@ struct BftFileContent {  // what a .bft holds, as the GPU build wants it
 };
 bool bft_file_read(const char* path, BftFileContent& out, std::string& err);
 
-// Gigabytes of host vectors are given back by a detached thread: unmapping them costs the caller 0.1 s per gigabyte (config 3: a third of the
-// load, a fifth of the write) and nothing depends on it.  `obj` is left empty (moved from).
+// Gigabytes of host vectors are given back by a thread of their own: unmapping them costs the caller 0.1 s per gigabyte (config 3: a third of the
+// load, a fifth of the write) and nothing depends on it.  `obj` is left empty (moved from).  The threads are counted: bft_dispose_drain() -- called
+// when the library is unloaded or the process exits (a destructor in bft_file.cpp) and available to a caller that wants the memory back now -- waits
+// for them, so that none is still running in code that is being unmapped or beside the static destructors.
+void bft_dispose_begin(void);
+void bft_dispose_end(void);
+void bft_dispose_drain(void);
 template <class T>
 void bft_dispose_async(T& obj) {
     T* p = new (std::nothrow) T(std::move(obj));
     if (!p) return;  // (obj keeps its content and is destroyed by its owner)
+    bft_dispose_begin();
     try {
-        std::thread([p] { delete p; }).detach();
+        std::thread([p] { delete p; bft_dispose_end(); }).detach();
     } catch (...) {
         delete p;
+        bft_dispose_end();
     }
 }
 

@@ -385,6 +385,7 @@ struct bft_gpu {
     uint64_t sq_units = 0;
     DevBuf qc_cs, qc_tmp;            // scratch of the resident colour-list queries: colour-set id per k-mer, the scan's temporary (grown, never shrunk)
     hipStream_t qc_stream = nullptr;
+    hipEvent_t qc_ev = nullptr;  // where the last use of the scratch ends (the stream it ran on is the caller's: it may be gone by the next call)
     bool qc_used = false;  // bound on the blocks of k-mer positions the sequence kernel deals out (claim_counters)
     bool inject_build_failure = false;  // test hook: the next bft_gpu_build fails right before its commit point (one shot)
     bool opt_build_stages = false;      // "build_stages": the next builds record GPU time and bytes per stage (bft_gpu_build_stages)
@@ -535,6 +536,7 @@ extern "C" void bft_gpu_free(bft_gpu* h) {
     h->free_ev.clear();
     for (auto& e : h->ext) (void)hipEventDestroy(e.ev);
     h->ext.clear();
+    if (h->qc_ev) { (void)hipEventDestroy(h->qc_ev); h->qc_ev = nullptr; }
     const hipStream_t s = h->stream;
     if (s) (void)hipStreamSynchronize(s);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
@@ -1939,7 +1941,15 @@ static void ensure_claim_counters(bft_gpu* h) {
 // (bft_gpu_build_time, entry 20: nothing is silent).
 static BftClaimCtr claim_counters(bft_gpu* h, hipStream_t s, uint64_t n, uint64_t units) {
     static const bool env_off = getenv("BFT_GPU_QUERY_DYNAMIC") && atoi(getenv("BFT_GPU_QUERY_DYNAMIC")) == 0;
+    h->kh_ctr_pending = -1;  // (a launch that failed between claim_counters and claims_launched must not leave its slot behind for the next one)
     if (!h->opt_query_dynamic || env_off || n < h->opt_query_dynamic_min || !h->kh_ctr) return BftClaimCtr{nullptr, 0};
+    {   // a launch being recorded into a graph gets static rounds: `base` is a kernel argument, frozen at capture time, and from the second replay on the
+        // counter stands above it -- every workgroup would answer its first round only (the counter cannot be reset on the device without giving up
+        // the property that nothing an unfinished launch leaves behind can hurt the next one)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) (void)hipGetLastError();
+        else if (st != hipStreamCaptureStatusNone) return BftClaimCtr{nullptr, 0};
+    }
     int slot = -1;
     for (int i = 0; i < h->kh_ctr_used; i++)
         if (h->kh_ctr_stream[i] == s) slot = i;
@@ -2282,7 +2292,11 @@ static int query_rows(bft_gpu* h, const uint8_t* kmers, uint64_t m, DevBuf& dk, 
 // from the dictionary, and the wavefronts stream the ids out.  No row, no sorted table ("compact_table" stays), no host round trip.
 static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
                        hipStream_t s, bool fill) {
-    if (h->qc_used && h->qc_stream != s) HIPCK(hipStreamSynchronize(h->qc_stream));  // (the scratch belongs to the handle: one stream at a time)
+    if (h->qc_used && h->qc_stream != s) {  // (the scratch belongs to the handle: one stream at a time -- behind an event of the handle's own, not the other stream)
+        const hipError_t e = h->qc_ev ? hipEventSynchronize(h->qc_ev) : hipDeviceSynchronize();
+        h->qc_stream = s;
+        HIPCK(e);
+    }
     const size_t tb = ((n + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
     if (h->qc_cs.bytes < n * 4 || h->qc_tmp.bytes < tb) {
         if (h->qc_used) HIPCK(hipStreamSynchronize(s));
@@ -2304,6 +2318,8 @@ static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
         hipLaunchKernelGGL(k_color_fill_cs, dim3(grid_for((n + 255) / 256)), dim3(256), 0, s, d_cs, h->im.cs_off, h->im.cs_ids, h->im.cs_w, d_offsets, n, ids_cap, d_ids, d_needed);
         HIPCK(hipGetLastError());
     }
+    if (!h->qc_ev && hipEventCreateWithFlags(&h->qc_ev, hipEventDisableTiming) != hipSuccess) { h->qc_ev = nullptr; (void)hipGetLastError(); }
+    if (h->qc_ev && hipEventRecord(h->qc_ev, s) != hipSuccess) (void)hipGetLastError();
     return 0;
 }
 

@@ -183,8 +183,9 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   (a fault, a killed process sharing nothing) cannot make a later one skip blocks -- nothing is reset by anyone (round 5; "test_stale_claims" is
  *   the test hook that leaves the counters where such a launch would).  A handle keeps counters for 32 streams; queried on more, the least recently
  *   used slot moves to the new stream once its last launch has completed, else that launch runs static and is counted (bft_gpu_build_time entry 20).
- *   0: always static.  Launches of ONE handle on ONE stream must not run concurrently (two host threads, or a captured graph replayed while a direct
- *   launch is in flight): they would share a range -- use one stream per thread, as for any stream-ordered API.
+ *   0: always static.  Launches of ONE handle on ONE stream must not run concurrently (two host threads): they would share a range -- use one stream
+ *   per thread, as for any stream-ordered API.  A *_dev call recorded into a HIP graph (its stream is being captured) runs static rounds: a range's
+ *   start is a kernel argument, which a replay cannot move (tests/test_gpu_parity.py::test_captured_queries_replay).
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),

@@ -958,3 +958,41 @@ def test_resident_id_lists_through_the_kmer_hash(k, ngen):
             assert (hb == obits).all() and (hoff == ooff).all() and (hids == oids).all()
             assert t.footprint()["kmer_table"] <= 8
     t.close()
+
+
+@pytest.mark.gpu
+def test_captured_queries_replay():
+    """A *_dev presence query recorded into a HIP graph and replayed: every replay answers every block (claim counters hand a launch the start of its
+    range as a kernel argument, which a replay cannot move: a launch on a stream that is being captured runs static rounds), direct launches on the same
+    stream in between do not disturb it, and the batch is large enough for the claimed rounds to be on (2^16 k-mers and more)."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k = 27
+    km = S.distinct(S.kmers_of(S.random_genome(300000, 23), k))
+    rng = np.random.default_rng(5)
+    q = np.ascontiguousarray(np.concatenate([km[rng.integers(0, len(km), 150000)], S.snp_mutants(km[rng.integers(0, len(km), 150000)], k, 9)]))
+    want = S.member(q, km)
+    with BFT(k) as t:
+        t.insert_kmers(km, 0)
+        t.build()
+        dev = torch.device("cuda", 0)
+        dq = torch.from_numpy(q).to(dev)
+        bits = torch.zeros((len(q) + 63) // 64 * 8, dtype=torch.uint8, device=dev)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            t.query_presence_dev(dq.data_ptr(), len(q), bits.data_ptr(), s.cuda_stream)  # (a direct launch first: the stream's counter has moved)
+        s.synchronize()
+        assert (S.from_bits(bits.cpu().numpy(), len(q)) == want).all()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            t.query_presence_dev(dq.data_ptr(), len(q), bits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            bits.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert (S.from_bits(bits.cpu().numpy(), len(q)) == want).all(), rep
+            with torch.cuda.stream(s):  # a direct launch between the replays
+                t.query_presence_dev(dq.data_ptr(), len(q), bits.data_ptr(), s.cuda_stream)
+            s.synchronize()
+            assert (S.from_bits(bits.cpu().numpy(), len(q)) == want).all()
+
