@@ -52,6 +52,18 @@ GATHER_CEILING_SRC = "profiles/r04/microbench_gather.jsonl (indep4/8, 64 MiB tab
 PMC_FALLBACK = "r05/pmc_query.json"
 
 
+def cpu_model():
+    """the host's CPU as /proc/cpuinfo names it (state nproc and CPU model beside the CPU baseline)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +289,21 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         parity_ok = bool(okt.item())
 
+    # ---- the other sharded queries under the same process group (only in the dist-path check's child: `--force-dist`): colour rows and branching,
+    # answered shard by shard on the replicated handle, gathered, and compared with the handle's own unsharded answers ----
+    dist_extra = None
+    if args.force_dist:
+        from bloomfiltertrie_amd.dist import query_branching_sharded, query_color_rows_sharded
+        sample = np.ascontiguousarray(dq[: min(nq, 200_000)].cpu().numpy())
+        cb, crows = query_color_rows_sharded(bft, sample, genomes)
+        hb, hrows = bft.query_color_rows(sample)
+        nb8 = (len(sample) + 7) // 8
+        ok_rows = bool((cb[:nb8] == np.asarray(hb)[:nb8]).all() and (crows == np.asarray(hrows).reshape(crows.shape)).all())
+        bb, bcounts = query_branching_sharded(bft, sample)
+        hbb, hcounts = bft.query_branching(sample, with_counts=True)
+        ok_br = bool((bb[:nb8] == np.asarray(hbb)[:nb8]).all() and (bcounts == np.asarray(hcounts)).all())
+        dist_extra = {"color_rows": ok_rows, "branching": ok_br, "queries": int(len(sample))}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -307,6 +334,7 @@ def main():
             "parallelism": f"query-shard x{world}, trie replicated ({args.replicate if use_dist else 'single copy'})",
         },
         "parity_ok": parity_ok,
+        "dist_extra_paths": dist_extra,
         "answers_checked_per_gpu": nq,
         "present_fraction": round(n_present / nq, 4),
         "build": {"insert_build_s_incl_torch": round(t_insert, 3), "M_pairs_per_s_incl_torch_packing": round(n_pairs_in / max(t_insert, 1e-9) / 1e6, 1),
@@ -412,7 +440,7 @@ def main():
                 "value": round(ns / t_q / 1e6, 3), "unit": "M k-mers/s", "cores": cores, "kind": "port",
                 "sample": f"first {ns} queries of the same batch; the oracle's isKmerPresent loop over {cores} threads on the trie the GPU built, read from the "
                           f".bft file it wrote by the oracle's restatement of read_BFT_Root ({t_load:.1f} s)",
-                "cores_detail": {"os_cpu_count": cores_os, "sched_affinity": cores_aff, "cgroup_cpu_quota": quota, "threads_used": cores},
+                "cpu_model": cpu_model(), "cores_detail": {"os_cpu_count": cores_os, "sched_affinity": cores_aff, "cgroup_cpu_quota": quota, "threads_used": cores},
                 "M_kmers_per_s_by_threads": scaling, "single_thread": scaling.get("1"),
                 "note": "a reported baseline, not the target; the thread-scaling row says how far the host's memory system carries the loop",
             }
@@ -609,7 +637,11 @@ def main():
             line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
             if r.returncode == 0 and line:
                 d = json.loads(line[-1])
-                out["dist_path_check"] = {"ok": bool(d.get("parity_ok")), "backend": "nccl (RCCL)", "world_size": 1, "replicate": "broadcast of the packed image, unpacked (always_copy)",
+                ex = d.get("dist_extra_paths") or {}
+                out["dist_path_check"] = {"ok": bool(d.get("parity_ok")) and bool(ex.get("color_rows")) and bool(ex.get("branching")),
+                                          "paths": {"presence (overlapped all_gather)": bool(d.get("parity_ok")), "color_rows (sharded, rows gathered)": bool(ex.get("color_rows")),
+                                                    "branching (sharded, counts gathered)": bool(ex.get("branching"))},
+                                          "backend": "nccl (RCCL)", "world_size": 1, "replicate": "broadcast of the packed image, unpacked (always_copy)",
                                           "gather": "all_gather of the presence bitmaps, overlapped with the next step's kernel (GatherPipeline)",
                                           "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "answers_checked": d.get("answers_checked_per_gpu"),
                                           "workload": "10-genome index, 2x10^7 queries, 3 steps", "seconds": round(time.perf_counter() - t0, 1),
