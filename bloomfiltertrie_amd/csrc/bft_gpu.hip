@@ -2297,6 +2297,23 @@ static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
         h->qc_stream = s;
         HIPCK(e);
     }
+    if (fill && h->im.kh_lines != nullptr && !h->opt_walk_hash && bft_kh_has_kernels(h->W, h->im.kh.S)) {
+        // through the k-mer hash: lookup, offsets and ids in ONE launch (k_colors_kh; the host entry point counts first and fills per chunk: the three steps below)
+        const size_t sb = bft_kh_colors_scratch_bytes(n);
+        if (h->qc_tmp.bytes < sb) {
+            if (h->qc_used) HIPCK(hipStreamSynchronize(s));
+            CK(h->qc_tmp.alloc(sb + sb / 2));
+        }
+        h->qc_used = true;
+        h->qc_stream = s;
+        hipEvent_t e0, e1;
+        CK(timing_begin(h, s, &e0, &e1));
+        CK(bft_kh_colors(h->im, d_kmers, n, h->B, d_bits64, d_offsets, d_ids, d_ids ? ids_cap : 0, d_needed, h->qc_tmp.p, s));
+        CK(timing_end(h, s, e0, e1));
+        if (!h->qc_ev && hipEventCreateWithFlags(&h->qc_ev, hipEventDisableTiming) != hipSuccess) { h->qc_ev = nullptr; (void)hipGetLastError(); }
+        if (h->qc_ev && hipEventRecord(h->qc_ev, s) != hipSuccess) (void)hipGetLastError();
+        return 0;
+    }
     const size_t tb = ((n + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
     if (h->qc_cs.bytes < n * 4 || h->qc_tmp.bytes < tb) {
         if (h->qc_used) HIPCK(hipStreamSynchronize(s));

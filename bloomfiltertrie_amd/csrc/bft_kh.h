@@ -27,6 +27,10 @@ int bft_kh_dump(const BftImage& im, uint64_t* d_keys, uint64_t stride, uint32_t*
 // are then claimed instead of dealt out by workgroup number (bft_claims.h), and the kernel leaves the words zeroed
 int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint32_t* d_out32, BftClaimCtr d_ctr, uint32_t chunk,
                  hipStream_t s);
+// presence bits, offsets [n + 1] and genome ids of n packed k-mers in ONE launch; d_scratch: bft_kh_colors_scratch_bytes(n) bytes of the caller's
+size_t bft_kh_colors_scratch_bytes(uint64_t n);
+int bft_kh_colors(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
+                  void* d_scratch, hipStream_t s);
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s);
 // colour set of every k-mer position of a chunk of sequences (the arrays of query_sequences_core)
 int bft_kh_seq(const BftImage& im, const uint64_t* d_codes, const uint32_t* d_bad, const uint64_t* d_seq_off, const uint64_t* d_pos_off, const uint32_t* d_tile_seq,

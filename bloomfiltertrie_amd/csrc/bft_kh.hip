@@ -107,6 +107,169 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
     cl.done();
 }
 
+// get_annotation + get_list_id_genomes of a resident batch (src/bft.c:363-387, 622-641; src/annotation.c:2086-2250) in ONE launch: lookup, offsets and
+// ids.  A workgroup claims tiles of CT x 256 k-mers in order; per block of the tile: the lookup of k_query_kh (quad fetch into LDS, scan of the
+// line) hands every lane its colour set, whose list length comes out of the dictionary's offsets; the tile's total is published as one
+// 8-byte word and the first wavefront looks back over the 64 tiles before it for the tile's 64-bit offset (the scan of bft_scan.h, inside
+// this kernel); then every wavefront writes its k-mers' offsets and streams their ids out coalesced (every output element finds its k-mer by
+// six shuffles over the lanes' starts, as k_color_fill_cs did).  Round 5 ran three launches -- lookup writing a colour-set id per k-mer,
+// a library scan reading it back, the fill reading both: 24.8 G k-mers/s on the config-4 index.
+// scratch: [0] the tile counter, [1 ..] the tiles' states {flag:2, value:62}; zeroed before the launch.  ids beyond ids_cap are not written
+// (the caller compares *needed = offsets[n] with its capacity).
+#ifndef BFT_KH_CT
+#define BFT_KH_CT 4
+#endif
+template <int W, int S>
+__global__ __launch_bounds__(BFT_KH_BLOCK) void k_colors_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                           unsigned long long* __restrict__ offsets, uint32_t* __restrict__ ids, uint64_t ids_cap, unsigned long long* __restrict__ needed,
+                                                           unsigned long long* __restrict__ scratch) {
+    constexpr uint32_t WPB = BFT_KH_BLOCK / 64, CT = BFT_KH_CT;
+    constexpr unsigned long long F_AGG = 1ull << 62, F_INC = 2ull << 62, VMASK = (1ull << 62) - 1ull;
+    __shared__ uint4 s_lines[WPB][64 * BFT_KH_LDS_LINE];
+    __shared__ uint64_t s_bits[CT * WPB];
+    __shared__ uint32_t s_sum[CT * WPB];
+    __shared__ uint32_t s_len[CT * BFT_KH_BLOCK], s_src[CT * BFT_KH_BLOCK];  // a k-mer's list: ids, where they start in the dictionary (in LDS, not registers:
+    __shared__ uint32_t s_tile;                                              // the lookups need the wavefronts the registers would cost)
+    __shared__ unsigned long long s_prefix;
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4* const wave_lines = s_lines[wave];
+    const uint4* const mine = wave_lines + lane * BFT_KH_LDS_LINE;
+    const uint64_t ntiles = (n + (uint64_t)CT * BFT_KH_BLOCK - 1) / ((uint64_t)CT * BFT_KH_BLOCK), nwords = (n + 63) / 64;
+    unsigned long long* states = scratch + 1;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(scratch, 1ull);
+        __syncthreads();
+        const uint64_t tile = s_tile;
+        if (tile >= ntiles) return;
+#pragma unroll 1
+        for (uint32_t c = 0; c < CT; c++) {
+            const uint64_t i = (tile * CT + c) * BFT_KH_BLOCK + threadIdx.x;
+            const bool live = i < n;
+            BftKhKey<W> key;
+            key.home = 0;
+            key.field = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+            uint64_t t[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) t[w] = 0;
+            if (live) {
+                uint64_t x[W];
+                load_x<W>(packed, i, B, end_aligned, x);
+                bft_tform_from_x<W>(x, im.k, t);
+                bft_kh_key<W>(t, im.k, im.kh, key);
+            }
+            kh_fetch_quad(im, key.home, live, wave_lines);
+            bool present = false;
+            uint32_t val = 0;
+            if (live) {
+                int res = kh_lds_scan<W, S>(im, mine, key, 0u, &val);
+                for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {
+                    const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
+                    uint64_t hd[2];
+                    bft_kh_load_header(line, hd);
+                    res = bft_kh_scan<W, S>(im, line, hd, key, d, &val);
+                }
+                if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;
+                present = res > 0;
+            }
+            uint32_t len = 0, src = 0;
+            if (present) {
+                src = im.cs_off[val];
+                len = im.cs_off[val + 1] - src;
+            }
+            s_len[c * BFT_KH_BLOCK + threadIdx.x] = len;
+            s_src[c * BFT_KH_BLOCK + threadIdx.x] = src;
+            const uint64_t mask = __ballot(present);
+            uint32_t ws = len;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o);
+            if (lane == 0) { s_bits[c * WPB + wave] = mask; s_sum[c * WPB + wave] = ws; }
+        }
+        __syncthreads();
+        {   // the presence words of the tile leave together; the tile's total; its place among all ids
+            const uint64_t w0 = tile * CT * WPB;
+            if (threadIdx.x < CT * WPB && w0 + threadIdx.x < nwords) __builtin_nontemporal_store(s_bits[threadIdx.x], &bits64[w0 + threadIdx.x]);
+        }
+        if (wave == 0) {
+            unsigned long long total = lane < CT * WPB ? s_sum[lane] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o);
+            total = __shfl(total, 0);
+            unsigned long long ex = 0;
+            if (tile == 0) {
+                if (lane == 0) __hip_atomic_store(&states[0], F_INC | (total & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0) __hip_atomic_store(&states[tile], F_AGG | (total & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long first = (long long)tile - 1;
+                for (;;) {
+                    const long long tt = first - (long long)lane;
+                    unsigned long long st = F_INC;
+                    if (tt >= 0) {
+                        do { st = __hip_atomic_load(&states[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st >> 62) == 0ull && (__builtin_amdgcn_s_sleep(1), true));
+                    }
+                    const uint64_t incl = __ballot((st >> 62) == 2ull);
+                    const int stop = incl ? __builtin_ctzll(incl) : 64;
+                    unsigned long long x = ((int)lane <= stop && tt >= 0) ? (st & VMASK) : 0ull;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+                    ex += __shfl(x, 0);
+                    if (stop < 64) break;
+                    first -= 64;
+                }
+                if (lane == 0) __hip_atomic_store(&states[tile], F_INC | ((ex + total) & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) {
+                s_prefix = ex;
+                if (tile == ntiles - 1) {  // (the last tile knows the total)
+                    offsets[n] = ex + total;
+                    if (needed) *needed = ex + total;
+                }
+            }
+        }
+        __syncthreads();
+        unsigned long long run = s_prefix;
+#pragma unroll 1
+        for (uint32_t c = 0; c < CT; c++) {
+            const uint32_t len = s_len[c * BFT_KH_BLOCK + threadIdx.x], src = s_src[c * BFT_KH_BLOCK + threadIdx.x];
+            // the lane's start: the tile's, the (block, wavefront) sums before it, the lanes before it
+            unsigned long long wbase = run;
+#pragma unroll
+            for (uint32_t w = 0; w < WPB; w++) {
+                if (w < wave) wbase += s_sum[c * WPB + w];
+                run += s_sum[c * WPB + w];
+            }
+            uint32_t inc = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(inc, o);
+                if ((int)lane >= o) inc += y;
+            }
+            const uint32_t ar = inc - len, span = __shfl(inc, 63);  // start relative to the wavefront's first id; ids of the wavefront's 64 k-mers
+            const uint64_t i = (tile * CT + c) * BFT_KH_BLOCK + threadIdx.x;
+            if (i < n) offsets[i] = wbase + ar;
+            if (!ids) continue;
+            for (uint32_t r0 = 0; r0 < span; r0 += 64) {
+                const uint32_t r = r0 + lane;
+                const bool in = r < span;
+                const uint32_t rr = in ? r : span - 1;
+                uint32_t lo = 0, hi = 63;  // the last lane whose list starts at or before rr (starts are non-decreasing over the lanes)
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    const uint32_t am = __shfl(ar, mid);
+                    if (am <= rr) lo = mid; else hi = mid - 1;
+                }
+                const uint32_t as = __shfl(ar, lo);
+                const uint32_t ss = __shfl(src, lo);
+                if (in && wbase + r < ids_cap) ids[wbase + r] = bft_cs_id_at(im.cs_ids, im.cs_w, ss + (r - as));
+            }
+        }
+        __syncthreads();  // (s_tile, s_sum, s_bits, s_prefix are rewritten by the next tile)
+    }
+}
+
 // How many of the four successors (or the four predecessors) of a k-mer are stored.  They share their home line and differ in two stored key
 // bits (bft_image.h: the bits that tell them apart are not hashed), so ONE line is fetched by the quad and looked through ONCE, the two bits
 // left out of the comparison: every slot that matches is one of the four (src/presenceNode.c:15-1211 shares one descent between the four;
@@ -526,6 +689,20 @@ int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint
     chunk = std::max(1u, std::min(chunk, BFT_KH_MAX_CLAIM));
     const dim3 grid = kh_round_grid(n, chunk, grid_mult, d_ctr.p != nullptr);
     KH_DISPATCH(im.W, (int)im.kh.S, hipLaunchKernelGGL((k_query_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, d_out32, d_ctr, chunk));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// presence bits, offsets [n + 1] and genome ids of n packed k-mers in one launch (k_colors_kh); d_scratch: bft_kh_colors_scratch_bytes(n) bytes
+size_t bft_kh_colors_scratch_bytes(uint64_t n) { return ((n + (uint64_t)BFT_KH_CT * BFT_KH_BLOCK - 1) / ((uint64_t)BFT_KH_CT * BFT_KH_BLOCK) + 1) * 8; }
+int bft_kh_colors(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
+                  void* d_scratch, hipStream_t s) {
+    const uint64_t ntiles = (n + (uint64_t)BFT_KH_CT * BFT_KH_BLOCK - 1) / ((uint64_t)BFT_KH_CT * BFT_KH_BLOCK);
+    HIPCK(hipMemsetAsync(d_scratch, 0, (ntiles + 1) * 8, s));
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 256ull * 8))), block(BFT_KH_BLOCK);
+    KH_DISPATCH(im.W, (int)im.kh.S,
+                hipLaunchKernelGGL((k_colors_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, (unsigned long long*)d_offsets, d_ids, ids_cap, (unsigned long long*)d_needed,
+                                   (unsigned long long*)d_scratch));
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -104,11 +104,14 @@ int bft_gpu_query_colors(bft_gpu* h, const uint8_t* kmers, uint64_t nb_kmers, ui
                          uint64_t* offsets, uint32_t* ids, uint64_t ids_cap, uint64_t* ids_needed);
 /* The same on a RESIDENT batch, without synchronisation (runs on hip_stream; NULL = the handle's stream): d_present_bits as in
  * bft_gpu_query_presence_dev, d_offsets = nb_kmers + 1 uint64 (offsets[nb_kmers] = the number of ids), d_ids = room for ids_cap uint32; *d_ids_needed
- * (device, may be NULL) receives the number of ids -- when it exceeds ids_cap NOTHING is written to d_ids (offsets and bits are complete): size
- * the buffer and call again, or pass d_ids = NULL / ids_cap = 0 first to learn the size.  The colour set of every found k-mer comes out of the line
- * of the k-mer hash that answers presence (no row, no sorted table: "compact_table" stays in force), the lists' lengths are scanned into the
- * offsets straight from the dictionary, and the ids are streamed out wavefront by wavefront.  Scratch (4 bytes per k-mer) belongs to the
- * handle: calls of one handle on different streams are serialised by the library. */
+ * (device, may be NULL) receives the number of ids -- when it exceeds ids_cap, d_ids holds the first ids_cap ids only (never a byte beyond
+ * ids_cap; offsets and bits are complete): size the buffer and call again, or pass d_ids = NULL / ids_cap = 0 first to learn the size.  (Until
+ * round 6 nothing at all was written in that case; lookup, offsets and ids are ONE launch now -- k_colors_kh --, which knows the total only at its
+ * end.)  The colour set of every found k-mer comes out of the line of the k-mer hash that answers presence (no row, no sorted table:
+ * "compact_table" stays in force), its list's length out of the dictionary's offsets, a tile's place among all ids by a look-back over the tiles
+ * before it, and the ids are streamed out wavefront by wavefront.  Scratch (8 bytes per 1024 k-mers) belongs to the handle: calls of one handle
+ * on different streams are serialised by the library.  An image without the k-mer hash ("kmer_hash" 0, "walk_hash" 1) takes three launches --
+ * the container walk, a scan, the fill -- and keeps the old rule (nothing written to a buffer that is too small). */
 int bft_gpu_query_colors_dev(bft_gpu* h, const void* d_kmers, uint64_t nb_kmers, void* d_present_bits, void* d_offsets, void* d_ids, uint64_t ids_cap,
                              void* d_ids_needed, void* hip_stream);
 /* Fixed-width variant = the CSV row of src/file_io.c:744-765 before formatting: row i is
