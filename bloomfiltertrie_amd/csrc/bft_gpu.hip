@@ -2493,6 +2493,12 @@ extern "C" int bft_gpu_query_color_rows_dev(bft_gpu* h, const void* d_kmers, uin
     // walk): no row -> colour set pass
     CK(ensure_cs_bitmaps(h));
     const bool direct = h->has_cs_bm;
+    // rows of 16 bytes and up through the k-mer hash: lookup and rows in one launch (the scratch array stays unused)
+    if (direct && rowbytes >= 16 && ((uintptr_t)d_rows & 15u) == 0 && h->im.kh_lines != nullptr && !h->opt_walk_hash && bft_kh_has_kernels(h->W, h->im.kh.S)) {
+        CK(bft_kh_color_rows(h->im, (const uint8_t*)d_kmers, n, h->B, (uint64_t*)d_present_bits, h->d_cs_bm.as<uint8_t>() + CS_BM_SLACK, (rowbytes + 3) & ~3u, rowbytes,
+                             (uint8_t*)d_rows, h->device, s));
+        return note_foreign_stream(h, s);
+    }
     if (!direct) CK(ensure_table(h));
     if (direct) h->im.emit_cs = 1;
     const int rc = launch_query(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint32_t*)d_scratch_rows_u32, s);

@@ -29,6 +29,9 @@ int bft_kh_query(const BftImage& im, int grid_mult, const uint8_t* d_kmers, uint
                  hipStream_t s);
 // presence bits, offsets [n + 1] and genome ids of n packed k-mers in ONE launch; d_scratch: bft_kh_colors_scratch_bytes(n) bytes of the caller's
 size_t bft_kh_colors_scratch_bytes(uint64_t n);
+// presence bits and bitmap rows (rowbytes >= 16, d_out 16-byte aligned) of n packed k-mers in ONE launch
+int bft_kh_color_rows(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, const uint8_t* bm, uint32_t stride, uint32_t rowbytes, uint8_t* d_out,
+                      int device, hipStream_t s);
 int bft_kh_colors(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
                   void* d_scratch, hipStream_t s);
 int bft_kh_branching(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int B, uint64_t* d_bits64, uint8_t* d_counts, BftClaimCtr d_ctr, uint32_t chunk, hipStream_t s);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 
 #include "bft_dev.h"
@@ -15,6 +16,7 @@
 #include "bft_kernels_seqwin.h"
 #include "bft_kh_dev.h"
 #include "bft_scan.h"
+#include "bft_rows16.h"
 #include "bft_sort.h"
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -105,6 +107,74 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_query_kh(BftImage im, const ui
         cl.advance();  // (its barriers stand between these reads of s_bits and the next round's writes)
     }
     cl.done();
+}
+
+// Colour rows of a resident batch (get_annotation + the bitmap form of get_list_id_genomes, src/bft.c:363-387, 622-641) in ONE launch: the
+// tiles belong to wavefronts as in k_color_rows_bm16 (bft_kernels_color.h), but the wavefront looks its tile's k-mers up itself -- 64 at a
+// time, the lookup of k_query_kh -- and keeps their dictionary rows in its LDS slice; nothing but the presence words and the rows is
+// written.  Round 5 ran the lookup as its own launch, writing a colour-set id per k-mer that the row kernel read back.
+// tile_rows: a multiple of 64 (a presence word per lookup round; tiles start 16-byte aligned), at most BFT_KH_ROWS_TILE.
+#ifndef BFT_KH_ROWS_TILE
+#define BFT_KH_ROWS_TILE 256u
+#endif
+template <int W, int S>
+__global__ __launch_bounds__(256) void k_color_rows_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
+                                                       const uint8_t* __restrict__ bm, uint32_t stride, uint32_t rowbytes, uint32_t tile_rows, uint32_t div_m, uint32_t div_l,
+                                                       uint8_t* __restrict__ out) {
+    __shared__ uint4 s_lines[4][64 * BFT_KH_LDS_LINE];
+    __shared__ uint32_t s_cs_all[4][BFT_KH_ROWS_TILE + 1];
+    const uint64_t end_aligned = ((uint64_t)packed + n * (uint64_t)B) & ~3ull;
+    const uint64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4* const wave_lines = s_lines[wave];
+    const uint4* const mine = wave_lines + lane * BFT_KH_LDS_LINE;
+    uint32_t* const s_cs = s_cs_all[wave];
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4u + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4u) {
+        const uint64_t q0 = tile * tile_rows;
+        const uint32_t nt = (uint32_t)min((uint64_t)tile_rows, n - q0);
+        __builtin_amdgcn_wave_barrier();  // (the last tile's reads of s_cs come before these writes: same wavefront, in order)
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < nt; j0 += 64u) {
+            const uint64_t i = q0 + j0 + lane;
+            const bool live = i < n;
+            BftKhKey<W> key;
+            key.home = 0;
+            key.field = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) { key.body[w] = 0; key.bmask[w] = 0; }
+            uint64_t t[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) t[w] = 0;
+            if (live) {
+                uint64_t x[W];
+                load_x<W>(packed, i, B, end_aligned, x);
+                bft_tform_from_x<W>(x, im.k, t);
+                bft_kh_key<W>(t, im.k, im.kh, key);
+            }
+            kh_fetch_quad(im, key.home, live, wave_lines);
+            bool present = false;
+            uint32_t val = 0;
+            if (live) {
+                int res = kh_lds_scan<W, S>(im, mine, key, 0u, &val);
+                for (uint32_t d = 1; res < 0 && d <= im.kh.maxd; d++) {
+                    const uint64_t* line = im.kh_lines + (key.home + d) * BFT_KH_LINE_WORDS;
+                    uint64_t hd[2];
+                    bft_kh_load_header(line, hd);
+                    res = bft_kh_scan<W, S>(im, line, hd, key, d, &val);
+                }
+                if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;
+                present = res > 0;
+            }
+            s_cs[j0 + lane] = present ? val * (stride >> 2) : CR16_ABSENT;
+            const uint64_t mask = __ballot(present);
+            if (lane == 0) bits64[(q0 + j0) >> 6] = mask;
+        }
+        if (lane == 0) s_cs[nt] = CR16_ABSENT;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cr16_stream_tile(s_cs, nt, rowbytes, div_m, div_l, bm, out + q0 * rowbytes, lane);
+    }
 }
 
 // get_annotation + get_list_id_genomes of a resident batch (src/bft.c:363-387, 622-641; src/annotation.c:2086-2250) in ONE launch: lookup, offsets and
@@ -703,6 +773,41 @@ int bft_kh_colors(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int re
     KH_DISPATCH(im.W, (int)im.kh.S,
                 hipLaunchKernelGGL((k_colors_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, (unsigned long long*)d_offsets, d_ids, ids_cap, (unsigned long long*)d_needed,
                                    (unsigned long long*)d_scratch));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+template <int W, int S>
+static void kh_color_rows_launch(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, const uint8_t* bm, uint32_t stride, uint32_t rowbytes,
+                                 uint32_t tile_rows, uint32_t div_m, uint32_t div_l, uint8_t* d_out, int device, hipStream_t s) {
+    // the tiles are dealt out by workgroup number: no more workgroups than are resident at once (per device: CU count and partition mode may differ)
+    static std::atomic<int> resident_dev[64];
+    std::atomic<int>& res = resident_dev[device & 63];
+    int r = res.load(std::memory_order_relaxed);
+    if (!r) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_color_rows_kh<W, S>, 256, 0) != hipSuccess || per_cu < 1) { per_cu = 4; (void)hipGetLastError(); }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) { cus = 256; (void)hipGetLastError(); }
+        r = per_cu * cus;
+        res.store(r, std::memory_order_relaxed);
+    }
+    const uint64_t tiles = (n + tile_rows - 1) / tile_rows;
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((tiles + 3) / 4, (uint64_t)r)));
+    hipLaunchKernelGGL((k_color_rows_kh<W, S>), grid, dim3(256), 0, s, im, d_kmers, n, rec, d_bits64, bm, stride, rowbytes, tile_rows, div_m, div_l, d_out);
+}
+
+// presence bits and colour rows (rowbytes >= 16 bytes each, d_out 16-byte aligned) of n packed k-mers in one launch (k_color_rows_kh); bm: the bitmap
+// dictionary (rows of `stride` bytes, slack on either side: ensure_cs_bitmaps)
+int bft_kh_color_rows(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, const uint8_t* bm, uint32_t stride, uint32_t rowbytes, uint8_t* d_out,
+                      int device, hipStream_t s) {
+    // tiles of about 16 KiB of output, a multiple of 64 k-mers.  (Config 5, 250-byte rows, 4x10^6 k-mers: tiles of 64 / 128 / 256 k-mers at 4, 5, 6
+    // workgroups per CU all take 0.37-0.40 ms, the smallest tiles and the most workgroups the least -- the launch costs what the lookups and the
+    // rows cost one after the other, whichever way they are interleaved: DESIGN.md.)
+    const uint32_t tile_rows = std::max(64u, std::min(BFT_KH_ROWS_TILE, ((16u << 10) / rowbytes) & ~63u));
+    uint32_t div_l = 0;
+    while ((1ull << div_l) < rowbytes) div_l++;
+    const uint32_t div_m = (uint32_t)(((1ull << 32) * ((1ull << div_l) - rowbytes)) / rowbytes + 1ull);
+    KH_DISPATCH(im.W, (int)im.kh.S, (kh_color_rows_launch<KW, KS>(im, d_kmers, n, rec, d_bits64, bm, stride, rowbytes, tile_rows, div_m, div_l, d_out, device, s)));
     HIPCK(hipGetLastError());
     return 0;
 }

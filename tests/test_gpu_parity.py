@@ -115,12 +115,14 @@ def test_colours(oracle_mod, k, ngen):
         assert cache[c] == omap[key]
 
 
-@pytest.mark.parametrize("ngen", [16, 17, 128, 131, 200, 260, 1999])
-def test_colour_rows_wide_against_ground_truth(ngen):
-    """Fixed-width colour rows for row widths around the 16-byte chunks of k_color_rows_bm (2, 3, 16, 17, 25, 33, 250 bytes):
-    every byte of every row against the sets that were inserted; absent k-mers give all-zero rows."""
+@pytest.mark.parametrize("ngen,k", [(16, 27), (17, 27), (128, 27), (131, 27), (200, 27), (260, 27), (1999, 27), (131, 45), (520, 63), (9000, 27)])
+def test_colour_rows_wide_against_ground_truth(ngen, k):
+    """Fixed-width colour rows for row widths around the 16-byte chunks of k_color_rows_bm (2, 3, 16, 17, 25, 33, 250 bytes; 1125 bytes:
+    a tile of 64 k-mers is more than 64 KiB): every byte of every row against the sets that were inserted; absent k-mers give all-zero
+    rows.  The host call goes through row numbers and k_color_rows_bm16; the device-resident call looks the k-mers up inside the row kernel
+    (k_color_rows_kh, rows of 16 bytes and up): both must give the same bytes."""
+    import torch
     from bloomfiltertrie_amd import BFT
-    k = 27
     km = S.distinct(S.kmers_of(S.random_genome(6000, 91), k))
     rng = np.random.default_rng(ngen)
     member = rng.random((ngen, len(km))) < (0.6 if ngen < 100 else 0.08)
@@ -146,6 +148,17 @@ def test_colour_rows_wide_against_ground_truth(ngen):
     for m in (1, 5, 63, 1000):
         b2, r2 = t.query_color_rows(np.ascontiguousarray(q[:m]))
         assert (r2 == rows[:m]).all()
+    # the device-resident call: lookup inside the row kernel; batch sizes around the tiles of 64 k-mers and the presence words
+    dq = torch.from_numpy(q).to("cuda:0")
+    for m in (len(q), 1, 63, 64, 65, 1000, 4097):
+        m = min(m, len(q))
+        dbits = torch.full((((m + 63) // 64) * 8,), 0xAA, dtype=torch.uint8, device="cuda:0")
+        drows = torch.full((m, rows.shape[1]), 0x55, dtype=torch.uint8, device="cuda:0")
+        scratch = torch.zeros(m, dtype=torch.int32, device="cuda:0")
+        t.query_color_rows_dev(dq.data_ptr(), m, dbits.data_ptr(), drows.data_ptr(), scratch.data_ptr())
+        torch.cuda.synchronize()
+        assert (drows.cpu().numpy() == rows[:m]).all()
+        assert (S.from_bits(dbits.cpu().numpy(), m).astype(bool) == pres[:m]).all()
 
 
 def test_incremental_insert_and_rebuild(oracle_mod):
