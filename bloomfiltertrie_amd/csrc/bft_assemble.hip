@@ -35,11 +35,6 @@ namespace {
 // small helpers
 // ---------------------------------------------------------------------------------------------
 // (PinBlock, bft_dev.h: counts the host needs come back through a pinned block that kernels write)
-__global__ void k_scan_total(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, uint64_t* __restrict__ slot, int tail) {
-    const uint64_t t = (uint64_t)in[n - 1] + out[n - 1];
-    *slot = t;
-    if (tail) out[n] = (uint32_t)t;  // (the offsets array has n + 1 entries)
-}
 __global__ void k_set32(uint32_t* __restrict__ p, uint32_t v) { *p = v; }
 __global__ void k_publish(const uint32_t* __restrict__ v, int n, uint64_t* __restrict__ slots) {
     if ((int)threadIdx.x < n) slots[threadIdx.x] = v[threadIdx.x];
@@ -59,8 +54,7 @@ struct Scan {
             if (tail) hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, out, 0u);
             return 0;
         }
-        CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp));
-        hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, s, in, out, n, pin.p + slot, tail ? 1 : 0);
+        CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp, (unsigned long long*)(pin.p + slot), tail));  // (the last tile writes the total)
         return 0;
     }
     // n <= PIN_SLOTS device words -> slots [slot, slot + n)

@@ -22,17 +22,6 @@ int bft_fail(int code, const std::string& msg);  // records the thread's last er
         if (rc_ != 0) return rc_; \
     } while (0)
 
-// Every radix sort of the library goes through this: rocPRIM's radix sort (ROCm 7.2) mis-sorts a bit range that starts above bit 0 AND ends at
-// bit 64 (found twice: composites of [2, 64) bits at k = 31, tests/test_gpu_parity.py::test_any_k_against_ground_truth; the root-prefix split of
-// (k-mer, id) pairs over [46, 64) at k = 32, tools/stress_parity.py) -- the callers route around such ranges (composites stay within 63 bits, k = 32
-// takes the device-wide sort); the check makes a range that slips through fail loudly instead of building a wrong index.
-#define BFT_RADIX_SORT(begin_bit, end_bit, call)                                                                                      \
-    do {                                                                                                                              \
-        if ((unsigned)(begin_bit) != 0u && (unsigned)(end_bit) >= 64u)                                                               \
-            return bft_fail(BFT_GPU_E_ARG, "internal: radix sort over the bit range [b, 64) with b > 0 (mis-sorted by the library)"); \
-        HIPCK(call);                                                                                                                  \
-    } while (0)
-
 // Device-memory cache behind DevBuf (bft_gpu.hip).  hipFree synchronises the device and costs ~0.1 ms per call on
 // large blocks; a bulk build releases dozens of temporaries.  Released blocks are kept (per device, tagged with the
 // stream of the ABI call that released them) and handed out again to requests of a similar size.  A block released
@@ -46,16 +35,19 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;  // requested size
     size_t cap = 0;    // size of the block behind it
+    uint32_t tag = 0, tag2 = 0;  // the user's (bft_scan.h: launches so far, states the last one used); zero after every alloc
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), tag(o.tag), tag2(o.tag2) { o.p = nullptr; o.bytes = 0; o.cap = 0; o.tag = 0; o.tag2 = 0; }
     ~DevBuf() { release(); }
     void release() {
         if (p) bft_pool_release(p, cap);
         p = nullptr;
         bytes = 0;
         cap = 0;
+        tag = 0;
+        tag2 = 0;
     }
     int alloc(size_t n) {
         release();
@@ -66,7 +58,8 @@ struct DevBuf {
     }
     int alloc_zero(size_t n, hipStream_t s) {
         CK(alloc(n));
-        HIPCK(hipMemsetAsync(p, 0, bytes, s));
+        // (whole 16-byte words: the runtime fills an odd tail with a second kernel)
+        HIPCK(hipMemsetAsync(p, 0, std::min(cap, (bytes + 15) & ~(size_t)15), s));
         return 0;
     }
     template <class T>
@@ -75,6 +68,8 @@ struct DevBuf {
         std::swap(p, o.p);
         std::swap(bytes, o.bytes);
         std::swap(cap, o.cap);
+        std::swap(tag, o.tag);
+        std::swap(tag2, o.tag2);
     }
 };
 

@@ -2314,7 +2314,7 @@ static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
         if (h->qc_ev && hipEventRecord(h->qc_ev, s) != hipSuccess) (void)hipGetLastError();
         return 0;
     }
-    const size_t tb = ((n + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
+    const size_t tb = bft_scan::scratch_bytes(n + 1);  // (the scan's tile states)
     if (h->qc_cs.bytes < n * 4 || h->qc_tmp.bytes < tb) {
         if (h->qc_used) HIPCK(hipStreamSynchronize(s));
         if (h->qc_cs.bytes < n * 4) CK(h->qc_cs.alloc(n * 4 + n / 2));
@@ -2585,7 +2585,7 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
     const uint64_t chunk = 1ull << 30;
     const uint64_t cmax = std::min(chunk, n_seqs);
     const uint64_t n_cw = (total_chars + 31) / 32;  // code words of the blob (32 characters each)
-    const size_t scan_bytes = ((cmax + 1 + bft_scan::TILE - 1) / bft_scan::TILE + 1) * 8;  // (the scan's tile states)
+    const size_t scan_bytes = bft_scan::scratch_bytes(cmax + 1);  // (the scan's tile states)
     CK(need(h->sq_codes, (n_cw + BFT_MAX_W + 2) * 8));
     CK(need(h->sq_bad, (n_cw + BFT_MAX_W + 2) * 4));
     CK(need(h->sq_npos, (cmax + 1) * 8));

@@ -13,7 +13,14 @@
 //     the 64 lanes of its first wavefront look at the 64 tiles before it at once: the values up to the nearest tile that already knows its
 //     inclusive prefix are combined with shuffles, and further windows are fetched only if none of the 64 does;
 //   * the operator and the input are template parameters: sums of 32- or 64-bit counts, flags computed on the fly from neighbouring keys
-//     (a functor instead of a flag array), max.  Values stay below 2^62.
+//     (a functor instead of a flag array), max.  Values stay below 2^62;
+//   * nothing is zeroed by a launch of its own between two scans that share a scratch block.  The block holds the states twice: launch L
+//     uses array L & 1 and zeroes, tile by tile, what launch L - 1 left in the other one (nobody reads that any more); the workgroup whose claim
+//     is the launch's last puts the tile counter back to zero.  The host zeroes a block once, when it is new (DevBuf::tag counts the launches,
+//     DevBuf::tag2 remembers how many states the last one used).  A CAPTURED launch cannot take part (it runs again with the arguments it was
+//     captured with): it is bracketed by memsets and leaves the block zeroed;
+//   * the grand total, which nearly every caller wants on the host or behind the last offset, is written by the last tile (total_slot, tail)
+//     instead of by a launch of its own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -58,15 +65,18 @@ __device__ __forceinline__ T shfl_t(T v, int l) {
         return (T)__shfl((uint32_t)v, l);
 }
 
-// scratch: [0] tile counter (u64 slot), [1 ..] tile states; zeroed before every call
-// SINGLE: the whole input is one tile (no counter, no states: nothing to zero)
+// scratch: [0] tile counter (zero between launches); states: this launch's tile states {flag:2, value:62}, zero on entry; zero_other[0 .. zero_n):
+// the states of the launch before, zeroed here
+// SINGLE: the whole input is one tile (no counter, no states)
+// total_slot (may be NULL; device or pinned host memory): receives init (+) in(0) (+) ... (+) in(n - 1); tail: out[n] receives it too
 template <class T, class In, class Op, bool INCLUSIVE, bool SINGLE>
-__global__ __launch_bounds__(THREADS) void k_scan(In in, T* __restrict__ out, uint64_t n, T init, Op op, unsigned long long* __restrict__ scratch) {
+__global__ __launch_bounds__(THREADS) void k_scan(In in, T* __restrict__ out, uint64_t n, T init, Op op, unsigned long long* __restrict__ scratch,
+                                                  unsigned long long* __restrict__ states, unsigned long long* __restrict__ zero_other, uint32_t zero_n,
+                                                  unsigned long long* __restrict__ total_slot, int tail) {
     __shared__ T s_wave[WAVES];
     __shared__ T s_prefix;
     __shared__ uint32_t s_tile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    unsigned long long* states = scratch + 1;
     const uint32_t ntiles = (uint32_t)((n + TILE - 1) / TILE);
     for (;;) {
         if (!SINGLE) {
@@ -74,7 +84,11 @@ __global__ __launch_bounds__(THREADS) void k_scan(In in, T* __restrict__ out, ui
             __syncthreads();
         }
         const uint32_t tile = SINGLE ? 0u : s_tile;
-        if (tile >= ntiles) return;
+        if (tile >= ntiles) {
+            // every workgroup makes exactly one claim that fails: the last of them leaves the counter at zero for the next launch
+            if (tid == 0 && tile == ntiles + gridDim.x - 1u) __hip_atomic_store(scratch, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         const uint64_t base = (uint64_t)tile * TILE + (uint64_t)wave * 64u * IPT;
         T v[IPT];
 #pragma unroll
@@ -137,6 +151,11 @@ __global__ __launch_bounds__(THREADS) void k_scan(In in, T* __restrict__ out, ui
                 if (lane == 0) __hip_atomic_store(&states[tile], F_INC | ((uint64_t)op(ex, total) & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (lane == 0) s_prefix = ex;
+            if (lane == 0 && tile == ntiles - 1u) {  // the grand total, for the host and / or behind the last element
+                const T grand = op(ex, total);
+                if (total_slot) *total_slot = (unsigned long long)grand;
+                if (tail) out[n] = grand;
+            }
         }
         __syncthreads();
         const T pre = op(s_prefix, wpre);
@@ -154,30 +173,63 @@ __global__ __launch_bounds__(THREADS) void k_scan(In in, T* __restrict__ out, ui
             }
         }
         if (SINGLE) return;
+        {   // this tile's share of the states the launch before left behind
+            const uint32_t per = (zero_n + ntiles - 1u) / ntiles;
+            for (uint32_t i = tid; i < per; i += THREADS) {
+                const uint64_t j = (uint64_t)tile * per + i;
+                if (j < zero_n) zero_other[j] = 0ull;
+            }
+        }
         __syncthreads();  // (s_tile, s_wave, s_prefix are rewritten by the next tile)
     }
 }
-// out[i] = init (+) in(0) (+) ... (+) in(i - 1) (exclusive) or ... (+) in(i) (inclusive); `scratch` is (re)allocated as needed
+inline size_t scratch_bytes(uint64_t n) { return ((((n + TILE - 1) / TILE) * 2 + 2) * 8 + 63) & ~(size_t)63; }  // what a scan of n elements needs (callers that must not allocate later)
+// out[i] = init (+) in(0) (+) ... (+) in(i - 1) (exclusive) or ... (+) in(i) (inclusive); `scratch` is (re)allocated as needed and may be shared by
+// any number of scans that follow one another on their stream(s)
 template <class T, class In, class Op, bool INCLUSIVE>
-int scan(In in, T* out, uint64_t n, T init, Op op, hipStream_t s, DevBuf& scratch) {
+int scan(In in, T* out, uint64_t n, T init, Op op, hipStream_t s, DevBuf& scratch, unsigned long long* total_slot = nullptr, bool tail = false) {
     if (n == 0) return 0;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     if (ntiles == 1) {
-        hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, true>), dim3(1), dim3(THREADS), 0, s, in, out, n, init, op, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, true>), dim3(1), dim3(THREADS), 0, s, in, out, n, init, op, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                           (unsigned long long*)nullptr, 0u, total_slot, tail ? 1 : 0);
         HIPCK(hipGetLastError());
         return 0;
     }
-    const size_t bytes = (ntiles + 1) * 8;
-    if (scratch.bytes < bytes) CK(scratch.alloc(bytes));
-    HIPCK(hipMemsetAsync(scratch.p, 0, bytes, s));
+    if (scratch.bytes < scratch_bytes(n)) CK(scratch.alloc(scratch_bytes(n)));
+    unsigned long long* const base = scratch.as<unsigned long long>();
+    const uint64_t half = (scratch.bytes / 8 - 2) / 2;  // states per array
     const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256ull * 8ull);
-    hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, false>), dim3(grid), dim3(THREADS), 0, s, in, out, n, init, op, scratch.as<unsigned long long>());
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    if (cap != hipStreamCaptureStatusNone) {
+        HIPCK(hipMemsetAsync(scratch.p, 0, scratch.bytes, s));
+        hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, false>), dim3(grid), dim3(THREADS), 0, s, in, out, n, init, op, base, base + 2, base + 2 + half, 0u, total_slot, tail ? 1 : 0);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemsetAsync(scratch.p, 0, scratch.bytes, s));
+        scratch.tag = 0;  // (whenever the graph runs it leaves zeros; what eager launches left before it is gone by then: start over)
+        return 0;
+    }
+    if (scratch.tag == 0) {  // a new block: anything may be in it
+        HIPCK(hipMemsetAsync(scratch.p, 0, scratch.bytes, s));
+        scratch.tag = 2;
+        scratch.tag2 = 0;
+    }
+    const uint64_t cur = scratch.tag & 1u;
+    hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, false>), dim3(grid), dim3(THREADS), 0, s, in, out, n, init, op, base, base + 2 + cur * half, base + 2 + (cur ^ 1u) * half,
+                       scratch.tag2, total_slot, tail ? 1 : 0);
     HIPCK(hipGetLastError());
+    scratch.tag2 = (uint32_t)ntiles;
+    if (++scratch.tag == 0) scratch.tag = 2;
     return 0;
 }
 template <class T, class In>
-int exclusive_sum(In in, T* out, uint64_t n, hipStream_t s, DevBuf& scratch) { return scan<T, In, Sum, false>(in, out, n, (T)0, Sum(), s, scratch); }
+int exclusive_sum(In in, T* out, uint64_t n, hipStream_t s, DevBuf& scratch, unsigned long long* total_slot = nullptr, bool tail = false) {
+    return scan<T, In, Sum, false>(in, out, n, (T)0, Sum(), s, scratch, total_slot, tail);
+}
 template <class T>
-int exclusive_sum_ptr(const T* in, T* out, uint64_t n, hipStream_t s, DevBuf& scratch) { return scan<T, PtrIn<T>, Sum, false>(PtrIn<T>{in}, out, n, (T)0, Sum(), s, scratch); }
+int exclusive_sum_ptr(const T* in, T* out, uint64_t n, hipStream_t s, DevBuf& scratch, unsigned long long* total_slot = nullptr, bool tail = false) {
+    return scan<T, PtrIn<T>, Sum, false>(PtrIn<T>{in}, out, n, (T)0, Sum(), s, scratch, total_slot, tail);
+}
 
 }  // namespace bft_scan

@@ -113,15 +113,28 @@ static int check_scan(uint64_t n, int what) {
     T *d, *o;
     HCK(hipMalloc(&d, n * sizeof(T) + 16)); HCK(hipMalloc(&o, n * sizeof(T) + 16));
     HCK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
-    DevBuf sc;
-    int rc;
-    if (what == 0) rc = bft_scan::exclusive_sum_ptr<T>(d, o, n, 0, sc);
-    else if (what == 1) rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Sum, true>(bft_scan::PtrIn<T>{d}, o, n, (T)0, bft_scan::Sum(), 0, sc);
-    else rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Max, true>(bft_scan::PtrIn<T>{d}, o, n, (T)5, bft_scan::Max(), 0, sc);
-    if (rc) return 1;
-    HCK(hipMemcpy(got.data(), o, n * sizeof(T), hipMemcpyDeviceToHost));
+    static DevBuf sc;  // shared by all the checks: the scans tell their states apart by epoch, nothing is zeroed in between
+    unsigned long long* d_total;
+    HCK(hipMalloc(&d_total, 8));
+    int rc = 0;
     uint64_t bad = 0;
-    for (uint64_t i = 0; i < n; i++) bad += got[i] != want[i];
+    for (int rep = 0; rep < 3 && !rc; rep++) {  // the same scratch block three times in a row
+        HCK(hipMemset(o, 0xEE, n * sizeof(T) + 16));
+        if (what == 0) rc = bft_scan::exclusive_sum_ptr<T>(d, o, n, 0, sc, d_total, true);
+        else if (what == 1) rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Sum, true>(bft_scan::PtrIn<T>{d}, o, n, (T)0, bft_scan::Sum(), 0, sc, d_total);
+        else rc = bft_scan::scan<T, bft_scan::PtrIn<T>, bft_scan::Max, true>(bft_scan::PtrIn<T>{d}, o, n, (T)5, bft_scan::Max(), 0, sc, d_total);
+        if (rc) break;
+        HCK(hipMemcpy(got.data(), o, n * sizeof(T), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) bad += got[i] != want[i];
+        unsigned long long tot = 0;
+        T tail = 0;
+        HCK(hipMemcpy(&tot, d_total, 8, hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(&tail, o + n, sizeof(T), hipMemcpyDeviceToHost));
+        bad += tot != (unsigned long long)run;           // the grand total (for the exclusive sum: the sum of everything)
+        if (what == 0) bad += tail != run;                // ... and behind the last offset
+    }
+    hipFree(d_total);
+    if (rc) return 1;
     printf("{\"check\": \"scan %s u%d\", \"n\": %llu, \"bad\": %llu}\n", what == 0 ? "exclusive sum" : what == 1 ? "inclusive sum" : "inclusive max", (int)sizeof(T) * 8, (unsigned long long)n, (unsigned long long)bad);
     hipFree(d); hipFree(o);
     return bad ? 1 : 0;
