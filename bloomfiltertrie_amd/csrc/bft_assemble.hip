@@ -543,6 +543,25 @@ __global__ __launch_bounds__(ABLK) void k_concat(const ConcatJobs jobs) {
     for (uint64_t i = blockIdx.x * (uint64_t)ABLK + threadIdx.x; i < j.words; i += (uint64_t)gridDim.x * ABLK) j.dst[i] = j.src[i];
 }
 
+// several arrays set to a value each in one launch (every size is a multiple of 4 bytes; what a depth would otherwise zero by a memset per array)
+struct FillJob { uint32_t* p; uint64_t words; uint32_t val; };
+struct FillJobs {
+    FillJob j[8];
+    int n = 0;
+    void add(DevBuf& b, uint32_t val = 0u) { add(b.as<uint32_t>(), b.bytes / 4, val); }
+    void add(uint32_t* p, uint64_t words, uint32_t val) { if (words) j[n++] = FillJob{p, words, val}; }
+};
+__global__ __launch_bounds__(ABLK) void k_fill_many(const FillJobs jobs) {
+    const FillJob j = jobs.j[blockIdx.y];
+    for (uint64_t i = blockIdx.x * (uint64_t)ABLK + threadIdx.x; i < j.words; i += (uint64_t)gridDim.x * ABLK) j.p[i] = j.val;
+}
+static void fill_many(const FillJobs& jobs, hipStream_t s) {
+    if (!jobs.n) return;
+    uint64_t mx = 1;
+    for (int i = 0; i < jobs.n; i++) mx = std::max(mx, jobs.j[i].words);
+    hipLaunchKernelGGL(k_fill_many, dim3(bft_grid_for((mx + ABLK - 1) / ABLK), (unsigned)jobs.n), dim3(ABLK), 0, s, jobs);
+}
+
 struct Seg {  // per-depth output segments, concatenated at the end
     DevBuf nodes, bfT, ccs, f2w, clus, child, uck, ucrow;
     uint64_t n_nodes = 0, n_bf8 = 0, n_ccs = 0, n_f2w = 0, n_clus = 0, n_child = 0, n_uc = 0;
@@ -613,10 +632,17 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         CK(key_node.alloc(K * 4));
         CK(key_cnt.alloc(K * 4));
         CK(node_kb.alloc((M + 1) * 4));
+        // (allocated here so that one launch presets them all) CC assignment: key -> CC (-1: unassigned); the format's limits
+        DevBuf key_cc, lim;  // lim: [0] largest number of CCs in a node, [1] that of node 0, [2] largest CC, [3] prefixes, [4] CCs with >= BFT_TRESH_SUF_PREF, [5] UC rows of node 0
+        CK(key_cc.alloc(K * 4));
+        CK(lim.alloc(8 * 4));
         {
-            // nodes of an empty trie (n == 0) have no keys: node_kb = 0
-            HIPCK(hipMemsetAsync(node_kb.p, 0, (M + 1) * 4, s));
-            hipLaunchKernelGGL(k_set32, dim3(1), dim3(1), 0, s, node_kb.as<uint32_t>() + M, (uint32_t)K);
+            FillJobs fj;
+            fj.add(node_kb.as<uint32_t>(), M, 0u);  // nodes of an empty trie (n == 0) have no keys: node_kb = 0
+            fj.add(node_kb.as<uint32_t>() + M, 1, (uint32_t)K);
+            if (K) fj.add(key_cc.as<uint32_t>(), K, 0xFFFFFFFFu);
+            fj.add(lim.as<uint32_t>(), 8, 0u);
+            fill_many(fj, s);
         }
         if (A) {
             hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
@@ -632,13 +658,11 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         // least 255, so a node of U k-mers holds at most U / 255 + 1 CCs: the Bloom bitsets are written at those upper-bound slots
         // (ubb) and the real CC numbering comes from a scan of the counts afterwards.  (A counting pass used to run first: the same
         // kernel twice, 3.0 ms of config 3's assembly.) ----
-        DevBuf key_cc, node_ncc, node_ccb, cc_bits, ub, ubb;
-        CK(key_cc.alloc(K * 4));
+        DevBuf node_ncc, node_ccb, cc_bits, ub, ubb;
         CK(node_ncc.alloc(M * 4));
         CK(node_ccb.alloc((M + 1) * 4));
         CK(ub.alloc(M * 4));
         CK(ubb.alloc((M + 1) * 4));
-        HIPCK(hipMemsetAsync(key_cc.p, 0xFF, key_cc.bytes, s));
         hipLaunchKernelGGL(k_cc_upper, G(M), nsz.as<uint32_t>(), (uint32_t)M, ub.as<uint32_t>());
         CK(scan.run(ub.as<uint32_t>(), ubb.as<uint32_t>(), M, nullptr));
         CK(cc_bits.alloc((A / BFT_NB_KMERS_PER_UC + M) * 48 * 4));  // (the sum of the upper bounds is at most that: no count to wait for)
@@ -660,8 +684,6 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
                            nd_lo.as<uint32_t>(), nd_hi.as<uint32_t>(), hashmod, key_cc.as<int32_t>(), node_ncc.as<uint32_t>(),
                            ubb.as<uint32_t>(), cc_bits.as<uint32_t>(), (uint32_t)M);
         // limits (format): CCs per node, Bloom slice width
-        DevBuf lim;  // [0] largest number of CCs in a node, [1] that of node 0, [2] largest CC, [3] prefixes, [4] CCs with >= BFT_TRESH_SUF_PREF, [5] UC rows of node 0
-        CK(lim.alloc_zero(8 * 4, s));
         hipLaunchKernelGGL(k_ncc_limits, G(M), node_ncc.as<uint32_t>(), (uint32_t)M, lim.as<uint32_t>());
         CK(scan.enqueue(node_ncc.as<uint32_t>(), node_ccb.as<uint32_t>(), M, 0, true));
         CK(scan.publish(lim.as<uint32_t>(), 2, 1));
@@ -694,10 +716,18 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
 
         // ---- CC runs, clusters ----
         DevBuf cc_qb, cc_qe, uc_qb, uc_qe, cc_nb, cc_s, cc_nwords, cc_f2;
-        CK(cc_qb.alloc_zero(C * 4, s));
-        CK(cc_qe.alloc_zero(C * 4, s));
-        CK(uc_qb.alloc_zero(M * 4, s));
-        CK(uc_qe.alloc_zero(M * 4, s));
+        CK(cc_qb.alloc(C * 4));
+        CK(cc_qe.alloc(C * 4));
+        CK(uc_qb.alloc(M * 4));
+        CK(uc_qe.alloc(M * 4));
+        {
+            FillJobs fj;
+            fj.add(cc_qb.as<uint32_t>(), C, 0u);
+            fj.add(cc_qe.as<uint32_t>(), C, 0u);
+            fj.add(uc_qb.as<uint32_t>(), M, 0u);
+            fj.add(uc_qe.as<uint32_t>(), M, 0u);
+            fill_many(fj, s);
+        }
         CK(cc_nb.alloc(C * 4));
         CK(cc_s.alloc(C * 4));
         CK(cc_nwords.alloc(C * 4));

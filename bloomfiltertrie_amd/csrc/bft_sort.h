@@ -370,7 +370,39 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         cur_j = blockIdx.x * tpr;
         rt_end = min(total_tiles, cur_j + tpr);
         if (cur_j >= rt_end) return;
-        for (uint32_t d = tid; d < DIGITS; d += THREADS) grun[d] = d <= mask ? dbase[d] + rows[(size_t)blockIdx.x * row_stride + d] : 0u;
+        if (nch == 0u) {
+            // (a pass that counted its own digit: chain_start = the digits' totals.  Where the digits start in the output -- their exclusive
+            // scan -- is 512 additions, made here by the first wavefront, eight digits per lane, instead of by a launch of its own; workgroup 0
+            // leaves it in `heads` for the caller.)
+            if (wave == 0) {
+                uint32_t t[8], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t d = lane * 8u + (uint32_t)q;
+                    t[q] = d <= mask ? chain_start[d] : 0u;
+                    sum += t[q];
+                }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t x = __shfl_up(inc, o);
+                    if ((int)lane >= o) inc += x;
+                }
+                uint32_t run = inc - sum;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    grun[lane * 8u + (uint32_t)q] = run;
+                    run += t[q];
+                }
+            }
+            __syncthreads();
+            for (uint32_t d = tid; d < DIGITS; d += THREADS) {
+                const uint32_t db = grun[d];
+                if (blockIdx.x == 0) heads[d] = db;
+                grun[d] = d <= mask ? db + rows[(size_t)blockIdx.x * row_stride + d] : 0u;
+            }
+        } else
+            for (uint32_t d = tid; d < DIGITS; d += THREADS) grun[d] = d <= mask ? dbase[d] + rows[(size_t)blockIdx.x * row_stride + d] : 0u;
     } else {
         if (wave == 0) {  // (uniform in the wavefront; lane 0 keeps `home` and the claim in flight)
             const uint32_t x = xcc_id();
@@ -878,7 +910,8 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
         return 0;
     }
     if (n < BFT_RS_CHAIN_MIN || pl.P == 1) {
-        // Passes that each count their own digit first: a histogram kernel per pass (one more read of the keys), and no pass ever looks back --
+        // Passes that each count their own digit first: a histogram kernel per pass (one more read of the keys), the scan of the digit's counts over
+        // the ranges, the pass (which finds the digits' starts itself: nch = 0), and no pass ever looks back --
         // every workgroup owns a contiguous range of tiles in every pass.  For arrays of up to a few 10^7 entries the extra read costs less than
         // the look-back's round trips and the chains' bookkeeping.
         const size_t words = (size_t)2 * DIGITS + (size_t)CT * 2 + (size_t)ranges * DIGITS + 8;
@@ -896,10 +929,9 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
     do {                                                                                                                                                                       \
         hipLaunchKernelGGL((k_rs_hist<K, INTYPE, HT>), dim3(ranges), dim3(HT), (size_t)p1.hwords * 4, s, INVAL, (uint32_t)n, p1, tpr * TILE, partial);                          \
         hipLaunchKernelGGL(k_rs_rowscan, dim3(1u << p1.nbits[0], 1), dim3(256), 0, s, partial, partial, p1, ranges, tot);                                                       \
-        hipLaunchKernelGGL(k_rs_digits, dim3(1), dim3(DIGITS), 0, s, tot, dbase, chain, p1, (uint32_t)n, TILE);                                                                 \
         lds_limit<&k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>>((int)lds);   \
         hipLaunchKernelGGL((k_rs_pass<K, V, INTYPE, THREADS, IPT, true, BAL, 1>), dim3(ranges), dim3(THREADS), lds, s, INVAL, dk, dv, (uint32_t)n, p1.bit[0], p1.nbits[0],      \
-                           partial, p1.hwords, dbase, tpr, chain, chain, 1u, chain, chain, 16u);                                                                               \
+                           partial, p1.hwords, dbase, tpr, tot, chain, 0u, dbase, chain, 16u);                                                                                 \
     } while (0)
             if (p == 0) {
                 if (ballot) BFT_RS_ONEPASS(In, in, true);
