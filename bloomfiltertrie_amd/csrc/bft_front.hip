@@ -49,6 +49,29 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbit
     return m;
 }
 
+// Ranks from ONE LDS atomic per run of equal neighbouring digits.  From a bucket's second pass on, the composites of one k-mer lie side by
+// side (they agree in every digit, and the pass before was stable): a k-mer that ten genomes hold is ten atomics on one address, which the LDS
+// serves one after the other.  Lanes whose digit equals their left neighbour's form a run; the run's first lane reserves the run's ranks
+// with one atomic and hands its base on.  Runs of one digit that do not touch are ordered as single lanes are (see radix_passes: checked).
+// Measured on config 3's buckets (~760 composites, 4.5 per k-mer; profiles/r06/pmc_build.txt): k_bucket_sort_wave 1.90 -> 1.39 ms,
+// SQ_LDS_BANK_CONFLICT 5.0 -> 2.1 x10^8 cycles, SQ_WAIT_INST_LDS 12.6 -> 2.3 x10^8.
+__device__ __forceinline__ uint32_t rank_runs(uint32_t* cnt, uint32_t d, bool valid, uint32_t lane) {
+    const uint32_t dprev = (uint32_t)__builtin_amdgcn_update_dpp((int)d, (int)d, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const uint64_t hm = __ballot(valid && (lane == 0 || d != dprev)), vm = __ballot(valid);
+    uint32_t rank = 0;
+    if (valid) {  // (the lanes that are not valid are the wavefront's last: a valid lane's left neighbour is valid)
+        const uint64_t upto = hm & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull)), above = lane == 63 ? 0ull : (hm >> (lane + 1));
+        const uint32_t start = 63u - (uint32_t)__builtin_clzll(upto);
+        uint32_t base = 0;
+        if (start == lane) {
+            const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : (uint32_t)__builtin_popcountll(vm);
+            base = atomicAdd(&cnt[d], next - lane);
+        }
+        rank = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(start * 4u), (int)base) + (lane - start);
+    }
+    return rank;
+}
+
 // vals != nullptr: c holds whole T-form k-mers grouped by their top bits and vals the genome id of each (vw bytes wide); the composite
 // (T's bits below the split) << lo_bit | genome is formed here -- the top bits are the bucket's number, so a k-mer of up to 64 - lo_bit
 // bits below the split fits whatever the number of genomes (k = 31: 44 bits and up to 2^20 genomes) -- and goes back into c.
@@ -98,6 +121,8 @@ __device__ __forceinline__ void radix_passes(uint64_t (&key)[EMAX], uint64_t* ke
                     base = __shfl(base, leader);
                     rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
                 }
+            } else if (bit > lo_bit) {
+                rank[r] = rank_runs(cnt[wave], d, valid, lane);
             } else if (valid) {
                 rank[r] = atomicAdd(&cnt[wave][d], 1u);
             }
@@ -281,7 +306,9 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
-                    if (attempt == 0) {
+                    if (attempt == 0 && bit > lo_bit) {
+                        rank[r] = rank_runs(cnt, d, valid, lane);
+                    } else if (attempt == 0) {
                         if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
                     } else {
                         const uint64_t peers = match_digit(d, valid, nbits);
@@ -462,6 +489,8 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
                 base = __shfl(base, leader);
                 rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
             }
+        } else if (from_hi || bit) {  // (not the first pass: rank_runs)
+            rank[r] = rank_runs(cnt[wave], d, valid, lane);
         } else if (valid) {
             rank[r] = atomicAdd(&cnt[wave][d], 1u);
         }
@@ -660,7 +689,9 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
-                    if (attempt == 0) {
+                    if (attempt == 0 && p) {
+                        rank[r] = rank_runs(cnt, d, valid, lane);
+                    } else if (attempt == 0) {
                         if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
                     } else {
                         const uint64_t peers = match_digit(d, valid, nbits);
