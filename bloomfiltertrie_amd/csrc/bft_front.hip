@@ -454,6 +454,11 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket_emit(const uint64_t* __rest
 // and ordering only the distinct k-mers, a quarter of the items on a pan-genome, by comparison.  The ranking alone is m^2 comparisons of
 // 16 bytes: 35 x 10^3 wavefront instructions per bucket of 1850 items / 445 k-mers where these thirteen passes take 13 x 10^3 all told;
 // 7.0 ms for config 5's 19 x 10^3 buckets.)
+// (rank_runs in the two-word kernels: measured on config 5 -- 2000 genomes, runs of hundreds of equal digits -- 4.79 ms for the bucket sorts
+// against 4.08 with one atomic per lane; the hardware serves a wavefront's atomics on ONE address faster than the ballots and the permute cost.)
+#ifndef FB2_RUNS
+#define FB2_RUNS 0
+#endif
 struct __attribute__((packed, aligned(4))) BftItem2 {
     uint64_t lo;
     uint32_t id;
@@ -489,7 +494,7 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
                 base = __shfl(base, leader);
                 rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
             }
-        } else if (from_hi || bit) {  // (not the first pass: rank_runs)
+        } else if (FB2_RUNS && (from_hi || bit)) {  // (not the first pass: rank_runs)
             rank[r] = rank_runs(cnt[wave], d, valid, lane);
         } else if (valid) {
             rank[r] = atomicAdd(&cnt[wave][d], 1u);
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
-                    if (attempt == 0 && p) {
+                    if (FB2_RUNS && attempt == 0 && p) {
                         rank[r] = rank_runs(cnt, d, valid, lane);
                     } else if (attempt == 0) {
                         if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
