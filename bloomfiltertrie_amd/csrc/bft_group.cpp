@@ -4,11 +4,19 @@
 // are independent and read-only, so the batched path shards them: the built index is replicated into the HBM of every
 // device of the group (bft_gpu_image_pack on the source GPU, one peer copy over xGMI per replica, bft_gpu_image_unpack there), a
 // host batch is cut into contiguous slices whose starts are multiples of 64 k-mers (so the per-device presence bitmaps are
-// byte ranges of the caller's bitmap), and one host thread per device runs the ordinary single-GPU entry point on its slice.
-// Nothing collective is involved: the answers land in the caller's buffers.  (Processes that hold one GPU each -- bench.py under
+// byte ranges of the caller's bitmap), and every member answers its slice on a host thread of its own.  The thread lives as long as the
+// group (a batch costs a wake-up, not a thread start) and owns what its member's host batches go through: a stream on the member's device,
+// two slots of pinned staging memory and of device buffers.  A slice moves in chunks: the thread copies chunk c + 1 into its pinned slot
+// while the GPU answers chunk c (copy in, *_dev entry point, copy out: all on the member's stream) -- eight members do not meet in the
+// runtime's one staging path for pageable memory.  Nothing collective is involved: the answers land in the caller's buffers.  (Processes that hold one GPU each -- bench.py under
 // torchrun -- replicate with one RCCL broadcast of the same blob instead: bloomfiltertrie_amd/dist.py.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -16,10 +24,112 @@
 #include "../../include/bft_gpu.h"
 #include "bft_dev.h"
 
+namespace {
+
+// what one query kind moves per k-mer, besides the packed k-mer itself
+struct StageShape {
+    uint64_t in_bytes;        // packed k-mer
+    bool bits;                // a presence / branching bitmap (one bit per k-mer)
+    uint64_t out_bytes;       // bytes per k-mer of the second output (colour row, neighbour counts; 0: none)
+    bool scratch;             // a u32 per k-mer of device scratch (colour rows)
+};
+
+struct Member {
+    bft_gpu* h = nullptr;
+    int device = 0;
+    // the member's thread: one job at a time, posted by run_sharded
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, finished = false, quit = false;
+    int rc = 0;
+    std::string msg;
+    // staging (touched by the member's thread only, or by the caller's when no thread could be started)
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr}, *dev_in[2] = {nullptr, nullptr}, *dev_out[2] = {nullptr, nullptr}, *dev_scr[2] = {nullptr, nullptr};
+    size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0, dev_scr_cap = 0;
+
+    void loop() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<int()> f = std::move(job);
+            has_job = false;
+            lk.unlock();
+            int r = 0;
+            std::string m;
+            try {
+                r = f();
+                if (r != 0) m = bft_gpu_last_error();
+            } catch (...) {  // (nothing may leave the thread)
+                r = BFT_GPU_E_HIP;
+                m = "exception on a group member's thread";
+            }
+            lk.lock();
+            rc = r;
+            msg = std::move(m);
+            finished = true;
+            cv.notify_all();
+        }
+    }
+    void free_staging() {
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 2; i++) {
+            if (pin_in[i]) (void)hipHostFree(pin_in[i]);
+            if (pin_out[i]) (void)hipHostFree(pin_out[i]);
+            if (dev_in[i]) (void)hipFree(dev_in[i]);
+            if (dev_out[i]) (void)hipFree(dev_out[i]);
+            if (dev_scr[i]) (void)hipFree(dev_scr[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            pin_in[i] = pin_out[i] = dev_in[i] = dev_out[i] = dev_scr[i] = nullptr;
+            ev[i] = nullptr;
+        }
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        pin_in_cap = pin_out_cap = dev_in_cap = dev_out_cap = dev_scr_cap = 0;
+        (void)hipGetLastError();
+    }
+    // both slots hold at least these many bytes
+    int reserve(size_t in_b, size_t out_b, size_t scr_b) {
+        HIPCK(hipSetDevice(device));
+        if (!st) HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++)
+            if (!ev[i]) HIPCK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        auto grow = [&](void** p, size_t& cap, size_t want, bool host) -> int {
+            if (want <= cap) return 0;
+            HIPCK(hipStreamSynchronize(st));
+            for (int i = 0; i < 2; i++) {
+                if (p[i]) { if (host) (void)hipHostFree(p[i]); else (void)hipFree(p[i]); p[i] = nullptr; }
+            }
+            cap = 0;
+            for (int i = 0; i < 2; i++) {
+                if (host) HIPCK(hipHostMalloc(&p[i], want, hipHostMallocDefault));
+                else HIPCK(hipMalloc(&p[i], want));
+            }
+            cap = want;
+            return 0;
+        };
+        CK(grow(pin_in, pin_in_cap, in_b, true));
+        CK(grow(pin_out, pin_out_cap, out_b, true));
+        CK(grow(dev_in, dev_in_cap, in_b, false));
+        CK(grow(dev_out, dev_out_cap, out_b, false));
+        CK(grow(dev_scr, dev_scr_cap, scr_b, false));
+        return 0;
+    }
+};
+
+}  // namespace
+
 struct bft_gpu_group {
     std::vector<bft_gpu*> members;  // one handle per device slot
     std::vector<bool> owned;        // replicas made here (freed with the group); the source handle is the caller's
     std::vector<int> devices;       // the device of every slot
+    std::vector<Member*> workers;   // one per slot (its thread may be missing: the caller's thread stands in)
     int k = 0, B = 0;
     uint32_t nb_genomes = 0;
 };
@@ -93,12 +203,35 @@ extern "C" int bft_gpu_group_create(bft_gpu* src, int src_device, const int* dev
         delete g;
         return bft_fail(rc, keep);
     }
+    for (size_t i = 0; i < g->members.size(); i++) {
+        Member* m = new (std::nothrow) Member();
+        if (!m) break;  // (the slots without a worker are answered by the single-GPU host entry points)
+        m->h = g->members[i];
+        m->device = g->devices[i];
+        try {
+            m->th = std::thread([m] { m->loop(); });
+        } catch (...) {  // (no thread to be had: the calling thread will run this member's jobs)
+        }
+        g->workers.push_back(m);
+    }
     *out = g;
     return BFT_GPU_OK;
 }
 
 extern "C" void bft_gpu_group_free(bft_gpu_group* g) {
     if (!g) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (Member* m : g->workers) {
+        if (m->th.joinable()) {
+            { std::lock_guard<std::mutex> lk(m->mu); m->quit = true; }
+            m->cv.notify_all();
+            m->th.join();
+        }
+        m->free_staging();
+        delete m;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
     for (size_t i = 0; i < g->members.size(); i++)
         if (g->owned[i]) bft_gpu_free(g->members[i]);
     delete g;
@@ -150,52 +283,130 @@ extern "C" int bft_gpu_group_query_branching_dev(bft_gpu_group* g, const void* c
     return BFT_GPU_OK;
 }
 
-// One host thread per member on its slice; the first failure (code and message) is reported on the calling thread.
+// Member i answers its slice on its own thread; the first failure (code and message) is reported on the calling thread.
 template <class F>
 static int run_sharded(bft_gpu_group* g, uint64_t n, F f) {
     const int parts = (int)g->members.size();
     std::vector<int> rc(parts, 0);
     std::vector<std::string> msg(parts);
     std::vector<uint64_t> lo(parts, 0), hi(parts, 0);
-    for (int i = 0; i < parts; i++) CK(bft_gpu_group_shard(n, parts, i, &lo[i], &hi[i]));  // (before any thread exists: an early return must not leave one unjoined)
-    std::vector<std::thread> th;
+    for (int i = 0; i < parts; i++) CK(bft_gpu_group_shard(n, parts, i, &lo[i], &hi[i]));  // (before any job is posted: an early return must not leave one behind)
+    std::vector<int> posted;
     for (int i = 0; i < parts; i++) {
         const uint64_t a = lo[i], b = hi[i];
         if (b <= a) continue;
-        auto work = [&, i, a, b] {
-            rc[i] = f(g->members[i], a, b - a);
+        Member* m = i < (int)g->workers.size() ? g->workers[(size_t)i] : nullptr;
+        if (m && m->th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m->mu);
+                m->job = [=] { return f(m, g->members[(size_t)i], a, b - a); };
+                m->has_job = true;
+                m->finished = false;
+            }
+            m->cv.notify_all();
+            posted.push_back(i);
+        } else {  // no thread for this slot: here and now
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            rc[i] = f(m, g->members[(size_t)i], a, b - a);
             if (rc[i] != 0) msg[i] = bft_gpu_last_error();
-        };
-        try {
-            th.emplace_back(work);
-        } catch (...) {  // (no thread to be had: this slice is answered on the calling thread -- nothing may cross the extern "C" boundary)
-            work();
+            if (prev >= 0) (void)hipSetDevice(prev);
         }
     }
-    for (std::thread& t : th) t.join();
+    for (int i : posted) {
+        Member* m = g->workers[(size_t)i];
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv.wait(lk, [&] { return m->finished; });
+        rc[i] = m->rc;
+        msg[i] = m->msg;
+    }
     for (int i = 0; i < parts; i++)
         if (rc[i] != 0) return bft_fail(rc[i], msg[i]);
     return BFT_GPU_OK;
 }
 
+// One member's slice through its pinned slots.  call(d_in, m, d_bits, d_out, d_scratch, stream) enqueues the *_dev entry point.
+// kmers / bits / out: the slice's first byte in the caller's arrays (bits, out may be NULL: not wanted -- the device still produces them).
+template <class Call>
+static int staged(Member* w, const StageShape& sh, const uint8_t* kmers, uint64_t n, uint8_t* bits, uint8_t* out, Call call) {
+    // chunks of at most 2^22 k-mers and ~64 MiB per buffer, whole presence words
+    const uint64_t per = std::max<uint64_t>(sh.in_bytes, std::max<uint64_t>(sh.out_bytes, 1));
+    const uint64_t chunk = std::max<uint64_t>(64, std::min<uint64_t>(1ull << 22, ((64ull << 20) / per) & ~63ull));
+    const uint64_t mc0 = std::min(n, chunk);
+    const size_t bits_b = (((mc0 + 63) / 64) * 8 + 255) & ~(size_t)255, out_b = bits_b + mc0 * sh.out_bytes;  // (the second output starts 256-byte aligned: the row kernels store 16 bytes per lane)
+    CK(w->reserve(mc0 * sh.in_bytes, out_b, sh.scratch ? mc0 * 4 : 0));
+    struct Pending { uint64_t at = 0, m = 0; bool live = false; } pend[2];
+    auto retire = [&](int slot) -> int {  // the slot's answers are in its pinned buffer: into the caller's arrays
+        if (!pend[slot].live) return 0;
+        HIPCK(hipEventSynchronize(w->ev[slot]));
+        const uint64_t at = pend[slot].at, m = pend[slot].m;
+        const uint8_t* p = (const uint8_t*)w->pin_out[slot];
+        if (bits) std::memcpy(bits + at / 8, p, (m + 7) / 8);
+        if (out && sh.out_bytes) std::memcpy(out + at * sh.out_bytes, p + bits_b, m * sh.out_bytes);
+        pend[slot].live = false;
+        return 0;
+    };
+    int rc = 0;
+    uint64_t c = 0;
+    for (uint64_t at = 0; at < n && rc == 0; at += chunk, c++) {
+        const int slot = (int)(c & 1);
+        const uint64_t m = std::min(chunk, n - at);
+        rc = retire(slot);
+        if (rc) break;
+        std::memcpy(w->pin_in[slot], kmers + at * sh.in_bytes, m * sh.in_bytes);
+        uint8_t* d_out = (uint8_t*)w->dev_out[slot];
+        if (hipMemcpyAsync(w->dev_in[slot], w->pin_in[slot], m * sh.in_bytes, hipMemcpyHostToDevice, w->st) != hipSuccess) { rc = bft_fail(BFT_GPU_E_HIP, "copy to the device failed"); break; }
+        rc = call(w->dev_in[slot], m, d_out, d_out + bits_b, w->dev_scr[slot], (void*)w->st);
+        if (rc) break;
+        if (hipMemcpyAsync(w->pin_out[slot], d_out, ((m + 63) / 64) * 8, hipMemcpyDeviceToHost, w->st) != hipSuccess ||
+            (sh.out_bytes && hipMemcpyAsync((uint8_t*)w->pin_out[slot] + bits_b, d_out + bits_b, m * sh.out_bytes, hipMemcpyDeviceToHost, w->st) != hipSuccess) ||
+            hipEventRecord(w->ev[slot], w->st) != hipSuccess) {
+            rc = bft_fail(BFT_GPU_E_HIP, "copy from the device failed");
+            break;
+        }
+        pend[slot] = Pending{at, m, true};
+    }
+    if (rc == 0) rc = retire((int)(c & 1));
+    if (rc == 0) rc = retire((int)((c + 1) & 1));
+    if (rc != 0) {
+        const std::string keep = bft_gpu_last_error();
+        (void)hipStreamSynchronize(w->st);  // (nothing of this call stays in flight over the caller's arrays or the slots)
+        (void)hipGetLastError();
+        return bft_fail(rc, keep);
+    }
+    return 0;
+}
+
 extern "C" int bft_gpu_group_query_presence(bft_gpu_group* g, const uint8_t* kmers, uint64_t n, uint8_t* present_bits) {
     if (!g || ((!kmers || !present_bits) && n)) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t B = (uint64_t)g->B;
-    return run_sharded(g, n, [&](bft_gpu* h, uint64_t a, uint64_t m) { return bft_gpu_query_presence(h, kmers + a * B, m, present_bits + a / 8); });
+    return run_sharded(g, n, [=](Member* w, bft_gpu* h, uint64_t a, uint64_t m) -> int {
+        if (!w) return bft_gpu_query_presence(h, kmers + a * B, m, present_bits + a / 8);
+        const StageShape sh{B, true, 0, false};
+        return staged(w, sh, kmers + a * B, m, present_bits + a / 8, nullptr,
+                      [&](void* d_in, uint64_t mc, void* d_bits, void*, void*, void* st) { return bft_gpu_query_presence_dev(h, d_in, mc, d_bits, st); });
+    });
 }
 
 extern "C" int bft_gpu_group_query_color_rows(bft_gpu_group* g, const uint8_t* kmers, uint64_t n, uint8_t* present_bits, uint8_t* rows) {
     if (!g || ((!rows || !kmers) && n)) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t B = (uint64_t)g->B, rowbytes = (g->nb_genomes + 7) / 8;
-    return run_sharded(g, n, [&](bft_gpu* h, uint64_t a, uint64_t m) {
-        return bft_gpu_query_color_rows(h, kmers + a * B, m, present_bits ? present_bits + a / 8 : nullptr, rows + a * rowbytes);
+    return run_sharded(g, n, [=](Member* w, bft_gpu* h, uint64_t a, uint64_t m) -> int {
+        if (!w || rowbytes == 0) return bft_gpu_query_color_rows(h, kmers + a * B, m, present_bits ? present_bits + a / 8 : nullptr, rows + a * rowbytes);
+        const StageShape sh{B, true, rowbytes, true};
+        return staged(w, sh, kmers + a * B, m, present_bits ? present_bits + a / 8 : nullptr, rows + a * rowbytes,
+                      [&](void* d_in, uint64_t mc, void* d_bits, void* d_rows, void* d_scr, void* st) { return bft_gpu_query_color_rows_dev(h, d_in, mc, d_bits, d_rows, d_scr, st); });
     });
 }
 
 extern "C" int bft_gpu_group_query_branching(bft_gpu_group* g, const uint8_t* kmers, uint64_t n, uint8_t* branching_bits, uint8_t* counts) {
     if (!g || ((!kmers || !branching_bits) && n)) return bft_fail(BFT_GPU_E_ARG, "NULL argument");
     const uint64_t B = (uint64_t)g->B;
-    return run_sharded(g, n, [&](bft_gpu* h, uint64_t a, uint64_t m) {
-        return bft_gpu_query_branching(h, kmers + a * B, m, branching_bits + a / 8, counts ? counts + a : nullptr);
+    return run_sharded(g, n, [=](Member* w, bft_gpu* h, uint64_t a, uint64_t m) -> int {
+        if (!w) return bft_gpu_query_branching(h, kmers + a * B, m, branching_bits + a / 8, counts ? counts + a : nullptr);
+        const StageShape sh{B, true, counts ? 1u : 0u, false};
+        return staged(w, sh, kmers + a * B, m, branching_bits + a / 8, counts ? counts + a : nullptr, [&](void* d_in, uint64_t mc, void* d_bits, void* d_counts, void*, void* st) {
+            return bft_gpu_query_branching_dev(h, d_in, mc, d_bits, counts ? d_counts : nullptr, st);
+        });
     });
 }

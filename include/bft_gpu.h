@@ -283,8 +283,10 @@ int bft_gpu_image_unpack(const void* d_blob, uint64_t nbytes, int device, bft_gp
  * devices[0..n_devices) -- image blob packed on the source GPU, one peer copy per replica, unpacked there; the first slot naming
  * src_device is served by src itself, further slots (the same device may appear twice) get copies.  The group owns its replicas, not src.
  * The *_query_* calls cut a host batch into contiguous slices whose starts are multiples of 64 k-mers (bft_gpu_group_shard gives slice i
- * of `parts`: the same rule bloomfiltertrie_amd/dist.py applies across processes), run the single-GPU entry point on every slice from
- * one host thread per device, and return when all have answered into the caller's buffers -- same layouts as the single-GPU calls.
+ * of `parts`: the same rule bloomfiltertrie_amd/dist.py applies across processes) and return when every slot has answered its slice into the
+ * caller's buffers -- same layouts as the single-GPU calls.  Every slot has a host thread of its own for as long as the group lives, with a
+ * stream on its device and two slots of pinned staging memory: a slice moves in chunks (at most 2^22 k-mers / ~64 MiB), chunk c + 1 copied into
+ * pinned memory while the GPU answers chunk c through the *_dev entry points -- the caller's arrays may be pageable, the copies never are.
  * Insertion stays single-GPU: insert into src, then create the group again. */
 typedef struct bft_gpu_group bft_gpu_group;
 int bft_gpu_group_shard(uint64_t n, int parts, int i, uint64_t* begin, uint64_t* end);
