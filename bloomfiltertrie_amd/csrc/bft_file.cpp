@@ -26,6 +26,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <chrono>
+#include <exception>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -84,6 +85,11 @@ struct ThreadJoiner {
             if (x.joinable()) x.join();
     }
 };
+// First thing a worker does: touch the C++ runtime's per-thread exception state.  libstdc++ keeps it in thread-local storage that the dynamic
+// loader allocates on a thread's FIRST access when the library came in through dlopen (ctypes, JNI, cgo all do that) -- and the loader aborts
+// the process if that allocation fails.  A worker whose first throw is the std::bad_alloc of an exhausted heap would ask for it at the worst
+// moment; asked for at the start, while there is memory, the failure stays an exception.
+inline void touch_exception_state() { (void)std::uncaught_exceptions(); }
 // jobs 0 .. n-1 over the threads (the calling thread takes part).  An exception inside a job -- an allocation a hostile file asks for -- stops the
 // hand-out of jobs and is thrown again, as std::bad_alloc, on the CALLING thread once every worker is back: the caller's try / catch sees it, and
 // nothing reaches std::terminate.
@@ -93,6 +99,7 @@ void parallel_jobs(size_t n, F f) {
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     auto work = [&](unsigned t) {
+        touch_exception_state();
         try {
             for (;;) {
                 const size_t j = next.fetch_add(1);
@@ -985,10 +992,16 @@ static bool file_write_impl(const char* path, const BftHostImage& im, std::strin
     const size_t nparts = parts.bufs.size(), njobs = parts.jobs.size();
     std::unique_ptr<std::atomic<uint8_t>[]> ready(new std::atomic<uint8_t>[nparts]);
     for (size_t i = 0; i < nparts; i++) ready[i].store(1);
-    for (size_t j = 0; j < njobs; j++) ready[parts.job_buf[j]].store(0);
+    std::vector<uint8_t> parts_is_job(nparts, 0);
+    for (size_t j = 0; j < njobs; j++) { ready[parts.job_buf[j]].store(0); parts_is_job[parts.job_buf[j]] = 1; }
     std::atomic<size_t> next{0};
     // (a job that throws -- an allocation failure -- marks its part ready and the file bad: the streaming thread never waits for it, and nothing
     // leaves a worker as an exception)
+    // Back-pressure: the pool may run at most WRITE_AHEAD bytes of filled parts ahead of the one stream that writes them -- a slow file system
+    // must not make the whole file pile up in memory beside the host image.  The writing thread is exempt (it fills the part it waits for
+    // itself when nobody else has taken it), so the cap cannot stall the file.
+    constexpr size_t WRITE_AHEAD = (size_t)1 << 30;
+    std::atomic<size_t> unwritten{0};
     auto one_job = [&](Writer& x, size_t j) {
         try {
             x.out = &parts.bufs[parts.job_buf[j]];
@@ -997,10 +1010,13 @@ static bool file_write_impl(const char* path, const BftHostImage& im, std::strin
         } catch (...) {
             bad = true;
         }
+        unwritten.fetch_add(parts.bufs[parts.job_buf[j]].size(), std::memory_order_relaxed);
         ready[parts.job_buf[j]].store(1, std::memory_order_release);
     };
     auto work = [&](unsigned t) {
+        touch_exception_state();
         for (;;) {
+            while (t != 0 && unwritten.load(std::memory_order_relaxed) > WRITE_AHEAD && !bad.load() && next.load() < njobs) std::this_thread::sleep_for(std::chrono::microseconds(200));
             const size_t j = next.fetch_add(1);
             if (j >= njobs) break;
             one_job(*ws[t], j);
@@ -1025,6 +1041,7 @@ static bool file_write_impl(const char* path, const BftHostImage& im, std::strin
             }
             std::vector<uint8_t>& b = parts.bufs[i];
             if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
+            if (parts_is_job[i]) unwritten.fetch_sub(b.size(), std::memory_order_relaxed);
             std::vector<uint8_t>().swap(b);  // (written: its memory goes back while the rest is still being filled)
         }
         if (!ok || bad) next.store(njobs);  // (nothing more to fill)

@@ -181,3 +181,57 @@ def test_reader_survives_mutated_files(hostlib):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_bft_reader.py"), "2", "120", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     assert b"fuzz OK" in r.stdout
+
+
+_STARVED_READER = r"""
+import ctypes as C, os, resource, sys
+lib = C.CDLL(sys.argv[1])
+lib.bft_hosttest_read_bft.restype = C.c_void_p
+lib.bft_hosttest_read_bft.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+lib.bft_hosttest_read_free.argtypes = [C.c_void_p]
+def vm_bytes():
+    return int(open("/proc/self/statm").read().split()[0]) * os.sysconf("SC_PAGE_SIZE")
+def read():
+    k, g, n = C.c_int(), C.c_int(), C.c_uint64()
+    h = lib.bft_hosttest_read_bft(sys.argv[2].encode(), C.byref(k), C.byref(g), C.byref(n))
+    if h:
+        lib.bft_hosttest_read_free(h)
+    return bool(h), n.value
+soft0, hard = resource.getrlimit(resource.RLIMIT_AS)
+res = []
+resource.setrlimit(resource.RLIMIT_STACK, (512 << 10, resource.getrlimit(resource.RLIMIT_STACK)[1]))  # (small stacks for the reader's threads: what is short is the heap)
+for extra_mb in (112, 104, 96, 64):  # address space left to the reader: it needs ~120 MB for this file
+    resource.setrlimit(resource.RLIMIT_AS, (vm_bytes() + (extra_mb << 20), hard))
+    try:
+        ok, _ = read()
+    except MemoryError:
+        ok = False
+    resource.setrlimit(resource.RLIMIT_AS, (soft0, hard))
+    res.append(ok)
+ok, n = read()  # the limit lifted: the library is as good as new
+print("starved", res, "final", ok, n)
+"""
+
+
+def test_reader_out_of_memory_in_its_worker_threads_is_an_error_not_the_end_of_the_process(oracle_mod, hostlib, tmp_path):
+    """A small file whose every k-mer is annotated with every genome (the reference writes a range annotation of a few bytes per row;
+    the reader's threads expand it to nb_genomes x k-mers x B bytes of per-genome output).  With the address space capped just above what the
+    process already holds, the allocations of the worker threads fail: the call returns an error -- no std::terminate from a thread, no joinable
+    thread left behind -- and the same process reads the file once the cap is lifted."""
+    k, ngen = 27, 96
+    km = S.distinct(S.kmers_of(S.random_genome(120000, 4), k))
+    a = oracle_mod.OracleBFT(k)
+    for g in range(ngen):
+        a.insert_kmers(km, g)
+    p = str(tmp_path / "wide.bft")
+    a.write_bft(p, ngen)
+    assert os.path.getsize(p) < 0.02 * ngen * len(km) * 7  # (the file is tiny beside what it decodes to)
+    r = subprocess.run([sys.executable, "-c", _STARVED_READER, os.path.join(_lib.CSRC, "libbft_hosttest.so"), p], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, BFT_GPU_IO_THREADS="3"))  # (few threads: glibc aborts a process whose NEW thread cannot get its thread-local block)
+    out = r.stdout.decode(errors="replace")
+    if r.returncode != 0 and "cannot allocate memory for thread-local data" in out:
+        pytest.skip("glibc itself aborts a process whose new thread cannot get its thread-local block: the cap hit that allocation, not the reader's")
+    assert r.returncode == 0, out[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith("starved")][-1]
+    assert "False" in line.split("final")[0], line        # at least one capped read failed cleanly ...
+    assert f"final True {len(km)}" in line, line           # ... and the process still reads the file afterwards
