@@ -43,11 +43,12 @@ python3 tools/bench_color_rows.py 2>&1 | strip | grep "^{" > "$OUT/color_rows.js
 python3 tools/bench_color_rows.py cfg4 2>&1 | strip | grep "^{" >> "$OUT/color_rows.jsonl"
 # config 5's kernels under the counters (branching through the k-mer hash, colour rows), and the microbenchmarks they are priced against
 bash tools/pmc_collect_config5.sh > "$OUT/pmc_config5.log" 2>&1
-cp gpurun_out/pmc/config5/pmc_k_branching.json "$OUT/pmc_config5_branching.json"; cp gpurun_out/pmc/config5/pmc_k_color_rows_bm.json "$OUT/pmc_config5_color_rows.json"
+cp gpurun_out/pmc/config5/pmc_k_branching.json "$OUT/pmc_config5_branching.json"; cp gpurun_out/pmc/config5/pmc_k_color_rows.json "$OUT/pmc_config5_color_rows.json"
 cp gpurun_out/pmc/config5/kernel_stats.txt "$OUT/config5_kernel_stats.txt"
 tools/microbench/gather 2 64 1024 8192 > "$OUT/microbench_gather.jsonl" 2>&1
 tools/microbench/stream > "$OUT/microbench_stream.jsonl" 2>&1
 [ -x tools/microbench/seg_sort ] && tools/microbench/seg_sort > "$OUT/microbench_seg_sort.jsonl" 2>&1
 [ -x tools/microbench/kh_sort ] && tools/microbench/kh_sort > "$OUT/microbench_kh_sort.jsonl" 2>&1
+[ -x tools/microbench/rs_sort ] && tools/microbench/rs_sort bench > "$OUT/microbench_rs_sort.jsonl" 2>&1
 python3 tools/probe_fill.py 27 2>&1 | strip | grep "^{" > "$OUT/kmer_hash_build.json"
 ls -la "$OUT"

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"],
           ["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"],
           ["SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SALU", "SQ_WAVES"]]
-KEEP = ("k_bucket", "k_group", "k_cs_", "onesweep", "k_assign", "k_kh_", "k_msd", "k_prefix", "k_flat")
+KEEP = ("k_bucket", "k_group", "k_cs_", "k_rs_", "k_scan", "k_assign", "k_kh_", "k_msd", "k_prefix", "k_flat")
 
 
 def short(name):

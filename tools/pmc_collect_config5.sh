@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats summary + --pmc passes (TCC traffic) for the config-5 kernels: k_branching, k_color_rows_bm,
-# k_row_colorsets (tools/pmc_config5.py).  Run on the GPU box from the repo root; results under gpurun_out/pmc/config5/.
+# rocprofv3 --kernel-trace --stats summary + --pmc passes (TCC traffic) for the config-5 kernels: k_branching, k_color_rows_kh (lookup and rows
+# in one launch since round 6) (tools/pmc_config5.py).  Run on the GPU box from the repo root; results under gpurun_out/pmc/config5/.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc/config5; REPS=3
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -14,7 +14,7 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_MISS_sum TCC_REQ_sum"; do
 done
 cd "$ROOT"
 python3 tools/pmc_parse.py "$OUT" config5 10000000 $REPS k_branching > "$OUT/pmc_k_branching.json"
-python3 tools/pmc_parse.py "$OUT" config5 4000000 $REPS k_color_rows_bm > "$OUT/pmc_k_color_rows_bm.json"
+python3 tools/pmc_parse.py "$OUT" config5 4000000 $REPS k_color_rows > "$OUT/pmc_k_color_rows.json"
 find "$OUT" -name "*.csv" -delete; find "$OUT" -name "*.db" -delete
 grep -E "l2_|fetch_bytes|write_bytes" "$OUT"/pmc_k_*.json
 grep -E "k_branching|k_color_rows|k_row_colorsets" "$OUT/kernel_stats.txt" | grep "grid=" | head

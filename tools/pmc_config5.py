@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3 passes over the config-5 kernels (k=63, 2000 colours): build the index (workloads.py), then `reps`
-launches each of k_branching (10^7 k-mers) and of the colour-row path (k_query + k_row_colorsets + k_color_rows_bm, 4x10^6 k-mers).
+launches each of k_branching (10^7 k-mers) and of the colour-row path (k_color_rows_kh: lookup and rows in one launch, 4x10^6 k-mers).
 usage: pmc_config5.py [reps]"""
 import os
 import sys
