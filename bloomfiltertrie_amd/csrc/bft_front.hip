@@ -54,7 +54,7 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbit
 // serves one after the other.  Lanes whose digit equals their left neighbour's form a run; the run's first lane reserves the run's ranks
 // with one atomic and hands its base on.  Runs of one digit that do not touch are ordered as single lanes are (see radix_passes: checked).
 // Measured on config 3's buckets (~760 composites, 4.5 per k-mer; profiles/r06/pmc_build.txt): k_bucket_sort_wave 1.90 -> 1.39 ms,
-// SQ_LDS_BANK_CONFLICT 5.0 -> 2.1 x10^8 cycles, SQ_WAIT_INST_LDS 12.6 -> 2.3 x10^8.
+// SQ_LDS_BANK_CONFLICT 5.0 -> 1.6 x10^8 cycles, SQ_WAIT_INST_LDS 12.6 -> 0.5 x10^8 (profiles/r06/bucket_experiments_2.txt).
 __device__ __forceinline__ uint32_t rank_runs(uint32_t* cnt, uint32_t d, bool valid, uint32_t lane) {
     const uint32_t dprev = (uint32_t)__builtin_amdgcn_update_dpp((int)d, (int)d, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     const uint64_t hm = __ballot(valid && (lane == 0 || d != dprev)), vm = __ballot(valid);

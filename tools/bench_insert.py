@@ -105,7 +105,7 @@ def measure(args):
     g = torch.Generator(device=dev)
     g.manual_seed(4242)
     anc = torch.randint(0, 4, (args.genome_len,), generator=g, device=dev, dtype=torch.uint8)
-    with BFT(args.k) as warm:  # loads the code objects and the hipCUB kernels once (≈25 ms on the first call of a process;
+    with BFT(args.k) as warm:  # loads the code objects once (≈25 ms on the first call of a process;
         w = pack_windows(anc[:50000], args.k)  # bench.py does the same): not part of any figure
         warm.set_option("build_msd", 2)  # (the root-prefix bucket kernels too: they otherwise load on the first large build)
         warm.insert_kmers_dev(w.data_ptr(), w.shape[0], 0)
