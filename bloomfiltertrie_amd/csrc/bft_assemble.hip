@@ -29,6 +29,43 @@
 
 #define ABLK 256
 
+__global__ void k_pin_ticket(uint64_t* __restrict__ slot, uint64_t v) {
+    __threadfence_system();
+    *reinterpret_cast<volatile uint64_t*>(slot) = v;
+}
+int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket) {
+    static std::atomic<uint64_t> tickets{0};
+    if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (pinned counts)");
+    *ticket = tickets.fetch_add(1) + 1;
+    hipLaunchKernelGGL(k_pin_ticket, dim3(1), dim3(1), 0, s, pin.p + PIN_SLOTS, *ticket);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+int bft_pin_wait_for(PinBlock& pin, hipStream_t s, uint64_t want) {
+    volatile uint64_t* t = pin.p + PIN_SLOTS;
+    for (uint32_t i = 1;; i++) {
+        if (*t == want) break;
+        __builtin_ia32_pause();
+        if ((i & 0xFFFu) == 0) {  // every 4096 polls: is the stream still at it?
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {  // through: the ticket is there
+                if (*t == want) break;
+                HIPCK(hipStreamSynchronize(s));
+                if (*t == want) break;
+                return bft_fail(BFT_GPU_E_HIP, "pinned ticket not written");
+            }
+            if (q != hipErrorNotReady) HIPCK(q);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+int bft_pin_wait(PinBlock& pin, hipStream_t s) {
+    uint64_t want = 0;
+    CK(bft_pin_post(pin, s, &want));
+    return bft_pin_wait_for(pin, s, want);
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -65,8 +102,7 @@ struct Scan {
     }
     int wait() {
         HIPCK(hipGetLastError());
-        HIPCK(hipStreamSynchronize(s));
-        return 0;
+        return bft_pin_wait(pin, s);
     }
     uint64_t get(int slot) const { return pin.p[slot]; }
     int run(const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* total) {

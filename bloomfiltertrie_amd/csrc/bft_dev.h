@@ -76,7 +76,16 @@ struct DevBuf {
 // Counts the host needs (array sizes, format limits) come back through a pinned block that kernels write: the scans and checks
 // of a stage are enqueued together and share ONE stream synchronisation (a total fetched by hipMemcpyAsync into pageable memory is
 // two staged copies and a synchronisation of its own: ~60 us each, sixteen per trie level).
-constexpr int PIN_SLOTS = 32;
+constexpr int PIN_SLOTS = 32;  // (+ one word behind them: the ticket of bft_pin_wait)
+struct PinBlock;
+// Waits until everything enqueued on `s` so far has run, by POLLING: a one-thread kernel behind it all writes a ticket into the pinned block and the
+// host spins on that word.  hipStreamSynchronize / hipEventSynchronize sleep on an interrupt and come back ~0.1 ms after the stream is through --
+// eleven such waits a build (array sizes the host needs) were a millisecond of idle GPU.  The stream's state is looked at every few thousand polls:
+// an error there ends the wait with that error.  (bft_assemble.hip)
+int bft_pin_wait(PinBlock& pin, hipStream_t s);
+// the same in two steps: the ticket enqueued here, waited for later (what is enqueued in between is not waited for; one ticket in flight per block)
+int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket);
+int bft_pin_wait_for(PinBlock& pin, hipStream_t s, uint64_t ticket);
 struct PinBlock {
     uint64_t* p = nullptr;
     PinBlock() {
@@ -84,7 +93,7 @@ struct PinBlock {
             std::lock_guard<std::mutex> lk(mu());
             if (!cache().empty()) { p = cache().back(); cache().pop_back(); }
         }
-        if (!p && hipHostMalloc((void**)&p, PIN_SLOTS * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+        if (!p && hipHostMalloc((void**)&p, (PIN_SLOTS + 1) * 8, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
     }
     ~PinBlock() {
         if (!p) return;

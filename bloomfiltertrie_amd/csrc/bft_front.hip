@@ -648,7 +648,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_tiny(uint64_t* __restrict_
 // item of LDS.  (With a workgroup per bucket the thirteen passes of k = 63 cost seven barriers each: 12.4 ms for config 5's 19 x 10^3 buckets.)
 // PACK: genome ids below 2^18 ride in the 18 free bits on top of hk's 46: four registers and two exchanged words per item instead of five and three
 template <int EW, bool PACK>
-__global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 2)) void k_bucket2_sort_wave(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone) {
     __shared__ uint64_t buf_all[FB_WAVES][64 * EW];
     __shared__ uint32_t cnt_all[FB_WAVES][FB_DIGITS];
@@ -687,17 +687,19 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
 #pragma unroll
                 for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[lane * (FB_DIGITS / 64) + j] = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t rank[EW];
+                uint32_t rank2[(EW + 1) / 2];  // two 16-bit ranks / slots per register (a bucket holds <= 2048 items)
+#pragma unroll
+                for (int j = 0; j < (EW + 1) / 2; j++) rank2[j] = 0;
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
-                    rank[r] = 0;
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
+                    uint32_t rk = 0;
                     if (FB2_RUNS && attempt == 0 && p) {
-                        rank[r] = rank_runs(cnt, d, valid, lane);
+                        rk = rank_runs(cnt, d, valid, lane);
                     } else if (attempt == 0) {
-                        if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
+                        if (valid) rk = atomicAdd(&cnt[d], 1u);
                     } else {
                         const uint64_t peers = match_digit(d, valid, nbits);
                         if (valid) {
@@ -708,10 +710,12 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                                 cnt[d] = base + (uint32_t)__builtin_popcountll(peers);
                             }
                             base = __shfl(base, leader);
-                            rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
+                            rk = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     }
+                    rank2[r >> 1] |= rk << ((r & 1u) * 16u);
+                    if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);  // (bounds what the scheduler keeps in flight: registers)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 {   // the lane's digits: counts -> starts
@@ -731,14 +735,20 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-                for (uint32_t r = 0; r < (uint32_t)EW; r++)  // (rank becomes the item's new slot)
-                    if (r < E && r * 64u + lane < n) rank[r] += cnt[(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask];
+                for (uint32_t r = 0; r < (uint32_t)EW; r++)  // (rank becomes the item's new slot: rank + start < 2048, no carry into the other half)
+                {
+                    if (r < E && r * 64u + lane < n) rank2[r >> 1] += cnt[(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask] << ((r & 1u) * 16u);
+                    if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
+                }
                 // the exchange, word by word through the wavefront's 8 bytes per item
 #pragma unroll
                 for (int f = 0; f < (PACK ? 2 : 3); f++) {
 #pragma unroll
                     for (uint32_t r = 0; r < (uint32_t)EW; r++)
-                        if (r < E && r * 64u + lane < n) buf[rank[r]] = f == 0 ? khi[r] : f == 1 ? klo[r] : (uint64_t)kid[PACK ? 0 : r];
+                    {
+                        if (r < E && r * 64u + lane < n) buf[(rank2[r >> 1] >> ((r & 1u) * 16u)) & 0xFFFFu] = f == 0 ? khi[r] : f == 1 ? klo[r] : (uint64_t)kid[PACK ? 0 : r];
+                        if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
                     for (uint32_t r = 0; r < (uint32_t)EW; r++) {
@@ -747,6 +757,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                             const uint64_t v = buf[idx];
                             if (f == 0) khi[r] = v; else if (f == 1) klo[r] = v; else kid[PACK ? 0 : r] = (uint32_t)v;
                         }
+                        if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
@@ -772,6 +783,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                         const uint32_t ai = PACK ? (uint32_t)(khi[r] >> 46) : kid[PACK ? 0 : r], bi = PACK ? (uint32_t)(ph >> 46) : pi;
                         off |= p46 > a46 || (p46 == a46 && (pl > klo[r] || (pl == klo[r] && bi > ai)));
                     }
+                    if (EW > 16 && (r & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
                 }
                 sorted = __ballot(off != 0) == 0ull;
                 if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
@@ -801,6 +813,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort_wave(uint64_t* __rest
                 x.id = ai;
                 it[a0 + idx] = x;
             }
+            if (EW > 16 && (r & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
         }
         for (int o = 32; o > 0; o >>= 1) { nk += __shfl_down(nk, o); np += __shfl_down(np, o); }
         if (lane == 0) counts[b] = ((uint64_t)nk << 32) | np;
@@ -1017,19 +1030,16 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     // The size of the largest bucket decides which workgroup variant the larger buckets need, and whether the buckets fit at all; it
     // travels to the host behind the split while the wavefront kernel -- whose own variant follows the MEAN bucket -- is already
     // running (a synchronisation in front of it left the GPU idle for ~0.15 ms).
-    hipEvent_t ev;
-    HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
-    hipError_t e = hipEventRecord(ev, s);
+    uint64_t ticket = 0;
+    CK(bft_pin_post(pin, s, &ticket));
     // the small buckets a wavefront each, the others a workgroup each (one after the other: on two streams the two kernels --
     // both latency-bound, different LDS footprints -- got in each other's way: 8.6 ms instead of 2.0 + 0.8)
     const uint32_t wave_cap = n / std::max(nb, 1u) <= 192u ? 512u : 1024u;
     const dim3 wgrid(std::min<uint32_t>((nb + FB_WAVES - 1) / FB_WAVES, 256u * 16u));
     if (wave_cap == 512u) hipLaunchKernelGGL(k_bucket_sort_wave<8>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
     else hipLaunchKernelGGL(k_bucket_sort_wave<16>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
-    if (e == hipSuccess) e = hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
-    HIPCK(e);
+    CK(bft_pin_wait_for(pin, s, ticket));
     const uint32_t mx = (uint32_t)pin.p[0];
     *max_bucket = mx;
     bft_trace_mark("root-prefix split done (largest bucket known)");
@@ -1045,7 +1055,7 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
     HIPCK(hipGetLastError());
     bft_stage("bucket sorts in LDS (+ scan of the counts)", (double)n * 16 + (d_vals ? (double)n * vw : 0.0), s);
-    HIPCK(hipStreamSynchronize(s));
+    CK(bft_pin_wait(pin, s));
     const uint64_t total = pin.p[1];
     if (n_redone) *n_redone = (uint32_t)pin.p[2];
     nk = total >> 32;
@@ -1083,9 +1093,8 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
     const dim3 block(FB_BLOCK);
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
-    hipEvent_t ev;
-    HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, s);
+    uint64_t ticket = 0;
+    CK(bft_pin_post(pin, s, &ticket));
     // (the size of the largest bucket travels to the host while the lists are made and the buckets of a wavefront each -- all of them, usually -- are sorted)
     hipLaunchKernelGGL(k_bucket2_lists, dim3((nb + FB_BLOCK - 1) / FB_BLOCK), block, 0, s, d_boff, nb, lists.as<uint32_t>(), n_lists.as<uint32_t>(), counts.as<uint64_t>());
     const uint32_t sh = (uint32_t)(2 * k - 64);
@@ -1103,9 +1112,7 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     FB2_WAVE(8, 0, 256u * 8u);
     FB2_WAVE(16, 1, 256u * 4u);
     FB2_WAVE(32, 2, 256u * 2u);
-    if (e == hipSuccess) e = hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
-    HIPCK(e);
+    CK(bft_pin_wait_for(pin, s, ticket));
     const uint32_t mx = (uint32_t)pin.p[0];
     *max_bucket = mx;
     if (mx > FB_BLOCK * 32) return 0;
@@ -1118,7 +1125,7 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, redone.as<uint32_t>(), pin.p + 3);
     HIPCK(hipGetLastError());
     bft_stage("two-word buckets: sorts in LDS (+ scan of the counts)", (double)n * 2 * 20, s);
-    HIPCK(hipStreamSynchronize(s));
+    CK(bft_pin_wait(pin, s));
     if (n_redone) *n_redone = (uint32_t)pin.p[3];
     if (pin.p[2] != 0) return 0;  // (a bucket beyond this front end: the caller sorts device-wide)
     const uint64_t total = pin.p[1];
