@@ -192,28 +192,36 @@ __device__ __forceinline__ void load_bucket(uint64_t (&key)[EMAX], const uint64_
 // EMAX: composites per thread, i.e. buckets of up to 256 EMAX composites (the host picks the smallest that holds the largest bucket:
 // the kernel is bound by the latency of its LDS round trips and barriers, and both the registers and the LDS of a workgroup -- hence
 // the workgroups a CU holds -- go with EMAX: 4 per CU at 16, 7 at 9)
-template <int EMAX>
+// REDO: the fallback launch -- the buckets on the `redo` list (*n_redone of them), ranks from ballots.  It is a launch of its own because the
+// ballot passes beside the atomic ones cost the kernel registers it then spills: a kernel that uses scratch memory starts ~0.13 ms late
+// whenever the kernels before it used none (the runtime hands a queue's scratch back and has to set it up again).
+template <int EMAX, bool REDO>
 __global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : EMAX <= 12 ? 4 : 3)) void k_bucket_sort(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
                                                           uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw, int mode, uint32_t* __restrict__ n_redone,
-                                                          uint32_t min_n) {  // buckets of up to min_n composites are k_bucket_sort_wave's
+                                                          uint32_t* __restrict__ redo, uint32_t min_n) {  // buckets of up to min_n composites are k_bucket_sort_wave's
     __shared__ uint64_t keys[FB_BLOCK * EMAX];
     __shared__ uint32_t cnt[FB_WAVES][FB_DIGITS];
     __shared__ uint32_t wtot[FB_WAVES];
     __shared__ uint32_t s_nk, s_np;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t n_items = REDO ? min(*n_redone, nb) : nb;
+    for (uint32_t bi = blockIdx.x; bi < n_items; bi += gridDim.x) {
+        const uint32_t b = REDO ? redo[bi] : bi;
         const uint32_t a0 = boff[b], n = boff[b + 1] - a0;
-        if (n <= min_n && min_n) continue;
+        if (!REDO && n <= min_n && min_n) continue;
         if (n == 0 || n > (uint32_t)(FB_BLOCK * EMAX)) {  // (buckets beyond the capacity are excluded by the caller: the whole build then takes the one-sort path)
             if (tid == 0) counts[b] = 0;
             continue;
         }
         const uint32_t E = (n + FB_BLOCK - 1) / FB_BLOCK;       // rounds
         const uint32_t wbase = wave * E * 64u;
+        if (!REDO && mode == 1 && lo_bit < hi_bit) {  // (ballots only: everything is the fallback's)
+            if (tid == 0) redo[atomicAdd(n_redone, 1u)] = b;
+            continue;
+        }
         uint64_t key[EMAX];
         load_bucket<EMAX>(key, c, vals, vw, a0, n, E, lo_bit, hi_bit);
-        bool sorted = false;
-        if (mode != 1 && lo_bit < hi_bit) {
+        if (!REDO && lo_bit < hi_bit) {
             radix_passes<false, EMAX>(key, keys, cnt, wtot, n, E, lo_bit, hi_bit);
             // In order over EVERY bit?  (The ids below lo_bit are not sorted on: equal k-mers must have kept their insertion order, i.e.
             // ascending ids, which only a stable sort does.)
@@ -223,13 +231,12 @@ __global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : EMAX <= 
                 const uint32_t idx = wbase + r * 64u + lane;
                 if (r < E && idx < n && idx) off |= keys[idx - 1] > key[r];
             }
-            sorted = __syncthreads_or(off) == 0;
-            if (!sorted) {
-                if (tid == 0) atomicAdd(n_redone, 1u);
-                load_bucket<EMAX>(key, c, vals, vw, a0, n, E, lo_bit, hi_bit);  // (the insertion order again)
+            if (__syncthreads_or(off) != 0) {  // out of order: the fallback launch sorts the bucket again, from the insertion order still in `c`
+                if (tid == 0) redo[atomicAdd(n_redone, 1u)] = b;
+                continue;
             }
         }
-        if (!sorted) radix_passes<true, EMAX>(key, keys, cnt, wtot, n, E, lo_bit, hi_bit);
+        if (REDO) radix_passes<true, EMAX>(key, keys, cnt, wtot, n, E, lo_bit, hi_bit);
         // duplicates against the left neighbour (the first composite of a bucket starts a k-mer: buckets differ in their top bits)
         if (tid == 0) { s_nk = 0; s_np = 0; }
         if (lo_bit >= hi_bit) {  // nothing was sorted (the split covered every T bit): the keys are only in registers yet
@@ -266,11 +273,10 @@ __global__ __launch_bounds__(FB_BLOCK, (EMAX <= 6 ? 6 : EMAX <= 9 ? 5 : EMAX <= 
 template <int EW>
 __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wave(uint64_t* __restrict__ c, const uint32_t* __restrict__ boff, uint32_t nb, uint32_t lo_bit, uint32_t hi_bit,
                                                                uint64_t* __restrict__ counts, const void* __restrict__ vals, uint32_t vw, int mode,
-                                                               uint32_t* __restrict__ n_redone) {
+                                                               uint32_t* __restrict__ n_redone, uint32_t* __restrict__ redo) {
     __shared__ uint64_t keys_all[FB_WAVES][64 * EW];
     __shared__ uint32_t cnt_all[FB_WAVES][FB_DIGITS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint64_t* keys = keys_all[wave];
     uint32_t* cnt = cnt_all[wave];
     for (uint32_t b = blockIdx.x * FB_WAVES + wave; b < nb; b += gridDim.x * FB_WAVES) {
@@ -281,9 +287,12 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
             continue;
         }
         const uint32_t E = (n + 63u) / 64u;  // rounds: slot (round r, lane l) = composite r 64 + l of the bucket
+        if (mode == 1 && lo_bit < hi_bit) {  // (ballots only: everything is the fallback launch's, k_bucket_sort<.., true>)
+            if (lane == 0) redo[atomicAdd(n_redone, 1u)] = b;
+            continue;
+        }
         uint64_t key[EW];
-        bool sorted = false;
-        for (int attempt = (mode == 1 ? 1 : 0); attempt < 2 && !sorted; attempt++) {  // 0: ranks from LDS atomics, checked; 1: from ballots (see radix_passes)
+        {   // ranks from LDS atomics, the order checked; a bucket that fails goes on the fallback launch's list
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                 const uint32_t idx = r * 64u + lane;
@@ -299,30 +308,18 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
 #pragma unroll
                 for (uint32_t j = 0; j < FB_DIGITS / 64; j++) cnt[lane * (FB_DIGITS / 64) + j] = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t rank[EW];
+                uint32_t rank2[(EW + 1) / 2];  // two 16-bit ranks per register (a bucket holds <= 1024 composites): at one rank per register the kernel
+#pragma unroll                                 // spills, and a kernel that uses scratch memory starts ~0.13 ms late behind kernels that use none
+                for (int j = 0; j < (EW + 1) / 2; j++) rank2[j] = 0;
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
-                    rank[r] = 0;
+                    uint32_t rk = 0;
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)(key[r] >> bit) & mask;
-                    if (attempt == 0 && bit > lo_bit) {
-                        rank[r] = rank_runs(cnt, d, valid, lane);
-                    } else if (attempt == 0) {
-                        if (valid) rank[r] = atomicAdd(&cnt[d], 1u);
-                    } else {
-                        const uint64_t peers = match_digit(d, valid, nbits);
-                        if (valid) {
-                            const int leader = __builtin_ctzll(peers);
-                            uint32_t base = 0;
-                            if ((int)lane == leader) {
-                                base = cnt[d];
-                                cnt[d] = base + (uint32_t)__builtin_popcountll(peers);
-                            }
-                            base = __shfl(base, leader);
-                            rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
-                        }
-                    }
+                    if (bit > lo_bit) rk = rank_runs(cnt, d, valid, lane);
+                    else if (valid) rk = atomicAdd(&cnt[d], 1u);
+                    rank2[r >> 1] |= rk << ((r & 1u) * 16u);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
                 {   // the lane's digits: counts -> starts
@@ -344,7 +341,7 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                     if (r >= E) continue;
-                    if (r * 64u + lane < n) keys[cnt[(uint32_t)(key[r] >> bit) & mask] + rank[r]] = key[r];
+                    if (r * 64u + lane < n) keys[cnt[(uint32_t)(key[r] >> bit) & mask] + ((rank2[r >> 1] >> ((r & 1u) * 16u)) & 0xFFFFu)] = key[r];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -362,17 +359,19 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            sorted = true;
-            if (attempt == 0 && lo_bit < hi_bit) {  // in order over EVERY bit (see k_bucket_sort)?
+            if (lo_bit < hi_bit) {  // in order over EVERY bit (see k_bucket_sort)?
                 int off = mode == 2;
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                     const uint32_t idx = r * 64u + lane;
                     if (r < E && idx < n && idx) off |= keys[idx - 1] > key[r];
                 }
-                sorted = __ballot(off != 0) == 0ull;
-                if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
+                const bool sorted = __ballot(off != 0) == 0ull;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (!sorted) {  // (nothing of this bucket has been written: `c` still holds the insertion order)
+                    if (lane == 0) redo[atomicAdd(n_redone, 1u)] = b;
+                    continue;
+                }
             }
         }
         uint32_t nk = 0, np = 0;
@@ -1025,8 +1024,9 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
     const dim3 grid(std::min<uint32_t>(nb, 256u * 16u)), block(FB_BLOCK);
-    DevBuf redone;
+    DevBuf redone, redo;  // buckets to sort again with ballot ranks: their number, their list
     CK(redone.alloc_zero(4, s));
+    CK(redo.alloc((size_t)nb * 4));
     // The size of the largest bucket decides which workgroup variant the larger buckets need, and whether the buckets fit at all; it
     // travels to the host behind the split while the wavefront kernel -- whose own variant follows the MEAN bucket -- is already
     // running (a synchronisation in front of it left the GPU idle for ~0.15 ms).
@@ -1037,20 +1037,23 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     // both latency-bound, different LDS footprints -- got in each other's way: 8.6 ms instead of 2.0 + 0.8)
     const uint32_t wave_cap = n / std::max(nb, 1u) <= 192u ? 512u : 1024u;
     const dim3 wgrid(std::min<uint32_t>((nb + FB_WAVES - 1) / FB_WAVES, 256u * 16u));
-    if (wave_cap == 512u) hipLaunchKernelGGL(k_bucket_sort_wave<8>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
-    else hipLaunchKernelGGL(k_bucket_sort_wave<16>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>());
+    if (wave_cap == 512u) hipLaunchKernelGGL(k_bucket_sort_wave<8>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>());
+    else hipLaunchKernelGGL(k_bucket_sort_wave<16>, wgrid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>());
     CK(bft_pin_wait_for(pin, s, ticket));
     const uint32_t mx = (uint32_t)pin.p[0];
     *max_bucket = mx;
     bft_trace_mark("root-prefix split done (largest bucket known)");
     if (mx > FB_CAP) return 0;
-#define FB_LAUNCH(E) hipLaunchKernelGGL(k_bucket_sort<E>, grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), wave_cap)
+#define FB_LAUNCH(E) hipLaunchKernelGGL((k_bucket_sort<E, false>), grid, block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>(), wave_cap)
     if (mx <= wave_cap) {}
     else if (mx <= 256u * 6u) FB_LAUNCH(6);
     else if (mx <= 256u * 9u) FB_LAUNCH(9);
     else if (mx <= 256u * 12u) FB_LAUNCH(12);
     else FB_LAUNCH(16);
 #undef FB_LAUNCH
+    // the fallback launch: the buckets whose order check failed (none, on every run so far), or all of them ("test_front_rank_mode" 1)
+    hipLaunchKernelGGL((k_bucket_sort<FB_EMAX, true>), dim3(g_rank_mode ? grid.x : 64u), block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode,
+                       redone.as<uint32_t>(), redo.as<uint32_t>(), 0u);
     CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
     HIPCK(hipGetLastError());

@@ -354,7 +354,11 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
     auto load_tile = [&](uint32_t c, uint32_t j) {
         uint32_t rem;
         if (RANGED) { a0 = j * (uint32_t)TILE; rem = n - a0; }
-        else { a0 = chain_start[c] + j * (uint32_t)TILE; rem = chain_start[c + 1] - a0; }
+        else {
+            const uint32_t cs0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_start[c]), cs1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_start[c + 1]);
+            a0 = cs0 + j * (uint32_t)TILE;
+            rem = cs1 - a0;
+        }
         tile_n = rem < (uint32_t)TILE ? rem : (uint32_t)TILE;
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             if (lane == 0) { shd[0] = cc; shd[1] = jj; }
         }
         __syncthreads();
-        cur_c = shd[0];
-        cur_j = shd[1];
+        cur_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[0]);  // (uniform: scalar registers, not one vector register per value)
+        cur_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[1]);
         if (cur_c == NONE) return;
     }
     load_tile(cur_c, cur_j);
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         uint32_t nxt_c = 0, nxt_j = 0;
         bool more;
         if (RANGED) { nxt_j = cur_j + 1; more = nxt_j < rt_end; }
-        else { nxt_c = shd[0]; nxt_j = shd[1]; more = nxt_c != NONE; }
+        else { nxt_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[0]); nxt_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[1]); more = nxt_c != NONE; }
         // ---- per digit: counts of the waves -> starts of (digit, wave) relative to the digit; the digit's total
         uint32_t s[DPT], tot = 0, inc = 0;
         if (tid < DT) {
@@ -1014,9 +1018,10 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
             constexpr int GMAX = THREADS / (DIGITS / 4);
             const uint32_t nchp = 1u << pl.cb[p];
             uint32_t grid = std::min<uint32_t>(tiles + nchp, (uint32_t)(cus * per_cu));
-            if (grid <= nchp * 4u) {
-                if (ballot) BFT_RS_LAUNCH1(true, 1);
-                else BFT_RS_LAUNCH1(false, 1);
+            // (the one-group form only where it uses no scratch memory -- the ballot variants, which are a fallback anyway: a kernel with scratch
+            // starts ~0.13 ms late behind kernels without, and the atomic-rank form with one group spills five registers)
+            if (grid <= nchp * 4u && ballot) {
+                BFT_RS_LAUNCH1(true, 1);
             } else {
                 grid = std::min<uint32_t>(grid, nchp * 4u * GMAX);
                 if (ballot) BFT_RS_LAUNCH1(true, GMAX);
@@ -1053,6 +1058,8 @@ int sort(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned beg
         constexpr int IPT = E <= 8 ? 8 : E <= 12 ? 5 : E <= 16 ? 4 : E <= 24 ? 3 : E <= 32 ? 2 : 1;
         return sort_cfg<K, V, In, 1024, IPT>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);
     } else {
+        // (ten 8-byte keys per thread, not twelve: at twelve the chained pass spills two registers, and a kernel that uses scratch memory starts
+        // ~0.13 ms late whenever the kernels before it used none -- the runtime hands the queue's scratch back and has to find it again)
         constexpr int IPT_BIG = E <= 8 ? 12 : E <= 12 ? 8 : E <= 16 ? 6 : E <= 24 ? 4 : E <= 32 ? 3 : 2;
 #ifdef BFT_RS_BIG_IPT
         return sort_cfg<K, V, In, BFT_RS_BIG_THREADS, (E <= 8 ? BFT_RS_BIG_IPT : IPT_BIG)>(in, n, out_k, out_v, tmp_k, tmp_v, begin_bit, end_bit, s, scratch, last_dbase);

@@ -505,9 +505,9 @@ def test_interning_when_nearly_every_colour_set_is_distinct():
                                     (9, [0, 1, 2])])
 def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
     """A root-prefix bucket ranks its digits with one LDS atomic per key, checks the final order over every bit -- k-mers ascending,
-    the ids of a k-mer in insertion order -- and is sorted again with ballot ranks (stable by construction) when the check fails
-    (bft_front.hip: a wavefront per bucket up to 1024 composites, a workgroup per larger one).  "test_front_rank_mode": 0 as shipped,
-    1 ballots only, 2 the check always fails (every bucket is sorted twice).  Image, extraction and colour sets are those of the
+    the ids of a k-mer in insertion order -- and goes on a list when the check fails: a second launch sorts the listed buckets again with
+    ballot ranks (stable by construction; bft_front.hip: a wavefront per bucket up to 1024 composites, a workgroup per larger one, one
+    fallback kernel).  "test_front_rank_mode": 0 as shipped, 1 ballots only, 2 the check always fails (every bucket is sorted twice).  Image, extraction and colour sets are those of the
     device-wide sort in every mode -- composites that fit 63 bits and those that only fit inside a bucket (k = 31; ids of one, two
     and four bytes) --; as shipped no bucket fails the check."""
     n_pref = 40
@@ -541,8 +541,10 @@ def test_bucket_sort_rank_modes_build_the_same_image(k, gids):
         for name in ARRAYS:
             assert (a[0][name] == b[0][name]).all(), name
         assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
-    assert redone[0] == 0 and redone[1] == 0 and redone[2] == 0, redone
-    assert redone[3] >= n_pref if k > 9 else redone[3] == 0, redone  # (k = 9: the split covers every bit, nothing is sorted in a bucket)
+    assert redone[0] == 0 and redone[1] == 0, redone  # as shipped no bucket fails the check
+    # (the ballot ranks are a launch of their own over a list of buckets: mode 1 puts every bucket on it unsorted, mode 2 after a sort whose check
+    # is made to fail; k = 9: the split covers every bit, nothing is sorted in a bucket)
+    assert (redone[2] >= n_pref and redone[3] >= n_pref) if k > 9 else (redone[2] == 0 and redone[3] == 0), redone
 
 
 def test_k32_builds_through_the_device_wide_sort_when_buckets_are_forced():
