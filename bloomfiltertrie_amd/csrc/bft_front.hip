@@ -648,11 +648,10 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_tiny(uint64_t* __restrict_
 // PACK: genome ids below 2^18 ride in the 18 free bits on top of hk's 46: four registers and two exchanged words per item instead of five and three
 template <int EW, bool PACK>
 __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 2)) void k_bucket2_sort_wave(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
-                                                                const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone) {
+                                                                const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone, uint32_t* __restrict__ redo) {
     __shared__ uint64_t buf_all[FB_WAVES][64 * EW];
     __shared__ uint32_t cnt_all[FB_WAVES][FB_DIGITS];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint64_t m46 = (1ull << 46) - 1ull;
     uint64_t* buf = buf_all[wave];
     uint32_t* cnt = cnt_all[wave];
@@ -662,8 +661,11 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
         const uint32_t E = (n + 63u) / 64u;  // rounds: slot (round r, lane l) = item r 64 + l of the bucket
         uint64_t khi[EW], klo[EW];
         uint32_t kid[PACK ? 1 : EW];
-        bool sorted = false;
-        for (int attempt = (mode == 1 ? 1 : 0); attempt < 2 && !sorted; attempt++) {  // 0: ranks from LDS atomics, checked; 1: from ballots
+        if (mode == 1) {  // (ballots only: everything is the fallback launch's, k_bucket2_sort<32, true>)
+            if (lane == 0) redo[atomicAdd(n_redone, 1u)] = b;
+            continue;
+        }
+        {   // ranks from LDS atomics, the order checked; a bucket that fails goes on the fallback launch's list
 #pragma unroll
             for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                 const uint32_t idx = r * 64u + lane;
@@ -695,24 +697,8 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
                     const bool valid = r * 64u + lane < n;
                     const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
                     uint32_t rk = 0;
-                    if (FB2_RUNS && attempt == 0 && p) {
-                        rk = rank_runs(cnt, d, valid, lane);
-                    } else if (attempt == 0) {
-                        if (valid) rk = atomicAdd(&cnt[d], 1u);
-                    } else {
-                        const uint64_t peers = match_digit(d, valid, nbits);
-                        if (valid) {
-                            const int leader = __builtin_ctzll(peers);
-                            uint32_t base = 0;
-                            if ((int)lane == leader) {
-                                base = cnt[d];
-                                cnt[d] = base + (uint32_t)__builtin_popcountll(peers);
-                            }
-                            base = __shfl(base, leader);
-                            rk = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    }
+                    if (FB2_RUNS && p) rk = rank_runs(cnt, d, valid, lane);
+                    else if (valid) rk = atomicAdd(&cnt[d], 1u);
                     rank2[r >> 1] |= rk << ((r & 1u) * 16u);
                     if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);  // (bounds what the scheduler keeps in flight: registers)
                 }
@@ -761,8 +747,7 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
             }
-            sorted = true;
-            if (attempt == 0) {  // in order over the key AND the ids (a stable sort keeps equal k-mers in insertion order: ascending ids)?
+            {   // in order over the key AND the ids (a stable sort keeps equal k-mers in insertion order: ascending ids)?
                 int off = mode == 2;
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
@@ -784,8 +769,10 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
                     }
                     if (EW > 16 && (r & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
                 }
-                sorted = __ballot(off != 0) == 0ull;
-                if (!sorted && lane == 0) atomicAdd(n_redone, 1u);
+                if (__ballot(off != 0) != 0ull) {  // (nothing of the bucket has been written: the fallback launch starts from the insertion order)
+                    if (lane == 0) redo[atomicAdd(n_redone, 1u)] = b;
+                    continue;
+                }
             }
         }
         uint32_t nk = 0, np = 0;
@@ -821,10 +808,11 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
 }
 
 // mode as k_bucket_sort's: 0 = ranks from LDS atomics, the order checked, ballots on failure; 1 = ballots only; 2 = the check always fails
-template <int EMAX>
+// REDO: the fallback launch over the `redo` list (ballot ranks), as k_bucket_sort's.
+template <int EMAX, bool REDO>
 __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort(uint64_t* __restrict__ hk, BftItem2* __restrict__ it, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ n_list, uint32_t sh, uint64_t* __restrict__ counts, int mode, uint32_t* __restrict__ n_redone,
-                                                           uint32_t* __restrict__ fail) {
+                                                           uint32_t* __restrict__ redo, uint32_t* __restrict__ fail) {
     constexpr uint32_t CAP = FB_BLOCK * EMAX;
     __shared__ uint64_t buf8[CAP];
     __shared__ uint32_t buf4[CAP];
@@ -891,17 +879,19 @@ __global__ __launch_bounds__(FB_BLOCK) void k_bucket2_sort(uint64_t* __restrict_
             }
             return __syncthreads_or(off);
         };
-        load();
-        bool sorted = false;
-        if (mode != 1) {
-            radix_passes2<false, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
-            sorted = !(out_of_order() | (mode == 2));
-            if (!sorted) {
-                if (tid == 0) atomicAdd(n_redone, 1u);
-                load();  // (the insertion order again)
-            }
+        if (!REDO && mode == 1) {  // (ballots only: everything is the fallback launch's)
+            if (tid == 0) redo[atomicAdd(n_redone, 1u)] = b;
+            continue;
         }
-        if (!sorted) radix_passes2<true, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
+        load();
+        if (!REDO) {
+            radix_passes2<false, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
+            if (out_of_order() | (mode == 2)) {  // (nothing of the bucket has been written: the fallback launch starts from the insertion order)
+                if (tid == 0) redo[atomicAdd(n_redone, 1u)] = b;
+                continue;
+            }
+        } else
+            radix_passes2<true, EMAX>(khi, klo, kid, sh, buf8, buf4, cnt, wtot, n, E);
         // duplicates against the left neighbour; the bucket back in place, sorted
         if (tid == 0) { s_nk = 0; s_np = 0; }
 #pragma unroll
@@ -1086,11 +1076,12 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     BftItem2* d_it = (BftItem2*)d_items;
     PinBlock pin;  // [0] the largest bucket, [1] k-mers << 32 | pairs, [2] buckets that failed, [3] buckets sorted again
     if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (front end counts)");
-    DevBuf counts, bases, tmp, fail, redone, lists, n_lists;
+    DevBuf counts, bases, tmp, fail, redone, redo, lists, n_lists;
     CK(counts.alloc(((uint64_t)nb + 1) * 8));
     CK(bases.alloc(((uint64_t)nb + 1) * 8));
     CK(fail.alloc_zero(4, s));
     CK(redone.alloc_zero(4, s));
+    CK(redo.alloc((size_t)nb * 4));  // (buckets to sort again with ballot ranks)
     CK(lists.alloc((size_t)FB2_CLASSES * nb * 4));
     CK(n_lists.alloc_zero(32, s));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
@@ -1104,13 +1095,13 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
 #define FB2_WAVE(EW_, CLS, GRID)                                                                                                                                                \
     do {                                                                                                                                                                       \
         if (pack) hipLaunchKernelGGL((k_bucket2_sort_wave<EW_, true>), dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, \
-                                     counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>());                                                                               \
+                                     counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>());                                                          \
         else hipLaunchKernelGGL((k_bucket2_sort_wave<EW_, false>), dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh,   \
-                                counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>());                                                                                    \
+                                counts.as<uint64_t>(), g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>());                                                               \
     } while (0)
 #define FB2_LAUNCH(EM, CLS, GRID)                                                                                                                                           \
-    hipLaunchKernelGGL(k_bucket2_sort<EM>, dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
-                       g_rank_mode, redone.as<uint32_t>(), fail.as<uint32_t>())
+    hipLaunchKernelGGL((k_bucket2_sort<EM, false>), dim3(GRID), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)CLS * nb, n_lists.as<uint32_t>() + CLS, sh, counts.as<uint64_t>(), \
+                       g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>(), fail.as<uint32_t>())
     hipLaunchKernelGGL(k_bucket2_tiny, dim3(256u * 8u), block, 0, s, d_hk, d_it, d_boff, lists.as<uint32_t>() + (size_t)5 * nb, n_lists.as<uint32_t>() + 5, counts.as<uint64_t>());
     FB2_WAVE(8, 0, 256u * 8u);
     FB2_WAVE(16, 1, 256u * 4u);
@@ -1123,6 +1114,9 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     if (mx > 4096u) FB2_LAUNCH(32, 4, 256u * 2u);
 #undef FB2_WAVE
 #undef FB2_LAUNCH
+    // the fallback launch: the buckets whose order check failed (none, on every run so far), or all of them ("test_front_rank_mode" 1): the list is `redo`
+    hipLaunchKernelGGL((k_bucket2_sort<32, true>), dim3(g_rank_mode ? 256u * 2u : 32u), block, 0, s, d_hk, d_it, d_boff, redo.as<uint32_t>(), redone.as<uint32_t>(), sh, counts.as<uint64_t>(),
+                       g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>(), fail.as<uint32_t>());
     CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, fail.as<uint32_t>(), pin.p + 1);
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, redone.as<uint32_t>(), pin.p + 3);
