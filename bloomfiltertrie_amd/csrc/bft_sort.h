@@ -149,7 +149,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_hist(In in, uint32_t n, Plan pl,
 }
 
 // the chain counters of the later passes: cnt[w] += sum over a slice of the histogram workgroups (grid.y slices; cnt zeroed)
-static inline __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t stride, uint32_t first, uint32_t words, uint32_t* __restrict__ cnt) {
+[[maybe_unused]] static __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t* __restrict__ partial, uint32_t nwg, uint32_t stride, uint32_t first, uint32_t words, uint32_t* __restrict__ cnt) {
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
     const uint32_t per = (nwg + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * per, g1 = min(nwg, g0 + per);
@@ -161,7 +161,7 @@ static inline __global__ __launch_bounds__(256) void k_rs_reduce(const uint32_t*
 
 // One workgroup per (digit, pass): exclusive scan of the digit's counts over the rows (ranges of pass 0 -- in place in the histogram
 // workgroups' blocks --, chains of a later pass), in place; the digit's total.  rows <= 1024.
-static inline __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ partial, uint32_t* __restrict__ cnt, Plan pl, uint32_t ranges, uint32_t* __restrict__ tot_all) {
+[[maybe_unused]] static __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ partial, uint32_t* __restrict__ cnt, Plan pl, uint32_t ranges, uint32_t* __restrict__ tot_all) {
     __shared__ uint32_t wsum[4];
     const uint32_t d = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (d >= (1u << pl.nbits[p])) return;
@@ -197,7 +197,7 @@ static inline __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __re
 // One workgroup per pass: where every digit starts in the pass's output; the chains and tiles of the NEXT pass.
 // chain table of a pass: start[65], tile_first[65]
 constexpr int CT = 2 * ((1 << MAXCB) + 1);
-static inline __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict__ tot, uint32_t* __restrict__ dbase, uint32_t* __restrict__ chain, Plan pl, uint32_t n, uint32_t tile) {
+[[maybe_unused]] static __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32_t* __restrict__ tot, uint32_t* __restrict__ dbase, uint32_t* __restrict__ chain, Plan pl, uint32_t n, uint32_t tile) {
     __shared__ uint32_t wsum[DIGITS / 64];
     __shared__ uint32_t db[DIGITS + 1];
     const uint32_t p = blockIdx.x, d = threadIdx.x, lane = d & 63u, wave = d >> 6, nd = 1u << pl.nbits[p];
@@ -239,7 +239,7 @@ static inline __global__ __launch_bounds__(DIGITS) void k_rs_digits(const uint32
 }
 
 // ---- do the lanes of one LDS atomic instruction that hit one address get their turns in lane order? ------------------------------------
-static inline __global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) {
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_rs_selftest(uint32_t* __restrict__ bad) {
     __shared__ uint32_t c[64];
     const uint32_t lane = threadIdx.x;
     uint32_t wrong = 0;
