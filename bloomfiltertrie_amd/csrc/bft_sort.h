@@ -46,6 +46,14 @@
 #define BFT_RS_BIG_THREADS 1024
 #endif
 
+#ifndef BFT_RS_RFL
+#define BFT_RS_RFL 1
+#endif
+#if BFT_RS_RFL
+#define BFT_RS_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define BFT_RS_UNI(x) (x)
+#endif
 namespace bft_rs {
 
 constexpr int DBITS = 9;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         uint32_t rem;
         if (RANGED) { a0 = j * (uint32_t)TILE; rem = n - a0; }
         else {
-            const uint32_t cs0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_start[c]), cs1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_start[c + 1]);
+            const uint32_t cs0 = BFT_RS_UNI(chain_start[c]), cs1 = BFT_RS_UNI(chain_start[c + 1]);
             a0 = cs0 + j * (uint32_t)TILE;
             rem = cs1 - a0;
         }
@@ -426,8 +434,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
             if (lane == 0) { shd[0] = cc; shd[1] = jj; }
         }
         __syncthreads();
-        cur_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[0]);  // (uniform: scalar registers, not one vector register per value)
-        cur_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[1]);
+        cur_c = BFT_RS_UNI(shd[0]);  // (uniform: scalar registers, not one vector register per value)
+        cur_j = BFT_RS_UNI(shd[1]);
         if (cur_c == NONE) return;
     }
     load_tile(cur_c, cur_j);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(In in, K* __restrict__ ok, 
         uint32_t nxt_c = 0, nxt_j = 0;
         bool more;
         if (RANGED) { nxt_j = cur_j + 1; more = nxt_j < rt_end; }
-        else { nxt_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[0]); nxt_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)shd[1]); more = nxt_c != NONE; }
+        else { nxt_c = BFT_RS_UNI(shd[0]); nxt_j = BFT_RS_UNI(shd[1]); more = nxt_c != NONE; }
         // ---- per digit: counts of the waves -> starts of (digit, wave) relative to the digit; the digit's total
         uint32_t s[DPT], tot = 0, inc = 0;
         if (tid < DT) {
@@ -838,6 +846,18 @@ static inline void lds_limit(int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done[0] |= 1u << dev;
 }
+// does the kernel use scratch memory (spilled registers)?  Asked once per kernel.  A kernel that does starts ~0.13 ms late behind kernels that do not
+// (the runtime sets the queue's scratch up again at the dispatch): where there is a choice, the variant without is launched.
+template <auto KERNEL>
+static inline bool uses_scratch() {
+    static int known = -1;
+    if (known < 0) {
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(KERNEL)) == hipSuccess) known = at.localSizeBytes > 0 ? 1 : 0;
+        else { known = 1; (void)hipGetLastError(); }
+    }
+    return known == 1;
+}
 static inline int cu_count() {
     static int n = 0;
     if (!n) {
@@ -1018,10 +1038,12 @@ int sort_cfg(In in, uint64_t n, K* out_k, V* out_v, K* tmp_k, V* tmp_v, unsigned
             constexpr int GMAX = THREADS / (DIGITS / 4);
             const uint32_t nchp = 1u << pl.cb[p];
             uint32_t grid = std::min<uint32_t>(tiles + nchp, (uint32_t)(cus * per_cu));
-            // (the one-group form only where it uses no scratch memory -- the ballot variants, which are a fallback anyway: a kernel with scratch
-            // starts ~0.13 ms late behind kernels without, and the atomic-rank form with one group spills five registers)
+            // (the one-group form where the grid is small enough for it -- unless it uses scratch memory: for 8-byte keys without a payload it
+            // spills five registers, the eight-group form none, and a kernel with scratch starts ~0.13 ms late behind kernels without)
             if (grid <= nchp * 4u && ballot) {
                 BFT_RS_LAUNCH1(true, 1);
+            } else if (grid <= nchp * 4u && !ballot && !uses_scratch<&k_rs_pass<K, V, PtrIn<K, V>, THREADS, IPT, false, false, 1>>()) {
+                BFT_RS_LAUNCH1(false, 1);
             } else {
                 grid = std::min<uint32_t>(grid, nchp * 4u * GMAX);
                 if (ballot) BFT_RS_LAUNCH1(true, GMAX);
