@@ -132,45 +132,58 @@ __global__ void k_sizes(const uint32_t* lo, const uint32_t* hi, uint32_t* sz, ui
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) sz[m] = hi[m] - lo[m];
 }
 
-// head[j] = row j starts a new prefix of its node; khead[j] = ... a new Bloom key
+// Row j of a depth's active rows starts a new prefix of its node (h) / a new Bloom key (kh): the input of ONE exclusive scan, both counts in a
+// word -- h << 31 | kh, either sum below 2^31 --, computed from the table's neighbouring rows as the scan reads them (bft_scan.h takes a functor).
+// Flag arrays, two scans and their four arrays of positions were 48 bytes per row; this is 8 (the T-form) in and 8 out.
+constexpr uint64_t PF_KMASK = (1ull << 31) - 1ull;
 template <int W>
-__global__ void k_prefix_flags(const uint64_t* __restrict__ tk, int k, int d, const uint32_t* __restrict__ nd_lo,
-                               const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, uint32_t* __restrict__ head,
-                               uint32_t* __restrict__ khead) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < A; j += gridDim.x * blockDim.x) {
-        const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
-        const uint32_t row = nd_lo[m] + (j - node_off[m]);
+struct PrefixFlagsIn {
+    const uint64_t* tk;
+    int k, d;
+    const uint32_t* nd_lo;
+    const uint32_t* node_off;
+    uint32_t M;
+    __device__ __forceinline__ uint64_t operator()(uint64_t j) const {
+        const uint32_t m = M == 1 ? 0u : find_node(node_off, M, (uint32_t)j);
+        const uint32_t row = nd_lo[m] + ((uint32_t)j - node_off[m]);
         const uint32_t r = bft_digit<W>(tk + (size_t)row * W, k, d);
-        uint32_t h = 1, kh = 1;
+        uint64_t h = 1, kh = 1;
         if (row != nd_lo[m]) {
             const uint32_t rp = bft_digit<W>(tk + (size_t)(row - 1) * W, k, d);
             h = r != rp;
             kh = (r >> 4) != (rp >> 4);
         }
-        head[j] = h;
-        khead[j] = kh;
+        return (h << 31) | kh;
     }
-}
+};
 
+// pos[j] = prefixes << 31 | keys in front of row j (pos[A] = the totals): a row whose prefix count grows is a prefix's first, likewise its key
 template <int W>
 __global__ void k_prefix_scatter(const uint64_t* __restrict__ tk, int k, int d, const uint32_t* __restrict__ nd_lo,
-                                 const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, const uint32_t* __restrict__ head,
-                                 const uint32_t* __restrict__ khead, const uint32_t* __restrict__ ppos, const uint32_t* __restrict__ kpos,
+                                 const uint32_t* __restrict__ node_off, uint32_t M, uint32_t A, const uint64_t* __restrict__ pos,
                                  uint32_t* __restrict__ pref_r, uint32_t* __restrict__ pref_row, uint32_t* __restrict__ pref_node,
                                  uint32_t* __restrict__ pref_key, uint32_t* __restrict__ key_val, uint32_t* __restrict__ key_row,
                                  uint32_t* __restrict__ key_node, uint32_t* __restrict__ node_kb) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < A; j += gridDim.x * blockDim.x) {
-        if (!head[j]) continue;
+    // (a row's own word by one coalesced load; the next row's from the neighbouring lane, by a load only in a wavefront's last lane)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < A; j0 += gridDim.x * blockDim.x) {  // (whole wavefronts take part in the shuffles)
+        const uint32_t j = j0 + threadIdx.x;
+        const uint64_t p0 = j <= A ? pos[j] : 0ull;
+        uint64_t p1 = ((uint64_t)(uint32_t)__shfl_down((uint32_t)(p0 >> 32), 1) << 32) | (uint32_t)__shfl_down((uint32_t)p0, 1);
+        if (lane == 63u && j < A) p1 = pos[j + 1];
+        if (j >= A) continue;
+        const uint32_t p = (uint32_t)(p0 >> 31), kp = (uint32_t)(p0 & PF_KMASK);
+        if ((uint32_t)(p1 >> 31) == p) continue;  // (not the first row of a prefix)
+        const bool khd = (uint32_t)(p1 & PF_KMASK) != kp;
         const uint32_t m = M == 1 ? 0u : find_node(node_off, M, j);
         const uint32_t row = nd_lo[m] + (j - node_off[m]);
         const uint32_t r = bft_digit<W>(tk + (size_t)row * W, k, d);
-        const uint32_t p = ppos[j];
-        const uint32_t kk = kpos[j] + khead[j] - 1;
+        const uint32_t kk = kp + (khd ? 1u : 0u) - 1u;
         pref_r[p] = r;
         pref_row[p] = row;
         pref_node[p] = m;
         pref_key[p] = kk;
-        if (khead[j]) {
+        if (khd) {
             key_val[kk] = r >> 4;
             key_row[kk] = row;
             key_node[kk] = m;
@@ -640,23 +653,19 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         const std::string lv = "containers depth " + std::to_string(d) + ": ";
         bft_stage((lv + "active rows").c_str(), (double)M * 12, s);
         // ---- prefixes and keys ----
-        DevBuf head, khead, ppos, kpos;
-        CK(head.alloc(A * 4));
-        CK(khead.alloc(A * 4));
-        CK(ppos.alloc(A * 4));
-        CK(kpos.alloc(A * 4));
+        DevBuf pos;  // [A + 1] prefixes << 31 | keys in front of every active row
+        CK(pos.alloc((A + 1) * 8));
         uint64_t P = 0, K = 0;
         if (A) {
-            hipLaunchKernelGGL(k_prefix_flags<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
-                               head.as<uint32_t>(), khead.as<uint32_t>());
-            CK(scan.enqueue(head.as<uint32_t>(), ppos.as<uint32_t>(), A, 0));
-            CK(scan.enqueue(khead.as<uint32_t>(), kpos.as<uint32_t>(), A, 1));
+            if (!scan.pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (scan totals)");
+            const PrefixFlagsIn<W> pf{tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M};
+            CK((bft_scan::exclusive_sum<uint64_t>(pf, pos.as<uint64_t>(), A, s, scan.tmp, (unsigned long long*)(scan.pin.p + 0), true)));
             CK(scan.wait());
-            P = scan.get(0);
-            K = scan.get(1);
+            P = scan.get(0) >> 31;
+            K = scan.get(0) & PF_KMASK;
         }
         bft_trace_mark("  level: prefix flags + scans");
-        bft_stage((lv + "prefix flags + scans").c_str(), (double)A * (8.0 * W + 8 + 16), s);
+        bft_stage((lv + "prefix flags + scans").c_str(), (double)A * (8.0 * W + 8), s);
         DevBuf pref_r, pref_row, pref_node, pref_key, pref_cnt, key_val, key_row, key_node, key_cnt, node_kb;
         CK(pref_r.alloc(P * 4));
         CK(pref_row.alloc(P * 4));
@@ -682,13 +691,13 @@ int assemble(const uint64_t* tk, uint64_t n, int k, const uint32_t* hashmod, hip
         }
         if (A) {
             hipLaunchKernelGGL(k_prefix_scatter<W>, G(A), tk, k, d, nd_lo.as<uint32_t>(), node_off.as<uint32_t>(), (uint32_t)M, (uint32_t)A,
-                               head.as<uint32_t>(), khead.as<uint32_t>(), ppos.as<uint32_t>(), kpos.as<uint32_t>(), pref_r.as<uint32_t>(),
+                               pos.as<uint64_t>(), pref_r.as<uint32_t>(),
                                pref_row.as<uint32_t>(), pref_node.as<uint32_t>(), pref_key.as<uint32_t>(), key_val.as<uint32_t>(),
                                key_row.as<uint32_t>(), key_node.as<uint32_t>(), node_kb.as<uint32_t>());
             hipLaunchKernelGGL(k_counts, G(P), pref_row.as<uint32_t>(), pref_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)P, pref_cnt.as<uint32_t>());
             hipLaunchKernelGGL(k_counts, G(K), key_row.as<uint32_t>(), key_node.as<uint32_t>(), nd_hi.as<uint32_t>(), (uint32_t)K, key_cnt.as<uint32_t>());
         }
-        head.release(); khead.release(); ppos.release(); kpos.release();
+        pos.release();
 
         // ---- CC assignment: one pass.  A node opens a CC only while >= 255 k-mers are unassigned and every CC but the last claims at
         // least 255, so a node of U k-mers holds at most U / 255 + 1 CCs: the Bloom bitsets are written at those upper-bound slots
