@@ -33,10 +33,13 @@ __global__ void k_pin_ticket(uint64_t* __restrict__ slot, uint64_t v) {
     __threadfence_system();
     *reinterpret_cast<volatile uint64_t*>(slot) = v;
 }
-int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket) {
+uint64_t bft_pin_next_ticket() {
     static std::atomic<uint64_t> tickets{0};
+    return tickets.fetch_add(1) + 1;
+}
+int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket) {
     if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (pinned counts)");
-    *ticket = tickets.fetch_add(1) + 1;
+    *ticket = bft_pin_next_ticket();
     hipLaunchKernelGGL(k_pin_ticket, dim3(1), dim3(1), 0, s, pin.p + PIN_SLOTS, *ticket);
     HIPCK(hipGetLastError());
     return 0;
@@ -76,6 +79,13 @@ __global__ void k_set32(uint32_t* __restrict__ p, uint32_t v) { *p = v; }
 __global__ void k_publish(const uint32_t* __restrict__ v, int n, uint64_t* __restrict__ slots) {
     if ((int)threadIdx.x < n) slots[threadIdx.x] = v[threadIdx.x];
 }
+// the same, and behind the values the block's ticket (bft_pin_wait_for): the launch the host waits for
+__global__ void k_publish_ticket(const uint32_t* __restrict__ v, int n, uint64_t* __restrict__ slots, uint64_t* __restrict__ ticket_slot, uint64_t ticket) {
+    if ((int)threadIdx.x < n) slots[threadIdx.x] = v[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile uint64_t*>(ticket_slot) = ticket;
+}
 
 struct Scan {
     DevBuf tmp;
@@ -94,13 +104,32 @@ struct Scan {
         CK(bft_scan::exclusive_sum_ptr<uint32_t>(in, out, n, s, tmp, (unsigned long long*)(pin.p + slot), tail));  // (the last tile writes the total)
         return 0;
     }
-    // n <= PIN_SLOTS device words -> slots [slot, slot + n)
+    // n <= PIN_SLOTS device words -> slots [slot, slot + n).  The launch is made by wait() (it carries the ticket the host polls for: one launch
+    // instead of two) or by the next publish(): the words are read when it runs, behind everything enqueued until then.
+    const uint32_t* pend_vals = nullptr;
+    int pend_n = 0, pend_slot = 0;
+    int flush() {
+        if (pend_vals) hipLaunchKernelGGL(k_publish, dim3(1), dim3(PIN_SLOTS), 0, s, pend_vals, pend_n, pin.p + pend_slot);
+        pend_vals = nullptr;
+        return 0;
+    }
     int publish(const uint32_t* d_vals, int n, int slot) {
         if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (scan totals)");
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(PIN_SLOTS), 0, s, d_vals, n, pin.p + slot);
+        CK(flush());
+        pend_vals = d_vals;
+        pend_n = n;
+        pend_slot = slot;
         return 0;
     }
     int wait() {
+        if (pend_vals) {
+            if (!pin.p) return bft_fail(BFT_GPU_E_HIP, "hipHostMalloc (scan totals)");
+            const uint64_t ticket = bft_pin_next_ticket();
+            hipLaunchKernelGGL(k_publish_ticket, dim3(1), dim3(PIN_SLOTS), 0, s, pend_vals, pend_n, pin.p + pend_slot, pin.p + PIN_SLOTS, ticket);
+            pend_vals = nullptr;
+            HIPCK(hipGetLastError());
+            return bft_pin_wait_for(pin, s, ticket);
+        }
         HIPCK(hipGetLastError());
         return bft_pin_wait(pin, s);
     }

@@ -86,6 +86,7 @@ int bft_pin_wait(PinBlock& pin, hipStream_t s);
 // the same in two steps: the ticket enqueued here, waited for later (what is enqueued in between is not waited for; one ticket in flight per block)
 int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket);
 int bft_pin_wait_for(PinBlock& pin, hipStream_t s, uint64_t ticket);
+uint64_t bft_pin_next_ticket();  // (for a kernel of the caller's that writes the ticket itself, behind its own results: pin.p[PIN_SLOTS], after __threadfence_system())
 struct PinBlock {
     uint64_t* p = nullptr;
     PinBlock() {

@@ -392,9 +392,15 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 5 : 4)) void k_bucket_sort_wav
 }
 
 // what the host waits for: slots[0] = *a (when given), slots[1] = *b
-__global__ void k_front_publish(const uint64_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t* __restrict__ slots) {
+// ticket != 0: the block's ticket behind the values (what the host polls for: bft_pin_wait_for)
+__global__ void k_front_publish(const uint64_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t* __restrict__ slots, uint64_t* __restrict__ ticket_slot = nullptr,
+                                uint64_t ticket = 0) {
     if (a) { slots[0] = *a; slots[1] = *b; }
     else slots[0] = *b;
+    if (ticket) {
+        __threadfence_system();
+        *reinterpret_cast<volatile uint64_t*>(ticket_slot) = ticket;
+    }
 }
 
 // bases[b] = exclusive scan of counts (k-mers << 32 | pairs).  Every bucket places its k-mers (T = c >> gb), the offset of each k-mer's
@@ -1020,9 +1026,8 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     // The size of the largest bucket decides which workgroup variant the larger buckets need, and whether the buckets fit at all; it
     // travels to the host behind the split while the wavefront kernel -- whose own variant follows the MEAN bucket -- is already
     // running (a synchronisation in front of it left the GPU idle for ~0.15 ms).
-    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
-    uint64_t ticket = 0;
-    CK(bft_pin_post(pin, s, &ticket));
+    const uint64_t ticket = bft_pin_next_ticket();
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p, pin.p + PIN_SLOTS, ticket);
     // the small buckets a wavefront each, the others a workgroup each (one after the other: on two streams the two kernels --
     // both latency-bound, different LDS footprints -- got in each other's way: 8.6 ms instead of 2.0 + 0.8)
     const uint32_t wave_cap = n / std::max(nb, 1u) <= 192u ? 512u : 1024u;
@@ -1045,10 +1050,11 @@ int bft_front_buckets(uint64_t* d_c, uint64_t n, const uint32_t* d_boff, uint32_
     hipLaunchKernelGGL((k_bucket_sort<FB_EMAX, true>), dim3(g_rank_mode ? grid.x : 64u), block, 0, s, d_c, d_boff, nb, gb, split_bit, counts.as<uint64_t>(), d_vals, vw, g_rank_mode,
                        redone.as<uint32_t>(), redo.as<uint32_t>(), 0u);
     CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
-    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1);
+    const uint64_t ticket2 = bft_pin_next_ticket();
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, redone.as<uint32_t>(), pin.p + 1, pin.p + PIN_SLOTS, ticket2);
     HIPCK(hipGetLastError());
     bft_stage("bucket sorts in LDS (+ scan of the counts)", (double)n * 16 + (d_vals ? (double)n * vw : 0.0), s);
-    CK(bft_pin_wait(pin, s));
+    CK(bft_pin_wait_for(pin, s, ticket2));
     const uint64_t total = pin.p[1];
     if (n_redone) *n_redone = (uint32_t)pin.p[2];
     nk = total >> 32;
@@ -1086,9 +1092,8 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     CK(n_lists.alloc_zero(32, s));
     HIPCK(hipMemsetAsync((uint8_t*)counts.p + (uint64_t)nb * 8, 0, 8, s));
     const dim3 block(FB_BLOCK);
-    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p);
-    uint64_t ticket = 0;
-    CK(bft_pin_post(pin, s, &ticket));
+    const uint64_t ticket = bft_pin_next_ticket();
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, d_max_bucket, pin.p, pin.p + PIN_SLOTS, ticket);
     // (the size of the largest bucket travels to the host while the lists are made and the buckets of a wavefront each -- all of them, usually -- are sorted)
     hipLaunchKernelGGL(k_bucket2_lists, dim3((nb + FB_BLOCK - 1) / FB_BLOCK), block, 0, s, d_boff, nb, lists.as<uint32_t>(), n_lists.as<uint32_t>(), counts.as<uint64_t>());
     const uint32_t sh = (uint32_t)(2 * k - 64);
@@ -1118,11 +1123,12 @@ int bft_front2_buckets(uint64_t* d_hk, void* d_items, uint64_t n, const uint32_t
     hipLaunchKernelGGL((k_bucket2_sort<32, true>), dim3(g_rank_mode ? 256u * 2u : 32u), block, 0, s, d_hk, d_it, d_boff, redo.as<uint32_t>(), redone.as<uint32_t>(), sh, counts.as<uint64_t>(),
                        g_rank_mode, redone.as<uint32_t>(), redo.as<uint32_t>(), fail.as<uint32_t>());
     CK(bft_scan::exclusive_sum_ptr<uint64_t>(counts.as<uint64_t>(), bases.as<uint64_t>(), (uint64_t)nb + 1, s, tmp));
+    const uint64_t ticket2 = bft_pin_next_ticket();
     hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, bases.as<uint64_t>() + nb, fail.as<uint32_t>(), pin.p + 1);
-    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, redone.as<uint32_t>(), pin.p + 3);
+    hipLaunchKernelGGL(k_front_publish, dim3(1), dim3(1), 0, s, (const uint64_t*)nullptr, redone.as<uint32_t>(), pin.p + 3, pin.p + PIN_SLOTS, ticket2);
     HIPCK(hipGetLastError());
     bft_stage("two-word buckets: sorts in LDS (+ scan of the counts)", (double)n * 2 * 20, s);
-    CK(bft_pin_wait(pin, s));
+    CK(bft_pin_wait_for(pin, s, ticket2));
     if (n_redone) *n_redone = (uint32_t)pin.p[3];
     if (pin.p[2] != 0) return 0;  // (a bucket beyond this front end: the caller sorts device-wide)
     const uint64_t total = pin.p[1];
