@@ -12,14 +12,17 @@
 //                   exchange through LDS per pass --, then duplicates are flagged against the left neighbour and the bucket goes back
 //                   in place together with its counts (distinct k-mers, distinct pairs).  The atomic ranks are stable only if the LDS
 //                   serves the lanes of an instruction in lane order -- it does, undocumented --: the final order is checked over
-//                   every bit, and a bucket that fails is sorted again with ranks from wavefront ballots (stable by construction).
+//                   every bit, and a bucket that fails goes on a list that a second launch (k_bucket_sort<.., true>) sorts again with
+//                   ranks from wavefront ballots (stable by construction; a launch of its own so that its registers do not make the
+//                   main kernels spill).  From the second pass on, one atomic serves a whole run of equal digits (rank_runs).
 //   k_bucket_sort   the same with one workgroup per bucket, for the larger ones (up to 4096 composites; variants by keys per thread)
+//   k_bucket2_*     the same front end for two-word keys (33 <= k <= 64): see BftItem2
 //   k_bucket_emit   after one scan of the 2^18 count pairs: every bucket writes its k-mers, their offsets and the genome ids at
 //                   its place in the outputs.
 // Composites that do not fit 63 bits (k = 31; k = 27 beyond 512 genomes) arrive as whole k-mers with the ids beside them: the bits a
 // bucket's k-mers share are dropped inside the bucket, which makes room for the id.
 // One read and one write of the array for all the remaining bits, where a device-wide LSD sort spends a pass per 8 bits
-// (rocPRIM: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms; these kernels: 3.0 ms).
+// (a library radix sort: 7 passes over 2x10^8 composites, 7.6 ms; its segmented sort of the same buckets: 4.5 ms; these kernels: 2.0 ms).
 #include "bft_dev.h"
 #include "bft_scan.h"
 #include "bft_sort.h"

@@ -1475,7 +1475,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
         const uint32_t* src_g = h->log_g.as<uint32_t>();
         const uint64_t src_stride = h->log_cap;
         const int gb = h->log_comp ? (int)h->log_gb : bits_for(h->max_gid_seen);  // (a log of composites: their id field as logged)
-        // (composites of up to 63 bits: rocPRIM's radix sort mis-sorts the bit range [2, 64) -- found by test_any_k_against_ground_truth[31-0])
+        // (composites of up to 63 bits: a limit from the time of the library sort -- rocPRIM's radix sort mis-sorts the bit range [2, 64), found by
+        // test_any_k_against_ground_truth[31-0] -- kept: the paths behind it are the tested ones for such k)
         if (W == 1 && h->log_g_sorted && 2 * h->k + gb <= 63 && !h->opt_no_composite) {
             // 2c + 3c. composite path (bft_kernels_build.h): sort (T << gb | genome) on the T bits, flags on the fly, one scan
             DevBuf cs, tmp, pos;
@@ -1543,8 +1544,8 @@ extern "C" int bft_gpu_build(bft_gpu* h) {
             // the ids beside the keys, then the buckets -- where the composite does fit, the bucket's number being implied
             bool done = false;
             h->msd_max_bucket = 0;
-            // (not at k = 32: the split would sort the bit range [46, 64), and rocPRIM's radix sort mis-sorts ranges that start above bit 0 and end at
-            // bit 64 -- the same defect the composite path avoids by staying within 63 bits; found by tools/stress_parity.py, k = 32 with build_msd = 2)
+            // (not at k = 32: a limit from the time of the library sort, which mis-sorted the bit range [46, 64) the split would sort -- found by
+            // tools/stress_parity.py, k = 32 with build_msd = 2; bft_rs sorts that very range for two-word keys, but k = 32 stays on its tested path)
             if (h->opt_msd && (total >= (1u << 20) || h->opt_msd == 2) && (2 * h->k - std::min(18, 2 * h->k)) + gb <= 64 && 2 * h->k < 64) {
                 if (h->max_gid_seen < 256) CK(split_dedupe_w1<uint8_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
                 else if (h->max_gid_seen < 65536) CK(split_dedupe_w1<uint16_t>(h, src_k, src_g, total, gb, tk, seg_off, npg, nk, np, done));
