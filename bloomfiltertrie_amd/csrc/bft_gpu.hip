@@ -2947,6 +2947,56 @@ extern "C" int bft_gpu_debug_get_array(bft_gpu* h, const char* name, void* out, 
     return fail(BFT_GPU_E_ARG, "unknown array");
 }
 
+// ------------------------------------------------------------------------------------------------
+// test hooks (tests/test_gpu_sort_scan.py; not part of include/bft_gpu.h): the library's own sort and scan on the caller's device arrays
+// ------------------------------------------------------------------------------------------------
+// kind 0: u64 keys; 1: u64 keys + u32 values; 2: u32 keys + u32 values.  shape: bft_rs::SHAPE_*.  Stable LSD over the bits [begin_bit, end_bit).
+extern "C" int bft_gpu_test_sort(int kind, int shape, const void* d_keys, const void* d_vals, uint64_t n, unsigned begin_bit, unsigned end_bit, void* d_out_keys, void* d_out_vals,
+                                 void* hip_stream) {
+    if ((!d_keys || !d_out_keys) && n) return fail(BFT_GPU_E_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int dev = 0;
+    HIPCK(hipGetDevice(&dev));
+    bft_pool_set_stream(dev, s);
+    int rc = BFT_GPU_E_ARG;
+#define BFT_TS(K, V, SH) rc = bft_rs::sort_pairs<K, V, SH>((const K*)d_keys, (const V*)d_vals, n, (K*)d_out_keys, (V*)d_out_vals, begin_bit, end_bit, s)
+    if (kind == 0) {
+        rc = bft_rs::sort_keys<uint64_t>((const uint64_t*)d_keys, n, (uint64_t*)d_out_keys, begin_bit, end_bit, s);
+    } else if (kind == 1) {
+        if (shape == bft_rs::SHAPE_LIGHT) BFT_TS(uint64_t, uint32_t, bft_rs::SHAPE_LIGHT);
+        else if (shape == bft_rs::SHAPE_BACK) BFT_TS(uint64_t, uint32_t, bft_rs::SHAPE_BACK);
+        else BFT_TS(uint64_t, uint32_t, bft_rs::SHAPE_BIG);
+    } else if (kind == 2) {
+        if (shape == bft_rs::SHAPE_LIGHT) BFT_TS(uint32_t, uint32_t, bft_rs::SHAPE_LIGHT);
+        else if (shape == bft_rs::SHAPE_BACK) BFT_TS(uint32_t, uint32_t, bft_rs::SHAPE_BACK);
+        else BFT_TS(uint32_t, uint32_t, bft_rs::SHAPE_BIG);
+    }
+#undef BFT_TS
+    if (rc) return rc;
+    HIPCK(hipStreamSynchronize(s));
+    return BFT_GPU_OK;
+}
+// kind 0: exclusive sum of u32 (out[n] = the total as well); 1: exclusive sum of u64 (likewise); 2: inclusive max of u64, init 5.  *d_total: the grand total.
+// reps scans in a row share one scratch block (nothing is zeroed between them: bft_scan.h).
+extern "C" int bft_gpu_test_scan(int kind, const void* d_in, uint64_t n, void* d_out, void* d_total, int reps, void* hip_stream) {
+    if ((!d_in || !d_out) && n) return fail(BFT_GPU_E_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int dev = 0;
+    HIPCK(hipGetDevice(&dev));
+    bft_pool_set_stream(dev, s);
+    DevBuf scratch;
+    for (int r = 0; r < std::max(1, reps); r++) {
+        if (kind == 0) CK(bft_scan::exclusive_sum_ptr<uint32_t>((const uint32_t*)d_in, (uint32_t*)d_out, n, s, scratch, (unsigned long long*)d_total, true));
+        else if (kind == 1) CK(bft_scan::exclusive_sum_ptr<uint64_t>((const uint64_t*)d_in, (uint64_t*)d_out, n, s, scratch, (unsigned long long*)d_total, true));
+        else if (kind == 2)
+            CK((bft_scan::scan<uint64_t, bft_scan::PtrIn<uint64_t>, bft_scan::Max, true>(bft_scan::PtrIn<uint64_t>{(const uint64_t*)d_in}, (uint64_t*)d_out, n, 5ull, bft_scan::Max(), s, scratch,
+                                                                                          (unsigned long long*)d_total)));
+        else return fail(BFT_GPU_E_ARG, "bad scan kind");
+    }
+    HIPCK(hipStreamSynchronize(s));
+    return BFT_GPU_OK;
+}
+
 extern "C" int bft_gpu_set_option(bft_gpu* h, const char* name, int64_t value) {
     if (!h || !name) return fail(BFT_GPU_E_ARG, "NULL argument");
     const std::string nm(name);

@@ -331,3 +331,41 @@ def test_hot_kernels_use_no_scratch(built):
         if m.group(1) == "k_query_kh":
             assert int(vgpr) <= 128, name   # (a lane's line passes through sixteen registers on its way from the quad: ~95; four wavefronts per SIMD at least)
     assert seen == {"k_query_kh", "k_seq_kh", "k_branching_kh", "k_kh_assemble"}
+
+
+def test_build_and_resident_query_kernels_use_no_scratch(built):
+    """A kernel that uses scratch memory starts ~0.13 ms late whenever the kernels before it on the queue used none (the runtime hands the queue's
+    scratch back and sets it up again at the dispatch: DESIGN.md section 3, round 6).  The kernels one build and the resident colour queries launch --
+    the sort's histogram and passes with atomic ranks (ranged, and chained with eight look-back groups: the forms the launcher picks), the scan, the
+    bucket sorts of one- and two-word keys, the emits, the one-launch colour kernels -- must stay without; the ballot-rank fallbacks are launches
+    of their own and may spill."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for pat in ("k_rs_", "k_scan", "k_bucket", "k_colors_kh", "k_color_rows_kh", "k_msd", "k_fill_many", "k_prefix_scatter"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), pat], capture_output=True, text=True).stdout
+        for l in out.splitlines()[1:]:
+            if not l.strip():
+                continue
+            vgpr, sgpr, vspill, sspill, scratch, lds, maxwg, name = l.split(None, 7)
+            m = re.search(r"(k_rs_hist|k_rs_pass|k_rs_tiny|k_scan|k_bucket_sort_wave|k_bucket_sort|k_bucket2_sort_wave|k_bucket2_sort|k_bucket2_tiny|k_bucket_emit|k_bucket2_emit|"
+                          r"k_colors_kh|k_color_rows_kh|k_msd_bounds|k_fill_many|k_prefix_scatter)<?([^(]*)", name)
+            if not m:
+                continue
+            kern, targs = m.group(1), m.group(2)
+            if kern == "k_rs_pass":  # <K, V, In, THREADS, IPT, RANGED, BALLOT, LBG>
+                a = [x.strip() for x in targs.rstrip(">").split(",")]
+                ranged, ballot, lbg = a[-3] == "true", a[-2] == "true", int(a[-1])
+                if ballot or (not ranged and lbg == 1):
+                    continue  # (fallback ranks; the one-group form is launched only where it spills nothing: bft_rs::uses_scratch)
+            if kern == "k_rs_tiny" and targs.rstrip(">").split(",")[-1].strip() == "true":
+                continue  # (ballot ranks)
+            if kern in ("k_bucket_sort", "k_bucket2_sort") and targs.rstrip(">").split(",")[-1].strip() == "true":
+                continue  # (the REDO launch: ballot ranks)
+            if kern == "k_bucket2_sort_wave" and targs.rstrip(">").split(",")[-1].strip() == "false" and targs.startswith("32"):
+                continue  # (ids of 2^18 and up at 32 items per lane: one wavefront per SIMD, AGPRs)
+            seen.add(kern)
+            assert int(scratch) == 0, (name[:160], scratch)
+    assert {"k_rs_hist", "k_rs_pass", "k_scan", "k_bucket_sort_wave", "k_bucket_sort", "k_bucket2_sort_wave", "k_bucket_emit", "k_colors_kh", "k_color_rows_kh"} <= seen, seen
