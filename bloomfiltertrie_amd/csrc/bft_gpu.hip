@@ -2298,7 +2298,7 @@ static int colors_core(bft_gpu* h, const uint8_t* d_kmers, uint64_t n, uint64_t*
         h->qc_stream = s;
         HIPCK(e);
     }
-    if (fill && h->im.kh_lines != nullptr && !h->opt_walk_hash && bft_kh_has_kernels(h->W, h->im.kh.S)) {
+    if (fill && h->im.kh_lines != nullptr && !h->opt_walk_hash && bft_kh_has_kernels(h->W, h->im.kh.S) && h->im.nb_genomes < 65536u) {  // (k_colors_kh keeps list lengths in 16 bits)
         // through the k-mer hash: lookup, offsets and ids in ONE launch (k_colors_kh; the host entry point counts first and fills per chunk: the three steps below)
         const size_t sb = bft_kh_colors_scratch_bytes(n);
         if (h->qc_tmp.bytes < sb) {
