@@ -90,7 +90,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = os.environ.get("BFT_GPU_LIB", LIB_PATH)  # tuning experiments only: another build of the same sources
+    path = os.environ.get("BFT_GPU_LIB") or LIB_PATH  # tuning experiments only: another build of the same sources
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void k_color_rows_kh(BftImage im, const uint8_
 #ifndef BFT_KH_CT
 #define BFT_KH_CT 4
 #endif
+#ifndef BFT_KH_LEN_T
+#define BFT_KH_LEN_T uint16_t
+#endif
 template <int W, int S>
 __global__ __launch_bounds__(BFT_KH_BLOCK) void k_colors_kh(BftImage im, const uint8_t* __restrict__ packed, uint64_t n, int B, uint64_t* __restrict__ bits64,
                                                            unsigned long long* __restrict__ offsets, uint32_t* __restrict__ ids, uint64_t ids_cap, unsigned long long* __restrict__ needed,
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_colors_kh(BftImage im, const u
     __shared__ uint4 s_lines[WPB][64 * BFT_KH_LDS_LINE];
     __shared__ uint64_t s_bits[CT * WPB];
     __shared__ uint32_t s_sum[CT * WPB];
-    __shared__ uint16_t s_len[CT * BFT_KH_BLOCK];  // (16 bits: the launcher sends indexes of 2^16 genomes and more the three-launch way; with 32 the LDS
+    __shared__ BFT_KH_LEN_T s_len[CT * BFT_KH_BLOCK];  // (16 bits: the launcher sends indexes of 2^16 genomes and more the three-launch way; with 32 the LDS
     __shared__ uint32_t s_src[CT * BFT_KH_BLOCK];  // holds five workgroups per CU instead of six: 2.04 -> 1.97 ms on config 4)  // a k-mer's list: ids, where they start in the dictionary (in LDS, not registers:
     __shared__ uint32_t s_tile;                                              // the lookups need the wavefronts the registers would cost)
     __shared__ unsigned long long s_prefix;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_colors_kh(BftImage im, const u
                 src = im.cs_off[val];
                 len = im.cs_off[val + 1] - src;
             }
-            s_len[c * BFT_KH_BLOCK + threadIdx.x] = (uint16_t)len;
+            s_len[c * BFT_KH_BLOCK + threadIdx.x] = (BFT_KH_LEN_T)len;
             s_src[c * BFT_KH_BLOCK + threadIdx.x] = src;
             const uint64_t mask = __ballot(present);
             uint32_t ws = len;

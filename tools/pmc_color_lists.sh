@@ -24,3 +24,4 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
 for k, e in res.items():
     print(k, {c: (round(v), e["_n_" + c]) for c, v in e.items() if not c.startswith("_n_")})
 PY
+rm -rf "$OUT"  # (the raw traces are tens of MB: only the summary above leaves the box)
