@@ -190,8 +190,8 @@ class BFT:
         return bits, rows
 
     def query_colors_dev(self, d_kmers_ptr, n, d_bits_ptr, d_offsets_ptr, d_ids_ptr, ids_cap, d_needed_ptr=0, stream=None):
-        """Device-resident id lists (bft_gpu_query_colors_dev): offsets (n + 1 uint64) and ids (uint32) in HBM, no synchronisation; nothing is
-        written to the ids when they number more than ids_cap (*d_needed_ptr says how many)."""
+        """Device-resident id lists (bft_gpu_query_colors_dev): offsets (n + 1 uint64) and ids (uint32) in HBM, no synchronisation; when the
+        ids number more than ids_cap only the first ids_cap of them are written (*d_needed_ptr says how many there are)."""
         _lib.check(self._lib.bft_gpu_query_colors_dev(self._h, C.c_void_p(d_kmers_ptr), n, C.c_void_p(d_bits_ptr), C.c_void_p(d_offsets_ptr),
                                                       C.c_void_p(d_ids_ptr or 0), ids_cap, C.c_void_p(d_needed_ptr or 0), C.c_void_p(stream or 0)))
 

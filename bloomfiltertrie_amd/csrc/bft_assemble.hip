@@ -33,6 +33,17 @@ __global__ void k_pin_ticket(uint64_t* __restrict__ slot, uint64_t v) {
     __threadfence_system();
     *reinterpret_cast<volatile uint64_t*>(slot) = v;
 }
+__global__ void k_zero_words(uint32_t* __restrict__ p, uint64_t words) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int bft_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (!bytes) return 0;
+    if ((bytes & 3u) || ((uintptr_t)p & 3u)) return bft_fail(BFT_GPU_E_ARG, "internal: bft_zero_async wants whole aligned words");
+    const uint64_t words = bytes / 4;
+    hipLaunchKernelGGL(k_zero_words, dim3(bft_grid_for((words + 255) / 256)), dim3(256), 0, s, (uint32_t*)p, words);
+    HIPCK(hipGetLastError());
+    return 0;
+}
 uint64_t bft_pin_next_ticket() {
     static std::atomic<uint64_t> tickets{0};
     return tickets.fetch_add(1) + 1;

@@ -86,6 +86,10 @@ int bft_pin_wait(PinBlock& pin, hipStream_t s);
 // the same in two steps: the ticket enqueued here, waited for later (what is enqueued in between is not waited for; one ticket in flight per block)
 int bft_pin_post(PinBlock& pin, hipStream_t s, uint64_t* ticket);
 int bft_pin_wait_for(PinBlock& pin, hipStream_t s, uint64_t ticket);
+// Zeroes `bytes` bytes (a multiple of 4, 4-byte aligned) at p with a kernel of the library's own.  For every path a caller may record into a HIP graph:
+// a hipMemsetAsync node replays correctly ONCE on this runtime (ROCm 7.0.2: the second replay of a captured memset writes garbage --
+// tools/probe_graph_memset.py), a kernel node every time.  (bft_assemble.hip)
+int bft_zero_async(void* p, size_t bytes, hipStream_t s);
 uint64_t bft_pin_next_ticket();  // (for a kernel of the caller's that writes the ticket itself, behind its own results: pin.p[PIN_SLOTS], after __threadfence_system())
 struct PinBlock {
     uint64_t* p = nullptr;

@@ -2348,8 +2348,8 @@ extern "C" int bft_gpu_query_colors_dev(bft_gpu* h, const void* d_kmers, uint64_
     CK(ensure_built(h, false));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     if (n == 0) {
-        HIPCK(hipMemsetAsync(d_offsets, 0, 8, s));
-        if (d_ids_needed) HIPCK(hipMemsetAsync(d_ids_needed, 0, 8, s));
+        CK(bft_zero_async(d_offsets, 8, s));  // (kernels, not memsets, wherever a caller may be capturing: bft_dev.h)
+        if (d_ids_needed) CK(bft_zero_async(d_ids_needed, 8, s));
         return note_foreign_stream(h, s);
     }
     CK(colors_core(h, (const uint8_t*)d_kmers, n, (uint64_t*)d_present_bits, (uint64_t*)d_offsets, (uint32_t*)d_ids, ids_cap, (uint64_t*)d_ids_needed, s, true));
@@ -2597,8 +2597,8 @@ static int query_sequences_core(bft_gpu* h, const char* d_seqs, const uint64_t* 
     h->sq_used = true;
     h->sq_stream = s;
     // (the slack words behind the codes are read by windows at the very end of the blob: keep them defined)
-    HIPCK(hipMemsetAsync(h->sq_codes.as<uint64_t>() + n_cw, 0, (BFT_MAX_W + 2) * 8, s));
-    HIPCK(hipMemsetAsync(h->sq_bad.as<uint32_t>() + n_cw, 0, (BFT_MAX_W + 2) * 4, s));
+    CK(bft_zero_async(h->sq_codes.as<uint64_t>() + n_cw, (BFT_MAX_W + 2) * 8, s));
+    CK(bft_zero_async(h->sq_bad.as<uint32_t>() + n_cw, (BFT_MAX_W + 2) * 4, s));
     if (n_cw)
         hipLaunchKernelGGL(k_seq_encode, dim3(grid_for((n_cw + 255) / 256)), dim3(256), 0, s, d_seqs, total_chars, n_cw, h->sq_codes.as<uint64_t>(),
                            h->sq_bad.as<uint32_t>());

@@ -772,7 +772,7 @@ size_t bft_kh_colors_scratch_bytes(uint64_t n) { return ((n + (uint64_t)BFT_KH_C
 int bft_kh_colors(const BftImage& im, const uint8_t* d_kmers, uint64_t n, int rec, uint64_t* d_bits64, uint64_t* d_offsets, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_needed,
                   void* d_scratch, hipStream_t s) {
     const uint64_t ntiles = (n + (uint64_t)BFT_KH_CT * BFT_KH_BLOCK - 1) / ((uint64_t)BFT_KH_CT * BFT_KH_BLOCK);
-    HIPCK(hipMemsetAsync(d_scratch, 0, (ntiles + 1) * 8, s));
+    CK(bft_zero_async(d_scratch, (ntiles + 1) * 8, s));  // (a kernel, not a memset: the call may be recorded into a graph, bft_dev.h)
     const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 256ull * 8))), block(BFT_KH_BLOCK);
     KH_DISPATCH(im.W, (int)im.kh.S,
                 hipLaunchKernelGGL((k_colors_kh<KW, KS>), grid, block, 0, s, im, d_kmers, n, rec, d_bits64, (unsigned long long*)d_offsets, d_ids, ids_cap, (unsigned long long*)d_needed,

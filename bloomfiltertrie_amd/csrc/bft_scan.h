@@ -18,7 +18,7 @@
 //     uses array L & 1 and zeroes, tile by tile, what launch L - 1 left in the other one (nobody reads that any more); the workgroup whose claim
 //     is the launch's last puts the tile counter back to zero.  The host zeroes a block once, when it is new (DevBuf::tag counts the launches,
 //     DevBuf::tag2 remembers how many states the last one used).  A CAPTURED launch cannot take part (it runs again with the arguments it was
-//     captured with): it is bracketed by memsets and leaves the block zeroed;
+//     captured with): it is bracketed by zeroing kernels (not memset nodes: bft_zero_async) and leaves the block zeroed;
 //   * the grand total, which nearly every caller wants on the host or behind the last offset, is written by the last tile (total_slot, tail)
 //     instead of by a launch of its own.
 #pragma once
@@ -203,10 +203,10 @@ int scan(In in, T* out, uint64_t n, T init, Op op, hipStream_t s, DevBuf& scratc
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
     if (cap != hipStreamCaptureStatusNone) {
-        HIPCK(hipMemsetAsync(scratch.p, 0, scratch.bytes, s));
+        CK(bft_zero_async(scratch.p, scratch.bytes & ~(size_t)3, s));  // (kernels, not memset nodes: those replay correctly only once on this runtime, bft_dev.h)
         hipLaunchKernelGGL((k_scan<T, In, Op, INCLUSIVE, false>), dim3(grid), dim3(THREADS), 0, s, in, out, n, init, op, base, base + 2, base + 2 + half, 0u, total_slot, tail ? 1 : 0);
         HIPCK(hipGetLastError());
-        HIPCK(hipMemsetAsync(scratch.p, 0, scratch.bytes, s));
+        CK(bft_zero_async(scratch.p, scratch.bytes & ~(size_t)3, s));
         scratch.tag = 0;  // (whenever the graph runs it leaves zeros; what eager launches left before it is gone by then: start over)
         return 0;
     }

@@ -188,7 +188,10 @@ int bft_gpu_footprint(bft_gpu* h, uint64_t* out, int n_out);
  *   used slot moves to the new stream once its last launch has completed, else that launch runs static and is counted (bft_gpu_build_time entry 20).
  *   0: always static.  Launches of ONE handle on ONE stream must not run concurrently (two host threads): they would share a range -- use one stream
  *   per thread, as for any stream-ordered API.  A *_dev call recorded into a HIP graph (its stream is being captured) runs static rounds: a range's
- *   start is a kernel argument, which a replay cannot move (tests/test_gpu_parity.py::test_captured_queries_replay).
+ *   start is a kernel argument, which a replay cannot move (tests/test_gpu_parity.py::test_captured_queries_replay).  The id-list, colour-row and
+ *   sequence calls may be recorded too, after one direct call of the same size (which sizes the handle's scratch: nothing may allocate while a stream
+ *   is captured); what they zero they zero with kernels of the library's own -- a captured hipMemsetAsync replays correctly only once on ROCm 7.0.2
+ *   (test_captured_colour_queries_replay, test_captured_sequence_queries_replay; tools/probe_graph_memset.py).
  * The container walk (k_query*): "query_wgs_per_cu" (how it sits on a CU: 1 = one 1024-thread workgroup, 4 wavefronts per SIMD; 2 = two of them, 8 per
  *   SIMD with 64 VGPRs each; 3 = two 768-thread workgroups, 6 per SIMD with 84 VGPRs each; 0, default = by rule: 3), "query_probe" (rows per probe of the
  *   suffix-group search: 4 = adjacent 32-byte blocks, 8 = 64-byte blocks with a re-interpolated guess, 0 = by rule from the mean group size),

@@ -1024,3 +1024,111 @@ def test_captured_queries_replay():
             s.synchronize()
             assert (S.from_bits(bits.cpu().numpy(), len(q)) == want).all()
 
+
+def test_captured_colour_queries_replay():
+    """The one-launch colour queries of a resident batch (id lists: k_colors_kh, whose tile counter and look-back states are zeroed by a memset
+    that is captured with it; bitmap rows: k_color_rows_kh) recorded into HIP graphs and replayed with other k-mers in the same buffers: every
+    replay equals the direct call's answers.  (The handle's scratch is sized by a direct call first: nothing allocates while a stream is captured.)"""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k, ngen = 27, 140  # (18-byte rows: the 16-bytes-per-lane row kernel)
+    anc = S.random_genome(40000, 31)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 700 + g) if g else anc, k)) for g in range(ngen)]
+    allk = S.distinct(np.concatenate(gk))
+    rng = np.random.default_rng(8)
+    n = 70000
+    batches = [np.ascontiguousarray(np.concatenate([allk[rng.integers(0, len(allk), n // 2)], S.snp_mutants(allk[rng.integers(0, len(allk), n // 2)], k, 3 + i)])) for i in range(3)]
+    with BFT(k) as t:
+        for g, km in enumerate(gk):
+            t.insert_kmers(km, g)
+        t.build()
+        dev = torch.device("cuda", 0)
+        rb = (ngen + 7) // 8
+        expect = []
+        for q in batches:  # the host calls (through row numbers / the three-launch path where they take it): what every replay must give
+            b, off, ids = t.query_colors(q)
+            b2, rows = t.query_color_rows(q)
+            expect.append((b, off, ids, rows))
+        cap = max(len(e[2]) for e in expect) + 16
+        dq = torch.from_numpy(batches[0]).to(dev)
+        bits = torch.zeros((n + 63) // 64 * 8, dtype=torch.uint8, device=dev)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+        need = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = torch.zeros((n, rb), dtype=torch.uint8, device=dev)
+        scr = torch.zeros(n, dtype=torch.int32, device=dev)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):  # direct calls first: scratch sized, bitmap dictionary derived
+            t.query_colors_dev(dq.data_ptr(), n, bits.data_ptr(), offs.data_ptr(), ids.data_ptr(), cap, need.data_ptr(), s.cuda_stream)
+            t.query_color_rows_dev(dq.data_ptr(), n, bits.data_ptr(), rows.data_ptr(), scr.data_ptr(), s.cuda_stream)
+        s.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=s):
+            t.query_colors_dev(dq.data_ptr(), n, bits.data_ptr(), offs.data_ptr(), ids.data_ptr(), cap, need.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.graph(g2, stream=s):
+            t.query_color_rows_dev(dq.data_ptr(), n, bits.data_ptr(), rows.data_ptr(), scr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for rep in range(6):
+            q, (eb, eoff, eids, erows) = batches[rep % 3], expect[rep % 3]
+            dq.copy_(torch.from_numpy(q))
+            offs.zero_(); ids.zero_(); bits.zero_()
+            g1.replay()
+            torch.cuda.synchronize()
+            assert (bits.cpu().numpy()[: len(eb)] == eb).all(), rep
+            assert (offs.cpu().numpy().astype(np.uint64) == eoff).all(), rep
+            assert int(need[0]) == len(eids) and (ids[: len(eids)].cpu().numpy().astype(np.uint32) == eids).all(), rep
+            rows.zero_(); bits.zero_()
+            g2.replay()
+            torch.cuda.synchronize()
+            assert (bits.cpu().numpy()[: len(eb)] == eb).all() and (rows.cpu().numpy() == erows).all(), rep
+            if rep == 2:  # a direct call between the replays (its own scratch epoch, the handle's event)
+                with torch.cuda.stream(s):
+                    t.query_colors_dev(dq.data_ptr(), n, bits.data_ptr(), offs.data_ptr(), ids.data_ptr(), cap, need.data_ptr(), s.cuda_stream)
+                s.synchronize()
+                assert (offs.cpu().numpy().astype(np.uint64) == eoff).all()
+
+
+
+def test_captured_sequence_queries_replay():
+    """bft_gpu_query_sequences_dev recorded into a HIP graph (encode, plan, a multi-tile scan of the reads' position counts -- bracketed by zeroing
+    kernels of the library's own under capture --, lookups, tally) and replayed on other reads in the same buffers: every replay gives the rows of a
+    direct call.  (Enough reads for the scan to take its multi-tile form: more than 4096.)"""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    k, ngen, rl, n_reads = 27, 9, 80, 6000
+    anc = S.random_genome(60000, 77)
+    gs = [S.mutate(anc, 0.01, 900 + g) if g else anc for g in range(ngen)]
+    with BFT(k) as t:
+        for g, seq in enumerate(gs):
+            t.insert_kmers(S.distinct(S.kmers_of(seq, k)), g)
+        t.build()
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(4)
+        def blob_of(seed):
+            r = np.random.default_rng(seed)
+            src = gs[seed % ngen]
+            starts = r.integers(0, len(src) - rl, n_reads)
+            codes = np.stack([src[a:a + rl] for a in starts])
+            return np.ascontiguousarray(S._ASCII[codes]).reshape(-1)
+        blobs = [blob_of(i) for i in range(3)]
+        off = torch.arange(0, (n_reads + 1) * rl, rl, dtype=torch.int64, device=dev)
+        d_blob = torch.from_numpy(blobs[0]).to(dev)
+        rows = torch.zeros((n_reads, (ngen + 7) // 8), dtype=torch.uint8, device=dev)
+        s = torch.cuda.Stream()
+        expect = []
+        for b in blobs:  # direct calls: the expected rows (and the handle's scratch sized for the capture)
+            d_blob.copy_(torch.from_numpy(b))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s):
+                t.query_sequences_dev(d_blob.data_ptr(), off.data_ptr(), n_reads, n_reads * rl, 0.8, rows.data_ptr(), False, s.cuda_stream)
+            s.synchronize()
+            expect.append(rows.cpu().numpy().copy())
+        assert expect[0].any() and not (expect[0] == expect[1]).all()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            t.query_sequences_dev(d_blob.data_ptr(), off.data_ptr(), n_reads, n_reads * rl, 0.8, rows.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
+        for rep in range(6):
+            d_blob.copy_(torch.from_numpy(blobs[rep % 3]))
+            rows.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert (rows.cpu().numpy() == expect[rep % 3]).all(), rep

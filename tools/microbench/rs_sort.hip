@@ -18,6 +18,7 @@ static std::string g_err;
 int bft_fail(int code, const std::string& msg) { g_err = msg; fprintf(stderr, "fail: %s\n", msg.c_str()); return code; }
 int bft_pool_alloc(void** p, size_t n, size_t* cap) { *cap = n; return hipMalloc(p, n) == hipSuccess ? 0 : -1; }
 void bft_pool_release(void* p, size_t) { (void)hipFree(p); }
+int bft_zero_async(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? 0 : -1; }  // (nothing is captured here)
 
 #define HCK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
