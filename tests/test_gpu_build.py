@@ -837,3 +837,37 @@ def test_two_word_front_end_builds_the_same_image(k, ngen, glen, rate):
 
 
 
+
+
+@pytest.mark.parametrize("k,ngen,glen", [(27, 6, 400000), (63, 5, 300000), (99, 3, 200000)])
+def test_ballot_ranks_in_the_device_wide_sort_build_the_same_image(k, ngen, glen):
+    """bft_sort.h ranks the keys of a tile with one LDS atomic per key where the device serves such an instruction's lanes in lane order (checked once
+    per process by a kernel) and with wavefront ballots otherwise; "sort_ballots" 1 forces the ballots -- the path a device that fails the check would
+    take, in every sort of the build (root-prefix split, k-mer hash sort, the assembly's and the interning's sorts; one-word, two-word and longer keys).
+    Same image, same extraction."""
+    from bloomfiltertrie_amd import BFT
+    anc = S.random_genome(glen, k)
+    gk = [S.distinct(S.kmers_of(S.mutate(anc, 0.01, 40 + g) if g else anc, k)) for g in range(ngen)]
+    imgs = []
+    try:
+        for ballots in (0, 1):
+            t = BFT(k)
+            t.set_option("sort_ballots", ballots)
+            t.set_option("build_msd", 2)
+            for g, km in enumerate(gk):
+                t.insert_kmers(km, g)
+            t.build()
+            ek, ecs = t.extract()
+            imgs.append(({name: t.debug_array(name) for name in ARRAYS}, ek, ecs, t.info()))
+            q = np.concatenate([gk[0][::5], S.snp_mutants(gk[1][::7], k, 3)])
+            imgs[-1] += (t.query_presence(q), t.query_colors(q))
+            t.close()
+    finally:
+        w = BFT(k)
+        w.set_option("sort_ballots", 0)
+        w.close()
+    a, b = imgs
+    for name in ARRAYS:
+        assert (a[0][name] == b[0][name]).all(), name
+    assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3]
+    assert (a[4] == b[4]).all() and all((x == y).all() for x, y in zip(a[5], b[5]))

@@ -55,6 +55,39 @@ def test_sort_is_the_stable_sort_of_the_bit_range(lib, kind, shape, bits):
             assert torch.equal(out_v, vals[order]), (kind, shape, bits, n)
 
 
+def test_sort_with_ballot_ranks(lib):
+    """"sort_ballots" 1: the ranks of a tile from wavefront ballots (what a device that does not serve an LDS atomic's lanes in lane order would run),
+    in all three regimes -- the chained passes with one and with eight look-back groups included."""
+    import torch
+    from bloomfiltertrie_amd import BFT
+    dev = torch.device("cuda", 0)
+    w = BFT(27)
+    try:
+        w.set_option("sort_ballots", 1)
+        g = torch.Generator(device=dev)
+        g.manual_seed(99)
+        for kind, shape, (b0, b1) in ((0, 0, (43, 61)), (1, 0, (0, 40)), (2, 2, (0, 27)), (1, 1, (7, 30))):
+            for n in (100, 12289, 700_001, 9_000_001, 20_000_003):
+                if kind == 2:
+                    keys = torch.randint(0, 2**31 - 1, (n,), dtype=torch.int32, device=dev, generator=g)
+                    wide = keys.to(torch.int64)
+                else:
+                    keys = torch.randint(0, 2**62, (n,), dtype=torch.int64, device=dev, generator=g)
+                    keys[::5] = keys[1]
+                    wide = keys
+                vals = torch.arange(n, dtype=torch.int32, device=dev)
+                order = torch.sort((wide >> b0) & ((1 << (b1 - b0)) - 1), stable=True).indices
+                out_k, out_v = torch.empty_like(keys), torch.empty_like(vals)
+                assert lib.bft_gpu_test_sort(kind, shape, keys.data_ptr(), vals.data_ptr() if kind else None, n, b0, b1, out_k.data_ptr(), out_v.data_ptr() if kind else None, None) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(out_k, keys[order]), (kind, shape, n)
+                if kind:
+                    assert torch.equal(out_v, vals[order]), (kind, shape, n)
+    finally:
+        w.set_option("sort_ballots", 0)
+        w.close()
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_scans_and_their_totals(lib, kind):
     """Exclusive sums of u32 and u64 (with the total behind the last element and in a slot of its own) and the inclusive running maximum; three scans
