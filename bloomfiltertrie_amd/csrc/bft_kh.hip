@@ -248,18 +248,31 @@ __global__ __launch_bounds__(BFT_KH_BLOCK) void k_colors_kh(BftImage im, const u
                 if (res < 0 && im.kh_ovf_n) res = bft_kh_overflow_find<W>(im, t, &val) ? 1 : 0;
                 present = res > 0;
             }
-            uint32_t len = 0, src = 0;
-            if (present) {
-                src = im.cs_off[val];
-                len = im.cs_off[val + 1] - src;
-            }
-            s_len[c * BFT_KH_BLOCK + threadIdx.x] = (BFT_KH_LEN_T)len;
-            s_src[c * BFT_KH_BLOCK + threadIdx.x] = src;
+            // (the colour set for now -- NONE when absent --: the dictionary is asked about all CT blocks together below, CT loads in flight per lane
+            // instead of one behind every lookup)
+            s_src[c * BFT_KH_BLOCK + threadIdx.x] = present ? val : 0xFFFFFFFFu;
             const uint64_t mask = __ballot(present);
-            uint32_t ws = len;
+            if (lane == 0) s_bits[c * WPB + wave] = mask;
+        }
+        {
+            uint32_t cs[CT], o0[CT], o1[CT];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o);
-            if (lane == 0) { s_bits[c * WPB + wave] = mask; s_sum[c * WPB + wave] = ws; }
+            for (uint32_t c = 0; c < CT; c++) cs[c] = s_src[c * BFT_KH_BLOCK + threadIdx.x];  // (this thread's own words: no barrier)
+#pragma unroll
+            for (uint32_t c = 0; c < CT; c++) {
+                o0[c] = 0; o1[c] = 0;
+                if (cs[c] != 0xFFFFFFFFu) { o0[c] = im.cs_off[cs[c]]; o1[c] = im.cs_off[cs[c] + 1]; }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < CT; c++) {
+                const uint32_t len = o1[c] - o0[c];
+                s_len[c * BFT_KH_BLOCK + threadIdx.x] = (BFT_KH_LEN_T)len;
+                s_src[c * BFT_KH_BLOCK + threadIdx.x] = o0[c];
+                uint32_t ws = len;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o);
+                if (lane == 0) s_sum[c * WPB + wave] = ws;
+            }
         }
         __syncthreads();
         {   // the presence words of the tile leave together; the tile's total; its place among all ids
