@@ -472,8 +472,20 @@ struct __attribute__((packed, aligned(4))) BftItem2 {
     uint32_t id;
 };
 
+// digit of the (sh + 46)-bit key hi46 : lo over the bits [b, b + 9): the passes run over the two words as over one number (twelve passes at k = 63,
+// where passes that stop at the words' border made thirteen)
+__device__ __forceinline__ uint32_t digit2(uint64_t hi, uint64_t lo, uint32_t b, uint32_t sh, uint32_t mask) {
+    uint64_t v;
+    if (b >= sh) v = hi >> (b - sh);
+    else {
+        v = lo >> b;
+        if (b + FB_DBITS > sh) v |= hi << (sh - b);  // (1 <= sh - b <= 8)
+    }
+    return (uint32_t)v & mask;
+}
+
 template <bool BALLOT, int EMAX>
-__device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&klo)[EMAX], uint32_t (&kid)[EMAX], bool from_hi, uint32_t bit, int nbits, uint64_t* buf8, uint32_t* buf4,
+__device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&klo)[EMAX], uint32_t (&kid)[EMAX], uint32_t bit, int nbits, uint32_t sh, uint64_t* buf8, uint32_t* buf4,
                                             uint32_t (*cnt)[FB_DIGITS], uint32_t* wtot, uint32_t n, uint32_t E) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -489,7 +501,7 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
         if (r >= E) continue;  // (uniform)
         const uint32_t idx = wbase + r * 64u + lane;
         const bool valid = idx < n;
-        const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
+        const uint32_t d = digit2(khi[r], klo[r], bit, sh, mask);
         if (BALLOT) {
             const uint64_t peers = match_digit(d, valid, nbits);
             if (valid) {
@@ -502,7 +514,7 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
                 base = __shfl(base, leader);
                 rank[r] = base + (uint32_t)__builtin_popcountll(peers & lt_mask);
             }
-        } else if (FB2_RUNS && (from_hi || bit)) {  // (not the first pass: rank_runs)
+        } else if (FB2_RUNS && bit) {  // (not the first pass: rank_runs)
             rank[r] = rank_runs(cnt[wave], d, valid, lane);
         } else if (valid) {
             rank[r] = atomicAdd(&cnt[wave][d], 1u);
@@ -545,7 +557,7 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
         const uint32_t idx = wbase + r * 64u + lane;
         dst[r] = 0xFFFFFFFFu;
         if (r < E && idx < n) {
-            dst[r] = cnt[wave][(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask] + rank[r];
+            dst[r] = cnt[wave][digit2(khi[r], klo[r], bit, sh, mask)] + rank[r];
             buf8[dst[r]] = khi[r];
             buf4[dst[r]] = kid[r];
         }
@@ -572,8 +584,7 @@ __device__ __forceinline__ void radix_pass2(uint64_t (&khi)[EMAX], uint64_t (&kl
 template <bool BALLOT, int EMAX>
 __device__ __forceinline__ void radix_passes2(uint64_t (&khi)[EMAX], uint64_t (&klo)[EMAX], uint32_t (&kid)[EMAX], uint32_t sh, uint64_t* buf8, uint32_t* buf4, uint32_t (*cnt)[FB_DIGITS],
                                               uint32_t* wtot, uint32_t n, uint32_t E) {
-    for (uint32_t bit = 0; bit < sh; bit += FB_DBITS) radix_pass2<BALLOT, EMAX>(khi, klo, kid, false, bit, (int)min((uint32_t)FB_DBITS, sh - bit), buf8, buf4, cnt, wtot, n, E);
-    for (uint32_t bit = 0; bit < 46u; bit += FB_DBITS) radix_pass2<BALLOT, EMAX>(khi, klo, kid, true, bit, (int)min((uint32_t)FB_DBITS, 46u - bit), buf8, buf4, cnt, wtot, n, E);
+    for (uint32_t bit = 0; bit < sh + 46u; bit += FB_DBITS) radix_pass2<BALLOT, EMAX>(khi, klo, kid, bit, (int)min((uint32_t)FB_DBITS, sh + 46u - bit), sh, buf8, buf4, cnt, wtot, n, E);
 }
 
 // the non-empty buckets by size class (lists[c * nb ..], n_lists[c]): up to 64 items (class 5: k_bucket2_tiny), up to 512 / 1024 / 2048 -- a wavefront each, 8 / 16 / 32 items per lane --,
@@ -688,10 +699,8 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
                     else kid[r] = x.id;
                 }
             }
-            const uint32_t np_lo = (sh + FB_DBITS - 1) / FB_DBITS, np_hi = (46u + FB_DBITS - 1) / FB_DBITS;
-            for (uint32_t p = 0; p < np_lo + np_hi; p++) {
-                const bool from_hi = p >= np_lo;
-                const uint32_t bit = (from_hi ? p - np_lo : p) * FB_DBITS, width = from_hi ? 46u : sh;
+            for (uint32_t p = 0, bit = 0; bit < sh + 46u; p++, bit += FB_DBITS) {  // (the two words as one number: digit2)
+                const uint32_t width = sh + 46u;
                 const int nbits = (int)min((uint32_t)FB_DBITS, width - bit);
                 const uint32_t mask = (1u << nbits) - 1u;
 #pragma unroll
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
                 for (uint32_t r = 0; r < (uint32_t)EW; r++) {
                     if (r >= E) continue;  // (uniform)
                     const bool valid = r * 64u + lane < n;
-                    const uint32_t d = (uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask;
+                    const uint32_t d = digit2(khi[r], klo[r], bit, sh, mask);
                     uint32_t rk = 0;
                     if (FB2_RUNS && p) rk = rank_runs(cnt, d, valid, lane);
                     else if (valid) rk = atomicAdd(&cnt[d], 1u);
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(FB_BLOCK, (EW <= 8 ? 3 : (EW >= 32 && !PACK) ? 1 : 
 #pragma unroll
                 for (uint32_t r = 0; r < (uint32_t)EW; r++)  // (rank becomes the item's new slot: rank + start < 2048, no carry into the other half)
                 {
-                    if (r < E && r * 64u + lane < n) rank2[r >> 1] += cnt[(uint32_t)((from_hi ? khi[r] : klo[r]) >> bit) & mask] << ((r & 1u) * 16u);
+                    if (r < E && r * 64u + lane < n) rank2[r >> 1] += cnt[digit2(khi[r], klo[r], bit, sh, mask)] << ((r & 1u) * 16u);
                     if (EW > 16 && (r & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
                 }
                 // the exchange, word by word through the wavefront's 8 bytes per item
